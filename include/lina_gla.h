@@ -1,0 +1,149 @@
+/* lina_gla.h -- C ABI of the MI355X-native Lina-Speech codec-token generation path.
+ *
+ * Drop-in boundary.  The reference has no FFI of its own: its
+ * hot path is reached through Python operator names imported from the external
+ * `fla` package (reference model/gla.py:19-23).  Each entry point below replaces
+ * one of those operators (or one in-tree torch-eager stretch of the decode loop)
+ * and is what a ctypes stub on the reference side binds.
+ *
+ * Conventions (all entry points):
+ *   - raw DEVICE pointers + explicit shapes/strides (in ELEMENTS) + dtype enum;
+ *     no torch types; the caller owns every buffer; nothing is allocated;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) and never
+ *     synchronised -> every call is hipGraph-capturable and re-entrant;
+ *   - return 0 on success, a negative LINA_ERR_* on argument errors (nothing was
+ *     launched) or when the launch itself failed; lina_last_error() then holds a
+ *     thread-local message.  Never throws.
+ *   - recurrent state is ALWAYS fp32 [B,H,Dk,Dv] contiguous (the reference keeps
+ *     it in the model dtype between decode steps; fp32 is >= that).
+ *   - "model dtype" tensors (q,k,v,o,x,y,weights,conv caches) are LINA_F32 or
+ *     LINA_BF16; the innermost dimension is always contiguous.
+ */
+#ifndef LINA_GLA_H
+#define LINA_GLA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lina_stream_t; /* hipStream_t */
+
+enum { LINA_F32 = 0, LINA_BF16 = 1 };
+enum {
+    LINA_OK = 0,
+    LINA_ERR_ARG = -1,         /* bad shape / null pointer / bad enum                  */
+    LINA_ERR_UNSUPPORTED = -2, /* legal request this build has no kernel for           */
+    LINA_ERR_LAUNCH = -3       /* hipLaunchKernel reported an error                    */
+};
+
+/* ABI version (major*10000 + minor*100 + patch). */
+int lina_version(void);
+/* Thread-local text of the last error returned on this thread ("" if none). */
+const char* lina_last_error(void);
+
+/* Strides of one head-first view [B,H,T,D] (D contiguous), in elements.
+ * A `rearrange(x,'b l (h d) -> b h l d')` view of [B,L,H*D] is (L*H*D, D, H*D). */
+typedef struct lina_bht_strides {
+    int64_t b, h, t;
+} lina_bht_strides;
+
+/* K1 -- GLA recurrence, T sequential steps (T = 1 is the decode step).
+ *   S_t = diag(exp(gk_t)) S_{t-1} + k_t^T v_t ;  o_t = scale * q_t S_t     (fp32 math)
+ * Replaces fla.ops.gla.fused_recurrent_gla and fla.ops.gla.naive.naive_recurrent_gla
+ * (reference model/gla.py:188,190,197,201).
+ *   q,k,gk: [B,H,T,Dk]   v,o: [B,H,T,Dv]   (views described by the stride structs)
+ *   h0: initial state or NULL (= zeros);  ht: final state or NULL (not written).
+ *   ht may alias h0 (in-place decode update: the state is read once, written once).
+ *   dtype: dtype of q,k,v,o;  g_dtype: dtype of gk.
+ *   Dk in {64,128,256}, Dv a multiple of 64. */
+int lina_gla_recurrent_fwd(const void* q, const void* k, const void* v, const void* gk, void* o,
+                           const float* h0, float* ht,
+                           int B, int H, int T, int Dk, int Dv,
+                           lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
+                           lina_bht_strides sg, lina_bht_strides so,
+                           int dtype, int g_dtype, float scale, lina_stream_t stream);
+
+/* K2 -- the same recurrence evaluated chunk-wise on the matrix cores (state tile kept in
+ * MFMA accumulators, no per-chunk state in HBM).  Same contract as K1.
+ * Replaces fla.ops.gla.chunk_gla and fla.ops.gla.fused_chunk_gla
+ * (reference model/gla.py:193,195; 'fused_chunk' is the mixer's default mode, :48). */
+int lina_gla_chunk_fwd(const void* q, const void* k, const void* v, const void* gk, void* o,
+                       const float* h0, float* ht,
+                       int B, int H, int T, int Dk, int Dv,
+                       lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
+                       lina_bht_strides sg, lina_bht_strides so,
+                       int dtype, int g_dtype, float scale, lina_stream_t stream);
+
+/* K3 -- causal depthwise short convolution (+ optional SiLU), prefill form.
+ * Replaces fla.modules.ShortConvolution.forward for T > 1 or cache == NULL
+ * (ctor reference model/gla.py:106-108, calls :161-163).
+ *   x,y: [B,T,D] with batch/time strides (D contiguous); w: [D,W]; bias: [D] or NULL;
+ *   mask: fp32 [B,T] multiplied into x, or NULL;
+ *   cache: [B,D,W] (model dtype) or NULL -- receives the last W (masked) inputs,
+ *   left zero-padded when T < W.  W <= 8.  activation: 0 none, 1 SiLU. */
+int lina_short_conv_fwd(const void* x, const void* w, const void* bias, const float* mask,
+                        void* cache, void* y, int B, int T, int D, int W,
+                        int64_t x_sb, int64_t x_st, int64_t y_sb, int64_t y_st,
+                        int activation, int dtype, lina_stream_t stream);
+
+/* K4 -- single-token step of the same convolution: cache <- roll(cache,-1);
+ * cache[..,-1] <- x; y = act(sum_j cache[..,j] w[..,j] + bias).  x,y: [B,D] with row strides.
+ * Replaces ShortConvolution.forward when T == 1 and a cache is given. */
+int lina_short_conv_step(const void* x, const void* w, const void* bias, void* cache, void* y,
+                         int B, int D, int W, int64_t x_sb, int64_t y_sb,
+                         int activation, int dtype, lina_stream_t stream);
+
+/* K5 -- y = x * rsqrt(mean(x^2) + eps) * w  [ * g * sigmoid(g) ]   over the last dim D.
+ * g == NULL -> plain RMSNorm.  w == NULL -> no affine.  Rows are addressed by strides.
+ * `n_partial` > 1: x holds n_partial partial sums per row, `x_part_stride` apart, which are
+ * added first (used by the decode step; pass 1 / 0 otherwise).  x_dtype: dtype of x (the
+ * decode path hands over fp32 partial o); dtype: dtype of g, w, y.
+ * Replaces fla.modules.FusedRMSNormSwishGate / fla.modules.RMSNorm
+ * (reference model/gla.py:111,115,219,222). */
+int lina_rmsnorm_gate_fwd(const void* x, const void* g, const void* w, void* y,
+                          int64_t rows, int D, int64_t x_row, int64_t g_row, int64_t y_row,
+                          int n_partial, int64_t x_part_stride,
+                          float eps, int x_dtype, int dtype, lina_stream_t stream);
+
+/* K6a -- codec-token embedding gather-sum: out[n,:] = sum_q table[q, idx[q,n], :].
+ * Replaces MultiEmbedding.forward + reduce('q b n d -> b n d','sum')
+ * (reference model/multiembed.py:21-23, model/modeling_lina.py:131,178-179).
+ *   idx: int64 [Q,N];  table: [Q,n_emb,d];  out: [N,d]. */
+int lina_embed_sum(const int64_t* idx, const void* table, void* out,
+                   int Q, int64_t N, int n_emb, int d, int dtype, lina_stream_t stream);
+
+/* K6b -- greedy pick: out[r] = argmax_j logits[r,j], lowest index on exact ties.
+ * Replaces topk_sampling(k=1) (reference model/tools.py:38-44, modeling_lina.py:159-164);
+ * identical except on exact ties, where the reference draws uniformly among them. */
+int lina_argmax_rows(const void* logits, int64_t* out, int64_t rows, int n, int64_t row_stride,
+                     int dtype, lina_stream_t stream);
+
+/* K4x3 + K7 -- decode-step prologue of one GLA mixer (reference model/gla.py:158-163,174-180
+ * at T = 1): three conv steps on the q/k/v slices of the fused projection row `z`, and the
+ * gate  gk = logsigmoid(W2 * z_lowrank + b2) / normalizer  (optionally clamped from below).
+ *   z: [B, ldz] model dtype; q_pre at column off_q (Kd wide), k_pre at off_k (Kd),
+ *      v_pre at off_v (Vd), gate low-rank activations at off_lr (R wide, R <= 32).
+ *   wq,wk: [Kd,W]; wv: [Vd,W];  cq,ck: [B,Kd,W]; cv: [B,Vd,W] (updated in place).
+ *   w2: [Kd,R]; b2: [Kd] (model dtype).
+ *   qkv: [B, 2*Kd+Vd] model dtype, receives silu(conv(q)) | silu(conv(k)) | silu(conv(v));
+ *   gk: fp32 [B,Kd].   clamp_min: NaN = no clamp.  W == 4 only. */
+int lina_gla_decode_prologue(const void* z, int64_t ldz, int off_q, int off_k, int off_v, int off_lr,
+                             const void* wq, const void* wk, const void* wv,
+                             void* cq, void* ck, void* cv,
+                             const void* w2, const void* b2,
+                             void* qkv, float* gk,
+                             int B, int Kd, int Vd, int W, int R,
+                             float normalizer, float clamp_min, int dtype, lina_stream_t stream);
+
+/* SwiGLU gate of the channel mixer (reference model/base_blocks.py:48-50):
+ *   y[r, j] = silu(u[r, j]) * u[r, Hd + j]   for j < Hd;   y[r, Hd] = 1 if ld_y > Hd (bias
+ *   column of a K-padded down-projection), y[r, Hd+1 ..] = 0.   u: [rows, 2*Hd] (+ row stride). */
+int lina_swiglu(const void* u, void* y, int64_t rows, int Hd, int64_t ld_u, int64_t ld_y,
+                int dtype, lina_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINA_GLA_H */

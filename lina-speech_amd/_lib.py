@@ -1,0 +1,74 @@
+"""ctypes binding of the C-ABI library (include/lina_gla.h).
+
+The HIP library is the ONLY compute backend of this package: ``load()`` raises if
+``csrc/liblina_gla.so`` is missing (run ``python -m lina_speech_amd.build`` or
+``__graft_entry__.build()``) -- there is no CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblina_gla.so")
+
+LINA_F32, LINA_BF16 = 0, 1
+
+
+class BHT(C.Structure):
+    """lina_bht_strides: element strides of a head-first [B,H,T,D] view."""
+    _fields_ = [("b", C.c_int64), ("h", C.c_int64), ("t", C.c_int64)]
+
+
+_p, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+_GLA_SIG = [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, BHT, BHT, BHT, BHT, BHT, _i, _i, _f, _p]
+
+PROTOTYPES = {
+    "lina_version": (C.c_int, []),
+    "lina_last_error": (C.c_char_p, []),
+    "lina_gla_recurrent_fwd": (C.c_int, _GLA_SIG),
+    "lina_gla_chunk_fwd": (C.c_int, _GLA_SIG),
+    "lina_short_conv_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _p]),
+    "lina_short_conv_step": (C.c_int, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _i64, _i, _i, _p]),
+    "lina_rmsnorm_gate_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i, _i64, _i64, _i64, _i, _i64, _f, _i, _i, _p]),
+    "lina_embed_sum": (C.c_int, [_p, _p, _p, _i, _i64, _i, _i, _i, _p]),
+    "lina_argmax_rows": (C.c_int, [_p, _p, _i64, _i, _i64, _i, _p]),
+    "lina_gla_decode_prologue": (C.c_int, [_p, _i64, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                           _i, _i, _i, _i, _i, _f, _f, _i, _p]),
+    "lina_swiglu": (C.c_int, [_p, _p, _i64, _i, _i64, _i64, _i, _p]),
+}
+
+
+def bind(path: str) -> C.CDLL:
+    """dlopen `path` and attach the prototypes of include/lina_gla.h (raises if a symbol is missing)."""
+    lib = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"lina_speech_amd: HIP library not built ({LIB_PATH} missing). Run `python -m lina_speech_amd.build`."
+                " There is no CPU fallback.")
+        _lib = bind(LIB_PATH)
+    return _lib
+
+
+class LinaError(RuntimeError):
+    pass
+
+
+def check(rc: int, lib=None) -> None:
+    if rc != 0:
+        lib = lib or load()
+        raise LinaError(f"lina C-ABI error {rc}: {lib.lina_last_error().decode()}")

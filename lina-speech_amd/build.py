@@ -1,0 +1,61 @@
+"""Build the C-ABI shared library (hand-written HIP, gfx950 only) in-tree.
+
+    python -m lina_speech_amd.build          # or: __graft_entry__.build()
+
+Output: lina-speech_amd/csrc/liblina_gla.so (git-ignored; travels to the GPU box).
+hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "liblina_gla.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
+        glob.glob(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "*.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not stale():
+        return LIB
+    objs = []
+    procs = []
+    for src in sources():
+        obj = src[:-4] + ".o"
+        cmd = [HIPCC, *[f for f in FLAGS if f != "-shared"], "-I", CSRC, "-c", src, "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    bad = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0 or (verbose and out.strip()):
+            sys.stderr.write(f"--- hipcc {os.path.basename(src)}\n{out}\n")
+        bad |= p.returncode != 0
+    if bad:
+        raise RuntimeError("hipcc failed (see messages above)")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    subprocess.run(cmd, check=True)
+    if verbose:
+        print(f"built {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

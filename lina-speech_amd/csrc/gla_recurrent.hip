@@ -1,0 +1,155 @@
+// gla_recurrent.hip -- K1: GLA recurrence with the (Dk x BV) fp32 state tile held in VGPRs.
+//
+// Replaces fla.ops.gla.fused_recurrent_gla / naive_recurrent_gla at the reference call sites
+// model/gla.py:188,190,197,201.  T = 1 is the decode step, which is
+// HBM-bound on the state: 8*Dk*Dv bytes (read + write) per (row, head) -- DESIGN.md.
+//
+// Work split: grid = (B*H, Dv/BV); one 256-thread workgroup owns S[b,h, 0:Dk, v0:v0+BV].
+//   thread (rg = tid / CG, cg = tid % CG), CG = BV/4:  columns v0+4cg..+3 (one float4, so a
+//   16-lane group reads 256 contiguous bytes of a state row), rows rg + RG*i, i < Dk/RG.
+//   All Dk/RG float4 state loads of a thread are independent and issued up front, i.e. the
+//   whole 64 KiB tile of a workgroup is in flight at once; <=128 VGPRs -> 4 workgroups per CU.
+//   Per step: q*scale, k, exp(gk) (Dk values) and v (BV values) are staged in LDS, each thread
+//   updates its rows and accumulates q.S for its 4 columns; the row-group partials are reduced
+//   with two wave64 xor-shuffles (lanes +16, +32) and across the 4 waves through LDS.
+#include <lina_dev.h>
+#include "lina_common.h"
+
+namespace lina {
+
+template <int DK, int BV, typename TIO, typename TG>
+__global__ __launch_bounds__(256) void gla_recurrent_kernel(
+    const TIO* __restrict__ q, const TIO* __restrict__ k, const TIO* __restrict__ v,
+    const TG* __restrict__ gk, TIO* __restrict__ o, const float* h0, float* ht,
+    int H, int T, int Dv, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
+    lina_bht_strides sg, lina_bht_strides so, float scale) {
+    constexpr int CG = BV / 4;    // float4 column groups per row
+    constexpr int RG = 256 / CG;  // row groups
+    constexpr int NR = DK / RG;   // rows per thread
+    constexpr int NW = 4;         // waves per workgroup
+    static_assert(CG == 16 && DK % RG == 0, "tile shape");
+
+    __shared__ float s_q[DK], s_k[DK], s_d[DK];
+    __shared__ __attribute__((aligned(16))) float s_v[BV];
+    __shared__ __attribute__((aligned(16))) float s_red[NW][BV];
+
+    const int tid = threadIdx.x;
+    const int cg = tid % CG, rg = tid / CG;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int v0 = blockIdx.y * BV;
+
+    const int64_t tile = ((int64_t)bh * DK) * Dv + v0 + 4 * cg;
+    float4 S[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int row = rg + RG * i;
+        S[i] = h0 ? *reinterpret_cast<const float4*>(h0 + tile + (int64_t)row * Dv) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    const TIO* qb = q + b * sq.b + h * sq.h;
+    const TIO* kb = k + b * sk.b + h * sk.h;
+    const TG* gb = gk + b * sg.b + h * sg.h;
+    const TIO* vb = v + b * sv.b + h * sv.h + v0;
+    TIO* ob = o + b * so.b + h * so.h + v0;
+
+    for (int t = 0; t < T; ++t) {
+        for (int c = tid; c < DK; c += 256) {
+            s_q[c] = ld(qb + t * sq.t + c) * scale;
+            s_k[c] = ld(kb + t * sk.t + c);
+            s_d[c] = expf(ld(gb + t * sg.t + c));
+        }
+        if (tid < BV) s_v[tid] = ld(vb + t * sv.t + tid);
+        __syncthreads();
+
+        const float4 vv = *reinterpret_cast<const float4*>(&s_v[4 * cg]);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int row = rg + RG * i;
+            const float d = s_d[row], kk = s_k[row], qq = s_q[row];
+            S[i].x = fmaf(S[i].x, d, kk * vv.x);
+            S[i].y = fmaf(S[i].y, d, kk * vv.y);
+            S[i].z = fmaf(S[i].z, d, kk * vv.z);
+            S[i].w = fmaf(S[i].w, d, kk * vv.w);
+            acc.x = fmaf(qq, S[i].x, acc.x);
+            acc.y = fmaf(qq, S[i].y, acc.y);
+            acc.z = fmaf(qq, S[i].z, acc.z);
+            acc.w = fmaf(qq, S[i].w, acc.w);
+        }
+        // reduce over the 4 row groups that share a wave (lanes l, l^16, l^32, l^48)
+        acc.x += shfl_xor(acc.x, 16); acc.y += shfl_xor(acc.y, 16);
+        acc.z += shfl_xor(acc.z, 16); acc.w += shfl_xor(acc.w, 16);
+        acc.x += shfl_xor(acc.x, 32); acc.y += shfl_xor(acc.y, 32);
+        acc.z += shfl_xor(acc.z, 32); acc.w += shfl_xor(acc.w, 32);
+        if ((tid & 63) < CG) *reinterpret_cast<float4*>(&s_red[tid >> 6][4 * cg]) = acc;
+        __syncthreads();
+        if (tid < BV) {
+            const float r = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+            st(ob + t * so.t + tid, r);
+        }
+    }
+
+    if (ht) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int row = rg + RG * i;
+            *reinterpret_cast<float4*>(ht + tile + (int64_t)row * Dv) = S[i];
+        }
+    }
+}
+
+template <int DK, typename TIO, typename TG>
+static int launch_recurrent(const void* q, const void* k, const void* v, const void* gk, void* o,
+                            const float* h0, float* ht, int B, int H, int T, int Dv,
+                            lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
+                            lina_bht_strides sg, lina_bht_strides so, float scale, lina_stream_t stream) {
+    constexpr int BV = 64;
+    dim3 grid((unsigned)(B * H), (unsigned)(Dv / BV));
+    LINA_LAUNCH((gla_recurrent_kernel<DK, BV, TIO, TG>), grid, dim3(256), 0, stream,
+                (const TIO*)q, (const TIO*)k, (const TIO*)v, (const TG*)gk, (TIO*)o, h0, ht,
+                H, T, Dv, sq, sk, sv, sg, so, scale);
+    return check_launch("lina_gla_recurrent_fwd");
+}
+
+template <typename TIO, typename TG>
+static int dispatch_dk(int Dk, const void* q, const void* k, const void* v, const void* gk, void* o,
+                       const float* h0, float* ht, int B, int H, int T, int Dv,
+                       lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
+                       lina_bht_strides sg, lina_bht_strides so, float scale, lina_stream_t stream) {
+    switch (Dk) {
+        case 64: return launch_recurrent<64, TIO, TG>(q, k, v, gk, o, h0, ht, B, H, T, Dv, sq, sk, sv, sg, so, scale, stream);
+        case 128: return launch_recurrent<128, TIO, TG>(q, k, v, gk, o, h0, ht, B, H, T, Dv, sq, sk, sv, sg, so, scale, stream);
+        case 256: return launch_recurrent<256, TIO, TG>(q, k, v, gk, o, h0, ht, B, H, T, Dv, sq, sk, sv, sg, so, scale, stream);
+    }
+    return fail(LINA_ERR_UNSUPPORTED, "lina_gla_recurrent_fwd: Dk=%d not in {64,128,256}", Dk);
+}
+
+// shared argument validation of K1 / K2
+int check_gla_args(const char* fn, const void* q, const void* k, const void* v, const void* gk, const void* o,
+                   int B, int H, int T, int Dk, int Dv, int dtype, int g_dtype) {
+    if (!q || !k || !v || !gk || !o) return fail(LINA_ERR_ARG, "%s: null tensor pointer", fn);
+    if (B <= 0 || H <= 0 || T <= 0) return fail(LINA_ERR_ARG, "%s: B,H,T must be positive (got %d,%d,%d)", fn, B, H, T);
+    if (!valid_dtype(dtype) || !valid_dtype(g_dtype)) return fail(LINA_ERR_ARG, "%s: bad dtype enum", fn);
+    if (Dk != 64 && Dk != 128 && Dk != 256) return fail(LINA_ERR_UNSUPPORTED, "%s: Dk=%d not in {64,128,256}", fn, Dk);
+    if (Dv <= 0 || Dv % 64 != 0) return fail(LINA_ERR_UNSUPPORTED, "%s: Dv=%d must be a positive multiple of 64", fn, Dv);
+    return LINA_OK;
+}
+
+}  // namespace lina
+
+extern "C" int lina_gla_recurrent_fwd(const void* q, const void* k, const void* v, const void* gk, void* o,
+                                      const float* h0, float* ht, int B, int H, int T, int Dk, int Dv,
+                                      lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
+                                      lina_bht_strides sg, lina_bht_strides so,
+                                      int dtype, int g_dtype, float scale, lina_stream_t stream) {
+    using namespace lina;
+    int rc = check_gla_args("lina_gla_recurrent_fwd", q, k, v, gk, o, B, H, T, Dk, Dv, dtype, g_dtype);
+    if (rc) return rc;
+    if (dtype == LINA_F32 && g_dtype == LINA_F32)
+        return dispatch_dk<float, float>(Dk, q, k, v, gk, o, h0, ht, B, H, T, Dv, sq, sk, sv, sg, so, scale, stream);
+    if (dtype == LINA_BF16 && g_dtype == LINA_BF16)
+        return dispatch_dk<bf16_t, bf16_t>(Dk, q, k, v, gk, o, h0, ht, B, H, T, Dv, sq, sk, sv, sg, so, scale, stream);
+    if (dtype == LINA_BF16 && g_dtype == LINA_F32)
+        return dispatch_dk<bf16_t, float>(Dk, q, k, v, gk, o, h0, ht, B, H, T, Dv, sq, sk, sv, sg, so, scale, stream);
+    return fail(LINA_ERR_UNSUPPORTED, "lina_gla_recurrent_fwd: dtype=f32 with bf16 gates is not built");
+}

@@ -1,0 +1,63 @@
+// lina_common.h -- host-side helpers shared by the C-ABI launchers (error text, checks)
+// and tiny device-side dtype adaptors.  Included after <lina_dev.h>.
+#pragma once
+#include <lina_dev.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/lina_gla.h"
+
+namespace lina {
+
+char* last_error_buf();  // thread-local, defined in abi.hip
+
+static inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LINA_ERR_LAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return LINA_OK;
+}
+
+#define LINA_REQUIRE(cond, ...) \
+    do {                        \
+        if (!(cond)) return ::lina::fail(LINA_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+// ---- element load/store adaptors: T = float or unsigned short (bf16 bits) ----
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float ld(const float* p) { return *p; }
+__device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ void st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+
+// 4 consecutive elements (pointer must be 16-B aligned for float, 8-B for bf16)
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)),
+                       bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+    uint2 u;
+    u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+    u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// log(sigmoid(x)) = min(x,0) - log1p(exp(-|x|))   (the form torch's CPU kernel uses)
+__device__ __forceinline__ float logsigmoidf(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
+
+static inline bool valid_dtype(int d) { return d == LINA_F32 || d == LINA_BF16; }
+
+}  // namespace lina

@@ -1,0 +1,40 @@
+// lina_dev.h -- gfx950 (CDNA4) device primitives used by the kernels in this directory.
+// wave = 64 lanes; MFMA fragment layouts per /opt/skills/guides/cdna_hip_programming.md s3:
+//   v_mfma_f32_16x16x4_f32   : A[i=l&15][k=l>>4]        B[k=l>>4][n=l&15]
+//   v_mfma_f32_16x16x32_bf16 : A[i=l&15][k=8*(l>>4)+j]  B[k=8*(l>>4)+j][n=l&15]   (j<8)
+//   C/D (both)               : col = l&15, row = 4*(l>>4) + reg
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LINA_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
+#define LINA_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+
+namespace lina {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round-to-nearest-even
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ int shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
+
+__device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+}  // namespace lina

@@ -1,0 +1,135 @@
+// short_conv.hip -- K3/K4: causal depthwise short convolution (+SiLU) and its decode step.
+//
+// Replaces fla.modules.ShortConvolution (ctor reference model/gla.py:106-108, calls :161-163;
+// SURVEY.md 8(a) a-4, Appendix A.2):  y_t[c] = act(sum_j w[c,j] * x_{t-(W-1)+j}[c] + bias[c]),
+// x_{<0} = 0; cache[b,c,:] <- last W (masked) inputs.  Pure streaming op: lanes run along the
+// contiguous channel dimension, each thread slides a W-wide register window over TT steps.
+#include <lina_dev.h>
+#include "lina_common.h"
+
+namespace lina {
+
+constexpr int kConvTT = 16;  // time steps per thread in the prefill kernel
+
+template <int W, typename T>
+__global__ __launch_bounds__(256) void short_conv_fwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias, const float* __restrict__ mask,
+    T* cache, T* __restrict__ y, int Tn, int D, int64_t x_sb, int64_t x_st, int64_t y_sb, int64_t y_st, int act) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = blockIdx.y * kConvTT;
+    const int b = blockIdx.z;
+    if (c >= D) return;
+    float wv[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) wv[j] = ld(w + (int64_t)c * W + j);
+    const float bv = bias ? ld(bias + c) : 0.0f;
+    const T* xb = x + b * x_sb + c;
+    const float* mb = mask ? mask + (int64_t)b * Tn : nullptr;
+    float win[W];  // win[j] = x_{t-(W-1)+j}
+    win[0] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < W - 1; ++j) {
+        const int tt = t0 - (W - 1) + j;
+        win[j + 1] = (tt >= 0) ? ld(xb + tt * x_st) * (mb ? mb[tt] : 1.0f) : 0.0f;
+    }
+    const int t1 = min(t0 + kConvTT, Tn);
+    for (int t = t0; t < t1; ++t) {
+#pragma unroll
+        for (int j = 0; j < W - 1; ++j) win[j] = win[j + 1];
+        win[W - 1] = ld(xb + t * x_st) * (mb ? mb[t] : 1.0f);
+        float acc = bv;
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc = fmaf(wv[j], win[j], acc);
+        st(y + b * y_sb + t * y_st + c, act ? silu(acc) : acc);
+    }
+    if (cache && t1 == Tn) {  // this thread saw the tail: win holds x_{Tn-W..Tn-1} (zeros left of 0)
+        T* cb = cache + ((int64_t)b * D + c) * W;
+#pragma unroll
+        for (int j = 0; j < W; ++j) st(cb + j, win[j]);
+    }
+}
+
+template <int W, typename T>
+__global__ __launch_bounds__(256) void short_conv_step_kernel(
+    const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias, T* cache, T* __restrict__ y,
+    int D, int64_t x_sb, int64_t y_sb, int act) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (c >= D) return;
+    T* cb = cache + ((int64_t)b * D + c) * W;
+    float win[W];
+#pragma unroll
+    for (int j = 0; j < W - 1; ++j) win[j] = ld(cb + j + 1);
+    win[W - 1] = ld(x + b * x_sb + c);
+    float acc = bias ? ld(bias + c) : 0.0f;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        acc = fmaf(ld(w + (int64_t)c * W + j), win[j], acc);
+        st(cb + j, win[j]);
+    }
+    st(y + b * y_sb + c, act ? silu(acc) : acc);
+}
+
+template <typename T>
+static int conv_fwd_dispatch(const void* x, const void* w, const void* bias, const float* mask, void* cache, void* y,
+                             int B, int Tn, int D, int W, int64_t x_sb, int64_t x_st, int64_t y_sb, int64_t y_st,
+                             int act, lina_stream_t stream) {
+    dim3 grid((unsigned)((D + 255) / 256), (unsigned)((Tn + kConvTT - 1) / kConvTT), (unsigned)B);
+#define LINA_CONV_CASE(WW)                                                                                          \
+    case WW:                                                                                                        \
+        LINA_LAUNCH((short_conv_fwd_kernel<WW, T>), grid, dim3(256), 0, stream, (const T*)x, (const T*)w,           \
+                    (const T*)bias, mask, (T*)cache, (T*)y, Tn, D, x_sb, x_st, y_sb, y_st, act);                    \
+        break;
+    switch (W) {
+        LINA_CONV_CASE(2) LINA_CONV_CASE(3) LINA_CONV_CASE(4) LINA_CONV_CASE(5)
+        LINA_CONV_CASE(6) LINA_CONV_CASE(7) LINA_CONV_CASE(8)
+        default: return fail(LINA_ERR_UNSUPPORTED, "lina_short_conv_fwd: W=%d not in 2..8", W);
+    }
+#undef LINA_CONV_CASE
+    return check_launch("lina_short_conv_fwd");
+}
+
+template <typename T>
+static int conv_step_dispatch(const void* x, const void* w, const void* bias, void* cache, void* y, int B, int D, int W,
+                              int64_t x_sb, int64_t y_sb, int act, lina_stream_t stream) {
+    dim3 grid((unsigned)((D + 255) / 256), (unsigned)B);
+#define LINA_CONV_CASE(WW)                                                                                     \
+    case WW:                                                                                                   \
+        LINA_LAUNCH((short_conv_step_kernel<WW, T>), grid, dim3(256), 0, stream, (const T*)x, (const T*)w,     \
+                    (const T*)bias, (T*)cache, (T*)y, D, x_sb, y_sb, act);                                     \
+        break;
+    switch (W) {
+        LINA_CONV_CASE(2) LINA_CONV_CASE(3) LINA_CONV_CASE(4) LINA_CONV_CASE(5)
+        LINA_CONV_CASE(6) LINA_CONV_CASE(7) LINA_CONV_CASE(8)
+        default: return fail(LINA_ERR_UNSUPPORTED, "lina_short_conv_step: W=%d not in 2..8", W);
+    }
+#undef LINA_CONV_CASE
+    return check_launch("lina_short_conv_step");
+}
+
+}  // namespace lina
+
+extern "C" int lina_short_conv_fwd(const void* x, const void* w, const void* bias, const float* mask, void* cache,
+                                   void* y, int B, int T, int D, int W, int64_t x_sb, int64_t x_st, int64_t y_sb,
+                                   int64_t y_st, int activation, int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(x && w && y, "lina_short_conv_fwd: null pointer");
+    LINA_REQUIRE(B > 0 && T > 0 && D > 0, "lina_short_conv_fwd: B,T,D must be positive (got %d,%d,%d)", B, T, D);
+    LINA_REQUIRE(valid_dtype(dtype), "lina_short_conv_fwd: bad dtype %d", dtype);
+    LINA_REQUIRE(activation == 0 || activation == 1, "lina_short_conv_fwd: activation must be 0 or 1");
+    if (dtype == LINA_F32)
+        return conv_fwd_dispatch<float>(x, w, bias, mask, cache, y, B, T, D, W, x_sb, x_st, y_sb, y_st, activation, stream);
+    return conv_fwd_dispatch<bf16_t>(x, w, bias, mask, cache, y, B, T, D, W, x_sb, x_st, y_sb, y_st, activation, stream);
+}
+
+extern "C" int lina_short_conv_step(const void* x, const void* w, const void* bias, void* cache, void* y, int B, int D,
+                                    int W, int64_t x_sb, int64_t y_sb, int activation, int dtype,
+                                    lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(x && w && y && cache, "lina_short_conv_step: null pointer");
+    LINA_REQUIRE(B > 0 && D > 0, "lina_short_conv_step: B,D must be positive (got %d,%d)", B, D);
+    LINA_REQUIRE(valid_dtype(dtype), "lina_short_conv_step: bad dtype %d", dtype);
+    LINA_REQUIRE(activation == 0 || activation == 1, "lina_short_conv_step: activation must be 0 or 1");
+    if (dtype == LINA_F32) return conv_step_dispatch<float>(x, w, bias, cache, y, B, D, W, x_sb, y_sb, activation, stream);
+    return conv_step_dispatch<bf16_t>(x, w, bias, cache, y, B, D, W, x_sb, y_sb, activation, stream);
+}

@@ -1,0 +1,137 @@
+"""LinaModel: text embed + codec embed -> AttentiveRNN -> codec logits, with the
+teacher-forced ``forward`` and the batched autoregressive ``generate_batch`` of the
+reference (model/modeling_lina.py:14-192; same constructor, argument names, returns and
+state-dict keys ``txt_embed / rvq_embed / logits_head / attentive_rnn / txt_encoder``).
+
+MI355X-first differences that do not change results:
+  * the text side of the cross-attention is projected once per utterance (prepare());
+  * greedy picks, stop bookkeeping and the next-token embedding stay on the device, and the
+    "all rows stopped" test is read back every ``stop_check_every`` steps instead of every step
+    (the loop may run up to that many extra steps; the returned tensors are trimmed to the exact
+    length the reference would have produced);
+  * ``engine='fused'`` routes the loop through decode.DecodeEngine (fused HIP step + hipGraph).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from .attentive import AttentiveRNN
+from .codec import CodecHead, MultiEmbedding, topk_sampling, undelay_rvq
+
+
+class LinaModel(nn.Module):
+    def __init__(self, attentive_rnn: AttentiveRNN, d_model: int, n_quant: int, n_codebook: int,
+                 n_special_token_in: int, n_special_token_out: int, n_txt_vocab: int, tie_embed: bool = False,
+                 txt_encoder: Optional[nn.Module] = None, spk_encoder: Optional[nn.Module] = None,
+                 mask_text_p: float = 0.0):
+        super().__init__()
+        if mask_text_p > 0.0:
+            raise NotImplementedError("mask_text_p > 0 raises in the reference too (SURVEY App. D)")
+        self.n_quant, self.n_codebook = n_quant, n_codebook
+        self.n_special_token_in, self.n_special_token_out = n_special_token_in, n_special_token_out
+        self.mask_text_p = mask_text_p
+        self.n_txt_vocab = n_txt_vocab
+        self.n_target_vocab = n_codebook + n_special_token_out
+        self.txt_encoder, self.spk_encoder, self.attentive_rnn = txt_encoder, spk_encoder, attentive_rnn
+        self.txt_embed = nn.Embedding(n_txt_vocab, d_model, padding_idx=0)
+        self.rvq_embed = MultiEmbedding(n_quant, n_codebook + n_special_token_in, d_model, padding_idx=0)
+        self.logits_head = CodecHead(n_quant, self.n_target_vocab, d_model)
+        if tie_embed:
+            self.logits_head.weight = self.rvq_embed.weight
+
+    # ------------------------------------------------------------------ teacher-forced
+    def forward(self, x, y, encoder_mask, crossatt_mask, logits_mask=None, attention_only=False,
+                forced_attention=None, init_state=None, crossatt_pos=None):
+        x_embd = self.txt_embed(x)
+        y_embd = self.rvq_embed(y.permute(2, 0, 1)).sum(0)            # 'b n q -> q b n' -> sum over q
+        x_enc = self.txt_encoder(x_embd, mask=encoder_mask)
+        if self.spk_encoder is not None:
+            y_embd[:, 0] = self.spk_encoder(y_embd)
+        y_hat, att = self.attentive_rnn(
+            y_embd[:, :-1, :], x_enc, mask=crossatt_mask[:, :-1],
+            forced_attention=None if forced_attention is None else forced_attention[:, :, :y_embd.shape[1] - 1],
+            attention_only=attention_only, init_state=init_state, crossatt_pos=crossatt_pos)
+        if attention_only:
+            return att
+        logits = self.logits_head(y_hat)
+        if logits_mask is not None:
+            masked_logits = logits[logits_mask[:, 1:], :, :]
+            masked_target = y[:, 1:][logits_mask[:, 1:], :]
+        else:
+            masked_logits, masked_target = logits, y[:, 1:]
+        loss = F.cross_entropy(masked_logits.reshape(-1, masked_logits.shape[-1]), masked_target.reshape(-1),
+                               ignore_index=1)
+        return logits, loss, att, masked_logits, masked_target
+
+    # ------------------------------------------------------------------ batched decode
+    @torch.inference_mode()
+    def generate_batch(self, x: Tensor, batch_size: int = 3, prompt: Optional[Tensor] = None, device: str = "cpu",
+                       max_seqlen: int = 1000, k: int = 100, first_greedy_quant: int = 1, temp: float = 1.0,
+                       init_state=None, force_max_seqlen: bool = False, stop_check_every: int = 16,
+                       engine: Optional[str] = None):
+        B, Q = batch_size, self.n_quant
+        x = (x.unsqueeze(0).expand(B, -1) if x.dim() == 1 else x).to(device)   # 1-D: one text for every row
+        x_enc = self.txt_encoder(self.txt_embed(x))
+        y_embd = self.rvq_embed.embed_sum(torch.ones(Q, B, 1, dtype=torch.long, device=device))
+
+        p_len = -1
+        if prompt is not None:
+            if prompt.shape[1] != B:
+                prompt = prompt.expand(Q, B, -1) + 3
+            prompt = self.rvq_embed.embed_sum(prompt.to(device))
+            p_len = prompt.shape[1]
+            if self.spk_encoder is not None:
+                prompt[:, 0] = self.spk_encoder(prompt)
+
+        if engine == "fused":
+            from .decode import DecodeEngine
+            step_fn = DecodeEngine(self, x_enc, batch_size=B, state=init_state)
+        else:
+            state = init_state if init_state is not None else self.attentive_rnn.init_state(
+                max_seqlen=max_seqlen, batch_size=B)
+            prepared = self.attentive_rnn.cross_att.prepare(x_enc)
+
+            def step_fn(y, t):
+                h, att, _ = self.attentive_rnn.step(y, x_enc, t, state, prepared=prepared)
+                return self.logits_head(h), att
+
+        all_stop = torch.zeros(B, 1, dtype=torch.bool, device=device)
+        qs, atts, stop_tokens = [], [], []
+        stop_at = None                      # first step index at which every row had stopped
+        for t in range(max_seqlen):
+            logits, att = step_fn(y_embd, t)                    # [B,1,Q,L], [B,2,1,Ttxt]
+            atts.append(att)
+            per_q = logits.squeeze(1).transpose(0, 1)           # [Q,B,L]
+            picks = [topk_sampling(per_q[i], k=k, temp=temp) if i < first_greedy_quant
+                     else topk_sampling(per_q[i], k=1) for i in range(Q)]
+            q_sampled = torch.stack(picks)                      # [Q,B,1]
+            qs.append(q_sampled)
+            is_stop = (q_sampled == 2).all(dim=0)               # every quantizer emitted the stop token
+            stop_tokens.append(is_stop)
+            all_stop |= is_stop
+            if not force_max_seqlen and ((t + 1) % stop_check_every == 0 or t == max_seqlen - 1):
+                flags = torch.stack([s.squeeze(-1) for s in stop_tokens]).cumsum(0).bool().all(dim=1)  # [t+1]
+                if bool(flags.any()):
+                    stop_at = int(torch.nonzero(flags)[0])
+                    break
+            y_embd = prompt[:, [t]] if (prompt is not None and t < p_len) else self.rvq_embed.embed_sum(q_sampled)
+
+        if stop_at is not None:             # trim to what a per-step check would have produced
+            qs, atts, stop_tokens = qs[:stop_at + 1], atts[:stop_at + 1], stop_tokens[:stop_at + 1]
+        atts = torch.cat(atts, dim=2) if atts[0] is not None else None
+        qs = torch.stack(qs, dim=2).squeeze(-1)                                  # [Q,B,n]
+        stop_tokens = torch.stack([s.float() for s in stop_tokens] + [torch.ones(B, 1, device=device)],
+                                  dim=1).squeeze(-1)
+        n = stop_tokens.shape[1]
+        rvq = (undelay_rvq(qs) - self.n_special_token_in).clamp_min(0)
+        stop_idx = (stop_tokens * torch.arange(n, device=device)[None, :]).long()
+        cuts = []
+        for i in range(B):
+            idx = torch.unique(stop_idx[i])[1]
+            cuts.append((rvq[:, [i], :idx - self.n_quant], None if atts is None else atts[i, :, :idx]))
+        return qs, atts, stop_tokens, cuts

@@ -1,0 +1,285 @@
+"""Operator-level drop-in surface: the names the reference imports from ``fla``
+(/root/reference/model/gla.py:19-23), served by the hand-written HIP kernels through
+the C ABI of include/lina_gla.h.
+
+Every function takes/returns torch tensors exactly like the fla operator it replaces
+(head-first ``[B,H,T,D]`` views, ``(o, final_state)`` returns) and enqueues on the
+CURRENT torch HIP stream without synchronising, so callers can graph-capture.
+There is no CPU path: tensors must live on a ROCm device (``Backend.require``).
+Forward only in this round -- a tensor that requires grad raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BHT, LINA_BF16, LINA_F32
+
+
+class HipBackend:
+    """Default provider of the C ABI: the in-tree HIP library, tensors on a ROCm device."""
+    name = "hip"
+
+    def __init__(self):
+        self._lib = None
+
+    @property
+    def lib(self):
+        if self._lib is None:
+            self._lib = _lib.load()
+        return self._lib
+
+    def require(self, *tensors):
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise RuntimeError("lina_speech_amd ops run on a ROCm GPU only (got a %s tensor); "
+                                   "there is no CPU fallback" % t.device)
+
+    def stream(self, ref: torch.Tensor):
+        return C.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream)
+
+
+_BACKEND = HipBackend()
+
+
+def set_backend(backend) -> None:
+    """Install another provider of the same C ABI (object with .lib/.require/.stream)."""
+    global _BACKEND
+    _BACKEND = backend
+
+
+def get_backend():
+    return _BACKEND
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return LINA_F32
+    if t.dtype == torch.bfloat16:
+        return LINA_BF16
+    raise TypeError(f"unsupported dtype {t.dtype} (float32 or bfloat16)")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _no_grad(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError("lina_speech_amd: backward kernels (K2b/K3b/K5b) are not built yet; "
+                                  "call under torch.no_grad()/inference_mode()")
+
+
+def _inner_contig(t: torch.Tensor) -> torch.Tensor:
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def _bht(t: torch.Tensor) -> BHT:
+    return BHT(t.stride(0), t.stride(1), t.stride(2))
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise _lib.LinaError(f"lina C-ABI error {rc}: {_BACKEND.lib.lina_last_error().decode()}")
+
+
+# --------------------------------------------------------------------------- GLA (K1 / K2)
+def _gla(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inplace_state=False):
+    if q.dim() != 4:
+        raise ValueError("q must be [B,H,T,Dk]")
+    B, H, T, Dk = q.shape
+    Dv = v.shape[-1]
+    if k.shape != q.shape or gk.shape != q.shape or v.shape[:3] != q.shape[:3]:
+        raise ValueError(f"shape mismatch q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)} gk{tuple(gk.shape)}")
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        raise TypeError("q, k, v must share a dtype")
+    _no_grad(q, k, v, gk, initial_state)
+    be = _BACKEND
+    be.require(q, k, v, gk, initial_state)
+    if gk.dtype != q.dtype and gk.dtype != torch.float32:
+        gk = gk.float()
+    if q.dtype == torch.float32 and gk.dtype != torch.float32:
+        gk = gk.float()
+    q, k, v, gk = (_inner_contig(x) for x in (q, k, v, gk))
+    if v.stride(0) % 4 or v.stride(1) % 4 or v.stride(2) % 4:
+        v = v.contiguous()
+    if scale is None:
+        scale = Dk ** -0.5
+    # o is laid out [B,T,H,Dv] in memory and returned as the head-first view, so the caller's
+    # 'b h l d -> b l h d' rearrange (reference model/gla.py:215) is free.
+    o = torch.empty(B, T, H, Dv, dtype=q.dtype, device=q.device).transpose(1, 2)
+    h0 = None
+    if initial_state is not None:
+        if tuple(initial_state.shape) != (B, H, Dk, Dv):
+            raise ValueError(f"initial_state must be [B,H,Dk,Dv]={B, H, Dk, Dv}, got {tuple(initial_state.shape)}")
+        h0 = initial_state
+        if h0.dtype != torch.float32 or not h0.is_contiguous():
+            h0 = h0.float().contiguous()
+            inplace_state = False
+    ht = None
+    if output_final_state:
+        ht = h0 if (inplace_state and h0 is not None) else torch.empty(B, H, Dk, Dv, dtype=torch.float32,
+                                                                      device=q.device)
+    fn = getattr(be.lib, entry)
+    _check(fn(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(o), _ptr(h0), _ptr(ht), B, H, T, Dk, Dv,
+              _bht(q), _bht(k), _bht(v), _bht(gk), _bht(o), _dt(q), _dt(gk), float(scale), be.stream(q)))
+    return o, ht
+
+
+def fused_recurrent_gla(q, k, v, gk, scale=None, initial_state=None, output_final_state=False,
+                        inplace_state: bool = False):
+    """fla.ops.gla.fused_recurrent_gla (reference call sites model/gla.py:188,190,201) -> K1.
+    ``inplace_state=True`` updates ``initial_state`` in place and returns it as the final state."""
+    return _gla("lina_gla_recurrent_fwd", q, k, v, gk, scale, initial_state, output_final_state, inplace_state)
+
+
+def naive_recurrent_gla(q, k, v, gk, initial_state=None, output_final_state=False):
+    """fla.ops.gla.naive.naive_recurrent_gla (reference model/gla.py:197): same recurrence -> K1."""
+    return _gla("lina_gla_recurrent_fwd", q, k, v, gk, None, initial_state, output_final_state)
+
+
+def chunk_gla(q, k, v, g, scale=None, initial_state=None, output_final_state=False):
+    """fla.ops.gla.chunk_gla (reference model/gla.py:195) -> K2 (MFMA chunk scan)."""
+    return _gla("lina_gla_chunk_fwd", q, k, v, g, scale, initial_state, output_final_state)
+
+
+def fused_chunk_gla(q, k, v, g, scale=None, initial_state=None, output_final_state=False):
+    """fla.ops.gla.fused_chunk_gla (reference model/gla.py:193; the mixer's default mode) -> K2."""
+    return _gla("lina_gla_chunk_fwd", q, k, v, g, scale, initial_state, output_final_state)
+
+
+def chunk_simple_gla(q, k, v, g, scale=None, initial_state=None, output_final_state=False):
+    """fla.ops.simple_gla.chunk_simple_gla: scalar gate per head g [B,H,T] -> K2 with the gate
+    broadcast over Dk (stride-0 view, no copy)."""
+    gk = g.unsqueeze(-1).expand(*g.shape, q.shape[-1])
+    return _gla("lina_gla_chunk_fwd", q, k, v, gk.contiguous(), scale, initial_state, output_final_state)
+
+
+# --------------------------------------------------------------------------- short conv (K3 / K4)
+def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional[str] = "silu"):
+    """ShortConvolution.forward semantics: x [B,T,D], weight [D,1,W]|[D,W],
+    mask [B,T]|None, cache [B,D,W]|None (mutated in place)."""
+    B, T, D = x.shape
+    w = weight.reshape(D, -1)
+    W = w.shape[1]
+    _no_grad(x, weight, bias)
+    be = _BACKEND
+    be.require(x, w, bias, mask, cache)
+    x = _inner_contig(x)
+    w = w.to(x.dtype).contiguous()
+    bias = None if bias is None else bias.to(x.dtype).contiguous()
+    act = 1 if activation in ("silu", "swish") else 0
+    if activation not in ("silu", "swish", None):
+        raise ValueError(f"activation {activation!r} not supported")
+    if cache is not None:
+        if tuple(cache.shape) != (B, D, W) or cache.dtype != x.dtype or not cache.is_contiguous():
+            raise ValueError(f"cache must be a contiguous {x.dtype} tensor [B,D,W]={B, D, W}")
+    y = torch.empty(B, T, D, dtype=x.dtype, device=x.device)
+    if cache is not None and T == 1:
+        if mask is not None:
+            x = x * mask.unsqueeze(-1).to(x.dtype)
+        _check(be.lib.lina_short_conv_step(_ptr(x), _ptr(w), _ptr(bias), _ptr(cache), _ptr(y), B, D, W,
+                                           x.stride(0), y.stride(0), act, _dt(x), be.stream(x)))
+    else:
+        m = None if mask is None else mask.to(torch.float32).contiguous()
+        _check(be.lib.lina_short_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(m), _ptr(cache), _ptr(y), B, T, D, W,
+                                          x.stride(0), x.stride(1), y.stride(0), y.stride(1), act, _dt(x),
+                                          be.stream(x)))
+    return y
+
+
+# --------------------------------------------------------------------------- norm (K5)
+def rmsnorm_swish_gate(x, g=None, weight=None, eps: float = 1e-5, n_partial: int = 1, out_dtype=None):
+    """FusedRMSNormSwishGate / RMSNorm forward over the last dim.
+    ``n_partial`` > 1: ``x`` is [n_partial, ..., D] partial sums (fp32) that are added first."""
+    _no_grad(x, g, weight)
+    be = _BACKEND
+    be.require(x, g, weight)
+    if n_partial > 1:
+        xs = x.contiguous()
+        part_stride = xs.stride(0)
+        shape = xs.shape[1:]
+    else:
+        xs = x.contiguous()
+        part_stride = 0
+        shape = xs.shape
+    D = shape[-1]
+    rows = int(math.prod(shape[:-1]))
+    odt = out_dtype or (g.dtype if g is not None else xs.dtype)
+    gs = None if g is None else g.to(odt).contiguous()
+    ws = None if weight is None else weight.to(odt).contiguous()
+    y = torch.empty(shape, dtype=odt, device=xs.device)
+    _check(be.lib.lina_rmsnorm_gate_fwd(_ptr(xs), _ptr(gs), _ptr(ws), _ptr(y), rows, D, D, D, D, n_partial,
+                                        part_stride, float(eps), _dt(xs), _dt(y), be.stream(xs)))
+    return y
+
+
+def rmsnorm(x, weight=None, eps: float = 1e-5):
+    return rmsnorm_swish_gate(x, None, weight, eps)
+
+
+# --------------------------------------------------------------------------- codec head (K6)
+def embed_sum(table, idx):
+    """table [Q,n_emb,d], idx int64 [Q,B,n] -> sum_q table[q, idx[q]] : [B,n,d]
+    (MultiEmbedding + reduce over quantizers; reference modeling_lina.py:131,178-179)."""
+    _no_grad(table)
+    be = _BACKEND
+    be.require(table, idx)
+    Q, n_emb, d = table.shape
+    if idx.shape[0] != Q or idx.dtype != torch.int64:
+        raise ValueError("idx must be int64 [Q, ...]")
+    flat = idx.reshape(Q, -1).contiguous()
+    N = flat.shape[1]
+    out = torch.empty(N, d, dtype=table.dtype, device=table.device)
+    _check(be.lib.lina_embed_sum(_ptr(flat), _ptr(table.contiguous()), _ptr(out), Q, N, n_emb, d, _dt(table),
+                                 be.stream(table)))
+    return out.view(*idx.shape[1:], d)
+
+
+def argmax_rows(logits, out=None):
+    """Greedy pick over the last dim, lowest index on ties (topk_sampling(k=1), reference tools.py:38-44)."""
+    be = _BACKEND
+    be.require(logits)
+    lg = _inner_contig(logits)
+    n = lg.shape[-1]
+    lg2 = lg.reshape(-1, n)
+    if out is None:
+        out = torch.empty(lg2.shape[0], dtype=torch.int64, device=lg.device)
+    _check(be.lib.lina_argmax_rows(_ptr(lg2), _ptr(out), lg2.shape[0], n, lg2.stride(0), _dt(lg2), be.stream(lg2)))
+    return out.view(logits.shape[:-1])
+
+
+# --------------------------------------------------------------------------- decode-step fusions
+def gla_decode_prologue(z, off_q, off_k, off_v, off_lr, wq, wk, wv, cq, ck, cv, w2, b2, qkv, gk,
+                        normalizer: float = 16.0, clamp_min: Optional[float] = None):
+    """K4x3 + K7 in one launch (reference model/gla.py:158-163,174-180 at T = 1). See lina_gla.h."""
+    be = _BACKEND
+    be.require(z, wq, wk, wv, cq, ck, cv, w2, b2, qkv, gk)
+    B = z.shape[0]
+    Kd, W = wq.shape[0], wq.shape[-1]
+    Vd = wv.shape[0]
+    R = w2.shape[1]
+    _check(be.lib.lina_gla_decode_prologue(_ptr(z), z.stride(0), off_q, off_k, off_v, off_lr, _ptr(wq), _ptr(wk),
+                                           _ptr(wv), _ptr(cq), _ptr(ck), _ptr(cv), _ptr(w2), _ptr(b2), _ptr(qkv),
+                                           _ptr(gk), B, Kd, Vd, W, R, float(normalizer),
+                                           float("nan") if clamp_min is None else float(clamp_min), _dt(z),
+                                           be.stream(z)))
+
+
+def swiglu(u, hidden: int, out=None, pad_to: Optional[int] = None):
+    """y = silu(u[..., :hidden]) * u[..., hidden:2*hidden]  (reference base_blocks.py:48-50).
+    ``pad_to`` > hidden: the row is padded; column ``hidden`` holds 1 (bias column), the rest 0."""
+    _no_grad(u)
+    be = _BACKEND
+    be.require(u)
+    u2 = _inner_contig(u).reshape(-1, u.shape[-1])
+    ld_y = pad_to or hidden
+    if out is None:
+        out = torch.empty(u2.shape[0], ld_y, dtype=u.dtype, device=u.device)
+    _check(be.lib.lina_swiglu(_ptr(u2), _ptr(out), u2.shape[0], hidden, u2.stride(0), out.stride(0), _dt(u2),
+                              be.stream(u2)))
+    return out.view(*u.shape[:-1], ld_y)

@@ -1,0 +1,54 @@
+"""TEST INFRASTRUCTURE: compile the kernel sources of lina-speech_amd/csrc for the CPU
+wave64 emulator (tests/emu/lina_dev.h shadows csrc/lina_dev.h) -> tests/_emu_build/liblina_gla_emu.so.
+The emulated library exposes the same C ABI (include/lina_gla.h); pointers are host pointers."""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "lina-speech_amd", "csrc")
+OUT = os.path.join(ROOT, "tests", "_emu_build")
+LIB = os.path.join(OUT, "liblina_gla_emu.so")
+CXX = os.environ.get("CXX", "g++")
+FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+         "-Wno-unknown-pragmas", "-Wno-attributes", "-Wno-sign-compare"]
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + \
+        glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(HERE, "*.cpp")) + \
+        glob.glob(os.path.join(ROOT, "include", "*.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False) -> str:
+    if not force and not stale():
+        return LIB
+    os.makedirs(OUT, exist_ok=True)
+    procs, objs = [], []
+    for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + [os.path.join(HERE, "emu_runtime.cpp")]:
+        obj = os.path.join(OUT, os.path.basename(src) + ".o")
+        cmd = [CXX, *FLAGS, "-I", HERE, "-I", CSRC, "-x", "c++", "-c", src, "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    bad = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if out.strip():
+            sys.stderr.write(f"--- {CXX} {os.path.basename(src)}\n{out}\n")
+        bad |= p.returncode != 0
+    if bad:
+        raise RuntimeError("emulator build failed")
+    subprocess.run([CXX, "-shared", "-fPIC", *objs, "-o", LIB], check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

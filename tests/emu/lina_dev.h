@@ -1,0 +1,165 @@
+// tests/emu/lina_dev.h -- TEST INFRASTRUCTURE: a CPU emulation of the small set of
+// gfx950 device primitives the kernels in lina-speech_amd/csrc use (<lina_dev.h>).
+//
+// The product build includes lina-speech_amd/csrc/lina_dev.h (real HIP builtins) and is
+// the only thing that ships.  This header shadows it when tests/emu/build_emu.py compiles
+// the very same kernel sources with g++, so that the index arithmetic, LDS staging, wave64
+// shuffles and MFMA fragment layouts of every kernel can be checked against the CPU oracle
+// in the GPU-less build container.  Each GPU thread is a ucontext fiber; __syncthreads and
+// the wave-collective primitives are cooperative yield points.  MFMA lane layouts follow
+// /opt/skills/guides/cdna_hip_programming.md section 3.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <algorithm>
+using std::min;
+using std::max;
+
+#define LINA_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
+struct alignas(8) ushort4 { unsigned short x, y, z, w; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(8) uint2 { unsigned x, y; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+
+#define __expf(x) expf(x)
+#define __logf(x) logf(x)
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __fdividef(float a, float b) { return a / b; }
+
+namespace lina_emu {
+struct Fiber;
+extern Fiber* cur;
+extern dim3 g_blockIdx, g_blockDim, g_gridDim;
+extern unsigned char* g_dyn_smem;
+const dim3& cur_tid();
+int cur_lane();
+void syncthreads();
+// wave-collective exchange: every lane of the wave deposits `n` 32-bit words, then reads
+// the 64 x n table `out` (out[lane*n + i]).
+void wave_exchange(const uint32_t* mine, int n, uint32_t* out);
+void launch_impl(const std::function<void()>& body, dim3 grid, dim3 block, size_t smem);
+template <class K, class... A>
+void launch(K kernel, dim3 grid, dim3 block, size_t smem, void*, A... args) {
+    launch_impl([=]() { kernel(args...); }, grid, block, smem);
+}
+}  // namespace lina_emu
+
+#define threadIdx (lina_emu::cur_tid())
+#define blockIdx (lina_emu::g_blockIdx)
+#define blockDim (lina_emu::g_blockDim)
+#define gridDim (lina_emu::g_gridDim)
+static inline void __syncthreads() { lina_emu::syncthreads(); }
+
+#define LINA_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    lina_emu::launch(kernel, grid, block, smem, stream, __VA_ARGS__)
+#define LINA_DYN_SMEM(name) unsigned char* name = lina_emu::g_dyn_smem
+
+namespace lina {
+
+struct f32x4 {
+    float v[4];
+    float& operator[](int i) { return v[i]; }
+    const float& operator[](int i) const { return v[i]; }
+};
+struct bf16x8 {
+    short v[8];
+    short& operator[](int i) { return v[i]; }
+    const short& operator[](int i) const { return v[i]; }
+};
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+static inline float bf2f(unsigned short h) { return u2f((uint32_t)h << 16); }
+static inline unsigned short f2bf(float f) {  // round-to-nearest-even, NaN kept quiet
+    uint32_t u = f2u(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+static inline float shfl_xor(float v, int mask) {
+    uint32_t mine = f2u(v), tab[64];
+    lina_emu::wave_exchange(&mine, 1, tab);
+    return u2f(tab[lina_emu::cur_lane() ^ mask]);
+}
+static inline float shfl(float v, int src) {
+    uint32_t mine = f2u(v), tab[64];
+    lina_emu::wave_exchange(&mine, 1, tab);
+    return u2f(tab[src & 63]);
+}
+static inline int shfl_xor_i(int v, int mask) {
+    uint32_t mine = (uint32_t)v, tab[64];
+    lina_emu::wave_exchange(&mine, 1, tab);
+    return (int)tab[lina_emu::cur_lane() ^ mask];
+}
+
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D: col=l&15, row=4*(l>>4)+r.
+static inline f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
+    uint32_t mine[2] = {f2u(a), f2u(b)}, tab[128];
+    lina_emu::wave_exchange(mine, 2, tab);
+    const int l = lina_emu::cur_lane(), col = l & 15;
+    f32x4 d;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(u2f(tab[(row + 16 * k) * 2]), u2f(tab[(col + 16 * k) * 2 + 1]), acc);
+        d[r] = acc;
+    }
+    return d;
+}
+
+// v_mfma_f32_16x16x32_bf16: lane l holds A[i=l&15][k=8*(l>>4)+j], B[k=8*(l>>4)+j][n=l&15], j<8.
+static inline f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+    uint32_t mine[8], tab[512];
+    for (int j = 0; j < 4; ++j) {
+        mine[j] = (uint32_t)(uint16_t)a[2 * j] | ((uint32_t)(uint16_t)a[2 * j + 1] << 16);
+        mine[4 + j] = (uint32_t)(uint16_t)b[2 * j] | ((uint32_t)(uint16_t)b[2 * j + 1] << 16);
+    }
+    lina_emu::wave_exchange(mine, 8, tab);
+    const int l = lina_emu::cur_lane(), col = l & 15;
+    auto A = [&](int i, int k) {
+        const uint32_t w = tab[(i + 16 * (k >> 3)) * 8 + ((k & 7) >> 1)];
+        return bf2f((unsigned short)((k & 1) ? (w >> 16) : (w & 0xffff)));
+    };
+    auto Bm = [&](int k, int n) {
+        const uint32_t w = tab[(n + 16 * (k >> 3)) * 8 + 4 + ((k & 7) >> 1)];
+        return bf2f((unsigned short)((k & 1) ? (w >> 16) : (w & 0xffff)));
+    };
+    f32x4 d;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) acc = fmaf(A(row, k), Bm(k, col), acc);
+        d[r] = acc;
+    }
+    return d;
+}
+
+}  // namespace lina

@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ -- runs ONLY in the build container.
+
+It imports the reference's in-tree host modules from /root/reference (model/gla.py,
+model/modeling_lina.py, model/crossatt.py, model/encoder.py, model/base_blocks.py,
+model/multiembed.py, model/tools.py) with the CPU oracle bound to the absent
+``fla.*`` names (oracle/fla_standin.py), runs them on seeded synthetic inputs and
+stores inputs + weights + outputs as .npz.  Only DATA is stored; no reference source
+travels.  Re-run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle import fla_standin  # noqa: E402
+
+fla_standin.install()
+
+from model.gla import AttentiveGLA, GatedLinearAttention  # noqa: E402  (reference)
+from model.encoder import TextEncoder  # noqa: E402
+from model.modeling_lina import LinaModel  # noqa: E402
+from model import tools as ref_tools  # noqa: E402
+
+
+def npz(path, **kw):
+    out = {}
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez(os.path.join(HERE, path), **out)
+    print("wrote", path, {k: tuple(v.shape) for k, v in out.items() if v.ndim} and
+          sum(v.nbytes for v in out.values()) // 1024, "KiB")
+
+
+POS_ROWS = 32  # ConvPos holds a 2000-row table (crossatt.py:22-24); only the rows a test can touch are stored
+
+
+def sd_arrays(model, prefix="sd::"):
+    out = {}
+    for k, v in model.state_dict().items():
+        if k.endswith("pos_embed.embed.weight"):
+            out[prefix + k + "::first_rows"] = v[:POS_ROWS]
+            out[prefix + k + "::full_rows"] = torch.tensor(v.shape[0])
+        else:
+            out[prefix + k] = v
+    return out
+
+
+def golden_mixer():
+    """One GatedLinearAttention (model/gla.py:44-247): prefill through every mode, then
+    cached prefill + 3 single-token steps (cache layout, model/gla.py:229-240)."""
+    torch.manual_seed(0)
+    cfg = dict(hidden_size=128, num_heads=2, expand_k=1.0, expand_v=2.0, use_short_conv=True, layer_idx=0)
+    m = GatedLinearAttention(mode="fused_chunk", **cfg).eval()
+    B, T = 3, 21
+    x = torch.randn(B, T + 3, 128)
+    out = {"x": x}
+    with torch.no_grad():
+        for mode in ("fused_chunk", "chunk", "fused_recurrent"):
+            m.mode = mode
+            out["o_" + mode] = m(x[:, :T])
+        # reset mask (packing): gate -20 at two positions (model/gla.py:182-183)
+        reset = torch.zeros(B, T, dtype=torch.bool)
+        reset[0, 7] = True
+        reset[2, 13] = True
+        m.mode = "fused_chunk"
+        out["reset_mask"] = reset
+        out["o_reset"] = m(x[:, :T], reset_mask=reset)
+        # cached prefill + steps
+        cache = fla_standin.Cache()
+        cache.update(m.init_state(B), 0, offset=0)
+        m.mode = "fused_recurrent"
+        out["o_prefill_cached"] = m(x[:, :T], past_key_values=cache, use_cache=True)
+        for i in range(3):
+            out[f"o_step{i}"] = m(x[:, T + i:T + i + 1], past_key_values=cache, use_cache=True)
+        for j, s in enumerate(cache.states[0]):
+            out[f"cache_after_{j}"] = s.clone()
+    out.update(sd_arrays(m))
+    npz("mixer_d128.npz", **out)
+
+
+def build_lina(d=64, n_layer=1, heads=1, ev=1.0, n_codebook=253, txt_layers=1):
+    rnn = AttentiveGLA(d_model=d, n_layer=n_layer, heads=heads, blind=True, use_short_conv=True,
+                       expand_k=1.0, expand_v=ev, pos_type="convolutional")
+    txt = TextEncoder(d, heads, n_layers=txt_layers, dropout=0.0, rotary=False)
+    return LinaModel(rnn, d_model=d, n_quant=1, n_codebook=n_codebook, n_special_token_in=3,
+                     n_special_token_out=3, n_txt_vocab=256, txt_encoder=txt)
+
+
+def golden_lina():
+    """LinaModel.forward (modeling_lina.py:61-108) and generate_batch (:111-192), greedy."""
+    torch.manual_seed(0)
+    model = build_lina().eval()
+    B, Ttxt, n = 3, 9, 14
+    x = torch.randint(3, 256, (B, Ttxt))
+    y = torch.randint(3, 256, (B, n, 1))
+    y[:, 0] = 1
+    txt_len = torch.tensor([9, 6, 8])
+    enc_mask = (torch.arange(Ttxt)[None, :] < txt_len[:, None])
+    encoder_mask = enc_mask[:, None, :] & enc_mask[:, :, None]
+    crossatt_mask = enc_mask[:, None, :].expand(B, n, Ttxt).contiguous()
+    logits_mask = torch.ones(B, n, dtype=torch.bool)
+    logits_mask[1, 10:] = False
+    out = dict(x=x, y=y, encoder_mask=encoder_mask, crossatt_mask=crossatt_mask, logits_mask=logits_mask)
+    with torch.no_grad():
+        logits, loss, att, _, _ = model(x, y, encoder_mask, crossatt_mask, logits_mask=logits_mask)
+        out.update(fwd_logits=logits, fwd_loss=loss, fwd_att=att)
+        # decode: one text repeated over the batch (modeling_lina.py:125)
+        xg = x[0]
+        qs, atts, stop_tokens, cuts = model.generate_batch(xg, batch_size=B, max_seqlen=12, k=1,
+                                                           first_greedy_quant=0, force_max_seqlen=True)
+        out.update(gen_x=xg, gen_qs=qs, gen_atts=atts, gen_stop_tokens=stop_tokens)
+        out["gen_cut_lens"] = torch.tensor([c[0].shape[-1] for c in cuts])
+        # with a codec prompt (prompt-forcing branch, modeling_lina.py:134-142,175-176)
+        prompt = torch.randint(0, 253, (1, 1, 4))
+        qs2, atts2, st2, _ = model.generate_batch(xg, batch_size=B, prompt=prompt, max_seqlen=9, k=1,
+                                                  first_greedy_quant=0, force_max_seqlen=True)
+        out.update(gen_prompt=prompt, gen_prompt_qs=qs2, gen_prompt_atts=atts2, gen_prompt_stop=st2)
+        # per-step logits of a teacher-forced step loop + final cache (AttentiveGLA.step, gla.py:358-365)
+        x_enc = model.txt_encoder(model.txt_embed(x))
+        state = model.attentive_rnn.init_state(batch_size=B)
+        from einops import reduce, rearrange
+        y_embd = reduce(model.rvq_embed(rearrange(y, "b n q -> q b n")), "q b n d -> b n d", "sum")
+        step_logits = []
+        for t in range(n - 1):
+            h, a, state = model.attentive_rnn.step(y_embd[:, t:t + 1], x_enc, t, state)
+            step_logits.append(model.logits_head(h))
+        out["step_logits"] = torch.cat(step_logits, 1)
+        for li, st in enumerate(state.states):
+            for j, s in enumerate(st):
+                out[f"cache_{li}_{j}"] = s
+    out.update(sd_arrays(model))
+    npz("lina_d64.npz", **out)
+
+
+def golden_tools():
+    """Known answers of model/tools.py helpers."""
+    torch.manual_seed(0)
+    code = torch.tensor([[10, 11, 12, 13]]) + 3
+    d = ref_tools.delay_rvq(code, head_token=1, tail_token=2)
+    code2 = torch.randint(3, 100, (3, 7))
+    d2 = ref_tools.delay_rvq(code2, head_token=1, tail_token=2)
+    und = ref_tools.undelay_rvq(d2.unsqueeze(1))
+    logits = torch.randn(5, 4099)
+    k1 = ref_tools.topk_sampling(logits.clone(), k=1)
+    pm = ref_tools.packmask_2d([2, 1], [3, 2])
+    sm = ref_tools.sequence_mask(torch.tensor([3, 1, 4]), device="cpu")
+    npz("tools.npz", delay_in=code, delay_out=d, delay2_in=code2, delay2_out=d2, undelay2=und,
+        topk_logits=logits, topk_k1=k1, packmask=pm, seqmask=sm)
+
+
+if __name__ == "__main__":
+    golden_tools()
+    golden_mixer()
+    golden_lina()

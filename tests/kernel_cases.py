@@ -1,0 +1,213 @@
+"""Shared kernel-vs-oracle checks.  `dev` = "cpu" (ops bound to the wave64 emulator) or
+"cuda" (ops bound to the HIP library on a real MI355X).  The oracle always runs on the CPU
+in fp64 on exactly the inputs the kernel saw (bf16 inputs are rounded first).
+
+Tolerances, relative to max|reference| of the compared tensor:
+    fp32 I/O : K1 / K3 / K4 / K5 / prologue   <= 1e-5
+               K2 (different summation order, fast exp)  <= 1e-4
+    bf16 I/O : outputs <= 2e-2, fp32 state <= 1e-2  (operands are rounded to bf16 for the MFMA)
+    token / index outputs: exact.
+"""
+import torch
+import torch.nn.functional as F
+
+from lina_speech_amd import ops
+from oracle import gla_oracle as O
+
+F64 = torch.float64
+
+
+def tol_out(dtype, chunk=False):
+    if dtype == torch.bfloat16:
+        return 2e-2
+    return 1e-4 if chunk else 1e-5
+
+
+def assert_close(got, ref, rel, what):
+    got, ref = got.detach().cpu().to(F64), ref.detach().cpu().to(F64)
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    scale = ref.abs().max().clamp_min(1e-30)
+    err = (got - ref).abs().max() / scale
+    assert torch.isfinite(got).all(), f"{what}: non-finite values"
+    assert err <= rel, f"{what}: max rel err {err:.3e} > {rel:.1e}"
+
+
+def make_gla_inputs(B, H, T, Dk, Dv, dtype, dev, seed=0, resets=False):
+    g = torch.Generator().manual_seed(seed)
+    # projections arrive as [B,T,H*D]; the ops see the head-first VIEW (reference gla.py:173)
+    def heads(x):
+        return x.view(B, T, H, -1).transpose(1, 2)
+    q = torch.randn(B, T, H * Dk, generator=g).to(dtype)
+    k = torch.randn(B, T, H * Dk, generator=g).to(dtype)
+    v = torch.randn(B, T, H * Dv, generator=g).to(dtype)
+    gk = (F.logsigmoid(torch.randn(B, T, H * Dk, generator=g) * 2.0) / 4.0)
+    if resets:
+        gk[:, 5:9] = -20.0          # 4 consecutive resets: 80 > 60 forces a chunk cut
+        gk[:, 17, ::3] = -20.0
+        gk[:, 23, 1::2] = -70.0     # single gate beyond the clamp
+        gk[:, 30:33, :7] = -25.0
+    gk = gk.to(dtype)
+    h0 = torch.randn(B, H, Dk, Dv, generator=g) * 0.5
+    return [heads(x.to(dev)) for x in (q, k, v, gk)] + [h0.to(dev)]
+
+
+def oracle_gla(q, k, v, gk, h0):
+    o, S = O.naive_recurrent_gla(q.cpu().to(F64), k.cpu().to(F64), v.cpu().to(F64), gk.cpu().to(F64),
+                                 initial_state=None if h0 is None else h0.cpu().to(F64),
+                                 output_final_state=True, compute_dtype=F64)
+    return o, S
+
+
+def check_recurrent(dev, B, H, T, Dk, Dv, dtype):
+    q, k, v, gk, h0 = make_gla_inputs(B, H, T, Dk, Dv, dtype, dev)
+    ro, rS = oracle_gla(q, k, v, gk, h0)
+    o, S = ops.fused_recurrent_gla(q, k, v, gk, initial_state=h0, output_final_state=True)
+    assert o.dtype == dtype and S.dtype == torch.float32 and S.data_ptr() != h0.data_ptr()
+    assert_close(o, ro, tol_out(dtype), "K1 o")
+    assert_close(S, rS, 1e-5 if dtype == torch.float32 else 1e-2, "K1 state")
+    # no initial state, no final state
+    o2, S2 = ops.fused_recurrent_gla(q, k, v, gk)
+    assert S2 is None
+    assert_close(o2, oracle_gla(q, k, v, gk, None)[0], tol_out(dtype), "K1 o (h0=None)")
+    # in-place decode form
+    h_in = h0.clone()
+    o3, S3 = ops.fused_recurrent_gla(q, k, v, gk, initial_state=h_in, output_final_state=True, inplace_state=True)
+    assert S3.data_ptr() == h_in.data_ptr()
+    assert torch.equal(S3, S) and torch.equal(o3, o)
+    # fp32 gates next to bf16 activations (decode path)
+    if dtype == torch.bfloat16:
+        o4, _ = ops.fused_recurrent_gla(q, k, v, gk.float(), initial_state=h0, output_final_state=True)
+        assert_close(o4, ro, tol_out(dtype), "K1 o (f32 gates)")
+
+
+def check_chunk(dev, B, H, T, Dk, Dv, dtype, resets=False):
+    q, k, v, gk, h0 = make_gla_inputs(B, H, T, Dk, Dv, dtype, dev, seed=1, resets=resets)
+    ro, rS = oracle_gla(q, k, v, gk, h0)
+    for fn in (ops.chunk_gla, ops.fused_chunk_gla):
+        o, S = fn(q, k, v, gk, initial_state=h0, output_final_state=True)
+        assert o.dtype == dtype and S.dtype == torch.float32
+        assert_close(o, ro, tol_out(dtype, chunk=True), f"K2 o ({fn.__name__})")
+        assert_close(S, rS, 1e-4 if dtype == torch.float32 else 1e-2, "K2 state")
+    o2, S2 = ops.chunk_gla(q, k, v, gk)
+    assert S2 is None
+    assert_close(o2, oracle_gla(q, k, v, gk, None)[0], tol_out(dtype, chunk=True), "K2 o (h0=None)")
+    # chunk == recurrent kernel (self-consistency law)
+    o3, S3 = ops.fused_recurrent_gla(q, k, v, gk, initial_state=h0, output_final_state=True)
+    assert_close(o, o3.float(), 2 * tol_out(dtype, chunk=True), "K2 vs K1")
+
+
+def check_conv(dev, B, T, D, W, dtype):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, T, D, generator=g).to(dtype).to(dev)
+    w = (torch.randn(D, 1, W, generator=g) * 0.5).to(dtype).to(dev)
+    mask = (torch.rand(B, T, generator=g) > 0.2).float().to(dev) if T > 1 else None
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    # no cache
+    y = ops.short_conv(x, w, None, mask, None, "silu")
+    ry = O.short_conv(x.cpu().to(F64), w.cpu().to(F64), None if mask is None else mask.cpu().to(F64), None)
+    assert_close(y, ry, tol, "K3 y")
+    # prefill into a cache, then two steps
+    cache = torch.full((B, D, W), 7.0, dtype=dtype, device=dev)
+    rcache = torch.full((B, D, W), 7.0, dtype=F64)
+    if T > 1:
+        y = ops.short_conv(x, w, None, mask, cache, "silu")
+        ry = O.short_conv(x.cpu().to(F64), w.cpu().to(F64), mask.cpu().to(F64), rcache)
+        assert_close(y, ry, tol, "K3 y (cache)")
+        assert_close(cache, rcache, 1e-6 if dtype == torch.float32 else 1e-2, "K3 cache")
+    for i in range(2):
+        xs = torch.randn(B, 1, D, generator=g).to(dtype).to(dev)
+        ys = ops.short_conv(xs, w, None, None, cache, "silu")
+        rys = O.short_conv(xs.cpu().to(F64), w.cpu().to(F64), None, rcache)
+        assert_close(ys, rys, tol, f"K4 y step {i}")
+        assert_close(cache, rcache, 1e-6 if dtype == torch.float32 else 1e-2, f"K4 cache step {i}")
+    # no activation + bias
+    bias = torch.randn(D, generator=g).to(dtype).to(dev)
+    y = ops.short_conv(x, w, bias, None, None, None)
+    ry = O.short_conv(x.cpu().to(F64), w.cpu().to(F64), None, None, activation=None, bias=bias.cpu().to(F64))
+    assert_close(y, ry, tol, "K3 y (bias, no act)")
+
+
+def check_rmsnorm(dev, rows, D, dtype):
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(rows, 3, D, generator=g) * 3).to(dtype).to(dev)
+    gate = torch.randn(rows, 3, D, generator=g).to(dtype).to(dev)
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(dtype).to(dev)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    y = ops.rmsnorm_swish_gate(x, gate, w, 1e-5)
+    assert y.dtype == dtype and y.shape == x.shape
+    assert_close(y, O.rmsnorm_swish_gate(x.cpu().to(F64), gate.cpu().to(F64), w.cpu().to(F64), 1e-5), tol, "K5 gate")
+    y = ops.rmsnorm(x, w, 1e-5)
+    assert_close(y, O.rmsnorm(x.cpu().to(F64), w.cpu().to(F64), 1e-5), tol, "K5 plain")
+    y = ops.rmsnorm(x, None, 1e-5)
+    assert_close(y, O.rmsnorm(x.cpu().to(F64), None, 1e-5), tol, "K5 no affine")
+    # fp32 partial sums in, model dtype out (decode path)
+    parts = torch.randn(2, rows, D, generator=g).to(dev)
+    gate2 = gate[:, 0].contiguous()
+    y = ops.rmsnorm_swish_gate(parts, gate2, w, 1e-5, n_partial=2, out_dtype=dtype)
+    ry = O.rmsnorm_swish_gate(parts.cpu().to(F64).sum(0), gate2.cpu().to(F64), w.cpu().to(F64), 1e-5)
+    assert y.dtype == dtype
+    assert_close(y, ry, tol, "K5 partials")
+
+
+def check_embed(dev, Q, B, n, n_emb, d, dtype):
+    g = torch.Generator().manual_seed(4)
+    table = torch.randn(Q, n_emb, d, generator=g).to(dtype).to(dev)
+    idx = torch.randint(0, n_emb, (Q, B, n), generator=g).to(dev)
+    out = ops.embed_sum(table, idx)
+    ref = O.embed_sum(table.cpu().to(F64), idx.cpu())
+    assert out.shape == (B, n, d)
+    assert_close(out, ref, 1e-6 if dtype == torch.float32 else 1e-2, "K6a")
+
+
+def check_argmax(dev, rows, n, dtype):
+    g = torch.Generator().manual_seed(5)
+    lg = torch.randn(rows, n, generator=g).to(dtype)
+    lg[1, 100] = lg[1, 3000] = 50.0        # exact tie -> lowest index
+    lg[2, n - 1] = 60.0                    # max in the last column
+    lg[3, 0] = 60.0
+    got = ops.argmax_rows(lg.to(dev))
+    ref = O.argmax_lowest(lg.float())
+    assert got.dtype == torch.int64
+    assert torch.equal(got.cpu(), ref), (got, ref)
+    assert got[1].item() == 100 and got[2].item() == n - 1 and got[3].item() == 0
+    # 3-D input keeps its leading shape
+    got3 = ops.argmax_rows(lg.view(rows, 1, n).to(dev))
+    assert got3.shape == (rows, 1) and torch.equal(got3.cpu().view(-1), ref)
+
+
+def check_swiglu(dev, rows, hidden, dtype):
+    g = torch.Generator().manual_seed(6)
+    u = torch.randn(rows, 2 * hidden, generator=g).to(dtype).to(dev)
+    ref = F.silu(u.cpu().to(F64)[:, :hidden]) * u.cpu().to(F64)[:, hidden:]
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    y = ops.swiglu(u, hidden)
+    assert_close(y, ref, tol, "swiglu")
+    pad = hidden + 3
+    y = ops.swiglu(u, hidden, pad_to=pad)
+    assert y.shape == (rows, pad)
+    assert_close(y[:, :hidden], ref, tol, "swiglu padded")
+    assert torch.equal(y[:, hidden].float().cpu(), torch.ones(rows)) and (y[:, hidden + 1:] == 0).all()
+
+
+def check_prologue(dev, B, Kd, Vd, dtype, R=16, W=4, clamp_min=None):
+    g = torch.Generator().manual_seed(7)
+    ldz = 2 * Kd + 2 * Vd + R + 5                      # q | k | v | g | low-rank (+ slack)
+    off_q, off_k, off_v, off_lr = 0, Kd, 2 * Kd, 2 * Kd + 2 * Vd
+    z = torch.randn(B, ldz, generator=g).to(dtype).to(dev)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dtype).to(dev)
+    wq, wk, wv = mk(Kd, W), mk(Kd, W), mk(Vd, W)
+    cq, ck, cv = mk(B, Kd, W), mk(B, Kd, W), mk(B, Vd, W)
+    w2, b2 = mk(Kd, R) * 4, mk(Kd)
+    qkv = torch.empty(B, 2 * Kd + Vd, dtype=dtype, device=dev)
+    gk = torch.empty(B, Kd, dtype=torch.float32, device=dev)
+    rc = [c.cpu().to(F64).clone() for c in (cq, ck, cv)]
+    zc = z.cpu().to(F64)
+    ry = [O.short_conv(zc[:, None, o:o + D], w.cpu().to(F64), None, c)
+          for o, D, w, c in ((off_q, Kd, wq, rc[0]), (off_k, Kd, wk, rc[1]), (off_v, Vd, wv, rc[2]))]
+    rgk = O.gate_logsigmoid(zc[:, off_lr:off_lr + R] @ w2.cpu().to(F64).t() + b2.cpu().to(F64), 16.0, clamp_min)
+    ops.gla_decode_prologue(z, off_q, off_k, off_v, off_lr, wq, wk, wv, cq, ck, cv, w2, b2, qkv, gk, 16.0, clamp_min)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert_close(qkv, torch.cat([r[:, 0] for r in ry], dim=1), tol, "prologue qkv")
+    assert_close(gk, rgk, 1e-5 if dtype == torch.float32 else 2e-2, "prologue gk")
+    for c, r, nm in zip((cq, ck, cv), rc, "qkv"):
+        assert_close(c, r, 1e-6 if dtype == torch.float32 else 1e-2, f"prologue cache {nm}")

@@ -1,0 +1,47 @@
+"""Kernel SOURCES vs the CPU oracle, run on the wave64 emulator (no GPU needed).
+The same checks run on the real device in tests/test_kernels_gpu.py."""
+import pytest
+import torch
+
+from oracle import gla_oracle as O
+from kernel_cases import (check_argmax, check_chunk, check_conv, check_embed, check_prologue, check_recurrent,
+                          check_rmsnorm, check_swiglu)
+
+DEV = "cpu"
+
+
+@pytest.mark.parametrize("Dk,Dv,T,dtype", [(64, 64, 1, torch.float32), (128, 64, 3, torch.float32),
+                                           (256, 128, 1, torch.float32), (64, 64, 2, torch.bfloat16)])
+def test_recurrent(emu, Dk, Dv, T, dtype):
+    check_recurrent(DEV, B=2, H=2, T=T, Dk=Dk, Dv=Dv, dtype=dtype)
+
+
+@pytest.mark.parametrize("Dk,Dv,T,dtype", [(64, 64, 37, torch.float32), (128, 64, 20, torch.float32),
+                                           (256, 64, 18, torch.float32), (64, 64, 33, torch.bfloat16),
+                                           (128, 128, 17, torch.bfloat16)])
+def test_chunk(emu, Dk, Dv, T, dtype):
+    check_chunk(DEV, B=1, H=2, T=T, Dk=Dk, Dv=Dv, dtype=dtype)
+
+
+def test_chunk_reset_gates(emu):
+    # adversarial gates: runs of -20 resets force the adaptive chunk cut
+    check_chunk(DEV, B=1, H=1, T=40, Dk=64, Dv=64, dtype=torch.float32, resets=True)
+
+
+@pytest.mark.parametrize("T,W,dtype", [(1, 4, torch.float32), (3, 4, torch.float32), (37, 4, torch.float32),
+                                       (19, 3, torch.bfloat16)])
+def test_conv(emu, T, W, dtype):
+    check_conv(DEV, B=2, T=T, D=96, W=W, dtype=dtype)
+
+
+@pytest.mark.parametrize("D,dtype", [(64, torch.float32), (256, torch.float32), (512, torch.bfloat16)])
+def test_rmsnorm(emu, D, dtype):
+    check_rmsnorm(DEV, rows=7, D=D, dtype=dtype)
+
+
+def test_embed_argmax_swiglu_prologue(emu):
+    check_embed(DEV, Q=2, B=3, n=2, n_emb=37, d=64, dtype=torch.float32)
+    check_argmax(DEV, rows=5, n=4099, dtype=torch.float32)
+    check_swiglu(DEV, rows=3, hidden=85, dtype=torch.float32)
+    check_prologue(DEV, B=3, Kd=64, Vd=128, dtype=torch.float32)
+    check_prologue(DEV, B=2, Kd=64, Vd=64, dtype=torch.bfloat16)
