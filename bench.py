@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py -- codec tokens/s of the 169M (d1024 x l12) batched greedy decode on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one decode token for every row of the batch: the whole hot path (13 GLA blocks with
+the fused HIP step kernels, blind cross-attention, 4099-way head, device-side argmax + next-token
+embedding) as one hipGraph replay.  B = 64 rows per GPU (BASELINE.json configs[1]); with N GPUs the
+utterance batch is sharded 64/GPU with NO data-path collective (weak scaling; B = 512 at N = 8).
+Inputs and state are resident in HBM when the timed region starts.  Synthetic data, seeded
+random-init weights from the reference initialisers.
+
+Prints ONE JSON line (rank 0) with the driver contract plus
+  roofline      the dominant kernel of the step (K1, lina::gla_recurrent_kernel): algorithmic bytes per
+                launch / its average launch duration measured here with HIP events on the launch stream
+  chunk_kernel  the same accounting for K2 (lina::gla_chunk_*_kernel) at the training shape
+  cpu_baseline  the CPU oracle (pure-PyTorch recurrent port of the reference path) on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+B_PER_GPU = 64
+T_TXT = 64
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def k1_algorithmic_bytes(B, H, Dk, Dv, e_io, e_g):
+    """Per launch (one layer, one token): state read + write in fp32, q,k (e_io), gk (e_g) in, v in, o out.
+    SURVEY 8(d): 2*4*H*Dk*Dv + e*(3*H*Dk + 2*H*Dv) per (row, layer, token)."""
+    return B * (8 * H * Dk * Dv + e_io * (2 * H * Dk + 2 * H * Dv) + e_g * H * Dk)
+
+
+def measure_k1(engine, reps=20):
+    """Average duration of one K1 launch at the decode shape, real buffers, cycling through the 13 layers
+    (1.7 GB of state > L3, so every launch streams from HBM).  HIP events on torch's current stream --
+    the stream the C-ABI launches are enqueued on."""
+    from lina_speech_amd import ops
+    packs = engine.packs
+    B = engine.B
+
+    def one_pass():
+        for P in packs:
+            q = P.qkv[:, :P.Kd].view(B, P.H, 1, P.Dk)
+            k = P.qkv[:, P.Kd:2 * P.Kd].view(B, P.H, 1, P.Dk)
+            v = P.qkv[:, 2 * P.Kd:].view(B, P.H, 1, P.Dv)
+            ops.fused_recurrent_gla(q, k, v, P.gk.view(B, P.H, 1, P.Dk), initial_state=P.S,
+                                    output_final_state=True, inplace_state=True)
+
+    one_pass()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        one_pass()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) * 1e-3 / (reps * len(packs))
+
+
+def measure_chunk(dev, B=16, H=4, T=4096, Dk=256, Dv=256, reps=3):
+    """K2 at the training shape (config 5: seqlen 4096), bf16 I/O."""
+    from lina_speech_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(0)
+    mk = lambda D: torch.randn(B, T, H * D, generator=g).to(torch.bfloat16).to(dev).view(B, T, H, D).transpose(1, 2)
+    q, k, v = mk(Dk), mk(Dk), mk(Dv)
+    gk = (torch.nn.functional.logsigmoid(torch.randn(B, T, H * Dk, generator=g)) / 16).to(torch.bfloat16).to(dev)
+    gk = gk.view(B, T, H, Dk).transpose(1, 2)
+    ops.chunk_gla(q, k, v, gk, output_final_state=True)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        ops.chunk_gla(q, k, v, gk, output_final_state=True)
+    ev1.record()
+    torch.cuda.synchronize()
+    dt = ev0.elapsed_time(ev1) * 1e-3 / reps
+    nbytes = B * H * T * 2 * (3 * Dk + 2 * Dv)                       # e*(3Dk+2Dv) per (row,head,token)
+    flops = B * H * T * (2 * 64 * (Dk + Dv) + 4 * Dk * Dv)            # nominal C=64 count of SURVEY 8(d)
+    return {"kernel": "lina::gla_chunk_bf16_kernel<256>", "shape": {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv},
+            "dtype": "bf16", "ms": dt * 1e3, "bound": "hbm", "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS, "tflops": flops / dt / 1e12,
+            "tokens_per_s": B * T / dt}
+
+
+def cpu_baseline(model, seconds=12.0, B=8, max_steps=64):
+    """The reference's pure-PyTorch recurrent path (mode='naive') restated in oracle/, timed on the host cores
+    on a bounded sample of the same workload: same 166.7M weights (fp32), B=8 rows, T_txt=64, greedy."""
+    from oracle.lina_decode_oracle import OracleLina
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    orc = OracleLina(sd, n_layer=6, heads=4, txt_heads=4)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(3, 256, (B, T_TXT), generator=g)
+    with torch.no_grad():
+        x_enc = orc.text_encoder(x)
+        state = orc.init_state(B)
+        y = orc.embed(torch.ones(1, B, 1, dtype=torch.long))
+        orc.step(y, x_enc, state)                                   # warm-up step
+        n, t0 = 0, time.time()
+        while n < max_steps and time.time() - t0 < seconds:
+            logits, _ = orc.step(y, x_enc, state)
+            y = orc.embed(logits[:, 0].argmax(-1).t().unsqueeze(-1))
+            n += 1
+        dt = time.time() - t0
+    return {"value": B * n / dt, "unit": "codec tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/lina_decode_oracle.py (pure-PyTorch recurrent, fp32), 166.7M model, B={B}, "
+                      f"T_txt={T_TXT}, {n} greedy steps in {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-chunk", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)               # "nccl" is RCCL on ROCm
+
+    from lina_speech_amd import ops
+    from lina_speech_amd.configs import l169, n_params
+    from lina_speech_amd.decode import DecodeEngine
+    ops.get_backend().lib                                            # fail loudly if the HIP library is missing
+
+    from lina_speech_amd.shard import shard_rows
+    total_rows = B_PER_GPU * world
+    lo, hi = shard_rows(total_rows, rank, world)                     # this rank's utterances
+    B = hi - lo
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    torch.manual_seed(0)
+    model = l169().eval()
+    nparam = n_params(model)
+    model_dev = model.to(dev, dtype)
+    g = torch.Generator().manual_seed(1234)
+    texts = torch.randint(3, 256, (total_rows, T_TXT), generator=g)[lo:hi].to(dev)   # one distinct text per row
+
+    with torch.inference_mode():
+        x_enc = model_dev.txt_encoder(model_dev.txt_embed(texts))
+        eng = DecodeEngine(model_dev, x_enc, batch_size=B)
+        eng.begin_greedy(args.steps + args.warmup)
+        for _ in range(args.warmup):
+            eng.greedy_step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.greedy_step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        toks = eng.greedy_tokens()
+        assert toks.shape == (1, B, args.steps + args.warmup)
+        assert int(toks.min()) >= 0 and int(toks.max()) < 4099
+
+        out = None
+        if rank == 0:
+            P = eng.packs[0]
+            k1_dt = measure_k1(eng)
+            e_io = 2 if dtype == torch.bfloat16 else 4
+            k1_bytes = k1_algorithmic_bytes(B, P.H, P.Dk, P.Dv, e_io, 4)
+            roof = {"kernel": "lina::gla_recurrent_kernel<256,64>", "bound": "hbm",
+                    "achieved": k1_bytes / k1_dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": k1_bytes / k1_dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "bytes_per_launch": k1_bytes, "us_per_launch": k1_dt * 1e6, "launches_per_step": len(eng.packs)}
+            out = {
+                "metric": "codec tokens/sec (whole node), 169M d1024xl12 batched greedy decode",
+                "value": total_rows * args.steps / elapsed, "unit": "codec tokens/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+                "config": {"workload": f"L169 greedy codec-token decode, B={B_PER_GPU}/GPU (B_total={total_rows}), "
+                                       f"T_txt={T_TXT}, H=4 Dk=Dv=256, 12+1 GLA blocks, fp32 recurrent state, "
+                                       f"{nparam / 1e6:.1f}M params, one hipGraph replay per token",
+                           "global_batch": total_rows, "parallelism": f"batch-shard x{world} (no collective)"},
+                "roofline": roof,
+            }
+            if not args.no_chunk:
+                out["chunk_kernel"] = measure_chunk(dev)
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,14 +96,18 @@ int lina_short_conv_step(const void* x, const void* w, const void* bias, void* c
                          int activation, int dtype, lina_stream_t stream);
 
 /* K5 -- y = x * rsqrt(mean(x^2) + eps) * w  [ * g * sigmoid(g) ]   over the last dim D.
- * g == NULL -> plain RMSNorm.  w == NULL -> no affine.  Rows are addressed by strides.
- * `n_partial` > 1: x holds n_partial partial sums per row, `x_part_stride` apart, which are
- * added first (used by the decode step; pass 1 / 0 otherwise).  x_dtype: dtype of x (the
- * decode path hands over fp32 partial o); dtype: dtype of g, w, y.
+ * g == NULL -> plain RMSNorm.  w == NULL -> no affine.
+ * Rows are addressed two-level: row r -> (ro, ri) = (r / rows_inner, r % rows_inner) and the row
+ * starts at  ro * outer + ri * inner  (elements) of x / g / y -- e.g. rows = B*H, rows_inner = H
+ * reads the gate straight out of a wider fused-projection row.  rows_inner = 1 for flat rows.
+ * `n_partial` > 1: x holds n_partial fp32 partial sums per row, `x_part_stride` apart, which are
+ * added first (pass 1 / 0 otherwise).  x_dtype: dtype of x; dtype: dtype of g, w, y.
  * Replaces fla.modules.FusedRMSNormSwishGate / fla.modules.RMSNorm
  * (reference model/gla.py:111,115,219,222). */
 int lina_rmsnorm_gate_fwd(const void* x, const void* g, const void* w, void* y,
-                          int64_t rows, int D, int64_t x_row, int64_t g_row, int64_t y_row,
+                          int64_t rows, int rows_inner, int D,
+                          int64_t x_outer, int64_t x_inner, int64_t g_outer, int64_t g_inner,
+                          int64_t y_outer, int64_t y_inner,
                           int n_partial, int64_t x_part_stride,
                           float eps, int x_dtype, int dtype, lina_stream_t stream);
 

@@ -31,7 +31,8 @@ PROTOTYPES = {
     "lina_gla_chunk_fwd": (C.c_int, _GLA_SIG),
     "lina_short_conv_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _p]),
     "lina_short_conv_step": (C.c_int, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _i64, _i, _i, _p]),
-    "lina_rmsnorm_gate_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i, _i64, _i64, _i64, _i, _i64, _f, _i, _i, _p]),
+    "lina_rmsnorm_gate_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i64,
+                                        _f, _i, _i, _p]),
     "lina_embed_sum": (C.c_int, [_p, _p, _p, _i, _i64, _i, _i, _i, _p]),
     "lina_argmax_rows": (C.c_int, [_p, _p, _i64, _i, _i64, _i, _p]),
     "lina_gla_decode_prologue": (C.c_int, [_p, _i64, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,

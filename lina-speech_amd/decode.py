@@ -1,0 +1,234 @@
+"""DecodeEngine: the single-token step of ``AttentiveGLA.step`` + logits head
+(reference model/gla.py:358-365 driven by model/modeling_lina.py:152-179) restructured for
+MI355X: per GLA block ONE fused projection GEMM (q|k|v|g|gate-low-rank), ONE prologue launch
+(3 conv steps + gate), the in-place recurrent-state kernel K1, the norm-gate kernel K5 reading
+the gate straight out of the projection row, residual-fused GEMMs (``addmm``) and a K-padded
+SwiGLU down-projection that carries its bias as an extra column -- 11 launches per block instead
+of ~30 -- and the whole step captured in a hipGraph (no per-step host work, no host sync).
+
+The text side of the cross-attention is projected once (BlindCrossAttention.prepare).
+State lives in the caller-visible ``Cache`` tensors (reference layout, updated in place).
+GEMMs / LayerNorm / softmax stay on torch-ROCm (hipBLASLt), as SURVEY 8(a) a-7/a-8 prescribes.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .mixer import GatedLinearAttention
+from .modules import Cache
+
+
+class _BlockPack:
+    """Decode-time weights of one MixingBlock(GatedLinearAttention, SwiGLU, LayerNorm)."""
+
+    def __init__(self, blk, state):
+        m: GatedLinearAttention = blk.tmix
+        if not (m.use_short_conv and not m.share_conv_kernel and m.conv_size == 4 and not m.conv_bias
+                and m.fuse_norm_and_gate):
+            raise NotImplementedError("DecodeEngine needs use_short_conv=True, conv_size=4, no conv bias, "
+                                      "fused swish norm gate (the 'convblind_shortconv' configuration)")
+        dt = m.q_proj.weight.dtype
+        self.H, self.Dk, self.Dv, self.Kd, self.Vd = m.num_heads, m.head_qk_dim, m.head_v_dim, m.key_dim, m.value_dim
+        self.R = m.gk_proj[0].weight.shape[0]
+        self.normalizer, self.clamp_min = float(m.gate_logit_normalizer), m.clamp_min
+        self.eps_gate = m.g_norm_swish_gate.eps
+        # fused projection: rows = q | k | v | g | low-rank gate
+        self.w_in = torch.cat([m.q_proj.weight, m.k_proj.weight, m.v_proj.weight, m.g_proj.weight,
+                               m.gk_proj[0].weight], dim=0).contiguous()
+        self.off_q, self.off_k, self.off_v = 0, self.Kd, 2 * self.Kd
+        self.off_g, self.off_lr = 2 * self.Kd + self.Vd, 2 * self.Kd + 2 * self.Vd
+        self.wq = m.q_conv1d.weight.reshape(self.Kd, 4).contiguous()
+        self.wk = m.k_conv1d.weight.reshape(self.Kd, 4).contiguous()
+        self.wv = m.v_conv1d.weight.reshape(self.Vd, 4).contiguous()
+        self.w2, self.b2 = m.gk_proj[1].weight.contiguous(), m.gk_proj[1].bias.contiguous()
+        self.gnw = m.g_norm_swish_gate.weight.contiguous()
+        self.w_o = m.o_proj.weight.t()                                  # [Vd, d] view for addmm
+        self.n1, self.n2 = blk.norm1, blk.norm2
+        c = blk.cmix
+        self.hid = c.hidden
+        self.hid_pad = (self.hid + 1 + 7) // 8 * 8                      # +1 bias column, 16-byte rows in bf16
+        self.w_up, self.b_up = c.p_in.weight.t(), c.p_in.bias
+        w_down = torch.zeros(c.p_out.weight.shape[0], self.hid_pad, dtype=dt, device=c.p_out.weight.device)
+        w_down[:, :self.hid] = c.p_out.weight
+        w_down[:, self.hid] = c.p_out.bias
+        self.w_down = w_down.t()                                        # [hid_pad, d]
+        self.cq, self.ck, self.cv, self.S = state
+        if self.S.dtype != torch.float32 or not self.S.is_contiguous():
+            raise ValueError("recurrent state must be a contiguous fp32 tensor (see GatedLinearAttention.init_state)")
+        B = self.S.shape[0]
+        self.qkv = torch.empty(B, 2 * self.Kd + self.Vd, dtype=dt, device=self.S.device)
+        self.gk = torch.empty(B, self.Kd, dtype=torch.float32, device=self.S.device)
+
+
+class DecodeEngine:
+    def __init__(self, model, x_enc: torch.Tensor, batch_size: int, state: Optional[Cache] = None,
+                 use_graph: Optional[bool] = None):
+        rnn = model.attentive_rnn
+        self.model = model
+        self.B = batch_size
+        self.dev = x_enc.device
+        self.state = state if state is not None else rnn.init_state(batch_size=batch_size)
+        blocks = list(rnn.encoder) + list(rnn.decoder) + [rnn.cross_att.pos_net]
+        self.packs = [_BlockPack(b, self.state[i]) for i, b in enumerate(blocks)]
+        self.n_enc = len(rnn.encoder)
+        ca = rnn.cross_att
+        self.ca = ca
+        kk, vv, pe = ca.prepare(x_enc)                                   # [B,1,Ttxt,d] x2, [1,1,Ttxt,d]
+        self.kk, self.vv = kk.squeeze(1).contiguous(), vv.squeeze(1).contiguous()
+        self.pe = pe.squeeze(1).squeeze(0).contiguous()                  # [Ttxt, d]
+        self.att_scale = 1.0 / math.sqrt(self.kk.shape[-1])
+        hw = model.logits_head.weight
+        self.Q, self.L, self.d = hw.shape
+        self.w_head = hw.reshape(self.Q * self.L, self.d).t()
+        self.use_graph = (self.dev.type == "cuda") if use_graph is None else use_graph
+        self._graph = None
+        self._y_in = torch.zeros(batch_size, self.d, dtype=hw.dtype, device=self.dev)
+        self._logits = None
+        self._att = None
+
+    # ------------------------------------------------------------------ one GLA block, T = 1
+    def _block(self, x, P: _BlockPack):
+        B = x.shape[0]
+        h = F.layer_norm(x, (x.shape[-1],), P.n1.weight, P.n1.bias, P.n1.eps)
+        z = h @ P.w_in.t()
+        ops.gla_decode_prologue(z, P.off_q, P.off_k, P.off_v, P.off_lr, P.wq, P.wk, P.wv, P.cq, P.ck, P.cv,
+                                P.w2, P.b2, P.qkv, P.gk, P.normalizer, P.clamp_min)
+        q = P.qkv[:, :P.Kd].view(B, P.H, 1, P.Dk)
+        k = P.qkv[:, P.Kd:2 * P.Kd].view(B, P.H, 1, P.Dk)
+        v = P.qkv[:, 2 * P.Kd:].view(B, P.H, 1, P.Dv)
+        o, _ = ops.fused_recurrent_gla(q, k, v, P.gk.view(B, P.H, 1, P.Dk), initial_state=P.S,
+                                       output_final_state=True, inplace_state=True)
+        gate = z[:, P.off_g:P.off_g + P.Vd].view(B, P.H, P.Dv)
+        og = ops.rmsnorm_swish_gate(o.reshape(B, P.H, P.Dv), gate, P.gnw, P.eps_gate)
+        x = torch.addmm(x, og.view(B, P.Vd), P.w_o)
+        h2 = F.layer_norm(x, (x.shape[-1],), P.n2.weight, P.n2.bias, P.n2.eps)
+        u = torch.addmm(P.b_up, h2, P.w_up)
+        s = ops.swiglu(u, P.hid, pad_to=P.hid_pad)
+        return torch.addmm(x, s, P.w_down)
+
+    def _cross(self, x):
+        ca = self.ca
+        qq = F.layer_norm(F.linear(x, ca.q.weight, ca.q.bias), (x.shape[-1],), ca.ln_q.weight, ca.ln_q.bias,
+                          ca.ln_q.eps)
+        att1 = torch.softmax(torch.bmm(self.kk, qq.unsqueeze(-1)).squeeze(-1) * self.att_scale, dim=-1)  # [B,Ttxt]
+        xp = self._block(att1 @ self.pe, self.packs[-1])
+        att2 = torch.softmax((xp @ self.pe.t()) * self.att_scale, dim=-1)
+        out = torch.bmm(att2.unsqueeze(1), self.vv).squeeze(1)
+        return out, torch.stack((att1, att2), dim=1).unsqueeze(2)          # [B,2,1,Ttxt]
+
+    def _core(self, y):
+        x = y
+        for P in self.packs[:self.n_enc]:
+            x = self._block(x, P)
+        v, att = self._cross(x)
+        x = x + v
+        for P in self.packs[self.n_enc:-1]:
+            x = self._block(x, P)
+        logits = (x @ self.w_head).view(self.B, 1, self.Q, self.L)
+        return logits, att
+
+    # ------------------------------------------------------------------ graph capture
+    def _snapshot(self):
+        return [[t.clone() for t in (P.cq, P.ck, P.cv, P.S)] for P in self.packs]
+
+    def _restore(self, snap):
+        for P, saved in zip(self.packs, snap):
+            for dst, src in zip((P.cq, P.ck, P.cv, P.S), saved):
+                dst.copy_(src)
+
+    def _capture(self):
+        snap = self._snapshot()
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):                                           # warm hipBLASLt workspaces / autotune
+                self._core(self._y_in)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        self._restore(snap)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._logits, self._att = self._core(self._y_in)
+        self._graph = g
+
+    def __call__(self, y_embd: torch.Tensor, t: int = 0):
+        """One token for every row: y_embd [B,1,d] -> (logits [B,1,Q,L], att [B,2,1,Ttxt])."""
+        y = y_embd.reshape(self.B, self.d)
+        if not self.use_graph:
+            return self._core(y)
+        if self._graph is None:
+            self._capture()
+        self._y_in.copy_(y)
+        self._graph.replay()
+        return self._logits, self._att.clone()
+
+    step = __call__
+
+    # ------------------------------------------------------------------ fully device-side greedy loop
+    def begin_greedy(self, max_steps: int, y0: Optional[torch.Tensor] = None):
+        """Arm the device-side greedy loop: token picks (K6b), the next-token embedding (K6a) and the
+        token log are part of the captured step, so one token == one graph replay and nothing is read
+        back until ``greedy_tokens()``."""
+        emb = self.model.rvq_embed
+        if y0 is None:
+            y0 = emb.embed_sum(torch.ones(self.Q, self.B, 1, dtype=torch.long, device=self.dev))
+        self._y_in.copy_(y0.reshape(self.B, self.d))
+        self._tok_log = torch.zeros(max_steps, self.Q, self.B, dtype=torch.long, device=self.dev)
+        self._t_idx = torch.zeros(1, dtype=torch.long, device=self.dev)
+        self._n_done = 0
+
+        def body():
+            logits, att = self._core(self._y_in)
+            pick = ops.argmax_rows(logits.view(self.B, self.Q, self.L)).t().contiguous()    # [Q,B]
+            self._tok_log.index_copy_(0, self._t_idx, pick.unsqueeze(0))
+            self._t_idx.add_(1)
+            self._y_in.copy_(ops.embed_sum(emb.weight, pick))
+            return att
+
+        self._greedy_body = body
+        self._greedy_graph = None
+        if self.use_graph:
+            snap, y_keep = self._snapshot(), self._y_in.clone()
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    body()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            self._restore(snap)
+            self._y_in.copy_(y_keep)
+            self._tok_log.zero_()
+            self._t_idx.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._greedy_att = body()
+            self._greedy_graph = g
+
+    def greedy_step(self):
+        """Enqueue one token for every row (no host sync). Returns the step's attention weights
+        (a static buffer under graph replay: clone to keep)."""
+        self._n_done += 1
+        if self._greedy_graph is not None:
+            self._greedy_graph.replay()
+            return self._greedy_att
+        return self._greedy_body()
+
+    def greedy_tokens(self):
+        """Tokens produced so far: [Q,B,n]."""
+        return self._tok_log[:self._n_done].permute(1, 2, 0).contiguous()
+
+    @torch.inference_mode()
+    def run_greedy(self, n_steps: int, y0: Optional[torch.Tensor] = None, record_att: bool = False):
+        """Greedy decode of ``n_steps`` tokens. Returns tokens [Q,B,n_steps] (and atts [B,2,n,Ttxt])."""
+        self.begin_greedy(n_steps, y0)
+        atts = []
+        for _ in range(n_steps):
+            att = self.greedy_step()
+            if record_att:
+                atts.append(att.clone())
+        toks = self.greedy_tokens()
+        return (toks, torch.cat(atts, dim=2)) if record_att else toks

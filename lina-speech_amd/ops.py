@@ -154,7 +154,7 @@ def fused_chunk_gla(q, k, v, g, scale=None, initial_state=None, output_final_sta
 
 def chunk_simple_gla(q, k, v, g, scale=None, initial_state=None, output_final_state=False):
     """fla.ops.simple_gla.chunk_simple_gla: scalar gate per head g [B,H,T] -> K2 with the gate
-    broadcast over Dk (stride-0 view, no copy)."""
+    broadcast over Dk."""
     gk = g.unsqueeze(-1).expand(*g.shape, q.shape[-1])
     return _gla("lina_gla_chunk_fwd", q, k, v, gk.contiguous(), scale, initial_state, output_final_state)
 
@@ -193,28 +193,34 @@ def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional
 
 
 # --------------------------------------------------------------------------- norm (K5)
-def rmsnorm_swish_gate(x, g=None, weight=None, eps: float = 1e-5, n_partial: int = 1, out_dtype=None):
+def rmsnorm_swish_gate(x, g=None, weight=None, eps: float = 1e-5, n_partial: int = 1, out_dtype=None, out=None):
     """FusedRMSNormSwishGate / RMSNorm forward over the last dim.
-    ``n_partial`` > 1: ``x`` is [n_partial, ..., D] partial sums (fp32) that are added first."""
+    ``n_partial`` > 1: ``x`` is [n_partial, ..., D] partial sums (fp32) that are added first.
+    A gate ``g`` that is a strided 3-D view [R, H, D] (head slices of a wider row) is read in place."""
     _no_grad(x, g, weight)
     be = _BACKEND
     be.require(x, g, weight)
-    if n_partial > 1:
-        xs = x.contiguous()
-        part_stride = xs.stride(0)
-        shape = xs.shape[1:]
-    else:
-        xs = x.contiguous()
-        part_stride = 0
-        shape = xs.shape
+    xs = x.contiguous()
+    part_stride = xs.stride(0) if n_partial > 1 else 0
+    shape = xs.shape[1:] if n_partial > 1 else xs.shape
     D = shape[-1]
     rows = int(math.prod(shape[:-1]))
     odt = out_dtype or (g.dtype if g is not None else xs.dtype)
-    gs = None if g is None else g.to(odt).contiguous()
+    rows_inner, g_outer, g_inner = 1, D, 0
+    gs = None
+    if g is not None:
+        gs = g if g.dtype == odt else g.to(odt)
+        if (gs.dim() == 3 and gs.stride(-1) == 1 and tuple(gs.shape) == tuple(shape[-3:]) and rows == gs.shape[0] * gs.shape[1]
+                and gs.stride(0) % 4 == 0 and gs.stride(1) % 4 == 0):
+            rows_inner, g_outer, g_inner = gs.shape[1], gs.stride(0), gs.stride(1)
+        else:
+            gs = gs.contiguous()
     ws = None if weight is None else weight.to(odt).contiguous()
-    y = torch.empty(shape, dtype=odt, device=xs.device)
-    _check(be.lib.lina_rmsnorm_gate_fwd(_ptr(xs), _ptr(gs), _ptr(ws), _ptr(y), rows, D, D, D, D, n_partial,
-                                        part_stride, float(eps), _dt(xs), _dt(y), be.stream(xs)))
+    y = out if out is not None else torch.empty(shape, dtype=odt, device=xs.device)
+    _check(be.lib.lina_rmsnorm_gate_fwd(_ptr(xs), _ptr(gs), _ptr(ws), _ptr(y), rows, rows_inner, D,
+                                        D * rows_inner, D if rows_inner > 1 else 0, g_outer, g_inner,
+                                        D * rows_inner, D if rows_inner > 1 else 0,
+                                        n_partial, part_stride, float(eps), _dt(xs), _dt(y), be.stream(xs)))
     return y
 
 

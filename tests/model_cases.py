@@ -1,0 +1,126 @@
+"""Module / model level checks against the golden vectors captured from the reference's own
+in-tree modules (tests/golden/make_golden.py).  `dev` = "cpu" (emulator) or "cuda" (HIP).
+
+Tolerance: golden activations were produced in fp32 by the reference glue + CPU oracle, the
+kernels accumulate in a different order -> 2e-4 relative to max|golden| (fp32 model);
+token ids, stop flags, shapes: exact.
+"""
+import os
+
+import numpy as np
+import torch
+
+from lina_speech_amd.attentive import AttentiveGLA
+from lina_speech_amd.blocks import TextEncoder
+from lina_speech_amd.lina_model import LinaModel
+from lina_speech_amd.mixer import GatedLinearAttention
+from lina_speech_amd.modules import Cache
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REL = 2e-4
+
+
+def load_golden(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", name))
+
+
+def golden_state_dict(g):
+    sd = {}
+    for k in g.files:
+        if not k.startswith("sd::"):
+            continue
+        name = k[4:]
+        if name.endswith("::first_rows"):
+            base = name[: -len("::first_rows")]
+            full = int(g["sd::" + base + "::full_rows"])
+            rows = torch.from_numpy(g[k])
+            w = torch.zeros(full, rows.shape[1])
+            w[: rows.shape[0]] = rows
+            sd[base] = w
+        elif name.endswith("::full_rows"):
+            continue
+        else:
+            sd[name] = torch.from_numpy(g[k])
+    return sd
+
+
+def close(got, ref, what, rel=REL):
+    got = got.detach().float().cpu()
+    ref = torch.as_tensor(ref).float()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    err = (got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)
+    assert err <= rel, f"{what}: rel err {err:.3e} > {rel:.1e}"
+
+
+def build_lina(d=64, n_layer=1, heads=1, ev=1.0, n_codebook=253, txt_layers=1):
+    rnn = AttentiveGLA(d_model=d, n_layer=n_layer, heads=heads, blind=True, use_short_conv=True, expand_k=1.0,
+                       expand_v=ev, pos_type="convolutional")
+    txt = TextEncoder(d, heads, n_layers=txt_layers, dropout=0.0, rotary=False)
+    return LinaModel(rnn, d_model=d, n_quant=1, n_codebook=n_codebook, n_special_token_in=3, n_special_token_out=3,
+                     n_txt_vocab=256, txt_encoder=txt)
+
+
+def check_mixer_golden(dev):
+    g = load_golden("mixer_d128.npz")
+    m = GatedLinearAttention(mode="fused_chunk", hidden_size=128, num_heads=2, expand_k=1.0, expand_v=2.0,
+                             use_short_conv=True, layer_idx=0)
+    missing = m.load_state_dict(golden_state_dict(g), strict=True)   # same keys as the reference module
+    m = m.to(dev).eval()
+    x = torch.from_numpy(g["x"]).to(dev)
+    T = 21
+    with torch.no_grad():
+        for mode in ("fused_chunk", "chunk", "fused_recurrent"):
+            m.mode = mode
+            close(m(x[:, :T]), g["o_" + mode], f"mixer {mode}")
+        m.mode = "fused_chunk"
+        close(m(x[:, :T], reset_mask=torch.from_numpy(g["reset_mask"]).to(dev)), g["o_reset"], "mixer reset")
+        cache = Cache()
+        cache.update(m.init_state(3), 0, offset=0)
+        m.mode = "fused_recurrent"
+        close(m(x[:, :T], past_key_values=cache, use_cache=True), g["o_prefill_cached"], "mixer cached prefill")
+        for i in range(3):
+            close(m(x[:, T + i:T + i + 1], past_key_values=cache, use_cache=True), g[f"o_step{i}"], f"mixer step {i}")
+        for j, s in enumerate(cache.states[0]):
+            close(s, g[f"cache_after_{j}"], f"mixer cache[{j}]")
+
+
+def check_lina_golden(dev, engine=None):
+    g = load_golden("lina_d64.npz")
+    model = build_lina()
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    model = model.to(dev).eval()
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    with torch.no_grad():
+        if engine is None:
+            logits, loss, att, _, _ = model(t("x"), t("y"), t("encoder_mask"), t("crossatt_mask"),
+                                            logits_mask=t("logits_mask"))
+            close(logits, g["fwd_logits"], "forward logits")
+            close(loss, g["fwd_loss"], "forward loss")
+            close(att, g["fwd_att"], "forward att")
+        qs, atts, stops, cuts = model.generate_batch(t("gen_x"), batch_size=3, max_seqlen=12, k=1,
+                                                     first_greedy_quant=0, force_max_seqlen=True, device=dev,
+                                                     engine=engine)
+        assert torch.equal(qs.cpu(), torch.from_numpy(g["gen_qs"])), "greedy token ids differ from the reference"
+        assert torch.equal(stops.cpu(), torch.from_numpy(g["gen_stop_tokens"]))
+        close(atts, g["gen_atts"], "generate atts")
+        assert [c[0].shape[-1] for c in cuts] == list(g["gen_cut_lens"])
+        qs2, atts2, st2, _ = model.generate_batch(t("gen_x"), batch_size=3, prompt=t("gen_prompt"), max_seqlen=9,
+                                                  k=1, first_greedy_quant=0, force_max_seqlen=True, device=dev,
+                                                  engine=engine)
+        assert torch.equal(qs2.cpu(), torch.from_numpy(g["gen_prompt_qs"])), "prompted token ids differ"
+        close(atts2, g["gen_prompt_atts"], "prompted atts")
+        if engine is None:
+            # teacher-forced step loop == reference step logits, and the cache layout/content
+            x_enc = model.txt_encoder(model.txt_embed(t("x")))
+            state = model.attentive_rnn.init_state(batch_size=3)
+            y_embd = model.rvq_embed.embed_sum(t("y").permute(2, 0, 1))
+            outs = []
+            for i in range(y_embd.shape[1] - 1):
+                h, a, state = model.attentive_rnn.step(y_embd[:, i:i + 1], x_enc, i, state)
+                outs.append(model.logits_head(h))
+            close(torch.cat(outs, 1), g["step_logits"], "step logits")
+            assert len(state.states) == 3
+            for li, st in enumerate(state.states):
+                assert len(st) == 4
+                for j, s in enumerate(st):
+                    close(s, g[f"cache_{li}_{j}"], f"cache[{li}][{j}]")

@@ -1,0 +1,105 @@
+"""HIP kernels on a real MI355X vs the CPU oracle, through the C ABI (ops -> ctypes -> liblina_gla.so)."""
+import pytest
+import torch
+
+from kernel_cases import (assert_close, check_argmax, check_chunk, check_conv, check_embed, check_prologue,
+                          check_recurrent, check_rmsnorm, check_swiglu, make_gla_inputs, oracle_gla)
+from lina_speech_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("Dk,Dv,T,dtype", [(64, 64, 1, torch.float32), (128, 64, 3, torch.float32),
+                                           (256, 128, 1, torch.float32), (256, 256, 5, torch.float32),
+                                           (64, 64, 2, torch.bfloat16), (256, 256, 1, torch.bfloat16)])
+def test_recurrent(hip, Dk, Dv, T, dtype):
+    check_recurrent(DEV, B=3, H=2, T=T, Dk=Dk, Dv=Dv, dtype=dtype)
+
+
+@pytest.mark.parametrize("Dk,Dv,T,dtype", [(64, 64, 37, torch.float32), (128, 64, 20, torch.float32),
+                                           (256, 64, 18, torch.float32), (256, 256, 100, torch.float32),
+                                           (64, 64, 33, torch.bfloat16), (128, 128, 17, torch.bfloat16),
+                                           (256, 256, 130, torch.bfloat16)])
+def test_chunk(hip, Dk, Dv, T, dtype):
+    check_chunk(DEV, B=2, H=2, T=T, Dk=Dk, Dv=Dv, dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_chunk_reset_gates(hip, dtype):
+    check_chunk(DEV, B=2, H=2, T=70, Dk=128, Dv=64, dtype=dtype, resets=True)
+
+
+@pytest.mark.parametrize("T,W,dtype", [(1, 4, torch.float32), (3, 4, torch.float32), (37, 4, torch.float32),
+                                       (300, 4, torch.float32), (19, 3, torch.bfloat16), (64, 4, torch.bfloat16)])
+def test_conv(hip, T, W, dtype):
+    check_conv(DEV, B=3, T=T, D=1000, W=W, dtype=dtype)
+
+
+@pytest.mark.parametrize("D,dtype", [(64, torch.float32), (256, torch.float32), (1024, torch.float32),
+                                     (512, torch.bfloat16)])
+def test_rmsnorm(hip, D, dtype):
+    check_rmsnorm(DEV, rows=37, D=D, dtype=dtype)
+
+
+def test_embed_argmax_swiglu_prologue(hip):
+    for dt in (torch.float32, torch.bfloat16):
+        check_embed(DEV, Q=2, B=5, n=3, n_emb=4099, d=1024, dtype=dt)
+        check_argmax(DEV, rows=64, n=4099, dtype=dt)
+        check_swiglu(DEV, rows=64, hidden=1365, dtype=dt)
+        check_prologue(DEV, B=64, Kd=1024, Vd=1024, dtype=dt)
+    check_prologue(DEV, B=3, Kd=64, Vd=128, dtype=torch.float32, clamp_min=-0.05)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json sizes (B=64, H=4, Dk=Dv=256): size-independent properties, no CPU oracle needed
+# ---------------------------------------------------------------------------------------------
+def test_full_size_decode_step_properties(hip):
+    B, H, Dk, Dv = 64, 4, 256, 256
+    q, k, v, gk, h0 = make_gla_inputs(B, H, 1, Dk, Dv, torch.float32, DEV, seed=3)
+    o, S = ops.fused_recurrent_gla(q, k, v, gk, initial_state=h0, output_final_state=True)
+    # (1) in-place == out-of-place, bit for bit
+    h_in = h0.clone()
+    o_i, S_i = ops.fused_recurrent_gla(q, k, v, gk, initial_state=h_in, output_final_state=True, inplace_state=True)
+    assert S_i.data_ptr() == h_in.data_ptr() and torch.equal(S_i, S) and torch.equal(o_i, o)
+    # (2) closed form of one step: S' = exp(g) S + k^T v ; o = scale q S'
+    S_ref = h0 * gk[:, :, 0].exp().unsqueeze(-1) + k[:, :, 0].unsqueeze(-1) * v[:, :, 0].unsqueeze(-2)
+    o_ref = torch.einsum("bhk,bhkv->bhv", q[:, :, 0] * Dk ** -0.5, S_ref)
+    assert_close(S, S_ref, 1e-6, "full-size S'")
+    assert_close(o[:, :, 0], o_ref, 1e-5, "full-size o")
+    # (3) linearity in v with a zero state
+    v2 = torch.randn_like(v)
+    oa, _ = ops.fused_recurrent_gla(q, k, v, gk)
+    ob, _ = ops.fused_recurrent_gla(q, k, v2, gk)
+    oc, _ = ops.fused_recurrent_gla(q, k, v + v2, gk)
+    assert_close(oc, oa + ob, 1e-5, "linearity in v")
+    # (4) the chunk kernel agrees on the same single step
+    o2, S2 = ops.chunk_gla(q, k, v, gk, initial_state=h0, output_final_state=True)
+    assert_close(o2, o, 1e-4, "K2 == K1 (o)")
+    assert_close(S2, S, 1e-4, "K2 == K1 (S)")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_full_length_chunk_equals_recurrent_kernel(hip, dtype):
+    # seqlen 4096 (config 5): K2's final state / outputs == K1 run sequentially over the same tokens
+    B, H, T, Dk, Dv = 2, 4, 4096, 256, 256
+    q, k, v, gk, h0 = make_gla_inputs(B, H, T, Dk, Dv, dtype, DEV, seed=4)
+    gk = (gk.float() / 4).to(dtype)             # logsigmoid/16 scale, as in the model
+    o1, S1 = ops.fused_recurrent_gla(q, k, v, gk, initial_state=h0, output_final_state=True)
+    o2, S2 = ops.chunk_gla(q, k, v, gk, initial_state=h0, output_final_state=True)
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert_close(o2, o1.float(), tol, "T=4096 K2 vs K1 (o)")
+    assert_close(S2, S1, 2e-4 if dtype == torch.float32 else 2e-2, "T=4096 K2 vs K1 (S)")
+    # split the sequence: prefill 3000 tokens then 1096 more from the carried state == one pass
+    oa, Sa = ops.chunk_gla(q[:, :, :3000], k[:, :, :3000], v[:, :, :3000], gk[:, :, :3000], initial_state=h0,
+                           output_final_state=True)
+    ob, Sb = ops.chunk_gla(q[:, :, 3000:], k[:, :, 3000:], v[:, :, 3000:], gk[:, :, 3000:], initial_state=Sa,
+                           output_final_state=True)
+    assert_close(torch.cat([oa, ob], 2), o2, tol, "split prefill (o)")
+    assert_close(Sb, S2, 1e-3 if dtype == torch.float32 else 2e-2, "split prefill (S)")
+
+
+def test_missing_device_tensor_is_an_error(hip):
+    x = torch.randn(2, 2, 1, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.fused_recurrent_gla(x, x, x, x)

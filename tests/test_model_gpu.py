@@ -1,0 +1,75 @@
+"""Module / model level parity on a real MI355X: reference goldens, fused engine + hipGraph,
+and the 166.7M model's greedy tokens against the CPU oracle."""
+import pytest
+import torch
+
+from model_cases import check_lina_golden, check_mixer_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mixer_matches_reference_module(hip):
+    check_mixer_golden("cuda")
+
+
+def test_lina_forward_and_greedy_decode_match_reference(hip):
+    check_lina_golden("cuda")
+
+
+def test_fused_engine_with_hipgraph_matches_reference_tokens(hip):
+    check_lina_golden("cuda", engine="fused")
+
+
+def test_l169_greedy_tokens_match_cpu_oracle(hip):
+    """Full 166.7M model, fp32: device-side greedy loop (graph replay) vs oracle/lina_decode_oracle.py.
+    Token ids must be identical wherever the oracle's top-2 logit margin exceeds 1e-3 (SURVEY A.8:
+    equality is not meaningful at near-ties); teacher forcing keeps both sides on the oracle's tokens."""
+    from lina_speech_amd.configs import l169
+    from lina_speech_amd.decode import DecodeEngine
+    from oracle.lina_decode_oracle import OracleLina
+    torch.manual_seed(0)
+    model = l169().eval()
+    B, n = 4, 6
+    x = torch.randint(3, 256, (B, 16))
+    orc = OracleLina(model.state_dict(), n_layer=6, heads=4, txt_heads=4)
+    ref_toks, ref_logits, ref_atts, margins = orc.generate_greedy(x, n)
+    with torch.inference_mode():
+        m = model.to("cuda")
+        x_enc = m.txt_encoder(m.txt_embed(x.cuda()))
+        eng = DecodeEngine(m, x_enc, batch_size=B)
+        # teacher-forced logits through the generic step API
+        y = m.rvq_embed.embed_sum(torch.ones(1, B, 1, dtype=torch.long, device="cuda"))
+        worst = 0.0
+        for t in range(n):
+            logits, att = eng(y, t)
+            ref = ref_logits[:, t:t + 1]
+            worst = max(worst, float((logits.cpu() - ref).abs().max() / ref.abs().max()))
+            pick = logits[:, 0, 0].argmax(-1).cpu()
+            safe = margins[:, t] > 1e-3
+            assert torch.equal(pick[safe], ref_toks[0, :, t][safe]), f"token mismatch at step {t}"
+            y = m.rvq_embed.embed_sum(ref_toks[:, :, t:t + 1].cuda())
+        assert worst < 5e-4, f"logits rel err {worst:.2e}"
+        # free-running device-side loop on a fresh state
+        eng2 = DecodeEngine(m, x_enc, batch_size=B)
+        toks = eng2.run_greedy(n).cpu()
+    # rows stay comparable until their first near-tie
+    for b in range(B):
+        ok = (margins[b] > 1e-3).long().cumprod(0).bool()
+        assert torch.equal(toks[0, b][ok], ref_toks[0, b][ok])
+
+
+def test_bf16_engine_runs_and_tracks_fp32(hip):
+    from lina_speech_amd.configs import tiny
+    from lina_speech_amd.decode import DecodeEngine
+    torch.manual_seed(1)
+    model = tiny(d=256, heads=2, n_layer=2, n_codebook=4096).eval().cuda()
+    x = torch.randint(3, 256, (8, 20), device="cuda")
+    with torch.inference_mode():
+        x_enc = model.txt_encoder(model.txt_embed(x))
+        y = model.rvq_embed.embed_sum(torch.ones(1, 8, 1, dtype=torch.long, device="cuda"))
+        l32, _ = DecodeEngine(model, x_enc, batch_size=8)(y, 0)
+        l32 = l32.clone()
+        mb = model.to(torch.bfloat16)
+        lb, _ = DecodeEngine(mb, x_enc.bfloat16(), batch_size=8)(y.bfloat16(), 0)
+    err = (lb.float() - l32).abs().max() / l32.abs().max()
+    assert torch.isfinite(lb.float()).all() and err < 5e-2, f"bf16 vs fp32 logits rel err {err:.3e}"

@@ -1,0 +1,104 @@
+"""The oracle checked against (a) its own laws and (b) the vectors captured from the reference's
+in-tree modules.  CPU only; no product code is involved except the golden state-dict helper."""
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden
+from model_cases import golden_state_dict, load_golden
+from oracle import gla_oracle as O
+from oracle.lina_decode_oracle import OracleLina
+
+
+def _inputs(B=2, H=2, T=50, Dk=32, Dv=48, resets=False, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    q, k = torch.randn(B, H, T, Dk, generator=g), torch.randn(B, H, T, Dk, generator=g)
+    v = torch.randn(B, H, T, Dv, generator=g)
+    gk = F.logsigmoid(torch.randn(B, H, T, Dk, generator=g)) / 4
+    if resets:
+        gk[:, :, 7] = -20.0
+        gk[:, :, 20:24] = -20.0
+    return q, k, v, gk, torch.randn(B, H, Dk, Dv, generator=g)
+
+
+@pytest.mark.parametrize("resets", [False, True])
+def test_chunk_equals_recurrent_equals_fp64(resets):
+    q, k, v, gk, h0 = _inputs(resets=resets)
+    o64, s64 = O.naive_recurrent_gla(q, k, v, gk, h0, True, compute_dtype=torch.float64)
+    o32, s32 = O.naive_recurrent_gla(q, k, v, gk, h0, True)
+    for chunk in (16, 64):
+        oc, sc = O.chunk_gla(q, k, v, gk, initial_state=h0, output_final_state=True, chunk=chunk)
+        assert (oc.double() - o64).abs().max() / o64.abs().max() < 1e-5
+        assert (sc.double() - s64).abs().max() / s64.abs().max() < 1e-5
+    assert (o32.double() - o64).abs().max() / o64.abs().max() < 1e-5
+
+
+def test_prefill_then_step_equals_longer_prefill():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 11, 24, generator=g)
+    w = torch.randn(24, 1, 4, generator=g)
+    full = O.short_conv(x, w)
+    cache = torch.zeros(2, 24, 4)
+    part = O.short_conv(x[:, :8], w, None, cache)
+    steps = [O.short_conv(x[:, t:t + 1], w, None, cache) for t in range(8, 11)]
+    assert torch.allclose(torch.cat([part] + steps, 1), full, atol=1e-6)
+    assert torch.allclose(cache, x[:, -4:].transpose(1, 2))
+    # T < W prefill left-pads the cache with zeros
+    c2 = torch.ones(2, 24, 4)
+    O.short_conv(x[:, :2], w, None, c2)
+    assert torch.equal(c2[:, :, :2], torch.zeros(2, 24, 2)) and torch.allclose(c2[:, :, 2:], x[:, :2].transpose(1, 2))
+
+
+def test_recurrent_T_steps_equals_T_single_steps():
+    q, k, v, gk, h0 = _inputs(T=9)
+    o, s = O.naive_recurrent_gla(q, k, v, gk, h0, True)
+    st = h0
+    outs = []
+    for t in range(9):
+        ot, st = O.naive_recurrent_gla(q[:, :, t:t + 1], k[:, :, t:t + 1], v[:, :, t:t + 1], gk[:, :, t:t + 1], st, True)
+        outs.append(ot)
+    assert torch.allclose(torch.cat(outs, 2), o, atol=1e-6) and torch.allclose(st, s, atol=1e-6)
+
+
+def test_config1_simple_gla_plumbing_cpu():
+    """BASELINE.json configs[0]: d256 x l2 simple-GLA forward, pure-PyTorch recurrent on CPU, B=4 T=256."""
+    from oracle.fla_standin import SimpleGatedLinearAttention
+    torch.manual_seed(0)
+    layers = [SimpleGatedLinearAttention(hidden_size=256, num_heads=4, layer_idx=i) for i in range(2)]
+    x = torch.randn(4, 256, 256)
+    t0 = time.time()
+    with torch.no_grad():
+        for l in layers:
+            x = l(x)[0] + x
+    assert x.shape == (4, 256, 256) and torch.isfinite(x).all()
+    assert time.time() - t0 < 60
+
+
+def test_oracle_decode_restatement_reproduces_reference_goldens():
+    g = load_golden("lina_d64.npz")
+    orc = OracleLina(golden_state_dict(g), n_layer=1, heads=1)
+    x = torch.from_numpy(g["gen_x"]).unsqueeze(0).expand(3, -1)
+    toks, logits, atts, margins = orc.generate_greedy(x, 12)
+    assert torch.equal(toks, torch.from_numpy(g["gen_qs"]))
+    assert (atts - torch.from_numpy(g["gen_atts"])).abs().max() < 1e-5
+    # teacher-forced logits == reference AttentiveGLA.step logits, final cache == reference cache
+    y = torch.from_numpy(g["y"])                                   # [B,n,q]
+    orc2 = OracleLina(golden_state_dict(g), n_layer=1, heads=1)
+    teacher = y.permute(2, 0, 1)[:, :, 1:]
+    # the golden step loop saw DISTINCT texts per row
+    _, logits2, _, _ = orc2.generate_greedy(torch.from_numpy(g["x"]), 13, teacher=teacher)
+    ref = torch.from_numpy(g["step_logits"])
+    assert (logits2 - ref).abs().max() / ref.abs().max() < 1e-5
+    for li, st in enumerate(orc2.final_state):
+        for j, s in enumerate(st):
+            assert (s - torch.from_numpy(g[f"cache_{li}_{j}"])).abs().max() < 1e-5
+
+
+def test_tools_known_answers_from_reference():
+    g = golden("tools.npz")
+    assert O.delay_rvq(torch.from_numpy(g["delay_in"]), 1, 2).tolist() == [[1, 13, 14, 15, 16, 2]]
+    lg = torch.from_numpy(g["topk_logits"])
+    assert torch.equal(O.argmax_lowest(lg), torch.from_numpy(g["topk_k1"]).squeeze(-1))
