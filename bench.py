@@ -13,7 +13,7 @@ Inputs and state are resident in HBM when the timed region starts.  Synthetic da
 random-init weights from the reference initialisers.
 
 Prints ONE JSON line (rank 0) with the driver contract plus
-  roofline      the dominant kernel of the step (K1, lina::gla_recurrent_kernel): algorithmic bytes per
+  roofline      the dominant kernel of the step (K1d, lina::gla_decode_rowsplit_kernel): algorithmic bytes per
                 launch / its average launch duration measured here with HIP events on the launch stream
   chunk_kernel  the same accounting for K2 (lina::gla_chunk_*_kernel) at the training shape
   cpu_baseline  the CPU oracle (pure-PyTorch recurrent port of the reference path) on a bounded sample
@@ -47,20 +47,19 @@ def k1_algorithmic_bytes(B, H, Dk, Dv, e_io, e_g):
 
 
 def measure_k1(engine, reps=20):
-    """Average duration of one K1 launch at the decode shape, real buffers, cycling through the 13 layers
-    (1.7 GB of state > L3, so every launch streams from HBM).  HIP events on torch's current stream --
-    the stream the C-ABI launches are enqueued on."""
+    """Average duration of one K1d launch (lina::gla_decode_rowsplit_kernel) at the decode shape, real buffers,
+    cycling through the 13 layers (1.7 GB of state > L3, so every launch streams from HBM).  HIP events on
+    torch's current stream -- the stream the C-ABI launches are enqueued on."""
     from lina_speech_amd import ops
     packs = engine.packs
     B = engine.B
 
     def one_pass():
         for P in packs:
-            q = P.qkv[:, :P.Kd].view(B, P.H, 1, P.Dk)
-            k = P.qkv[:, P.Kd:2 * P.Kd].view(B, P.H, 1, P.Dk)
-            v = P.qkv[:, 2 * P.Kd:].view(B, P.H, 1, P.Dv)
-            ops.fused_recurrent_gla(q, k, v, P.gk.view(B, P.H, 1, P.Dk), initial_state=P.S,
-                                    output_final_state=True, inplace_state=True)
+            q = P.qkv[:, :P.Kd].view(B, P.H, P.Dk)
+            k = P.qkv[:, P.Kd:2 * P.Kd].view(B, P.H, P.Dk)
+            v = P.qkv[:, 2 * P.Kd:].view(B, P.H, P.Dv)
+            ops.gla_decode_update(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S)
 
     one_pass()
     torch.cuda.synchronize()
@@ -102,7 +101,7 @@ def cpu_baseline(model, seconds=12.0, B=8, max_steps=64):
     """The reference's pure-PyTorch recurrent path (mode='naive') restated in oracle/, timed on the host cores
     on a bounded sample of the same workload: same 166.7M weights (fp32), B=8 rows, T_txt=64, greedy."""
     from oracle.lina_decode_oracle import OracleLina
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))   # small-op decode: more threads only add sync cost
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     orc = OracleLina(sd, n_layer=6, heads=4, txt_heads=4)
     g = torch.Generator().manual_seed(0)
@@ -196,7 +195,7 @@ def main():
             k1_dt = measure_k1(eng)
             e_io = 2 if dtype == torch.bfloat16 else 4
             k1_bytes = k1_algorithmic_bytes(B, P.H, P.Dk, P.Dv, e_io, 4)
-            roof = {"kernel": "lina::gla_recurrent_kernel<256,64>", "bound": "hbm",
+            roof = {"kernel": "lina::gla_decode_rowsplit_kernel<256>", "bound": "hbm",
                     "achieved": k1_bytes / k1_dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": k1_bytes / k1_dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
                     "bytes_per_launch": k1_bytes, "us_per_launch": k1_dt * 1e6, "launches_per_step": len(eng.packs)}

@@ -147,6 +147,33 @@ int lina_gla_decode_prologue(const void* z, int64_t ldz, int off_q, int off_k, i
 int lina_swiglu(const void* u, void* y, int64_t rows, int Hd, int64_t ld_u, int64_t ld_y,
                 int dtype, lina_stream_t stream);
 
+/* K1d -- decode-step (T = 1) state update, row-split: same arithmetic as K1, but each workgroup
+ * streams a contiguous 64-row block of the fp32 state (in place) and the q.S products of the Dk/64
+ * row blocks are returned as fp32 PARTIALS  o_part[Dk/64][B*H][Dv]  for K5 to add (n_partial).
+ * q,k,gk: [B,H,Dk], v: [B,H,Dv] addressed by (batch, head) strides.  Dv in {64,128,256}, Dk % 64 == 0.
+ * Same reference call sites as K1 (model/gla.py:188-201 at T = 1). */
+int lina_gla_decode_update(const void* q, const void* k, const void* v, const void* gk,
+                           float* o_part, float* state, int B, int H, int Dk, int Dv,
+                           int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
+                           int64_t v_sb, int64_t v_sh, int64_t g_sb, int64_t g_sh,
+                           int dtype, int g_dtype, float scale, lina_stream_t stream);
+
+/* Decode-step projection with fused neighbours: out[M,N] = epi(A[M,K] . W[N,K]^T), M ~ batch rows.
+ *   ln_dim > 0 : A is layer-normalised over its ln_dim features first, folded algebraically:
+ *                out = rstd*(A.W^T - mu*c1) + c2   with W pre-scaled by the LN gamma,
+ *                c1[n] = sum_k W[n,k] (fp32), c2[n] = sum_k beta_k W0[n,k] + bias[n] (fp32);
+ *   ln_dim == 0: out = A.W^T + c2 (c2 may be NULL);
+ *   swiglu_hidden = Hd > 0: W holds 2*Hd rows (gate half, value half; c1,c2 2*Hd long); out column n
+ *                < Hd is silu(gate_n)*value_n, column Hd is the constant 1, columns > Hd are 0;
+ *   resid != NULL: out += resid (out may alias resid).
+ * Replaces the nn.Linear / nn.LayerNorm / SwiGLU glue of the reference decode step
+ * (model/gla.py:158-160,216,225; model/base_blocks.py:48-50,65-69; model/modeling_lina.py:155).
+ * K must be a multiple of 32 (bf16) / 16 (f32); lda, ldw multiples of 8 / 4 elements. */
+int lina_linear_skinny(const void* A, int64_t lda, const void* W, int64_t ldw,
+                       const float* c1, const float* c2, const void* resid, int64_t ldr,
+                       void* out, int64_t ldo, int M, int N, int K,
+                       int swiglu_hidden, int ln_dim, float ln_eps, int dtype, lina_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,11 +38,30 @@ PROTOTYPES = {
     "lina_gla_decode_prologue": (C.c_int, [_p, _i64, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                            _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "lina_swiglu": (C.c_int, [_p, _p, _i64, _i, _i64, _i64, _i, _p]),
+    "lina_gla_decode_update": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64,
+                                         _i64, _i64, _i, _i, _f, _p]),
+    "lina_linear_skinny": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _i, _i, _i, _i, _i, _f, _i, _p]),
 }
 
 
-def bind(path: str) -> C.CDLL:
+def _preload_hip_runtime() -> None:
+    """The library is linked without a DT_NEEDED for libamdhip64 (build.py): it must bind to the ONE
+    HIP runtime of the process -- torch's bundled copy -- or its launches could not use torch's
+    streams.  Import torch and put that runtime's symbols in the global scope before dlopen."""
+    import torch  # noqa: F401  (loads torch/lib/libamdhip64.so)
+    cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"),
+             "/opt/rocm/lib/libamdhip64.so"]
+    for c in cands:
+        if os.path.exists(c):
+            C.CDLL(c, mode=C.RTLD_GLOBAL)
+            return
+    raise RuntimeError("no libamdhip64.so found (torch/lib or /opt/rocm/lib)")
+
+
+def bind(path: str, hip_runtime: bool = True) -> C.CDLL:
     """dlopen `path` and attach the prototypes of include/lina_gla.h (raises if a symbol is missing)."""
+    if hip_runtime:
+        _preload_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

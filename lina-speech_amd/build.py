@@ -50,7 +50,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
         bad |= p.returncode != 0
     if bad:
         raise RuntimeError("hipcc failed (see messages above)")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    # Link WITHOUT a DT_NEEDED on a particular libamdhip64: the HIP symbols resolve at load time
+    # against the runtime the host process already holds (torch bundles its own copy with no SONAME;
+    # a second runtime in one process cannot see torch's streams/devices).  See _lib.bind().
+    cmd = [os.environ.get("CXX", "g++"), "-shared", "-fPIC", *objs, "-o", LIB]
     subprocess.run(cmd, check=True)
     if verbose:
         print(f"built {LIB}")

@@ -153,3 +153,115 @@ extern "C" int lina_gla_recurrent_fwd(const void* q, const void* k, const void* 
         return dispatch_dk<bf16_t, float>(Dk, q, k, v, gk, o, h0, ht, B, H, T, Dv, sq, sk, sv, sg, so, scale, stream);
     return fail(LINA_ERR_UNSUPPORTED, "lina_gla_recurrent_fwd: dtype=f32 with bf16 gates is not built");
 }
+
+// ================================================================================================
+// K1d -- decode-step state update, ROW-split: one workgroup owns 64 full state rows of one (b,h),
+// i.e. a CONTIGUOUS 64*Dv*4-byte block of HBM that it streams in once and out once with
+// non-temporal 16-byte accesses (a wave instruction covers whole 1 KiB rows).  The q.S products of
+// the Dk/64 row blocks are written as fp32 partials o_part[Dk/64][B*H][Dv]; the norm-gate kernel K5
+// adds them (n_partial) -- no atomics, deterministic.  T = 1 only.
+// ================================================================================================
+namespace lina {
+
+template <int DV, typename TIO, typename TG>
+__global__ __launch_bounds__(256) void gla_decode_rowsplit_kernel(
+    const TIO* __restrict__ q, const TIO* __restrict__ k, const TIO* __restrict__ v, const TG* __restrict__ gk,
+    float* __restrict__ o_part, float* S, int H, int Dk, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
+    int64_t v_sb, int64_t v_sh, int64_t g_sb, int64_t g_sh, float scale) {
+    constexpr int RB = 64;            // rows per workgroup
+    constexpr int CG = DV / 4;        // lanes per row
+    constexpr int RPI = 256 / CG;     // rows per pass of the workgroup
+    constexpr int NP = RB / RPI;      // float4 per thread
+    __shared__ float s_q[RB], s_k[RB], s_d[RB];
+    __shared__ __attribute__((aligned(16))) float s_v[DV];
+    __shared__ __attribute__((aligned(16))) float s_red[RPI * DV];
+
+    const int tid = threadIdx.x;
+    const int cg = tid % CG, rg = tid / CG;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int r0 = blockIdx.y * RB;
+    float* tile = S + ((int64_t)bh * Dk + r0) * DV + 4 * cg;
+
+    float4 St[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) St[i] = ld_nt4(tile + (int64_t)(rg + RPI * i) * DV);
+
+    if (tid < RB) {
+        const int c = r0 + tid;
+        s_q[tid] = ld(q + b * q_sb + h * q_sh + c) * scale;
+        s_k[tid] = ld(k + b * k_sb + h * k_sh + c);
+        s_d[tid] = expf(ld(gk + b * g_sb + h * g_sh + c));
+    }
+    for (int c = tid; c < DV; c += 256) s_v[c] = ld(v + b * v_sb + h * v_sh + c);
+    __syncthreads();
+
+    const float4 vv = *reinterpret_cast<const float4*>(&s_v[4 * cg]);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int row = rg + RPI * i;
+        const float d = s_d[row], kk = s_k[row], qq = s_q[row];
+        St[i].x = fmaf(St[i].x, d, kk * vv.x);
+        St[i].y = fmaf(St[i].y, d, kk * vv.y);
+        St[i].z = fmaf(St[i].z, d, kk * vv.z);
+        St[i].w = fmaf(St[i].w, d, kk * vv.w);
+        acc.x = fmaf(qq, St[i].x, acc.x);
+        acc.y = fmaf(qq, St[i].y, acc.y);
+        acc.z = fmaf(qq, St[i].z, acc.z);
+        acc.w = fmaf(qq, St[i].w, acc.w);
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) st_nt4(tile + (int64_t)(rg + RPI * i) * DV, St[i]);
+
+    *reinterpret_cast<float4*>(&s_red[rg * DV + 4 * cg]) = acc;
+    __syncthreads();
+    if (tid < CG) {
+        float4 r = *reinterpret_cast<const float4*>(&s_red[4 * tid]);
+#pragma unroll
+        for (int j = 1; j < RPI; ++j) {
+            const float4 t = *reinterpret_cast<const float4*>(&s_red[j * DV + 4 * tid]);
+            r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        }
+        const int64_t BH = gridDim.x;
+        *reinterpret_cast<float4*>(o_part + ((int64_t)blockIdx.y * BH + bh) * DV + 4 * tid) = r;
+    }
+}
+
+template <typename TIO, typename TG>
+static int launch_rowsplit(const void* q, const void* k, const void* v, const void* gk, float* o_part, float* S,
+                           int B, int H, int Dk, int Dv, const int64_t* st, float scale, lina_stream_t stream) {
+    dim3 grid((unsigned)(B * H), (unsigned)(Dk / 64));
+#define LINA_RS_CASE(DVV)                                                                                           \
+    case DVV:                                                                                                       \
+        LINA_LAUNCH((gla_decode_rowsplit_kernel<DVV, TIO, TG>), grid, dim3(256), 0, stream, (const TIO*)q,          \
+                    (const TIO*)k, (const TIO*)v, (const TG*)gk, o_part, S, H, Dk, st[0], st[1], st[2], st[3], st[4], \
+                    st[5], st[6], st[7], scale);                                                                    \
+        break;
+    switch (Dv) {
+        LINA_RS_CASE(64) LINA_RS_CASE(128) LINA_RS_CASE(256)
+        default: return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_update: Dv=%d not in {64,128,256}", Dv);
+    }
+#undef LINA_RS_CASE
+    return check_launch("lina_gla_decode_update");
+}
+
+}  // namespace lina
+
+extern "C" int lina_gla_decode_update(const void* q, const void* k, const void* v, const void* gk, float* o_part,
+                                      float* state, int B, int H, int Dk, int Dv, int64_t q_sb, int64_t q_sh,
+                                      int64_t k_sb, int64_t k_sh, int64_t v_sb, int64_t v_sh, int64_t g_sb,
+                                      int64_t g_sh, int dtype, int g_dtype, float scale, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(q && k && v && gk && o_part && state, "lina_gla_decode_update: null pointer");
+    LINA_REQUIRE(B > 0 && H > 0, "lina_gla_decode_update: B,H must be positive");
+    LINA_REQUIRE(valid_dtype(dtype) && valid_dtype(g_dtype), "lina_gla_decode_update: bad dtype enum");
+    if (Dk <= 0 || Dk % 64 != 0) return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_update: Dk=%d must be a multiple of 64", Dk);
+    const int64_t st[8] = {q_sb, q_sh, k_sb, k_sh, v_sb, v_sh, g_sb, g_sh};
+    if (dtype == LINA_F32 && g_dtype == LINA_F32)
+        return launch_rowsplit<float, float>(q, k, v, gk, o_part, state, B, H, Dk, Dv, st, scale, stream);
+    if (dtype == LINA_BF16 && g_dtype == LINA_F32)
+        return launch_rowsplit<bf16_t, float>(q, k, v, gk, o_part, state, B, H, Dk, Dv, st, scale, stream);
+    if (dtype == LINA_BF16 && g_dtype == LINA_BF16)
+        return launch_rowsplit<bf16_t, bf16_t>(q, k, v, gk, o_part, state, B, H, Dk, Dv, st, scale, stream);
+    return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_update: dtype=f32 with bf16 gates is not built");
+}

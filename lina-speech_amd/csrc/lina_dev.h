@@ -37,4 +37,14 @@ __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c)
                                                    __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// streaming (read-once / write-once) 16-byte accesses: keep the state tile out of the caches
+__device__ __forceinline__ float4 ld_nt4(const float* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st_nt4(float* p, float4 v) {
+    f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+}
+
 }  // namespace lina

@@ -1,14 +1,18 @@
 """DecodeEngine: the single-token step of ``AttentiveGLA.step`` + logits head
 (reference model/gla.py:358-365 driven by model/modeling_lina.py:152-179) restructured for
-MI355X: per GLA block ONE fused projection GEMM (q|k|v|g|gate-low-rank), ONE prologue launch
-(3 conv steps + gate), the in-place recurrent-state kernel K1, the norm-gate kernel K5 reading
-the gate straight out of the projection row, residual-fused GEMMs (``addmm``) and a K-padded
-SwiGLU down-projection that carries its bias as an extra column -- 11 launches per block instead
-of ~30 -- and the whole step captured in a hipGraph (no per-step host work, no host sync).
+MI355X: per GLA block SEVEN launches instead of ~30 --
+  1 fused projection q|k|v|g|gate-low-rank with LayerNorm-1 folded in      (lina_linear_skinny)
+  2 prologue: 3 conv steps + gate                                           (lina_gla_decode_prologue)
+  3 in-place recurrent-state update, row-split, fp32 partial o             (lina_gla_decode_update, K1d)
+  4 partial-sum + RMSNorm (x) swish gate, gate read from the projection row (lina_rmsnorm_gate_fwd, K5)
+  5 o_proj + residual                                                       (lina_linear_skinny)
+  6 up-projection with LayerNorm-2 folded in + bias + SwiGLU                (lina_linear_skinny)
+  7 down-projection (bias as a constant-1 column) + residual                (lina_linear_skinny)
+-- and the whole step captured in a hipGraph (no per-step host work, no host sync).
 
 The text side of the cross-attention is projected once (BlindCrossAttention.prepare).
 State lives in the caller-visible ``Cache`` tensors (reference layout, updated in place).
-GEMMs / LayerNorm / softmax stay on torch-ROCm (hipBLASLt), as SURVEY 8(a) a-7/a-8 prescribes.
+Only the small cross-attention softmax/bmm glue stays on torch-ROCm.
 """
 from __future__ import annotations
 
@@ -23,6 +27,17 @@ from .mixer import GatedLinearAttention
 from .modules import Cache
 
 
+def _fold_layernorm(weight, ln, bias=None):
+    """LN(x) @ W^T == rstd * (x @ W'^T - mu * c1) + c2  with  W' = gamma (*) W  (lina_linear_skinny)."""
+    dt = weight.dtype
+    w_ln = (weight.float() * ln.weight.float()[None, :]).to(dt).contiguous()
+    c1 = w_ln.float().sum(1).contiguous()
+    c2 = weight.float() @ ln.bias.float()
+    if bias is not None:
+        c2 = c2 + bias.float()
+    return w_ln, c1, c2.contiguous()
+
+
 class _BlockPack:
     """Decode-time weights of one MixingBlock(GatedLinearAttention, SwiGLU, LayerNorm)."""
 
@@ -33,13 +48,21 @@ class _BlockPack:
             raise NotImplementedError("DecodeEngine needs use_short_conv=True, conv_size=4, no conv bias, "
                                       "fused swish norm gate (the 'convblind_shortconv' configuration)")
         dt = m.q_proj.weight.dtype
+        dev = m.q_proj.weight.device
+        kq = 32 if dt == torch.bfloat16 else 16                         # k-step of lina_linear_skinny
         self.H, self.Dk, self.Dv, self.Kd, self.Vd = m.num_heads, m.head_qk_dim, m.head_v_dim, m.key_dim, m.value_dim
+        self.d = m.hidden_size
+        if self.d % kq or self.Vd % kq:
+            raise NotImplementedError(f"hidden/value dims must be multiples of {kq}")
         self.R = m.gk_proj[0].weight.shape[0]
         self.normalizer, self.clamp_min = float(m.gate_logit_normalizer), m.clamp_min
         self.eps_gate = m.g_norm_swish_gate.eps
-        # fused projection: rows = q | k | v | g | low-rank gate
-        self.w_in = torch.cat([m.q_proj.weight, m.k_proj.weight, m.v_proj.weight, m.g_proj.weight,
-                               m.gk_proj[0].weight], dim=0).contiguous()
+        self.n1_eps, self.n2_eps = blk.norm1.eps, blk.norm2.eps
+        # fused projection: rows = q | k | v | g | low-rank gate, LayerNorm-1 folded in
+        w_cat = torch.cat([m.q_proj.weight, m.k_proj.weight, m.v_proj.weight, m.g_proj.weight,
+                           m.gk_proj[0].weight], dim=0)
+        self.w_in, self.c1_in, self.c2_in = _fold_layernorm(w_cat, blk.norm1)
+        self.ldz = w_cat.shape[0]
         self.off_q, self.off_k, self.off_v = 0, self.Kd, 2 * self.Kd
         self.off_g, self.off_lr = 2 * self.Kd + self.Vd, 2 * self.Kd + 2 * self.Vd
         self.wq = m.q_conv1d.weight.reshape(self.Kd, 4).contiguous()
@@ -47,22 +70,26 @@ class _BlockPack:
         self.wv = m.v_conv1d.weight.reshape(self.Vd, 4).contiguous()
         self.w2, self.b2 = m.gk_proj[1].weight.contiguous(), m.gk_proj[1].bias.contiguous()
         self.gnw = m.g_norm_swish_gate.weight.contiguous()
-        self.w_o = m.o_proj.weight.t()                                  # [Vd, d] view for addmm
-        self.n1, self.n2 = blk.norm1, blk.norm2
+        self.w_o = m.o_proj.weight.contiguous()                         # [d, Vd]
         c = blk.cmix
         self.hid = c.hidden
-        self.hid_pad = (self.hid + 1 + 7) // 8 * 8                      # +1 bias column, 16-byte rows in bf16
-        self.w_up, self.b_up = c.p_in.weight.t(), c.p_in.bias
-        w_down = torch.zeros(c.p_out.weight.shape[0], self.hid_pad, dtype=dt, device=c.p_out.weight.device)
+        self.hid_pad = (self.hid + 1 + kq - 1) // kq * kq               # + bias column, whole k-steps
+        self.w_up, self.c1_up, self.c2_up = _fold_layernorm(c.p_in.weight, blk.norm2, c.p_in.bias)
+        w_down = torch.zeros(c.p_out.weight.shape[0], self.hid_pad, dtype=dt, device=dev)
         w_down[:, :self.hid] = c.p_out.weight
-        w_down[:, self.hid] = c.p_out.bias
-        self.w_down = w_down.t()                                        # [hid_pad, d]
+        w_down[:, self.hid] = c.p_out.bias                              # multiplied by the constant-1 column
+        self.w_down = w_down
         self.cq, self.ck, self.cv, self.S = state
         if self.S.dtype != torch.float32 or not self.S.is_contiguous():
             raise ValueError("recurrent state must be a contiguous fp32 tensor (see GatedLinearAttention.init_state)")
         B = self.S.shape[0]
-        self.qkv = torch.empty(B, 2 * self.Kd + self.Vd, dtype=dt, device=self.S.device)
-        self.gk = torch.empty(B, self.Kd, dtype=torch.float32, device=self.S.device)
+        self.row_split = self.Dk % 64 == 0 and self.Dv in (64, 128, 256)
+        self.z = torch.empty(B, self.ldz, dtype=dt, device=dev)
+        self.qkv = torch.empty(B, 2 * self.Kd + self.Vd, dtype=dt, device=dev)
+        self.gk = torch.empty(B, self.Kd, dtype=torch.float32, device=dev)
+        self.o_part = torch.empty(max(self.Dk // 64, 1), B, self.H, self.Dv, dtype=torch.float32, device=dev)
+        self.og = torch.empty(B, self.H, self.Dv, dtype=dt, device=dev)
+        self.s = torch.empty(B, self.hid_pad, dtype=dt, device=dev)
 
 
 class DecodeEngine:
@@ -82,54 +109,64 @@ class DecodeEngine:
         self.kk, self.vv = kk.squeeze(1).contiguous(), vv.squeeze(1).contiguous()
         self.pe = pe.squeeze(1).squeeze(0).contiguous()                  # [Ttxt, d]
         self.att_scale = 1.0 / math.sqrt(self.kk.shape[-1])
+        self.ca_qw, self.ca_qb = ca.q.weight.contiguous(), ca.q.bias.float().contiguous()
         hw = model.logits_head.weight
         self.Q, self.L, self.d = hw.shape
-        self.w_head = hw.reshape(self.Q * self.L, self.d).t()
+        self.w_head = hw.reshape(self.Q * self.L, self.d).contiguous()
         self.use_graph = (self.dev.type == "cuda") if use_graph is None else use_graph
         self._graph = None
         self._y_in = torch.zeros(batch_size, self.d, dtype=hw.dtype, device=self.dev)
+        self._x = torch.zeros(batch_size, self.d, dtype=hw.dtype, device=self.dev)     # residual stream
+        self._xp = torch.zeros(batch_size, self.d, dtype=hw.dtype, device=self.dev)    # pos_net stream
         self._logits = None
         self._att = None
 
-    # ------------------------------------------------------------------ one GLA block, T = 1
+    # ------------------------------------------------------------------ one GLA block, T = 1 (7 launches)
     def _block(self, x, P: _BlockPack):
+        """x [B,d] is the residual stream and is UPDATED IN PLACE."""
         B = x.shape[0]
-        h = F.layer_norm(x, (x.shape[-1],), P.n1.weight, P.n1.bias, P.n1.eps)
-        z = h @ P.w_in.t()
+        z = ops.linear_skinny(x, P.w_in, P.c1_in, P.c2_in, out=P.z, ln_dim=P.d, ln_eps=P.n1_eps)
         ops.gla_decode_prologue(z, P.off_q, P.off_k, P.off_v, P.off_lr, P.wq, P.wk, P.wv, P.cq, P.ck, P.cv,
                                 P.w2, P.b2, P.qkv, P.gk, P.normalizer, P.clamp_min)
-        q = P.qkv[:, :P.Kd].view(B, P.H, 1, P.Dk)
-        k = P.qkv[:, P.Kd:2 * P.Kd].view(B, P.H, 1, P.Dk)
-        v = P.qkv[:, 2 * P.Kd:].view(B, P.H, 1, P.Dv)
-        o, _ = ops.fused_recurrent_gla(q, k, v, P.gk.view(B, P.H, 1, P.Dk), initial_state=P.S,
-                                       output_final_state=True, inplace_state=True)
+        q = P.qkv[:, :P.Kd].view(B, P.H, P.Dk)
+        k = P.qkv[:, P.Kd:2 * P.Kd].view(B, P.H, P.Dk)
+        v = P.qkv[:, 2 * P.Kd:].view(B, P.H, P.Dv)
         gate = z[:, P.off_g:P.off_g + P.Vd].view(B, P.H, P.Dv)
-        og = ops.rmsnorm_swish_gate(o.reshape(B, P.H, P.Dv), gate, P.gnw, P.eps_gate)
-        x = torch.addmm(x, og.view(B, P.Vd), P.w_o)
-        h2 = F.layer_norm(x, (x.shape[-1],), P.n2.weight, P.n2.bias, P.n2.eps)
-        u = torch.addmm(P.b_up, h2, P.w_up)
-        s = ops.swiglu(u, P.hid, pad_to=P.hid_pad)
-        return torch.addmm(x, s, P.w_down)
+        if P.row_split:
+            ops.gla_decode_update(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S)
+            ops.rmsnorm_swish_gate(P.o_part, gate, P.gnw, P.eps_gate, n_partial=P.o_part.shape[0], out=P.og)
+        else:
+            o, _ = ops.fused_recurrent_gla(q.unsqueeze(2), k.unsqueeze(2), v.unsqueeze(2),
+                                           P.gk.view(B, P.H, 1, P.Dk), initial_state=P.S,
+                                           output_final_state=True, inplace_state=True)
+            ops.rmsnorm_swish_gate(o.reshape(B, P.H, P.Dv), gate, P.gnw, P.eps_gate, out=P.og)
+        ops.linear_skinny(P.og.view(B, P.Vd), P.w_o, resid=x, out=x)
+        ops.linear_skinny(x, P.w_up, P.c1_up, P.c2_up, out=P.s, swiglu_hidden=P.hid, ln_dim=P.d, ln_eps=P.n2_eps,
+                          n_out=P.hid_pad)
+        ops.linear_skinny(P.s, P.w_down, resid=x, out=x)
+        return x
 
     def _cross(self, x):
         ca = self.ca
-        qq = F.layer_norm(F.linear(x, ca.q.weight, ca.q.bias), (x.shape[-1],), ca.ln_q.weight, ca.ln_q.bias,
-                          ca.ln_q.eps)
+        qq = F.layer_norm(ops.linear_skinny(x, self.ca_qw, c2=self.ca_qb), (x.shape[-1],), ca.ln_q.weight,
+                          ca.ln_q.bias, ca.ln_q.eps)
         att1 = torch.softmax(torch.bmm(self.kk, qq.unsqueeze(-1)).squeeze(-1) * self.att_scale, dim=-1)  # [B,Ttxt]
-        xp = self._block(att1 @ self.pe, self.packs[-1])
+        torch.matmul(att1, self.pe, out=self._xp)
+        xp = self._block(self._xp, self.packs[-1])
         att2 = torch.softmax((xp @ self.pe.t()) * self.att_scale, dim=-1)
         out = torch.bmm(att2.unsqueeze(1), self.vv).squeeze(1)
         return out, torch.stack((att1, att2), dim=1).unsqueeze(2)          # [B,2,1,Ttxt]
 
     def _core(self, y):
-        x = y
+        x = self._x
+        x.copy_(y)
         for P in self.packs[:self.n_enc]:
-            x = self._block(x, P)
+            self._block(x, P)
         v, att = self._cross(x)
-        x = x + v
+        x.add_(v)
         for P in self.packs[self.n_enc:-1]:
-            x = self._block(x, P)
-        logits = (x @ self.w_head).view(self.B, 1, self.Q, self.L)
+            self._block(x, P)
+        logits = ops.linear_skinny(x, self.w_head).view(self.B, 1, self.Q, self.L)
         return logits, att
 
     # ------------------------------------------------------------------ graph capture

@@ -289,3 +289,46 @@ def swiglu(u, hidden: int, out=None, pad_to: Optional[int] = None):
     _check(be.lib.lina_swiglu(_ptr(u2), _ptr(out), u2.shape[0], hidden, u2.stride(0), out.stride(0), _dt(u2),
                               be.stream(u2)))
     return out.view(*u.shape[:-1], ld_y)
+
+
+def gla_decode_update(q, k, v, gk, o_part, state, scale=None):
+    """K1d: in-place decode-step state update, row-split (see lina_gla.h).  q,k,gk [B,H,Dk], v [B,H,Dv]
+    (strided views, last dim contiguous); state fp32 [B,H,Dk,Dv]; o_part fp32 [Dk/64, B, H, Dv]."""
+    be = _BACKEND
+    be.require(q, k, v, gk, o_part, state)
+    B, H, Dk = q.shape
+    Dv = v.shape[-1]
+    if state.dtype != torch.float32 or not state.is_contiguous() or tuple(state.shape) != (B, H, Dk, Dv):
+        raise ValueError("state must be contiguous fp32 [B,H,Dk,Dv]")
+    if o_part.dtype != torch.float32 or not o_part.is_contiguous() or tuple(o_part.shape) != (Dk // 64, B, H, Dv):
+        raise ValueError("o_part must be contiguous fp32 [Dk/64,B,H,Dv]")
+    for t in (q, k, v, gk):
+        if t.stride(-1) != 1:
+            raise ValueError("innermost dimension must be contiguous")
+    _check(be.lib.lina_gla_decode_update(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(o_part), _ptr(state), B, H, Dk, Dv,
+                                         q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                         gk.stride(0), gk.stride(1), _dt(q), _dt(gk),
+                                         float(Dk ** -0.5 if scale is None else scale), be.stream(q)))
+    return o_part
+
+
+def linear_skinny(a, w, c1=None, c2=None, resid=None, out=None, swiglu_hidden: int = 0, ln_dim: int = 0,
+                  ln_eps: float = 1e-5, n_out: Optional[int] = None):
+    """Decode-step projection with fused LayerNorm fold / bias / residual / SwiGLU (see lina_gla.h).
+    a [M,K] (row stride free), w [N_w,K]; returns out [M, n_out] (n_out defaults to N_w, or to the padded
+    SwiGLU width the caller asks for)."""
+    be = _BACKEND
+    be.require(a, w, c1, c2, resid, out)
+    M, K = a.shape
+    if w.shape[1] != K or a.stride(1) != 1 or w.stride(1) != 1:
+        raise ValueError("a [M,K], w [N,K] with contiguous rows expected")
+    N = n_out if n_out is not None else (swiglu_hidden if swiglu_hidden else w.shape[0])
+    if out is None:
+        out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    for t in (c1, c2):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise ValueError("c1/c2 must be contiguous fp32 vectors")
+    _check(be.lib.lina_linear_skinny(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(c1), _ptr(c2), _ptr(resid),
+                                     0 if resid is None else resid.stride(0), _ptr(out), out.stride(0), M, N, K,
+                                     swiglu_hidden, ln_dim, float(ln_eps), _dt(a), be.stream(a)))
+    return out

@@ -41,7 +41,7 @@ class EmuBackend:
 def emu_lib():
     from emu import build_emu
     from lina_speech_amd import _lib
-    return _lib.bind(build_emu.build())
+    return _lib.bind(build_emu.build(), hip_runtime=False)
 
 
 @pytest.fixture()

@@ -162,4 +162,7 @@ static inline f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
     return d;
 }
 
+static inline float4 ld_nt4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+static inline void st_nt4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
 }  // namespace lina

@@ -211,3 +211,64 @@ def check_prologue(dev, B, Kd, Vd, dtype, R=16, W=4, clamp_min=None):
     assert_close(gk, rgk, 1e-5 if dtype == torch.float32 else 2e-2, "prologue gk")
     for c, r, nm in zip((cq, ck, cv), rc, "qkv"):
         assert_close(c, r, 1e-6 if dtype == torch.float32 else 1e-2, f"prologue cache {nm}")
+
+
+def check_decode_update(dev, B, H, Dk, Dv, dtype):
+    """K1d (row-split, partial o) == one oracle step; partials are added by K5's n_partial path."""
+    q, k, v, gk, h0 = make_gla_inputs(B, H, 1, Dk, Dv, dtype, dev, seed=8)
+    ro, rS = oracle_gla(q, k, v, gk, h0)
+    S = h0.clone()
+    o_part = torch.empty(Dk // 64, B, H, Dv, dtype=torch.float32, device=dev)
+    ops.gla_decode_update(q[:, :, 0], k[:, :, 0], v[:, :, 0], gk[:, :, 0].float(), o_part, S)
+    assert_close(S, rS, 1e-5 if dtype == torch.float32 else 1e-2, "K1d state")
+    assert_close(o_part.sum(0), ro[:, :, 0], 1e-5 if dtype == torch.float32 else 1e-2, "K1d sum of partials")
+    # bit-identical state to the V-split kernel K1 (same fma order per element)
+    _, S1 = ops.fused_recurrent_gla(q, k, v, gk.float(), initial_state=h0, output_final_state=True)
+    assert torch.equal(S, S1)
+
+
+def check_linear_skinny(dev, M, N, K, dtype, ln=False, bias=False, resid=False, swiglu=0):
+    g = torch.Generator().manual_seed(9)
+    kq = 32 if dtype == torch.bfloat16 else 16
+    assert K % kq == 0
+    a = (torch.randn(M, K, generator=g) * 1.5 + (0.7 if ln else 0.0)).to(dtype).to(dev)
+    n_w = 2 * swiglu if swiglu else N
+    w = (torch.randn(n_w, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+    b = torch.randn(n_w, generator=g).to(dev) if bias else None
+    r = torch.randn(M, N, generator=g).to(dtype).to(dev) if resid else None
+    a64, w64 = a.cpu().to(F64), w.cpu().to(F64)
+    c1 = c2 = None
+    if ln:
+        gamma = (1 + 0.2 * torch.randn(K, generator=g)).to(dev)
+        beta = (0.3 * torch.randn(K, generator=g)).to(dev)
+        w_ln = (w.float() * gamma[None, :]).to(dtype).contiguous()
+        c1 = w_ln.float().sum(1).contiguous()
+        c2 = (w.float() @ beta).contiguous()
+        if bias:
+            c2 = c2 + b
+        # reference: true LayerNorm in fp64, projected with the SAME rounded folded weight
+        mu = a64.mean(1, keepdim=True)
+        var = a64.var(1, unbiased=False, keepdim=True)
+        ref = ((a64 - mu) / torch.sqrt(var + 1e-5)) @ w_ln.cpu().to(F64).t() + c2.cpu().to(F64)
+        w_used = w_ln
+    else:
+        c2 = b
+        ref = a64 @ w64.t() + (0 if b is None else b.cpu().to(F64))
+        w_used = w
+    n_out = N
+    if swiglu:
+        ga, gb = ref[:, :swiglu], ref[:, swiglu:]
+        ref = torch.zeros(M, N, dtype=F64)
+        ref[:, :swiglu] = F.silu(ga) * gb
+        ref[:, swiglu] = 1.0
+    if resid:
+        ref = ref + r.cpu().to(F64)
+    out = ops.linear_skinny(a, w_used, c1, None if c2 is None else c2.float().contiguous(), resid=r,
+                            swiglu_hidden=swiglu, ln_dim=K if ln else 0, n_out=n_out)
+    assert out.shape == (M, N) and out.dtype == dtype
+    assert_close(out, ref, 2e-5 if dtype == torch.float32 else 2e-2, f"linear_skinny M{M} N{N} K{K}")
+    if resid:   # in-place residual form (out aliases resid)
+        r2 = r.clone()
+        ops.linear_skinny(a, w_used, c1, None if c2 is None else c2.float().contiguous(), resid=r2, out=r2,
+                          swiglu_hidden=swiglu, ln_dim=K if ln else 0, n_out=n_out)
+        assert torch.equal(r2, out)

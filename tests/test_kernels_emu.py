@@ -4,8 +4,8 @@ import pytest
 import torch
 
 from oracle import gla_oracle as O
-from kernel_cases import (check_argmax, check_chunk, check_conv, check_embed, check_prologue, check_recurrent,
-                          check_rmsnorm, check_swiglu)
+from kernel_cases import (check_argmax, check_chunk, check_conv, check_decode_update, check_embed, check_linear_skinny,
+                          check_prologue, check_recurrent, check_rmsnorm, check_swiglu)
 
 DEV = "cpu"
 
@@ -45,3 +45,21 @@ def test_embed_argmax_swiglu_prologue(emu):
     check_swiglu(DEV, rows=3, hidden=85, dtype=torch.float32)
     check_prologue(DEV, B=3, Kd=64, Vd=128, dtype=torch.float32)
     check_prologue(DEV, B=2, Kd=64, Vd=64, dtype=torch.bfloat16)
+
+
+@pytest.mark.parametrize("Dk,Dv,dtype", [(64, 64, torch.float32), (128, 256, torch.float32), (256, 128, torch.bfloat16)])
+def test_decode_update_rowsplit(emu, Dk, Dv, dtype):
+    check_decode_update(DEV, B=2, H=2, Dk=Dk, Dv=Dv, dtype=dtype)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(M=5, N=20, K=64, dtype=torch.float32),
+    dict(M=64, N=48, K=128, dtype=torch.float32, ln=True, bias=True),
+    dict(M=70, N=33, K=96, dtype=torch.float32, resid=True, bias=True),
+    dict(M=9, N=96, K=64, dtype=torch.float32, ln=True, bias=True, swiglu=85),
+    dict(M=7, N=40, K=160, dtype=torch.bfloat16, ln=True),
+    dict(M=66, N=64, K=64, dtype=torch.bfloat16, ln=True, bias=True, swiglu=37),
+    dict(M=3, N=17, K=352, dtype=torch.bfloat16, resid=True),
+])
+def test_linear_skinny(emu, kw):
+    check_linear_skinny(DEV, **kw)

@@ -2,8 +2,9 @@
 import pytest
 import torch
 
-from kernel_cases import (assert_close, check_argmax, check_chunk, check_conv, check_embed, check_prologue,
-                          check_recurrent, check_rmsnorm, check_swiglu, make_gla_inputs, oracle_gla)
+from kernel_cases import (assert_close, check_argmax, check_chunk, check_conv, check_decode_update, check_embed,
+                          check_linear_skinny, check_prologue, check_recurrent, check_rmsnorm, check_swiglu,
+                          make_gla_inputs, oracle_gla)
 from lina_speech_amd import ops
 
 pytestmark = pytest.mark.gpu
@@ -49,6 +50,27 @@ def test_embed_argmax_swiglu_prologue(hip):
         check_swiglu(DEV, rows=64, hidden=1365, dtype=dt)
         check_prologue(DEV, B=64, Kd=1024, Vd=1024, dtype=dt)
     check_prologue(DEV, B=3, Kd=64, Vd=128, dtype=torch.float32, clamp_min=-0.05)
+
+
+@pytest.mark.parametrize("Dk,Dv,dtype", [(64, 64, torch.float32), (128, 256, torch.float32),
+                                         (256, 256, torch.float32), (256, 256, torch.bfloat16)])
+def test_decode_update_rowsplit(hip, Dk, Dv, dtype):
+    check_decode_update(DEV, B=5, H=4, Dk=Dk, Dv=Dv, dtype=dtype)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(M=5, N=20, K=64, dtype=torch.float32),
+    dict(M=64, N=4112, K=1024, dtype=torch.float32, ln=True),
+    dict(M=64, N=4112, K=1024, dtype=torch.bfloat16, ln=True),
+    dict(M=70, N=1024, K=1024, dtype=torch.bfloat16, resid=True),
+    dict(M=64, N=1376, K=1024, dtype=torch.bfloat16, ln=True, bias=True, swiglu=1365),
+    dict(M=64, N=1376, K=1024, dtype=torch.float32, ln=True, bias=True, swiglu=1365),
+    dict(M=64, N=1024, K=1376, dtype=torch.bfloat16, resid=True),
+    dict(M=64, N=4099, K=1024, dtype=torch.bfloat16),
+    dict(M=130, N=100, K=96, dtype=torch.float32, resid=True, bias=True),
+])
+def test_linear_skinny(hip, kw):
+    check_linear_skinny(DEV, **kw)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ def _setup_emu():
     from conftest import EmuBackend
     from emu import build_emu
     from lina_speech_amd import _lib, ops
-    ops.set_backend(EmuBackend(_lib.bind(build_emu.build())))
+    ops.set_backend(EmuBackend(_lib.bind(build_emu.build(), hip_runtime=False)))
 
 
 def _decode(rows_lo, rows_hi, n_steps):
