@@ -72,7 +72,7 @@ def measure_k1(engine, reps=20):
     return ev0.elapsed_time(ev1) * 1e-3 / (reps * len(packs))
 
 
-def measure_chunk(dev, B=16, H=4, T=4096, Dk=256, Dv=256, reps=3):
+def measure_chunk(dev, B=64, H=4, T=4096, Dk=256, Dv=256, reps=3):
     """K2 at the training shape (config 5: seqlen 4096), bf16 I/O."""
     from lina_speech_amd import ops
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -91,7 +91,7 @@ def measure_chunk(dev, B=16, H=4, T=4096, Dk=256, Dv=256, reps=3):
     dt = ev0.elapsed_time(ev1) * 1e-3 / reps
     nbytes = B * H * T * 2 * (3 * Dk + 2 * Dv)                       # e*(3Dk+2Dv) per (row,head,token)
     flops = B * H * T * (2 * 64 * (Dk + Dv) + 4 * Dk * Dv)            # nominal C=64 count of SURVEY 8(d)
-    return {"kernel": "lina::gla_chunk_bf16_kernel<256>", "shape": {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv},
+    return {"kernel": "lina::gla_chunk_bf16_h256_kernel", "shape": {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv},
             "dtype": "bf16", "ms": dt * 1e3, "bound": "hbm", "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS, "tflops": flops / dt / 1e12,
             "tokens_per_s": B * T / dt}

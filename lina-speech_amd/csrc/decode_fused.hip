@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void decode_prologue_kernel(
     } else if (idx < nconv + Kd) {
         const int c = idx - nconv;
         float acc = ld(b2 + c);
-        if ((R & 3) == 0 && (off_lr & 3) == 0) {   // 8/16-byte loads of the rank-R row and activations
+        if ((R & 3) == 0 && (off_lr & 3) == 0 && (ldz & 3) == 0) {   // 8/16-byte loads of the rank-R row and activations
             for (int r = 0; r < R; r += 4) {
                 const float4 zv = ld4(zb + off_lr + r), wv4 = ld4(w2 + (int64_t)c * R + r);
                 acc = fmaf(zv.x, wv4.x, acc); acc = fmaf(zv.y, wv4.y, acc);

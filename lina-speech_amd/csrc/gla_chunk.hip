@@ -33,6 +33,11 @@ constexpr float kMaxDecay = 60.0f;
 
 int check_gla_args(const char* fn, const void* q, const void* k, const void* v, const void* gk, const void* o,
                    int B, int H, int T, int Dk, int Dv, int dtype, int g_dtype);
+// gla_chunk_full.hip: bf16, Dk = Dv = 256, one workgroup per head
+int launch_chunk_full(const void* q, const void* k, const void* v, const void* gk, void* o, const float* h0,
+                      float* ht, int B, int H, int T, int Dk, int Dv, lina_bht_strides sq, lina_bht_strides sk,
+                      lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides so, int dtype, int g_dtype,
+                      float scale, lina_stream_t stream, bool* taken);
 
 // ----------------------------------------------------------------------------------------------
 // phase A helper: scan the gates of one channel, return the chunk length this channel allows
@@ -388,6 +393,10 @@ extern "C" int lina_gla_chunk_fwd(const void* q, const void* k, const void* v, c
     using namespace lina;
     int rc = check_gla_args("lina_gla_chunk_fwd", q, k, v, gk, o, B, H, T, Dk, Dv, dtype, g_dtype);
     if (rc) return rc;
+    bool taken = false;
+    rc = launch_chunk_full(q, k, v, gk, o, h0, ht, B, H, T, Dk, Dv, sq, sk, sv, sg, so, dtype, g_dtype, scale, stream,
+                           &taken);
+    if (taken) return rc;
     // v rows are read 4 elements at a time
     LINA_REQUIRE(sv.t % 4 == 0 && sv.b % 4 == 0 && sv.h % 4 == 0, "lina_gla_chunk_fwd: v strides must be multiples of 4");
     switch (Dk) {

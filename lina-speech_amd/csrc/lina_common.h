@@ -48,8 +48,8 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     uint2 u;
-    u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-    u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    u.x = pack_bf16x2(v.x, v.y);
+    u.y = pack_bf16x2(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = u;
 }
 

@@ -14,14 +14,17 @@
 namespace lina {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((uint32_t)h << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f) {  // round-to-nearest-even
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even, via the native __bf16 conversion (v_cvt_pk_bf16_f32 on gfx950;
+// branch-free, NaN stays NaN)
+__device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
@@ -35,6 +38,22 @@ __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c)
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                    __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+//   v_mfma_f32_32x32x16_bf16 : A[i=l&31][k=8*(l>>5)+j]  B[k=8*(l>>5)+j][n=l&31]  (j<8)
+//   C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5), reg < 16
+__device__ __forceinline__ f32x16 mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// Asynchronous 16-byte-per-lane global -> LDS copy (global_load_lds_dwordx4): the LDS destination is
+// `lds_wave_base + lane*16` (wave-uniform base), the global source is per lane.  Completion: vmcnt;
+// hipcc drains it at the next __syncthreads() (a pending LDS write), which is what the kernels rely on.
+__device__ __forceinline__ void dma16_to_lds(const void* gsrc_lane, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 // streaming (read-once / write-once) 16-byte accesses: keep the state tile out of the caches

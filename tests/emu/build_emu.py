@@ -14,7 +14,7 @@ CSRC = os.path.join(ROOT, "lina-speech_amd", "csrc")
 OUT = os.path.join(ROOT, "tests", "_emu_build")
 LIB = os.path.join(OUT, "liblina_gla_emu.so")
 CXX = os.environ.get("CXX", "g++")
-FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasing", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
          "-Wno-unknown-pragmas", "-Wno-attributes", "-Wno-sign-compare"]
 
 

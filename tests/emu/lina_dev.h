@@ -87,6 +87,11 @@ struct f32x4 {
     float& operator[](int i) { return v[i]; }
     const float& operator[](int i) const { return v[i]; }
 };
+struct f32x16 {
+    float v[16];
+    float& operator[](int i) { return v[i]; }
+    const float& operator[](int i) const { return v[i]; }
+};
 struct bf16x8 {
     short v[8];
     short& operator[](int i) { return v[i]; }
@@ -103,6 +108,8 @@ static inline unsigned short f2bf(float f) {  // round-to-nearest-even, NaN kept
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
+
+static inline uint32_t pack_bf16x2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
 static inline float shfl_xor(float v, int mask) {
     uint32_t mine = f2u(v), tab[64];
@@ -160,6 +167,38 @@ static inline f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
         d[r] = acc;
     }
     return d;
+}
+
+// v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8*(l>>5)+j], B[k=8*(l>>5)+j][n=l&31];
+// D: col=l&31, row=(reg&3)+8*(reg>>2)+4*(l>>5).
+static inline f32x16 mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    uint32_t mine[8], tab[512];
+    for (int j = 0; j < 4; ++j) {
+        mine[j] = (uint32_t)(uint16_t)a[2 * j] | ((uint32_t)(uint16_t)a[2 * j + 1] << 16);
+        mine[4 + j] = (uint32_t)(uint16_t)b[2 * j] | ((uint32_t)(uint16_t)b[2 * j + 1] << 16);
+    }
+    lina_emu::wave_exchange(mine, 8, tab);
+    const int l = lina_emu::cur_lane(), col = l & 31, hi = l >> 5;
+    auto A = [&](int i, int k) {
+        const uint32_t w = tab[(i + 32 * (k >> 3)) * 8 + ((k & 7) >> 1)];
+        return bf2f((unsigned short)((k & 1) ? (w >> 16) : (w & 0xffff)));
+    };
+    auto Bm = [&](int k, int n) {
+        const uint32_t w = tab[(n + 32 * (k >> 3)) * 8 + 4 + ((k & 7) >> 1)];
+        return bf2f((unsigned short)((k & 1) ? (w >> 16) : (w & 0xffff)));
+    };
+    f32x16 d;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) acc = fmaf(A(row, k), Bm(k, col), acc);
+        d[r] = acc;
+    }
+    return d;
+}
+
+static inline void dma16_to_lds(const void* gsrc_lane, void* lds_wave_base) {
+    memcpy((unsigned char*)lds_wave_base + 16 * lina_emu::cur_lane(), gsrc_lane, 16);
 }
 
 static inline float4 ld_nt4(const float* p) { return *reinterpret_cast<const float4*>(p); }

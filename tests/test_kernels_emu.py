@@ -23,6 +23,11 @@ def test_chunk(emu, Dk, Dv, T, dtype):
     check_chunk(DEV, B=1, H=2, T=T, Dk=Dk, Dv=Dv, dtype=dtype)
 
 
+@pytest.mark.parametrize("T,resets", [(5, False), (40, False), (70, True)])
+def test_chunk_full_head_kernel(emu, T, resets):
+    check_chunk(DEV, B=1, H=1, T=T, Dk=256, Dv=256, dtype=torch.bfloat16, resets=resets)
+
+
 def test_chunk_reset_gates(emu):
     # adversarial gates: runs of -20 resets force the adaptive chunk cut
     check_chunk(DEV, B=1, H=1, T=40, Dk=64, Dv=64, dtype=torch.float32, resets=True)

@@ -31,6 +31,12 @@ def test_chunk_reset_gates(hip, dtype):
     check_chunk(DEV, B=2, H=2, T=70, Dk=128, Dv=64, dtype=dtype, resets=True)
 
 
+@pytest.mark.parametrize("T,resets", [(5, False), (32, False), (33, False), (200, False), (100, True)])
+def test_chunk_full_head_kernel(hip, T, resets):
+    # bf16, Dk = Dv = 256: the one-workgroup-per-head kernel (gla_chunk_full.hip), incl. the adaptive cut
+    check_chunk(DEV, B=3, H=4, T=T, Dk=256, Dv=256, dtype=torch.bfloat16, resets=resets)
+
+
 @pytest.mark.parametrize("T,W,dtype", [(1, 4, torch.float32), (3, 4, torch.float32), (37, 4, torch.float32),
                                        (300, 4, torch.float32), (19, 3, torch.bfloat16), (64, 4, torch.bfloat16)])
 def test_conv(hip, T, W, dtype):
