@@ -38,18 +38,10 @@ __device__ __forceinline__ void unpack8(const uint4 u, float (&f)[8]) {
     f[6] = bf2f((bf16_t)(u.w & 0xffff)); f[7] = bf2f((bf16_t)(u.w >> 16));
 }
 __device__ __forceinline__ bf16x8 frag16(const bf16_t* p) {   // one 16-byte LDS read
-    const uint4 u = *reinterpret_cast<const uint4*>(p);
-    bf16x8 r;
-    r[0] = (short)(u.x & 0xffff); r[1] = (short)(u.x >> 16); r[2] = (short)(u.y & 0xffff); r[3] = (short)(u.y >> 16);
-    r[4] = (short)(u.z & 0xffff); r[5] = (short)(u.z >> 16); r[6] = (short)(u.w & 0xffff); r[7] = (short)(u.w >> 16);
-    return r;
+    return as_bf16x8(*reinterpret_cast<const uint4*>(p));
 }
 __device__ __forceinline__ bf16x8 frag8x2(const bf16_t* p_lo, const bf16_t* p_hi) {   // two 8-byte LDS reads
-    const uint2 a = *reinterpret_cast<const uint2*>(p_lo), b = *reinterpret_cast<const uint2*>(p_hi);
-    bf16x8 r;
-    r[0] = (short)(a.x & 0xffff); r[1] = (short)(a.x >> 16); r[2] = (short)(a.y & 0xffff); r[3] = (short)(a.y >> 16);
-    r[4] = (short)(b.x & 0xffff); r[5] = (short)(b.x >> 16); r[6] = (short)(b.y & 0xffff); r[7] = (short)(b.y >> 16);
-    return r;
+    return as_bf16x8(*reinterpret_cast<const uint2*>(p_lo), *reinterpret_cast<const uint2*>(p_hi));
 }
 
 __global__ __launch_bounds__(512) void gla_chunk_bf16_h256_kernel(
@@ -71,9 +63,9 @@ __global__ __launch_bounds__(512) void gla_chunk_bf16_h256_kernel(
     float* s_tot = s_ot;                                  // [16][DK] fp32   (phase A)
     bf16_t* s_o = reinterpret_cast<bf16_t*>(s_ot);        // [C][SQ] bf16    (phase B)
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int li = lane & 31, hi = lane >> 5;
-    const int co = tid & 31, rg = tid >> 5;
+    int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int li = lane & 31, hi = lane >> 5;
+    int co = tid & 31, rg = tid >> 5;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
 
     // ---- state: wave w owns columns [32w, 32w+32), tile p = rows [32p, 32p+32) ----
@@ -101,9 +93,9 @@ __global__ __launch_bounds__(512) void gla_chunk_bf16_h256_kernel(
 
     // wave w DMAs rows 4w..4w+3 of each raw tile: one instruction = 2 rows x 512 B, 16 B per lane.
     // Rows past the end of the sequence re-read row T-1 (always mapped); phase A masks them.
-    auto dma_chunk = [&](int t_first) {
+    auto dma_chunk = [&](int t_first, int a_lo, int a_hi) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = a_lo; a < a_hi; ++a)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int row = 4 * w + 2 * u;
@@ -121,83 +113,86 @@ __global__ __launch_bounds__(512) void gla_chunk_bf16_h256_kernel(
             float f[8];
             unsigned pk[8];
             unpack8(*reinterpret_cast<const uint4*>(&s_raw[0][row * DK + 8 * co]), f);
+            float e[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) pk[c] = f2bf(valid ? f[c] * scale * __expf(bc[rr][c]) : 0.0f);
+            for (int c = 0; c < 8; ++c) {
+                e[c] = __expf(bc[rr][c]);
+                pk[c] = f2bf(valid ? f[c] * scale * e[c] : 0.0f);
+            }
             *reinterpret_cast<uint4*>(&s_q[row * SQ + 8 * co]) =
                 make_uint4(pk[0] | (pk[1] << 16), pk[2] | (pk[3] << 16), pk[4] | (pk[5] << 16), pk[6] | (pk[7] << 16));
             unpack8(*reinterpret_cast<const uint4*>(&s_raw[1][row * DK + 8 * co]), f);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                pk[c] = f2bf(valid ? f[c] * __expf(-bc[rr][c]) : 0.0f);
-                s_kT[(8 * co + c) * ST + row] = (bf16_t)pk[c];
+                pk[c] = f2bf(valid ? __fdividef(f[c], e[c]) : 0.0f);
             }
             *reinterpret_cast<uint4*>(&s_k[row * SQ + 8 * co]) =
                 make_uint4(pk[0] | (pk[1] << 16), pk[2] | (pk[3] << 16), pk[4] | (pk[5] << 16), pk[6] | (pk[7] << 16));
-            const uint4 rv = *reinterpret_cast<const uint4*>(&s_raw[3][row * DK + 8 * co]);
-            const unsigned vw[4] = {rv.x, rv.y, rv.z, rv.w};
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const unsigned bits = (c & 1) ? (vw[c >> 1] >> 16) : (vw[c >> 1] & 0xffffu);
-                s_vT[(8 * co + c) * ST + row] = (bf16_t)(valid ? bits : 0u);
-            }
             if (row == nv - 1) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) s_dec[8 * co + c] = __expf(bc[rr][c]);
+                for (int c = 0; c < 8; ++c) s_dec[8 * co + c] = e[c];
             }
         }
     };
 
-    dma_chunk(0);
+    // this thread's 2 rows x 8 channels of clamped gates, summed down the 2 rows (rows >= nrem count as 0)
+    auto local_gates = [&](float (&bc)[2][8], int nrem) {
+        float g0[8], g1[8];
+        unpack8(*reinterpret_cast<const uint4*>(&s_raw[2][(2 * rg) * DK + 8 * co]), g0);
+        unpack8(*reinterpret_cast<const uint4*>(&s_raw[2][(2 * rg + 1) * DK + 8 * co]), g1);
+        const bool in0 = 2 * rg < nrem, in1 = 2 * rg + 1 < nrem;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            bc[0][c] = in0 ? fmaxf(g0[c], -kFullMaxDecay) : 0.0f;
+            bc[1][c] = bc[0][c] + (in1 ? fmaxf(g1[c], -kFullMaxDecay) : 0.0f);
+        }
+    };
+    // add the exclusive prefix over the 16 row groups (from s_tot); true if the chunk's total decay is too large
+    auto add_prefix = [&](float (&bc)[2][8]) {
+        float pre[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pre[c] = 0.f;
+#pragma unroll 1
+        for (int r = 0; r < rg; ++r) {     // rg takes two values per wave: at most one partially masked trip
+            const float4 x0 = *reinterpret_cast<const float4*>(&s_tot[r * DK + 8 * co]);
+            const float4 x1 = *reinterpret_cast<const float4*>(&s_tot[r * DK + 8 * co + 4]);
+            pre[0] += x0.x; pre[1] += x0.y; pre[2] += x0.z; pre[3] += x0.w;
+            pre[4] += x1.x; pre[5] += x1.y; pre[6] += x1.z; pre[7] += x1.w;
+        }
+        bool viol = false;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            bc[0][c] += pre[c];
+            bc[1][c] += pre[c];
+            viol |= (-bc[1][c] > kFullMaxDecay);   // b is monotone: the last row group sees the chunk total
+        }
+        return viol;
+    };
+
+    dma_chunk(0, 0, 4);
     __syncthreads();   // DMA of chunk 0 landed (hipcc drains vmcnt before the barrier)
     int t0 = 0;
     while (t0 < T) {
+        // keep the per-lane index arithmetic INSIDE the loop: hoisted, it would need ~100 more VGPRs than the
+        // 128 the state leaves free and be spilled to scratch
+        opaque(tid); opaque(lane); opaque(li); opaque(hi); opaque(co); opaque(rg);
         const int nrem = T - t0;
         // ---------------- phase A: gate scan ----------------
         float bc[2][8];
-        {
-            float g0[8], g1[8];
-            unpack8(*reinterpret_cast<const uint4*>(&s_raw[2][(2 * rg) * DK + 8 * co]), g0);
-            unpack8(*reinterpret_cast<const uint4*>(&s_raw[2][(2 * rg + 1) * DK + 8 * co]), g1);
-            const bool in0 = 2 * rg < nrem, in1 = 2 * rg + 1 < nrem;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                bc[0][c] = in0 ? fmaxf(g0[c], -kFullMaxDecay) : 0.0f;
-                bc[1][c] = bc[0][c] + (in1 ? fmaxf(g1[c], -kFullMaxDecay) : 0.0f);
-            }
-        }
+        local_gates(bc, nrem);
         *reinterpret_cast<float4*>(&s_tot[rg * DK + 8 * co]) = make_float4(bc[1][0], bc[1][1], bc[1][2], bc[1][3]);
         *reinterpret_cast<float4*>(&s_tot[rg * DK + 8 * co + 4]) = make_float4(bc[1][4], bc[1][5], bc[1][6], bc[1][7]);
         if (tid == 0) s_flag = 0;
         __syncthreads();   // (1)
-        {
-            float pre[8], tot[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { pre[c] = 0.f; tot[c] = 0.f; }
-#pragma unroll 4
-            for (int r = 0; r < 16; ++r) {
-                const float4 x0 = *reinterpret_cast<const float4*>(&s_tot[r * DK + 8 * co]);
-                const float4 x1 = *reinterpret_cast<const float4*>(&s_tot[r * DK + 8 * co + 4]);
-                const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    tot[c] += xs[c];
-                    pre[c] += (r < rg) ? xs[c] : 0.0f;
-                }
-            }
-            bool viol = false;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                viol |= (-tot[c] > kFullMaxDecay);
-                bc[0][c] += pre[c];
-                bc[1][c] += pre[c];
-            }
-            if (viol) s_flag = 1;
-        }
+        if (add_prefix(bc)) s_flag = 1;
         int n = min(C, nrem);
         write_tiles(bc, n);
-        __syncthreads();   // (2) operand tiles ready; s_tot dead; raw tiles consumed
+        __syncthreads();   // (2) operand tiles ready; raw q,k,g consumed
         if (s_flag) {
             // ---- rare: the decay inside this chunk exceeds e^-60 -> cut the chunk at the first such row ----
+            float bc[2][8];                 // recomputed (s_tot is intact until the o tile is staged)
+            local_gates(bc, nrem);
+            add_prefix(bc);
             int nc = C;
 #pragma unroll
             for (int rr = 1; rr >= 0; --rr) {
@@ -217,36 +212,57 @@ __global__ __launch_bounds__(512) void gla_chunk_bf16_h256_kernel(
             write_tiles(bc, n);
             __syncthreads();
         }
-        if (t0 + n < T) dma_chunk(t0 + n);   // next chunk's raw tiles fly under phase B
+        if (t0 + n < T) dma_chunk(t0 + n, 0, 3);   // next chunk's raw q,k,g fly under phase B (v: see below)
+
+        // ---------------- transposed operands: k~^T[c][t], v^T[col][t] ----------------
+        // thread (ch = tid & 255, half = tid >> 8) gathers 16 tokens of one channel/column (2-byte LDS reads,
+        // lanes along ch: conflict-free) and writes them as two 16-byte pieces (row stride 80 B: conflict-free)
+        {
+            const int ch = tid & 255, r0 = 16 * (tid >> 8);
+            unsigned w8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                w8[j] = (unsigned)s_k[(r0 + 2 * j) * SQ + ch] | ((unsigned)s_k[(r0 + 2 * j + 1) * SQ + ch] << 16);
+            *reinterpret_cast<uint4*>(&s_kT[ch * ST + r0]) = make_uint4(w8[0], w8[1], w8[2], w8[3]);
+            *reinterpret_cast<uint4*>(&s_kT[ch * ST + r0 + 8]) = make_uint4(w8[4], w8[5], w8[6], w8[7]);
+            cfence();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ra = r0 + 2 * j, rb = ra + 1;
+                const unsigned va = ra < n ? (unsigned)s_raw[3][ra * DK + ch] : 0u;
+                const unsigned vb_ = rb < n ? (unsigned)s_raw[3][rb * DK + ch] : 0u;
+                w8[j] = va | (vb_ << 16);
+            }
+            *reinterpret_cast<uint4*>(&s_vT[ch * ST + r0]) = make_uint4(w8[0], w8[1], w8[2], w8[3]);
+            *reinterpret_cast<uint4*>(&s_vT[ch * ST + r0 + 8]) = make_uint4(w8[4], w8[5], w8[6], w8[7]);
+            cfence();
+        }
 
         // ---------------- phase B ----------------
         f32x16 acc;
+        bf16x8 afr[2];   // mask(A)[t = li][k-slots] as the A operand of (3)
         {
-            // (2) A^T[s][t] = k~_s . q~_t  (lane t = li holds A[t][drow(reg,hi)])
             f32x16 at;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { at[r] = 0.0f; acc[r] = 0.0f; }
-#pragma unroll 4
+            // (2) A^T[s][t] = k~_s . q~_t  (lane t = li holds A[t][drow(reg,hi)])
+#pragma unroll
             for (int ks = 0; ks < DK / 16; ++ks) {
                 const int cc = 16 * ks + 8 * hi;
                 at = mfma_bf16_32x32x16(frag16(&s_k[li * SQ + cc]), frag16(&s_q[li * SQ + cc]), at);
+                if ((ks & 1) == 1) cfence();
             }
-            // (3) o = mask(A) . v ; v fragments in the same token order as the C/D rows
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 a;
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int stok = drow(8 * s2 + j, hi);
-                    a[j] = (short)f2bf((stok <= li) ? at[8 * s2 + j] : 0.0f);
+                    afr[s2][j] = (short)f2bf((stok <= li) ? at[8 * s2 + j] : 0.0f);
                 }
-                const bf16_t* vp = &s_vT[(32 * w + li) * ST + 16 * s2 + 4 * hi];
-                acc = mfma_bf16_32x32x16(a, frag8x2(vp, vp + 8), acc);
-            }
         }
-        // (1) o += q~ . S_old   (B operand = this wave's state tiles, converted to bf16 in registers)
+        // (1) o = q~ . S_old   (B operand = this wave's state tiles, converted to bf16 in registers)
 #pragma unroll
-        for (int p = 0; p < 8; ++p)
+        for (int p = 0; p < 8; ++p) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16_t* qp = &s_q[li * SQ + 32 * p + 16 * s + 4 * hi];
@@ -256,6 +272,16 @@ __global__ __launch_bounds__(512) void gla_chunk_bf16_h256_kernel(
                 for (int j = 0; j < 8; ++j) bb[j] = (short)f2bf(S[p][8 * s + j]);
                 acc = mfma_bf16_32x32x16(a, bb, acc);
             }
+            cfence();
+        }
+        __syncthreads();   // (2b) k~^T / v^T complete; raw v consumed
+        if (t0 + n < T) dma_chunk(t0 + n, 3, 4);
+        // (3) o += mask(A) . v ; v fragments in the same token order as the C/D rows
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16_t* vp = &s_vT[(32 * w + li) * ST + 16 * s2 + 4 * hi];
+            acc = mfma_bf16_32x32x16(afr[s2], frag8x2(vp, vp + 8), acc);
+        }
         // stage o (this wave's 32 x 32 block)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_o[drow(r, hi) * SQ + 32 * w + li] = f2bf(acc[r]);
@@ -275,6 +301,7 @@ __global__ __launch_bounds__(512) void gla_chunk_bf16_h256_kernel(
                     S[p][4 * r4 + 0] *= d.x; S[p][4 * r4 + 1] *= d.y;
                     S[p][4 * r4 + 2] *= d.z; S[p][4 * r4 + 3] *= d.w;
                 }
+                cfence();
             }
         }
         __syncthreads();   // (3) o tile complete, operand tiles dead, next chunk's DMA landed

@@ -56,6 +56,21 @@ __device__ __forceinline__ void dma16_to_lds(const void* gsrc_lane, void* lds_wa
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// reinterpret 16 bytes of packed bf16 as an MFMA operand (no instructions)
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 u) { return __builtin_bit_cast(bf16x8, u); }
+__device__ __forceinline__ bf16x8 as_bf16x8(uint2 lo, uint2 hi) {
+    return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+
+// compiler-only fence: memory operations are not moved across it (keeps LDS-read hoisting, and with it
+// register pressure, bounded in the fully unrolled MFMA loops)
+__device__ __forceinline__ void cfence() { asm volatile("" ::: "memory"); }
+
+// make a per-lane value opaque to the optimiser (same value): expressions built from it are not
+// hoisted out of a loop, so loop-invariant address arithmetic is recomputed instead of living in
+// (and being spilled from) VGPRs across the whole loop
+__device__ __forceinline__ void opaque(int& x) { asm volatile("" : "+v"(x)); }
+
 // streaming (read-once / write-once) 16-byte accesses: keep the state tile out of the caches
 __device__ __forceinline__ float4 ld_nt4(const float* p) {
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));

@@ -201,6 +201,13 @@ static inline void dma16_to_lds(const void* gsrc_lane, void* lds_wave_base) {
     memcpy((unsigned char*)lds_wave_base + 16 * lina_emu::cur_lane(), gsrc_lane, 16);
 }
 
+static inline bf16x8 as_bf16x8(uint4 u) { bf16x8 r; memcpy(&r, &u, 16); return r; }
+static inline bf16x8 as_bf16x8(uint2 lo, uint2 hi) { bf16x8 r; memcpy(&r.v[0], &lo, 8); memcpy(&r.v[4], &hi, 8); return r; }
+
+static inline void cfence() { asm volatile("" ::: "memory"); }
+
+static inline void opaque(int& x) { asm volatile("" : "+r"(x)); }
+
 static inline float4 ld_nt4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static inline void st_nt4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
