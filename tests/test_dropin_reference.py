@@ -1,0 +1,51 @@
+"""Drop-in proof at the operator boundary: the reference's UNMODIFIED model/gla.py + modeling_lina.py,
+with lina_speech_amd.fla_compat serving the fla.* names, run on this package's kernels (through the CPU
+emulator here) and reproduce the goldens that were captured with the oracle behind the same names.
+Runs only where /root/reference exists (the build container); nothing of it is copied."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import sys, types, torch, numpy as np
+sys.path.insert(0, "%(root)s"); sys.path.insert(0, "%(root)s/tests"); sys.path.insert(0, "%(ref)s")
+from conftest import EmuBackend
+from emu import build_emu
+from lina_speech_amd import _lib, ops, fla_compat
+ops.set_backend(EmuBackend(_lib.bind(build_emu.build(), hip_runtime=False)))
+fla_compat.install(override=True)
+rot = types.ModuleType("rotary_embedding_torch")       # import-time name only (rotary=False)
+rot.RotaryEmbedding = rot.apply_rotary_emb = object
+sys.modules["rotary_embedding_torch"] = rot
+from model.gla import AttentiveGLA                      # reference code
+from model.encoder import TextEncoder
+from model.modeling_lina import LinaModel
+from model_cases import golden_state_dict, load_golden
+g = load_golden("lina_d64.npz")
+rnn = AttentiveGLA(d_model=64, n_layer=1, heads=1, blind=True, use_short_conv=True, expand_k=1.0, expand_v=1.0,
+                   pos_type="convolutional")
+model = LinaModel(rnn, d_model=64, n_quant=1, n_codebook=253, n_special_token_in=3, n_special_token_out=3,
+                  n_txt_vocab=256, txt_encoder=TextEncoder(64, 1, n_layers=1, dropout=0.0, rotary=False)).eval()
+model.load_state_dict(golden_state_dict(g), strict=True)
+with torch.no_grad():
+    t = lambda k: torch.from_numpy(g[k])
+    logits, loss, att, _, _ = model(t("x"), t("y"), t("encoder_mask"), t("crossatt_mask"), logits_mask=t("logits_mask"))
+    err = float((logits - t("fwd_logits")).abs().max() / t("fwd_logits").abs().max())
+    assert err < 2e-4, err
+    qs, atts, stops, cuts = model.generate_batch(t("gen_x"), batch_size=3, max_seqlen=12, k=1, first_greedy_quant=0,
+                                                 force_max_seqlen=True)
+    assert torch.equal(qs, t("gen_qs")), "reference generate_batch on lina_speech_amd ops: tokens differ"
+print("DROPIN_OK", err)
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "model")), reason="reference tree not present")
+def test_reference_modules_run_on_our_operators():
+    out = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT, "ref": REF}], capture_output=True, text=True,
+                         timeout=600)
+    assert "DROPIN_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
