@@ -174,6 +174,21 @@ int lina_linear_skinny(const void* A, int64_t lda, const void* W, int64_t ldw,
                        void* out, int64_t ldo, int M, int N, int K,
                        int swiglu_hidden, int ln_dim, float ln_eps, int dtype, lina_stream_t stream);
 
+/* The whole input side of one GLA mixer at T = 1 in ONE launch: LayerNorm-1 (folded as in
+ * lina_linear_skinny) -> fused projection -> q,k,v conv step (+SiLU, caches rolled in place) | g | gate
+ * (rank-16 up-projection + bias + logsigmoid / normalizer [+clamp]).  Equivalent to
+ * lina_linear_skinny(ln) + lina_gla_decode_prologue without the intermediate row.
+ *   x: [B,K];  w_in: [2Kd+2Vd+R, K] rows q|k|v|g|low-rank, LayerNorm gamma folded in; c1,c2 fp32 (same length);
+ *   outputs qkv [B,2Kd+Vd], g_out [B,Vd] (model dtype), gk fp32 [B,Kd].  W = 4, R = 16, Kd,Vd % 16 == 0.
+ * Replaces reference model/base_blocks.py:66 (norm1) + model/gla.py:158-163,174-180,216 at T = 1. */
+int lina_gla_decode_inproj(const void* x, int64_t ldx, const void* w_in, int64_t ldw,
+                           const float* c1, const float* c2,
+                           const void* wq, const void* wk, const void* wv,
+                           void* cq, void* ck, void* cv, const void* w2, const void* b2,
+                           void* qkv, void* g_out, float* gk,
+                           int B, int K, int Kd, int Vd, int W, int R,
+                           float ln_eps, float normalizer, float clamp_min, int dtype, lina_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

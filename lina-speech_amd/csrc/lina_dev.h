@@ -62,6 +62,12 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint2 lo, uint2 hi) {
     return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 }
 
+// c + a.lo*b.lo + a.hi*b.hi on packed bf16 pairs, fp32 accumulate (v_dot2c_f32_bf16)
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+
 // compiler-only fence: memory operations are not moved across it (keeps LDS-read hoisting, and with it
 // register pressure, bounded in the fully unrolled MFMA loops)
 __device__ __forceinline__ void cfence() { asm volatile("" ::: "memory"); }

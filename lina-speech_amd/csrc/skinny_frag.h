@@ -1,0 +1,51 @@
+// skinny_frag.h -- MFMA operand fragments loaded straight from global memory (16 B per lane), shared by the
+// decode-step projection kernels (linear_skinny.hip, gla_inproj.hip).
+#pragma once
+#include <lina_dev.h>
+#include "lina_common.h"
+
+namespace lina {
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+    static constexpr int KSTEP = 32, KL = 8;  // k per step / k per lane
+    uint4 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void zero() { v = make_uint4(0u, 0u, 0u, 0u); }
+    __device__ __forceinline__ void stats(float& s1, float& s2) const {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s1 = dot2_bf16(w[j], 0x3f803f80u, s1);   // (1.0, 1.0) in bf16
+            s2 = dot2_bf16(w[j], w[j], s2);
+        }
+    }
+    __device__ __forceinline__ bf16x8 pack() const {
+        bf16x8 r;
+        r[0] = (short)(v.x & 0xffff); r[1] = (short)(v.x >> 16); r[2] = (short)(v.y & 0xffff); r[3] = (short)(v.y >> 16);
+        r[4] = (short)(v.z & 0xffff); r[5] = (short)(v.z >> 16); r[6] = (short)(v.w & 0xffff); r[7] = (short)(v.w >> 16);
+        return r;
+    }
+    static __device__ __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
+        return mfma_bf16_16x16x32(a.pack(), b.pack(), c);
+    }
+};
+template <> struct Frag<float> {
+    static constexpr int KSTEP = 16, KL = 4;
+    float4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ void stats(float& s1, float& s2) const {
+        s1 += (v.x + v.y) + (v.z + v.w);
+        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    // k-slot (step s, lane group g) <-> k0 + 4g + s on both operands: any bijection is valid
+    static __device__ __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
+        c = mfma_f32_16x16x4(a.v.x, b.v.x, c);
+        c = mfma_f32_16x16x4(a.v.y, b.v.y, c);
+        c = mfma_f32_16x16x4(a.v.z, b.v.z, c);
+        return mfma_f32_16x16x4(a.v.w, b.v.w, c);
+    }
+};
+
+}  // namespace lina

@@ -1,8 +1,8 @@
 """DecodeEngine: the single-token step of ``AttentiveGLA.step`` + logits head
 (reference model/gla.py:358-365 driven by model/modeling_lina.py:152-179) restructured for
-MI355X: per GLA block SEVEN launches instead of ~30 --
-  1 fused projection q|k|v|g|gate-low-rank with LayerNorm-1 folded in      (lina_linear_skinny)
-  2 prologue: 3 conv steps + gate                                           (lina_gla_decode_prologue)
+MI355X: per GLA block SIX launches instead of ~30 --
+  1 LayerNorm-1 (folded) + fused projection q|k|v|g|gate-low-rank + 3 conv steps + gate
+                                                                            (lina_gla_decode_inproj)
   3 in-place recurrent-state update, row-split, fp32 partial o             (lina_gla_decode_update, K1d)
   4 partial-sum + RMSNorm (x) swish gate, gate read from the projection row (lina_rmsnorm_gate_fwd, K5)
   5 o_proj + residual                                                       (lina_linear_skinny)
@@ -84,7 +84,9 @@ class _BlockPack:
             raise ValueError("recurrent state must be a contiguous fp32 tensor (see GatedLinearAttention.init_state)")
         B = self.S.shape[0]
         self.row_split = self.Dk % 64 == 0 and self.Dv in (64, 128, 256)
+        self.fused_in = self.R == 16 and self.Kd % 16 == 0 and self.Vd % 16 == 0
         self.z = torch.empty(B, self.ldz, dtype=dt, device=dev)
+        self.g = torch.empty(B, self.Vd, dtype=dt, device=dev)
         self.qkv = torch.empty(B, 2 * self.Kd + self.Vd, dtype=dt, device=dev)
         self.gk = torch.empty(B, self.Kd, dtype=torch.float32, device=dev)
         self.o_part = torch.empty(max(self.Dk // 64, 1), B, self.H, self.Dv, dtype=torch.float32, device=dev)
@@ -125,13 +127,18 @@ class DecodeEngine:
     def _block(self, x, P: _BlockPack):
         """x [B,d] is the residual stream and is UPDATED IN PLACE."""
         B = x.shape[0]
-        z = ops.linear_skinny(x, P.w_in, P.c1_in, P.c2_in, out=P.z, ln_dim=P.d, ln_eps=P.n1_eps)
-        ops.gla_decode_prologue(z, P.off_q, P.off_k, P.off_v, P.off_lr, P.wq, P.wk, P.wv, P.cq, P.ck, P.cv,
-                                P.w2, P.b2, P.qkv, P.gk, P.normalizer, P.clamp_min)
+        if P.fused_in:
+            ops.gla_decode_inproj(x, P.w_in, P.c1_in, P.c2_in, P.wq, P.wk, P.wv, P.cq, P.ck, P.cv, P.w2, P.b2,
+                                  P.qkv, P.g, P.gk, P.n1_eps, P.normalizer, P.clamp_min)
+            gate = P.g.view(B, P.H, P.Dv)
+        else:
+            z = ops.linear_skinny(x, P.w_in, P.c1_in, P.c2_in, out=P.z, ln_dim=P.d, ln_eps=P.n1_eps)
+            ops.gla_decode_prologue(z, P.off_q, P.off_k, P.off_v, P.off_lr, P.wq, P.wk, P.wv, P.cq, P.ck, P.cv,
+                                    P.w2, P.b2, P.qkv, P.gk, P.normalizer, P.clamp_min)
+            gate = z[:, P.off_g:P.off_g + P.Vd].view(B, P.H, P.Dv)
         q = P.qkv[:, :P.Kd].view(B, P.H, P.Dk)
         k = P.qkv[:, P.Kd:2 * P.Kd].view(B, P.H, P.Dk)
         v = P.qkv[:, 2 * P.Kd:].view(B, P.H, P.Dv)
-        gate = z[:, P.off_g:P.off_g + P.Vd].view(B, P.H, P.Dv)
         if P.row_split:
             ops.gla_decode_update(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S)
             ops.rmsnorm_swish_gate(P.o_part, gate, P.gnw, P.eps_gate, n_partial=P.o_part.shape[0], out=P.og)

@@ -332,3 +332,20 @@ def linear_skinny(a, w, c1=None, c2=None, resid=None, out=None, swiglu_hidden: i
                                      0 if resid is None else resid.stride(0), _ptr(out), out.stride(0), M, N, K,
                                      swiglu_hidden, ln_dim, float(ln_eps), _dt(a), be.stream(a)))
     return out
+
+
+def gla_decode_inproj(x, w_in, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_out, gk, ln_eps: float = 1e-5,
+                      normalizer: float = 16.0, clamp_min: Optional[float] = None):
+    """LayerNorm-1 + fused projection + conv steps + gate of one GLA mixer at T = 1, one launch
+    (lina_gla_decode_inproj, see lina_gla.h)."""
+    be = _BACKEND
+    be.require(x, w_in, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_out, gk)
+    B, K = x.shape
+    Kd, W = wq.shape[0], wq.shape[-1]
+    Vd, R = wv.shape[0], w2.shape[1]
+    _check(be.lib.lina_gla_decode_inproj(_ptr(x), x.stride(0), _ptr(w_in), w_in.stride(0), _ptr(c1), _ptr(c2),
+                                         _ptr(wq), _ptr(wk), _ptr(wv), _ptr(cq), _ptr(ck), _ptr(cv), _ptr(w2),
+                                         _ptr(b2), _ptr(qkv), _ptr(g_out), _ptr(gk), B, K, Kd, Vd, W, R,
+                                         float(ln_eps), float(normalizer),
+                                         float("nan") if clamp_min is None else float(clamp_min), _dt(x),
+                                         be.stream(x)))

@@ -204,6 +204,11 @@ static inline void dma16_to_lds(const void* gsrc_lane, void* lds_wave_base) {
 static inline bf16x8 as_bf16x8(uint4 u) { bf16x8 r; memcpy(&r, &u, 16); return r; }
 static inline bf16x8 as_bf16x8(uint2 lo, uint2 hi) { bf16x8 r; memcpy(&r.v[0], &lo, 8); memcpy(&r.v[4], &hi, 8); return r; }
 
+static inline float dot2_bf16(uint32_t a, uint32_t b, float c) {
+    return fmaf(bf2f((unsigned short)(a >> 16)), bf2f((unsigned short)(b >> 16)),
+                fmaf(bf2f((unsigned short)(a & 0xffff)), bf2f((unsigned short)(b & 0xffff)), c));
+}
+
 static inline void cfence() { asm volatile("" ::: "memory"); }
 
 static inline void opaque(int& x) { asm volatile("" : "+r"(x)); }

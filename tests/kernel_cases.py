@@ -272,3 +272,51 @@ def check_linear_skinny(dev, M, N, K, dtype, ln=False, bias=False, resid=False, 
         ops.linear_skinny(a, w_used, c1, None if c2 is None else c2.float().contiguous(), resid=r2, out=r2,
                           swiglu_hidden=swiglu, ln_dim=K if ln else 0, n_out=n_out)
         assert torch.equal(r2, out)
+
+
+def check_inproj(dev, B, K, Kd, Vd, dtype):
+    """lina_gla_decode_inproj == lina_linear_skinny(LayerNorm fold) + lina_gla_decode_prologue (both oracle-checked
+    above), and == the oracle's LayerNorm -> projections -> conv step -> gate in fp64."""
+    g = torch.Generator().manual_seed(11)
+    R, W = 16, 4
+    x = (torch.randn(B, K, generator=g) * 1.3 + 0.4).to(dtype).to(dev)
+    n_w = 2 * Kd + 2 * Vd + R
+    w = (torch.randn(n_w, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+    gamma = (1 + 0.2 * torch.randn(K, generator=g)).to(dev)
+    beta = (0.3 * torch.randn(K, generator=g)).to(dev)
+    w_ln = (w.float() * gamma[None, :]).to(dtype).contiguous()
+    c1 = w_ln.float().sum(1).contiguous()
+    c2 = (w.float() @ beta).contiguous()
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dtype).to(dev)
+    wq, wk, wv = mk(Kd, W), mk(Kd, W), mk(Vd, W)
+    caches = [mk(B, Kd, W), mk(B, Kd, W), mk(B, Vd, W)]
+    w2, b2 = mk(Kd, R) * 4, mk(Kd)
+    # unfused product path
+    c_a = [c.clone() for c in caches]
+    z = ops.linear_skinny(x, w_ln, c1, c2, ln_dim=K)
+    qkv_a = torch.empty(B, 2 * Kd + Vd, dtype=dtype, device=dev)
+    gk_a = torch.empty(B, Kd, dtype=torch.float32, device=dev)
+    ops.gla_decode_prologue(z, 0, Kd, 2 * Kd, 2 * Kd + 2 * Vd, wq, wk, wv, *c_a, w2, b2, qkv_a, gk_a)
+    # fused
+    c_b = [c.clone() for c in caches]
+    qkv_b = torch.empty_like(qkv_a)
+    g_b = torch.empty(B, Vd, dtype=dtype, device=dev)
+    gk_b = torch.empty_like(gk_a)
+    ops.gla_decode_inproj(x, w_ln, c1, c2, wq, wk, wv, *c_b, w2, b2, qkv_b, g_b, gk_b)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert_close(qkv_b, qkv_a, tol, "inproj qkv vs unfused")
+    assert_close(g_b, z[:, 2 * Kd + Vd:2 * Kd + 2 * Vd], tol, "inproj g vs unfused")
+    assert_close(gk_b, gk_a, 1e-4 if dtype == torch.float32 else 3e-2, "inproj gk vs unfused")
+    for a, b_, nm in zip(c_a, c_b, "qkv"):
+        assert_close(b_, a, 1e-5 if dtype == torch.float32 else 1e-2, f"inproj cache {nm}")
+    # oracle (fp64) for the fp32 case
+    if dtype == torch.float32:
+        x64 = x.cpu().to(F64)
+        ln = (x64 - x64.mean(1, keepdim=True)) / torch.sqrt(x64.var(1, unbiased=False, keepdim=True) + 1e-5)
+        ln = ln * gamma.cpu().to(F64) + beta.cpu().to(F64)
+        zz = ln @ w.cpu().to(F64).t()
+        rc = caches[0].cpu().to(F64).clone()
+        rq = O.short_conv(zz[:, None, :Kd], wq.cpu().to(F64), None, rc)
+        assert_close(qkv_b[:, :Kd], rq[:, 0], 1e-4, "inproj q vs oracle")
+        rgk = O.gate_logsigmoid(zz[:, 2 * Kd + 2 * Vd:] @ w2.cpu().to(F64).t() + b2.cpu().to(F64), 16.0)
+        assert_close(gk_b, rgk, 1e-4, "inproj gk vs oracle")

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import gla_oracle as O
-from kernel_cases import (check_argmax, check_chunk, check_conv, check_decode_update, check_embed, check_linear_skinny,
+from kernel_cases import (check_argmax, check_chunk, check_conv, check_decode_update, check_embed, check_inproj, check_linear_skinny,
                           check_prologue, check_recurrent, check_rmsnorm, check_swiglu)
 
 DEV = "cpu"
@@ -68,3 +68,8 @@ def test_decode_update_rowsplit(emu, Dk, Dv, dtype):
 ])
 def test_linear_skinny(emu, kw):
     check_linear_skinny(DEV, **kw)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_inproj_fused(emu, dtype):
+    check_inproj(DEV, B=5, K=64, Kd=32, Vd=48, dtype=dtype)

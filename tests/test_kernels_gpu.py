@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from kernel_cases import (assert_close, check_argmax, check_chunk, check_conv, check_decode_update, check_embed,
+from kernel_cases import (assert_close, check_argmax, check_chunk, check_conv, check_decode_update, check_embed, check_inproj,
                           check_linear_skinny, check_prologue, check_recurrent, check_rmsnorm, check_swiglu,
                           make_gla_inputs, oracle_gla)
 from lina_speech_amd import ops
@@ -77,6 +77,12 @@ def test_decode_update_rowsplit(hip, Dk, Dv, dtype):
 ])
 def test_linear_skinny(hip, kw):
     check_linear_skinny(DEV, **kw)
+
+
+@pytest.mark.parametrize("B,K,Kd,Vd,dtype", [(5, 64, 32, 48, torch.float32), (64, 1024, 1024, 1024, torch.float32),
+                                              (64, 1024, 1024, 1024, torch.bfloat16), (70, 256, 128, 256, torch.bfloat16)])
+def test_inproj_fused(hip, B, K, Kd, Vd, dtype):
+    check_inproj(DEV, B=B, K=K, Kd=Kd, Vd=Vd, dtype=dtype)
 
 
 # ---------------------------------------------------------------------------------------------
