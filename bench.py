@@ -52,7 +52,7 @@ def measure_k1(engine, reps=20):
     torch's current stream -- the stream the C-ABI launches are enqueued on."""
     from lina_speech_amd import ops
     packs = engine.packs
-    B = engine.B
+    B = packs[0].S.shape[0]          # rows per launch (the engine may split the batch into parallel row ranges)
 
     def one_pass():
         for P in packs:
@@ -194,11 +194,13 @@ def main():
             P = eng.packs[0]
             k1_dt = measure_k1(eng)
             e_io = 2 if dtype == torch.bfloat16 else 4
-            k1_bytes = k1_algorithmic_bytes(B, P.H, P.Dk, P.Dv, e_io, 4)
+            k1_rows = P.S.shape[0]
+            k1_bytes = k1_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4)
             roof = {"kernel": "lina::gla_decode_rowsplit_kernel<256>", "bound": "hbm",
                     "achieved": k1_bytes / k1_dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": k1_bytes / k1_dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                    "bytes_per_launch": k1_bytes, "us_per_launch": k1_dt * 1e6, "launches_per_step": len(eng.packs)}
+                    "bytes_per_launch": k1_bytes, "us_per_launch": k1_dt * 1e6, "rows_per_launch": k1_rows,
+                    "launches_per_step": len(eng.packs) * len(eng.parts)}
             out = {
                 "metric": "codec tokens/sec (whole node), 169M d1024xl12 batched greedy decode",
                 "value": total_rows * args.steps / elapsed, "unit": "codec tokens/s", "n_gpus": world,
@@ -207,7 +209,8 @@ def main():
                 "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
                 "config": {"workload": f"L169 greedy codec-token decode, B={B_PER_GPU}/GPU (B_total={total_rows}), "
                                        f"T_txt={T_TXT}, H=4 Dk=Dv=256, 12+1 GLA blocks, fp32 recurrent state, "
-                                       f"{nparam / 1e6:.1f}M params, one hipGraph replay per token",
+                                       f"{nparam / 1e6:.1f}M params, one hipGraph replay per token, "
+                                       f"{len(eng.parts)} parallel row ranges per GPU",
                            "global_batch": total_rows, "parallelism": f"batch-shard x{world} (no collective)"},
                 "roofline": roof,
             }

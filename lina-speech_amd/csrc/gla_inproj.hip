@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
         ap[mt] = A + (int64_t)(m_ok[mt] ? m : 0) * lda + F::KL * lg;
     }
     const int nsteps = K / F::KSTEP;
-    constexpr int U = 4;
+    constexpr int U = 8;
     int ks = w;
     for (; ks + 4 * (U - 1) < nsteps; ks += 4 * U) {
         F fb[U], fa[U][4];

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
 
     const int nsteps = K / F::KSTEP;
     // U k-steps of loads are issued before their MFMAs: (NB + 4) * U independent 16-byte loads per lane
-    constexpr int U = SWIGLU ? 2 : 4;
+    constexpr int U = 8;
     int ks = w;
     for (; ks + 4 * (U - 1) < nsteps; ks += 4 * U) {
         F fb[U], fb2[U], fa[U][4];

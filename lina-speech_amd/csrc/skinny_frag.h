@@ -20,12 +20,7 @@ template <> struct Frag<bf16_t> {
             s2 = dot2_bf16(w[j], w[j], s2);
         }
     }
-    __device__ __forceinline__ bf16x8 pack() const {
-        bf16x8 r;
-        r[0] = (short)(v.x & 0xffff); r[1] = (short)(v.x >> 16); r[2] = (short)(v.y & 0xffff); r[3] = (short)(v.y >> 16);
-        r[4] = (short)(v.z & 0xffff); r[5] = (short)(v.z >> 16); r[6] = (short)(v.w & 0xffff); r[7] = (short)(v.w >> 16);
-        return r;
-    }
+    __device__ __forceinline__ bf16x8 pack() const { return as_bf16x8(v); }   // a register reinterpretation
     static __device__ __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
         return mfma_bf16_16x16x32(a.pack(), b.pack(), c);
     }

@@ -17,6 +17,7 @@ Only the small cross-attention softmax/bmm glue stays on torch-ROCm.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -41,7 +42,16 @@ def _fold_layernorm(weight, ln, bias=None):
 class _BlockPack:
     """Decode-time weights of one MixingBlock(GatedLinearAttention, SwiGLU, LayerNorm)."""
 
-    def __init__(self, blk, state):
+    _SHARED = ("H", "Dk", "Dv", "Kd", "Vd", "d", "R", "normalizer", "clamp_min", "eps_gate", "n1_eps", "n2_eps",
+               "w_in", "c1_in", "c2_in", "ldz", "off_q", "off_k", "off_v", "off_g", "off_lr", "wq", "wk", "wv",
+               "w2", "b2", "gnw", "w_o", "hid", "hid_pad", "w_up", "c1_up", "c2_up", "w_down")
+
+    def __init__(self, blk, state, lo=0, hi=None, shared=None):
+        if shared is not None:                     # same block, another row range: reuse the packed weights
+            for name in self._SHARED:
+                setattr(self, name, getattr(shared, name))
+            self._buffers(state, lo, hi, shared.w_in.dtype, shared.w_in.device)
+            return
         m: GatedLinearAttention = blk.tmix
         if not (m.use_short_conv and not m.share_conv_kernel and m.conv_size == 4 and not m.conv_bias
                 and m.fuse_norm_and_gate):
@@ -79,10 +89,14 @@ class _BlockPack:
         w_down[:, :self.hid] = c.p_out.weight
         w_down[:, self.hid] = c.p_out.bias                              # multiplied by the constant-1 column
         self.w_down = w_down
-        self.cq, self.ck, self.cv, self.S = state
-        if self.S.dtype != torch.float32 or not self.S.is_contiguous():
+        self._buffers(state, lo, hi, dt, dev)
+
+    def _buffers(self, state, lo, hi, dt, dev):
+        if state[3].dtype != torch.float32 or not state[3].is_contiguous():
             raise ValueError("recurrent state must be a contiguous fp32 tensor (see GatedLinearAttention.init_state)")
-        B = self.S.shape[0]
+        hi = state[3].shape[0] if hi is None else hi
+        self.cq, self.ck, self.cv, self.S = (t[lo:hi] for t in state)    # row slices stay contiguous
+        B = hi - lo
         self.row_split = self.Dk % 64 == 0 and self.Dv in (64, 128, 256)
         self.fused_in = self.R == 16 and self.Kd % 16 == 0 and self.Vd % 16 == 0
         self.z = torch.empty(B, self.ldz, dtype=dt, device=dev)
@@ -94,34 +108,59 @@ class _BlockPack:
         self.s = torch.empty(B, self.hid_pad, dtype=dt, device=dev)
 
 
+class _Part:
+    """Rows [lo, hi) of the batch: own residual/workspace buffers and state slices, shared weights."""
+
+    def __init__(self, lo, hi, packs, kk, vv, d, dtype, dev):
+        self.lo, self.hi, self.packs = lo, hi, packs
+        self.kk, self.vv = kk, vv
+        self.x = torch.zeros(hi - lo, d, dtype=dtype, device=dev)       # residual stream
+        self.xp = torch.zeros(hi - lo, d, dtype=dtype, device=dev)      # pos_net stream
+
+
 class DecodeEngine:
     def __init__(self, model, x_enc: torch.Tensor, batch_size: int, state: Optional[Cache] = None,
-                 use_graph: Optional[bool] = None):
+                 use_graph: Optional[bool] = None, n_split: Optional[int] = None):
+        """``n_split`` > 1 cuts the batch into independent row ranges that run on parallel HIP streams inside
+        the same graph: the step is a chain of ~100 short dependent launches, so two (or four) independent
+        chains in flight hide each other's launch/drain latency; rows never interact."""
         rnn = model.attentive_rnn
         self.model = model
         self.B = batch_size
         self.dev = x_enc.device
         self.state = state if state is not None else rnn.init_state(batch_size=batch_size)
         blocks = list(rnn.encoder) + list(rnn.decoder) + [rnn.cross_att.pos_net]
-        self.packs = [_BlockPack(b, self.state[i]) for i, b in enumerate(blocks)]
         self.n_enc = len(rnn.encoder)
         ca = rnn.cross_att
         self.ca = ca
         kk, vv, pe = ca.prepare(x_enc)                                   # [B,1,Ttxt,d] x2, [1,1,Ttxt,d]
-        self.kk, self.vv = kk.squeeze(1).contiguous(), vv.squeeze(1).contiguous()
+        kk, vv = kk.squeeze(1).contiguous(), vv.squeeze(1).contiguous()
         self.pe = pe.squeeze(1).squeeze(0).contiguous()                  # [Ttxt, d]
-        self.att_scale = 1.0 / math.sqrt(self.kk.shape[-1])
+        self.att_scale = 1.0 / math.sqrt(kk.shape[-1])
         self.ca_qw, self.ca_qb = ca.q.weight.contiguous(), ca.q.bias.float().contiguous()
         hw = model.logits_head.weight
         self.Q, self.L, self.d = hw.shape
         self.w_head = hw.reshape(self.Q * self.L, self.d).contiguous()
         self.use_graph = (self.dev.type == "cuda") if use_graph is None else use_graph
+        if n_split is None:
+            n_split = int(os.environ.get("LINA_DECODE_SPLIT", "0")) or (2 if (self.dev.type == "cuda" and batch_size >= 32) else 1)
+        n_split = max(1, min(n_split, batch_size))
+        from .shard import shard_rows
+        self.parts = []
+        first = None
+        for i in range(n_split):
+            lo, hi = shard_rows(batch_size, i, n_split)
+            packs = [_BlockPack(b, self.state[j], lo, hi, shared=None if first is None else first[j])
+                     for j, b in enumerate(blocks)]
+            first = first or packs
+            self.parts.append(_Part(lo, hi, packs, kk[lo:hi], vv[lo:hi], self.d, hw.dtype, self.dev))
+        self.packs = self.parts[0].packs
+        self._streams = ([torch.cuda.Stream(device=self.dev) for _ in self.parts]
+                         if (len(self.parts) > 1 and self.dev.type == "cuda") else None)
         self._graph = None
         self._y_in = torch.zeros(batch_size, self.d, dtype=hw.dtype, device=self.dev)
-        self._x = torch.zeros(batch_size, self.d, dtype=hw.dtype, device=self.dev)     # residual stream
-        self._xp = torch.zeros(batch_size, self.d, dtype=hw.dtype, device=self.dev)    # pos_net stream
-        self._logits = None
-        self._att = None
+        self._logits = torch.zeros(batch_size, self.Q * self.L, dtype=hw.dtype, device=self.dev)
+        self._att = torch.zeros(batch_size, 2, 1, kk.shape[1], dtype=hw.dtype, device=self.dev)
 
     # ------------------------------------------------------------------ one GLA block, T = 1 (7 launches)
     def _block(self, x, P: _BlockPack):
@@ -153,35 +192,54 @@ class DecodeEngine:
         ops.linear_skinny(P.s, P.w_down, resid=x, out=x)
         return x
 
-    def _cross(self, x):
+    def _cross(self, part, x):
         ca = self.ca
         qq = F.layer_norm(ops.linear_skinny(x, self.ca_qw, c2=self.ca_qb), (x.shape[-1],), ca.ln_q.weight,
                           ca.ln_q.bias, ca.ln_q.eps)
-        att1 = torch.softmax(torch.bmm(self.kk, qq.unsqueeze(-1)).squeeze(-1) * self.att_scale, dim=-1)  # [B,Ttxt]
-        torch.matmul(att1, self.pe, out=self._xp)
-        xp = self._block(self._xp, self.packs[-1])
+        att1 = torch.softmax(torch.bmm(part.kk, qq.unsqueeze(-1)).squeeze(-1) * self.att_scale, dim=-1)  # [b,Ttxt]
+        torch.matmul(att1, self.pe, out=part.xp)
+        xp = self._block(part.xp, part.packs[-1])
         att2 = torch.softmax((xp @ self.pe.t()) * self.att_scale, dim=-1)
-        out = torch.bmm(att2.unsqueeze(1), self.vv).squeeze(1)
-        return out, torch.stack((att1, att2), dim=1).unsqueeze(2)          # [B,2,1,Ttxt]
+        out = torch.bmm(att2.unsqueeze(1), part.vv).squeeze(1)
+        att = self._att[part.lo:part.hi]
+        att[:, 0, 0].copy_(att1)
+        att[:, 1, 0].copy_(att2)
+        return out
+
+    def _core_part(self, part, y):
+        x = part.x
+        x.copy_(y[part.lo:part.hi])
+        for P in part.packs[:self.n_enc]:
+            self._block(x, P)
+        x.add_(self._cross(part, x))
+        for P in part.packs[self.n_enc:-1]:
+            self._block(x, P)
+        ops.linear_skinny(x, self.w_head, out=self._logits[part.lo:part.hi])
 
     def _core(self, y):
-        x = self._x
-        x.copy_(y)
-        for P in self.packs[:self.n_enc]:
-            self._block(x, P)
-        v, att = self._cross(x)
-        x.add_(v)
-        for P in self.packs[self.n_enc:-1]:
-            self._block(x, P)
-        logits = ops.linear_skinny(x, self.w_head).view(self.B, 1, self.Q, self.L)
-        return logits, att
+        """y [B,d] -> (logits [B,1,Q,L], att [B,2,1,Ttxt]) written into the engine's static buffers."""
+        if self._streams is None:
+            for part in self.parts:
+                self._core_part(part, y)
+        else:
+            main = torch.cuda.current_stream(self.dev)
+            for part, st in zip(self.parts, self._streams):       # fork
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    self._core_part(part, y)
+            for st in self._streams:                                # join
+                main.wait_stream(st)
+        return self._logits.view(self.B, 1, self.Q, self.L), self._att
 
     # ------------------------------------------------------------------ graph capture
+    def _all_packs(self):
+        return [P for part in self.parts for P in part.packs]
+
     def _snapshot(self):
-        return [[t.clone() for t in (P.cq, P.ck, P.cv, P.S)] for P in self.packs]
+        return [[t.clone() for t in (P.cq, P.ck, P.cv, P.S)] for P in self._all_packs()]
 
     def _restore(self, snap):
-        for P, saved in zip(self.packs, snap):
+        for P, saved in zip(self._all_packs(), snap):
             for dst, src in zip((P.cq, P.ck, P.cv, P.S), saved):
                 dst.copy_(src)
 
@@ -196,19 +254,20 @@ class DecodeEngine:
         self._restore(snap)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._logits, self._att = self._core(self._y_in)
+            self._core(self._y_in)
         self._graph = g
 
     def __call__(self, y_embd: torch.Tensor, t: int = 0):
         """One token for every row: y_embd [B,1,d] -> (logits [B,1,Q,L], att [B,2,1,Ttxt])."""
         y = y_embd.reshape(self.B, self.d)
         if not self.use_graph:
-            return self._core(y)
+            logits, att = self._core(y)
+            return logits, att.clone()
         if self._graph is None:
             self._capture()
         self._y_in.copy_(y)
         self._graph.replay()
-        return self._logits, self._att.clone()
+        return self._logits.view(self.B, 1, self.Q, self.L), self._att.clone()
 
     step = __call__
 
@@ -254,7 +313,7 @@ class DecodeEngine:
 
     def greedy_step(self):
         """Enqueue one token for every row (no host sync). Returns the step's attention weights
-        (a static buffer under graph replay: clone to keep)."""
+        (a static buffer: clone to keep)."""
         self._n_done += 1
         if self._greedy_graph is not None:
             self._greedy_graph.replay()

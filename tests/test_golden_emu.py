@@ -48,7 +48,8 @@ def test_engine_device_side_greedy_loop(emu):
     with torch.no_grad():
         x = torch.from_numpy(g["gen_x"]).unsqueeze(0).expand(3, -1)
         x_enc = model.txt_encoder(model.txt_embed(x))
-        eng = DecodeEngine(model, x_enc, batch_size=3)
+        eng = DecodeEngine(model, x_enc, batch_size=3, n_split=2)     # two row ranges (parallel streams on a GPU)
+        assert [(p.lo, p.hi) for p in eng.parts] == [(0, 2), (2, 3)]
         toks, atts = eng.run_greedy(12, record_att=True)
     assert torch.equal(toks, torch.from_numpy(g["gen_qs"]))
     assert atts.shape == g["gen_atts"].shape
