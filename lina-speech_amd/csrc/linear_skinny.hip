@@ -21,34 +21,36 @@
 
 namespace lina {
 
-template <typename T, bool SWIGLU, bool LN>
+template <typename T, bool SWIGLU, bool LN, int MT>
 __global__ __launch_bounds__(256) void linear_skinny_kernel(
     const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw, const float* __restrict__ c1,
     const float* __restrict__ c2, const T* resid, int64_t ldr, T* out, int64_t ldo, int M, int N, int K, int Hd,
     int ln_dim, float ln_eps) {
     using F = Frag<T>;
     constexpr int NB = SWIGLU ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) float s_acc[4][NB * 4][64][4];   // [wave][m-tile (x half)][lane][reg]
-    __shared__ float s_st[4][64][2];
+    __shared__ __attribute__((aligned(16))) float s_acc[4][NB * MT][64][4];  // [wave][m-tile (x half)][lane][reg]
+    __shared__ float s_st[4][16 * MT][2];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * MT);
     const int n = n0 + li;
     const int n_rows = SWIGLU ? Hd : N;          // weight rows per half
     const bool n_ok = n < n_rows;
 
-    f32x4 acc[NB * 4];
+    f32x4 acc[NB * MT];
 #pragma unroll
-    for (int i = 0; i < NB * 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NB * MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float s1[MT], s2[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
 
     const T* wp = W + (int64_t)(n_ok ? n : 0) * ldw + F::KL * lg;
     const T* wp2 = SWIGLU ? W + (int64_t)(n_ok ? Hd + n : 0) * ldw + F::KL * lg : nullptr;
-    const T* ap[4];
-    bool m_ok[4];
+    const T* ap[MT];
+    bool m_ok[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         const int m = m0 + 16 * mt + li;
         m_ok[mt] = m < M;
         ap[mt] = A + (int64_t)(m_ok[mt] ? m : 0) * lda + F::KL * lg;
@@ -59,46 +61,46 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
     constexpr int U = 8;
     int ks = w;
     for (; ks + 4 * (U - 1) < nsteps; ks += 4 * U) {
-        F fb[U], fb2[U], fa[U][4];
+        F fb[U], fb2[U], fa[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k0 = (ks + 4 * u) * F::KSTEP;
             if (n_ok) fb[u].load(wp + k0); else fb[u].zero();
             if (SWIGLU) { if (n_ok) fb2[u].load(wp2 + k0); else fb2[u].zero(); }
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) { if (m_ok[mt]) fa[u][mt].load(ap[mt] + k0); else fa[u][mt].zero(); }
+            for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[u][mt].load(ap[mt] + k0); else fa[u][mt].zero(); }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 if (LN) fa[u][mt].stats(s1[mt], s2[mt]);
                 acc[mt] = F::mma(fa[u][mt], fb[u], acc[mt]);
-                if (SWIGLU) acc[4 + mt] = F::mma(fa[u][mt], fb2[u], acc[4 + mt]);
+                if (SWIGLU) acc[MT + mt] = F::mma(fa[u][mt], fb2[u], acc[MT + mt]);
             }
     }
     for (; ks < nsteps; ks += 4) {
         const int k0 = ks * F::KSTEP;
-        F fb, fb2, fa[4];
+        F fb, fb2, fa[MT];
         if (n_ok) fb.load(wp + k0); else fb.zero();
         if (SWIGLU) { if (n_ok) fb2.load(wp2 + k0); else fb2.zero(); }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) { if (m_ok[mt]) fa[mt].load(ap[mt] + k0); else fa[mt].zero(); }
+        for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[mt].load(ap[mt] + k0); else fa[mt].zero(); }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             if (LN) fa[mt].stats(s1[mt], s2[mt]);
             acc[mt] = F::mma(fa[mt], fb, acc[mt]);
-            if (SWIGLU) acc[4 + mt] = F::mma(fa[mt], fb2, acc[4 + mt]);
+            if (SWIGLU) acc[MT + mt] = F::mma(fa[mt], fb2, acc[MT + mt]);
         }
     }
 
     // ---- in-workgroup split-K reduction ----
 #pragma unroll
-    for (int i = 0; i < NB * 4; ++i)
+    for (int i = 0; i < NB * MT; ++i)
         *reinterpret_cast<float4*>(&s_acc[w][i][lane][0]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
     if (LN) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {   // sum over the 4 lane groups that share row li
+        for (int mt = 0; mt < MT; ++mt) {   // sum over the 4 lane groups that share row li
             float a = s1[mt], b = s2[mt];
             a += shfl_xor(a, 16); b += shfl_xor(b, 16);
             a += shfl_xor(a, 32); b += shfl_xor(b, 32);
@@ -106,15 +108,16 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
         }
     }
     __syncthreads();
+    if (w >= MT) return;
 
     // wave w finalises m-tile w: D layout -> rows m0 + 16w + 4*lg + r, column n
     float val[NB][4];
 #pragma unroll
     for (int hb = 0; hb < NB; ++hb) {
-        float4 t = *reinterpret_cast<const float4*>(&s_acc[0][4 * hb + w][lane][0]);
+        float4 t = *reinterpret_cast<const float4*>(&s_acc[0][MT * hb + w][lane][0]);
 #pragma unroll
         for (int ww = 1; ww < 4; ++ww) {
-            const float4 u = *reinterpret_cast<const float4*>(&s_acc[ww][4 * hb + w][lane][0]);
+            const float4 u = *reinterpret_cast<const float4*>(&s_acc[ww][MT * hb + w][lane][0]);
             t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
         val[hb][0] = t.x; val[hb][1] = t.y; val[hb][2] = t.z; val[hb][3] = t.w;
@@ -167,11 +170,23 @@ extern "C" int lina_linear_skinny(const void* A, int64_t lda, const void* W, int
     LINA_REQUIRE(lda % al == 0 && ldw % al == 0, "lina_linear_skinny: lda/ldw must keep rows 16-byte aligned");
     LINA_REQUIRE(ln_dim >= 0 && (ln_dim == 0 || c1), "lina_linear_skinny: LayerNorm folding needs c1");
     LINA_REQUIRE(swiglu_hidden >= 0 && swiglu_hidden <= N, "lina_linear_skinny: bad swiglu_hidden");
-    dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + 63) / 64));
+    // Tile rows: every workgroup re-reads its rows of A; with few column tiles (N <= 2048) one 16-row m-tile per
+    // workgroup puts 4x more workgroups (CUs) on the job, each pulling 16 rows of A + 16 rows of W.
+    const bool small_n = (N + 15) / 16 <= 128 || M <= 16;
+    const int mrows = small_n ? 16 : 64;
+    dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + mrows - 1) / mrows));
     const bool sw = swiglu_hidden > 0, ln = ln_dim > 0;
 #define LINA_LS(TT, SW, LNN)                                                                                        \
-    LINA_LAUNCH((linear_skinny_kernel<TT, SW, LNN>), grid, dim3(256), 0, stream, (const TT*)A, lda, (const TT*)W,   \
-                ldw, c1, c2, (const TT*)resid, ldr, (TT*)out, ldo, M, N, K, swiglu_hidden, ln_dim, ln_eps)
+    do {                                                                                                            \
+        if (small_n)                                                                                                \
+            LINA_LAUNCH((linear_skinny_kernel<TT, SW, LNN, 1>), grid, dim3(256), 0, stream, (const TT*)A, lda,      \
+                        (const TT*)W, ldw, c1, c2, (const TT*)resid, ldr, (TT*)out, ldo, M, N, K, swiglu_hidden,   \
+                        ln_dim, ln_eps);                                                                            \
+        else                                                                                                        \
+            LINA_LAUNCH((linear_skinny_kernel<TT, SW, LNN, 4>), grid, dim3(256), 0, stream, (const TT*)A, lda,      \
+                        (const TT*)W, ldw, c1, c2, (const TT*)resid, ldr, (TT*)out, ldo, M, N, K, swiglu_hidden,   \
+                        ln_dim, ln_eps);                                                                            \
+    } while (0)
     if (dtype == LINA_BF16) {
         if (sw && ln) LINA_LS(bf16_t, true, true); else if (sw) LINA_LS(bf16_t, true, false);
         else if (ln) LINA_LS(bf16_t, false, true); else LINA_LS(bf16_t, false, false);

@@ -143,7 +143,9 @@ class DecodeEngine:
         self.w_head = hw.reshape(self.Q * self.L, self.d).contiguous()
         self.use_graph = (self.dev.type == "cuda") if use_graph is None else use_graph
         if n_split is None:
-            n_split = int(os.environ.get("LINA_DECODE_SPLIT", "0")) or (2 if (self.dev.type == "cuda" and batch_size >= 32) else 1)
+            # measured on MI355X (B=64): 1 range 1.035 ms/step, 2 ranges 1.013 ms, 4 ranges 1.64 ms -- the forked
+            # branches of a hipGraph barely overlap, so one range stays the default
+            n_split = int(os.environ.get("LINA_DECODE_SPLIT", "0")) or 1
         n_split = max(1, min(n_split, batch_size))
         from .shard import shard_rows
         self.parts = []

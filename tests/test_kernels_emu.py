@@ -65,6 +65,7 @@ def test_decode_update_rowsplit(emu, Dk, Dv, dtype):
     dict(M=7, N=40, K=160, dtype=torch.bfloat16, ln=True),
     dict(M=66, N=64, K=64, dtype=torch.bfloat16, ln=True, bias=True, swiglu=37),
     dict(M=3, N=17, K=352, dtype=torch.bfloat16, resid=True),
+    dict(M=40, N=2080, K=32, dtype=torch.bfloat16, ln=True, bias=True),      # > 128 column tiles: 64-row workgroups
 ])
 def test_linear_skinny(emu, kw):
     check_linear_skinny(DEV, **kw)
