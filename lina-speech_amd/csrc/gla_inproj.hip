@@ -14,7 +14,7 @@
 
 namespace lina {
 
-template <typename T>
+template <typename T, int NT>
 __global__ __launch_bounds__(256) void gla_inproj_kernel(
     const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw, const float* __restrict__ c1,
     const float* __restrict__ c2, const T* __restrict__ wq, const T* __restrict__ wk, const T* __restrict__ wv,
@@ -22,8 +22,9 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
     T* __restrict__ g_out, float* __restrict__ gk, int M, int K, int Kd, int Vd, float ln_eps, float inv_norm,
     float clamp_min, int has_clamp) {
     using F = Frag<T>;
-    constexpr int R = 16;
-    __shared__ __attribute__((aligned(16))) float s_acc[4][4][64][4];
+    constexpr int R = 16, MT = 4;
+    constexpr int U = (NT + MT) * 8 <= 48 ? 8 : 4;
+    __shared__ __attribute__((aligned(16))) float s_acc[4][NT * MT][64][4];
     __shared__ float s_st[4][64][2];
     __shared__ float s_lr[64][R + 1];
 
@@ -31,140 +32,162 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
     const int li = lane & 15, lg = lane >> 4;
     const int m0 = blockIdx.y * 64;
     const int n_direct = 2 * Kd + 2 * Vd;               // q | k | v | g columns; low-rank rows follow in W
-    const int tile0 = blockIdx.x * 16;
-    const bool gate_tile = tile0 >= n_direct;           // block-uniform
-    const int wrow = gate_tile ? n_direct + li : tile0 + li;
+    const int tile0 = blockIdx.x * (16 * NT);           // first output column of this workgroup
+    const bool gate_wg = tile0 >= n_direct;             // block-uniform: NT tiles of gate channels, ONE lr tile
 
-    f32x4 acc[4];
+    f32x4 acc[NT * MT], st1[MT], st2[MT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const T* wp = W + (int64_t)wrow * ldw + F::KL * lg;
-    const T* ap[4];
-    bool m_ok[4];
+    for (int i = 0; i < NT * MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int i = 0; i < MT; ++i) { st1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; st2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    F f_ones;
+    f_ones.ones();
+    const T* wp[NT];
+    bool g_on[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        g_on[j] = !gate_wg || j == 0;
+        const int wrow = gate_wg ? n_direct + li : tile0 + 16 * j + li;
+        wp[j] = W + (int64_t)wrow * ldw + F::KL * lg;
+    }
+    const T* ap[MT];
+    bool m_ok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
         const int m = m0 + 16 * mt + li;
         m_ok[mt] = m < M;
         ap[mt] = A + (int64_t)(m_ok[mt] ? m : 0) * lda + F::KL * lg;
     }
     const int nsteps = K / F::KSTEP;
-    constexpr int U = 8;
     int ks = w;
     for (; ks + 4 * (U - 1) < nsteps; ks += 4 * U) {
-        F fb[U], fa[U][4];
+        F fb[U][NT], fa[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k0 = (ks + 4 * u) * F::KSTEP;
-            fb[u].load(wp + k0);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) { if (m_ok[mt]) fa[u][mt].load(ap[mt] + k0); else fa[u][mt].zero(); }
+            for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[u][j].load(wp[j] + k0); else fb[u][j].zero(); }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[u][mt].load(ap[mt] + k0); else fa[u][mt].zero(); }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                fa[u][mt].stats(s1[mt], s2[mt]);
-                acc[mt] = F::mma(fa[u][mt], fb[u], acc[mt]);
+            for (int mt = 0; mt < MT; ++mt) {
+                st1[mt] = F::mma(fa[u][mt], f_ones, st1[mt]);          // row sums      (LayerNorm mean)
+                st2[mt] = F::mma(fa[u][mt], fa[u][mt], st2[mt]);       // Gram diagonal (LayerNorm variance)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j * MT + mt] = F::mma(fa[u][mt], fb[u][j], acc[j * MT + mt]);
             }
     }
     for (; ks < nsteps; ks += 4) {
         const int k0 = ks * F::KSTEP;
-        F fb, fa[4];
-        fb.load(wp + k0);
+        F fb[NT], fa[MT];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) { if (m_ok[mt]) fa[mt].load(ap[mt] + k0); else fa[mt].zero(); }
+        for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[j].load(wp[j] + k0); else fb[j].zero(); }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            fa[mt].stats(s1[mt], s2[mt]);
-            acc[mt] = F::mma(fa[mt], fb, acc[mt]);
+        for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[mt].load(ap[mt] + k0); else fa[mt].zero(); }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            st1[mt] = F::mma(fa[mt], f_ones, st1[mt]);
+            st2[mt] = F::mma(fa[mt], fa[mt], st2[mt]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j * MT + mt] = F::mma(fa[mt], fb[j], acc[j * MT + mt]);
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NT * MT; ++i)
         *reinterpret_cast<float4*>(&s_acc[w][i][lane][0]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        float a = s1[mt], b = s2[mt];
-        a += shfl_xor(a, 16); b += shfl_xor(b, 16);
-        a += shfl_xor(a, 32); b += shfl_xor(b, 32);
-        if (lg == 0) { s_st[w][16 * mt + li][0] = a; s_st[w][16 * mt + li][1] = b; }
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (li == 4 * lg + r) { s_st[w][16 * mt + li][0] = st1[mt][r]; s_st[w][16 * mt + li][1] = st2[mt][r]; }
     __syncthreads();
 
-    // wave w finalises m-tile w (rows m0 + 16w + 4lg + r, column li of the tile)
-    float val[4];
-    {
-        float4 t = *reinterpret_cast<const float4*>(&s_acc[0][w][lane][0]);
+    // wave w finalises m-tile w (rows m0 + 16w + 4lg + r, column li of each tile)
+    float val[NT][4], mu[4], rstd[4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        float4 t = *reinterpret_cast<const float4*>(&s_acc[0][j * MT + w][lane][0]);
 #pragma unroll
         for (int ww = 1; ww < 4; ++ww) {
-            const float4 u = *reinterpret_cast<const float4*>(&s_acc[ww][w][lane][0]);
+            const float4 u = *reinterpret_cast<const float4*>(&s_acc[ww][j * MT + w][lane][0]);
             t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
-        val[0] = t.x; val[1] = t.y; val[2] = t.z; val[3] = t.w;
+        val[j][0] = t.x; val[j][1] = t.y; val[j][2] = t.z; val[j][3] = t.w;
     }
-    const float cc1 = c1[wrow], cc2 = c2[wrow];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 16 * w + 4 * lg + r;
         const float a = (s_st[0][row][0] + s_st[1][row][0]) + (s_st[2][row][0] + s_st[3][row][0]);
         const float b = (s_st[0][row][1] + s_st[1][row][1]) + (s_st[2][row][1] + s_st[3][row][1]);
-        const float mu = a / (float)K;
-        const float rstd = rsqrtf(fmaxf(b / (float)K - mu * mu, 0.f) + ln_eps);
-        val[r] = rstd * (val[r] - mu * cc1) + cc2;      // the projected value z[m, wrow]
+        mu[r] = a / (float)K;
+        rstd[r] = rsqrtf(fmaxf(b / (float)K - mu[r] * mu[r], 0.f) + ln_eps);
     }
 
-    if (gate_tile) {
+    if (gate_wg) {
+        const float cc1 = c1[n_direct + li], cc2 = c2[n_direct + li];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_lr[16 * w + 4 * lg + r][li] = val[r];
+        for (int r = 0; r < 4; ++r) s_lr[16 * w + 4 * lg + r][li] = rstd[r] * (val[0][r] - mu[r] * cc1) + cc2;
         __syncthreads();
-        const int c = (tile0 - n_direct) + li;          // gate channel
-        float w2r[R];
 #pragma unroll
-        for (int j = 0; j < R; ++j) w2r[j] = ld(w2 + (int64_t)c * R + j);
-        const float bias = ld(b2 + c);
+        for (int j = 0; j < NT; ++j) {
+            const int c = (tile0 - n_direct) + 16 * j + li;          // gate channel
+            if (c >= Kd) continue;
+            float w2r[R];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * w + 4 * lg + r, m = m0 + row;
-            float accg = bias;
+            for (int jj = 0; jj < R; ++jj) w2r[jj] = ld(w2 + (int64_t)c * R + jj);
+            const float bias = ld(b2 + c);
 #pragma unroll
-            for (int j = 0; j < R; ++j) accg = fmaf(s_lr[row][j], w2r[j], accg);
-            float gv = logsigmoidf(accg) * inv_norm;
-            if (has_clamp) gv = fmaxf(gv, clamp_min);
-            if (m < M) gk[(int64_t)m * Kd + c] = gv;
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * w + 4 * lg + r, m = m0 + row;
+                float accg = bias;
+#pragma unroll
+                for (int jj = 0; jj < R; ++jj) accg = fmaf(s_lr[row][jj], w2r[jj], accg);
+                float gv = logsigmoidf(accg) * inv_norm;
+                if (has_clamp) gv = fmaxf(gv, clamp_min);
+                if (m < M) gk[(int64_t)m * Kd + c] = gv;
+            }
         }
         return;
     }
-    const int n = tile0 + li;
-    if (n >= 2 * Kd + Vd) {                              // g columns
-        const int c = n - (2 * Kd + Vd);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = tile0 + 16 * j + li;
+        const float cc1 = c1[n], cc2 = c2[n];
+        float z[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[r] = rstd[r] * (val[j][r] - mu[r] * cc1) + cc2;   // projected value z[m, n]
+        if (n >= 2 * Kd + Vd) {                              // g columns
+            const int c = n - (2 * Kd + Vd);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * w + 4 * lg + r;
+                if (m < M) st(g_out + (int64_t)m * Vd + c, z[r]);
+            }
+            continue;
+        }
+        // q / k / v columns: conv step on the rolled cache (W = 4) + SiLU
+        const T* wsel; T* csel; int c, D;
+        if (n < Kd) { c = n; D = Kd; wsel = wq; csel = cq; }
+        else if (n < 2 * Kd) { c = n - Kd; D = Kd; wsel = wk; csel = ck; }
+        else { c = n - 2 * Kd; D = Vd; wsel = wv; csel = cv; }
+        const float4 wj = ld4(wsel + (int64_t)c * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + 16 * w + 4 * lg + r;
-            if (m < M) st(g_out + (int64_t)m * Vd + c, val[r]);
-        }
-        return;
-    }
-    // q / k / v columns: conv step on the rolled cache (W = 4) + SiLU
-    const T* wsel; T* csel; int c, D;
-    if (n < Kd) { c = n; D = Kd; wsel = wq; csel = cq; }
-    else if (n < 2 * Kd) { c = n - Kd; D = Kd; wsel = wk; csel = ck; }
-    else { c = n - 2 * Kd; D = Vd; wsel = wv; csel = cv; }
-    const float4 wj = ld4(wsel + (int64_t)c * 4);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 16 * w + 4 * lg + r;
-        if (m < M) {
-            T* cb = csel + ((int64_t)m * D + c) * 4;
-            const float4 old = ld4(cb);
-            float xn = val[r];
-            T tmp;                                       // the conv sees the projection in the model dtype
-            st(&tmp, xn);
-            xn = ld(&tmp);
-            const float4 nw = make_float4(old.y, old.z, old.w, xn);
-            st4(cb, nw);
-            const float y = fmaf(wj.w, nw.w, fmaf(wj.z, nw.z, fmaf(wj.y, nw.y, wj.x * nw.x)));
-            st(qkv + (int64_t)m * (2 * Kd + Vd) + n, silu(y));
+            if (m < M) {
+                T* cb = csel + ((int64_t)m * D + c) * 4;
+                const float4 old = ld4(cb);
+                T tmp;                                       // the conv sees the projection in the model dtype
+                st(&tmp, z[r]);
+                const float xn = ld(&tmp);
+                const float4 nw = make_float4(old.y, old.z, old.w, xn);
+                st4(cb, nw);
+                const float y = fmaf(wj.w, nw.w, fmaf(wj.z, nw.z, fmaf(wj.y, nw.y, wj.x * nw.x)));
+                st(qkv + (int64_t)m * (2 * Kd + Vd) + n, silu(y));
+            }
         }
     }
 }
@@ -187,16 +210,17 @@ extern "C" int lina_gla_decode_inproj(const void* x, int64_t ldx, const void* w_
     LINA_REQUIRE(K % kstep == 0 && ldx % al == 0 && ldw % al == 0, "lina_gla_decode_inproj: K/ldx/ldw alignment");
     LINA_REQUIRE(normalizer != 0.0f, "lina_gla_decode_inproj: normalizer must be non-zero");
     const int has_clamp = (clamp_min == clamp_min) ? 1 : 0;
-    dim3 grid((unsigned)((2 * Kd + 2 * Vd + Kd) / 16), (unsigned)((B + 63) / 64));
-    if (dtype == LINA_F32)
-        LINA_LAUNCH((gla_inproj_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, ldx, (const float*)w_in, ldw,
-                    c1, c2, (const float*)wq, (const float*)wk, (const float*)wv, (float*)cq, (float*)ck, (float*)cv,
-                    (const float*)w2, (const float*)b2, (float*)qkv, (float*)g_out, gk, B, K, Kd, Vd, ln_eps,
-                    1.0f / normalizer, clamp_min, has_clamp);
-    else
-        LINA_LAUNCH((gla_inproj_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)w_in,
-                    ldw, c1, c2, (const bf16_t*)wq, (const bf16_t*)wk, (const bf16_t*)wv, (bf16_t*)cq, (bf16_t*)ck,
-                    (bf16_t*)cv, (const bf16_t*)w2, (const bf16_t*)b2, (bf16_t*)qkv, (bf16_t*)g_out, gk, B, K, Kd, Vd,
-                    ln_eps, 1.0f / normalizer, clamp_min, has_clamp);
+    // 64 rows x 32 columns per workgroup when the q|k|v|g regions allow it (fewer, fatter workgroups: one per CU at
+    // L169 -- the busiest CU's byte count sets the time, see linear_skinny.hip); else 64 x 16
+    const bool wide = Kd % 32 == 0 && Vd % 32 == 0;
+    const int cols = wide ? 32 : 16;
+    dim3 grid((unsigned)((2 * Kd + 2 * Vd + Kd) / cols), (unsigned)((B + 63) / 64));
+#define LINA_INPROJ(TT, NTT)                                                                                         \
+    LINA_LAUNCH((gla_inproj_kernel<TT, NTT>), grid, dim3(256), 0, stream, (const TT*)x, ldx, (const TT*)w_in, ldw, c1, \
+                c2, (const TT*)wq, (const TT*)wk, (const TT*)wv, (TT*)cq, (TT*)ck, (TT*)cv, (const TT*)w2,            \
+                (const TT*)b2, (TT*)qkv, (TT*)g_out, gk, B, K, Kd, Vd, ln_eps, 1.0f / normalizer, clamp_min, has_clamp)
+    if (dtype == LINA_F32) { if (wide) LINA_INPROJ(float, 2); else LINA_INPROJ(float, 1); }
+    else { if (wide) LINA_INPROJ(bf16_t, 2); else LINA_INPROJ(bf16_t, 1); }
+#undef LINA_INPROJ
     return check_launch("lina_gla_decode_inproj");
 }

@@ -21,32 +21,42 @@
 
 namespace lina {
 
-template <typename T, bool SWIGLU, bool LN, int MT>
+template <typename T, bool SWIGLU, bool LN, int MT, int NT>
 __global__ __launch_bounds__(256) void linear_skinny_kernel(
     const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw, const float* __restrict__ c1,
     const float* __restrict__ c2, const T* resid, int64_t ldr, T* out, int64_t ldo, int M, int N, int K, int Hd,
     int ln_dim, float ln_eps) {
     using F = Frag<T>;
-    constexpr int NB = SWIGLU ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) float s_acc[4][NB * MT][64][4];  // [wave][m-tile (x half)][lane][reg]
+    constexpr int NB = SWIGLU ? 2 : 1;      // weight-row halves (gate | value) per output column
+    constexpr int G = NB * NT;              // 16-row groups of W per workgroup
+    constexpr int U = (G + MT) * 8 <= 48 ? 8 : 4;   // k-steps in flight: (G + MT) * U 16-byte loads per lane
+    __shared__ __attribute__((aligned(16))) float s_acc[4][G * MT][64][4];   // [wave][group x m-tile][lane][reg]
     __shared__ float s_st[4][16 * MT][2];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * MT);
-    const int n = n0 + li;
-    const int n_rows = SWIGLU ? Hd : N;          // weight rows per half
-    const bool n_ok = n < n_rows;
+    const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * (16 * MT);
+    const int n_rows = SWIGLU ? Hd : N;     // weight rows per half
 
-    f32x4 acc[NB * MT];
+    f32x4 acc[G * MT];
 #pragma unroll
-    for (int i = 0; i < NB * MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float s1[MT], s2[MT];
+    for (int i = 0; i < G * MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // LayerNorm statistics without VALU work: sum_k a = (A . 1)[i][*], sum_k a^2 = diag(A . A^T) -- the A
+    // fragment is also a valid B fragment (same lane layout with i <-> n), so both are two more MFMAs per step
+    f32x4 st1[MT], st2[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    for (int i = 0; i < MT; ++i) { st1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; st2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    F f_ones;
+    f_ones.ones();
 
-    const T* wp = W + (int64_t)(n_ok ? n : 0) * ldw + F::KL * lg;
-    const T* wp2 = SWIGLU ? W + (int64_t)(n_ok ? Hd + n : 0) * ldw + F::KL * lg : nullptr;
+    const T* wp[G];
+    bool g_ok[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int n = n0 + 16 * (g % NT) + li;
+        g_ok[g] = n < n_rows;
+        wp[g] = W + (int64_t)(g_ok[g] ? (g / NT) * Hd + n : 0) * ldw + F::KL * lg;
+    }
     const T* ap[MT];
     bool m_ok[MT];
 #pragma unroll
@@ -57,16 +67,14 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
     }
 
     const int nsteps = K / F::KSTEP;
-    // U k-steps of loads are issued before their MFMAs: (NB + 4) * U independent 16-byte loads per lane
-    constexpr int U = 8;
     int ks = w;
     for (; ks + 4 * (U - 1) < nsteps; ks += 4 * U) {
-        F fb[U], fb2[U], fa[U][MT];
+        F fb[U][G], fa[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k0 = (ks + 4 * u) * F::KSTEP;
-            if (n_ok) fb[u].load(wp + k0); else fb[u].zero();
-            if (SWIGLU) { if (n_ok) fb2[u].load(wp2 + k0); else fb2[u].zero(); }
+#pragma unroll
+            for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[u][g].load(wp[g] + k0); else fb[u][g].zero(); }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[u][mt].load(ap[mt] + k0); else fa[u][mt].zero(); }
         }
@@ -74,53 +82,58 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                if (LN) fa[u][mt].stats(s1[mt], s2[mt]);
-                acc[mt] = F::mma(fa[u][mt], fb[u], acc[mt]);
-                if (SWIGLU) acc[MT + mt] = F::mma(fa[u][mt], fb2[u], acc[MT + mt]);
+                if (LN) {
+                    st1[mt] = F::mma(fa[u][mt], f_ones, st1[mt]);
+                    st2[mt] = F::mma(fa[u][mt], fa[u][mt], st2[mt]);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g * MT + mt] = F::mma(fa[u][mt], fb[u][g], acc[g * MT + mt]);
             }
     }
     for (; ks < nsteps; ks += 4) {
         const int k0 = ks * F::KSTEP;
-        F fb, fb2, fa[MT];
-        if (n_ok) fb.load(wp + k0); else fb.zero();
-        if (SWIGLU) { if (n_ok) fb2.load(wp2 + k0); else fb2.zero(); }
+        F fb[G], fa[MT];
+#pragma unroll
+        for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[g].load(wp[g] + k0); else fb[g].zero(); }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[mt].load(ap[mt] + k0); else fa[mt].zero(); }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            if (LN) fa[mt].stats(s1[mt], s2[mt]);
-            acc[mt] = F::mma(fa[mt], fb, acc[mt]);
-            if (SWIGLU) acc[MT + mt] = F::mma(fa[mt], fb2, acc[MT + mt]);
+            if (LN) {
+                st1[mt] = F::mma(fa[mt], f_ones, st1[mt]);
+                st2[mt] = F::mma(fa[mt], fa[mt], st2[mt]);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g * MT + mt] = F::mma(fa[mt], fb[g], acc[g * MT + mt]);
         }
     }
 
     // ---- in-workgroup split-K reduction ----
 #pragma unroll
-    for (int i = 0; i < NB * MT; ++i)
+    for (int i = 0; i < G * MT; ++i)
         *reinterpret_cast<float4*>(&s_acc[w][i][lane][0]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
     if (LN) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {   // sum over the 4 lane groups that share row li
-            float a = s1[mt], b = s2[mt];
-            a += shfl_xor(a, 16); b += shfl_xor(b, 16);
-            a += shfl_xor(a, 32); b += shfl_xor(b, 32);
-            if (lg == 0) { s_st[w][16 * mt + li][0] = a; s_st[w][16 * mt + li][1] = b; }
+        for (int mt = 0; mt < MT; ++mt) {   // D layout: lane (col li, rows 4lg+r); the diagonal sits at li == 4lg+r
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (li == 4 * lg + r) { s_st[w][16 * mt + li][0] = st1[mt][r]; s_st[w][16 * mt + li][1] = st2[mt][r]; }
         }
     }
     __syncthreads();
     if (w >= MT) return;
 
-    // wave w finalises m-tile w: D layout -> rows m0 + 16w + 4*lg + r, column n
-    float val[NB][4];
+    // wave w finalises m-tile w of every group: D layout -> rows m0 + 16w + 4*lg + r, column li of the tile
+    float val[G][4];
 #pragma unroll
-    for (int hb = 0; hb < NB; ++hb) {
-        float4 t = *reinterpret_cast<const float4*>(&s_acc[0][MT * hb + w][lane][0]);
+    for (int g = 0; g < G; ++g) {
+        float4 t = *reinterpret_cast<const float4*>(&s_acc[0][g * MT + w][lane][0]);
 #pragma unroll
         for (int ww = 1; ww < 4; ++ww) {
-            const float4 u = *reinterpret_cast<const float4*>(&s_acc[ww][MT * hb + w][lane][0]);
+            const float4 u = *reinterpret_cast<const float4*>(&s_acc[ww][g * MT + w][lane][0]);
             t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
-        val[hb][0] = t.x; val[hb][1] = t.y; val[hb][2] = t.z; val[hb][3] = t.w;
+        val[g][0] = t.x; val[g][1] = t.y; val[g][2] = t.z; val[g][3] = t.w;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -133,24 +146,29 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
             mu = a / (float)ln_dim;
             rstd = rsqrtf(fmaxf(b / (float)ln_dim - mu * mu, 0.f) + ln_eps);
         }
-        float res;
-        if (SWIGLU) {
-            float ga = val[0][r], gb = val[1][r];
-            if (n_ok) {
-                if (LN) { ga = rstd * (ga - mu * c1[n]); gb = rstd * (gb - mu * c1[Hd + n]); }
-                if (c2) { ga += c2[n]; gb += c2[Hd + n]; }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + 16 * j + li;
+            const bool n_ok = n < n_rows;
+            float res;
+            if (SWIGLU) {
+                float ga = val[j][r], gb = val[NT + j][r];
+                if (n_ok) {
+                    if (LN) { ga = rstd * (ga - mu * c1[n]); gb = rstd * (gb - mu * c1[Hd + n]); }
+                    if (c2) { ga += c2[n]; gb += c2[Hd + n]; }
+                }
+                res = n_ok ? silu(ga) * gb : ((n == Hd) ? 1.0f : 0.0f);   // bias column of the K-padded row
+            } else {
+                res = val[j][r];
+                if (n_ok) {
+                    if (LN) res = rstd * (res - mu * c1[n]);
+                    if (c2) res += c2[n];
+                }
             }
-            res = n_ok ? silu(ga) * gb : ((n == Hd) ? 1.0f : 0.0f);   // bias column of the K-padded row
-        } else {
-            res = val[0][r];
-            if (n_ok) {
-                if (LN) res = rstd * (res - mu * c1[n]);
-                if (c2) res += c2[n];
+            if (m < M && n < N) {
+                if (resid) res += ld(resid + (int64_t)m * ldr + n);
+                st(out + (int64_t)m * ldo + n, res);
             }
-        }
-        if (m < M && n < N) {
-            if (resid) res += ld(resid + (int64_t)m * ldr + n);
-            st(out + (int64_t)m * ldo + n, res);
         }
     }
 }
@@ -170,22 +188,33 @@ extern "C" int lina_linear_skinny(const void* A, int64_t lda, const void* W, int
     LINA_REQUIRE(lda % al == 0 && ldw % al == 0, "lina_linear_skinny: lda/ldw must keep rows 16-byte aligned");
     LINA_REQUIRE(ln_dim >= 0 && (ln_dim == 0 || c1), "lina_linear_skinny: LayerNorm folding needs c1");
     LINA_REQUIRE(swiglu_hidden >= 0 && swiglu_hidden <= N, "lina_linear_skinny: bad swiglu_hidden");
-    // Tile rows: every workgroup re-reads its rows of A; with few column tiles (N <= 2048) one 16-row m-tile per
-    // workgroup puts 4x more workgroups (CUs) on the job, each pulling 16 rows of A + 16 rows of W.
-    const bool small_n = (N + 15) / 16 <= 128 || M <= 16;
-    const int mrows = small_n ? 16 : 64;
-    dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + mrows - 1) / mrows));
+    // Tiling.  Measured on MI355X (tools/perf_skinny2.py): one CU ingests only ~30 GB/s on this access pattern,
+    // so the kernel time is (bytes pulled by the busiest CU) / 30 GB/s + ~2.4 us.  A workgroup pulls
+    // (16*MT rows of A + 16*NT*NB rows of W) * K elements; pick (MT, NT) minimising rounds * bytes-per-workgroup
+    // with rounds = ceil(workgroups / 256 CUs).
     const bool sw = swiglu_hidden > 0, ln = ln_dim > 0;
+    const int nb = sw ? 2 : 1;
+    int best_mt = 4, best_nt = 1;
+    long best_cost = -1;
+    const int cand[5][2] = {{1, 1}, {2, 1}, {4, 1}, {2, 2}, {4, 2}};
+    for (int c = 0; c < 5; ++c) {
+        const int mt = cand[c][0], nt = cand[c][1];
+        const long wgs = (long)((N + 16 * nt - 1) / (16 * nt)) * ((M + 16 * mt - 1) / (16 * mt));
+        const long cost = ((wgs + 255) / 256) * (16L * mt + 16L * nt * nb);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_mt = mt; best_nt = nt; }
+    }
+    dim3 grid((unsigned)((N + 16 * best_nt - 1) / (16 * best_nt)), (unsigned)((M + 16 * best_mt - 1) / (16 * best_mt)));
+#define LINA_LS_ONE(TT, SW, LNN, MTT, NTT)                                                                          \
+    LINA_LAUNCH((linear_skinny_kernel<TT, SW, LNN, MTT, NTT>), grid, dim3(256), 0, stream, (const TT*)A, lda,       \
+                (const TT*)W, ldw, c1, c2, (const TT*)resid, ldr, (TT*)out, ldo, M, N, K, swiglu_hidden, ln_dim,    \
+                ln_eps)
 #define LINA_LS(TT, SW, LNN)                                                                                        \
     do {                                                                                                            \
-        if (small_n)                                                                                                \
-            LINA_LAUNCH((linear_skinny_kernel<TT, SW, LNN, 1>), grid, dim3(256), 0, stream, (const TT*)A, lda,      \
-                        (const TT*)W, ldw, c1, c2, (const TT*)resid, ldr, (TT*)out, ldo, M, N, K, swiglu_hidden,   \
-                        ln_dim, ln_eps);                                                                            \
-        else                                                                                                        \
-            LINA_LAUNCH((linear_skinny_kernel<TT, SW, LNN, 4>), grid, dim3(256), 0, stream, (const TT*)A, lda,      \
-                        (const TT*)W, ldw, c1, c2, (const TT*)resid, ldr, (TT*)out, ldo, M, N, K, swiglu_hidden,   \
-                        ln_dim, ln_eps);                                                                            \
+        if (best_nt == 1 && best_mt == 1) LINA_LS_ONE(TT, SW, LNN, 1, 1);                                           \
+        else if (best_nt == 1 && best_mt == 2) LINA_LS_ONE(TT, SW, LNN, 2, 1);                                      \
+        else if (best_nt == 1) LINA_LS_ONE(TT, SW, LNN, 4, 1);                                                      \
+        else if (best_mt == 2) LINA_LS_ONE(TT, SW, LNN, 2, 2);                                                      \
+        else LINA_LS_ONE(TT, SW, LNN, 4, 2);                                                                        \
     } while (0)
     if (dtype == LINA_BF16) {
         if (sw && ln) LINA_LS(bf16_t, true, true); else if (sw) LINA_LS(bf16_t, true, false);
@@ -195,5 +224,6 @@ extern "C" int lina_linear_skinny(const void* A, int64_t lda, const void* W, int
         else if (ln) LINA_LS(float, false, true); else LINA_LS(float, false, false);
     }
 #undef LINA_LS
+#undef LINA_LS_ONE
     return check_launch("lina_linear_skinny");
 }

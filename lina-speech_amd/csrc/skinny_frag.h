@@ -12,6 +12,7 @@ template <> struct Frag<bf16_t> {
     uint4 v;
     __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
     __device__ __forceinline__ void zero() { v = make_uint4(0u, 0u, 0u, 0u); }
+    __device__ __forceinline__ void ones() { v = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u); }
     __device__ __forceinline__ void stats(float& s1, float& s2) const {
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -30,6 +31,7 @@ template <> struct Frag<float> {
     float4 v;
     __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
     __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ void ones() { v = make_float4(1.f, 1.f, 1.f, 1.f); }
     __device__ __forceinline__ void stats(float& s1, float& s2) const {
         s1 += (v.x + v.y) + (v.z + v.w);
         s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);

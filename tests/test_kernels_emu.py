@@ -65,7 +65,10 @@ def test_decode_update_rowsplit(emu, Dk, Dv, dtype):
     dict(M=7, N=40, K=160, dtype=torch.bfloat16, ln=True),
     dict(M=66, N=64, K=64, dtype=torch.bfloat16, ln=True, bias=True, swiglu=37),
     dict(M=3, N=17, K=352, dtype=torch.bfloat16, resid=True),
-    dict(M=40, N=2080, K=32, dtype=torch.bfloat16, ln=True, bias=True),      # > 128 column tiles: 64-row workgroups
+    dict(M=40, N=2080, K=32, dtype=torch.bfloat16, ln=True, bias=True),      # tiling (MT,NT) = (4,1)/(2,2) territory
+    dict(M=64, N=4112, K=32, dtype=torch.bfloat16, ln=True),                 # (4,2): 64 rows x 32 columns per workgroup
+    dict(M=32, N=4112, K=32, dtype=torch.float32, resid=True),               # (2,2)
+    dict(M=64, N=1376, K=64, dtype=torch.bfloat16, ln=True, bias=True, swiglu=1365),   # (2,1) with SwiGLU halves
 ])
 def test_linear_skinny(emu, kw):
     check_linear_skinny(DEV, **kw)
@@ -73,4 +76,5 @@ def test_linear_skinny(emu, kw):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_inproj_fused(emu, dtype):
-    check_inproj(DEV, B=5, K=64, Kd=32, Vd=48, dtype=dtype)
+    check_inproj(DEV, B=5, K=64, Kd=32, Vd=48, dtype=dtype)       # 16-column workgroups
+    check_inproj(DEV, B=70, K=64, Kd=64, Vd=32, dtype=dtype)      # 32-column workgroups, two row blocks
