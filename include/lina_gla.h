@@ -158,6 +158,21 @@ int lina_gla_decode_update(const void* q, const void* k, const void* v, const vo
                            int64_t v_sb, int64_t v_sh, int64_t g_sb, int64_t g_sh,
                            int dtype, int g_dtype, float scale, lina_stream_t stream);
 
+/* K1d + K5 in one launch: as lina_gla_decode_update, and the LAST of a head's Dk/64 row-block workgroups
+ * adds the partials, RMS-normalises over Dv, applies `norm_weight` and the swish gate and writes
+ * og [B,H,Dv] (model dtype).  gate: [B,H,Dv] addressed by (batch, head) strides.  counters: int32 [B*H],
+ * zero before the first call (each launch leaves them zero).  The inter-workgroup hand-off uses 8-byte
+ * agent-scope atomics on both sides and never spins (programming guide G16); results are bit-identical to
+ * lina_gla_decode_update followed by lina_rmsnorm_gate_fwd(n_partial = Dk/64).
+ * Replaces reference model/gla.py:186-220 at T = 1. */
+int lina_gla_decode_update_norm(const void* q, const void* k, const void* v, const void* gk,
+                                float* o_part, float* state, const void* gate, const void* norm_weight,
+                                void* og, int* counters, int B, int H, int Dk, int Dv,
+                                int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
+                                int64_t v_sb, int64_t v_sh, int64_t g_sb, int64_t g_sh,
+                                int64_t gate_sb, int64_t gate_sh, float eps,
+                                int dtype, int g_dtype, float scale, lina_stream_t stream);
+
 /* Decode-step projection with fused neighbours: out[M,N] = epi(A[M,K] . W[N,K]^T), M ~ batch rows.
  *   ln_dim > 0 : A is layer-normalised over its ln_dim features first, folded algebraically:
  *                out = rstd*(A.W^T - mu*c1) + c2   with W pre-scaled by the LN gamma,

@@ -40,6 +40,9 @@ PROTOTYPES = {
     "lina_swiglu": (C.c_int, [_p, _p, _i64, _i, _i64, _i64, _i, _p]),
     "lina_gla_decode_update": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64,
                                          _i64, _i64, _i, _i, _f, _p]),
+    "lina_gla_decode_update_norm": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i,
+                                              _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f,
+                                              _i, _i, _f, _p]),
     "lina_gla_decode_inproj": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                          _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _p]),
     "lina_linear_skinny": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _i, _i, _i, _i, _i, _f, _i, _p]),

@@ -163,11 +163,13 @@ extern "C" int lina_gla_recurrent_fwd(const void* q, const void* k, const void* 
 // ================================================================================================
 namespace lina {
 
-template <int DV, typename TIO, typename TG>
+template <int DV, typename TIO, typename TG, bool FUSE>
 __global__ __launch_bounds__(256) void gla_decode_rowsplit_kernel(
     const TIO* __restrict__ q, const TIO* __restrict__ k, const TIO* __restrict__ v, const TG* __restrict__ gk,
-    float* __restrict__ o_part, float* S, int H, int Dk, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
-    int64_t v_sb, int64_t v_sh, int64_t g_sb, int64_t g_sh, float scale) {
+    float* o_part, float* S, int H, int Dk, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
+    int64_t v_sb, int64_t v_sh, int64_t g_sb, int64_t g_sh, float scale,
+    const TIO* __restrict__ gate, int64_t gate_sb, int64_t gate_sh, const TIO* __restrict__ nw, float eps,
+    TIO* __restrict__ og, int* counters) {
     constexpr int RB = 64;            // rows per workgroup
     constexpr int CG = DV / 4;        // lanes per row
     constexpr int RPI = 256 / CG;     // rows per pass of the workgroup
@@ -210,32 +212,78 @@ __global__ __launch_bounds__(256) void gla_decode_rowsplit_kernel(
         acc.z = fmaf(qq, St[i].z, acc.z);
         acc.w = fmaf(qq, St[i].w, acc.w);
     }
-#pragma unroll
-    for (int i = 0; i < NP; ++i) st_nt4(tile + (int64_t)(rg + RPI * i) * DV, St[i]);
-
     *reinterpret_cast<float4*>(&s_red[rg * DV + 4 * cg]) = acc;
     __syncthreads();
-    if (tid < CG) {
+    const int64_t BH = gridDim.x;
+    if (tid < CG) {                     // wave 0 (CG <= 64): this row block's partial q.S for 4 columns
         float4 r = *reinterpret_cast<const float4*>(&s_red[4 * tid]);
 #pragma unroll
         for (int j = 1; j < RPI; ++j) {
             const float4 t = *reinterpret_cast<const float4*>(&s_red[j * DV + 4 * tid]);
             r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
         }
-        const int64_t BH = gridDim.x;
-        *reinterpret_cast<float4*>(o_part + ((int64_t)blockIdx.y * BH + bh) * DV + 4 * tid) = r;
+        float* op = o_part + ((int64_t)blockIdx.y * BH + bh) * DV + 4 * tid;
+        if (FUSE) { st_agent8(op, r.x, r.y); st_agent8(op + 2, r.z, r.w); }
+        else *reinterpret_cast<float4*>(op) = r;
     }
+    if (FUSE && tid < 64) {
+        // ---- K5 fused: the LAST of this head's Dk/64 row blocks adds the partials, RMS-normalises over Dv and
+        // applies weight and swish gate.  Hand-off = 8-byte agent-scope atomics on both sides (lina_dev.h); the
+        // state stores below are issued only afterwards so that this drain waits for 1 KiB, not for 64 KiB.
+        drain_stores();
+        int t = 0;
+        if (tid == 0) t = ticket_agent(&counters[bh]);
+        t = shfl_i(t, 0);
+        if (t == (int)gridDim.y - 1) {
+            if (tid == 0) counters[bh] = 0;                     // re-armed for the next launch
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid < CG) {
+                const float* xp = o_part + (int64_t)bh * DV + 4 * tid;
+                for (int p = 0; p < (int)gridDim.y; ++p) {      // same order as K5's n_partial loop
+                    const float2 lo = ld_agent8(xp + (int64_t)p * BH * DV), hi = ld_agent8(xp + (int64_t)p * BH * DV + 2);
+                    if (p == 0) a = make_float4(lo.x, lo.y, hi.x, hi.y);
+                    else { a.x += lo.x; a.y += lo.y; a.z += hi.x; a.w += hi.y; }
+                }
+            }
+            float ss = 0.0f;
+            ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            ss += shfl_xor(ss, 1); ss += shfl_xor(ss, 2); ss += shfl_xor(ss, 4);
+            ss += shfl_xor(ss, 8); ss += shfl_xor(ss, 16); ss += shfl_xor(ss, 32);
+            const float rs = rsqrtf(ss / (float)DV + eps);
+            if (tid < CG) {
+                a.x *= rs; a.y *= rs; a.z *= rs; a.w *= rs;
+                const float4 ww = ld4(nw + 4 * tid);
+                a.x *= ww.x; a.y *= ww.y; a.z *= ww.z; a.w *= ww.w;
+                const float4 gg = ld4(gate + b * gate_sb + h * gate_sh + 4 * tid);
+                a.x *= gg.x * sigmoidf(gg.x); a.y *= gg.y * sigmoidf(gg.y);
+                a.z *= gg.z * sigmoidf(gg.z); a.w *= gg.w * sigmoidf(gg.w);
+                st4(og + (int64_t)bh * DV + 4 * tid, a);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) st_nt4(tile + (int64_t)(rg + RPI * i) * DV, St[i]);
 }
 
 template <typename TIO, typename TG>
 static int launch_rowsplit(const void* q, const void* k, const void* v, const void* gk, float* o_part, float* S,
-                           int B, int H, int Dk, int Dv, const int64_t* st, float scale, lina_stream_t stream) {
+                           int B, int H, int Dk, int Dv, const int64_t* st, float scale, lina_stream_t stream,
+                           const void* gate = nullptr, int64_t gate_sb = 0, int64_t gate_sh = 0,
+                           const void* nw = nullptr, float eps = 0.f, void* og = nullptr, int* counters = nullptr) {
     dim3 grid((unsigned)(B * H), (unsigned)(Dk / 64));
-#define LINA_RS_CASE(DVV)                                                                                           \
-    case DVV:                                                                                                       \
-        LINA_LAUNCH((gla_decode_rowsplit_kernel<DVV, TIO, TG>), grid, dim3(256), 0, stream, (const TIO*)q,          \
-                    (const TIO*)k, (const TIO*)v, (const TG*)gk, o_part, S, H, Dk, st[0], st[1], st[2], st[3], st[4], \
-                    st[5], st[6], st[7], scale);                                                                    \
+    const bool fuse = og != nullptr;
+#define LINA_RS_CASE(DVV)                                                                                            \
+    case DVV:                                                                                                        \
+        if (fuse)                                                                                                    \
+            LINA_LAUNCH((gla_decode_rowsplit_kernel<DVV, TIO, TG, true>), grid, dim3(256), 0, stream, (const TIO*)q, \
+                        (const TIO*)k, (const TIO*)v, (const TG*)gk, o_part, S, H, Dk, st[0], st[1], st[2], st[3],   \
+                        st[4], st[5], st[6], st[7], scale, (const TIO*)gate, gate_sb, gate_sh, (const TIO*)nw, eps,  \
+                        (TIO*)og, counters);                                                                         \
+        else                                                                                                         \
+            LINA_LAUNCH((gla_decode_rowsplit_kernel<DVV, TIO, TG, false>), grid, dim3(256), 0, stream, (const TIO*)q, \
+                        (const TIO*)k, (const TIO*)v, (const TG*)gk, o_part, S, H, Dk, st[0], st[1], st[2], st[3],   \
+                        st[4], st[5], st[6], st[7], scale, (const TIO*)nullptr, (int64_t)0, (int64_t)0,              \
+                        (const TIO*)nullptr, 0.f, (TIO*)nullptr, (int*)nullptr);                                     \
         break;
     switch (Dv) {
         LINA_RS_CASE(64) LINA_RS_CASE(128) LINA_RS_CASE(256)
@@ -264,4 +312,30 @@ extern "C" int lina_gla_decode_update(const void* q, const void* k, const void* 
     if (dtype == LINA_BF16 && g_dtype == LINA_BF16)
         return launch_rowsplit<bf16_t, bf16_t>(q, k, v, gk, o_part, state, B, H, Dk, Dv, st, scale, stream);
     return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_update: dtype=f32 with bf16 gates is not built");
+}
+
+extern "C" int lina_gla_decode_update_norm(const void* q, const void* k, const void* v, const void* gk, float* o_part,
+                                           float* state, const void* gate, const void* norm_weight, void* og,
+                                           int* counters, int B, int H, int Dk, int Dv, int64_t q_sb, int64_t q_sh,
+                                           int64_t k_sb, int64_t k_sh, int64_t v_sb, int64_t v_sh, int64_t g_sb,
+                                           int64_t g_sh, int64_t gate_sb, int64_t gate_sh, float eps, int dtype,
+                                           int g_dtype, float scale, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(q && k && v && gk && o_part && state && gate && norm_weight && og && counters,
+                 "lina_gla_decode_update_norm: null pointer");
+    LINA_REQUIRE(B > 0 && H > 0, "lina_gla_decode_update_norm: B,H must be positive");
+    LINA_REQUIRE(valid_dtype(dtype) && valid_dtype(g_dtype), "lina_gla_decode_update_norm: bad dtype enum");
+    if (Dk <= 0 || Dk % 64 != 0) return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_update_norm: Dk=%d must be a multiple of 64", Dk);
+    LINA_REQUIRE(gate_sb % 4 == 0 && gate_sh % 4 == 0, "lina_gla_decode_update_norm: gate strides must be multiples of 4");
+    const int64_t st[8] = {q_sb, q_sh, k_sb, k_sh, v_sb, v_sh, g_sb, g_sh};
+    if (dtype == LINA_F32 && g_dtype == LINA_F32)
+        return launch_rowsplit<float, float>(q, k, v, gk, o_part, state, B, H, Dk, Dv, st, scale, stream, gate, gate_sb,
+                                             gate_sh, norm_weight, eps, og, counters);
+    if (dtype == LINA_BF16 && g_dtype == LINA_F32)
+        return launch_rowsplit<bf16_t, float>(q, k, v, gk, o_part, state, B, H, Dk, Dv, st, scale, stream, gate, gate_sb,
+                                              gate_sh, norm_weight, eps, og, counters);
+    if (dtype == LINA_BF16 && g_dtype == LINA_BF16)
+        return launch_rowsplit<bf16_t, bf16_t>(q, k, v, gk, o_part, state, B, H, Dk, Dv, st, scale, stream, gate,
+                                               gate_sb, gate_sh, norm_weight, eps, og, counters);
+    return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_update_norm: dtype=f32 with bf16 gates is not built");
 }

@@ -30,6 +30,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ int shfl_i(int v, int src) { return __shfl(v, src, 64); }
 
 __device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -66,6 +67,24 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint2 lo, uint2 hi) {
 __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+
+// ---- inter-workgroup hand-off inside one launch (programming guide, Guideline 16, "8-byte agent-scope
+// atomics on both sides"): payload written with relaxed agent-scope 8-byte atomic stores (sc1, write-through),
+// the storing wave drains them (vmcnt(0)), ONE lane takes a relaxed agent-scope ticket; the last arriver reads
+// the payload with relaxed agent-scope 8-byte atomic loads.  Placement-independent; nothing spins.
+__device__ __forceinline__ void st_agent8(float* p, float a, float b) {
+    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld_agent8(const float* p) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)(v & 0xffffffffu)), __uint_as_float((unsigned)(v >> 32)));
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ int ticket_agent(int* counter) {
+    return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // compiler-only fence: memory operations are not moved across it (keeps LDS-read hoisting, and with it

@@ -105,6 +105,7 @@ class _BlockPack:
         self.gk = torch.empty(B, self.Kd, dtype=torch.float32, device=dev)
         self.o_part = torch.empty(max(self.Dk // 64, 1), B, self.H, self.Dv, dtype=torch.float32, device=dev)
         self.og = torch.empty(B, self.H, self.Dv, dtype=dt, device=dev)
+        self.counters = torch.zeros(B * self.H, dtype=torch.int32, device=dev)
         self.s = torch.empty(B, self.hid_pad, dtype=dt, device=dev)
 
 
@@ -120,12 +121,13 @@ class _Part:
 
 class DecodeEngine:
     def __init__(self, model, x_enc: torch.Tensor, batch_size: int, state: Optional[Cache] = None,
-                 use_graph: Optional[bool] = None, n_split: Optional[int] = None):
+                 use_graph: Optional[bool] = None, n_split: Optional[int] = None, fuse_norm: bool = True):
         """``n_split`` > 1 cuts the batch into independent row ranges that run on parallel HIP streams inside
         the same graph: the step is a chain of ~100 short dependent launches, so two (or four) independent
         chains in flight hide each other's launch/drain latency; rows never interact."""
         rnn = model.attentive_rnn
         self.model = model
+        self.fuse_norm = fuse_norm and os.environ.get("LINA_DECODE_FUSE_NORM", "1") != "0"
         self.B = batch_size
         self.dev = x_enc.device
         self.state = state if state is not None else rnn.init_state(batch_size=batch_size)
@@ -180,7 +182,10 @@ class DecodeEngine:
         q = P.qkv[:, :P.Kd].view(B, P.H, P.Dk)
         k = P.qkv[:, P.Kd:2 * P.Kd].view(B, P.H, P.Dk)
         v = P.qkv[:, 2 * P.Kd:].view(B, P.H, P.Dv)
-        if P.row_split:
+        if P.row_split and self.fuse_norm:
+            ops.gla_decode_update_norm(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S, gate, P.gnw, P.og,
+                                       P.counters, P.eps_gate)
+        elif P.row_split:
             ops.gla_decode_update(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S)
             ops.rmsnorm_swish_gate(P.o_part, gate, P.gnw, P.eps_gate, n_partial=P.o_part.shape[0], out=P.og)
         else:

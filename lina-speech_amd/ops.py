@@ -349,3 +349,27 @@ def gla_decode_inproj(x, w_in, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_ou
                                          float(ln_eps), float(normalizer),
                                          float("nan") if clamp_min is None else float(clamp_min), _dt(x),
                                          be.stream(x)))
+
+
+def gla_decode_update_norm(q, k, v, gk, o_part, state, gate, norm_weight, og, counters, eps: float = 1e-5, scale=None):
+    """K1d + K5 in one launch (lina_gla_decode_update_norm): in-place state update and, by the last row-block
+    workgroup of each head, partial-sum + RMSNorm (x) swish gate -> og [B,H,Dv].  counters: int32 [B*H] zeros."""
+    be = _BACKEND
+    be.require(q, k, v, gk, o_part, state, gate, norm_weight, og, counters)
+    B, H, Dk = q.shape
+    Dv = v.shape[-1]
+    if state.dtype != torch.float32 or not state.is_contiguous() or tuple(state.shape) != (B, H, Dk, Dv):
+        raise ValueError("state must be contiguous fp32 [B,H,Dk,Dv]")
+    if o_part.dtype != torch.float32 or not o_part.is_contiguous() or tuple(o_part.shape) != (Dk // 64, B, H, Dv):
+        raise ValueError("o_part must be contiguous fp32 [Dk/64,B,H,Dv]")
+    if counters.dtype != torch.int32 or counters.numel() < B * H or not counters.is_contiguous():
+        raise ValueError("counters must be a contiguous int32 tensor with B*H entries")
+    if not og.is_contiguous() or og.dtype != q.dtype or gate.dtype != q.dtype or gate.stride(-1) != 1:
+        raise ValueError("og/gate must be model-dtype tensors, og contiguous, gate row-contiguous")
+    _check(be.lib.lina_gla_decode_update_norm(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(o_part), _ptr(state), _ptr(gate),
+                                              _ptr(norm_weight), _ptr(og), _ptr(counters), B, H, Dk, Dv,
+                                              q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0),
+                                              v.stride(1), gk.stride(0), gk.stride(1), gate.stride(0), gate.stride(1),
+                                              float(eps), _dt(q), _dt(gk),
+                                              float(Dk ** -0.5 if scale is None else scale), be.stream(q)))
+    return og

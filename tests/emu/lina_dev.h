@@ -121,6 +121,11 @@ static inline float shfl(float v, int src) {
     lina_emu::wave_exchange(&mine, 1, tab);
     return u2f(tab[src & 63]);
 }
+static inline int shfl_i(int v, int src) {
+    uint32_t mine = (uint32_t)v, tab[64];
+    lina_emu::wave_exchange(&mine, 1, tab);
+    return (int)tab[src & 63];
+}
 static inline int shfl_xor_i(int v, int mask) {
     uint32_t mine = (uint32_t)v, tab[64];
     lina_emu::wave_exchange(&mine, 1, tab);
@@ -208,6 +213,11 @@ static inline float dot2_bf16(uint32_t a, uint32_t b, float c) {
     return fmaf(bf2f((unsigned short)(a >> 16)), bf2f((unsigned short)(b >> 16)),
                 fmaf(bf2f((unsigned short)(a & 0xffff)), bf2f((unsigned short)(b & 0xffff)), c));
 }
+
+static inline void st_agent8(float* p, float a, float b) { p[0] = a; p[1] = b; }
+static inline float2 ld_agent8(const float* p) { return make_float2(p[0], p[1]); }
+static inline void drain_stores() {}
+static inline int ticket_agent(int* counter) { return (*counter)++; }
 
 static inline void cfence() { asm volatile("" ::: "memory"); }
 

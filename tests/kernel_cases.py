@@ -320,3 +320,28 @@ def check_inproj(dev, B, K, Kd, Vd, dtype):
         assert_close(qkv_b[:, :Kd], rq[:, 0], 1e-4, "inproj q vs oracle")
         rgk = O.gate_logsigmoid(zz[:, 2 * Kd + 2 * Vd:] @ w2.cpu().to(F64).t() + b2.cpu().to(F64), 16.0)
         assert_close(gk_b, rgk, 1e-4, "inproj gk vs oracle")
+
+
+def check_decode_update_norm(dev, B, H, Dk, Dv, dtype, repeats=1):
+    """K1d+K5 fused (last-arriver hand-off between the Dk/64 row-block workgroups of a head) must be BIT-identical to
+    K1d followed by K5(n_partial) -- repeated so that a stale/early read of a partial would show up."""
+    g = torch.Generator().manual_seed(12)
+    q, k, v, gk, h0 = make_gla_inputs(B, H, 1, Dk, Dv, dtype, dev, seed=13)
+    q, k, v, gk = q[:, :, 0], k[:, :, 0], v[:, :, 0], gk[:, :, 0].float()
+    ldz = H * Dv + 8
+    zrow = torch.randn(B, ldz, generator=g).to(dtype).to(dev)
+    gate = zrow[:, 4:4 + H * Dv].view(B, H, Dv)                      # strided view, like the projection row
+    w = (1 + 0.1 * torch.randn(Dv, generator=g)).to(dtype).to(dev)
+    NP = Dk // 64
+    counters = torch.zeros(B * H, dtype=torch.int32, device=dev)
+    S_a, S_b = h0.clone(), h0.clone()
+    for it in range(repeats):
+        op_a = torch.full((NP, B, H, Dv), float("nan"), device=dev)
+        op_b = torch.full((NP, B, H, Dv), float("nan"), device=dev)
+        ops.gla_decode_update(q, k, v, gk, op_a, S_a)
+        og_a = ops.rmsnorm_swish_gate(op_a, gate, w, 1e-5, n_partial=NP, out_dtype=dtype)
+        og_b = torch.full((B, H, Dv), float("nan"), dtype=dtype, device=dev)
+        ops.gla_decode_update_norm(q, k, v, gk, op_b, S_b, gate, w, og_b, counters, 1e-5)
+        assert torch.equal(S_a, S_b), f"state differs (iteration {it})"
+        assert torch.equal(og_a, og_b), f"fused norm output differs (iteration {it})"
+        assert int(counters.abs().sum()) == 0, "arrival counters must be left at zero"

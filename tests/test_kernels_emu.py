@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import gla_oracle as O
-from kernel_cases import (check_argmax, check_chunk, check_conv, check_decode_update, check_embed, check_inproj, check_linear_skinny,
+from kernel_cases import (check_argmax, check_chunk, check_conv, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
                           check_prologue, check_recurrent, check_rmsnorm, check_swiglu)
 
 DEV = "cpu"
@@ -78,3 +78,8 @@ def test_linear_skinny(emu, kw):
 def test_inproj_fused(emu, dtype):
     check_inproj(DEV, B=5, K=64, Kd=32, Vd=48, dtype=dtype)       # 16-column workgroups
     check_inproj(DEV, B=70, K=64, Kd=64, Vd=32, dtype=dtype)      # 32-column workgroups, two row blocks
+
+
+@pytest.mark.parametrize("Dk,Dv,dtype", [(64, 64, torch.float32), (256, 128, torch.bfloat16), (128, 256, torch.float32)])
+def test_decode_update_norm_fused(emu, Dk, Dv, dtype):
+    check_decode_update_norm(DEV, B=2, H=2, Dk=Dk, Dv=Dv, dtype=dtype, repeats=2)

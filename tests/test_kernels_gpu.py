@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from kernel_cases import (assert_close, check_argmax, check_chunk, check_conv, check_decode_update, check_embed, check_inproj,
+from kernel_cases import (assert_close, check_argmax, check_chunk, check_conv, check_decode_update, check_decode_update_norm, check_embed, check_inproj,
                           check_linear_skinny, check_prologue, check_recurrent, check_rmsnorm, check_swiglu,
                           make_gla_inputs, oracle_gla)
 from lina_speech_amd import ops
@@ -83,6 +83,13 @@ def test_linear_skinny(hip, kw):
                                               (64, 1024, 1024, 1024, torch.bfloat16), (70, 256, 128, 256, torch.bfloat16)])
 def test_inproj_fused(hip, B, K, Kd, Vd, dtype):
     check_inproj(DEV, B=B, K=K, Kd=Kd, Vd=Vd, dtype=dtype)
+
+
+@pytest.mark.parametrize("B,H,Dk,Dv,dtype,rep", [(3, 2, 64, 64, torch.float32, 3), (5, 4, 256, 128, torch.bfloat16, 3),
+                                                  (64, 4, 256, 256, torch.bfloat16, 40), (64, 4, 256, 256, torch.float32, 20),
+                                                  (200, 4, 256, 256, torch.bfloat16, 10)])
+def test_decode_update_norm_fused(hip, B, H, Dk, Dv, dtype, rep):
+    check_decode_update_norm(DEV, B=B, H=H, Dk=Dk, Dv=Dv, dtype=dtype, repeats=rep)
 
 
 # ---------------------------------------------------------------------------------------------
