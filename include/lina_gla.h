@@ -204,6 +204,16 @@ int lina_gla_decode_inproj(const void* x, int64_t ldx, const void* w_in, int64_t
                            int B, int K, int Kd, int Vd, int W, int R,
                            float ln_eps, float normalizer, float clamp_min, int dtype, lina_stream_t stream);
 
+/* Blind cross-attention at T = 1, text side precomputed (reference model/crossatt.py:105-155).
+ * step1: q = LayerNorm(q_lin[b]); att1[b] = softmax(q . kk[b]^T * scale); xp[b] = att1[b] . pe
+ * step2: att2[b] = softmax(xp[b] . pe^T * scale); x[b] += att2[b] . vv[b]      (xp = pos_net output)
+ *   q_lin, xp, x: [B,d];  kk, vv: [B,T_txt,d];  pe: [T_txt,d];  att1/att2: rows of length T_txt, att_sb apart. */
+int lina_cross_att_step1(const void* q_lin, const void* ln_w, const void* ln_b, float ln_eps,
+                         const void* kk, const void* pe, void* att1, int64_t att_sb, void* xp,
+                         int B, int T_txt, int d, float scale, int dtype, lina_stream_t stream);
+int lina_cross_att_step2(const void* xp, const void* pe, const void* vv, void* att2, int64_t att_sb, void* x,
+                         int B, int T_txt, int d, float scale, int dtype, lina_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,172 @@
+// cross_att.hip -- the two attention steps of the blind cross-attention at T = 1 (SURVEY.md 8(f) f-1;
+// reference model/crossatt.py:105-155 with the eager softmax(q k^T / sqrt d) v of :13-19), one workgroup
+// per utterance row, text-side tensors precomputed once per utterance (BlindCrossAttention.prepare):
+//   step 1: q = LayerNorm(q_lin) ; att1 = softmax(q . K_b^T * scale) ; xp = att1 . PE          (:114,143)
+//   step 2: att2 = softmax(xp' . PE^T * scale) ; x += att2 . V_b                                   (:149, gla.py:362)
+// (xp' = xp after the pos_net GLA block, :145).  Replaces ~11 small torch launches per token.
+// Scores live in LDS; the d-long dot products are split over the 256 threads (4 elements per lane per trip,
+// wave64 shuffle + LDS reduction), the weighted sums over the T_txt rows are column-parallel.
+#include <lina_dev.h>
+#include "lina_common.h"
+
+namespace lina {
+
+constexpr int kCaMaxT = 1024;   // text positions held in LDS
+
+__device__ __forceinline__ float block_sum(float v, float* s_red) {   // 256 threads
+    v += shfl_xor(v, 1); v += shfl_xor(v, 2); v += shfl_xor(v, 4);
+    v += shfl_xor(v, 8); v += shfl_xor(v, 16); v += shfl_xor(v, 32);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+__device__ __forceinline__ float block_max(float v, float* s_red) {
+    v = fmaxf(v, shfl_xor(v, 1)); v = fmaxf(v, shfl_xor(v, 2)); v = fmaxf(v, shfl_xor(v, 4));
+    v = fmaxf(v, shfl_xor(v, 8)); v = fmaxf(v, shfl_xor(v, 16)); v = fmaxf(v, shfl_xor(v, 32));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+}
+
+// scores[t] = scale * <vec, M[t,:]> for t < T, then softmax in place (s_sc); every thread returns with s_sc valid
+template <typename T>
+__device__ __forceinline__ void scores_softmax(const float* s_vec, const T* __restrict__ Mrows, int64_t row_stride,
+                                               int Tn, int d, float scale, float* s_sc, float* s_red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int t = w; t < Tn; t += 4) {          // one wave per text row
+        float acc = 0.0f;
+        for (int e = lane * 4; e < d; e += 256) {
+            const float4 m = ld4(Mrows + (int64_t)t * row_stride + e);
+            acc = fmaf(m.x, s_vec[e], fmaf(m.y, s_vec[e + 1], fmaf(m.z, s_vec[e + 2], fmaf(m.w, s_vec[e + 3], acc))));
+        }
+        acc += shfl_xor(acc, 1); acc += shfl_xor(acc, 2); acc += shfl_xor(acc, 4);
+        acc += shfl_xor(acc, 8); acc += shfl_xor(acc, 16); acc += shfl_xor(acc, 32);
+        if (lane == 0) s_sc[t] = acc * scale;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = threadIdx.x; t < Tn; t += 256) mx = fmaxf(mx, s_sc[t]);
+    mx = block_max(mx, s_red);
+    float sum = 0.0f;
+    for (int t = threadIdx.x; t < Tn; t += 256) { const float e = expf(s_sc[t] - mx); s_sc[t] = e; sum += e; }
+    sum = block_sum(sum, s_red);
+    const float inv = 1.0f / sum;
+    for (int t = threadIdx.x; t < Tn; t += 256) s_sc[t] *= inv;
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cross_att_step1_kernel(
+    const T* __restrict__ qlin, const T* __restrict__ ln_w, const T* __restrict__ ln_b, float ln_eps,
+    const T* __restrict__ kk, const T* __restrict__ pe, T* __restrict__ att1, int64_t att_sb, T* __restrict__ xp,
+    int Tn, int d, float scale) {
+    LINA_DYN_SMEM(smem);
+    float* s_q = reinterpret_cast<float*>(smem);            // [d]
+    float* s_sc = s_q + d;                                  // [Tn]
+    __shared__ float s_red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    // LayerNorm of the projected query (two-pass, fp32)
+    float s = 0.0f;
+    for (int e = tid; e < d; e += 256) { const float x = ld(qlin + (int64_t)b * d + e); s_q[e] = x; s += x; }
+    const float mu = block_sum(s, s_red) / (float)d;
+    float vs = 0.0f;
+    for (int e = tid; e < d; e += 256) { const float c = s_q[e] - mu; vs += c * c; }
+    const float rstd = rsqrtf(block_sum(vs, s_red) / (float)d + ln_eps);
+    for (int e = tid; e < d; e += 256) {
+        T tmp;                                               // the reference rounds the LN output to the model dtype
+        st(&tmp, (s_q[e] - mu) * rstd * ld(ln_w + e) + ld(ln_b + e));
+        s_q[e] = ld(&tmp);
+    }
+    __syncthreads();
+    scores_softmax<T>(s_q, kk + (int64_t)b * Tn * d, d, Tn, d, scale, s_sc, s_red);
+    for (int t = tid; t < Tn; t += 256) {
+        T tmp;
+        st(&tmp, s_sc[t]);
+        att1[(int64_t)b * att_sb + t] = tmp;
+        s_sc[t] = ld(&tmp);                                  // att1 is used in the model dtype downstream
+    }
+    __syncthreads();
+    for (int e = tid * 4; e < d; e += 1024) {               // xp = att1 . PE   (column-parallel)
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < Tn; ++t) {
+            const float a = s_sc[t];
+            const float4 p = ld4(pe + (int64_t)t * d + e);
+            acc.x = fmaf(a, p.x, acc.x); acc.y = fmaf(a, p.y, acc.y); acc.z = fmaf(a, p.z, acc.z); acc.w = fmaf(a, p.w, acc.w);
+        }
+        st4(xp + (int64_t)b * d + e, acc);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cross_att_step2_kernel(
+    const T* __restrict__ xp, const T* __restrict__ pe, const T* __restrict__ vv, T* __restrict__ att2,
+    int64_t att_sb, T* x, int Tn, int d, float scale) {
+    LINA_DYN_SMEM(smem);
+    float* s_q = reinterpret_cast<float*>(smem);
+    float* s_sc = s_q + d;
+    __shared__ float s_red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int e = tid; e < d; e += 256) s_q[e] = ld(xp + (int64_t)b * d + e);
+    __syncthreads();
+    scores_softmax<T>(s_q, pe, d, Tn, d, scale, s_sc, s_red);
+    for (int t = tid; t < Tn; t += 256) {
+        T tmp;
+        st(&tmp, s_sc[t]);
+        att2[(int64_t)b * att_sb + t] = tmp;
+        s_sc[t] = ld(&tmp);
+    }
+    __syncthreads();
+    for (int e = tid * 4; e < d; e += 1024) {               // x += att2 . V_b
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < Tn; ++t) {
+            const float a = s_sc[t];
+            const float4 p = ld4(vv + ((int64_t)b * Tn + t) * d + e);
+            acc.x = fmaf(a, p.x, acc.x); acc.y = fmaf(a, p.y, acc.y); acc.z = fmaf(a, p.z, acc.z); acc.w = fmaf(a, p.w, acc.w);
+        }
+        T tmp4[4];
+        st4(tmp4, acc);                                      // bmm result in the model dtype, then the residual add
+        const float4 o = ld4(tmp4), r = ld4(x + (int64_t)b * d + e);
+        st4(x + (int64_t)b * d + e, make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w));
+    }
+}
+
+}  // namespace lina
+
+extern "C" int lina_cross_att_step1(const void* q_lin, const void* ln_w, const void* ln_b, float ln_eps, const void* kk,
+                                    const void* pe, void* att1, int64_t att_sb, void* xp, int B, int Tn, int d,
+                                    float scale, int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(q_lin && ln_w && ln_b && kk && pe && att1 && xp, "lina_cross_att_step1: null pointer");
+    LINA_REQUIRE(B > 0 && Tn > 0 && Tn <= kCaMaxT, "lina_cross_att_step1: B > 0, 0 < T_txt <= %d", kCaMaxT);
+    LINA_REQUIRE(d > 0 && d % 4 == 0 && d <= 8192, "lina_cross_att_step1: d must be a multiple of 4, <= 8192");
+    LINA_REQUIRE(valid_dtype(dtype), "lina_cross_att_step1: bad dtype %d", dtype);
+    const size_t smem = sizeof(float) * (size_t)(d + Tn);
+    if (dtype == LINA_F32)
+        LINA_LAUNCH((cross_att_step1_kernel<float>), dim3((unsigned)B), dim3(256), smem, stream, (const float*)q_lin,
+                    (const float*)ln_w, (const float*)ln_b, ln_eps, (const float*)kk, (const float*)pe, (float*)att1,
+                    att_sb, (float*)xp, Tn, d, scale);
+    else
+        LINA_LAUNCH((cross_att_step1_kernel<bf16_t>), dim3((unsigned)B), dim3(256), smem, stream, (const bf16_t*)q_lin,
+                    (const bf16_t*)ln_w, (const bf16_t*)ln_b, ln_eps, (const bf16_t*)kk, (const bf16_t*)pe,
+                    (bf16_t*)att1, att_sb, (bf16_t*)xp, Tn, d, scale);
+    return check_launch("lina_cross_att_step1");
+}
+
+extern "C" int lina_cross_att_step2(const void* xp, const void* pe, const void* vv, void* att2, int64_t att_sb, void* x,
+                                    int B, int Tn, int d, float scale, int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(xp && pe && vv && att2 && x, "lina_cross_att_step2: null pointer");
+    LINA_REQUIRE(B > 0 && Tn > 0 && Tn <= kCaMaxT, "lina_cross_att_step2: B > 0, 0 < T_txt <= %d", kCaMaxT);
+    LINA_REQUIRE(d > 0 && d % 4 == 0 && d <= 8192, "lina_cross_att_step2: d must be a multiple of 4, <= 8192");
+    LINA_REQUIRE(valid_dtype(dtype), "lina_cross_att_step2: bad dtype %d", dtype);
+    const size_t smem = sizeof(float) * (size_t)(d + Tn);
+    if (dtype == LINA_F32)
+        LINA_LAUNCH((cross_att_step2_kernel<float>), dim3((unsigned)B), dim3(256), smem, stream, (const float*)xp,
+                    (const float*)pe, (const float*)vv, (float*)att2, att_sb, (float*)x, Tn, d, scale);
+    else
+        LINA_LAUNCH((cross_att_step2_kernel<bf16_t>), dim3((unsigned)B), dim3(256), smem, stream, (const bf16_t*)xp,
+                    (const bf16_t*)pe, (const bf16_t*)vv, (bf16_t*)att2, att_sb, (bf16_t*)x, Tn, d, scale);
+    return check_launch("lina_cross_att_step2");
+}

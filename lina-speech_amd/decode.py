@@ -12,7 +12,7 @@ MI355X: per GLA block SIX launches instead of ~30 --
 
 The text side of the cross-attention is projected once (BlindCrossAttention.prepare).
 State lives in the caller-visible ``Cache`` tensors (reference layout, updated in place).
-Only the small cross-attention softmax/bmm glue stays on torch-ROCm.
+The blind cross-attention is 3 more launches (query projection + lina_cross_att_step1/2) around its pos_net block.
 """
 from __future__ import annotations
 
@@ -117,6 +117,7 @@ class _Part:
         self.kk, self.vv = kk, vv
         self.x = torch.zeros(hi - lo, d, dtype=dtype, device=dev)       # residual stream
         self.xp = torch.zeros(hi - lo, d, dtype=dtype, device=dev)      # pos_net stream
+        self.q_lin = torch.zeros(hi - lo, d, dtype=dtype, device=dev)   # projected cross-attention query
 
 
 class DecodeEngine:
@@ -200,25 +201,21 @@ class DecodeEngine:
         return x
 
     def _cross(self, part, x):
+        """x += blind cross-attention (3 launches + the pos_net block); attention weights go to self._att."""
         ca = self.ca
-        qq = F.layer_norm(ops.linear_skinny(x, self.ca_qw, c2=self.ca_qb), (x.shape[-1],), ca.ln_q.weight,
-                          ca.ln_q.bias, ca.ln_q.eps)
-        att1 = torch.softmax(torch.bmm(part.kk, qq.unsqueeze(-1)).squeeze(-1) * self.att_scale, dim=-1)  # [b,Ttxt]
-        torch.matmul(att1, self.pe, out=part.xp)
-        xp = self._block(part.xp, part.packs[-1])
-        att2 = torch.softmax((xp @ self.pe.t()) * self.att_scale, dim=-1)
-        out = torch.bmm(att2.unsqueeze(1), part.vv).squeeze(1)
         att = self._att[part.lo:part.hi]
-        att[:, 0, 0].copy_(att1)
-        att[:, 1, 0].copy_(att2)
-        return out
+        q_lin = ops.linear_skinny(x, self.ca_qw, c2=self.ca_qb, out=part.q_lin)
+        ops.cross_att_step1(q_lin, ca.ln_q.weight, ca.ln_q.bias, ca.ln_q.eps, part.kk, self.pe, att[:, 0, 0], part.xp,
+                            self.att_scale)
+        self._block(part.xp, part.packs[-1])
+        ops.cross_att_step2(part.xp, self.pe, part.vv, att[:, 1, 0], x, self.att_scale)
 
     def _core_part(self, part, y):
         x = part.x
         x.copy_(y[part.lo:part.hi])
         for P in part.packs[:self.n_enc]:
             self._block(x, P)
-        x.add_(self._cross(part, x))
+        self._cross(part, x)
         for P in part.packs[self.n_enc:-1]:
             self._block(x, P)
         ops.linear_skinny(x, self.w_head, out=self._logits[part.lo:part.hi])

@@ -373,3 +373,24 @@ def gla_decode_update_norm(q, k, v, gk, o_part, state, gate, norm_weight, og, co
                                               float(eps), _dt(q), _dt(gk),
                                               float(Dk ** -0.5 if scale is None else scale), be.stream(q)))
     return og
+
+
+def cross_att_step1(q_lin, ln_w, ln_b, ln_eps, kk, pe, att1, xp, scale):
+    """Blind cross-attention step 1 (see lina_gla.h).  att1: [B,T_txt] view (row stride free), written in place."""
+    be = _BACKEND
+    be.require(q_lin, ln_w, ln_b, kk, pe, att1, xp)
+    B, d = q_lin.shape
+    Tn = kk.shape[1]
+    _check(be.lib.lina_cross_att_step1(_ptr(q_lin), _ptr(ln_w), _ptr(ln_b), float(ln_eps), _ptr(kk), _ptr(pe),
+                                       _ptr(att1), att1.stride(0), _ptr(xp), B, Tn, d, float(scale), _dt(q_lin),
+                                       be.stream(q_lin)))
+
+
+def cross_att_step2(xp, pe, vv, att2, x, scale):
+    """Blind cross-attention step 2: x += softmax(xp . pe^T * scale) . vv   (see lina_gla.h)."""
+    be = _BACKEND
+    be.require(xp, pe, vv, att2, x)
+    B, d = xp.shape
+    Tn = vv.shape[1]
+    _check(be.lib.lina_cross_att_step2(_ptr(xp), _ptr(pe), _ptr(vv), _ptr(att2), att2.stride(0), _ptr(x), B, Tn, d,
+                                       float(scale), _dt(xp), be.stream(xp)))

@@ -345,3 +345,28 @@ def check_decode_update_norm(dev, B, H, Dk, Dv, dtype, repeats=1):
         assert torch.equal(S_a, S_b), f"state differs (iteration {it})"
         assert torch.equal(og_a.reshape(B, H, Dv), og_b), f"fused norm output differs (iteration {it})"
         assert int(counters.abs().sum()) == 0, "arrival counters must be left at zero"
+
+
+def check_cross_att(dev, B, Tn, d, dtype):
+    """lina_cross_att_step1/2 vs the eager attention of reference crossatt.py:13-19,114,143,149 in fp64."""
+    g = torch.Generator().manual_seed(14)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dtype).to(dev)
+    q_lin, kk, vv, pe = mk(B, d), mk(B, Tn, d), mk(B, Tn, d), mk(Tn, d)
+    ln_w, ln_b = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype).to(dev), (0.1 * torch.randn(d, generator=g)).to(dtype).to(dev)
+    x = mk(B, d)
+    scale = d ** -0.5
+    att = torch.zeros(B, 2, 1, Tn, dtype=dtype, device=dev)
+    xp = torch.empty(B, d, dtype=dtype, device=dev)
+    ops.cross_att_step1(q_lin, ln_w, ln_b, 1e-5, kk, pe, att[:, 0, 0], xp, scale)
+    c = lambda t: t.cpu().to(F64)
+    q = F.layer_norm(c(q_lin), (d,), c(ln_w), c(ln_b), 1e-5)
+    a1 = torch.softmax(torch.einsum("bd,btd->bt", q, c(kk)) * scale, -1)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert_close(att[:, 0, 0], a1, tol, "cross-att att1")
+    assert_close(xp, a1 @ c(pe), tol, "cross-att xp")
+    xp2 = mk(B, d)
+    x0 = x.clone()
+    ops.cross_att_step2(xp2, pe, vv, att[:, 1, 0], x, scale)
+    a2 = torch.softmax(c(xp2) @ c(pe).t() * scale, -1)
+    assert_close(att[:, 1, 0], a2, tol, "cross-att att2")
+    assert_close(x, c(x0) + torch.einsum("bt,btd->bd", a2, c(vv)), tol, "cross-att x")
