@@ -82,7 +82,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 
     const bf16_t* gsrc[4] = {q + b * sq.b + h * sq.h, k + b * sk.b + h * sk.h, gk + b * sg.b + h * sg.h,
                              v + b * sv.b + h * sv.h};
-    const int64_t gst[4] = {sq.t, sk.t, sg.t, sv.t};
+    const unsigned gst[4] = {(unsigned)sq.t, (unsigned)sk.t, (unsigned)sg.t, (unsigned)sv.t};   // < 2^31 (launcher)
     bf16_t* ob = o + b * so.b + h * so.h;
 
     // wave w DMAs rows 2w, 2w+1 of each raw tile: one instruction = 2 rows x 512 B, 16 B per lane.
@@ -90,8 +90,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     auto dma_chunk = [&](int t_first, int a_lo, int a_hi) {
 #pragma unroll
         for (int a = a_lo; a < a_hi; ++a) {
-            const int t = min(t_first + 2 * w + (lane >> 5), T - 1);
-            dma16_to_lds(gsrc[a] + t * gst[a] + 8 * (lane & 31), &s_raw[a][(2 * w) * DK]);
+            const unsigned t = (unsigned)min(t_first + 2 * w + (lane >> 5), T - 1);
+            dma16_to_lds(gsrc[a] + (t * gst[a] + 8u * (unsigned)(lane & 31)), &s_raw[a][(2 * w) * DK]);   // uniform base + 32-bit lane offset
         }
     };
     // this thread's 2 rows x 4 channels of clamped gates, summed down the 2 rows (rows >= nrem count as 0)
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     int t0 = 0;
     while (t0 < T) {
         // keep the per-lane index arithmetic INSIDE the loop: hoisted, it would live in (and spill from) VGPRs
-        opaque(tid); opaque(lane); opaque(li); opaque(lg); opaque(co);
+        opaque(tid); opaque(lane); opaque(li); opaque(lg); opaque(co); opaque(rg); opaque(w);
         const int nrem = T - t0;
         int n = min(C, nrem);
         // ---------------- phase A: gate scan, scaled operands ----------------
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         {
             const int row = tid >> 5, seg = tid & 31;      // 32 lanes x 16 B = one 512-byte output row
             if (row < n)
-                *reinterpret_cast<uint4*>(ob + (t0 + row) * so.t + 8 * seg) =
+                *reinterpret_cast<uint4*>(ob + ((unsigned)(t0 + row) * (unsigned)so.t + 8u * (unsigned)seg)) =
                     *reinterpret_cast<const uint4*>(&s_o[row * SQ + 8 * seg]);
         }
         __syncthreads();   // (4) s_o (aliases the scan totals) has been read
@@ -308,6 +308,8 @@ static bool full_ok(int Dk, int Dv, int dtype, const void* q, const void* k, con
     if (dtype != LINA_BF16 || g_dtype != LINA_BF16 || Dk != 256 || Dv != 256) return false;
     auto al = [](lina_bht_strides s, int m) { return s.b % m == 0 && s.h % m == 0 && s.t % m == 0; };
     if (!al(sq, 8) || !al(sk, 8) || !al(sv, 8) || !al(so, 8) || !al(sg, 8)) return false;
+    auto small = [](lina_bht_strides s) { return s.t >= 0 && s.t < (1LL << 20); };   // 32-bit in-sequence offsets
+    if (!small(sq) || !small(sk) || !small(sv) || !small(so) || !small(sg)) return false;
     auto p16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
     return p16(q) && p16(k) && p16(v) && p16(gk) && p16(o);
 }
@@ -316,7 +318,9 @@ int launch_chunk_full(const void* q, const void* k, const void* v, const void* g
                       float* ht, int B, int H, int T, int Dk, int Dv, lina_bht_strides sq, lina_bht_strides sk,
                       lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides so, int dtype, int g_dtype,
                       float scale, lina_stream_t stream, bool* taken) {
-    *taken = full_ok(Dk, Dv, dtype, q, k, v, gk, o, g_dtype, sq, sk, sv, sg, so);
+    auto fits32 = [T](lina_bht_strides st) { return (int64_t)T * st.t < (1LL << 31); };
+    *taken = full_ok(Dk, Dv, dtype, q, k, v, gk, o, g_dtype, sq, sk, sv, sg, so) && fits32(sq) && fits32(sk) &&
+             fits32(sv) && fits32(sg) && fits32(so);
     if (!*taken) return LINA_OK;
     dim3 grid((unsigned)(B * H));
     LINA_LAUNCH(gla_chunk_bf16_h256_kernel, grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
