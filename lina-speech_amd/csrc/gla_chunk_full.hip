@@ -151,7 +151,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     int t0 = 0;
     while (t0 < T) {
         // keep the per-lane index arithmetic INSIDE the loop: hoisted, it would live in (and spill from) VGPRs
-        opaque(tid); opaque(lane); opaque(li); opaque(lg); opaque(co); opaque(rg); opaque(w);
+        // (only tid is carried across iterations; everything else is re-derived from it)
+        opaque(tid);
+        lane = tid & 63; w = tid >> 6; li = lane & 15; lg = lane >> 4; co = lane; rg = w;
         const int nrem = T - t0;
         int n = min(C, nrem);
         // ---------------- phase A: gate scan, scaled operands ----------------
