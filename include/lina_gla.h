@@ -214,6 +214,19 @@ int lina_cross_att_step1(const void* q_lin, const void* ln_w, const void* ln_b, 
 int lina_cross_att_step2(const void* xp, const void* pe, const void* vv, void* att2, int64_t att_sb, void* x,
                          int B, int T_txt, int d, float scale, int dtype, lina_stream_t stream);
 
+/* The same two attention steps as spread kernels (>= 256 workgroups on the text-side tensors; the engine uses
+ * these with lina_linear_skinny for  xp = att1 . pe  and  scores2 = xp . pe^T):
+ *   lina_cross_scores     : scores[b,t] = scale * <LayerNorm(q_lin[b]), kk[b,t,:]>            (fp32 [B,T_txt])
+ *   lina_softmax_rows     : att[b, 0:Tn] = softmax(x[b, 0:Tn] * scale)  -> strided `att` rows AND a contiguous
+ *                           zero-padded copy attc [B, Tp] (Tp >= Tn) that feeds the next projection
+ *   lina_weighted_rows_add: x[b,:] += sum_t attc[b,t] * vv[b,t,:]                                              */
+int lina_cross_scores(const void* q_lin, const void* ln_w, const void* ln_b, float ln_eps, const void* kk,
+                      float* scores, int B, int T_txt, int d, float scale, int dtype, lina_stream_t stream);
+int lina_softmax_rows(const void* x, int64_t x_sb, int x_dtype, float scale, void* att, int64_t att_sb,
+                      void* attc, int B, int T_txt, int Tp, int dtype, lina_stream_t stream);
+int lina_weighted_rows_add(const void* attc, int Tp, const void* vv, void* x, int B, int T_txt, int d,
+                           int dtype, lina_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,93 @@ __device__ __forceinline__ void scores_softmax(const float* s_vec, const T* __re
     __syncthreads();
 }
 
+// ---- spread versions (one workgroup per utterance row pulls 256 KiB through a single CU: 30-40 us; these
+// ---- put >= 256 workgroups on the text-side tensors) ----------------------------------------------------------
+
+// scores[b,t] = scale * <LN(q_lin[b]), kk[b,t,:]>   grid (ceil(Tn/16), B): 4 waves x 4 text rows each
+template <typename T>
+__global__ __launch_bounds__(256) void cross_scores_kernel(
+    const T* __restrict__ qlin, const T* __restrict__ ln_w, const T* __restrict__ ln_b, float ln_eps,
+    const T* __restrict__ kk, float* __restrict__ scores, int Tn, int d, float scale) {
+    LINA_DYN_SMEM(smem);
+    float* s_q = reinterpret_cast<float*>(smem);            // [d]
+    __shared__ float s_red[4];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float s = 0.0f;
+    for (int e = tid; e < d; e += 256) { const float x = ld(qlin + (int64_t)b * d + e); s_q[e] = x; s += x; }
+    const float mu = block_sum(s, s_red) / (float)d;
+    float vs = 0.0f;
+    for (int e = tid; e < d; e += 256) { const float c = s_q[e] - mu; vs += c * c; }
+    const float rstd = rsqrtf(block_sum(vs, s_red) / (float)d + ln_eps);
+    for (int e = tid; e < d; e += 256) {
+        T tmp;                                               // the reference rounds the LN output to the model dtype
+        st(&tmp, (s_q[e] - mu) * rstd * ld(ln_w + e) + ld(ln_b + e));
+        s_q[e] = ld(&tmp);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = blockIdx.x * 16 + 4 * w + i;           // wave-uniform
+        if (t >= Tn) break;
+        const T* row = kk + ((int64_t)b * Tn + t) * d;
+        float acc = 0.0f;
+        for (int e = lane * 4; e < d; e += 256) {
+            const float4 m = ld4(row + e);
+            acc = fmaf(m.x, s_q[e], fmaf(m.y, s_q[e + 1], fmaf(m.z, s_q[e + 2], fmaf(m.w, s_q[e + 3], acc))));
+        }
+        acc += shfl_xor(acc, 1); acc += shfl_xor(acc, 2); acc += shfl_xor(acc, 4);
+        acc += shfl_xor(acc, 8); acc += shfl_xor(acc, 16); acc += shfl_xor(acc, 32);
+        if (lane == 0) scores[(int64_t)b * Tn + t] = acc * scale;
+    }
+}
+
+// row softmax of x[b, 0:Tn] * scale; written (model dtype) to the strided attention buffer AND to a contiguous
+// zero-padded [B, Tp] copy that feeds the following projection.  One wave per row.
+template <typename TX, typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const TX* __restrict__ x, int64_t x_sb, float scale,
+                                                           T* __restrict__ att, int64_t att_sb, T* __restrict__ attc,
+                                                           int B, int Tn, int Tp) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;                                      // whole wave
+    float mx = -INFINITY;
+    for (int t = lane; t < Tn; t += 64) mx = fmaxf(mx, ld(x + b * x_sb + t) * scale);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) mx = fmaxf(mx, shfl_xor(mx, m));
+    float sum = 0.0f;
+    for (int t = lane; t < Tn; t += 64) sum += expf(ld(x + b * x_sb + t) * scale - mx);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) sum += shfl_xor(sum, m);
+    const float inv = 1.0f / sum;
+    for (int t = lane; t < Tp; t += 64) {
+        const float p = t < Tn ? expf(ld(x + b * x_sb + t) * scale - mx) * inv : 0.0f;
+        if (t < Tn) st(att + b * att_sb + t, p);
+        st(attc + (int64_t)b * Tp + t, p);
+    }
+}
+
+// x[b, e] += sum_t att[b,t] * vv[b,t,e]    grid (d/1024 ... ) : workgroup = (b, 1024-column slab), 4 columns per thread
+template <typename T>
+__global__ __launch_bounds__(256) void weighted_rows_kernel(const T* __restrict__ attc, int Tp, const T* __restrict__ vv,
+                                                            T* x, int Tn, int d) {
+    __shared__ float s_a[kCaMaxT];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int t = tid; t < Tn; t += 256) s_a[t] = ld(attc + (int64_t)b * Tp + t);
+    __syncthreads();
+    const int e = blockIdx.x * 1024 + tid * 4;
+    if (e >= d) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < Tn; ++t) {
+        const float a = s_a[t];
+        const float4 p = ld4(vv + ((int64_t)b * Tn + t) * d + e);
+        acc.x = fmaf(a, p.x, acc.x); acc.y = fmaf(a, p.y, acc.y); acc.z = fmaf(a, p.z, acc.z); acc.w = fmaf(a, p.w, acc.w);
+    }
+    T tmp4[4];
+    st4(tmp4, acc);                                          // bmm result in the model dtype, then the residual add
+    const float4 o = ld4(tmp4), r = ld4(x + (int64_t)b * d + e);
+    st4(x + (int64_t)b * d + e, make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void cross_att_step1_kernel(
     const T* __restrict__ qlin, const T* __restrict__ ln_w, const T* __restrict__ ln_b, float ln_eps,
@@ -169,4 +256,60 @@ extern "C" int lina_cross_att_step2(const void* xp, const void* pe, const void* 
         LINA_LAUNCH((cross_att_step2_kernel<bf16_t>), dim3((unsigned)B), dim3(256), smem, stream, (const bf16_t*)xp,
                     (const bf16_t*)pe, (const bf16_t*)vv, (bf16_t*)att2, att_sb, (bf16_t*)x, Tn, d, scale);
     return check_launch("lina_cross_att_step2");
+}
+
+extern "C" int lina_cross_scores(const void* q_lin, const void* ln_w, const void* ln_b, float ln_eps, const void* kk,
+                                 float* scores, int B, int Tn, int d, float scale, int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(q_lin && ln_w && ln_b && kk && scores, "lina_cross_scores: null pointer");
+    LINA_REQUIRE(B > 0 && Tn > 0, "lina_cross_scores: B, T_txt must be positive");
+    LINA_REQUIRE(d > 0 && d % 4 == 0 && d <= 16384, "lina_cross_scores: d must be a multiple of 4, <= 16384");
+    LINA_REQUIRE(valid_dtype(dtype), "lina_cross_scores: bad dtype %d", dtype);
+    dim3 grid((unsigned)((Tn + 15) / 16), (unsigned)B);
+    const size_t smem = sizeof(float) * (size_t)d;
+    if (dtype == LINA_F32)
+        LINA_LAUNCH((cross_scores_kernel<float>), grid, dim3(256), smem, stream, (const float*)q_lin, (const float*)ln_w,
+                    (const float*)ln_b, ln_eps, (const float*)kk, scores, Tn, d, scale);
+    else
+        LINA_LAUNCH((cross_scores_kernel<bf16_t>), grid, dim3(256), smem, stream, (const bf16_t*)q_lin,
+                    (const bf16_t*)ln_w, (const bf16_t*)ln_b, ln_eps, (const bf16_t*)kk, scores, Tn, d, scale);
+    return check_launch("lina_cross_scores");
+}
+
+extern "C" int lina_softmax_rows(const void* x, int64_t x_sb, int x_dtype, float scale, void* att, int64_t att_sb,
+                                 void* attc, int B, int Tn, int Tp, int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(x && att && attc, "lina_softmax_rows: null pointer");
+    LINA_REQUIRE(B > 0 && Tn > 0 && Tp >= Tn, "lina_softmax_rows: bad shape");
+    LINA_REQUIRE(valid_dtype(dtype) && valid_dtype(x_dtype), "lina_softmax_rows: bad dtype");
+    dim3 grid((unsigned)((B + 3) / 4));
+    if (x_dtype == LINA_F32 && dtype == LINA_F32)
+        LINA_LAUNCH((softmax_rows_kernel<float, float>), grid, dim3(256), 0, stream, (const float*)x, x_sb, scale,
+                    (float*)att, att_sb, (float*)attc, B, Tn, Tp);
+    else if (x_dtype == LINA_F32 && dtype == LINA_BF16)
+        LINA_LAUNCH((softmax_rows_kernel<float, bf16_t>), grid, dim3(256), 0, stream, (const float*)x, x_sb, scale,
+                    (bf16_t*)att, att_sb, (bf16_t*)attc, B, Tn, Tp);
+    else if (x_dtype == LINA_BF16 && dtype == LINA_BF16)
+        LINA_LAUNCH((softmax_rows_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)x, x_sb, scale,
+                    (bf16_t*)att, att_sb, (bf16_t*)attc, B, Tn, Tp);
+    else
+        return fail(LINA_ERR_UNSUPPORTED, "lina_softmax_rows: bf16 input with f32 output is not built");
+    return check_launch("lina_softmax_rows");
+}
+
+extern "C" int lina_weighted_rows_add(const void* attc, int Tp, const void* vv, void* x, int B, int Tn, int d, int dtype,
+                                      lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(attc && vv && x, "lina_weighted_rows_add: null pointer");
+    LINA_REQUIRE(B > 0 && Tn > 0 && Tn <= kCaMaxT && Tp >= Tn, "lina_weighted_rows_add: 0 < T_txt <= %d", kCaMaxT);
+    LINA_REQUIRE(d > 0 && d % 4 == 0, "lina_weighted_rows_add: d must be a multiple of 4");
+    LINA_REQUIRE(valid_dtype(dtype), "lina_weighted_rows_add: bad dtype %d", dtype);
+    dim3 grid((unsigned)((d + 1023) / 1024), (unsigned)B);
+    if (dtype == LINA_F32)
+        LINA_LAUNCH((weighted_rows_kernel<float>), grid, dim3(256), 0, stream, (const float*)attc, Tp, (const float*)vv,
+                    (float*)x, Tn, d);
+    else
+        LINA_LAUNCH((weighted_rows_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)attc, Tp,
+                    (const bf16_t*)vv, (bf16_t*)x, Tn, d);
+    return check_launch("lina_weighted_rows_add");
 }

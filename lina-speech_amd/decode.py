@@ -118,6 +118,11 @@ class _Part:
         self.x = torch.zeros(hi - lo, d, dtype=dtype, device=dev)       # residual stream
         self.xp = torch.zeros(hi - lo, d, dtype=dtype, device=dev)      # pos_net stream
         self.q_lin = torch.zeros(hi - lo, d, dtype=dtype, device=dev)   # projected cross-attention query
+        Tn = kk.shape[1]
+        Tp = (Tn + 31) // 32 * 32
+        self.scores = torch.zeros(hi - lo, Tn, dtype=torch.float32, device=dev)
+        self.sc2 = torch.zeros(hi - lo, Tp, dtype=dtype, device=dev)
+        self.attc = torch.zeros(hi - lo, Tp, dtype=dtype, device=dev)  # softmax rows, zero-padded to whole k-steps
 
 
 class DecodeEngine:
@@ -139,6 +144,11 @@ class DecodeEngine:
         kk, vv, pe = ca.prepare(x_enc)                                   # [B,1,Ttxt,d] x2, [1,1,Ttxt,d]
         kk, vv = kk.squeeze(1).contiguous(), vv.squeeze(1).contiguous()
         self.pe = pe.squeeze(1).squeeze(0).contiguous()                  # [Ttxt, d]
+        self.Tn = self.pe.shape[0]
+        Tp = (self.Tn + 31) // 32 * 32
+        self.pe_pad = torch.zeros(Tp, self.pe.shape[1], dtype=self.pe.dtype, device=self.pe.device)
+        self.pe_pad[:self.Tn] = self.pe                                   # weight rows of  scores2 = xp . pe^T
+        self.peT = self.pe_pad.t().contiguous()                           # [d, Tp]: weight rows of  xp = att1 . pe
         self.att_scale = 1.0 / math.sqrt(kk.shape[-1])
         self.ca_qw, self.ca_qb = ca.q.weight.contiguous(), ca.q.bias.float().contiguous()
         hw = model.logits_head.weight
@@ -201,14 +211,18 @@ class DecodeEngine:
         return x
 
     def _cross(self, part, x):
-        """x += blind cross-attention (3 launches + the pos_net block); attention weights go to self._att."""
+        """x += blind cross-attention: 7 short launches around the pos_net block, every one of them spread over
+        >= 256 workgroups (query projection, scores, softmax, att1.pe | xp.pe^T, softmax, att2.V + residual)."""
         ca = self.ca
         att = self._att[part.lo:part.hi]
         q_lin = ops.linear_skinny(x, self.ca_qw, c2=self.ca_qb, out=part.q_lin)
-        ops.cross_att_step1(q_lin, ca.ln_q.weight, ca.ln_q.bias, ca.ln_q.eps, part.kk, self.pe, att[:, 0, 0], part.xp,
-                            self.att_scale)
+        ops.cross_scores(q_lin, ca.ln_q.weight, ca.ln_q.bias, ca.ln_q.eps, part.kk, part.scores, self.att_scale)
+        ops.softmax_rows(part.scores, 1.0, att[:, 0, 0], part.attc, self.Tn)
+        ops.linear_skinny(part.attc, self.peT, out=part.xp)                   # xp = att1 . pe
         self._block(part.xp, part.packs[-1])
-        ops.cross_att_step2(part.xp, self.pe, part.vv, att[:, 1, 0], x, self.att_scale)
+        ops.linear_skinny(part.xp, self.pe_pad, out=part.sc2)                 # scores2 = xp . pe^T
+        ops.softmax_rows(part.sc2, self.att_scale, att[:, 1, 0], part.attc, self.Tn)
+        ops.weighted_rows_add(part.attc, part.vv, x)
 
     def _core_part(self, part, y):
         x = part.x

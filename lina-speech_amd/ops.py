@@ -394,3 +394,29 @@ def cross_att_step2(xp, pe, vv, att2, x, scale):
     Tn = vv.shape[1]
     _check(be.lib.lina_cross_att_step2(_ptr(xp), _ptr(pe), _ptr(vv), _ptr(att2), att2.stride(0), _ptr(x), B, Tn, d,
                                        float(scale), _dt(xp), be.stream(xp)))
+
+
+def cross_scores(q_lin, ln_w, ln_b, ln_eps, kk, scores, scale):
+    """scores[b,t] = scale * <LayerNorm(q_lin[b]), kk[b,t,:]> (fp32 [B,T_txt]); see lina_gla.h."""
+    be = _BACKEND
+    be.require(q_lin, ln_w, ln_b, kk, scores)
+    B, d = q_lin.shape
+    _check(be.lib.lina_cross_scores(_ptr(q_lin), _ptr(ln_w), _ptr(ln_b), float(ln_eps), _ptr(kk), _ptr(scores), B,
+                                    kk.shape[1], d, float(scale), _dt(q_lin), be.stream(q_lin)))
+
+
+def softmax_rows(x, scale, att, attc, Tn):
+    """att[b,:Tn] = softmax(x[b,:Tn]*scale) into the strided `att` rows and the contiguous padded copy attc [B,Tp]."""
+    be = _BACKEND
+    be.require(x, att, attc)
+    B = x.shape[0]
+    _check(be.lib.lina_softmax_rows(_ptr(x), x.stride(0), _dt(x), float(scale), _ptr(att), att.stride(0), _ptr(attc), B,
+                                    Tn, attc.shape[1], _dt(attc), be.stream(x)))
+
+
+def weighted_rows_add(attc, vv, x):
+    """x[b,:] += sum_t attc[b,t] * vv[b,t,:]."""
+    be = _BACKEND
+    be.require(attc, vv, x)
+    B, Tn, d = vv.shape
+    _check(be.lib.lina_weighted_rows_add(_ptr(attc), attc.shape[1], _ptr(vv), _ptr(x), B, Tn, d, _dt(x), be.stream(x)))

@@ -370,3 +370,31 @@ def check_cross_att(dev, B, Tn, d, dtype):
     a2 = torch.softmax(c(xp2) @ c(pe).t() * scale, -1)
     assert_close(att[:, 1, 0], a2, tol, "cross-att att2")
     assert_close(x, c(x0) + torch.einsum("bt,btd->bd", a2, c(vv)), tol, "cross-att x")
+
+
+def check_cross_spread(dev, B, Tn, d, dtype):
+    """lina_cross_scores / lina_softmax_rows / lina_weighted_rows_add vs fp64 torch (reference crossatt.py:13-19)."""
+    g = torch.Generator().manual_seed(15)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dtype).to(dev)
+    q_lin, kk, vv = mk(B, d), mk(B, Tn, d), mk(B, Tn, d)
+    ln_w, ln_b = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype).to(dev), (0.1 * torch.randn(d, generator=g)).to(dtype).to(dev)
+    c = lambda t: t.cpu().to(F64)
+    scale = d ** -0.5
+    scores = torch.empty(B, Tn, dtype=torch.float32, device=dev)
+    ops.cross_scores(q_lin, ln_w, ln_b, 1e-5, kk, scores, scale)
+    q = F.layer_norm(c(q_lin), (d,), c(ln_w), c(ln_b), 1e-5)
+    ref_sc = torch.einsum("bd,btd->bt", q, c(kk)) * scale
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert_close(scores, ref_sc, tol, "cross scores")
+    Tp = (Tn + 31) // 32 * 32
+    att = torch.zeros(B, 2, 1, Tn, dtype=dtype, device=dev)
+    attc = torch.full((B, Tp), 7.0, dtype=dtype, device=dev)
+    ops.softmax_rows(scores, 1.0, att[:, 1, 0], attc, Tn)
+    ref_att = torch.softmax(c(scores), -1)
+    assert_close(att[:, 1, 0], ref_att, tol, "softmax rows (strided)")
+    assert_close(attc[:, :Tn], ref_att, tol, "softmax rows (padded copy)")
+    assert (attc[:, Tn:] == 0).all() and (att[:, 0] == 0).all()
+    x = mk(B, d)
+    x0 = x.clone()
+    ops.weighted_rows_add(attc, vv, x)
+    assert_close(x, c(x0) + torch.einsum("bt,btd->bd", c(attc[:, :Tn]), c(vv)), tol, "weighted rows add")

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import gla_oracle as O
-from kernel_cases import (check_argmax, check_chunk, check_conv, check_cross_att, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
+from kernel_cases import (check_argmax, check_chunk, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
                           check_prologue, check_recurrent, check_rmsnorm, check_swiglu)
 
 DEV = "cpu"
@@ -88,3 +88,8 @@ def test_decode_update_norm_fused(emu, Dk, Dv, dtype):
 @pytest.mark.parametrize("Tn,d,dtype", [(9, 64, torch.float32), (70, 128, torch.bfloat16)])
 def test_cross_att_fused(emu, Tn, d, dtype):
     check_cross_att(DEV, B=3, Tn=Tn, d=d, dtype=dtype)
+
+
+@pytest.mark.parametrize("Tn,d,dtype", [(9, 64, torch.float32), (70, 128, torch.bfloat16)])
+def test_cross_att_spread(emu, Tn, d, dtype):
+    check_cross_spread(DEV, B=5, Tn=Tn, d=d, dtype=dtype)

@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from kernel_cases import (assert_close, check_argmax, check_chunk, check_conv, check_cross_att, check_decode_update, check_decode_update_norm, check_embed, check_inproj,
+from kernel_cases import (assert_close, check_argmax, check_chunk, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj,
                           check_linear_skinny, check_prologue, check_recurrent, check_rmsnorm, check_swiglu,
                           make_gla_inputs, oracle_gla)
 from lina_speech_amd import ops
@@ -96,6 +96,12 @@ def test_decode_update_norm_fused(hip, B, H, Dk, Dv, dtype, rep):
                                            (64, 64, 1024, torch.bfloat16), (5, 300, 1024, torch.bfloat16)])
 def test_cross_att_fused(hip, B, Tn, d, dtype):
     check_cross_att(DEV, B=B, Tn=Tn, d=d, dtype=dtype)
+
+
+@pytest.mark.parametrize("B,Tn,d,dtype", [(3, 9, 64, torch.float32), (64, 64, 1024, torch.float32),
+                                           (64, 64, 1024, torch.bfloat16), (5, 300, 1024, torch.bfloat16)])
+def test_cross_att_spread(hip, B, Tn, d, dtype):
+    check_cross_spread(DEV, B=B, Tn=Tn, d=d, dtype=dtype)
 
 
 # ---------------------------------------------------------------------------------------------
