@@ -196,9 +196,14 @@ def main():
             e_io = 2 if dtype == torch.bfloat16 else 4
             k1_rows = P.S.shape[0]
             k1_bytes = k1_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4)
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "r01_k1d_traffic.json")
+            if os.path.exists(tpath) and k1_rows == 64:      # PMC passes are separate runs; their committed summary
+                tj = json.load(open(tpath))
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_k1d_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
             roof = {"kernel": "lina::gla_decode_rowsplit_kernel<256>", "bound": "hbm",
                     "achieved": k1_bytes / k1_dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": k1_bytes / k1_dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "frac": k1_bytes / k1_dt / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": k1_bytes, "us_per_launch": k1_dt * 1e6, "rows_per_launch": k1_rows,
                     "launches_per_step": len(eng.packs) * len(eng.parts)}
             out = {
