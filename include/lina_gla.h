@@ -76,6 +76,26 @@ int lina_gla_chunk_fwd(const void* q, const void* k, const void* v, const void* 
                        lina_bht_strides sg, lina_bht_strides so,
                        int dtype, int g_dtype, float scale, lina_stream_t stream);
 
+/* K2b -- backward of K2: given d_o = dL/do (and optionally
+ * dht = dL/d final_state) produce dq, dk, dv, dg and optionally dh0 = dL/d initial_state.
+ * Replaces the autograd backward of fla.ops.gla.chunk_gla / fused_chunk_gla that the reference
+ * reaches through loss.backward() (train_lina.py:88-94 over the call sites model/gla.py:193,195).
+ *   q,k,v,gk,d_o and the outputs dq,dk,dv,dg are head-first [B,H,T,D] views with explicit strides;
+ *   h0, dht, dh0: fp32 [B,H,Dk,Dv] contiguous or NULL;
+ *   dg_tail: fp32 [B,H,Dk] or NULL -- sum_v final_state (.) dht, the gate gradient that enters
+ *            through the final state (the caller holds final_state; NULL when dht is NULL);
+ *   workspace: fp32 scratch of lina_gla_chunk_bwd_workspace(...) BYTES (dq, dk stay fp32 there until
+ *            dg = reverse-cumsum(q dq - k dk) has been formed).  Nothing is allocated inside. */
+int64_t lina_gla_chunk_bwd_workspace(int B, int H, int T, int Dk, int Dv);
+int lina_gla_chunk_bwd(const void* q, const void* k, const void* v, const void* gk, const void* d_o,
+                       const float* h0, const float* dht, const float* dg_tail,
+                       void* dq, void* dk, void* dv, void* dg, float* dh0, float* workspace,
+                       int B, int H, int T, int Dk, int Dv,
+                       lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
+                       lina_bht_strides sg, lina_bht_strides sdo,
+                       lina_bht_strides sdq, lina_bht_strides sdk, lina_bht_strides sdv, lina_bht_strides sdg,
+                       int dtype, int g_dtype, float scale, lina_stream_t stream);
+
 /* K3 -- causal depthwise short convolution (+ optional SiLU), prefill form.
  * Replaces fla.modules.ShortConvolution.forward for T > 1 or cache == NULL
  * (ctor reference model/gla.py:106-108, calls :161-163).

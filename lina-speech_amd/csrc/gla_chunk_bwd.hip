@@ -1,0 +1,463 @@
+// gla_chunk_bwd.hip -- K2b: backward of the chunk-wise GLA scan.
+//
+// Replaces the autograd backward of fla.ops.gla.chunk_gla / fused_chunk_gla that the reference reaches
+// through loss.backward() (train_lina.py:88-94 over model/gla.py:193,195).
+//
+// With  S_t = diag(e^{g_t}) S_{t-1} + k_t^T v_t,  o_t = scale q_t S_t  and dS_t = dL/dS_t:
+//     dS_t = scale q_t^T do_t + diag(e^{g_{t+1}}) dS_{t+1}
+//     dq_t = scale S_t do_t^T          dk_t = dS_t v_t^T          dv_t = k_t dS_t
+//     dg_t = q_t (.) dq_t - k_t (.) dk_t + dg_{t+1}          dh0 = diag(e^{g_1}) dS_1
+// Chunk form (b = inclusive cumsum of the gates inside a chunk, q~ = scale q e^{b}, k~ = k e^{-b}):
+//     dq~ = do S^T + mask_{s<=t}(do v^T) k~       dq = scale e^{b} (.) dq~      [S   forward in time ]
+//     dv  = k~ D   + mask_{t>=s}(k~ q~^T) do      D  = diag(e^{b_last}) dS_in   [dS  backward in time]
+//     dk~ = v D^T  + mask_{t>=s}(v do^T) q~       dk = e^{-b} (.) dk~           [dS^T backward in time]
+//     dS_out = D + q~^T do
+// An MFMA accumulator tile can be contracted only along its row index, so the three products need the
+// state in three orientations: three sweeps, each the forward kernel's shape
+//     out = X R + mask(X Y^T) Z ,   R <- R + Y^T Z   (R decayed along rows or columns)
+// with the state slice R (D1 x 64) resident in accumulators for the whole sequence:
+//     sweep V  (reverse): X = k~, Y = q~, Z = do[:, slice]   R = dS  [Dk x 64 of Dv]  -> dv, dh0
+//     sweep Q  (forward): X = do, Y = v,  Z = k~[:, slice]   R = S^T [Dv x 64 of Dk]  -> dq (fp32)
+//     sweep K  (reverse): X = v,  Y = do, Z = q~[:, slice]   R = dS^T[Dv x 64 of Dk]  -> dk (fp32), dh0 not needed
+// grid = (B*H, 4 slices of 64): every slice is independent (any chunk partition is exact), so a
+// training micro-batch of b rows gives 4*b*H workgroups.  Chunks are 16 tokens, cut adaptively where the
+// in-chunk decay would exceed e^-60 (reverse sweeps cut from the END of the tile), exactly like K2.
+// All contractions run on v_mfma_f32_16x16x4_f32 (fp32 operands, bf16 I/O is widened when staged):
+// gradients are fp32-accurate; dq, dk stay fp32 in a workspace until dg = reverse-cumsum(q dq - k dk)
+// has been formed from them, then they are cast to the I/O dtype by the same kernel.
+#include <lina_dev.h>
+#include "lina_common.h"
+
+namespace lina {
+
+constexpr int kBC = 16;               // chunk length
+constexpr float kBMaxDecay = 60.0f;
+constexpr int kDgSeg = 64;            // tokens per segment of the dg reverse scan
+
+int check_gla_args(const char* fn, const void* q, const void* k, const void* v, const void* gk, const void* o,
+                   int B, int H, int T, int Dk, int Dv, int dtype, int g_dtype);
+
+__device__ __forceinline__ int wave_min_b(int v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = min(v, shfl_xor_i(v, m));
+    return v;
+}
+__device__ __forceinline__ int wave_max_b(int v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = max(v, shfl_xor_i(v, m));
+    return v;
+}
+
+// Gate scan of one channel over a 16-row tile.
+//   forward: rows [0, n) form the chunk, bv[r] = sum_{u<=r} g_u; returns the first row that must start a new chunk
+//   reverse: rows [start, 16) form the chunk, bv[r] = sum_{start<=u<=r} g_u; returns the smallest admissible start
+__device__ __forceinline__ int scan_fwd(float (&bv)[kBC], const float (&gv)[kBC]) {
+    float b = 0.0f;
+    int nc = kBC;
+#pragma unroll
+    for (int r = 0; r < kBC; ++r) {
+        b += fmaxf(gv[r], -kBMaxDecay);
+        if (r > 0 && nc == kBC && -b > kBMaxDecay) nc = r;
+        bv[r] = b;
+    }
+    return nc;
+}
+// suffix sums cs[r] = sum_{u>=r} g_u (cs[16] = 0); smallest start with -cs[start] <= kBMaxDecay (cs is monotone)
+__device__ __forceinline__ int scan_rev(float (&cs)[kBC + 1], const float (&gv)[kBC]) {
+    float c = 0.0f;
+    cs[kBC] = 0.0f;
+    int start = kBC - 1;
+#pragma unroll
+    for (int r = kBC - 1; r >= 0; --r) {
+        c += fmaxf(gv[r], -kBMaxDecay);
+        cs[r] = c;
+        if (-c <= kBMaxDecay) start = r;
+    }
+    return start;
+}
+// bv[r] for r >= start once the workgroup-wide start is known; returns the chunk total b_last
+__device__ __forceinline__ float finish_rev(float (&bv)[kBC], const float (&cs)[kBC + 1], int start) {
+    float tot = 0.0f;
+#pragma unroll
+    for (int r = 0; r < kBC; ++r) tot = (r == start) ? cs[r] : tot;
+#pragma unroll
+    for (int r = 0; r < kBC; ++r) bv[r] = tot - cs[r + 1];
+    return tot;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the shared MFMA phase:  out(acc) = X R + mask(X Y^T) Z ;  R += Y^T Z ; decay applied by the caller
+//   s_x, s_y : [16][SX] fp32 row-major (row = token), s_z : [16][SZ] fp32 (row = token, 64 slice columns)
+//   wave w owns slice columns [16w, 16w+16); R[p] = rows [16p, 16p+16) in C/D layout
+//   UPPER = false: mask keeps s <= t (time runs forward);  true: keeps t >= s for row s (reverse sweeps)
+// ---------------------------------------------------------------------------------------------------
+template <int D1, bool UPPER>
+__device__ __forceinline__ f32x4 chunk_products(f32x4 (&R)[D1 / 16], const float* s_x, const float* s_y,
+                                                const float* s_z, float (*s_A)[kBC][kBC + 1], int w, int li, int lg) {
+    constexpr int NT = D1 / 16, SX = D1 + 2, SZ = 64 + 16;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+        const float* xp = &s_x[li * SX + 16 * p + 4 * lg];
+        acc0 = mfma_f32_16x16x4(xp[0], R[p][0], acc0);
+        acc1 = mfma_f32_16x16x4(xp[1], R[p][1], acc1);
+        acc0 = mfma_f32_16x16x4(xp[2], R[p][2], acc0);
+        acc1 = mfma_f32_16x16x4(xp[3], R[p][3], acc1);
+    }
+    {   // partial M[m][n] = X[m] . Y[n] over this wave's quarter of D1
+        f32x4 pa = {0.f, 0.f, 0.f, 0.f};
+        const int c0 = w * (D1 / 4);
+#pragma unroll
+        for (int kk = 0; kk < D1 / 16; ++kk) {
+            const int cc = c0 + 4 * kk + lg;
+            pa = mfma_f32_16x16x4(s_x[li * SX + cc], s_y[li * SX + cc], pa);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_A[w][4 * lg + r][li] = pa[r];
+    }
+    __syncthreads();
+    float zf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int s = 4 * kk + lg;                       // contraction index (a token), output row = li
+        zf[kk] = s_z[s * SZ + 16 * w + li];
+        float a = (s_A[0][li][s] + s_A[1][li][s]) + (s_A[2][li][s] + s_A[3][li][s]);
+        a = (UPPER ? (s >= li) : (s <= li)) ? a : 0.0f;
+        if (kk & 1) acc1 = mfma_f32_16x16x4(a, zf[kk], acc1);
+        else acc0 = mfma_f32_16x16x4(a, zf[kk], acc0);
+    }
+#pragma unroll
+    for (int p = 0; p < NT; ++p)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) R[p] = mfma_f32_16x16x4(s_y[(4 * kk + lg) * SX + 16 * p + li], zf[kk], R[p]);
+    return f32x4{acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]};
+}
+
+// ===================================== sweep V : dv, dh0 ==========================================
+template <int DK, typename TIO, typename TG>
+__global__ __launch_bounds__(256) void gla_bwd_dv_kernel(
+    const TIO* __restrict__ q, const TIO* __restrict__ k, const TG* __restrict__ gk, const TIO* __restrict__ dout,
+    TIO* __restrict__ dv, const float* dht, float* dh0, int H, int T, int Dv, lina_bht_strides sq,
+    lina_bht_strides sk, lina_bht_strides sg, lina_bht_strides sdo, lina_bht_strides sdv, float scale) {
+    constexpr int C = kBC, NT = DK / 16, SX = DK + 2, SZ = 64 + 16;
+    __shared__ float s_x[C * SX], s_y[C * SX];
+    __shared__ float s_z[C * SZ];
+    __shared__ float s_dec[DK];
+    __shared__ float s_A[4][C][C + 1];
+    __shared__ int s_nw[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int v0 = blockIdx.y * 64;
+
+    f32x4 R[NT];
+    {
+        const float* hp = dht ? dht + ((int64_t)bh * DK) * Dv + v0 + 16 * w + li : nullptr;
+#pragma unroll
+        for (int p = 0; p < NT; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[p][r] = hp ? hp[(int64_t)(16 * p + 4 * lg + r) * Dv] : 0.0f;
+    }
+    const TIO* qb = q + b * sq.b + h * sq.h;
+    const TIO* kb = k + b * sk.b + h * sk.h;
+    const TG* gb = gk + b * sg.b + h * sg.h;
+    const TIO* dob = dout + b * sdo.b + h * sdo.h + v0;
+    TIO* dvb = dv + b * sdv.b + h * sdv.h + v0 + 16 * w + li;
+    const bool chan = tid < DK;
+    const int vr = tid >> 4, vc = (tid & 15) * 4;
+
+    int t_end = T;
+    while (t_end > 0) {
+        const int base = t_end - C;                       // tile row r <-> token base + r (may start before 0)
+        float gv[C], qv[C], kv[C];
+#pragma unroll
+        for (int r = 0; r < C; ++r) {
+            const int t = base + r;
+            const bool in = chan && t >= 0;
+            gv[r] = in ? ld(gb + t * sg.t + tid) : 0.0f;
+            qv[r] = in ? ld(qb + t * sq.t + tid) : 0.0f;
+            kv[r] = in ? ld(kb + t * sk.t + tid) : 0.0f;
+        }
+        float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (base + vr >= 0) zz = ld4(dob + (base + vr) * sdo.t + vc);
+        float cs[C + 1], bv[C];
+        const int wst = wave_max_b(scan_rev(cs, gv));
+        if (lane == 0) s_nw[w] = wst;
+        __syncthreads();   // (1) also: everyone is done with the previous chunk's tiles
+        const int start = max(max(max(s_nw[0], s_nw[1]), max(s_nw[2], s_nw[3])), -base);
+        if (chan) {
+            const float tot = finish_rev(bv, cs, start);
+#pragma unroll
+            for (int r = 0; r < C; ++r) {
+                const bool valid = r >= start;
+                s_x[r * SX + tid] = valid ? kv[r] * __expf(-bv[r]) : 0.0f;
+                s_y[r * SX + tid] = valid ? qv[r] * scale * __expf(bv[r]) : 0.0f;
+            }
+            s_dec[tid] = __expf(tot);
+        }
+        {
+            const bool valid = vr >= start;
+            float* d = &s_z[vr * SZ + vc];
+            d[0] = valid ? zz.x : 0.0f; d[1] = valid ? zz.y : 0.0f;
+            d[2] = valid ? zz.z : 0.0f; d[3] = valid ? zz.w : 0.0f;
+        }
+        __syncthreads();   // (2)
+#pragma unroll
+        for (int p = 0; p < NT; ++p)                      // D = diag(e^{b_last}) dS_in
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[p][r] *= s_dec[16 * p + 4 * lg + r];
+        const f32x4 acc = chunk_products<DK, true>(R, s_x, s_y, s_z, s_A, w, li, lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * lg + r;
+            if (row >= start) st(dvb + (base + row) * sdv.t, acc[r]);
+        }
+        t_end = base + start;
+    }
+    if (dh0) {
+        float* hp = dh0 + ((int64_t)bh * DK) * Dv + v0 + 16 * w + li;
+#pragma unroll
+        for (int p = 0; p < NT; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hp[(int64_t)(16 * p + 4 * lg + r) * Dv] = R[p][r];
+    }
+}
+
+// ============================ sweeps Q (REV = false) and K (REV = true) ============================
+//   REV = false:  X = do, Y = v,  Z = k[:, slice] e^{-b},        out32 = scale e^{b} (.) out    (dq), R0 = h0^T
+//   REV = true :  X = v,  Y = do, Z = scale q[:, slice] e^{b},   out32 = e^{-b} (.) out         (dk), R0 = dht^T
+template <int DV, typename TIO, typename TG, bool REV>
+__global__ __launch_bounds__(256) void gla_bwd_dqk_kernel(
+    const TIO* __restrict__ xin, const TIO* __restrict__ yin, const TIO* __restrict__ zin,
+    const TG* __restrict__ gk, float* __restrict__ out32, const float* r0, int H, int T, int Dk,
+    lina_bht_strides sx, lina_bht_strides sy, lina_bht_strides sz, lina_bht_strides sg, float scale) {
+    constexpr int C = kBC, NT = DV / 16, SX = DV + 2, SZ = 64 + 16;
+    __shared__ float s_x[C * SX], s_y[C * SX];
+    __shared__ float s_z[C * SZ];
+    __shared__ float s_b[C][64 + 1];
+    __shared__ float s_dec[64];
+    __shared__ float s_A[4][C][C + 1];
+    __shared__ int s_cut;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int c0 = blockIdx.y * 64;
+
+    f32x4 R[NT];                                          // R[p][r] <-> (v = 16p + 4lg + r, c = c0 + 16w + li)
+    {
+        const float* hp = r0 ? r0 + ((int64_t)bh * Dk + c0 + 16 * w + li) * DV + 4 * lg : nullptr;
+#pragma unroll
+        for (int p = 0; p < NT; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[p][r] = hp ? hp[16 * p + r] : 0.0f;
+    }
+    const TIO* xb = xin + b * sx.b + h * sx.h;
+    const TIO* yb = yin + b * sy.b + h * sy.h;
+    const TIO* zb = zin + b * sz.b + h * sz.h + c0;
+    const TG* gb = gk + b * sg.b + h * sg.h + c0;
+    float* ob = out32 + ((int64_t)bh * T) * Dk + c0 + 16 * w + li;
+    const bool chan = tid < DV;
+    const int vr = tid >> 4, vc = (tid & 15) * 4;
+
+    int pos = REV ? T : 0;                                // REV: tokens [0,pos) remain; else tokens [pos,T) remain
+    while (REV ? pos > 0 : pos < T) {
+        const int base = REV ? pos - C : pos;
+        float xv[C], yv[C];
+#pragma unroll
+        for (int r = 0; r < C; ++r) {
+            const int t = base + r;
+            const bool in = chan && t >= 0 && t < T;
+            xv[r] = in ? ld(xb + t * sx.t + tid) : 0.0f;
+            yv[r] = in ? ld(yb + t * sy.t + tid) : 0.0f;
+        }
+        float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (base + vr >= 0 && base + vr < T) zz = ld4(zb + (base + vr) * sz.t + vc);
+        float gv[C];
+        if (w == 0) {
+#pragma unroll
+            for (int r = 0; r < C; ++r) {
+                const int t = base + r;
+                gv[r] = (t >= 0 && t < T) ? ld(gb + t * sg.t + lane) : 0.0f;
+            }
+        }
+        __syncthreads();   // (0) previous chunk's tiles, s_b and s_dec are dead
+        if (chan) {
+#pragma unroll
+            for (int r = 0; r < C; ++r) {
+                s_x[r * SX + tid] = xv[r];
+                s_y[r * SX + tid] = yv[r];
+            }
+        }
+        if (w == 0) {
+            float bv[C];
+            float tot;
+            if (REV) {
+                float cs[C + 1];
+                const int wst = max(wave_max_b(scan_rev(cs, gv)), -base);
+                tot = finish_rev(bv, cs, wst);
+                if (lane == 0) s_cut = wst;
+            } else {
+                int n = min(wave_min_b(scan_fwd(bv, gv)), T - base);
+                tot = 0.0f;
+#pragma unroll
+                for (int r = 0; r < C; ++r) tot = (r == n - 1) ? bv[r] : tot;
+                if (lane == 0) s_cut = n;
+            }
+#pragma unroll
+            for (int r = 0; r < C; ++r) s_b[r][lane] = bv[r];
+            s_dec[lane] = __expf(tot);
+        }
+        __syncthreads();   // (1)
+        const int cut = s_cut;                            // REV: first valid row; else number of valid rows
+        {
+            const bool valid = REV ? vr >= cut : vr < cut;
+            const float zr[4] = {zz.x, zz.y, zz.z, zz.w};
+            float* d = &s_z[vr * SZ + vc];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float bb = s_b[vr][vc + i];
+                d[i] = valid ? (REV ? zr[i] * scale * __expf(bb) : zr[i] * __expf(-bb)) : 0.0f;
+            }
+        }
+        __syncthreads();   // (2)
+        const float dcol = s_dec[16 * w + li];
+        if (REV) {
+#pragma unroll
+            for (int p = 0; p < NT; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R[p][r] *= dcol;
+        }
+        const f32x4 acc = chunk_products<DV, REV>(R, s_x, s_y, s_z, s_A, w, li, lg);
+        if (!REV) {
+#pragma unroll
+            for (int p = 0; p < NT; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R[p][r] *= dcol;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * lg + r;
+            const bool valid = REV ? row >= cut : row < cut;
+            if (valid) {
+                const float bb = s_b[row][16 * w + li];
+                ob[(int64_t)(base + row) * Dk] = acc[r] * (REV ? __expf(-bb) : scale * __expf(bb));
+            }
+        }
+        pos = REV ? base + cut : base + cut;
+    }
+}
+
+// ======================================= dg = reverse cumsum =======================================
+// pass 1: per (b,h, segment of 64 tokens, channel) total of q dq - k dk
+template <typename TIO>
+__global__ void gla_bwd_dg_totals_kernel(const TIO* __restrict__ q, const TIO* __restrict__ k,
+                                         const float* __restrict__ dq32, const float* __restrict__ dk32,
+                                         float* __restrict__ tot, int H, int T, int Dk, int nseg,
+                                         lina_bht_strides sq, lina_bht_strides sk) {
+    const int c = threadIdx.x, bh = blockIdx.x, seg = blockIdx.y, b = bh / H, h = bh % H;
+    const TIO* qb = q + b * sq.b + h * sq.h + c;
+    const TIO* kb = k + b * sk.b + h * sk.h + c;
+    const float* dqb = dq32 + ((int64_t)bh * T) * Dk + c;
+    const float* dkb = dk32 + ((int64_t)bh * T) * Dk + c;
+    const int t_lo = seg * kDgSeg, t_hi = min(T, t_lo + kDgSeg);
+    float a = 0.0f;
+    for (int t = t_lo; t < t_hi; ++t)
+        a += ld(qb + t * sq.t) * dqb[(int64_t)t * Dk] - ld(kb + t * sk.t) * dkb[(int64_t)t * Dk];
+    tot[((int64_t)bh * nseg + seg) * Dk + c] = a;
+}
+// pass 2: suffix of the later segments' totals (+ the dht term), in-segment reverse scan, casts of dq / dk
+template <typename TIO, typename TG>
+__global__ void gla_bwd_dg_final_kernel(const TIO* __restrict__ q, const TIO* __restrict__ k,
+                                        const float* __restrict__ dq32, const float* __restrict__ dk32,
+                                        const float* __restrict__ tot, const float* __restrict__ dg_tail,
+                                        TIO* __restrict__ dq, TIO* __restrict__ dk, TG* __restrict__ dg, int H, int T,
+                                        int Dk, int nseg, lina_bht_strides sq, lina_bht_strides sk,
+                                        lina_bht_strides sdq, lina_bht_strides sdk, lina_bht_strides sdg) {
+    const int c = threadIdx.x, bh = blockIdx.x, seg = blockIdx.y, b = bh / H, h = bh % H;
+    const TIO* qb = q + b * sq.b + h * sq.h + c;
+    const TIO* kb = k + b * sk.b + h * sk.h + c;
+    const float* dqb = dq32 + ((int64_t)bh * T) * Dk + c;
+    const float* dkb = dk32 + ((int64_t)bh * T) * Dk + c;
+    TIO* dqo = dq + b * sdq.b + h * sdq.h + c;
+    TIO* dko = dk + b * sdk.b + h * sdk.h + c;
+    TG* dgo = dg + b * sdg.b + h * sdg.h + c;
+    float a = dg_tail ? dg_tail[(int64_t)bh * Dk + c] : 0.0f;
+    for (int s = nseg - 1; s > seg; --s) a += tot[((int64_t)bh * nseg + s) * Dk + c];
+    const int t_lo = seg * kDgSeg, t_hi = min(T, t_lo + kDgSeg);
+    for (int t = t_hi - 1; t >= t_lo; --t) {
+        const float dqv = dqb[(int64_t)t * Dk], dkv = dkb[(int64_t)t * Dk];
+        a += ld(qb + t * sq.t) * dqv - ld(kb + t * sk.t) * dkv;
+        st(dgo + t * sdg.t, a);
+        st(dqo + t * sdq.t, dqv);
+        st(dko + t * sdk.t, dkv);
+    }
+}
+
+template <int DK, int DV, typename TIO, typename TG>
+static int launch_bwd(const void* q, const void* k, const void* v, const void* gk, const void* d_o, const float* h0,
+                      const float* dht, const float* dg_tail, void* dq, void* dk, void* dv, void* dg, float* dh0,
+                      float* ws, int B, int H, int T, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
+                      lina_bht_strides sg, lina_bht_strides sdo, lina_bht_strides sdq, lina_bht_strides sdk,
+                      lina_bht_strides sdv, lina_bht_strides sdg, float scale, lina_stream_t stream) {
+    const int nseg = (T + kDgSeg - 1) / kDgSeg;
+    float* dq32 = ws;
+    float* dk32 = ws + (int64_t)B * H * T * DK;
+    float* tot = dk32 + (int64_t)B * H * T * DK;
+    const TIO *qq = (const TIO*)q, *kk = (const TIO*)k, *vv = (const TIO*)v, *dd = (const TIO*)d_o;
+    const TG* gg = (const TG*)gk;
+    LINA_LAUNCH((gla_bwd_dv_kernel<DK, TIO, TG>), dim3((unsigned)(B * H), (unsigned)(DV / 64)), dim3(256), 0, stream, qq,
+                kk, gg, dd, (TIO*)dv, dht, dh0, H, T, DV, sq, sk, sg, sdo, sdv, scale);
+    LINA_LAUNCH((gla_bwd_dqk_kernel<DV, TIO, TG, false>), dim3((unsigned)(B * H), (unsigned)(DK / 64)), dim3(256), 0,
+                stream, dd, vv, kk, gg, dq32, h0, H, T, DK, sdo, sv, sk, sg, scale);
+    LINA_LAUNCH((gla_bwd_dqk_kernel<DV, TIO, TG, true>), dim3((unsigned)(B * H), (unsigned)(DK / 64)), dim3(256), 0,
+                stream, vv, dd, qq, gg, dk32, dht, H, T, DK, sv, sdo, sq, sg, scale);
+    LINA_LAUNCH((gla_bwd_dg_totals_kernel<TIO>), dim3((unsigned)(B * H), (unsigned)nseg), dim3(DK), 0, stream, qq, kk,
+                dq32, dk32, tot, H, T, DK, nseg, sq, sk);
+    LINA_LAUNCH((gla_bwd_dg_final_kernel<TIO, TG>), dim3((unsigned)(B * H), (unsigned)nseg), dim3(DK), 0, stream, qq, kk,
+                dq32, dk32, tot, dg_tail, (TIO*)dq, (TIO*)dk, (TG*)dg, H, T, DK, nseg, sq, sk, sdq, sdk, sdg);
+    return check_launch("lina_gla_chunk_bwd");
+}
+
+template <typename TIO, typename TG, typename... A>
+static int dispatch_bwd(int Dk, int Dv, A... a) {
+#define LINA_BWD_CASE(DKV, DVV) \
+    if (Dk == DKV && Dv == DVV) return launch_bwd<DKV, DVV, TIO, TG>(a...);
+    LINA_BWD_CASE(64, 64) LINA_BWD_CASE(64, 128) LINA_BWD_CASE(64, 256)
+    LINA_BWD_CASE(128, 64) LINA_BWD_CASE(128, 128) LINA_BWD_CASE(128, 256)
+    LINA_BWD_CASE(256, 64) LINA_BWD_CASE(256, 128) LINA_BWD_CASE(256, 256)
+#undef LINA_BWD_CASE
+    return fail(LINA_ERR_UNSUPPORTED, "lina_gla_chunk_bwd: (Dk,Dv)=(%d,%d) not in {64,128,256}^2", Dk, Dv);
+}
+
+}  // namespace lina
+
+extern "C" int64_t lina_gla_chunk_bwd_workspace(int B, int H, int T, int Dk, int Dv) {
+    (void)Dv;
+    if (B <= 0 || H <= 0 || T <= 0 || Dk <= 0) return 0;
+    const int64_t nseg = (T + lina::kDgSeg - 1) / lina::kDgSeg;
+    return (int64_t)sizeof(float) * ((int64_t)2 * B * H * T * Dk + (int64_t)B * H * nseg * Dk);
+}
+
+extern "C" int lina_gla_chunk_bwd(const void* q, const void* k, const void* v, const void* gk, const void* d_o,
+                                  const float* h0, const float* dht, const float* dg_tail, void* dq, void* dk,
+                                  void* dv, void* dg, float* dh0, float* workspace, int B, int H, int T, int Dk,
+                                  int Dv, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
+                                  lina_bht_strides sg, lina_bht_strides sdo, lina_bht_strides sdq,
+                                  lina_bht_strides sdk, lina_bht_strides sdv, lina_bht_strides sdg, int dtype,
+                                  int g_dtype, float scale, lina_stream_t stream) {
+    using namespace lina;
+    int rc = check_gla_args("lina_gla_chunk_bwd", q, k, v, gk, d_o, B, H, T, Dk, Dv, dtype, g_dtype);
+    if (rc) return rc;
+    LINA_REQUIRE(dq && dk && dv && dg && workspace, "lina_gla_chunk_bwd: null output / workspace pointer");
+    auto mult4 = [](lina_bht_strides s) { return s.b % 4 == 0 && s.h % 4 == 0 && s.t % 4 == 0; };
+    LINA_REQUIRE(mult4(sq) && mult4(sk) && mult4(sdo), "lina_gla_chunk_bwd: q, k, do strides must be multiples of 4");
+#define LINA_BWD_ARGS q, k, v, gk, d_o, h0, dht, dg_tail, dq, dk, dv, dg, dh0, workspace, B, H, T, sq, sk, sv, sg, sdo, \
+                      sdq, sdk, sdv, sdg, scale, stream
+    if (dtype == LINA_F32 && g_dtype == LINA_F32) return dispatch_bwd<float, float>(Dk, Dv, LINA_BWD_ARGS);
+    if (dtype == LINA_BF16 && g_dtype == LINA_BF16) return dispatch_bwd<bf16_t, bf16_t>(Dk, Dv, LINA_BWD_ARGS);
+    if (dtype == LINA_BF16 && g_dtype == LINA_F32) return dispatch_bwd<bf16_t, float>(Dk, Dv, LINA_BWD_ARGS);
+#undef LINA_BWD_ARGS
+    return fail(LINA_ERR_UNSUPPORTED, "lina_gla_chunk_bwd: dtype=f32 with bf16 gates is not built");
+}

@@ -6,7 +6,8 @@ Every function takes/returns torch tensors exactly like the fla operator it repl
 (head-first ``[B,H,T,D]`` views, ``(o, final_state)`` returns) and enqueues on the
 CURRENT torch HIP stream without synchronising, so callers can graph-capture.
 There is no CPU path: tensors must live on a ROCm device (``Backend.require``).
-Forward only in this round -- a tensor that requires grad raises.
+GLA ops are differentiable (K2b); the other custom ops raise on tensors that require grad
+unless stated otherwise.
 """
 from __future__ import annotations
 
@@ -87,8 +88,10 @@ def _check(rc: int):
         raise _lib.LinaError(f"lina C-ABI error {rc}: {_BACKEND.lib.lina_last_error().decode()}")
 
 
-# --------------------------------------------------------------------------- GLA (K1 / K2)
-def _gla(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inplace_state=False):
+# --------------------------------------------------------------------------- GLA (K1 / K2 / K2b)
+def _gla_prepare(q, k, v, gk, scale, initial_state):
+    """Shape / dtype checks and the layout normalisation shared by forward and backward.  Uses only
+    differentiable torch ops, so it may run outside the autograd Function."""
     if q.dim() != 4:
         raise ValueError("q must be [B,H,T,Dk]")
     B, H, T, Dk = q.shape
@@ -97,9 +100,7 @@ def _gla(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inpl
         raise ValueError(f"shape mismatch q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)} gk{tuple(gk.shape)}")
     if k.dtype != q.dtype or v.dtype != q.dtype:
         raise TypeError("q, k, v must share a dtype")
-    _no_grad(q, k, v, gk, initial_state)
-    be = _BACKEND
-    be.require(q, k, v, gk, initial_state)
+    _BACKEND.require(q, k, v, gk, initial_state)
     if gk.dtype != q.dtype and gk.dtype != torch.float32:
         gk = gk.float()
     if q.dtype == torch.float32 and gk.dtype != torch.float32:
@@ -109,13 +110,24 @@ def _gla(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inpl
         v = v.contiguous()
     if scale is None:
         scale = Dk ** -0.5
-    # o is laid out [B,T,H,Dv] in memory and returned as the head-first view, so the caller's
+    if initial_state is not None and tuple(initial_state.shape) != (B, H, Dk, Dv):
+        raise ValueError(f"initial_state must be [B,H,Dk,Dv]={B, H, Dk, Dv}, got {tuple(initial_state.shape)}")
+    return q, k, v, gk, float(scale)
+
+
+def _head_first_empty(B, H, T, D, dtype, device):
+    # laid out [B,T,H,D] in memory and returned as the head-first view, so the caller's
     # 'b h l d -> b l h d' rearrange (reference model/gla.py:215) is free.
-    o = torch.empty(B, T, H, Dv, dtype=q.dtype, device=q.device).transpose(1, 2)
+    return torch.empty(B, T, H, D, dtype=dtype, device=device).transpose(1, 2)
+
+
+def _gla_launch(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inplace_state=False):
+    B, H, T, Dk = q.shape
+    Dv = v.shape[-1]
+    be = _BACKEND
+    o = _head_first_empty(B, H, T, Dv, q.dtype, q.device)
     h0 = None
     if initial_state is not None:
-        if tuple(initial_state.shape) != (B, H, Dk, Dv):
-            raise ValueError(f"initial_state must be [B,H,Dk,Dv]={B, H, Dk, Dv}, got {tuple(initial_state.shape)}")
         h0 = initial_state
         if h0.dtype != torch.float32 or not h0.is_contiguous():
             h0 = h0.float().contiguous()
@@ -126,8 +138,75 @@ def _gla(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inpl
                                                                       device=q.device)
     fn = getattr(be.lib, entry)
     _check(fn(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(o), _ptr(h0), _ptr(ht), B, H, T, Dk, Dv,
-              _bht(q), _bht(k), _bht(v), _bht(gk), _bht(o), _dt(q), _dt(gk), float(scale), be.stream(q)))
+              _bht(q), _bht(k), _bht(v), _bht(gk), _bht(o), _dt(q), _dt(gk), scale, be.stream(q)))
     return o, ht
+
+
+def gla_chunk_bwd(q, k, v, gk, d_o, scale, initial_state=None, final_state=None, d_final_state=None,
+                  need_dh0=False):
+    """K2b through the C ABI (lina_gla_chunk_bwd): returns (dq, dk, dv, dg, dh0)."""
+    B, H, T, Dk = q.shape
+    Dv = v.shape[-1]
+    be = _BACKEND
+    be.require(q, k, v, gk, d_o, initial_state, final_state, d_final_state)
+    d_o = _inner_contig(d_o.to(q.dtype))
+    if d_o.stride(0) % 4 or d_o.stride(1) % 4 or d_o.stride(2) % 4:
+        d_o = d_o.contiguous()
+    q, k = (x if not (x.stride(0) % 4 or x.stride(1) % 4 or x.stride(2) % 4) else x.contiguous() for x in (q, k))
+    h0 = None if initial_state is None else initial_state.float().contiguous()
+    dht = None if d_final_state is None else d_final_state.float().contiguous()
+    dg_tail = None
+    if dht is not None:
+        if final_state is None:
+            raise ValueError("a gradient for the final state needs the final state itself")
+        dg_tail = (final_state.float() * dht).sum(-1).contiguous()
+    dq = _head_first_empty(B, H, T, Dk, q.dtype, q.device)
+    dk = _head_first_empty(B, H, T, Dk, q.dtype, q.device)
+    dv = _head_first_empty(B, H, T, Dv, q.dtype, q.device)
+    dg = _head_first_empty(B, H, T, Dk, gk.dtype, q.device)
+    dh0 = torch.empty(B, H, Dk, Dv, dtype=torch.float32, device=q.device) if need_dh0 else None
+    nbytes = int(be.lib.lina_gla_chunk_bwd_workspace(B, H, T, Dk, Dv))
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+    _check(be.lib.lina_gla_chunk_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(d_o), _ptr(h0), _ptr(dht),
+                                     _ptr(dg_tail), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dg), _ptr(dh0), _ptr(ws),
+                                     B, H, T, Dk, Dv, _bht(q), _bht(k), _bht(v), _bht(gk), _bht(d_o), _bht(dq),
+                                     _bht(dk), _bht(dv), _bht(dg), _dt(q), _dt(gk), float(scale), be.stream(q)))
+    return dq, dk, dv, dg, dh0
+
+
+class _GLAFunction(torch.autograd.Function):
+    """K2 forward + K2b backward (the training path of reference model/gla.py:193,195).  The forward of a
+    call that needs gradients always takes the chunk kernel, whichever fla name it was reached through:
+    the recurrence is the same and K2b recomputes the states chunk-wise."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, gk, scale, initial_state, output_final_state):
+        o, ht = _gla_launch("lina_gla_chunk_fwd", q, k, v, gk, scale, initial_state, output_final_state)
+        ctx.save_for_backward(q, k, v, gk, initial_state, ht)
+        ctx.scale = scale
+        ctx.need_dh0 = initial_state is not None and initial_state.requires_grad
+        if ht is None:
+            return o, None
+        return o, ht
+
+    @staticmethod
+    def backward(ctx, d_o, d_ht):
+        q, k, v, gk, h0, ht = ctx.saved_tensors
+        dq, dk, dv, dg, dh0 = gla_chunk_bwd(q, k, v, gk, d_o, ctx.scale, h0, ht, d_ht, ctx.need_dh0)
+        if dh0 is not None and h0 is not None and dh0.dtype != h0.dtype:
+            dh0 = dh0.to(h0.dtype)
+        return dq, dk, dv, dg, None, dh0, None
+
+
+def _needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _gla(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inplace_state=False):
+    q, k, v, gk, scale = _gla_prepare(q, k, v, gk, scale, initial_state)
+    if _needs_grad(q, k, v, gk, initial_state):
+        return _GLAFunction.apply(q, k, v, gk, scale, initial_state, bool(output_final_state))
+    return _gla_launch(entry, q, k, v, gk, scale, initial_state, output_final_state, inplace_state)
 
 
 def fused_recurrent_gla(q, k, v, gk, scale=None, initial_state=None, output_final_state=False,

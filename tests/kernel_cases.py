@@ -96,6 +96,39 @@ def check_chunk(dev, B, H, T, Dk, Dv, dtype, resets=False):
     assert_close(o, o3.float(), 2 * tol_out(dtype, chunk=True), "K2 vs K1")
 
 
+def check_chunk_bwd(dev, B, H, T, Dk, Dv, dtype, resets=False, with_h0=True, with_dht=True, via="chunk_gla"):
+    """K2b: gradients of (o, final_state) w.r.t. q, k, v, g, h0 against torch autograd through the fp64
+    recurrent oracle.  Tolerances relative to max|ref|: fp32 I/O 2e-4 (different summation order, fast exp),
+    bf16 I/O 2e-2 (gradients are rounded to bf16 once; the arithmetic is fp32)."""
+    q, k, v, gk, h0 = make_gla_inputs(B, H, T, Dk, Dv, dtype, dev, seed=5, resets=resets)
+    if not with_h0:
+        h0 = None
+    g = torch.Generator().manual_seed(6)
+    d_o = torch.randn(B, T, H * Dv, generator=g).to(dtype).to(dev).view(B, T, H, Dv).transpose(1, 2)
+    d_ht = (torch.randn(B, H, Dk, Dv, generator=g) * 0.3).to(dev) if with_dht else None
+    leaves = [x.detach().clone().requires_grad_(True) for x in (q, k, v, gk)]
+    lh0 = None if h0 is None else h0.detach().clone().requires_grad_(True)
+    o, S = getattr(ops, via)(*leaves, initial_state=lh0, output_final_state=with_dht)
+    loss = (o.float() * d_o.float()).sum()
+    if with_dht:
+        loss = loss + (S * d_ht).sum()
+    loss.backward()
+    # oracle
+    rl = [x.detach().cpu().to(F64).requires_grad_(True) for x in (q, k, v, gk)]
+    rh0 = None if h0 is None else h0.detach().cpu().to(F64).requires_grad_(True)
+    ro, rS = O.naive_recurrent_gla(*rl, initial_state=rh0, output_final_state=True, compute_dtype=F64)
+    rloss = (ro * d_o.cpu().to(F64)).sum()
+    if with_dht:
+        rloss = rloss + (rS * d_ht.cpu().to(F64)).sum()
+    rloss.backward()
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-4
+    for name, a, r in zip(("dq", "dk", "dv", "dg"), leaves, rl):
+        assert a.grad is not None and a.grad.dtype == a.dtype, name
+        assert_close(a.grad, r.grad, tol, f"K2b {name}")
+    if h0 is not None:
+        assert_close(lh0.grad, rh0.grad, 2e-4 if dtype == torch.float32 else 1e-2, "K2b dh0")
+
+
 def check_conv(dev, B, T, D, W, dtype):
     g = torch.Generator().manual_seed(2)
     x = torch.randn(B, T, D, generator=g).to(dtype).to(dev)

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import gla_oracle as O
-from kernel_cases import (check_argmax, check_chunk, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
+from kernel_cases import (check_argmax, check_chunk, check_chunk_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
                           check_prologue, check_recurrent, check_rmsnorm, check_swiglu)
 
 DEV = "cpu"
@@ -26,6 +26,20 @@ def test_chunk(emu, Dk, Dv, T, dtype):
 @pytest.mark.parametrize("T,resets", [(5, False), (40, False), (70, True)])
 def test_chunk_full_head_kernel(emu, T, resets):
     check_chunk(DEV, B=1, H=1, T=T, Dk=256, Dv=256, dtype=torch.bfloat16, resets=resets)
+
+
+@pytest.mark.parametrize("Dk,Dv,T,dtype", [(64, 64, 37, torch.float32), (128, 64, 21, torch.float32),
+                                            (64, 128, 33, torch.bfloat16)])
+def test_chunk_bwd(emu, Dk, Dv, T, dtype):
+    check_chunk_bwd(DEV, B=1, H=2, T=T, Dk=Dk, Dv=Dv, dtype=dtype)
+
+
+def test_chunk_bwd_reset_gates_no_state(emu):
+    check_chunk_bwd(DEV, B=1, H=1, T=40, Dk=64, Dv=64, dtype=torch.float32, resets=True, with_h0=False, with_dht=False)
+
+
+def test_chunk_bwd_reset_gates(emu):
+    check_chunk_bwd(DEV, B=1, H=1, T=40, Dk=64, Dv=64, dtype=torch.float32, resets=True, via="fused_chunk_gla")
 
 
 def test_chunk_reset_gates(emu):
