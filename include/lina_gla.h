@@ -115,6 +115,16 @@ int lina_short_conv_step(const void* x, const void* w, const void* bias, void* c
                          int B, int D, int W, int64_t x_sb, int64_t y_sb,
                          int activation, int dtype, lina_stream_t stream);
 
+/* K3b -- backward of K3 (cache == NULL): dx [B,T,D] (strided like x) and fp32 partial sums of the
+ * weight / bias gradient, dwb_partial [B * ceil(T / LINA_CONV_BWD_TT)][D][W+1] (slot W = bias), which
+ * the caller sums over dim 0.  Replaces the autograd backward of ShortConvolution.forward
+ * (reference model/gla.py:161-163 under loss.backward()). */
+#define LINA_CONV_BWD_TT 64
+int lina_short_conv_bwd(const void* x, const void* w, const void* bias, const float* mask, const void* dy,
+                        void* dx, float* dwb_partial, int B, int T, int D, int W,
+                        int64_t x_sb, int64_t x_st, int64_t dy_sb, int64_t dy_st, int64_t dx_sb, int64_t dx_st,
+                        int activation, int dtype, lina_stream_t stream);
+
 /* K5 -- y = x * rsqrt(mean(x^2) + eps) * w  [ * g * sigmoid(g) ]   over the last dim D.
  * g == NULL -> plain RMSNorm.  w == NULL -> no affine.
  * Rows are addressed two-level: row r -> (ro, ri) = (r / rows_inner, r % rows_inner) and the row
@@ -130,6 +140,15 @@ int lina_rmsnorm_gate_fwd(const void* x, const void* g, const void* w, void* y,
                           int64_t y_outer, int64_t y_inner,
                           int n_partial, int64_t x_part_stride,
                           float eps, int x_dtype, int dtype, lina_stream_t stream);
+
+/* K5b -- backward of K5 over contiguous rows [rows][D], all tensors of `dtype` (training path).
+ * Replaces the autograd backward of FusedRMSNormSwishGate / RMSNorm (reference model/gla.py:219,222).
+ *   g, dg: both given (swish gate) or both NULL; w may be NULL;
+ *   dw_partial: fp32 [lina_rmsnorm_gate_bwd_partials(rows)][D], summed over dim 0 by the caller. */
+#define LINA_NORM_BWD_MAX_WG 512
+int lina_rmsnorm_gate_bwd_partials(int64_t rows);
+int lina_rmsnorm_gate_bwd(const void* x, const void* g, const void* w, const void* dy, void* dx, void* dg,
+                          float* dw_partial, int64_t rows, int D, float eps, int dtype, lina_stream_t stream);
 
 /* K6a -- codec-token embedding gather-sum: out[n,:] = sum_q table[q, idx[q,n], :].
  * Replaces MultiEmbedding.forward + reduce('q b n d -> b n d','sum')

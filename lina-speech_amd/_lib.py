@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblina_gla.so")
 
 LINA_F32, LINA_BF16 = 0, 1
+CONV_BWD_TT = 64          # LINA_CONV_BWD_TT in include/lina_gla.h
 
 
 class BHT(C.Structure):
@@ -33,6 +34,10 @@ PROTOTYPES = {
     "lina_gla_chunk_bwd": (C.c_int, [_p] * 14 + [_i] * 5 + [BHT] * 9 + [_i, _i, _f, _p]),
     "lina_short_conv_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _p]),
     "lina_short_conv_step": (C.c_int, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _i64, _i, _i, _p]),
+    "lina_short_conv_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64,
+                                      _i, _i, _p]),
+    "lina_rmsnorm_gate_bwd_partials": (C.c_int, [_i64]),
+    "lina_rmsnorm_gate_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _i, _p]),
     "lina_rmsnorm_gate_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i64,
                                         _f, _i, _i, _p]),
     "lina_embed_sum": (C.c_int, [_p, _p, _p, _i, _i64, _i, _i, _i, _p]),

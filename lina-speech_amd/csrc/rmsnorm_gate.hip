@@ -97,3 +97,142 @@ extern "C" int lina_rmsnorm_gate_fwd(const void* x, const void* g, const void* w
     }
     return check_launch("lina_rmsnorm_gate_fwd");
 }
+
+// ================================================================================================
+// K5b -- backward of K5 over contiguous rows [rows][D] (training path):
+//   n = x rs, u = n w, s = g sigmoid(g), y = u s
+//   dg = dy u sigmoid(g) (1 + g (1 - sigmoid(g)))      dn = dy s w      dw += dy s n
+//   dx = rs (dn - n mean(dn n))
+// One wave per row as in the forward; a wave walks rows with stride 4*gridDim.x and keeps its share of dw
+// in registers; the 4 waves of a workgroup are summed through LDS into dw_partial[blockIdx.x][D] (fp32),
+// which the caller sums (deterministic, no atomics).
+// ================================================================================================
+namespace lina {
+
+constexpr int kNormBwdMaxWG = LINA_NORM_BWD_MAX_WG;
+
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_gate_bwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ w, const T* __restrict__ dy,
+    T* __restrict__ dx, T* __restrict__ dg, float* __restrict__ dw_partial, int64_t rows, int D, float eps) {
+    __shared__ float4 s_dw[3][kNormMaxTrips * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int trips = (D + 255) / 256;
+    float4 dwa[kNormMaxTrips];
+#pragma unroll
+    for (int i = 0; i < kNormMaxTrips; ++i) dwa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int64_t off = row * D;
+        float4 xv[kNormMaxTrips], dn[kNormMaxTrips];
+        float ss = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kNormMaxTrips; ++i) {
+            const int e = i * 256 + lane * 4;
+            xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < trips && e < D) {
+                xv[i] = ld4(x + off + e);
+                ss += xv[i].x * xv[i].x + xv[i].y * xv[i].y + xv[i].z * xv[i].z + xv[i].w * xv[i].w;
+            }
+        }
+        ss += shfl_xor(ss, 1); ss += shfl_xor(ss, 2); ss += shfl_xor(ss, 4);
+        ss += shfl_xor(ss, 8); ss += shfl_xor(ss, 16); ss += shfl_xor(ss, 32);
+        const float rs = rsqrtf(ss / (float)D + eps);
+        float dot = 0.0f;   // sum dn n
+#pragma unroll
+        for (int i = 0; i < kNormMaxTrips; ++i) {
+            const int e = i * 256 + lane * 4;
+            dn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < trips && e < D) {
+                const float4 d4 = ld4(dy + off + e);
+                const float4 w4 = w ? ld4(w + e) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float nn[4] = {xv[i].x * rs, xv[i].y * rs, xv[i].z * rs, xv[i].w * rs};
+                const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+                const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+                float sv[4] = {1.f, 1.f, 1.f, 1.f}, dgo[4];
+                if (g) {
+                    const float4 g4 = ld4(g + off + e);
+                    const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float sg = sigmoidf(gg[c]);
+                        sv[c] = gg[c] * sg;
+                        dgo[c] = dd[c] * nn[c] * ww[c] * sg * (1.0f + gg[c] * (1.0f - sg));
+                    }
+                    st4(dg + off + e, make_float4(dgo[0], dgo[1], dgo[2], dgo[3]));
+                }
+                float dnn[4], dwv[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float du = dd[c] * sv[c];
+                    dwv[c] = du * nn[c];
+                    dnn[c] = du * ww[c];
+                    dot += dnn[c] * nn[c];
+                }
+                dwa[i].x += dwv[0]; dwa[i].y += dwv[1]; dwa[i].z += dwv[2]; dwa[i].w += dwv[3];
+                dn[i] = make_float4(dnn[0], dnn[1], dnn[2], dnn[3]);
+            }
+        }
+        dot += shfl_xor(dot, 1); dot += shfl_xor(dot, 2); dot += shfl_xor(dot, 4);
+        dot += shfl_xor(dot, 8); dot += shfl_xor(dot, 16); dot += shfl_xor(dot, 32);
+        const float m = dot / (float)D;
+#pragma unroll
+        for (int i = 0; i < kNormMaxTrips; ++i) {
+            const int e = i * 256 + lane * 4;
+            if (i < trips && e < D) {
+                float4 a;
+                a.x = rs * (dn[i].x - xv[i].x * rs * m); a.y = rs * (dn[i].y - xv[i].y * rs * m);
+                a.z = rs * (dn[i].z - xv[i].z * rs * m); a.w = rs * (dn[i].w - xv[i].w * rs * m);
+                st4(dx + off + e, a);
+            }
+        }
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int i = 0; i < kNormMaxTrips; ++i) s_dw[wv - 1][i * 64 + lane] = dwa[i];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int i = 0; i < kNormMaxTrips; ++i) {
+            const int e = i * 256 + lane * 4;
+            if (i < trips && e < D) {
+                float4 a = dwa[i];
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const float4 c = s_dw[o][i * 64 + lane];
+                    a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+                }
+                *reinterpret_cast<float4*>(dw_partial + (int64_t)blockIdx.x * D + e) = a;
+            }
+        }
+    }
+}
+
+}  // namespace lina
+
+extern "C" int lina_rmsnorm_gate_bwd_partials(int64_t rows) {
+    if (rows <= 0) return 0;
+    const int64_t wg = (rows + 3) / 4;
+    return (int)(wg < lina::kNormBwdMaxWG ? wg : lina::kNormBwdMaxWG);
+}
+
+extern "C" int lina_rmsnorm_gate_bwd(const void* x, const void* g, const void* w, const void* dy, void* dx, void* dg,
+                                     float* dw_partial, int64_t rows, int D, float eps, int dtype,
+                                     lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(x && dy && dx && dw_partial, "lina_rmsnorm_gate_bwd: null pointer");
+    LINA_REQUIRE(!g == !dg, "lina_rmsnorm_gate_bwd: g and dg must both be given or both be NULL");
+    LINA_REQUIRE(rows > 0, "lina_rmsnorm_gate_bwd: rows must be positive");
+    LINA_REQUIRE(D > 0 && D % 4 == 0 && D <= kNormMaxTrips * 256,
+                 "lina_rmsnorm_gate_bwd: D=%d must be a multiple of 4 and <= %d", D, kNormMaxTrips * 256);
+    LINA_REQUIRE(valid_dtype(dtype), "lina_rmsnorm_gate_bwd: bad dtype");
+    dim3 grid((unsigned)lina_rmsnorm_gate_bwd_partials(rows));
+    if (dtype == LINA_F32) {
+        LINA_LAUNCH((rmsnorm_gate_bwd_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, (const float*)g,
+                    (const float*)w, (const float*)dy, (float*)dx, (float*)dg, dw_partial, rows, D, eps);
+    } else {
+        LINA_LAUNCH((rmsnorm_gate_bwd_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)g,
+                    (const bf16_t*)w, (const bf16_t*)dy, (bf16_t*)dx, (bf16_t*)dg, dw_partial, rows, D, eps);
+    }
+    return check_launch("lina_rmsnorm_gate_bwd");
+}

@@ -133,3 +133,118 @@ extern "C" int lina_short_conv_step(const void* x, const void* w, const void* bi
     if (dtype == LINA_F32) return conv_step_dispatch<float>(x, w, bias, cache, y, B, D, W, x_sb, y_sb, activation, stream);
     return conv_step_dispatch<bf16_t>(x, w, bias, cache, y, B, D, W, x_sb, y_sb, activation, stream);
 }
+
+// ================================================================================================
+// K3b -- backward of the prefill convolution (no cache): recompute z, dz = dy * act'(z),
+//   dx_t = mask_t * sum_j w[j] dz_{t+(W-1)-j},   dw[j] = sum_{b,t} dz_t xm_{t-(W-1)+j},   dbias = sum dz.
+// Same thread map as the forward (lanes along channels, one thread slides over kConvBwdTT steps, plus W-1
+// look-ahead steps whose dz it needs for dx).  Weight / bias gradients leave as fp32 partials
+// [B * ceil(T/kConvBwdTT)][D][W+1] (slot W = bias) that the caller sums: deterministic, no atomics.
+// ================================================================================================
+namespace lina {
+
+constexpr int kConvBwdTT = LINA_CONV_BWD_TT;
+
+template <int W, typename T>
+__global__ __launch_bounds__(256) void short_conv_bwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias, const float* __restrict__ mask,
+    const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ part, int Tn, int D, int64_t x_sb, int64_t x_st,
+    int64_t dy_sb, int64_t dy_st, int64_t dx_sb, int64_t dx_st, int act) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = blockIdx.y * kConvBwdTT;
+    const int b = blockIdx.z;
+    if (c >= D) return;
+    float wv[W], dw[W], dzw[W];       // dzw[j] = dz_{u-j}
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        wv[j] = ld(w + (int64_t)c * W + j);
+        dw[j] = 0.0f;
+        dzw[j] = 0.0f;
+    }
+    float db = 0.0f;
+    const float bv = bias ? ld(bias + c) : 0.0f;
+    const T* xb = x + b * x_sb + c;
+    const T* dyb = dy + b * dy_sb + c;
+    const float* mb = mask ? mask + (int64_t)b * Tn : nullptr;
+    float win[W];
+    win[0] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < W - 1; ++j) {
+        const int tt = t0 - (W - 1) + j;
+        win[j + 1] = (tt >= 0) ? ld(xb + tt * x_st) * (mb ? mb[tt] : 1.0f) : 0.0f;
+    }
+    const int t1 = min(t0 + kConvBwdTT, Tn);
+    for (int u = t0; u < t1 + W - 1; ++u) {
+        float dz = 0.0f;
+        if (u < Tn) {
+#pragma unroll
+            for (int j = 0; j < W - 1; ++j) win[j] = win[j + 1];
+            win[W - 1] = ld(xb + u * x_st) * (mb ? mb[u] : 1.0f);
+            float z = bv;
+#pragma unroll
+            for (int j = 0; j < W; ++j) z = fmaf(wv[j], win[j], z);
+            dz = ld(dyb + u * dy_st);
+            if (act) {
+                const float sg = sigmoidf(z);
+                dz *= sg * (1.0f + z * (1.0f - sg));
+            }
+            if (u < t1) {
+#pragma unroll
+                for (int j = 0; j < W; ++j) dw[j] = fmaf(dz, win[j], dw[j]);
+                db += dz;
+            }
+        }
+#pragma unroll
+        for (int j = W - 1; j > 0; --j) dzw[j] = dzw[j - 1];
+        dzw[0] = dz;
+        const int t = u - (W - 1);
+        if (t >= t0) {
+            float a = 0.0f;
+#pragma unroll
+            for (int j = 0; j < W; ++j) a = fmaf(wv[j], dzw[j], a);
+            st(dx + b * dx_sb + t * dx_st + c, a * (mb ? mb[t] : 1.0f));
+        }
+    }
+    float* pp = part + (((int64_t)b * gridDim.y + blockIdx.y) * D + c) * (W + 1);
+#pragma unroll
+    for (int j = 0; j < W; ++j) pp[j] = dw[j];
+    pp[W] = db;
+}
+
+template <typename T>
+static int conv_bwd_dispatch(const void* x, const void* w, const void* bias, const float* mask, const void* dy,
+                             void* dx, float* part, int B, int Tn, int D, int W, int64_t x_sb, int64_t x_st,
+                             int64_t dy_sb, int64_t dy_st, int64_t dx_sb, int64_t dx_st, int act, lina_stream_t stream) {
+    dim3 grid((unsigned)((D + 255) / 256), (unsigned)((Tn + kConvBwdTT - 1) / kConvBwdTT), (unsigned)B);
+#define LINA_CONV_CASE(WW)                                                                                          \
+    case WW:                                                                                                        \
+        LINA_LAUNCH((short_conv_bwd_kernel<WW, T>), grid, dim3(256), 0, stream, (const T*)x, (const T*)w,           \
+                    (const T*)bias, mask, (const T*)dy, (T*)dx, part, Tn, D, x_sb, x_st, dy_sb, dy_st, dx_sb,        \
+                    dx_st, act);                                                                                    \
+        break;
+    switch (W) {
+        LINA_CONV_CASE(2) LINA_CONV_CASE(3) LINA_CONV_CASE(4) LINA_CONV_CASE(5)
+        LINA_CONV_CASE(6) LINA_CONV_CASE(7) LINA_CONV_CASE(8)
+        default: return fail(LINA_ERR_UNSUPPORTED, "lina_short_conv_bwd: W=%d not in 2..8", W);
+    }
+#undef LINA_CONV_CASE
+    return check_launch("lina_short_conv_bwd");
+}
+
+}  // namespace lina
+
+extern "C" int lina_short_conv_bwd(const void* x, const void* w, const void* bias, const float* mask, const void* dy,
+                                   void* dx, float* dwb_partial, int B, int T, int D, int W, int64_t x_sb,
+                                   int64_t x_st, int64_t dy_sb, int64_t dy_st, int64_t dx_sb, int64_t dx_st,
+                                   int activation, int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(x && w && dy && dx && dwb_partial, "lina_short_conv_bwd: null pointer");
+    LINA_REQUIRE(B > 0 && T > 0 && D > 0, "lina_short_conv_bwd: B,T,D must be positive (got %d,%d,%d)", B, T, D);
+    LINA_REQUIRE(valid_dtype(dtype), "lina_short_conv_bwd: bad dtype %d", dtype);
+    LINA_REQUIRE(activation == 0 || activation == 1, "lina_short_conv_bwd: activation must be 0 or 1");
+    if (dtype == LINA_F32)
+        return conv_bwd_dispatch<float>(x, w, bias, mask, dy, dx, dwb_partial, B, T, D, W, x_sb, x_st, dy_sb, dy_st,
+                                        dx_sb, dx_st, activation, stream);
+    return conv_bwd_dispatch<bf16_t>(x, w, bias, mask, dy, dx, dwb_partial, B, T, D, W, x_sb, x_st, dy_sb, dy_st, dx_sb,
+                                     dx_st, activation, stream);
+}

@@ -239,13 +239,57 @@ def chunk_simple_gla(q, k, v, g, scale=None, initial_state=None, output_final_st
 
 
 # --------------------------------------------------------------------------- short conv (K3 / K4)
+def _short_conv_launch(x, w, bias, mask, cache, act):
+    B, T, D = x.shape
+    W = w.shape[1]
+    be = _BACKEND
+    y = torch.empty(B, T, D, dtype=x.dtype, device=x.device)
+    if cache is not None and T == 1:
+        if mask is not None:
+            x = x * mask.unsqueeze(-1).to(x.dtype)
+        _check(be.lib.lina_short_conv_step(_ptr(x), _ptr(w), _ptr(bias), _ptr(cache), _ptr(y), B, D, W,
+                                           x.stride(0), y.stride(0), act, _dt(x), be.stream(x)))
+    else:
+        _check(be.lib.lina_short_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(mask), _ptr(cache), _ptr(y), B, T, D, W,
+                                          x.stride(0), x.stride(1), y.stride(0), y.stride(1), act, _dt(x),
+                                          be.stream(x)))
+    return y
+
+
+class _ShortConvFunction(torch.autograd.Function):
+    """K3 forward + K3b backward (cache-less prefill form, the training path)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, mask, act):
+        ctx.save_for_backward(x, w, bias, mask)
+        ctx.act = act
+        return _short_conv_launch(x, w, bias, mask, None, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, bias, mask = ctx.saved_tensors
+        B, T, D = x.shape
+        W = w.shape[1]
+        be = _BACKEND
+        dy = _inner_contig(dy.to(x.dtype))
+        dx = torch.empty(B, T, D, dtype=x.dtype, device=x.device)
+        nblk = B * ((T + _lib.CONV_BWD_TT - 1) // _lib.CONV_BWD_TT)
+        part = torch.empty(nblk, D, W + 1, dtype=torch.float32, device=x.device)
+        _check(be.lib.lina_short_conv_bwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(mask), _ptr(dy), _ptr(dx), _ptr(part),
+                                          B, T, D, W, x.stride(0), x.stride(1), dy.stride(0), dy.stride(1),
+                                          dx.stride(0), dx.stride(1), ctx.act, _dt(x), be.stream(x)))
+        red = part.sum(0)
+        dw = red[:, :W].to(w.dtype)
+        db = None if bias is None else red[:, W].to(bias.dtype)
+        return dx, dw, db, None, None
+
+
 def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional[str] = "silu"):
     """ShortConvolution.forward semantics: x [B,T,D], weight [D,1,W]|[D,W],
-    mask [B,T]|None, cache [B,D,W]|None (mutated in place)."""
+    mask [B,T]|None, cache [B,D,W]|None (mutated in place).  Differentiable when cache is None."""
     B, T, D = x.shape
     w = weight.reshape(D, -1)
     W = w.shape[1]
-    _no_grad(x, weight, bias)
     be = _BACKEND
     be.require(x, w, bias, mask, cache)
     x = _inner_contig(x)
@@ -257,28 +301,62 @@ def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional
     if cache is not None:
         if tuple(cache.shape) != (B, D, W) or cache.dtype != x.dtype or not cache.is_contiguous():
             raise ValueError(f"cache must be a contiguous {x.dtype} tensor [B,D,W]={B, D, W}")
-    y = torch.empty(B, T, D, dtype=x.dtype, device=x.device)
+    m = None if mask is None else mask.to(torch.float32).contiguous()
+    if _needs_grad(x, w, bias):
+        if cache is not None:
+            raise NotImplementedError("short_conv: gradients are built for the cache-less form only")
+        return _ShortConvFunction.apply(x, w, bias, m, act)
     if cache is not None and T == 1:
-        if mask is not None:
-            x = x * mask.unsqueeze(-1).to(x.dtype)
-        _check(be.lib.lina_short_conv_step(_ptr(x), _ptr(w), _ptr(bias), _ptr(cache), _ptr(y), B, D, W,
-                                           x.stride(0), y.stride(0), act, _dt(x), be.stream(x)))
-    else:
-        m = None if mask is None else mask.to(torch.float32).contiguous()
-        _check(be.lib.lina_short_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(m), _ptr(cache), _ptr(y), B, T, D, W,
-                                          x.stride(0), x.stride(1), y.stride(0), y.stride(1), act, _dt(x),
-                                          be.stream(x)))
-    return y
+        m = mask
+    return _short_conv_launch(x, w, bias, m, cache, act)
 
 
 # --------------------------------------------------------------------------- norm (K5)
+class _RMSNormGateFunction(torch.autograd.Function):
+    """K5 forward + K5b backward on contiguous rows [rows, D]."""
+
+    @staticmethod
+    def forward(ctx, x, g, w, eps):
+        be = _BACKEND
+        rows, D = x.shape
+        y = torch.empty_like(x)
+        _check(be.lib.lina_rmsnorm_gate_fwd(_ptr(x), _ptr(g), _ptr(w), _ptr(y), rows, 1, D, D, 0, D, 0, D, 0, 1, 0,
+                                            eps, _dt(x), _dt(y), be.stream(x)))
+        ctx.save_for_backward(x, g, w)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, w = ctx.saved_tensors
+        be = _BACKEND
+        rows, D = x.shape
+        dy = dy.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        dg = None if g is None else torch.empty_like(g)
+        npart = int(be.lib.lina_rmsnorm_gate_bwd_partials(rows))
+        part = torch.empty(npart, D, dtype=torch.float32, device=x.device)
+        _check(be.lib.lina_rmsnorm_gate_bwd(_ptr(x), _ptr(g), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dg), _ptr(part),
+                                            rows, D, ctx.eps, _dt(x), be.stream(x)))
+        dw = None if w is None else part.sum(0).to(w.dtype)
+        return dx, dg, dw, None
+
+
 def rmsnorm_swish_gate(x, g=None, weight=None, eps: float = 1e-5, n_partial: int = 1, out_dtype=None, out=None):
     """FusedRMSNormSwishGate / RMSNorm forward over the last dim.
     ``n_partial`` > 1: ``x`` is [n_partial, ..., D] partial sums (fp32) that are added first.
     A gate ``g`` that is a strided 3-D view [R, H, D] (head slices of a wider row) is read in place."""
-    _no_grad(x, g, weight)
     be = _BACKEND
     be.require(x, g, weight)
+    if _needs_grad(x, g, weight):
+        if n_partial != 1 or out is not None:
+            raise NotImplementedError("rmsnorm_swish_gate: gradients are built for the plain (n_partial=1) form only")
+        odt = out_dtype or (g.dtype if g is not None else x.dtype)
+        D = x.shape[-1]
+        x2 = x.to(odt).reshape(-1, D).contiguous()
+        g2 = None if g is None else g.to(odt).reshape(-1, D).contiguous()
+        w2 = None if weight is None else weight.to(odt).contiguous()
+        return _RMSNormGateFunction.apply(x2, g2, w2, float(eps)).view(x.shape)
     xs = x.contiguous()
     part_stride = xs.stride(0) if n_partial > 1 else 0
     shape = xs.shape[1:] if n_partial > 1 else xs.shape
@@ -308,21 +386,49 @@ def rmsnorm(x, weight=None, eps: float = 1e-5):
 
 
 # --------------------------------------------------------------------------- codec head (K6)
+def _embed_sum_launch(table, flat):
+    be = _BACKEND
+    Q, n_emb, d = table.shape
+    N = flat.shape[1]
+    out = torch.empty(N, d, dtype=table.dtype, device=table.device)
+    _check(be.lib.lina_embed_sum(_ptr(flat), _ptr(table.contiguous()), _ptr(out), Q, N, n_emb, d, _dt(table),
+                                 be.stream(table)))
+    return out
+
+
+class _EmbedSumFunction(torch.autograd.Function):
+    """K6 gather forward; the backward is a scatter-add of the output gradient into the table rows
+    (torch index_add_ in fp32 on the device -- plumbing, not a hand-written kernel)."""
+
+    @staticmethod
+    def forward(ctx, table, flat):
+        ctx.save_for_backward(flat)
+        ctx.tshape, ctx.tdtype = table.shape, table.dtype
+        return _embed_sum_launch(table, flat)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (flat,) = ctx.saved_tensors
+        Q, n_emb, d = ctx.tshape
+        dt = torch.zeros(Q, n_emb, d, dtype=torch.float32, device=dout.device)
+        src = dout.float()
+        for qi in range(Q):
+            dt[qi].index_add_(0, flat[qi], src)
+        return dt.to(ctx.tdtype), None
+
+
 def embed_sum(table, idx):
     """table [Q,n_emb,d], idx int64 [Q,B,n] -> sum_q table[q, idx[q]] : [B,n,d]
     (MultiEmbedding + reduce over quantizers; reference modeling_lina.py:131,178-179)."""
-    _no_grad(table)
     be = _BACKEND
     be.require(table, idx)
     Q, n_emb, d = table.shape
     if idx.shape[0] != Q or idx.dtype != torch.int64:
         raise ValueError("idx must be int64 [Q, ...]")
     flat = idx.reshape(Q, -1).contiguous()
-    N = flat.shape[1]
-    out = torch.empty(N, d, dtype=table.dtype, device=table.device)
-    _check(be.lib.lina_embed_sum(_ptr(flat), _ptr(table.contiguous()), _ptr(out), Q, N, n_emb, d, _dt(table),
-                                 be.stream(table)))
-    return out.view(*idx.shape[1:], d)
+    if _needs_grad(table):
+        return _EmbedSumFunction.apply(table, flat).view(*idx.shape[1:], d)
+    return _embed_sum_launch(table, flat).view(*idx.shape[1:], d)
 
 
 def argmax_rows(logits, out=None):

@@ -182,6 +182,69 @@ def check_rmsnorm(dev, rows, D, dtype):
     assert_close(y, ry, tol, "K5 partials")
 
 
+def _grad_pair(dev, dtype, *tensors):
+    mine = [None if t is None else t.to(dtype).to(dev).requires_grad_(True) for t in tensors]
+    ref = [None if t is None else t.to(dtype).float().requires_grad_(True) for t in tensors]
+    return mine, ref
+
+
+def check_conv_bwd(dev, B, T, D, W, dtype, use_bias=False, activation="silu"):
+    """K3b vs torch autograd through the oracle conv (fp32).  fp32: 2e-5; bf16: 2e-2 (dx rounded to bf16;
+    dw/dbias accumulated in fp32 from bf16 inputs, compared at 2e-2 as well)."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(B, T, D, generator=g)
+    w = torch.randn(D, 1, W, generator=g) * 0.5
+    bias = torch.randn(D, generator=g) if use_bias else None
+    mask = (torch.rand(B, T, generator=g) > 0.2).float()
+    dy = torch.randn(B, T, D, generator=g).to(dtype)
+    (mx, mw, mb), (rx, rw, rb) = _grad_pair(dev, dtype, x, w, bias)
+    y = ops.short_conv(mx, mw, mb, mask.to(dev), None, activation)
+    (y.float() * dy.to(dev).float()).sum().backward()
+    ry = O.short_conv(rx, rw, mask, None, activation=activation, bias=rb)
+    (ry * dy.float()).sum().backward()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert_close(y, ry, tol, "K3 y (grad mode)")
+    assert_close(mx.grad, rx.grad, tol, "K3b dx")
+    assert mw.grad.shape == mw.shape
+    assert_close(mw.grad, rw.grad, tol, "K3b dw")
+    if use_bias:
+        assert_close(mb.grad, rb.grad, tol, "K3b dbias")
+
+
+def check_rmsnorm_bwd(dev, rows, D, dtype, gate=True, affine=True):
+    """K5b vs torch autograd through the oracle norm (fp32).  fp32: 2e-5; bf16: 2e-2."""
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(rows, 2, D, generator=g) * 3
+    gt = torch.randn(rows, 2, D, generator=g) if gate else None
+    w = (1 + 0.1 * torch.randn(D, generator=g)) if affine else None
+    dy = torch.randn(rows, 2, D, generator=g).to(dtype)
+    (mx, mg, mw), (rx, rg, rw) = _grad_pair(dev, dtype, x, gt, w)
+    y = ops.rmsnorm_swish_gate(mx, mg, mw, 1e-5) if gate else ops.rmsnorm(mx, mw, 1e-5)
+    (y.float() * dy.to(dev).float()).sum().backward()
+    ry = O.rmsnorm_swish_gate(rx, rg, rw, 1e-5) if gate else O.rmsnorm(rx, rw, 1e-5)
+    (ry * dy.float()).sum().backward()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert_close(y, ry, tol, "K5 y (grad mode)")
+    assert_close(mx.grad, rx.grad, tol, "K5b dx")
+    if gate:
+        assert_close(mg.grad, rg.grad, tol, "K5b dg")
+    if affine:
+        assert_close(mw.grad, rw.grad, tol, "K5b dw")
+
+
+def check_embed_bwd(dev, Q, B, n, n_emb, d, dtype):
+    g = torch.Generator().manual_seed(14)
+    table = torch.randn(Q, n_emb, d, generator=g)
+    idx = torch.randint(0, n_emb, (Q, B, n), generator=g)
+    dy = torch.randn(B, n, d, generator=g).to(dtype)
+    (mt,), (rt,) = _grad_pair(dev, dtype, table)
+    y = ops.embed_sum(mt, idx.to(dev))
+    (y.float() * dy.to(dev).float()).sum().backward()
+    ry = O.embed_sum(rt, idx)
+    (ry * dy.float()).sum().backward()
+    assert_close(mt.grad, rt.grad, 1e-5 if dtype == torch.float32 else 1e-2, "K6 dtable")
+
+
 def check_embed(dev, Q, B, n, n_emb, d, dtype):
     g = torch.Generator().manual_seed(4)
     table = torch.randn(Q, n_emb, d, generator=g).to(dtype).to(dev)

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import gla_oracle as O
-from kernel_cases import (check_argmax, check_chunk, check_chunk_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
+from kernel_cases import (check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_rmsnorm_bwd, check_embed_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
                           check_prologue, check_recurrent, check_rmsnorm, check_swiglu)
 
 DEV = "cpu"
@@ -107,3 +107,19 @@ def test_cross_att_fused(emu, Tn, d, dtype):
 @pytest.mark.parametrize("Tn,d,dtype", [(9, 64, torch.float32), (70, 128, torch.bfloat16)])
 def test_cross_att_spread(emu, Tn, d, dtype):
     check_cross_spread(DEV, B=5, Tn=Tn, d=d, dtype=dtype)
+
+
+@pytest.mark.parametrize("T,W,dtype,bias,act", [(70, 4, torch.float32, False, "silu"), (5, 4, torch.float32, True, None),
+                                                (130, 3, torch.bfloat16, True, "silu")])
+def test_conv_bwd(emu, T, W, dtype, bias, act):
+    check_conv_bwd(DEV, B=2, T=T, D=96, W=W, dtype=dtype, use_bias=bias, activation=act)
+
+
+@pytest.mark.parametrize("D,dtype,gate,affine", [(256, torch.float32, True, True), (64, torch.float32, False, True),
+                                                 (128, torch.float32, True, False), (256, torch.bfloat16, True, True)])
+def test_rmsnorm_bwd(emu, D, dtype, gate, affine):
+    check_rmsnorm_bwd(DEV, rows=9, D=D, dtype=dtype, gate=gate, affine=affine)
+
+
+def test_embed_bwd(emu):
+    check_embed_bwd(DEV, Q=2, B=3, n=5, n_emb=11, d=64, dtype=torch.float32)
