@@ -1,0 +1,116 @@
+"""Minimal training step for the teacher-forced path.
+
+Mirrors what the reference's Lightning module does per step (train_lina.py:72-120): build the masks,
+``LinaModel.forward`` -> cross-entropy (``ignore_index=1``), ``loss.backward()``, AdamW.  Nothing of
+Lightning / the CLI / the data pipeline is rebuilt (out of scope).
+
+MI355X-first:
+  * the sequence kernels on the path are the HIP ones (K2/K2b chunk scan, K3/K3b short conv, K5/K5b
+    norm-gate, K6 embedding gather) reached through ``ops``; GEMMs, LayerNorm, softmax attention of the
+    text encoder and the loss stay on the vendor libraries through torch;
+  * data parallel only: one process per GPU, gradients all-reduced by RCCL over xGMI through
+    ``DistributedDataParallel`` with LARGE buckets (xGMI rings are per-link bound: few big all-reduces,
+    overlapped with the rest of backward) and ``gradient_as_bucket_view`` (no extra gradient copy);
+  * bf16 autocast for the GEMMs, fp32 master weights, fp32 recurrent state / gate cumsum inside K2.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .lina_model import LinaModel
+
+DDP_BUCKET_MB = 128        # ~0.67 GB of fp32 gradients at L169 -> 6 buckets
+
+
+@dataclass
+class Batch:
+    x: torch.Tensor                 # [b, Ttxt] text ids
+    y: torch.Tensor                 # [b, n, Q] codec ids (y[:,0] = BOS 1)
+    encoder_mask: torch.Tensor      # [b, Ttxt, Ttxt] bool
+    crossatt_mask: torch.Tensor     # [b, n, Ttxt] bool
+    logits_mask: Optional[torch.Tensor] = None   # [b, n] bool
+
+    def to(self, device):
+        mv = lambda t: None if t is None else t.to(device, non_blocking=True)
+        return Batch(mv(self.x), mv(self.y), mv(self.encoder_mask), mv(self.crossatt_mask), mv(self.logits_mask))
+
+
+def synthetic_batch(b: int, n: int, t_txt: int = 64, n_codebook: int = 4096, n_quant: int = 1, n_txt_vocab: int = 256,
+                    seed: int = 0, ragged: bool = False) -> Batch:
+    """SURVEY.md 8(d) config-5 inputs: text ids randint(3, vocab), codec ids randint(3, codebook+3) with
+    y[:,0] = 1, full masks (``ragged`` shortens some texts / targets to exercise the masks)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randint(3, n_txt_vocab, (b, t_txt), generator=g)
+    y = torch.randint(3, n_codebook + 3, (b, n, n_quant), generator=g)
+    y[:, 0] = 1
+    txt_len = torch.full((b,), t_txt)
+    y_len = torch.full((b,), n)
+    if ragged:
+        txt_len = torch.randint(max(1, t_txt // 2), t_txt + 1, (b,), generator=g)
+        y_len = torch.randint(max(2, n // 2), n + 1, (b,), generator=g)
+    em = torch.arange(t_txt)[None, :] < txt_len[:, None]
+    encoder_mask = em[:, None, :] & em[:, :, None]
+    crossatt_mask = em[:, None, :].expand(b, n, t_txt).contiguous()
+    logits_mask = torch.arange(n)[None, :] < y_len[:, None]
+    return Batch(x, y, encoder_mask, crossatt_mask, logits_mask)
+
+
+class TrainStep:
+    """forward + loss + backward + AdamW for one micro-batch per rank; data parallel when a process group is up."""
+
+    def __init__(self, model: LinaModel, lr: float = 2e-4, weight_decay: float = 0.1, betas=(0.9, 0.95),
+                 autocast_dtype: Optional[torch.dtype] = torch.bfloat16, device: Optional[torch.device] = None,
+                 grad_clip: Optional[float] = 1.0, ddp: Optional[bool] = None):
+        self.device = device if device is not None else next(model.parameters()).device
+        self.model = model.to(self.device).train()
+        self.autocast_dtype = autocast_dtype
+        self.grad_clip = grad_clip
+        use_ddp = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) if ddp is None else ddp
+        self.net = self.model
+        if use_ddp:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            ids = [self.device.index] if self.device.type == "cuda" else None
+            self.net = DDP(self.model, device_ids=ids, bucket_cap_mb=DDP_BUCKET_MB, gradient_as_bucket_view=True,
+                           broadcast_buffers=False)
+        fused = self.device.type == "cuda"
+        self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=weight_decay, betas=betas,
+                                     fused=fused)
+
+    def loss(self, batch: Batch) -> torch.Tensor:
+        if self.autocast_dtype is not None and self.device.type == "cuda":
+            with torch.autocast("cuda", dtype=self.autocast_dtype):
+                out = self.net(batch.x, batch.y, batch.encoder_mask, batch.crossatt_mask, logits_mask=batch.logits_mask)
+        else:
+            out = self.net(batch.x, batch.y, batch.encoder_mask, batch.crossatt_mask, logits_mask=batch.logits_mask)
+        return out[1]
+
+    def step(self, batch: Batch) -> torch.Tensor:
+        """One optimizer step; returns the (detached) loss of this rank's micro-batch."""
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.loss(batch)
+        loss.backward()                       # DDP: RCCL all-reduce (mean) of the buckets overlaps with backward
+        if self.grad_clip is not None:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
+        self.opt.step()
+        return loss.detach()
+
+
+def init_distributed(backend: Optional[str] = None) -> tuple[int, int, torch.device]:
+    """Join the process group torch.distributed.run describes in the environment (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*); backend 'nccl' is RCCL on ROCm.  Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local) if gpu else torch.device("cpu")
+    if gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend or ("nccl" if gpu else "gloo"), rank=rank, world_size=world)
+    return rank, world, device

@@ -138,6 +138,17 @@ def golden_lina():
         for li, st in enumerate(state.states):
             for j, s in enumerate(st):
                 out[f"cache_{li}_{j}"] = s
+    # training step: loss and parameter gradients of the teacher-forced forward in train() mode
+    # (train_lina.py:72-94; all dropouts are 0 so the step is deterministic)
+    model.train()
+    model.zero_grad()
+    _, tloss, _, _, _ = model(x, y, encoder_mask, crossatt_mask, logits_mask=logits_mask)
+    tloss.backward()
+    out["train_loss"] = tloss.detach()
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            out["grad::" + name] = p.grad.detach().clone()
+    model.eval()
     out.update(sd_arrays(model))
     npz("lina_d64.npz", **out)
 

@@ -124,3 +124,33 @@ def check_lina_golden(dev, engine=None):
                 assert len(st) == 4
                 for j, s in enumerate(st):
                     close(s, g[f"cache_{li}_{j}"], f"cache[{li}][{j}]")
+
+
+def check_lina_train_golden(dev, rel=5e-4):
+    """a-11: one teacher-forced training forward + backward in train() mode reproduces the reference's loss and
+    EVERY parameter gradient (golden captured from the reference modules under torch autograd,
+    tests/golden/make_golden.py).  fp32 model; tolerance 5e-4 of max|golden gradient| per tensor (gradients
+    pass through K2b/K3b/K5b whose summation order differs from the oracle's)."""
+    g = load_golden("lina_d64.npz")
+    model = build_lina()
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    model = model.to(dev).train()
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    logits, loss, att, _, _ = model(t("x"), t("y"), t("encoder_mask"), t("crossatt_mask"), logits_mask=t("logits_mask"))
+    close(loss, g["train_loss"], "train loss", 1e-5)
+    loss.backward()
+    names = [k[6:] for k in g.files if k.startswith("grad::")]
+    assert names, "golden has no gradients"
+    params = dict(model.named_parameters())
+    checked = 0
+    for name in names:
+        ref = g["grad::" + name]
+        p = params[name]
+        assert p.grad is not None, f"no gradient for {name}"
+        if np.abs(ref).max() < 1e-8:        # analytically zero (e.g. a key bias under softmax): rounding noise only
+            assert float(p.grad.abs().max()) < 1e-7, name
+            continue
+        close(p.grad, ref, f"grad {name}", rel)
+        checked += 1
+    assert checked >= len(names) - 4
+    return loss

@@ -54,3 +54,8 @@ def test_engine_device_side_greedy_loop(emu):
     assert torch.equal(toks, torch.from_numpy(g["gen_qs"]))
     assert atts.shape == g["gen_atts"].shape
     assert (atts - torch.from_numpy(g["gen_atts"])).abs().max() < 2e-4
+
+
+def test_train_step_loss_and_gradients_match_reference(emu):
+    from model_cases import check_lina_train_golden
+    check_lina_train_golden("cpu")

@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from kernel_cases import (assert_close, check_argmax, check_chunk, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj,
+from kernel_cases import (assert_close, check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_embed_bwd, check_rmsnorm_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj,
                           check_linear_skinny, check_prologue, check_recurrent, check_rmsnorm, check_swiglu,
                           make_gla_inputs, oracle_gla)
 from lina_speech_amd import ops
@@ -156,3 +156,49 @@ def test_missing_device_tensor_is_an_error(hip):
     x = torch.randn(2, 2, 1, 64)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.fused_recurrent_gla(x, x, x, x)
+
+
+# ----------------------------------------------------------------------------- backward kernels
+@pytest.mark.parametrize("Dk,Dv,T,dtype", [(64, 64, 37, torch.float32), (128, 256, 50, torch.float32),
+                                           (256, 256, 150, torch.float32), (256, 256, 150, torch.bfloat16),
+                                           (64, 128, 33, torch.bfloat16)])
+def test_chunk_bwd(hip, Dk, Dv, T, dtype):
+    check_chunk_bwd(DEV, B=2, H=2, T=T, Dk=Dk, Dv=Dv, dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_chunk_bwd_reset_gates(hip, dtype):
+    check_chunk_bwd(DEV, B=2, H=2, T=70, Dk=128, Dv=64, dtype=dtype, resets=True)
+    check_chunk_bwd(DEV, B=1, H=2, T=70, Dk=64, Dv=64, dtype=dtype, resets=True, with_h0=False, with_dht=False,
+                    via="fused_chunk_gla")
+
+
+def test_chunk_bwd_is_linear_in_the_output_gradient(hip):
+    # size-independent property at the training shape: grads(do1 + do2) == grads(do1) + grads(do2)
+    B, H, T, D = 2, 4, 1024, 256
+    q, k, v, gk, _ = make_gla_inputs(B, H, T, D, D, torch.bfloat16, DEV, seed=9)
+    g = torch.Generator().manual_seed(10)
+    d1 = torch.randn(B, H, T, D, generator=g).to(torch.bfloat16).to(DEV)
+    d2 = torch.randn(B, H, T, D, generator=g).to(torch.bfloat16).to(DEV)
+    scale = D ** -0.5
+    a = ops.gla_chunk_bwd(q, k, v, gk, d1, scale)
+    b = ops.gla_chunk_bwd(q, k, v, gk, d2, scale)
+    c = ops.gla_chunk_bwd(q, k, v, gk, (d1.float() + d2.float()).to(torch.bfloat16), scale)
+    for name, x, y, z in zip(("dq", "dk", "dv", "dg"), a, b, c):
+        assert_close(z.float(), x.float() + y.float(), 3e-2, f"K2b linearity {name}")
+
+
+@pytest.mark.parametrize("T,W,dtype,bias,act", [(70, 4, torch.float32, False, "silu"), (5, 4, torch.float32, True, None),
+                                                (300, 4, torch.bfloat16, False, "silu"), (130, 3, torch.bfloat16, True, "silu")])
+def test_conv_bwd(hip, T, W, dtype, bias, act):
+    check_conv_bwd(DEV, B=3, T=T, D=1024, W=W, dtype=dtype, use_bias=bias, activation=act)
+
+
+@pytest.mark.parametrize("D,dtype,gate,affine", [(256, torch.float32, True, True), (64, torch.float32, False, True),
+                                                 (1024, torch.float32, True, False), (256, torch.bfloat16, True, True)])
+def test_rmsnorm_bwd(hip, D, dtype, gate, affine):
+    check_rmsnorm_bwd(DEV, rows=2500, D=D, dtype=dtype, gate=gate, affine=affine)
+
+
+def test_embed_bwd(hip):
+    check_embed_bwd(DEV, Q=2, B=3, n=50, n_emb=4099, d=1024, dtype=torch.float32)

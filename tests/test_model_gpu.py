@@ -73,3 +73,21 @@ def test_bf16_engine_runs_and_tracks_fp32(hip):
         lb, _ = DecodeEngine(mb, x_enc.bfloat16(), batch_size=8)(y.bfloat16(), 0)
     err = (lb.float() - l32).abs().max() / l32.abs().max()
     assert torch.isfinite(lb.float()).all() and err < 5e-2, f"bf16 vs fp32 logits rel err {err:.3e}"
+
+
+def test_train_step_loss_and_gradients_match_reference(hip):
+    from model_cases import check_lina_train_golden
+    check_lina_train_golden("cuda")
+
+
+def test_l169_train_step_runs_in_bf16_autocast_and_learns(hip):
+    """a-11 at the real width: d=1024, H=4 (Dk=Dv=256) -> K2 full-head forward + K2b backward in bf16."""
+    from lina_speech_amd import configs
+    from lina_speech_amd.train import TrainStep, synthetic_batch
+    torch.manual_seed(0)
+    model = configs.l169()
+    ts = TrainStep(model, device=torch.device("cuda", 0), lr=1e-3, ddp=False)
+    batch = synthetic_batch(b=2, n=257, t_txt=32, seed=3).to("cuda")
+    losses = [float(ts.step(batch)) for _ in range(5)]
+    assert all(l == l and l < 1e4 for l in losses), losses
+    assert losses[-1] < losses[0], losses
