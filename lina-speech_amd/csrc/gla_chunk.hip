@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void gla_chunk_f32_kernel(
     float* ob = o + b * so.b + h * so.h + v0 + 16 * w + li;
 
     const bool chan = tid < DK;
+    const int ch = chan ? tid : 0;
     const int vr = tid >> 4, vc = (tid & 15) * 4;
 
     int t0 = 0;
@@ -105,14 +106,16 @@ __global__ __launch_bounds__(256) void gla_chunk_f32_kernel(
         float gv[C], qv[C], kv[C], bv[C];
 #pragma unroll
         for (int r = 0; r < C; ++r) {
-            const int t = t0 + r;
+            // unconditional loads from a clamped address + select: no branch, all loads in flight together
+            const int t = t0 + r, tc = min(t, T - 1);
             const bool in = chan && t < T;
-            gv[r] = in ? ld(gb + t * sg.t + tid) : 0.0f;
-            qv[r] = in ? qb[t * sq.t + tid] : 0.0f;
-            kv[r] = in ? kb[t * sk.t + tid] : 0.0f;
+            const float g_ = ld(gb + tc * sg.t + ch), q_ = qb[tc * sq.t + ch], k_ = kb[tc * sk.t + ch];
+            gv[r] = in ? g_ : 0.0f;
+            qv[r] = in ? q_ : 0.0f;
+            kv[r] = in ? k_ : 0.0f;
         }
-        float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t0 + vr < T) vv = *reinterpret_cast<const float4*>(vb + (t0 + vr) * sv.t + vc);
+        float4 vv = *reinterpret_cast<const float4*>(vb + min(t0 + vr, T - 1) * sv.t + vc);
+        if (t0 + vr >= T) vv = make_float4(0.f, 0.f, 0.f, 0.f);
         int nc = scan_gates(bv, gv);
         nc = wave_min_i(nc);
         if (lane == 0) s_nw[w] = nc;
@@ -248,6 +251,7 @@ __global__ __launch_bounds__(256) void gla_chunk_bf16_kernel(
     bf16_t* ob = o + b * so.b + h * so.h + v0 + 16 * w + li;
 
     const bool chan = tid < DK;
+    const int ch = chan ? tid : 0;
     const int vr = tid >> 4, vc = (tid & 15) * 4;
 
     int t0 = 0;
@@ -255,14 +259,15 @@ __global__ __launch_bounds__(256) void gla_chunk_bf16_kernel(
         float gv[C], qv[C], kv[C], bv[C];
 #pragma unroll
         for (int r = 0; r < C; ++r) {
-            const int t = t0 + r;
+            const int t = t0 + r, tc = min(t, T - 1);
             const bool in = chan && t < T;
-            gv[r] = in ? ld(gb + t * sg.t + tid) : 0.0f;
-            qv[r] = in ? ld(qb + t * sq.t + tid) : 0.0f;
-            kv[r] = in ? ld(kb + t * sk.t + tid) : 0.0f;
+            const float g_ = ld(gb + tc * sg.t + ch), q_ = ld(qb + tc * sq.t + ch), k_ = ld(kb + tc * sk.t + ch);
+            gv[r] = in ? g_ : 0.0f;
+            qv[r] = in ? q_ : 0.0f;
+            kv[r] = in ? k_ : 0.0f;
         }
-        float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t0 + vr < T) vv = ld4(vb + (t0 + vr) * sv.t + vc);
+        float4 vv = ld4(vb + min(t0 + vr, T - 1) * sv.t + vc);
+        if (t0 + vr >= T) vv = make_float4(0.f, 0.f, 0.f, 0.f);
         int nc = scan_gates(bv, gv);
         nc = wave_min_i(nc);
         if (lane == 0) s_nw[w] = nc;

@@ -19,7 +19,7 @@
 //     sweep V  (reverse): X = k~, Y = q~, Z = do[:, slice]   R = dS  [Dk x 64 of Dv]  -> dv, dh0
 //     sweep Q  (forward): X = do, Y = v,  Z = k~[:, slice]   R = S^T [Dv x 64 of Dk]  -> dq (fp32)
 //     sweep K  (reverse): X = v,  Y = do, Z = q~[:, slice]   R = dS^T[Dv x 64 of Dk]  -> dk (fp32), dh0 not needed
-// grid = (B*H, 4 slices of 64): every slice is independent (any chunk partition is exact), so a
+// grid = (B*H, slices of 64, 3 sweeps) in ONE launch: every slice is independent (any chunk partition is exact), so a
 // training micro-batch of b rows gives 4*b*H workgroups.  Chunks are 16 tokens, cut adaptively where the
 // in-chunk decay would exceed e^-60 (reverse sweeps cut from the END of the tile), exactly like K2.
 // All contractions run on v_mfma_f32_16x16x4_f32 (fp32 operands, bf16 I/O is widened when staged):
@@ -135,29 +135,35 @@ __device__ __forceinline__ f32x4 chunk_products(f32x4 (&R)[D1 / 16], const float
 
 // ===================================== sweep V : dv, dh0 ==========================================
 template <int DK, typename TIO, typename TG>
-__global__ __launch_bounds__(256) void gla_bwd_dv_kernel(
-    const TIO* __restrict__ q, const TIO* __restrict__ k, const TG* __restrict__ gk, const TIO* __restrict__ dout,
-    TIO* __restrict__ dv, const float* dht, float* dh0, int H, int T, int Dv, lina_bht_strides sq,
-    lina_bht_strides sk, lina_bht_strides sg, lina_bht_strides sdo, lina_bht_strides sdv, float scale) {
+__device__ __forceinline__ void sweep_v(
+    float* smem, int slice, const TIO* __restrict__ q, const TIO* __restrict__ k, const TG* __restrict__ gk,
+    const TIO* __restrict__ dout, TIO* __restrict__ dv, const float* dht, float* dh0, int H, int T, int Dv,
+    lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sg, lina_bht_strides sdo, lina_bht_strides sdv,
+    float scale) {
     constexpr int C = kBC, NT = DK / 16, SX = DK + 2, SZ = 64 + 16;
-    __shared__ float s_x[C * SX], s_y[C * SX];
-    __shared__ float s_z[C * SZ];
-    __shared__ float s_dec[DK];
-    __shared__ float s_A[4][C][C + 1];
-    __shared__ int s_nw[4];
+    float* s_x = smem;
+    float* s_y = s_x + C * SX;
+    float* s_z = s_y + C * SX;
+    float* s_dec = s_z + C * SZ;
+    float (*s_A)[C][C + 1] = reinterpret_cast<float (*)[C][C + 1]>(s_dec + DK);
+    int* s_nw = reinterpret_cast<int*>(s_dec + DK + 4 * C * (C + 1));
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const int v0 = blockIdx.y * 64;
+    const int v0 = slice * 64;
 
     f32x4 R[NT];
     {
-        const float* hp = dht ? dht + ((int64_t)bh * DK) * Dv + v0 + 16 * w + li : nullptr;
 #pragma unroll
-        for (int p = 0; p < NT; ++p)
+        for (int p = 0; p < NT; ++p) R[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (dht) {                                        // workgroup-uniform branch
+            const float* hp = dht + ((int64_t)bh * DK) * Dv + v0 + 16 * w + li;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) R[p][r] = hp ? hp[(int64_t)(16 * p + 4 * lg + r) * Dv] : 0.0f;
+            for (int p = 0; p < NT; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R[p][r] = hp[(int64_t)(16 * p + 4 * lg + r) * Dv];
+        }
     }
     const TIO* qb = q + b * sq.b + h * sq.h;
     const TIO* kb = k + b * sk.b + h * sk.h;
@@ -165,6 +171,7 @@ __global__ __launch_bounds__(256) void gla_bwd_dv_kernel(
     const TIO* dob = dout + b * sdo.b + h * sdo.h + v0;
     TIO* dvb = dv + b * sdv.b + h * sdv.h + v0 + 16 * w + li;
     const bool chan = tid < DK;
+    const int ch = chan ? tid : 0;
     const int vr = tid >> 4, vc = (tid & 15) * 4;
 
     int t_end = T;
@@ -173,14 +180,16 @@ __global__ __launch_bounds__(256) void gla_bwd_dv_kernel(
         float gv[C], qv[C], kv[C];
 #pragma unroll
         for (int r = 0; r < C; ++r) {
-            const int t = base + r;
+            // unconditional loads from a clamped address + select: no branch, all 48 loads in flight together
+            const int t = base + r, tc = max(t, 0);
             const bool in = chan && t >= 0;
-            gv[r] = in ? ld(gb + t * sg.t + tid) : 0.0f;
-            qv[r] = in ? ld(qb + t * sq.t + tid) : 0.0f;
-            kv[r] = in ? ld(kb + t * sk.t + tid) : 0.0f;
+            const float g_ = ld(gb + tc * sg.t + ch), q_ = ld(qb + tc * sq.t + ch), k_ = ld(kb + tc * sk.t + ch);
+            gv[r] = in ? g_ : 0.0f;
+            qv[r] = in ? q_ : 0.0f;
+            kv[r] = in ? k_ : 0.0f;
         }
-        float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (base + vr >= 0) zz = ld4(dob + (base + vr) * sdo.t + vc);
+        float4 zz = ld4(dob + max(base + vr, 0) * sdo.t + vc);
+        if (base + vr < 0) zz = make_float4(0.f, 0.f, 0.f, 0.f);
         float cs[C + 1], bv[C];
         const int wst = wave_max_b(scan_rev(cs, gv));
         if (lane == 0) s_nw[w] = wst;
@@ -228,30 +237,36 @@ __global__ __launch_bounds__(256) void gla_bwd_dv_kernel(
 //   REV = false:  X = do, Y = v,  Z = k[:, slice] e^{-b},        out32 = scale e^{b} (.) out    (dq), R0 = h0^T
 //   REV = true :  X = v,  Y = do, Z = scale q[:, slice] e^{b},   out32 = e^{-b} (.) out         (dk), R0 = dht^T
 template <int DV, typename TIO, typename TG, bool REV>
-__global__ __launch_bounds__(256) void gla_bwd_dqk_kernel(
-    const TIO* __restrict__ xin, const TIO* __restrict__ yin, const TIO* __restrict__ zin,
+__device__ __forceinline__ void sweep_qk(
+    float* smem, int slice, const TIO* __restrict__ xin, const TIO* __restrict__ yin, const TIO* __restrict__ zin,
     const TG* __restrict__ gk, float* __restrict__ out32, const float* r0, int H, int T, int Dk,
     lina_bht_strides sx, lina_bht_strides sy, lina_bht_strides sz, lina_bht_strides sg, float scale) {
     constexpr int C = kBC, NT = DV / 16, SX = DV + 2, SZ = 64 + 16;
-    __shared__ float s_x[C * SX], s_y[C * SX];
-    __shared__ float s_z[C * SZ];
-    __shared__ float s_b[C][64 + 1];
-    __shared__ float s_dec[64];
-    __shared__ float s_A[4][C][C + 1];
-    __shared__ int s_cut;
+    float* s_x = smem;
+    float* s_y = s_x + C * SX;
+    float* s_z = s_y + C * SX;
+    float (*s_b)[64 + 1] = reinterpret_cast<float (*)[64 + 1]>(s_z + C * SZ);
+    float* s_dec = s_z + C * SZ + C * (64 + 1);
+    float (*s_A)[C][C + 1] = reinterpret_cast<float (*)[C][C + 1]>(s_dec + 64);
+    int* s_cut_p = reinterpret_cast<int*>(s_dec + 64 + 4 * C * (C + 1));
+#define s_cut (*s_cut_p)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const int c0 = blockIdx.y * 64;
+    const int c0 = slice * 64;
 
     f32x4 R[NT];                                          // R[p][r] <-> (v = 16p + 4lg + r, c = c0 + 16w + li)
     {
-        const float* hp = r0 ? r0 + ((int64_t)bh * Dk + c0 + 16 * w + li) * DV + 4 * lg : nullptr;
 #pragma unroll
-        for (int p = 0; p < NT; ++p)
+        for (int p = 0; p < NT; ++p) R[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r0) {                                         // workgroup-uniform branch
+            const float* hp = r0 + ((int64_t)bh * Dk + c0 + 16 * w + li) * DV + 4 * lg;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) R[p][r] = hp ? hp[16 * p + r] : 0.0f;
+            for (int p = 0; p < NT; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R[p][r] = hp[16 * p + r];
+        }
     }
     const TIO* xb = xin + b * sx.b + h * sx.h;
     const TIO* yb = yin + b * sy.b + h * sy.h;
@@ -259,6 +274,7 @@ __global__ __launch_bounds__(256) void gla_bwd_dqk_kernel(
     const TG* gb = gk + b * sg.b + h * sg.h + c0;
     float* ob = out32 + ((int64_t)bh * T) * Dk + c0 + 16 * w + li;
     const bool chan = tid < DV;
+    const int ch = chan ? tid : 0;
     const int vr = tid >> 4, vc = (tid & 15) * 4;
 
     int pos = REV ? T : 0;                                // REV: tokens [0,pos) remain; else tokens [pos,T) remain
@@ -267,19 +283,22 @@ __global__ __launch_bounds__(256) void gla_bwd_dqk_kernel(
         float xv[C], yv[C];
 #pragma unroll
         for (int r = 0; r < C; ++r) {
-            const int t = base + r;
+            // unconditional loads from a clamped address + select: no branch, all loads in flight together
+            const int t = base + r, tc = min(max(t, 0), T - 1);
             const bool in = chan && t >= 0 && t < T;
-            xv[r] = in ? ld(xb + t * sx.t + tid) : 0.0f;
-            yv[r] = in ? ld(yb + t * sy.t + tid) : 0.0f;
+            const float x_ = ld(xb + tc * sx.t + ch), y_ = ld(yb + tc * sy.t + ch);
+            xv[r] = in ? x_ : 0.0f;
+            yv[r] = in ? y_ : 0.0f;
         }
-        float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (base + vr >= 0 && base + vr < T) zz = ld4(zb + (base + vr) * sz.t + vc);
+        float4 zz = ld4(zb + min(max(base + vr, 0), T - 1) * sz.t + vc);
+        if (base + vr < 0 || base + vr >= T) zz = make_float4(0.f, 0.f, 0.f, 0.f);
         float gv[C];
         if (w == 0) {
 #pragma unroll
             for (int r = 0; r < C; ++r) {
                 const int t = base + r;
-                gv[r] = (t >= 0 && t < T) ? ld(gb + t * sg.t + lane) : 0.0f;
+                const float g_ = ld(gb + min(max(t, 0), T - 1) * sg.t + lane);
+                gv[r] = (t >= 0 && t < T) ? g_ : 0.0f;
             }
         }
         __syncthreads();   // (0) previous chunk's tiles, s_b and s_dec are dead
@@ -349,6 +368,33 @@ __global__ __launch_bounds__(256) void gla_bwd_dqk_kernel(
     }
 }
 
+#undef s_cut
+
+// one launch for the three sweeps: grid = (B*H, max(Dk,Dv)/64, 3); blockIdx.z picks the sweep, so the three
+// independent recurrences share the chip (3x the workgroups of one sweep; the slices and sweeps of one
+// (b,h) land on the same XCD when B*H is a multiple of 8 and re-use its q/k/v/do lines in that L2)
+constexpr int bwd_smem_floats(int DK, int DV) {
+    const int dm = DK > DV ? DK : DV;
+    return 2 * kBC * (dm + 2) + kBC * 80 + kBC * 65 + dm + 4 * kBC * (kBC + 1) + 8;
+}
+
+template <int DK, int DV, typename TIO, typename TG>
+__global__ __launch_bounds__(256) void gla_bwd_sweeps_kernel(
+    const TIO* __restrict__ q, const TIO* __restrict__ k, const TIO* __restrict__ v, const TG* __restrict__ gk,
+    const TIO* __restrict__ dout, TIO* __restrict__ dv, float* __restrict__ dq32, float* __restrict__ dk32,
+    const float* h0, const float* dht, float* dh0, int H, int T, lina_bht_strides sq, lina_bht_strides sk,
+    lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides sdo, lina_bht_strides sdv, float scale) {
+    __shared__ __attribute__((aligned(16))) float smem[bwd_smem_floats(DK, DV)];
+    const int slice = blockIdx.y;
+    if (blockIdx.z == 0) {
+        if (slice < DV / 64) sweep_v<DK, TIO, TG>(smem, slice, q, k, gk, dout, dv, dht, dh0, H, T, DV, sq, sk, sg, sdo, sdv, scale);
+    } else if (blockIdx.z == 1) {
+        if (slice < DK / 64) sweep_qk<DV, TIO, TG, false>(smem, slice, dout, v, k, gk, dq32, h0, H, T, DK, sdo, sv, sk, sg, scale);
+    } else {
+        if (slice < DK / 64) sweep_qk<DV, TIO, TG, true>(smem, slice, v, dout, q, gk, dk32, dht, H, T, DK, sv, sdo, sq, sg, scale);
+    }
+}
+
 // ======================================= dg = reverse cumsum =======================================
 // pass 1: per (b,h, segment of 64 tokens, channel) total of q dq - k dk
 template <typename TIO>
@@ -407,12 +453,9 @@ static int launch_bwd(const void* q, const void* k, const void* v, const void* g
     float* tot = dk32 + (int64_t)B * H * T * DK;
     const TIO *qq = (const TIO*)q, *kk = (const TIO*)k, *vv = (const TIO*)v, *dd = (const TIO*)d_o;
     const TG* gg = (const TG*)gk;
-    LINA_LAUNCH((gla_bwd_dv_kernel<DK, TIO, TG>), dim3((unsigned)(B * H), (unsigned)(DV / 64)), dim3(256), 0, stream, qq,
-                kk, gg, dd, (TIO*)dv, dht, dh0, H, T, DV, sq, sk, sg, sdo, sdv, scale);
-    LINA_LAUNCH((gla_bwd_dqk_kernel<DV, TIO, TG, false>), dim3((unsigned)(B * H), (unsigned)(DK / 64)), dim3(256), 0,
-                stream, dd, vv, kk, gg, dq32, h0, H, T, DK, sdo, sv, sk, sg, scale);
-    LINA_LAUNCH((gla_bwd_dqk_kernel<DV, TIO, TG, true>), dim3((unsigned)(B * H), (unsigned)(DK / 64)), dim3(256), 0,
-                stream, vv, dd, qq, gg, dk32, dht, H, T, DK, sv, sdo, sq, sg, scale);
+    constexpr int NS = (DK > DV ? DK : DV) / 64;
+    LINA_LAUNCH((gla_bwd_sweeps_kernel<DK, DV, TIO, TG>), dim3((unsigned)(B * H), (unsigned)NS, 3u), dim3(256), 0, stream,
+                qq, kk, vv, gg, dd, (TIO*)dv, dq32, dk32, h0, dht, dh0, H, T, sq, sk, sv, sg, sdo, sdv, scale);
     LINA_LAUNCH((gla_bwd_dg_totals_kernel<TIO>), dim3((unsigned)(B * H), (unsigned)nseg), dim3(DK), 0, stream, qq, kk,
                 dq32, dk32, tot, H, T, DK, nseg, sq, sk);
     LINA_LAUNCH((gla_bwd_dg_final_kernel<TIO, TG>), dim3((unsigned)(B * H), (unsigned)nseg), dim3(DK), 0, stream, qq, kk,

@@ -9,4 +9,4 @@ timeout 1200 python -m pytest tests -m gpu -q --timeout=600 > gpurun_out/${TAG}_
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench=$?"; cat gpurun_out/${TAG}_bench.json; tail -5 gpurun_out/${TAG}_bench.err
 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_prof -o ${TAG} -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${TAG}_bench_prof.json 2> gpurun_out/${TAG}_bench_prof.err; echo "prof=$?"
 find gpurun_out/${TAG}_prof -type f | head -20
-f=$(find gpurun_out/${TAG}_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -25 "$f"
+db=$(find gpurun_out/${TAG}_prof -name "*results.db" | head -1); [ -n "$db" ] && python tools/prof_summary.py "$db" gpurun_out/${TAG}_kernel_stats.csv && head -25 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-200; rm -rf gpurun_out/${TAG}_prof

@@ -44,6 +44,9 @@ def main():
     bwd_bytes = B * H * T * e * (5 * D + 4 * D)          # q,k,v,g,do in; dq,dk,dv,dg out
     t_f = timed(lambda: ops.chunk_gla(q, k, v, gk))
     t_b = timed(lambda: ops.gla_chunk_bwd(q, k, v, gk, do, scale))
+    gk32 = gk.float()
+    t_g = timed(lambda: ops.chunk_gla(q, k, v, gk32))
+    print(json.dumps({"kernel": "K2 fwd, V-sliced generic kernel (fp32 gates)", "B": B, "H": H, "T": T, "ms": t_g * 1e3}))
     print(json.dumps({"kernel": "K2 fwd", "B": B, "H": H, "T": T, "ms": t_f * 1e3, "GB/s": fwd_bytes / t_f / 1e9}))
     print(json.dumps({"kernel": "K2b bwd (3 sweeps + dg)", "B": B, "H": H, "T": T, "ms": t_b * 1e3,
                       "GB/s": bwd_bytes / t_b / 1e9, "algorithmic_bytes": bwd_bytes}))
