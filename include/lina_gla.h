@@ -163,6 +163,17 @@ int lina_embed_sum(const int64_t* idx, const void* table, void* out,
 int lina_argmax_rows(const void* logits, int64_t* out, int64_t rows, int n, int64_t row_stride,
                      int dtype, lina_stream_t stream);
 
+/* K6c -- top-k / temperature sampling, one token per logits row, on the device.
+ * Replaces topk_sampling(seq, k, temp) for k > 1 (reference model/tools.py:38-44, called from
+ * model/modeling_lina.py:159-164): keep_j = (x_j / temp >= k-th largest x), p = softmax of the kept
+ * x_j / temp, token = inverse CDF (index order) of ONE uniform number per row.
+ *   u_ext: fp32 [rows] uniforms in [0,1) supplied by the caller, or NULL: then the kernel hashes
+ *          (seed, step[0], row) -- `step` is a DEVICE int64 the caller advances, so a replayed graph
+ *          draws fresh numbers (NULL step = 0).  n <= 8192.  out: int64 [rows]. */
+int lina_topk_sample_rows(const void* logits, int64_t* out, int64_t rows, int n, int64_t row_stride,
+                          int k, float temp, const float* u_ext, uint64_t seed, const int64_t* step,
+                          int dtype, lina_stream_t stream);
+
 /* K4x3 + K7 -- decode-step prologue of one GLA mixer (reference model/gla.py:158-163,174-180
  * at T = 1): three conv steps on the q/k/v slices of the fused projection row `z`, and the
  * gate  gk = logsigmoid(W2 * z_lowrank + b2) / normalizer  (optionally clamped from below).

@@ -43,13 +43,14 @@ class CodecHead(nn.Module):
 
 
 def topk_sampling(seq, k: int = 1, temp: float = 1.0, generator=None):
-    """Top-k / temperature sampling over the last dim of ``seq [rows, vocab]`` -> ``[rows, 1]``.
-    k == 1 is the greedy pick and runs as the device-side arg-max kernel (K6b)."""
+    """Top-k / temperature sampling over the last dim of ``seq [rows, vocab]`` -> ``[rows, 1]``
+    (reference model/tools.py:38-44).  k == 1 is the greedy pick (device-side arg-max, K6b); k > 1 runs the
+    device-side sampler K6c on one uniform number per row drawn from torch's generator (same distribution as
+    the reference's softmax + multinomial; torch.multinomial's own random stream is not reproduced)."""
     if k == 1:
         return ops.argmax_rows(seq).unsqueeze(-1)
-    kth = torch.topk(seq, k, dim=-1).values[:, -1:]
-    logits = (seq / temp).masked_fill((seq / temp) < kth, -float("inf"))
-    return torch.multinomial(torch.softmax(logits, dim=-1), num_samples=1, generator=generator)
+    u = torch.rand(seq.shape[0], device=seq.device, generator=generator)
+    return ops.topk_sample_rows(seq, k, temp, u=u).unsqueeze(-1)
 
 
 def delay_rvq(code, head_token: int = -2, tail_token: int = -3):

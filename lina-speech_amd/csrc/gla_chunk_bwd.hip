@@ -105,15 +105,16 @@ __device__ __forceinline__ f32x4 chunk_products(f32x4 (&R)[D1 / 16], const float
         acc1 = mfma_f32_16x16x4(xp[3], R[p][3], acc1);
     }
     {   // partial M[m][n] = X[m] . Y[n] over this wave's quarter of D1
-        f32x4 pa = {0.f, 0.f, 0.f, 0.f};
+        f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
         const int c0 = w * (D1 / 4);
 #pragma unroll
-        for (int kk = 0; kk < D1 / 16; ++kk) {
+        for (int kk = 0; kk < D1 / 16; kk += 2) {
             const int cc = c0 + 4 * kk + lg;
             pa = mfma_f32_16x16x4(s_x[li * SX + cc], s_y[li * SX + cc], pa);
+            pb = mfma_f32_16x16x4(s_x[li * SX + cc + 4], s_y[li * SX + cc + 4], pb);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_A[w][4 * lg + r][li] = pa[r];
+        for (int r = 0; r < 4; ++r) s_A[w][4 * lg + r][li] = pa[r] + pb[r];
     }
     __syncthreads();
     float zf[4];
@@ -126,10 +127,11 @@ __device__ __forceinline__ f32x4 chunk_products(f32x4 (&R)[D1 / 16], const float
         if (kk & 1) acc1 = mfma_f32_16x16x4(a, zf[kk], acc1);
         else acc0 = mfma_f32_16x16x4(a, zf[kk], acc0);
     }
+    // kk outermost: consecutive MFMAs hit different accumulators (the f32 MFMA's dependent latency exceeds its issue time)
 #pragma unroll
-    for (int p = 0; p < NT; ++p)
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) R[p] = mfma_f32_16x16x4(s_y[(4 * kk + lg) * SX + 16 * p + li], zf[kk], R[p]);
+        for (int p = 0; p < NT; ++p) R[p] = mfma_f32_16x16x4(s_y[(4 * kk + lg) * SX + 16 * p + li], zf[kk], R[p]);
     return f32x4{acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]};
 }
 

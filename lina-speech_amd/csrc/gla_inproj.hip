@@ -59,12 +59,14 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
         ap[mt] = A + (int64_t)(m_ok[mt] ? m : 0) * lda + F::KL * lg;
     }
     const int nsteps = K / F::KSTEP;
-    int ks = w;
-    for (; ks + 4 * (U - 1) < nsteps; ks += 4 * U) {
+    // wave w takes k-steps {2w, 2w+1} + 8j: its two consecutive 64-byte (bf16) loads of a row are the two halves
+    // of ONE 128-byte line, so every line is pulled into this CU's L1 by a single wave, back to back
+    int ks = 0;                                  // per-wave step counter; global k-step = kstep_of(w, ks)
+    for (; kstep_of(w, ks + U - 1) < nsteps; ks += U) {
         F fb[U][NT], fa[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int k0 = (ks + 4 * u) * F::KSTEP;
+            const int k0 = kstep_of(w, ks + u) * F::KSTEP;
 #pragma unroll
             for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[u][j].load(wp[j] + k0); else fb[u][j].zero(); }
 #pragma unroll
@@ -80,8 +82,8 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
                 for (int j = 0; j < NT; ++j) acc[j * MT + mt] = F::mma(fa[u][mt], fb[u][j], acc[j * MT + mt]);
             }
     }
-    for (; ks < nsteps; ks += 4) {
-        const int k0 = ks * F::KSTEP;
+    for (; kstep_of(w, ks) < nsteps; ++ks) {
+        const int k0 = kstep_of(w, ks) * F::KSTEP;
         F fb[NT], fa[MT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[j].load(wp[j] + k0); else fb[j].zero(); }

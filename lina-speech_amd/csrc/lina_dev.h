@@ -31,6 +31,12 @@ __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int shfl_i(int v, int src) { return __shfl(v, src, 64); }
+// value of lane+d / lane-d; a lane whose source is outside the wave gets its own value back
+__device__ __forceinline__ int shfl_down_i(int v, int d) { return __shfl_down(v, d, 64); }
+__device__ __forceinline__ float shfl_up(float v, int d) { return __shfl_up(v, d, 64); }
+// LDS atomics on a workgroup-shared int
+__device__ __forceinline__ void lds_atomic_add(int* p, int v) { atomicAdd(p, v); }
+__device__ __forceinline__ void lds_atomic_max(int* p, int v) { atomicMax(p, v); }
 
 __device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

@@ -10,7 +10,7 @@
 //   * bias, residual add (out = resid + ...), and the SwiGLU gate silu(a)*b of base_blocks.py:48-50
 //     (the workgroup computes column n of both halves), incl. the constant-1 bias column.
 // Work split: grid = (ceil(N/16), ceil(M/64)); 256 threads = 4 waves; a workgroup owns a 64 x 16
-// output tile; wave w takes k-steps w, w+4, ... for ALL four 16-row m-tiles (in-workgroup split-K),
+// output tile; wave w takes k-steps {2w,2w+1}+8j (whole 128-B lines) for ALL 16-row m-tiles (in-workgroup split-K),
 // so every byte of W and of A is loaded once per workgroup, straight from global memory into MFMA
 // fragment layout (16 B per lane, no LDS staging: each operand byte is used once per wave).  The four
 // partial accumulator sets are reduced through LDS; wave w finalises m-tile w.
@@ -67,12 +67,14 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
     }
 
     const int nsteps = K / F::KSTEP;
-    int ks = w;
-    for (; ks + 4 * (U - 1) < nsteps; ks += 4 * U) {
+    // wave w takes k-steps {2w, 2w+1} + 8j: its two consecutive 64-byte (bf16) loads of a row are the two halves
+    // of ONE 128-byte line, so every line is pulled into this CU's L1 by a single wave, back to back
+    int ks = 0;                                  // per-wave step counter; global k-step = kstep_of(w, ks)
+    for (; kstep_of(w, ks + U - 1) < nsteps; ks += U) {
         F fb[U][G], fa[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int k0 = (ks + 4 * u) * F::KSTEP;
+            const int k0 = kstep_of(w, ks + u) * F::KSTEP;
 #pragma unroll
             for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[u][g].load(wp[g] + k0); else fb[u][g].zero(); }
 #pragma unroll
@@ -90,8 +92,8 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
                 for (int g = 0; g < G; ++g) acc[g * MT + mt] = F::mma(fa[u][mt], fb[u][g], acc[g * MT + mt]);
             }
     }
-    for (; ks < nsteps; ks += 4) {
-        const int k0 = ks * F::KSTEP;
+    for (; kstep_of(w, ks) < nsteps; ++ks) {
+        const int k0 = kstep_of(w, ks) * F::KSTEP;
         F fb[G], fa[MT];
 #pragma unroll
         for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[g].load(wp[g] + k0); else fb[g].zero(); }

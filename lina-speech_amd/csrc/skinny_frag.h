@@ -6,6 +6,9 @@
 
 namespace lina {
 
+// split-K over the 4 waves of a workgroup: the i-th k-step of wave w (pairs of adjacent steps per wave)
+__device__ __forceinline__ int kstep_of(int w, int i) { return ((i >> 1) << 3) + 2 * w + (i & 1); }
+
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> {
     static constexpr int KSTEP = 32, KL = 8;  // k per step / k per lane

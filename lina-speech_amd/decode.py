@@ -290,10 +290,14 @@ class DecodeEngine:
     step = __call__
 
     # ------------------------------------------------------------------ fully device-side greedy loop
-    def begin_greedy(self, max_steps: int, y0: Optional[torch.Tensor] = None):
-        """Arm the device-side greedy loop: token picks (K6b), the next-token embedding (K6a) and the
-        token log are part of the captured step, so one token == one graph replay and nothing is read
-        back until ``greedy_tokens()``."""
+    def begin_greedy(self, max_steps: int, y0: Optional[torch.Tensor] = None, k: int = 1, temp: float = 1.0,
+                     seed: int = 0, first_greedy_quant: int = 0):
+        """Arm the device-side decode loop: token picks, the next-token embedding (K6a) and the token log are
+        part of the captured step, so one token == one graph replay and nothing is read back until
+        ``greedy_tokens()``.  Quantizers ``i < first_greedy_quant`` are SAMPLED (top-``k``, temperature
+        ``temp``, K6c with uniforms hashed from (seed, device step counter, row)) like the reference's default
+        generation mode (modeling_lina.py:159-164); the others -- all of them by default -- take the arg-max
+        (K6b)."""
         emb = self.model.rvq_embed
         if y0 is None:
             y0 = emb.embed_sum(torch.ones(self.Q, self.B, 1, dtype=torch.long, device=self.dev))
@@ -301,10 +305,20 @@ class DecodeEngine:
         self._tok_log = torch.zeros(max_steps, self.Q, self.B, dtype=torch.long, device=self.dev)
         self._t_idx = torch.zeros(1, dtype=torch.long, device=self.dev)
         self._n_done = 0
+        n_sampled = min(max(first_greedy_quant, 0), self.Q) if k > 1 else 0
+        is_sampled = (torch.arange(self.Q, device=self.dev) < n_sampled).unsqueeze(0)        # [1,Q]
 
         def body():
             logits, att = self._core(self._y_in)
-            pick = ops.argmax_rows(logits.view(self.B, self.Q, self.L)).t().contiguous()    # [Q,B]
+            lg = logits.view(self.B, self.Q, self.L)
+            if n_sampled == 0:
+                pick = ops.argmax_rows(lg)
+            elif n_sampled == self.Q:
+                pick = ops.topk_sample_rows(lg, k, temp, seed=seed, step=self._t_idx)
+            else:
+                pick = torch.where(is_sampled, ops.topk_sample_rows(lg, k, temp, seed=seed, step=self._t_idx),
+                                   ops.argmax_rows(lg))
+            pick = pick.t().contiguous()                                                      # [Q,B]
             self._tok_log.index_copy_(0, self._t_idx, pick.unsqueeze(0))
             self._t_idx.add_(1)
             self._y_in.copy_(ops.embed_sum(emb.weight, pick))
@@ -343,9 +357,10 @@ class DecodeEngine:
         return self._tok_log[:self._n_done].permute(1, 2, 0).contiguous()
 
     @torch.inference_mode()
-    def run_greedy(self, n_steps: int, y0: Optional[torch.Tensor] = None, record_att: bool = False):
-        """Greedy decode of ``n_steps`` tokens. Returns tokens [Q,B,n_steps] (and atts [B,2,n,Ttxt])."""
-        self.begin_greedy(n_steps, y0)
+    def run_greedy(self, n_steps: int, y0: Optional[torch.Tensor] = None, record_att: bool = False, **sampling):
+        """Decode ``n_steps`` tokens on the device (greedy unless ``k``/``temp``/``seed``/``first_greedy_quant``
+        say otherwise, see begin_greedy). Returns tokens [Q,B,n_steps] (and atts [B,2,n,Ttxt])."""
+        self.begin_greedy(n_steps, y0, **sampling)
         atts = []
         for _ in range(n_steps):
             att = self.greedy_step()

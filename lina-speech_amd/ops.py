@@ -445,6 +445,31 @@ def argmax_rows(logits, out=None):
 
 
 # --------------------------------------------------------------------------- decode-step fusions
+def topk_sample_rows(logits, k: int, temp: float = 1.0, u: Optional[torch.Tensor] = None, seed: int = 0,
+                     step: Optional[torch.Tensor] = None, out=None):
+    """K6c: one top-k / temperature sample per row of ``logits [..., n]`` -> int64 ``[...]`` (reference
+    tools.py:38-44 for k > 1).  ``u``: fp32 uniforms [rows] (else hashed from (seed, step[0], row); ``step`` is a
+    device int64 tensor)."""
+    be = _BACKEND
+    be.require(logits, u, step)
+    n = logits.shape[-1]
+    flat = logits.reshape(-1, n)
+    if flat.stride(-1) != 1:
+        flat = flat.contiguous()
+    rows = flat.shape[0]
+    if u is not None:
+        u = u.reshape(-1).to(torch.float32).contiguous()
+        if u.numel() != rows:
+            raise ValueError("u must hold one uniform number per row")
+    if step is not None and (step.dtype != torch.int64 or step.numel() < 1):
+        raise ValueError("step must be an int64 tensor")
+    if out is None:
+        out = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    _check(be.lib.lina_topk_sample_rows(_ptr(flat), _ptr(out), rows, n, flat.stride(0), int(k), float(temp), _ptr(u),
+                                        int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(step), _dt(flat), be.stream(flat)))
+    return out.view(logits.shape[:-1])
+
+
 def gla_decode_prologue(z, off_q, off_k, off_v, off_lr, wq, wk, wv, cq, ck, cv, w2, b2, qkv, gk,
                         normalizer: float = 16.0, clamp_min: Optional[float] = None):
     """K4x3 + K7 in one launch (reference model/gla.py:158-163,174-180 at T = 1). See lina_gla.h."""

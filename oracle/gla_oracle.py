@@ -233,3 +233,40 @@ def delay_rvq(code, head_token: int = -2, tail_token: int = -3):
     for i in range(q):
         ext[i, :] = torch.roll(ext[i, :], i + 1)
     return ext.long()
+
+
+# --------------------------------------------------------------------------- #
+# f-2  top-k sampling as an inverse CDF of a given uniform number (checker for K6c).
+#      Same distribution as topk_sampling above (model/tools.py:38-44), incl. its quirk that the tempered
+#      logits are compared with the UNtempered k-th largest value.
+# --------------------------------------------------------------------------- #
+def hash_uniform(seed: int, step: int, row: int, rows: int) -> float:
+    """splitmix64 finaliser over (seed, step, row) -> 24-bit uniform in [0,1) (mirrors sample.hip)."""
+    M = (1 << 64) - 1
+    z = (seed + 0x9E3779B97F4A7C15 * (step * rows + row + 1)) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    z = z ^ (z >> 31)
+    return (z >> 40) / 16777216.0
+
+
+def topk_sample_inverse_cdf(seq, k, temp, u):
+    """seq [rows, n], u [rows] in [0,1) -> (token [rows], margin [rows], probs [rows, n]); fp64.
+    margin = distance of u from the nearest CDF edge of the picked token (tokens whose margin is below
+    the fp32 rounding of the kernel's running sums are not comparable)."""
+    x = seq.to(torch.float64)
+    kth = torch.topk(x, min(k, x.shape[-1]), dim=-1).values[:, -1:]
+    logits = x / temp
+    logits = logits.masked_fill(logits < kth, -float("inf"))
+    p = torch.softmax(logits, dim=-1)
+    cdf = torch.cumsum(p, dim=-1)
+    uu = u.to(torch.float64).unsqueeze(-1)
+    tok = (cdf <= uu).sum(-1).clamp_max(x.shape[-1] - 1)
+    # step over zero-probability entries the search may have landed on at the very end
+    kept = p > 0
+    last_kept = (kept * torch.arange(x.shape[-1])).max(-1).values
+    tok = torch.minimum(tok, last_kept)
+    hi = cdf.gather(-1, tok.unsqueeze(-1)).squeeze(-1)
+    lo = hi - p.gather(-1, tok.unsqueeze(-1)).squeeze(-1)
+    margin = torch.minimum(u.to(torch.float64) - lo, hi - u.to(torch.float64))
+    return tok, margin, p

@@ -126,6 +126,21 @@ static inline int shfl_i(int v, int src) {
     lina_emu::wave_exchange(&mine, 1, tab);
     return (int)tab[src & 63];
 }
+static inline int shfl_down_i(int v, int d) {
+    uint32_t mine = (uint32_t)v, tab[64];
+    lina_emu::wave_exchange(&mine, 1, tab);
+    const int src = lina_emu::cur_lane() + d;
+    return src < 64 ? (int)tab[src] : v;
+}
+static inline float shfl_up(float v, int d) {
+    uint32_t mine = f2u(v), tab[64];
+    lina_emu::wave_exchange(&mine, 1, tab);
+    const int src = lina_emu::cur_lane() - d;
+    return src >= 0 ? u2f(tab[src]) : v;
+}
+// fibers are cooperative: a plain read-modify-write is atomic
+static inline void lds_atomic_add(int* p, int v) { *p += v; }
+static inline void lds_atomic_max(int* p, int v) { if (v > *p) *p = v; }
 static inline int shfl_xor_i(int v, int mask) {
     uint32_t mine = (uint32_t)v, tab[64];
     lina_emu::wave_exchange(&mine, 1, tab);

@@ -271,6 +271,35 @@ def check_argmax(dev, rows, n, dtype):
     assert got3.shape == (rows, 1) and torch.equal(got3.cpu().view(-1), ref)
 
 
+def check_topk_sample(dev, rows, n, k, temp, dtype, seed=3, draws=4000):
+    """K6c vs the fp64 inverse-CDF oracle: token ids EXACT wherever the uniform number sits further than 1e-5 from
+    a CDF edge (the kernel's running sums are fp32); both the caller-supplied-uniform and the hashed-uniform forms;
+    the picked token is always one of the top-k; and the empirical distribution over many draws follows p."""
+    g = torch.Generator().manual_seed(seed)
+    logits = (torch.randn(rows, n, generator=g) * 3).to(dtype)
+    u = torch.rand(rows, generator=g)
+    tok = ops.topk_sample_rows(logits.to(dev), k, temp, u=u.to(dev)).cpu()
+    rt, margin, p = O.topk_sample_inverse_cdf(logits.float(), k, temp, u)
+    ok = margin > 1e-5
+    assert ok.float().mean() > 0.8
+    assert torch.equal(tok[ok], rt[ok]), f"{int((tok[ok] != rt[ok]).sum())} sampled tokens differ"
+    assert bool((p.gather(-1, tok.unsqueeze(-1)) > 0).all()), "picked a token outside the top-k set"
+    # hashed uniforms: (seed, step, row)
+    step = torch.tensor([5], dtype=torch.int64)
+    tok2 = ops.topk_sample_rows(logits.to(dev), k, temp, seed=1234, step=step.to(dev)).cpu()
+    u2 = torch.tensor([O.hash_uniform(1234, 5, r, rows) for r in range(rows)], dtype=torch.float64)
+    rt2, margin2, _ = O.topk_sample_inverse_cdf(logits.float(), k, temp, u2)
+    ok2 = margin2 > 1e-5
+    assert torch.equal(tok2[ok2], rt2[ok2])
+    assert 0.0 <= float(u2.min()) and float(u2.max()) < 1.0
+    # distribution: one logits row, many uniforms -> chi-square-like bound on the top entries
+    row = logits[:1].expand(draws, n).contiguous()
+    uu = (torch.arange(draws, dtype=torch.float32) + 0.5) / draws          # stratified uniforms
+    tk = ops.topk_sample_rows(row.to(dev), k, temp, u=uu.to(dev)).cpu()
+    freq = torch.bincount(tk, minlength=n).double() / draws
+    assert (freq - p[0]).abs().max() < 2.0 / draws + 1e-6, "sampling frequencies do not follow softmax(top-k)"
+
+
 def check_swiglu(dev, rows, hidden, dtype):
     g = torch.Generator().manual_seed(6)
     u = torch.randn(rows, 2 * hidden, generator=g).to(dtype).to(dev)

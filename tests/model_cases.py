@@ -154,3 +154,42 @@ def check_lina_train_golden(dev, rel=5e-4):
         checked += 1
     assert checked >= len(names) - 4
     return loss
+
+
+def check_engine_sampling(dev, n_steps=10, k=20, temp=0.9, seed=77):
+    """f-2: the device-side SAMPLED decode loop (top-k + temperature, K6c inside the captured step).  The CPU oracle is
+    teacher-forced with the engine's tokens; at every step the engine's token must be the inverse-CDF pick of the
+    oracle's logits for the same hashed uniform number (wherever that number is not within 1e-4 of a CDF edge --
+    fp32 logits of two implementations differ by ~1e-5), and a different seed must give a different stream."""
+    from oracle import gla_oracle as O
+    from oracle.lina_decode_oracle import OracleLina
+    from lina_speech_amd.decode import DecodeEngine
+    g = load_golden("lina_d64.npz")
+    model = build_lina()
+    sd = golden_state_dict(g)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    x = torch.from_numpy(g["gen_x"]).unsqueeze(0).expand(3, -1).contiguous()
+    with torch.no_grad():
+        x_enc = model.txt_encoder(model.txt_embed(x.to(dev)))
+        toks = DecodeEngine(model, x_enc, batch_size=3).run_greedy(n_steps, k=k, temp=temp, seed=seed,
+                                                                   first_greedy_quant=1).cpu()
+        toks_b = DecodeEngine(model, x_enc, batch_size=3).run_greedy(n_steps, k=k, temp=temp, seed=seed + 1,
+                                                                     first_greedy_quant=1).cpu()
+        toks_g = DecodeEngine(model, x_enc, batch_size=3).run_greedy(n_steps, k=k, temp=temp, seed=seed,
+                                                                     first_greedy_quant=0).cpu()
+    assert toks.shape == (1, 3, n_steps)
+    assert not torch.equal(toks, toks_b), "another seed must give another token stream"
+    assert torch.equal(toks_g, torch.from_numpy(g["gen_qs"])[:, :, :n_steps]), "first_greedy_quant=0 must stay greedy"
+    orc = OracleLina(sd, n_layer=1, heads=1)
+    _, logits, _, _ = orc.generate_greedy(x, n_steps, teacher=toks)           # [B,n,q,l]
+    compared = 0
+    for t in range(n_steps):
+        u = torch.tensor([O.hash_uniform(seed, t, r, 3) for r in range(3)], dtype=torch.float64)
+        rt, margin, p = O.topk_sample_inverse_cdf(logits[:, t, 0].float(), k, temp, u)
+        for r in range(3):
+            assert p[r, toks[0, r, t]] > 0, "sampled token outside the oracle's top-k set"
+            if margin[r] > 1e-4:
+                assert int(toks[0, r, t]) == int(rt[r]), (t, r)
+                compared += 1
+    assert compared >= 2 * n_steps

@@ -59,3 +59,8 @@ def test_engine_device_side_greedy_loop(emu):
 def test_train_step_loss_and_gradients_match_reference(emu):
     from model_cases import check_lina_train_golden
     check_lina_train_golden("cpu")
+
+
+def test_engine_device_side_sampling_loop(emu):
+    from model_cases import check_engine_sampling
+    check_engine_sampling("cpu")

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import gla_oracle as O
-from kernel_cases import (check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_rmsnorm_bwd, check_embed_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
+from kernel_cases import (check_topk_sample, check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_rmsnorm_bwd, check_embed_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
                           check_prologue, check_recurrent, check_rmsnorm, check_swiglu)
 
 DEV = "cpu"
@@ -123,3 +123,9 @@ def test_rmsnorm_bwd(emu, D, dtype, gate, affine):
 
 def test_embed_bwd(emu):
     check_embed_bwd(DEV, Q=2, B=3, n=5, n_emb=11, d=64, dtype=torch.float32)
+
+
+@pytest.mark.parametrize("n,k,temp,dtype", [(4099, 100, 1.0, torch.float32), (300, 7, 0.7, torch.float32),
+                                            (50, 100, 1.3, torch.float32), (1030, 100, 0.9, torch.bfloat16)])
+def test_topk_sample(emu, n, k, temp, dtype):
+    check_topk_sample(DEV, rows=6, n=n, k=k, temp=temp, dtype=dtype, draws=60)

@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from kernel_cases import (assert_close, check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_embed_bwd, check_rmsnorm_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj,
+from kernel_cases import (check_topk_sample, assert_close, check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_embed_bwd, check_rmsnorm_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj,
                           check_linear_skinny, check_prologue, check_recurrent, check_rmsnorm, check_swiglu,
                           make_gla_inputs, oracle_gla)
 from lina_speech_amd import ops
@@ -202,3 +202,10 @@ def test_rmsnorm_bwd(hip, D, dtype, gate, affine):
 
 def test_embed_bwd(hip):
     check_embed_bwd(DEV, Q=2, B=3, n=50, n_emb=4099, d=1024, dtype=torch.float32)
+
+
+@pytest.mark.parametrize("n,k,temp,dtype", [(4099, 100, 1.0, torch.float32), (300, 7, 0.7, torch.float32),
+                                            (50, 100, 1.3, torch.float32), (4099, 100, 0.9, torch.bfloat16),
+                                            (8192, 1000, 1.0, torch.float32)])
+def test_topk_sample(hip, n, k, temp, dtype):
+    check_topk_sample(DEV, rows=64, n=n, k=k, temp=temp, dtype=dtype)

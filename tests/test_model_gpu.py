@@ -91,3 +91,8 @@ def test_l169_train_step_runs_in_bf16_autocast_and_learns(hip):
     losses = [float(ts.step(batch)) for _ in range(5)]
     assert all(l == l and l < 1e4 for l in losses), losses
     assert losses[-1] < losses[0], losses
+
+
+def test_engine_device_side_sampling_loop_in_hipgraph(hip):
+    from model_cases import check_engine_sampling
+    check_engine_sampling("cuda", n_steps=12)
