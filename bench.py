@@ -97,6 +97,54 @@ def measure_chunk(dev, B=64, H=4, T=4096, Dk=256, Dv=256, reps=3):
             "tokens_per_s": B * T / dt}
 
 
+def measure_chunk_bwd(dev, B=8, H=4, T=4096, Dk=256, Dv=256, reps=3):
+    """K2b (three sweeps + dg) at the training shape, bf16 I/O.  Algorithmic bytes: q,k,v,g,do in, dq,dk,dv,dg out."""
+    from lina_speech_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(0)
+    mk = lambda D: torch.randn(B, T, H * D, generator=g).to(torch.bfloat16).to(dev).view(B, T, H, D).transpose(1, 2)
+    q, k, v, do = mk(Dk), mk(Dk), mk(Dv), mk(Dv)
+    gk = (torch.nn.functional.logsigmoid(torch.randn(B, T, H * Dk, generator=g)) / 16).to(torch.bfloat16).to(dev)
+    gk = gk.view(B, T, H, Dk).transpose(1, 2)
+    scale = Dk ** -0.5
+    ops.gla_chunk_bwd(q, k, v, gk, do, scale)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        ops.gla_chunk_bwd(q, k, v, gk, do, scale)
+    ev1.record()
+    torch.cuda.synchronize()
+    dt = ev0.elapsed_time(ev1) * 1e-3 / reps
+    nbytes = B * H * T * 2 * (5 * Dk + 4 * Dv)
+    return {"kernel": "lina::gla_bwd_sweeps_kernel<256,256> + dg scan", "shape": {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv},
+            "dtype": "bf16 I/O, fp32 MFMA", "ms": dt * 1e3, "bound": "hbm", "achieved": nbytes / dt / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS}
+
+
+def measure_train_step(dev, b=8, T=4096, steps=3):
+    """a-11: one L169 training step (teacher-forced forward, CE loss, backward through K2b/K3b/K5b, fused AdamW) in
+    bf16 autocast on one GPU; synthetic config-5 batch."""
+    from lina_speech_amd.configs import l169
+    from lina_speech_amd.train import TrainStep, synthetic_batch
+    torch.manual_seed(0)
+    ts = TrainStep(l169(), device=dev, ddp=False)
+    batch = synthetic_batch(b=b, n=T + 1, t_txt=T_TXT, seed=1).to(dev)
+    for _ in range(2):
+        ts.step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = ts.step(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"what": "L169 train step: fwd + CE + bwd + AdamW, bf16 autocast, fp32 master weights", "micro_batch": b,
+           "seq_len": T, "ms_per_step": dt * 1e3, "tokens_per_s": b * T / dt, "loss": float(loss),
+           "max_mem_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
+    del ts, batch
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(model, seconds=12.0, B=8, max_steps=64):
     """The reference's pure-PyTorch recurrent path (mode='naive') restated in oracle/, timed on the host cores
     on a bounded sample of the same workload: same 166.7M weights (fp32), B=8 rows, T_txt=64, greedy."""
@@ -130,6 +178,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chunk", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,9 +268,27 @@ def main():
                            "global_batch": total_rows, "parallelism": f"batch-shard x{world} (no collective)"},
                 "roofline": roof,
             }
+            # secondary, untimed-region measurements (rank 0 only): the default sampling mode of the reference
+            # (top-k 100, temperature) through the same graph, K2 / K2b at the training shape
+            if world == 1:
+                eng.begin_greedy(60, k=100, temp=1.0, seed=1, first_greedy_quant=1)
+                for _ in range(10):
+                    eng.greedy_step()
+                torch.cuda.synchronize()
+                ts0 = time.perf_counter()
+                for _ in range(50):
+                    eng.greedy_step()
+                torch.cuda.synchronize()
+                out["sampled_decode"] = {"k": 100, "temp": 1.0, "ms_per_step": (time.perf_counter() - ts0) / 50 * 1e3,
+                                         "tokens_per_s": B * 50 / (time.perf_counter() - ts0)}
             if not args.no_chunk:
                 out["chunk_kernel"] = measure_chunk(dev)
+                out["chunk_bwd_kernel"] = measure_chunk_bwd(dev)
     if rank == 0:
+        if not args.no_train and world == 1:
+            del eng
+            torch.cuda.empty_cache()
+            out["train_step"] = measure_train_step(dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(out), flush=True)

@@ -18,6 +18,7 @@
 #include <lina_dev.h>
 #include "lina_common.h"
 #include "skinny_frag.h"
+#include <stdlib.h>
 
 namespace lina {
 
@@ -204,6 +205,13 @@ extern "C" int lina_linear_skinny(const void* A, int64_t lda, const void* W, int
         const long wgs = (long)((N + 16 * nt - 1) / (16 * nt)) * ((M + 16 * mt - 1) / (16 * mt));
         const long cost = ((wgs + 255) / 256) * (16L * mt + 16L * nt * nb);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_mt = mt; best_nt = nt; }
+    }
+    {   // tuning knob (tools/perf_skinny3.py): LINA_SKINNY_TILE="mt,nt" forces one of the built tilings
+        static const char* forced = getenv("LINA_SKINNY_TILE");
+        int fm = 0, fn = 0;
+        if (forced && sscanf(forced, "%d,%d", &fm, &fn) == 2)
+            for (int c = 0; c < 5; ++c)
+                if (cand[c][0] == fm && cand[c][1] == fn) { best_mt = fm; best_nt = fn; }
     }
     dim3 grid((unsigned)((N + 16 * best_nt - 1) / (16 * best_nt)), (unsigned)((M + 16 * best_mt - 1) / (16 * best_mt)));
 #define LINA_LS_ONE(TT, SW, LNN, MTT, NTT)                                                                          \

@@ -31,10 +31,14 @@ def bench(N, K, nset, ln=False, sw=0):
     def fn():
         for w in ws: ops.linear_skinny(a, w, c1, c1, out=out, ln_dim=K if ln else 0, swiglu_hidden=sw, n_out=N)
     return timed_graph(fn, nset)
-x = torch.zeros(64, device=dev)
-print(f"trivial torch add_ in graph: {timed_graph(lambda: [x.add_(1) for _ in range(50)], 50):.2f} us")
-for N, K in ((1024, 1024), (4112, 1024), (1024, 32), (4112, 32), (1024, 256), (4112, 256), (1024, 1376)):
-    nset_cold = min(max(2, int(400e6 // (N * K * 2))), 60)
-    print(f"N={N} K={K}: hot {bench(N, K, 40 if N*K*2 < 4e6 else 20) if False else bench(N, K, 1):.2f} us   cold {bench(N, K, nset_cold):.2f} us   "
-          f"cold+LN {bench(N, K, nset_cold, ln=True):.2f} us")
-print(f"up-proj swiglu N=1376 K=1024 cold+LN: {bench(1376, 1024, 60, ln=True, sw=1365):.2f} us")
+def main():
+    x = torch.zeros(64, device=dev)
+    print(f"trivial torch add_ in graph: {timed_graph(lambda: [x.add_(1) for _ in range(50)], 50):.2f} us")
+    for N, K in ((1024, 1024), (4112, 1024), (1024, 32), (4112, 32), (1024, 256), (4112, 256), (1024, 1376)):
+        nset_cold = min(max(2, int(400e6 // (N * K * 2))), 60)
+        print(f"N={N} K={K}: hot {bench(N, K, 40 if N*K*2 < 4e6 else 20) if False else bench(N, K, 1):.2f} us   cold {bench(N, K, nset_cold):.2f} us   "
+              f"cold+LN {bench(N, K, nset_cold, ln=True):.2f} us")
+    print(f"up-proj swiglu N=1376 K=1024 cold+LN: {bench(1376, 1024, 60, ln=True, sw=1365):.2f} us")
+
+if __name__ == "__main__":
+    main()
