@@ -40,7 +40,21 @@ with torch.no_grad():
     qs, atts, stops, cuts = model.generate_batch(t("gen_x"), batch_size=3, max_seqlen=12, k=1, first_greedy_quant=0,
                                                  force_max_seqlen=True)
     assert torch.equal(qs, t("gen_qs")), "reference generate_batch on lina_speech_amd ops: tokens differ"
-print("DROPIN_OK", err)
+# the reference's training forward + loss.backward() through K2b / K3b / K5b: every parameter gradient
+model.train()
+model.zero_grad()
+_, tloss, _, _, _ = model(t("x"), t("y"), t("encoder_mask"), t("crossatt_mask"), logits_mask=t("logits_mask"))
+tloss.backward()
+assert abs(float(tloss) - float(g["train_loss"])) < 1e-5 * abs(float(g["train_loss"]))
+worst = 0.0
+for name, p in model.named_parameters():
+    ref = torch.from_numpy(g["grad::" + name])
+    if float(ref.abs().max()) < 1e-8:
+        continue
+    e = float((p.grad - ref).abs().max() / ref.abs().max())
+    worst = max(worst, e)
+    assert e < 5e-4, (name, e)
+print("DROPIN_OK", err, worst)
 '''
 
 
