@@ -176,22 +176,27 @@ __device__ __forceinline__ void sweep_v(
     const int ch = chan ? tid : 0;
     const int vr = tid >> 4, vc = (tid & 15) * 4;
 
-    int t_end = T;
-    while (t_end > 0) {
-        const int base = t_end - C;                       // tile row r <-> token base + r (may start before 0)
-        float gv[C], qv[C], kv[C];
+    // Software pipeline: the raw loads of chunk n+1 are issued as soon as chunk n's registers have been staged in
+    // LDS (its extent is known by then) and fly under chunk n's MFMA phase; barriers only wait for LDS traffic.
+    float gr[C], qr[C], kr[C];
+    float4 zr;
+    auto issue = [&](int bs) {
 #pragma unroll
         for (int r = 0; r < C; ++r) {
-            // unconditional loads from a clamped address + select: no branch, all 48 loads in flight together
-            const int t = base + r, tc = max(t, 0);
-            const bool in = chan && t >= 0;
-            const float g_ = ld(gb + tc * sg.t + ch), q_ = ld(qb + tc * sq.t + ch), k_ = ld(kb + tc * sk.t + ch);
-            gv[r] = in ? g_ : 0.0f;
-            qv[r] = in ? q_ : 0.0f;
-            kv[r] = in ? k_ : 0.0f;
+            // unconditional loads from a clamped address (masked at use): no branch, all 48 loads in flight together
+            const int tc = max(bs + r, 0);
+            gr[r] = ld(gb + tc * sg.t + ch);
+            qr[r] = ld(qb + tc * sq.t + ch);
+            kr[r] = ld(kb + tc * sk.t + ch);
         }
-        float4 zz = ld4(dob + max(base + vr, 0) * sdo.t + vc);
-        if (base + vr < 0) zz = make_float4(0.f, 0.f, 0.f, 0.f);
+        zr = ld4(dob + max(bs + vr, 0) * sdo.t + vc);
+    };
+    int base = T - C;                                     // tile row r <-> token base + r (may start before 0)
+    issue(base);
+    while (true) {
+        float gv[C];
+#pragma unroll
+        for (int r = 0; r < C; ++r) gv[r] = (chan && base + r >= 0) ? gr[r] : 0.0f;
         float cs[C + 1], bv[C];
         const int wst = wave_max_b(scan_rev(cs, gv));
         if (lane == 0) s_nw[w] = wst;
@@ -201,18 +206,21 @@ __device__ __forceinline__ void sweep_v(
             const float tot = finish_rev(bv, cs, start);
 #pragma unroll
             for (int r = 0; r < C; ++r) {
-                const bool valid = r >= start;
-                s_x[r * SX + tid] = valid ? kv[r] * __expf(-bv[r]) : 0.0f;
-                s_y[r * SX + tid] = valid ? qv[r] * scale * __expf(bv[r]) : 0.0f;
+                const bool valid = r >= start;             // start >= -base: rows before token 0 are never valid
+                s_x[r * SX + tid] = valid ? kr[r] * __expf(-bv[r]) : 0.0f;
+                s_y[r * SX + tid] = valid ? qr[r] * scale * __expf(bv[r]) : 0.0f;
             }
             s_dec[tid] = __expf(tot);
         }
         {
             const bool valid = vr >= start;
             float* d = &s_z[vr * SZ + vc];
-            d[0] = valid ? zz.x : 0.0f; d[1] = valid ? zz.y : 0.0f;
-            d[2] = valid ? zz.z : 0.0f; d[3] = valid ? zz.w : 0.0f;
+            d[0] = valid ? zr.x : 0.0f; d[1] = valid ? zr.y : 0.0f;
+            d[2] = valid ? zr.z : 0.0f; d[3] = valid ? zr.w : 0.0f;
         }
+        const int t_end = base + start;                   // tokens [0, t_end) remain
+        const int nbase = t_end - C;
+        issue(nbase);                                     // harmless re-read of token 0 when nothing remains
         __syncthreads();   // (2)
 #pragma unroll
         for (int p = 0; p < NT; ++p)                      // D = diag(e^{b_last}) dS_in
@@ -224,7 +232,8 @@ __device__ __forceinline__ void sweep_v(
             const int row = 4 * lg + r;
             if (row >= start) st(dvb + (base + row) * sdv.t, acc[r]);
         }
-        t_end = base + start;
+        if (t_end <= 0) break;
+        base = nbase;
     }
     if (dh0) {
         float* hp = dh0 + ((int64_t)bh * DK) * Dv + v0 + 16 * w + li;
@@ -279,40 +288,38 @@ __device__ __forceinline__ void sweep_qk(
     const int ch = chan ? tid : 0;
     const int vr = tid >> 4, vc = (tid & 15) * 4;
 
-    int pos = REV ? T : 0;                                // REV: tokens [0,pos) remain; else tokens [pos,T) remain
-    while (REV ? pos > 0 : pos < T) {
-        const int base = REV ? pos - C : pos;
-        float xv[C], yv[C];
+    // Software pipeline as in sweep_v: chunk n+1's raw loads fly under chunk n's MFMA phase.
+    float xr[C], yr[C], gr[C];
+    float4 zr;
+    auto issue = [&](int bs) {
 #pragma unroll
         for (int r = 0; r < C; ++r) {
-            // unconditional loads from a clamped address + select: no branch, all loads in flight together
-            const int t = base + r, tc = min(max(t, 0), T - 1);
-            const bool in = chan && t >= 0 && t < T;
-            const float x_ = ld(xb + tc * sx.t + ch), y_ = ld(yb + tc * sy.t + ch);
-            xv[r] = in ? x_ : 0.0f;
-            yv[r] = in ? y_ : 0.0f;
+            const int tc = min(max(bs + r, 0), T - 1);    // clamped address, masked at use
+            xr[r] = ld(xb + tc * sx.t + ch);
+            yr[r] = ld(yb + tc * sy.t + ch);
         }
-        float4 zz = ld4(zb + min(max(base + vr, 0), T - 1) * sz.t + vc);
-        if (base + vr < 0 || base + vr >= T) zz = make_float4(0.f, 0.f, 0.f, 0.f);
-        float gv[C];
+        zr = ld4(zb + min(max(bs + vr, 0), T - 1) * sz.t + vc);
         if (w == 0) {
 #pragma unroll
-            for (int r = 0; r < C; ++r) {
-                const int t = base + r;
-                const float g_ = ld(gb + min(max(t, 0), T - 1) * sg.t + lane);
-                gv[r] = (t >= 0 && t < T) ? g_ : 0.0f;
-            }
+            for (int r = 0; r < C; ++r) gr[r] = ld(gb + min(max(bs + r, 0), T - 1) * sg.t + lane);
         }
+    };
+    int base = REV ? T - C : 0;                           // REV: tokens [0, base+cut) remain; else [base+cut, T)
+    issue(base);
+    while (true) {
         __syncthreads();   // (0) previous chunk's tiles, s_b and s_dec are dead
         if (chan) {
 #pragma unroll
-            for (int r = 0; r < C; ++r) {
-                s_x[r * SX + tid] = xv[r];
-                s_y[r * SX + tid] = yv[r];
+            for (int r = 0; r < C; ++r) {                 // X, Y rows outside the chunk only need to be finite: Z is zeroed
+                const bool in = base + r >= 0 && base + r < T;
+                s_x[r * SX + tid] = in ? xr[r] : 0.0f;
+                s_y[r * SX + tid] = in ? yr[r] : 0.0f;
             }
         }
         if (w == 0) {
-            float bv[C];
+            float gv[C], bv[C];
+#pragma unroll
+            for (int r = 0; r < C; ++r) gv[r] = (base + r >= 0 && base + r < T) ? gr[r] : 0.0f;
             float tot;
             if (REV) {
                 float cs[C + 1];
@@ -333,15 +340,19 @@ __device__ __forceinline__ void sweep_qk(
         __syncthreads();   // (1)
         const int cut = s_cut;                            // REV: first valid row; else number of valid rows
         {
-            const bool valid = REV ? vr >= cut : vr < cut;
-            const float zr[4] = {zz.x, zz.y, zz.z, zz.w};
+            const bool valid = (REV ? vr >= cut : vr < cut) && base + vr >= 0 && base + vr < T;
+            const float zv[4] = {zr.x, zr.y, zr.z, zr.w};
             float* d = &s_z[vr * SZ + vc];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float bb = s_b[vr][vc + i];
-                d[i] = valid ? (REV ? zr[i] * scale * __expf(bb) : zr[i] * __expf(-bb)) : 0.0f;
+                d[i] = valid ? (REV ? zv[i] * scale * __expf(bb) : zv[i] * __expf(-bb)) : 0.0f;
             }
         }
+        const int pos = base + cut;
+        const bool more = REV ? pos > 0 : pos < T;
+        const int nbase = REV ? pos - C : pos;
+        issue(nbase);                                     // harmless clamped re-read when nothing remains
         __syncthreads();   // (2)
         const float dcol = s_dec[16 * w + li];
         if (REV) {
@@ -366,10 +377,10 @@ __device__ __forceinline__ void sweep_qk(
                 ob[(int64_t)(base + row) * Dk] = acc[r] * (REV ? __expf(-bb) : scale * __expf(bb));
             }
         }
-        pos = REV ? base + cut : base + cut;
+        if (!more) break;
+        base = nbase;
     }
 }
-
 #undef s_cut
 
 // one launch for the three sweeps: grid = (B*H, max(Dk,Dv)/64, 3); blockIdx.z picks the sweep, so the three
@@ -381,7 +392,7 @@ constexpr int bwd_smem_floats(int DK, int DV) {
 }
 
 template <int DK, int DV, typename TIO, typename TG>
-__global__ __launch_bounds__(256) void gla_bwd_sweeps_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gla_bwd_sweeps_kernel(
     const TIO* __restrict__ q, const TIO* __restrict__ k, const TIO* __restrict__ v, const TG* __restrict__ gk,
     const TIO* __restrict__ dout, TIO* __restrict__ dv, float* __restrict__ dq32, float* __restrict__ dk32,
     const float* h0, const float* dht, float* dh0, int H, int T, lina_bht_strides sq, lina_bht_strides sk,
