@@ -283,6 +283,9 @@ def main():
                                          "tokens_per_s": B * 50 / (time.perf_counter() - ts0)}
             if not args.no_chunk:
                 out["chunk_kernel"] = measure_chunk(dev)
+                small = measure_chunk(dev, B=8)                      # training micro-batch: segment-parallel form
+                small["kernel"] = "lina_gla_chunk_fwd_seg (state-only pass + combine + full pass, 8 segments)"
+                out["chunk_kernel_b8"] = small
                 out["chunk_bwd_kernel"] = measure_chunk_bwd(dev)
     if rank == 0:
         if not args.no_train and world == 1:

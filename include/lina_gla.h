@@ -76,6 +76,19 @@ int lina_gla_chunk_fwd(const void* q, const void* k, const void* v, const void* 
                        lina_bht_strides sg, lina_bht_strides so,
                        int dtype, int g_dtype, float scale, lina_stream_t stream);
 
+/* K2 for SMALL B*H (training micro-batches): the same forward with the sequence cut into `nseg` segments that
+ * run concurrently (state-only pass, elementwise combine of the segment states, full pass) -- exact, nseg x the
+ * workgroups of lina_gla_chunk_fwd.  bf16 tensors and gates, Dk = Dv = 256, 16-byte aligned rows only
+ * (LINA_ERR_UNSUPPORTED otherwise: call lina_gla_chunk_fwd).
+ *   workspace: fp32 scratch of lina_gla_chunk_fwd_seg_workspace(B, H, Dk, Dv, nseg) BYTES. */
+int64_t lina_gla_chunk_fwd_seg_workspace(int B, int H, int Dk, int Dv, int nseg);
+int lina_gla_chunk_fwd_seg(const void* q, const void* k, const void* v, const void* gk, void* o,
+                           const float* h0, float* ht, float* workspace, int nseg,
+                           int B, int H, int T, int Dk, int Dv,
+                           lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
+                           lina_bht_strides sg, lina_bht_strides so,
+                           int dtype, int g_dtype, float scale, lina_stream_t stream);
+
 /* K2b -- backward of K2: given d_o = dL/do (and optionally
  * dht = dL/d final_state) produce dq, dk, dv, dg and optionally dh0 = dL/d initial_state.
  * Replaces the autograd backward of fla.ops.gla.chunk_gla / fused_chunk_gla that the reference

@@ -42,11 +42,16 @@ __device__ __forceinline__ bf16x8 frag8x2(const bf16_t* p_lo, const bf16_t* p_hi
     return as_bf16x8(*reinterpret_cast<const uint2*>(p_lo), *reinterpret_cast<const uint2*>(p_hi));
 }
 
+// Sequence segments: blockIdx.x = (b*H + h) * nseg + seg handles tokens [seg*Tseg, min(T, (seg+1)*Tseg)) with
+// h0 / ht / dec_out indexed by blockIdx.x (nseg = 1: the plain one-workgroup-per-head form).  STATE_ONLY: no output,
+// only the segment's state transition -- final state from the given start (zero if h0 == NULL) and the product of
+// the chunk decays dec_out[blockIdx.x][Dk] -- used by the two-pass segment-parallel forward below.
+template <bool STATE_ONLY>
 __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-    const bf16_t* __restrict__ gk, bf16_t* __restrict__ o, const float* h0, float* ht, int H, int T,
-    lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides so,
-    float scale) {
+    const bf16_t* __restrict__ gk, bf16_t* __restrict__ o, const float* h0, float* ht, float* dec_out, int H,
+    int T_total, int nseg, int Tseg, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
+    lina_bht_strides sg, lina_bht_strides so, float scale) {
     constexpr int DK = 256, DV = 256, C = kFullC;
     constexpr int SQ = DK + 8;   // bf16 row stride of q~ / o tiles (528 B): 8-byte fragment reads conflict-free
     constexpr int SK = DK + 16;  // bf16 row stride of the k~ tile (544 B): 16-byte fragment reads conflict-free
@@ -66,24 +71,28 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int li = lane & 15, lg = lane >> 4;
     int co = tid & 63, rg = tid >> 6;
-    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int slot = blockIdx.x;                             // state slot: (b*H + h) * nseg + segment
+    const int bh = slot / nseg, b = bh / H, h = bh % H;
+    const int t_begin = (slot % nseg) * Tseg;
+    const int T = min(Tseg, T_total - t_begin);              // tokens of this segment (>= 1 by construction)
 
     // ---- state: wave w owns columns [16w, 16w+16), tile p = rows [16p, 16p+16) ----
     f32x4 S[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) S[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (h0) {
-        const float* hp = h0 + ((int64_t)bh * DK + 4 * lg) * DV + 16 * w + li;
+        const float* hp = h0 + ((int64_t)slot * DK + 4 * lg) * DV + 16 * w + li;
 #pragma unroll
         for (int p = 0; p < 16; ++p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) S[p][r] = hp[(16 * p + r) * DV];
     }
 
-    const bf16_t* gsrc[4] = {q + b * sq.b + h * sq.h, k + b * sk.b + h * sk.h, gk + b * sg.b + h * sg.h,
-                             v + b * sv.b + h * sv.h};
+    const bf16_t* gsrc[4] = {q + b * sq.b + h * sq.h + t_begin * sq.t, k + b * sk.b + h * sk.h + t_begin * sk.t,
+                             gk + b * sg.b + h * sg.h + t_begin * sg.t, v + b * sv.b + h * sv.h + t_begin * sv.t};
     const unsigned gst[4] = {(unsigned)sq.t, (unsigned)sk.t, (unsigned)sg.t, (unsigned)sv.t};   // < 2^31 (launcher)
-    bf16_t* ob = o + b * so.b + h * so.h;
+    bf16_t* ob = STATE_ONLY ? nullptr : o + b * so.b + h * so.h + t_begin * so.t;
+    float4 decp = make_float4(1.f, 1.f, 1.f, 1.f);            // STATE_ONLY, wave 0: product of the chunk decays, channels 4*lane..+3
 
     // wave w DMAs rows 2w, 2w+1 of each raw tile: one instruction = 2 rows x 512 B, 16 B per lane.
     // Rows past the end of the sequence re-read row T-1 (always mapped); phase A masks them.
@@ -131,13 +140,15 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             const int row = 2 * rg + rr;
             const bool valid = row < nv;
             float f[4], e[4];
-            unpack4(*reinterpret_cast<const uint2*>(&s_raw[0][row * DK + 4 * co]), f);
 #pragma unroll
             for (int c = 0; c < 4; ++c) e[c] = __expf(bc[rr][c]);
             uint2 pq, pk;
-            pq.x = pack_bf16x2(valid ? f[0] * scale * e[0] : 0.0f, valid ? f[1] * scale * e[1] : 0.0f);
-            pq.y = pack_bf16x2(valid ? f[2] * scale * e[2] : 0.0f, valid ? f[3] * scale * e[3] : 0.0f);
-            *reinterpret_cast<uint2*>(&s_q[row * SQ + 4 * co]) = pq;
+            if constexpr (!STATE_ONLY) {
+                unpack4(*reinterpret_cast<const uint2*>(&s_raw[0][row * DK + 4 * co]), f);
+                pq.x = pack_bf16x2(valid ? f[0] * scale * e[0] : 0.0f, valid ? f[1] * scale * e[1] : 0.0f);
+                pq.y = pack_bf16x2(valid ? f[2] * scale * e[2] : 0.0f, valid ? f[3] * scale * e[3] : 0.0f);
+                *reinterpret_cast<uint2*>(&s_q[row * SQ + 4 * co]) = pq;
+            }
             unpack4(*reinterpret_cast<const uint2*>(&s_raw[1][row * DK + 4 * co]), f);
             pk.x = pack_bf16x2(valid ? __fdividef(f[0], e[0]) : 0.0f, valid ? __fdividef(f[1], e[1]) : 0.0f);
             pk.y = pack_bf16x2(valid ? __fdividef(f[2], e[2]) : 0.0f, valid ? __fdividef(f[3], e[3]) : 0.0f);
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         }
     };
 
-    dma_chunk(0, 0, 4);
+    dma_chunk(0, STATE_ONLY ? 1 : 0, 4);
     __syncthreads();   // DMA of chunk 0 landed (hipcc drains vmcnt before the barrier)
     int t0 = 0;
     while (t0 < T) {
@@ -191,7 +202,11 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             write_tiles(bc, n);
             __syncthreads();
         }
-        if (t0 + n < T) dma_chunk(t0 + n, 0, 3);   // next chunk's raw q,k,g fly under phase B (v: see below)
+        if (t0 + n < T) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 3);   // next chunk's raw q,k,g fly under phase B (v: see below)
+        if (STATE_ONLY && w == 0) {                                    // s_dec is stable between barriers (2) and (3)
+            const float4 d = *reinterpret_cast<const float4*>(&s_dec[4 * lane]);
+            decp.x *= d.x; decp.y *= d.y; decp.z *= d.z; decp.w *= d.w;
+        }
 
         // ---------------- transposed operands: k~^T[c][t], v^T[col][t] ----------------
         // thread (ch = tid & 255, qr = tid >> 8) gathers 8 tokens of one channel/column (2-byte LDS reads, lanes
@@ -217,62 +232,66 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         f32x4 acc[2];            // o for tokens [16nt, 16nt+16) x this wave's 16 columns
         acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        {
-            // (2) A^T[s][t] = k~_s . q~_t, computed ONCE per workgroup: wave w takes tile (mt = w&1: s block,
-            //     nt = (w>>1)&1: t block) and the K quarter w>>2 (2 MFMAs); the 4 partials per tile are summed
-            //     through LDS (s_tot's space, dead by now) in step (2c) below
-            const int mt = w & 1, nt = (w >> 1) & 1, kq = w >> 2;
-            f32x4 at = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (!STATE_ONLY) {
+            {
+                // (2) A^T[s][t] = k~_s . q~_t, computed ONCE per workgroup: wave w takes tile (mt = w&1: s block,
+                //     nt = (w>>1)&1: t block) and the K quarter w>>2 (2 MFMAs); the 4 partials per tile are summed
+                //     through LDS (s_tot's space, dead by now) in step (2c) below
+                const int mt = w & 1, nt = (w >> 1) & 1, kq = w >> 2;
+                f32x4 at = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int cc = 64 * kq + 32 * ks + 8 * lg;
-                at = mfma_bf16_16x16x32(frag16(&s_k[(16 * mt + li) * SK + cc]), frag16(&s_q[(16 * nt + li) * SQ + cc]), at);
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int cc = 64 * kq + 32 * ks + 8 * lg;
+                    at = mfma_bf16_16x16x32(frag16(&s_k[(16 * mt + li) * SK + cc]), frag16(&s_q[(16 * nt + li) * SQ + cc]), at);
+                }
+                *reinterpret_cast<float4*>(&s_tot[(w * 64 + lane) * 4]) = make_float4(at[0], at[1], at[2], at[3]);
             }
-            *reinterpret_cast<float4*>(&s_tot[(w * 64 + lane) * 4]) = make_float4(at[0], at[1], at[2], at[3]);
-        }
-        // (1) o = q~ . S_old : one K = 32 MFMA per pair of 16-row state tiles (converted to bf16 in registers)
+            // (1) o = q~ . S_old : one K = 32 MFMA per pair of 16-row state tiles (converted to bf16 in registers)
 #pragma unroll
-        for (int pp = 0; pp < 8; ++pp) {
-            bf16x8 bb;
+            for (int pp = 0; pp < 8; ++pp) {
+                bf16x8 bb;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                bb[r] = (short)f2bf(S[2 * pp][r]);
-                bb[4 + r] = (short)f2bf(S[2 * pp + 1][r]);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    bb[r] = (short)f2bf(S[2 * pp][r]);
+                    bb[4 + r] = (short)f2bf(S[2 * pp + 1][r]);
+                }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const bf16_t* qp = &s_q[(16 * nt + li) * SQ + 32 * pp + 4 * lg];
-                acc[nt] = mfma_bf16_16x16x32(frag8x2(qp, qp + 16), bb, acc[nt]);
+                for (int nt = 0; nt < 2; ++nt) {
+                    const bf16_t* qp = &s_q[(16 * nt + li) * SQ + 32 * pp + 4 * lg];
+                    acc[nt] = mfma_bf16_16x16x32(frag8x2(qp, qp + 16), bb, acc[nt]);
+                }
             }
         }
         __syncthreads();   // (2b) k~^T / v^T and the A^T partials complete; raw v consumed
         if (t0 + n < T) dma_chunk(t0 + n, 3, 4);
-        // (2c) thread (tile = tid>>8 ... ) sums the 4 K-quarter partials of ONE A^T element, masks it (s <= t) and
-        //      stores it as bf16 where step (3)'s A operand expects it: lane (li = t&15, lg) slot j of tile nt
-        //      holds A[t][s] with s = 4lg + j (j < 4, s block 0) or 16 + 4lg + (j-4) (s block 1)
-        {
-            const int e = tid & 255, tile = tid >> 8;           // element (lane_e = e>>2, reg = e&3) of tile (mt,nt)
-            const int mt = tile & 1, nt = tile >> 1, le = e >> 2, r = e & 3;
-            float a = 0.0f;
+        if constexpr (!STATE_ONLY) {
+            // (2c) thread (tile = tid>>8 ... ) sums the 4 K-quarter partials of ONE A^T element, masks it (s <= t) and
+            //      stores it as bf16 where step (3)'s A operand expects it: lane (li = t&15, lg) slot j of tile nt
+            //      holds A[t][s] with s = 4lg + j (j < 4, s block 0) or 16 + 4lg + (j-4) (s block 1)
+            {
+                const int e = tid & 255, tile = tid >> 8;       // element (lane_e = e>>2, reg = e&3) of tile (mt,nt)
+                const int mt = tile & 1, nt = tile >> 1, le = e >> 2, r = e & 3;
+                float a = 0.0f;
 #pragma unroll
-            for (int kq = 0; kq < 4; ++kq) a += s_tot[((4 * kq + tile) * 64 + le) * 4 + r];
-            const int tl = le & 15, sg = le >> 4;               // D layout of the partial: col t = tl, row s = 4sg + r
-            const int t = 16 * nt + tl, sidx = 16 * mt + 4 * sg + r;
-            s_A[(nt * 64 + sg * 16 + tl) * 8 + 4 * mt + r] = f2bf(sidx <= t ? a : 0.0f);
+                for (int kq = 0; kq < 4; ++kq) a += s_tot[((4 * kq + tile) * 64 + le) * 4 + r];
+                const int tl = le & 15, sg4 = le >> 4;           // D layout of the partial: col t = tl, row s = 4sg4 + r
+                const int t = 16 * nt + tl, srow = 16 * mt + 4 * sg4 + r;
+                s_A[(nt * 64 + sg4 * 16 + tl) * 8 + 4 * mt + r] = f2bf(srow <= t ? a : 0.0f);
+            }
+            __syncthreads();   // (2d) A ready
+            // (3) o += mask(A) . v ; v fragments in the same token order as the C/D rows
+            {
+                const bf16_t* vp = &s_vT[(16 * w + li) * ST + 4 * lg];
+                const bf16x8 vb = frag8x2(vp, vp + 16);
+                acc[0] = mfma_bf16_16x16x32(frag16(&s_A[(0 * 64 + lane) * 8]), vb, acc[0]);
+                acc[1] = mfma_bf16_16x16x32(frag16(&s_A[(1 * 64 + lane) * 8]), vb, acc[1]);
+            }
+            // stage o (this wave's 32 x 16 block)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_o[(16 * nt + 4 * lg + r) * SQ + 16 * w + li] = f2bf(acc[nt][r]);
         }
-        __syncthreads();   // (2d) A ready
-        // (3) o += mask(A) . v ; v fragments in the same token order as the C/D rows
-        {
-            const bf16_t* vp = &s_vT[(16 * w + li) * ST + 4 * lg];
-            const bf16x8 vb = frag8x2(vp, vp + 16);
-            acc[0] = mfma_bf16_16x16x32(frag16(&s_A[(0 * 64 + lane) * 8]), vb, acc[0]);
-            acc[1] = mfma_bf16_16x16x32(frag16(&s_A[(1 * 64 + lane) * 8]), vb, acc[1]);
-        }
-        // stage o (this wave's 32 x 16 block)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s_o[(16 * nt + 4 * lg + r) * SQ + 16 * w + li] = f2bf(acc[nt][r]);
         // (4) S <- e^{b_last} (S + k~^T v)
         {
             const bf16x8 vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
@@ -284,18 +303,22 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             }
         }
         __syncthreads();   // (3) o tile complete, operand tiles dead, next chunk's DMA landed
-        {
-            const int row = tid >> 5, seg = tid & 31;      // 32 lanes x 16 B = one 512-byte output row
-            if (row < n)
-                *reinterpret_cast<uint4*>(ob + ((unsigned)(t0 + row) * (unsigned)so.t + 8u * (unsigned)seg)) =
-                    *reinterpret_cast<const uint4*>(&s_o[row * SQ + 8 * seg]);
+        if constexpr (!STATE_ONLY) {
+            {
+                const int row = tid >> 5, piece = tid & 31;    // 32 lanes x 16 B = one 512-byte output row
+                if (row < n)
+                    *reinterpret_cast<uint4*>(ob + ((unsigned)(t0 + row) * (unsigned)so.t + 8u * (unsigned)piece)) =
+                        *reinterpret_cast<const uint4*>(&s_o[row * SQ + 8 * piece]);
+            }
+            __syncthreads();   // (4) s_o (aliases the scan totals) has been read
         }
-        __syncthreads();   // (4) s_o (aliases the scan totals) has been read
         t0 += n;
     }
 
+    if (STATE_ONLY && dec_out && w == 0)
+        *reinterpret_cast<float4*>(dec_out + (int64_t)slot * DK + 4 * lane) = decp;
     if (ht) {
-        float* hp = ht + ((int64_t)bh * DK + 4 * lg) * DV + 16 * w + li;
+        float* hp = ht + ((int64_t)slot * DK + 4 * lg) * DV + 16 * w + li;
 #pragma unroll
         for (int p = 0; p < 16; ++p)
 #pragma unroll
@@ -325,9 +348,74 @@ int launch_chunk_full(const void* q, const void* k, const void* v, const void* g
              fits32(sv) && fits32(sg) && fits32(so);
     if (!*taken) return LINA_OK;
     dim3 grid((unsigned)(B * H));
-    LINA_LAUNCH(gla_chunk_bf16_h256_kernel, grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
-                (const bf16_t*)v, (const bf16_t*)gk, (bf16_t*)o, h0, ht, H, T, sq, sk, sv, sg, so, scale);
+    LINA_LAUNCH(gla_chunk_bf16_h256_kernel<false>, grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                (const bf16_t*)v, (const bf16_t*)gk, (bf16_t*)o, h0, ht, (float*)nullptr, H, T, 1, T, sq, sk, sv, sg, so,
+                scale);
     return check_launch("lina_gla_chunk_fwd(full)");
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Segment-parallel forward for SMALL B*H (a training micro-batch gives only B*H workgroups to the kernel above):
+// the sequence is cut into nseg segments that run concurrently.
+//   pass 1  STATE_ONLY, zero start: local end state L_s and decay product P_s of every segment
+//   combine S_start[0] = h0, S_start[s+1] = diag(P_s) S_start[s] + L_s   (elementwise, sequential over nseg)
+//   pass 2  the full kernel on every segment with h0 = S_start[s]
+// Exact (the recurrence is linear in the state); costs one extra pass over k, g, v and 2 x nseg state tiles of
+// workspace traffic per head, buys nseg x the workgroups.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gla_seg_combine_kernel(const float* __restrict__ L, const float* __restrict__ P,
+                                                              const float* h0, float* __restrict__ Sstart, float* ht,
+                                                              int nseg) {
+    constexpr int DK = 256, DV = 256;
+    const int bh = blockIdx.x;
+    const int e = (blockIdx.y * 256 + threadIdx.x) * 4;       // element of the [DK][DV] state, 4 columns per thread
+    const int c = e / DV;
+    float4 S = h0 ? *reinterpret_cast<const float4*>(h0 + (int64_t)bh * DK * DV + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nseg; ++s) {
+        const int64_t slot = (int64_t)bh * nseg + s;
+        *reinterpret_cast<float4*>(Sstart + slot * DK * DV + e) = S;
+        const float p = P[slot * DK + c];
+        const float4 l = *reinterpret_cast<const float4*>(L + slot * DK * DV + e);
+        S.x = p * S.x + l.x; S.y = p * S.y + l.y; S.z = p * S.z + l.z; S.w = p * S.w + l.w;
+    }
+    if (ht) *reinterpret_cast<float4*>(ht + (int64_t)bh * DK * DV + e) = S;
+}
+
 }  // namespace lina
+
+extern "C" int64_t lina_gla_chunk_fwd_seg_workspace(int B, int H, int Dk, int Dv, int nseg) {
+    if (B <= 0 || H <= 0 || Dk <= 0 || Dv <= 0 || nseg <= 0) return 0;
+    return (int64_t)sizeof(float) * B * H * nseg * ((int64_t)2 * Dk * Dv + Dk);
+}
+
+extern "C" int lina_gla_chunk_fwd_seg(const void* q, const void* k, const void* v, const void* gk, void* o,
+                                      const float* h0, float* ht, float* workspace, int nseg, int B, int H, int T,
+                                      int Dk, int Dv, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
+                                      lina_bht_strides sg, lina_bht_strides so, int dtype, int g_dtype, float scale,
+                                      lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(q && k && v && gk && o && workspace, "lina_gla_chunk_fwd_seg: null pointer");
+    LINA_REQUIRE(B > 0 && H > 0 && T > 0, "lina_gla_chunk_fwd_seg: B,H,T must be positive");
+    LINA_REQUIRE(nseg >= 1, "lina_gla_chunk_fwd_seg: nseg must be >= 1");
+    auto fits32 = [T](lina_bht_strides st) { return (int64_t)T * st.t < (1LL << 31); };
+    if (!(full_ok(Dk, Dv, dtype, q, k, v, gk, o, g_dtype, sq, sk, sv, sg, so) && fits32(sq) && fits32(sk) && fits32(sv) &&
+          fits32(sg) && fits32(so)))
+        return fail(LINA_ERR_UNSUPPORTED, "lina_gla_chunk_fwd_seg: needs bf16 tensors and gates, Dk = Dv = 256, "
+                                          "16-byte aligned rows (use lina_gla_chunk_fwd)");
+    const int Tseg = ((T + nseg - 1) / nseg + kFullC - 1) / kFullC * kFullC;   // whole 32-token chunks per segment
+    const int ns = (T + Tseg - 1) / Tseg;                                       // segments that hold tokens
+    const int64_t slots = (int64_t)B * H * ns;
+    float* L = workspace;
+    float* Sstart = L + slots * Dk * Dv;
+    float* P = Sstart + slots * Dk * Dv;
+    dim3 grid((unsigned)slots);
+    LINA_LAUNCH(gla_chunk_bf16_h256_kernel<true>, grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                (const bf16_t*)v, (const bf16_t*)gk, (bf16_t*)nullptr, (const float*)nullptr, L, P, H, T, ns, Tseg, sq, sk,
+                sv, sg, so, scale);
+    LINA_LAUNCH(gla_seg_combine_kernel, dim3((unsigned)(B * H), 64u), dim3(256), 0, stream, (const float*)L,
+                (const float*)P, h0, Sstart, ht, ns);
+    LINA_LAUNCH(gla_chunk_bf16_h256_kernel<false>, grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                (const bf16_t*)v, (const bf16_t*)gk, (bf16_t*)o, (const float*)Sstart, (float*)nullptr, (float*)nullptr, H,
+                T, ns, Tseg, sq, sk, sv, sg, so, scale);
+    return check_launch("lina_gla_chunk_fwd_seg");
+}

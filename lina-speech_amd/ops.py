@@ -121,7 +121,7 @@ def _head_first_empty(B, H, T, D, dtype, device):
     return torch.empty(B, T, H, D, dtype=dtype, device=device).transpose(1, 2)
 
 
-def _gla_launch(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inplace_state=False):
+def _gla_launch(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inplace_state=False, nseg=None):
     B, H, T, Dk = q.shape
     Dv = v.shape[-1]
     be = _BACKEND
@@ -136,10 +136,30 @@ def _gla_launch(entry: str, q, k, v, gk, scale, initial_state, output_final_stat
     if output_final_state:
         ht = h0 if (inplace_state and h0 is not None) else torch.empty(B, H, Dk, Dv, dtype=torch.float32,
                                                                       device=q.device)
+    if entry == "lina_gla_chunk_fwd":
+        nseg = chunk_segments(B * H, T) if nseg is None else nseg
+        if (nseg > 1 and q.dtype == torch.bfloat16 and gk.dtype == torch.bfloat16 and Dk == 256 and Dv == 256):
+            ws = torch.empty(int(be.lib.lina_gla_chunk_fwd_seg_workspace(B, H, Dk, Dv, nseg)) // 4, dtype=torch.float32,
+                             device=q.device)
+            rc = be.lib.lina_gla_chunk_fwd_seg(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(o), _ptr(h0), _ptr(ht), _ptr(ws),
+                                               nseg, B, H, T, Dk, Dv, _bht(q), _bht(k), _bht(v), _bht(gk), _bht(o),
+                                               _dt(q), _dt(gk), scale, be.stream(q))
+            if rc == 0:
+                return o, ht
+            if rc != -2:                         # -2 = layout not eligible for the segmented kernel: use the plain one
+                _check(rc)
     fn = getattr(be.lib, entry)
     _check(fn(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(o), _ptr(h0), _ptr(ht), B, H, T, Dk, Dv,
               _bht(q), _bht(k), _bht(v), _bht(gk), _bht(o), _dt(q), _dt(gk), scale, be.stream(q)))
     return o, ht
+
+
+def chunk_segments(n_heads_total: int, T: int) -> int:
+    """Segments for the segment-parallel K2 (lina_gla_chunk_fwd_seg): enough to put ~256 workgroups on the chip
+    when B*H is small, at least 256 tokens per segment; 1 = the plain kernel."""
+    if n_heads_total >= 128 or T < 1024:
+        return 1
+    return max(1, min(256 // n_heads_total, T // 256, 16))
 
 
 def gla_chunk_bwd(q, k, v, gk, d_o, scale, initial_state=None, final_state=None, d_final_state=None,
@@ -202,11 +222,11 @@ def _needs_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def _gla(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inplace_state=False):
+def _gla(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inplace_state=False, nseg=None):
     q, k, v, gk, scale = _gla_prepare(q, k, v, gk, scale, initial_state)
     if _needs_grad(q, k, v, gk, initial_state):
         return _GLAFunction.apply(q, k, v, gk, scale, initial_state, bool(output_final_state))
-    return _gla_launch(entry, q, k, v, gk, scale, initial_state, output_final_state, inplace_state)
+    return _gla_launch(entry, q, k, v, gk, scale, initial_state, output_final_state, inplace_state, nseg)
 
 
 def fused_recurrent_gla(q, k, v, gk, scale=None, initial_state=None, output_final_state=False,
@@ -221,9 +241,10 @@ def naive_recurrent_gla(q, k, v, gk, initial_state=None, output_final_state=Fals
     return _gla("lina_gla_recurrent_fwd", q, k, v, gk, None, initial_state, output_final_state)
 
 
-def chunk_gla(q, k, v, g, scale=None, initial_state=None, output_final_state=False):
-    """fla.ops.gla.chunk_gla (reference model/gla.py:195) -> K2 (MFMA chunk scan)."""
-    return _gla("lina_gla_chunk_fwd", q, k, v, g, scale, initial_state, output_final_state)
+def chunk_gla(q, k, v, g, scale=None, initial_state=None, output_final_state=False, nseg=None):
+    """fla.ops.gla.chunk_gla (reference model/gla.py:195) -> K2 (MFMA chunk scan).  ``nseg`` (not an fla argument)
+    forces the number of concurrent sequence segments; default: chunk_segments(B*H, T)."""
+    return _gla("lina_gla_chunk_fwd", q, k, v, g, scale, initial_state, output_final_state, nseg=nseg)
 
 
 def fused_chunk_gla(q, k, v, g, scale=None, initial_state=None, output_final_state=False):

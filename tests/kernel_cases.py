@@ -96,6 +96,22 @@ def check_chunk(dev, B, H, T, Dk, Dv, dtype, resets=False):
     assert_close(o, o3.float(), 2 * tol_out(dtype, chunk=True), "K2 vs K1")
 
 
+def check_chunk_segmented(dev, B, H, T, nseg, resets=False):
+    """Segment-parallel K2 (state-only pass + combine + full pass) == the fp64 recurrent oracle and == the plain
+    one-workgroup-per-head kernel, with and without an initial state; bf16, Dk = Dv = 256."""
+    dtype = torch.bfloat16
+    q, k, v, gk, h0 = make_gla_inputs(B, H, T, 256, 256, dtype, dev, seed=21, resets=resets)
+    ro, rS = oracle_gla(q, k, v, gk, h0)
+    o, S = ops.chunk_gla(q, k, v, gk, initial_state=h0, output_final_state=True, nseg=nseg)
+    assert_close(o, ro, tol_out(dtype, chunk=True), f"K2 segmented o (nseg={nseg})")
+    assert_close(S, rS, 1e-2, "K2 segmented state")
+    o1, S1 = ops.chunk_gla(q, k, v, gk, initial_state=h0, output_final_state=True, nseg=1)
+    assert_close(o.float(), o1.float(), 2e-2, "K2 segmented vs plain")
+    o2, S2 = ops.chunk_gla(q, k, v, gk, nseg=nseg)
+    assert S2 is None
+    assert_close(o2, oracle_gla(q, k, v, gk, None)[0], tol_out(dtype, chunk=True), "K2 segmented o (h0=None)")
+
+
 def check_chunk_bwd(dev, B, H, T, Dk, Dv, dtype, resets=False, with_h0=True, with_dht=True, via="chunk_gla"):
     """K2b: gradients of (o, final_state) w.r.t. q, k, v, g, h0 against torch autograd through the fp64
     recurrent oracle.  Tolerances relative to max|ref|: fp32 I/O 2e-4 (different summation order, fast exp),

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import gla_oracle as O
-from kernel_cases import (check_topk_sample, check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_rmsnorm_bwd, check_embed_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
+from kernel_cases import (check_chunk_segmented, check_topk_sample, check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_rmsnorm_bwd, check_embed_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
                           check_prologue, check_recurrent, check_rmsnorm, check_swiglu)
 
 DEV = "cpu"
@@ -129,3 +129,8 @@ def test_embed_bwd(emu):
                                             (50, 100, 1.3, torch.float32), (1030, 100, 0.9, torch.bfloat16)])
 def test_topk_sample(emu, n, k, temp, dtype):
     check_topk_sample(DEV, rows=6, n=n, k=k, temp=temp, dtype=dtype, draws=60)
+
+
+@pytest.mark.parametrize("T,nseg,resets", [(100, 3, False), (70, 2, True)])
+def test_chunk_segment_parallel(emu, T, nseg, resets):
+    check_chunk_segmented(DEV, B=1, H=1, T=T, nseg=nseg, resets=resets)

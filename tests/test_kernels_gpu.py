@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from kernel_cases import (check_topk_sample, assert_close, check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_embed_bwd, check_rmsnorm_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj,
+from kernel_cases import (check_chunk_segmented, check_topk_sample, assert_close, check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_embed_bwd, check_rmsnorm_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj,
                           check_linear_skinny, check_prologue, check_recurrent, check_rmsnorm, check_swiglu,
                           make_gla_inputs, oracle_gla)
 from lina_speech_amd import ops
@@ -209,3 +209,14 @@ def test_embed_bwd(hip):
                                             (8192, 1000, 1.0, torch.float32)])
 def test_topk_sample(hip, n, k, temp, dtype):
     check_topk_sample(DEV, rows=64, n=n, k=k, temp=temp, dtype=dtype)
+
+
+@pytest.mark.parametrize("T,nseg,resets", [(100, 3, False), (300, 4, True), (1024, 8, False), (257, 16, False)])
+def test_chunk_segment_parallel(hip, T, nseg, resets):
+    check_chunk_segmented(DEV, B=2, H=2, T=T, nseg=nseg, resets=resets)
+
+
+def test_chunk_default_policy_uses_segments_for_small_batches(hip):
+    from lina_speech_amd.ops import chunk_segments
+    assert chunk_segments(32, 4096) == 8 and chunk_segments(256, 4096) == 1 and chunk_segments(4, 512) == 1
+    assert chunk_segments(8, 4096) == 16
