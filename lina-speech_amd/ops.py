@@ -281,10 +281,12 @@ class _ShortConvFunction(torch.autograd.Function):
     """K3 forward + K3b backward (cache-less prefill form, the training path)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, mask, act):
+    def forward(ctx, x, w, bias, mask, act, cache=None):
         ctx.save_for_backward(x, w, bias, mask)
         ctx.act = act
-        return _short_conv_launch(x, w, bias, mask, None, act)
+        # a cache given to the prefill form only RECEIVES the last W inputs (training with an initial state,
+        # reference model/gla.py:146-163 with use_cache=True): it does not enter y, so the backward is the same
+        return _short_conv_launch(x, w, bias, mask, cache, act)
 
     @staticmethod
     def backward(ctx, dy):
@@ -302,7 +304,7 @@ class _ShortConvFunction(torch.autograd.Function):
         red = part.sum(0)
         dw = red[:, :W].to(w.dtype)
         db = None if bias is None else red[:, W].to(bias.dtype)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional[str] = "silu"):
@@ -324,9 +326,9 @@ def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional
             raise ValueError(f"cache must be a contiguous {x.dtype} tensor [B,D,W]={B, D, W}")
     m = None if mask is None else mask.to(torch.float32).contiguous()
     if _needs_grad(x, w, bias):
-        if cache is not None:
-            raise NotImplementedError("short_conv: gradients are built for the cache-less form only")
-        return _ShortConvFunction.apply(x, w, bias, m, act)
+        if cache is not None and T == 1:
+            raise NotImplementedError("short_conv: gradients are built for the prefill form (T > 1 or no cache) only")
+        return _ShortConvFunction.apply(x, w, bias, m, act, cache)
     if cache is not None and T == 1:
         m = mask
     return _short_conv_launch(x, w, bias, m, cache, act)

@@ -148,6 +148,20 @@ def golden_lina():
     for name, p in model.named_parameters():
         if p.grad is not None:
             out["grad::" + name] = p.grad.detach().clone()
+    # initial-state tuning (initial_state.py:85-160): rank-1 state parameters, mode 'fused_recurrent', loss and the
+    # gradients w.r.t. the state parameters only
+    torch.manual_seed(5)
+    model.attentive_rnn.to_mode("fused_recurrent")
+    params = model.attentive_rnn.get_init_state_tuning_params(lora=1, device="cpu")
+    model.zero_grad()
+    init_state = model.attentive_rnn.get_state_from_params(params, B, scale=0.02)
+    _, iloss, _, _, _ = model(x, y, encoder_mask, crossatt_mask, logits_mask=logits_mask, init_state=init_state)
+    iloss.backward()
+    out["ist_loss"] = iloss.detach()
+    for i, (pk, pv) in enumerate(params):
+        out[f"ist_k_{i}"], out[f"ist_v_{i}"] = pk.detach().clone(), pv.detach().clone()
+        out[f"ist_gk_{i}"], out[f"ist_gv_{i}"] = pk.grad.detach().clone(), pv.grad.detach().clone()
+    model.attentive_rnn.to_mode("fused_chunk")
     model.eval()
     out.update(sd_arrays(model))
     npz("lina_d64.npz", **out)

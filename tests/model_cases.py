@@ -193,3 +193,33 @@ def check_engine_sampling(dev, n_steps=10, k=20, temp=0.9, seed=77):
                 assert int(toks[0, r, t]) == int(rt[r]), (t, r)
                 compared += 1
     assert compared >= 2 * n_steps
+
+
+def check_init_state_tuning_golden(dev, rel=5e-4):
+    """f-4: loss and the gradients of the rank-1 start-state parameters (dh0 out of K2b, through
+    get_state_from_params) equal the reference's (golden from the reference modules, mode 'fused_recurrent',
+    train()), and the speaker-state file round-trips."""
+    import tempfile
+    from lina_speech_amd.initial_state import parse_speaker_state, save_speaker_state, tuning_loss
+    from lina_speech_amd.train import Batch
+    g = load_golden("lina_d64.npz")
+    model = build_lina()
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    model = model.to(dev).train()
+    model.attentive_rnn.to_mode("fused_recurrent")
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    n = sum(1 for k in g.files if k.startswith("ist_k_"))
+    params = [(t(f"ist_k_{i}").requires_grad_(True), t(f"ist_v_{i}").requires_grad_(True)) for i in range(n)]
+    batch = Batch(t("x"), t("y"), t("encoder_mask"), t("crossatt_mask"), t("logits_mask"))
+    loss = tuning_loss(model, batch, params, scale=0.02)
+    close(loss, g["ist_loss"], "init-state-tuning loss", 1e-5)
+    loss.backward()
+    for i, (pk, pv) in enumerate(params):
+        close(pk.grad, g[f"ist_gk_{i}"], f"grad state k[{i}]", rel)
+        close(pv.grad, g[f"ist_gv_{i}"], f"grad state v[{i}]", rel)
+    with tempfile.TemporaryDirectory() as d:
+        path = d + "/spk.safetensors"
+        save_speaker_state(params, path)
+        back = parse_speaker_state(path)
+        assert len(back) == n and all(torch.equal(a.cpu(), b[0].detach().cpu()) and torch.equal(c.cpu(), b[1].detach().cpu())
+                                      for (a, c), b in zip(back, params))

@@ -64,3 +64,8 @@ def test_train_step_loss_and_gradients_match_reference(emu):
 def test_engine_device_side_sampling_loop(emu):
     from model_cases import check_engine_sampling
     check_engine_sampling("cpu")
+
+
+def test_init_state_tuning_gradients_match_reference(emu):
+    from model_cases import check_init_state_tuning_golden
+    check_init_state_tuning_golden("cpu")

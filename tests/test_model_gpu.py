@@ -96,3 +96,8 @@ def test_l169_train_step_runs_in_bf16_autocast_and_learns(hip):
 def test_engine_device_side_sampling_loop_in_hipgraph(hip):
     from model_cases import check_engine_sampling
     check_engine_sampling("cuda", n_steps=12)
+
+
+def test_init_state_tuning_gradients_match_reference(hip):
+    from model_cases import check_init_state_tuning_golden
+    check_init_state_tuning_golden("cuda")

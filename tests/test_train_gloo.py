@@ -84,3 +84,15 @@ def test_train_step_decreases_loss(emu):
     batch = _micro(0)
     losses = [float(ts.step(batch)) for _ in range(4)]
     assert losses[-1] < losses[0], losses
+
+
+def test_initial_state_tuning_loop_lowers_the_loss_with_frozen_weights(emu):
+    from lina_speech_amd.initial_state import train_initial_state
+    model = _model()
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    batch = _micro(0)
+    params, losses = train_initial_state(model, iter([batch] * 8), n_steps=8, lr=0.2, grad_acc=1, rank=1, device="cpu")
+    assert losses[-1] < losses[0], losses
+    assert len(params) == 2 and all(len(p) == 2 for p in params)          # one (k, v) pair per GLA block (encoder+decoder)
+    for n, p in model.named_parameters():
+        assert torch.equal(p, before[n]), f"{n} changed: the model must stay frozen"
