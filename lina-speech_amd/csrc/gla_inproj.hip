@@ -58,6 +58,33 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
         m_ok[mt] = m < M;
         ap[mt] = A + (int64_t)(m_ok[mt] ? m : 0) * lda + F::KL * lg;
     }
+    // Epilogue operands that do not depend on the GEMM -- the rolled conv caches of this wave's 4 rows (wave w
+    // finalises m-tile w), the conv taps and the LayerNorm-fold constants -- are requested NOW, so their
+    // (HBM-cold) latency is hidden under the main loop instead of sitting exposed after the reduction.
+    float4 pre_old[NT][4], pre_wj[NT];
+    float pre_c1[NT], pre_c2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = gate_wg ? n_direct + li : tile0 + 16 * j + li;
+        pre_c1[j] = c1[n];
+        pre_c2[j] = c2[n];
+        pre_wj[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pre_old[j][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!gate_wg && n < 2 * Kd + Vd) {
+            const T* wsel; const T* csel; int c, D;
+            if (n < Kd) { c = n; D = Kd; wsel = wq; csel = cq; }
+            else if (n < 2 * Kd) { c = n - Kd; D = Kd; wsel = wk; csel = ck; }
+            else { c = n - 2 * Kd; D = Vd; wsel = wv; csel = cv; }
+            pre_wj[j] = ld4(wsel + (int64_t)c * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * w + 4 * lg + r;
+                pre_old[j][r] = ld4(csel + ((int64_t)(m < M ? m : 0) * D + c) * 4);
+            }
+        }
+    }
+
     const int nsteps = K / F::KSTEP;
     // wave w takes k-steps {2w, 2w+1} + 8j: its two consecutive 64-byte (bf16) loads of a row are the two halves
     // of ONE 128-byte line, so every line is pulled into this CU's L1 by a single wave, back to back
@@ -129,7 +156,7 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
     }
 
     if (gate_wg) {
-        const float cc1 = c1[n_direct + li], cc2 = c2[n_direct + li];
+        const float cc1 = pre_c1[0], cc2 = pre_c2[0];
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_lr[16 * w + 4 * lg + r][li] = rstd[r] * (val[0][r] - mu[r] * cc1) + cc2;
         __syncthreads();
@@ -157,7 +184,7 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = tile0 + 16 * j + li;
-        const float cc1 = c1[n], cc2 = c2[n];
+        const float cc1 = pre_c1[j], cc2 = pre_c2[j];
         float z[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[r] = rstd[r] * (val[j][r] - mu[r] * cc1) + cc2;   // projected value z[m, n]
@@ -175,13 +202,13 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
         if (n < Kd) { c = n; D = Kd; wsel = wq; csel = cq; }
         else if (n < 2 * Kd) { c = n - Kd; D = Kd; wsel = wk; csel = ck; }
         else { c = n - 2 * Kd; D = Vd; wsel = wv; csel = cv; }
-        const float4 wj = ld4(wsel + (int64_t)c * 4);
+        const float4 wj = pre_wj[j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + 16 * w + 4 * lg + r;
             if (m < M) {
                 T* cb = csel + ((int64_t)m * D + c) * 4;
-                const float4 old = ld4(cb);
+                const float4 old = pre_old[j][r];
                 T tmp;                                       // the conv sees the projection in the model dtype
                 st(&tmp, z[r]);
                 const float xn = ld(&tmp);

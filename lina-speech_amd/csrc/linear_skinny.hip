@@ -67,6 +67,24 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
         ap[mt] = A + (int64_t)(m_ok[mt] ? m : 0) * lda + F::KL * lg;
     }
 
+    // epilogue operands that do not depend on the GEMM (residual, fold constants) are requested before the main loop:
+    // their latency hides under it instead of sitting exposed after the reduction
+    float pre_res[NT][4], pre_c1[G], pre_c2[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int n = n0 + 16 * (g % NT) + li;
+        const bool ok = n < n_rows;
+        pre_c1[g] = (LN && ok) ? c1[(g / NT) * Hd + n] : 0.0f;
+        pre_c2[g] = (c2 && ok) ? c2[(g / NT) * Hd + n] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * w + 4 * lg + r, n = n0 + 16 * j + li;
+            pre_res[j][r] = (resid && w < MT && m < M && n < N) ? ld(resid + (int64_t)m * ldr + n) : 0.0f;
+        }
+
     const int nsteps = K / F::KSTEP;
     // wave w takes k-steps {2w, 2w+1} + 8j: its two consecutive 64-byte (bf16) loads of a row are the two halves
     // of ONE 128-byte line, so every line is pulled into this CU's L1 by a single wave, back to back
@@ -157,19 +175,19 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
             if (SWIGLU) {
                 float ga = val[j][r], gb = val[NT + j][r];
                 if (n_ok) {
-                    if (LN) { ga = rstd * (ga - mu * c1[n]); gb = rstd * (gb - mu * c1[Hd + n]); }
-                    if (c2) { ga += c2[n]; gb += c2[Hd + n]; }
+                    if (LN) { ga = rstd * (ga - mu * pre_c1[j]); gb = rstd * (gb - mu * pre_c1[NT + j]); }
+                    if (c2) { ga += pre_c2[j]; gb += pre_c2[NT + j]; }
                 }
                 res = n_ok ? silu(ga) * gb : ((n == Hd) ? 1.0f : 0.0f);   // bias column of the K-padded row
             } else {
                 res = val[j][r];
                 if (n_ok) {
-                    if (LN) res = rstd * (res - mu * c1[n]);
-                    if (c2) res += c2[n];
+                    if (LN) res = rstd * (res - mu * pre_c1[j]);
+                    if (c2) res += pre_c2[j];
                 }
             }
             if (m < M && n < N) {
-                if (resid) res += ld(resid + (int64_t)m * ldr + n);
+                if (resid) res += pre_res[j][r];
                 st(out + (int64_t)m * ldo + n, res);
             }
         }
