@@ -69,6 +69,21 @@ __global__ __launch_bounds__(256) void cross_scores_kernel(
     float* s_q = reinterpret_cast<float*>(smem);            // [d]
     __shared__ float s_red[4];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // the text rows of this wave are requested FIRST (d <= 1024: 4 rows x 4 pieces of 4 elements per lane), so their
+    // HBM latency runs under the LayerNorm of the query below
+    constexpr int kIt = 4;
+    const bool pre = d <= 256 * kIt;
+    float4 m[4][kIt];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = min((int)blockIdx.x * 16 + 4 * w + i, Tn - 1);
+        const T* row = kk + ((int64_t)b * Tn + t) * d;
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int e = lane * 4 + 256 * it;
+            m[i][it] = (pre && e < d) ? ld4(row + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     float s = 0.0f;
     for (int e = tid; e < d; e += 256) { const float x = ld(qlin + (int64_t)b * d + e); s_q[e] = x; s += x; }
     const float mu = block_sum(s, s_red) / (float)d;
@@ -85,11 +100,22 @@ __global__ __launch_bounds__(256) void cross_scores_kernel(
     for (int i = 0; i < 4; ++i) {
         const int t = blockIdx.x * 16 + 4 * w + i;           // wave-uniform
         if (t >= Tn) break;
-        const T* row = kk + ((int64_t)b * Tn + t) * d;
         float acc = 0.0f;
-        for (int e = lane * 4; e < d; e += 256) {
-            const float4 m = ld4(row + e);
-            acc = fmaf(m.x, s_q[e], fmaf(m.y, s_q[e + 1], fmaf(m.z, s_q[e + 2], fmaf(m.w, s_q[e + 3], acc))));
+        if (pre) {
+#pragma unroll
+            for (int it = 0; it < kIt; ++it) {
+                const int e = lane * 4 + 256 * it;
+                if (e < d) {
+                    const float4 mm = m[i][it];
+                    acc = fmaf(mm.x, s_q[e], fmaf(mm.y, s_q[e + 1], fmaf(mm.z, s_q[e + 2], fmaf(mm.w, s_q[e + 3], acc))));
+                }
+            }
+        } else {
+            const T* row = kk + ((int64_t)b * Tn + t) * d;
+            for (int e = lane * 4; e < d; e += 256) {
+                const float4 mm = ld4(row + e);
+                acc = fmaf(mm.x, s_q[e], fmaf(mm.y, s_q[e + 1], fmaf(mm.z, s_q[e + 2], fmaf(mm.w, s_q[e + 3], acc))));
+            }
         }
         acc += shfl_xor(acc, 1); acc += shfl_xor(acc, 2); acc += shfl_xor(acc, 4);
         acc += shfl_xor(acc, 8); acc += shfl_xor(acc, 16); acc += shfl_xor(acc, 32);
@@ -122,21 +148,38 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const TX* __restrict_
     }
 }
 
-// x[b, e] += sum_t att[b,t] * vv[b,t,e]    grid (d/1024 ... ) : workgroup = (b, 1024-column slab), 4 columns per thread
+// x[b, e] += sum_t att[b,t] * vv[b,t,e]    grid (ceil(d/256), B): workgroup = (b, 256-column slab); lane = 4 columns,
+// wave w takes text rows w, w+4, ... (8 row loads in flight per lane), the 4 partial sums meet in LDS
 template <typename T>
 __global__ __launch_bounds__(256) void weighted_rows_kernel(const T* __restrict__ attc, int Tp, const T* __restrict__ vv,
                                                             T* x, int Tn, int d) {
     __shared__ float s_a[kCaMaxT];
-    const int b = blockIdx.y, tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float s_p[3][64][4];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int t = tid; t < Tn; t += 256) s_a[t] = ld(attc + (int64_t)b * Tp + t);
     __syncthreads();
-    const int e = blockIdx.x * 1024 + tid * 4;
-    if (e >= d) return;
+    const int e = blockIdx.x * 256 + lane * 4;
+    const bool live = e < d;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t = 0; t < Tn; ++t) {
-        const float a = s_a[t];
-        const float4 p = ld4(vv + ((int64_t)b * Tn + t) * d + e);
-        acc.x = fmaf(a, p.x, acc.x); acc.y = fmaf(a, p.y, acc.y); acc.z = fmaf(a, p.z, acc.z); acc.w = fmaf(a, p.w, acc.w);
+    const T* base = vv + (int64_t)b * Tn * d + (live ? e : 0);
+    for (int t0 = w; t0 < Tn; t0 += 32) {
+        float4 p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = ld4(base + (int64_t)min(t0 + 4 * u, Tn - 1) * d);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float a = (t0 + 4 * u < Tn) ? s_a[min(t0 + 4 * u, Tn - 1)] : 0.0f;
+            acc.x = fmaf(a, p[u].x, acc.x); acc.y = fmaf(a, p[u].y, acc.y);
+            acc.z = fmaf(a, p[u].z, acc.z); acc.w = fmaf(a, p[u].w, acc.w);
+        }
+    }
+    if (w > 0) *reinterpret_cast<float4*>(&s_p[w - 1][lane][0]) = acc;
+    __syncthreads();
+    if (w > 0 || !live) return;
+#pragma unroll
+    for (int ww = 0; ww < 3; ++ww) {
+        const float4 o = *reinterpret_cast<const float4*>(&s_p[ww][lane][0]);
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
     }
     T tmp4[4];
     st4(tmp4, acc);                                          // bmm result in the model dtype, then the residual add
@@ -304,7 +347,7 @@ extern "C" int lina_weighted_rows_add(const void* attc, int Tp, const void* vv, 
     LINA_REQUIRE(B > 0 && Tn > 0 && Tn <= kCaMaxT && Tp >= Tn, "lina_weighted_rows_add: 0 < T_txt <= %d", kCaMaxT);
     LINA_REQUIRE(d > 0 && d % 4 == 0, "lina_weighted_rows_add: d must be a multiple of 4");
     LINA_REQUIRE(valid_dtype(dtype), "lina_weighted_rows_add: bad dtype %d", dtype);
-    dim3 grid((unsigned)((d + 1023) / 1024), (unsigned)B);
+    dim3 grid((unsigned)((d + 255) / 256), (unsigned)B);
     if (dtype == LINA_F32)
         LINA_LAUNCH((weighted_rows_kernel<float>), grid, dim3(256), 0, stream, (const float*)attc, Tp, (const float*)vv,
                     (float*)x, Tn, d);
