@@ -226,7 +226,8 @@ class DecodeEngine:
 
     def _core_part(self, part, y):
         x = part.x
-        x.copy_(y[part.lo:part.hi])
+        if y is not x:                       # the device-side loop embeds the next token straight into part.x
+            x.copy_(y[part.lo:part.hi])
         for P in part.packs[:self.n_enc]:
             self._block(x, P)
         self._cross(part, x)
@@ -308,8 +309,12 @@ class DecodeEngine:
         n_sampled = min(max(first_greedy_quant, 0), self.Q) if k > 1 else 0
         is_sampled = (torch.arange(self.Q, device=self.dev) < n_sampled).unsqueeze(0)        # [1,Q]
 
+        # one row range: the residual-stream buffer itself is the step's input (no y -> x copy, no embed -> y copy)
+        y_buf = self.parts[0].x if len(self.parts) == 1 else self._y_in
+        y_buf.copy_(self._y_in)
+
         def body():
-            logits, att = self._core(self._y_in)
+            logits, att = self._core(y_buf)
             lg = logits.view(self.B, self.Q, self.L)
             if n_sampled == 0:
                 pick = ops.argmax_rows(lg)
@@ -321,13 +326,13 @@ class DecodeEngine:
             pick = pick.t().contiguous()                                                      # [Q,B]
             self._tok_log.index_copy_(0, self._t_idx, pick.unsqueeze(0))
             self._t_idx.add_(1)
-            self._y_in.copy_(ops.embed_sum(emb.weight, pick))
+            ops.embed_sum(emb.weight, pick, out=y_buf)              # next step's input, written in place
             return att
 
         self._greedy_body = body
         self._greedy_graph = None
         if self.use_graph:
-            snap, y_keep = self._snapshot(), self._y_in.clone()
+            snap, y_keep = self._snapshot(), y_buf.clone()
             side = torch.cuda.Stream(device=self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
@@ -335,7 +340,7 @@ class DecodeEngine:
                     body()
             torch.cuda.current_stream(self.dev).wait_stream(side)
             self._restore(snap)
-            self._y_in.copy_(y_keep)
+            y_buf.copy_(y_keep)
             self._tok_log.zero_()
             self._t_idx.zero_()
             g = torch.cuda.CUDAGraph()

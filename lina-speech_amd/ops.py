@@ -409,11 +409,14 @@ def rmsnorm(x, weight=None, eps: float = 1e-5):
 
 
 # --------------------------------------------------------------------------- codec head (K6)
-def _embed_sum_launch(table, flat):
+def _embed_sum_launch(table, flat, out=None):
     be = _BACKEND
     Q, n_emb, d = table.shape
     N = flat.shape[1]
-    out = torch.empty(N, d, dtype=table.dtype, device=table.device)
+    if out is None:
+        out = torch.empty(N, d, dtype=table.dtype, device=table.device)
+    elif tuple(out.shape) != (N, d) or out.dtype != table.dtype or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous {table.dtype} tensor [{N}, {d}]")
     _check(be.lib.lina_embed_sum(_ptr(flat), _ptr(table.contiguous()), _ptr(out), Q, N, n_emb, d, _dt(table),
                                  be.stream(table)))
     return out
@@ -440,9 +443,10 @@ class _EmbedSumFunction(torch.autograd.Function):
         return dt.to(ctx.tdtype), None
 
 
-def embed_sum(table, idx):
+def embed_sum(table, idx, out=None):
     """table [Q,n_emb,d], idx int64 [Q,B,n] -> sum_q table[q, idx[q]] : [B,n,d]
-    (MultiEmbedding + reduce over quantizers; reference modeling_lina.py:131,178-179)."""
+    (MultiEmbedding + reduce over quantizers; reference modeling_lina.py:131,178-179).
+    ``out``: optional contiguous [B*n, d] destination (no-grad path)."""
     be = _BACKEND
     be.require(table, idx)
     Q, n_emb, d = table.shape
@@ -451,7 +455,7 @@ def embed_sum(table, idx):
     flat = idx.reshape(Q, -1).contiguous()
     if _needs_grad(table):
         return _EmbedSumFunction.apply(table, flat).view(*idx.shape[1:], d)
-    return _embed_sum_launch(table, flat).view(*idx.shape[1:], d)
+    return _embed_sum_launch(table, flat, out).view(*idx.shape[1:], d)
 
 
 def argmax_rows(logits, out=None):
