@@ -145,6 +145,30 @@ def measure_train_step(dev, b=8, T=4096, steps=3):
     return out
 
 
+def measure_vocoder(dev, B=64, L=750, reps=3):
+    """f-3: codes -> 24 kHz waveform for the decode batch (B utterances x 750 tokens = 10 s each), bf16 backbone,
+    fp32 ISTFT head; random-init weights of the WavTokenizer-small shape."""
+    from lina_speech_amd.vocoder import WavTokenizerDecoder
+    torch.manual_seed(0)
+    voc = WavTokenizerDecoder().eval().to(dev)
+    voc.backbone.to(torch.bfloat16)
+    voc.codebook.data = voc.codebook.data.to(torch.bfloat16)
+    codes = torch.randint(0, 4096, (1, B, L), device=dev)
+    bw = torch.zeros(1, dtype=torch.long, device=dev)
+    run = lambda: voc.head(voc.backbone(voc.codes_to_features(codes), bandwidth_id=bw).float())
+    with torch.inference_mode():
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            audio = run()
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert audio.shape == (B, L * 320) and bool(torch.isfinite(audio).all())
+    return {"what": "WavTokenizer-small decode (12 ConvNeXt blocks, dim 768, ISTFT 1280/320), bf16 backbone", "batch": B,
+            "tokens_each": L, "ms": dt * 1e3, "codec_tokens_per_s": B * L / dt, "audio_seconds_per_s": B * L / 75.0 / dt}
+
+
 def cpu_baseline(model, seconds=12.0, B=8, max_steps=64):
     """The reference's pure-PyTorch recurrent path (mode='naive') restated in oracle/, timed on the host cores
     on a bounded sample of the same workload: same 166.7M weights (fp32), B=8 rows, T_txt=64, greedy."""
@@ -286,6 +310,7 @@ def main():
                 small = measure_chunk(dev, B=8)                      # training micro-batch: segment-parallel form
                 small["kernel"] = "lina_gla_chunk_fwd_seg (state-only pass + combine + full pass, 8 segments)"
                 out["chunk_kernel_b8"] = small
+                out["vocoder"] = measure_vocoder(dev)
                 out["chunk_bwd_kernel"] = measure_chunk_bwd(dev)
     if rank == 0:
         if not args.no_train and world == 1:

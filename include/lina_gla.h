@@ -290,6 +290,22 @@ int lina_softmax_rows(const void* x, int64_t x_sb, int x_dtype, float scale, voi
 int lina_weighted_rows_add(const void* attc, int Tp, const void* vv, void* x, int B, int T_txt, int d,
                            int dtype, lina_stream_t stream);
 
+/* ---- f-3: the codes -> waveform step after the generation path (reference 3rdparty/decoder) ---- */
+
+/* K8 -- depthwise conv (kernel 7, "same" zero padding along L) fused with the LayerNorm / AdaLayerNorm over C
+ * that follows it in ConvNeXtBlock (reference 3rdparty/decoder/modules.py:44-50, 62-82), channels-last:
+ *   x, y: [B, L, C] contiguous;  w: [C, 7];  bias: [C] or NULL;
+ *   scale / shift: NULL, or per-batch rows (row stride scale_sb elements; 0 = one shared row), applied as
+ *   LN(z) * scale + shift (LayerNorm weight/bias, or the AdaLayerNorm embeddings already looked up). C <= 1024. */
+int lina_dwconv7_ln(const void* x, const void* w, const void* bias, const void* scale, const void* shift,
+                    void* y, int B, int L, int C, int64_t scale_sb, float eps, int dtype, lina_stream_t stream);
+
+/* K9 -- ISTFT overlap-add with "same" padding (reference 3rdparty/decoder/spectral_ops.py:56-75):
+ *   frames: fp32 [B, T, win] inverse-transformed frames (NOT yet windowed); window: fp32 [win];
+ *   y: fp32 [B, (T-1)*hop + win - 2*((win-hop)/2)] = sum of the windowed frames / window envelope, trimmed. */
+int lina_istft_ola(const float* frames, const float* window, float* y, int B, int T, int win, int hop,
+                   lina_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,8 @@ PROTOTYPES = {
     "lina_embed_sum": (C.c_int, [_p, _p, _p, _i, _i64, _i, _i, _i, _p]),
     "lina_argmax_rows": (C.c_int, [_p, _p, _i64, _i, _i64, _i, _p]),
     "lina_topk_sample_rows": (C.c_int, [_p, _p, _i64, _i, _i64, _i, _f, _p, C.c_uint64, _p, _i, _p]),
+    "lina_dwconv7_ln": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _f, _i, _p]),
+    "lina_istft_ola": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "lina_gla_decode_prologue": (C.c_int, [_p, _i64, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                            _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "lina_swiglu": (C.c_int, [_p, _p, _i64, _i, _i64, _i64, _i, _p]),

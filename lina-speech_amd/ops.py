@@ -657,3 +657,47 @@ def weighted_rows_add(attc, vv, x):
     be.require(attc, vv, x)
     B, Tn, d = vv.shape
     _check(be.lib.lina_weighted_rows_add(_ptr(attc), attc.shape[1], _ptr(vv), _ptr(x), B, Tn, d, _dt(x), be.stream(x)))
+
+
+# --------------------------------------------------------------------------- codes -> waveform (f-3)
+def dwconv7_ln(x, weight, bias=None, scale=None, shift=None, eps: float = 1e-6):
+    """K8: depthwise conv (k = 7, 'same') + LayerNorm over channels, channels-last ``x [B,L,C]``
+    (ConvNeXtBlock.dwconv + norm, reference 3rdparty/decoder/modules.py:44-50).  ``weight`` [C,1,7]|[C,7];
+    ``scale`` / ``shift``: [C] (LayerNorm affine) or [B,C] (AdaLayerNorm rows) or None."""
+    _no_grad(x, weight, bias, scale, shift)
+    be = _BACKEND
+    be.require(x, weight, bias, scale, shift)
+    B, L, Cc = x.shape
+    x = x.contiguous()
+    w = weight.reshape(Cc, 7).to(x.dtype).contiguous()
+    b = None if bias is None else bias.to(x.dtype).contiguous()
+    sb = 0
+    if scale is not None:
+        scale = scale.to(x.dtype).contiguous()
+        sb = Cc if scale.dim() == 2 and scale.shape[0] == B and B > 1 else 0
+        if scale.dim() == 2 and scale.shape[0] not in (1, B):
+            raise ValueError("scale must be [C], [1,C] or [B,C]")
+    if shift is not None:
+        shift = shift.to(x.dtype).contiguous()
+        if scale is not None and tuple(shift.shape) != tuple(scale.shape):
+            raise ValueError("scale and shift must have the same shape")
+        if scale is None:
+            sb = Cc if shift.dim() == 2 and shift.shape[0] == B and B > 1 else 0
+    y = torch.empty_like(x)
+    _check(be.lib.lina_dwconv7_ln(_ptr(x), _ptr(w), _ptr(b), _ptr(scale), _ptr(shift), _ptr(y), B, L, Cc, sb, float(eps),
+                                  _dt(x), be.stream(x)))
+    return y
+
+
+def istft_ola(frames, window, hop: int):
+    """K9: windowed overlap-add + envelope normalisation with 'same' padding (reference spectral_ops.py:56-75).
+    ``frames`` fp32 [B,T,win] inverse-transformed frames, ``window`` fp32 [win] -> fp32 [B, T*hop] (win - hop even)."""
+    be = _BACKEND
+    be.require(frames, window)
+    B, T, win = frames.shape
+    frames = frames.float().contiguous()
+    window = window.float().contiguous()
+    pad = (win - hop) // 2
+    y = torch.empty(B, (T - 1) * hop + win - 2 * pad, dtype=torch.float32, device=frames.device)
+    _check(be.lib.lina_istft_ola(_ptr(frames), _ptr(window), _ptr(y), B, T, win, int(hop), be.stream(frames)))
+    return y

@@ -183,7 +183,45 @@ def golden_tools():
         topk_logits=logits, topk_k1=k1, packmask=pm, seqmask=sm)
 
 
+def golden_vocoder():
+    """WavTokenizer decode: VocosBackbone (3rdparty/decoder/models.py:152-235) + ISTFTHead (heads.py:24-67) of the
+    reference with small seeded weights; torchaudio is only an import-time name of heads.py (unused by ISTFTHead)."""
+    import types
+    ta = types.ModuleType("torchaudio"); taf = types.ModuleType("torchaudio.functional")
+    taff = types.ModuleType("torchaudio.functional.functional")
+    taff._hz_to_mel = taff._mel_to_hz = None
+    sys.modules.update({"torchaudio": ta, "torchaudio.functional": taf, "torchaudio.functional.functional": taff})
+    sys.path.insert(0, os.path.join(REF, "3rdparty"))
+    from decoder.models import VocosBackbone
+    from decoder.heads import ISTFTHead
+    torch.manual_seed(11)
+    C_in, dim, inter, layers, n_fft, hop = 32, 64, 128, 2, 64, 16
+    backbone = VocosBackbone(input_channels=C_in, dim=dim, intermediate_dim=inter, num_layers=layers,
+                             adanorm_num_embeddings=4).eval()
+    head = ISTFTHead(dim=dim, n_fft=n_fft, hop_length=hop, padding="same").eval()
+    with torch.no_grad():                       # the reference initialises most of these to constants: randomise
+        for name, p in list(backbone.named_parameters()) + list(head.named_parameters()):
+            if p.dim() == 1 or "scale" in name or "shift" in name:
+                p.add_(torch.randn_like(p) * 0.2)
+            else:
+                p.mul_(8.0)
+        head.out.weight.mul_(0.3)
+        B, L = 3, 23
+        feats = torch.randn(B, C_in, L)
+        bw = torch.tensor([2])                  # one shared bandwidth id (the only form the reference's AdaLayerNorm broadcasts)
+        hid = backbone(feats, bandwidth_id=bw)
+        audio = head(hid)
+    out = dict(feats=feats, bw=bw, hidden=hid, audio=audio,
+               cfg=torch.tensor([C_in, dim, inter, layers, n_fft, hop]))
+    for k, v in backbone.state_dict().items():
+        out["sd::backbone." + k] = v
+    for k, v in head.state_dict().items():
+        out["sd::head." + k] = v
+    npz("vocoder_small.npz", **out)
+
+
 if __name__ == "__main__":
+    golden_vocoder()
     golden_tools()
     golden_mixer()
     golden_lina()

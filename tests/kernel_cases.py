@@ -539,3 +539,41 @@ def check_cross_spread(dev, B, Tn, d, dtype):
     x0 = x.clone()
     ops.weighted_rows_add(attc, vv, x)
     assert_close(x, c(x0) + torch.einsum("bt,btd->bd", c(attc[:, :Tn]), c(vv)), tol, "weighted rows add")
+
+
+def check_dwconv7_ln(dev, B, L, C, dtype, ada=False):
+    """K8 vs the oracle (fp64 torch conv1d + layer_norm).  fp32 1e-5, bf16 2e-2 of max|ref|."""
+    from oracle import vocoder_oracle as VO
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, L, C, generator=g).to(dtype)
+    w = (torch.randn(C, 1, 7, generator=g) * 0.4).to(dtype)
+    bias = torch.randn(C, generator=g).to(dtype)
+    scale = (1 + 0.3 * torch.randn((B, C) if ada else (C,), generator=g)).to(dtype)
+    shift = (0.3 * torch.randn((B, C) if ada else (C,), generator=g)).to(dtype)
+    y = ops.dwconv7_ln(x.to(dev), w.to(dev), bias.to(dev), scale.to(dev), shift.to(dev), 1e-6)
+    ry = VO.dwconv7_ln(x.to(F64), w.to(F64), bias.to(F64), scale.to(F64), shift.to(F64), 1e-6)
+    assert y.dtype == dtype
+    assert_close(y, ry, 1e-5 if dtype == torch.float32 else 2e-2, "K8 dwconv7+LN")
+    y2 = ops.dwconv7_ln(x.to(dev), w.to(dev), None, None, None, 1e-6)
+    assert_close(y2, VO.dwconv7_ln(x.to(F64), w.to(F64)), 1e-5 if dtype == torch.float32 else 2e-2, "K8 plain")
+
+
+def check_istft_ola(dev, B, T, win, hop):
+    """K9 vs the oracle's fold-based overlap-add (fp64): 1e-5; and the constant-overlap-add identity: frames cut
+    from a signal with a Hann window reconstruct it exactly in the interior."""
+    from oracle import vocoder_oracle as VO
+    g = torch.Generator().manual_seed(32)
+    frames = torch.randn(B, T, win, generator=g)
+    window = torch.hann_window(win)
+    y = ops.istft_ola(frames.to(dev), window.to(dev), hop)
+    ry = VO.istft_same(frames.to(F64), window.to(F64), hop)
+    assert y.shape == ry.shape == (B, T * hop if (win - hop) % 2 == 0 else y.shape[1])
+    assert_close(y, ry, 1e-5, "K9 istft overlap-add")
+    sig = torch.randn(B, (T - 1) * hop + win, generator=g)
+    cut = sig.unfold(1, win, hop) * window                       # analysis frames (windowed once)
+    rec = ops.istft_ola(cut.contiguous().to(dev), window.to(dev), hop).cpu()
+    pad = (win - hop) // 2
+    inner = slice(win, rec.shape[1] - win)
+    if rec.shape[1] <= 2 * win:
+        return
+    assert (rec[:, inner] - sig[:, pad:pad + rec.shape[1]][:, inner]).abs().max() < 1e-4, "K9 does not invert the STFT framing"

@@ -223,3 +223,39 @@ def check_init_state_tuning_golden(dev, rel=5e-4):
         back = parse_speaker_state(path)
         assert len(back) == n and all(torch.equal(a.cpu(), b[0].detach().cpu()) and torch.equal(c.cpu(), b[1].detach().cpu())
                                       for (a, c), b in zip(back, params))
+
+
+def _vocoder_from_golden(g, dev):
+    from lina_speech_amd.vocoder import WavTokenizerDecoder
+    C_in, dim, inter, layers, n_fft, hop = (int(v) for v in g["cfg"])
+    voc = WavTokenizerDecoder(n_codes=50, n_codebooks=1, codebook_dim=C_in, dim=dim, intermediate_dim=inter,
+                              num_layers=layers, adanorm_num_embeddings=4, n_fft=n_fft, hop_length=hop)
+    sd = {k: v for k, v in golden_state_dict(g).items()}
+    missing, unexpected = voc.load_state_dict(sd, strict=False)
+    assert missing == ["codebook"] and not unexpected, (missing, unexpected)
+    return voc.to(dev).eval()
+
+
+def check_vocoder_golden(dev):
+    """f-3: backbone output and waveform equal the reference's VocosBackbone + ISTFTHead (golden from the reference
+    modules, tests/golden/make_golden.py::golden_vocoder) -- 2e-4 of max|golden| (fp32) -- and the fp64 oracle
+    restatement equals the same golden at 1e-5 (this is what pins the oracle)."""
+    from oracle.vocoder_oracle import OracleVocoder
+    g = load_golden("vocoder_small.npz")
+    voc = _vocoder_from_golden(g, dev)
+    feats, bw = torch.from_numpy(g["feats"]).to(dev), torch.from_numpy(g["bw"]).to(dev)
+    with torch.no_grad():
+        hid = voc.backbone(feats, bandwidth_id=bw)
+        audio = voc.head(hid)
+    close(hid, g["hidden"], "vocoder backbone output")
+    close(audio, g["audio"], "vocoder waveform")
+    C_in, dim, inter, layers, n_fft, hop = (int(v) for v in g["cfg"])
+    orc = OracleVocoder(golden_state_dict(g), layers, n_fft, hop)
+    close(orc.decode(torch.from_numpy(g["feats"]), torch.from_numpy(g["bw"])), g["audio"], "oracle waveform", 1e-5)
+    # codes -> features -> audio end to end: the gather is K6a
+    codes = torch.randint(0, 50, (1, 3, 23), generator=torch.Generator().manual_seed(4)).to(dev)
+    with torch.no_grad():
+        a2 = voc(codes, bandwidth_id=bw)
+        f2 = voc.codebook[0][codes[0]].transpose(1, 2)
+        close(a2, voc.decode(f2, bandwidth_id=bw).cpu().numpy(), "codes -> waveform", 1e-6)
+    assert a2.shape == (3, 23 * hop)

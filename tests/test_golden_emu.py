@@ -69,3 +69,8 @@ def test_engine_device_side_sampling_loop(emu):
 def test_init_state_tuning_gradients_match_reference(emu):
     from model_cases import check_init_state_tuning_golden
     check_init_state_tuning_golden("cpu")
+
+
+def test_vocoder_matches_reference_modules(emu):
+    from model_cases import check_vocoder_golden
+    check_vocoder_golden("cpu")

@@ -134,3 +134,15 @@ def test_topk_sample(emu, n, k, temp, dtype):
 @pytest.mark.parametrize("T,nseg,resets", [(100, 3, False), (70, 2, True)])
 def test_chunk_segment_parallel(emu, T, nseg, resets):
     check_chunk_segmented(DEV, B=1, H=1, T=T, nseg=nseg, resets=resets)
+
+
+@pytest.mark.parametrize("C,dtype,ada", [(64, torch.float32, False), (768, torch.float32, True), (96, torch.bfloat16, True)])
+def test_dwconv7_ln(emu, C, dtype, ada):
+    from kernel_cases import check_dwconv7_ln
+    check_dwconv7_ln(DEV, B=2, L=11, C=C, dtype=dtype, ada=ada)
+
+
+@pytest.mark.parametrize("T,win,hop", [(20, 64, 16), (5, 40, 10), (3, 1280, 320)])
+def test_istft_ola(emu, T, win, hop):
+    from kernel_cases import check_istft_ola
+    check_istft_ola(DEV, B=2, T=T, win=win, hop=hop)

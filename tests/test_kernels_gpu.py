@@ -220,3 +220,17 @@ def test_chunk_default_policy_uses_segments_for_small_batches(hip):
     from lina_speech_amd.ops import chunk_segments
     assert chunk_segments(32, 4096) == 8 and chunk_segments(256, 4096) == 1 and chunk_segments(4, 512) == 1
     assert chunk_segments(8, 4096) == 16
+
+
+# ----------------------------------------------------------------------------- codes -> waveform (f-3)
+@pytest.mark.parametrize("C,dtype,ada", [(64, torch.float32, False), (768, torch.float32, True), (768, torch.bfloat16, True),
+                                         (1024, torch.bfloat16, False)])
+def test_dwconv7_ln(hip, C, dtype, ada):
+    from kernel_cases import check_dwconv7_ln
+    check_dwconv7_ln(DEV, B=3, L=200, C=C, dtype=dtype, ada=ada)
+
+
+@pytest.mark.parametrize("T,win,hop", [(20, 64, 16), (5, 40, 10), (750, 1280, 320)])
+def test_istft_ola(hip, T, win, hop):
+    from kernel_cases import check_istft_ola
+    check_istft_ola(DEV, B=3, T=T, win=win, hop=hop)

@@ -101,3 +101,31 @@ def test_engine_device_side_sampling_loop_in_hipgraph(hip):
 def test_init_state_tuning_gradients_match_reference(hip):
     from model_cases import check_init_state_tuning_golden
     check_init_state_tuning_golden("cuda")
+
+
+def test_vocoder_matches_reference_modules(hip):
+    from model_cases import check_vocoder_golden
+    check_vocoder_golden("cuda")
+
+
+def test_full_size_vocoder_matches_cpu_oracle(hip):
+    """WavTokenizer-sized decoder (dim 768, 12 ConvNeXt blocks, n_fft 1280, hop 320), fp32, vs the fp64 oracle."""
+    from lina_speech_amd.vocoder import WavTokenizerDecoder
+    from oracle.vocoder_oracle import OracleVocoder
+    torch.manual_seed(3)
+    voc = WavTokenizerDecoder().eval()
+    with torch.no_grad():
+        for name, p in voc.named_parameters():
+            if "gamma" in name or "scale" in name or "shift" in name:
+                p.add_(torch.randn_like(p) * 0.1)
+        voc.head.out.weight.mul_(0.2)
+    codes = torch.randint(0, 4096, (1, 2, 60))
+    bw = torch.tensor([0])
+    sd = {k: v.detach().clone() for k, v in voc.state_dict().items()}
+    feats = voc.codebook[0][codes[0]].transpose(1, 2)
+    ref = OracleVocoder(sd, 12, 1280, 320).decode(feats, bw)
+    voc = voc.cuda()
+    audio = voc(codes.cuda(), bandwidth_id=bw.cuda())
+    assert audio.shape == (2, 60 * 320)
+    err = (audio.cpu().double() - ref).abs().max() / ref.abs().max()
+    assert err < 5e-4, float(err)
