@@ -305,7 +305,7 @@ def main():
                 torch.cuda.synchronize()
                 out["sampled_decode"] = {"k": 100, "temp": 1.0, "ms_per_step": (time.perf_counter() - ts0) / 50 * 1e3,
                                          "tokens_per_s": B * 50 / (time.perf_counter() - ts0)}
-            if not args.no_chunk:
+            if not args.no_chunk and world == 1:
                 out["chunk_kernel"] = measure_chunk(dev)
                 small = measure_chunk(dev, B=8)                      # training micro-batch: segment-parallel form
                 small["kernel"] = "lina_gla_chunk_fwd_seg (state-only pass + combine + full pass, 8 segments)"
