@@ -114,6 +114,10 @@ class GatedLinearAttention(nn.Module):
                 output_attentions: Optional[bool] = False, **kwargs) -> torch.Tensor:
         last_state = past_key_values[self.layer_idx] if use_cache else None
         conv_states: Tuple = ()
+        if hidden_states.is_cuda and torch.is_autocast_enabled():
+            # under autocast every one of the five projections below would cast this (fp32 LayerNorm output) tensor
+            # to the autocast dtype on its own: do it once (same values, 4 fewer passes over [B,T,d])
+            hidden_states = hidden_states.to(torch.get_autocast_gpu_dtype())
         if self.use_short_conv and self.share_conv_kernel:
             conv_states = (last_state[0] if use_cache else None,)
             hidden_states = self.h_conv1d(hidden_states, attention_mask, conv_states[0])
