@@ -22,8 +22,8 @@
 // grid = (B*H, slices of 64, 3 sweeps) in ONE launch: every slice is independent (any chunk partition is exact), so a
 // training micro-batch of b rows gives 4*b*H workgroups.  Chunks are 16 tokens, cut adaptively where the
 // in-chunk decay would exceed e^-60 (reverse sweeps cut from the END of the tile), exactly like K2.
-// All contractions run on v_mfma_f32_16x16x4_f32 (fp32 operands, bf16 I/O is widened when staged):
-// gradients are fp32-accurate; dq, dk stay fp32 in a workspace until dg = reverse-cumsum(q dq - k dk)
+// fp32 I/O contracts on v_mfma_f32_16x16x4_f32 (exact fp32), bf16 I/O on v_mfma_f32_16x16x32_bf16 with fp32
+// accumulation (operands q~, k~, do, v and the state rounded to bf16 as in K2); dq, dk stay fp32 in a workspace until dg = reverse-cumsum(q dq - k dk)
 // has been formed from them, then they are cast to the I/O dtype by the same kernel.
 #include <lina_dev.h>
 #include "lina_common.h"
@@ -135,6 +135,80 @@ __device__ __forceinline__ f32x4 chunk_products(f32x4 (&R)[D1 / 16], const float
     return f32x4{acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]};
 }
 
+// bf16 variant (bf16 I/O): the same phase on v_mfma_f32_16x16x32_bf16.  Tiles (bf16):
+//   s_xb, s_yb : [16][D1+8] row-major (A / B operands of X.Y^T, A operand of X.R)
+//   s_yT       : [D1][24]   Y transposed, s_zT : [64][24] Z transposed (operands whose K dimension is the token axis;
+//                16 tokens fill half of a K = 32 step: lane groups 2,3 feed zeros)
+// R stays fp32 in the accumulators and is rounded to bf16 only as the B operand of X.R, exactly like K2.
+struct BfTiles {
+    bf16_t *xb, *yb, *yT, *zT;
+};
+template <int D1>
+__device__ __forceinline__ BfTiles carve_bf(float* smem, float** rest) {
+    constexpr int SXB = D1 + 8, ST = kBC + 8;
+    BfTiles t;
+    t.xb = reinterpret_cast<bf16_t*>(smem);
+    t.yb = t.xb + kBC * SXB;
+    t.yT = t.yb + kBC * SXB;
+    t.zT = t.yT + D1 * ST;
+    *rest = smem + (2 * kBC * SXB + D1 * ST + 64 * ST) / 2;
+    return t;
+}
+template <int D1, bool UPPER>
+__device__ __forceinline__ f32x4 chunk_products_bf(f32x4 (&R)[D1 / 16], const BfTiles& t, float (*s_A)[kBC][kBC + 1],
+                                                   int w, int li, int lg) {
+    constexpr int NT = D1 / 16, SXB = D1 + 8, ST = kBC + 8, NWA = D1 / 64;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pp = 0; pp < NT / 2; ++pp) {
+        const bf16_t* xp = &t.xb[li * SXB + 32 * pp + 4 * lg];
+        const bf16x8 a = as_bf16x8(*reinterpret_cast<const uint2*>(xp), *reinterpret_cast<const uint2*>(xp + 16));
+        bf16x8 bb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bb[r] = (short)f2bf(R[2 * pp][r]);
+            bb[4 + r] = (short)f2bf(R[2 * pp + 1][r]);
+        }
+        acc = mfma_bf16_16x16x32(a, bb, acc);
+    }
+    if (w < NWA) {   // partial M[m][n] = X[m] . Y[n] over 64 channels
+        f32x4 pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int cc = 64 * w + 32 * kk + 8 * lg;
+            pa = mfma_bf16_16x16x32(as_bf16x8(*reinterpret_cast<const uint4*>(&t.xb[li * SXB + cc])),
+                                    as_bf16x8(*reinterpret_cast<const uint4*>(&t.yb[li * SXB + cc])), pa);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_A[w][4 * lg + r][li] = pa[r];
+    }
+    __syncthreads();
+    bf16x8 a_in, b_z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a_in[j] = 0; b_z[j] = 0; }
+    if (lg < 2) {
+        b_z = as_bf16x8(*reinterpret_cast<const uint4*>(&t.zT[(16 * w + li) * ST + 8 * lg]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = 8 * lg + j;                    // contraction index (a token), output row = li
+            float a = 0.0f;
+#pragma unroll
+            for (int ww = 0; ww < NWA; ++ww) a += s_A[ww][li][s];
+            a_in[j] = (short)f2bf((UPPER ? (s >= li) : (s <= li)) ? a : 0.0f);
+        }
+    }
+    acc = mfma_bf16_16x16x32(a_in, b_z, acc);
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+        bf16x8 a_y;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a_y[j] = 0;
+        if (lg < 2) a_y = as_bf16x8(*reinterpret_cast<const uint4*>(&t.yT[(16 * p + li) * ST + 8 * lg]));
+        R[p] = mfma_bf16_16x16x32(a_y, b_z, R[p]);
+    }
+    return acc;
+}
+
 // ===================================== sweep V : dv, dh0 ==========================================
 template <int DK, typename TIO, typename TG>
 __device__ __forceinline__ void sweep_v(
@@ -143,10 +217,15 @@ __device__ __forceinline__ void sweep_v(
     lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sg, lina_bht_strides sdo, lina_bht_strides sdv,
     float scale) {
     constexpr int C = kBC, NT = DK / 16, SX = DK + 2, SZ = 64 + 16;
+    constexpr bool kBf = sizeof(TIO) == 2;                // bf16 I/O: bf16 MFMA operands
+    constexpr int SXB = DK + 8, ST = C + 8;
+    float* rest = smem + 2 * C * SX + C * SZ;
+    BfTiles bt{};
+    if constexpr (kBf) bt = carve_bf<DK>(smem, &rest);
     float* s_x = smem;
     float* s_y = s_x + C * SX;
     float* s_z = s_y + C * SX;
-    float* s_dec = s_z + C * SZ;
+    float* s_dec = rest;
     float (*s_A)[C][C + 1] = reinterpret_cast<float (*)[C][C + 1]>(s_dec + DK);
     int* s_nw = reinterpret_cast<int*>(s_dec + DK + 4 * C * (C + 1));
 
@@ -207,16 +286,28 @@ __device__ __forceinline__ void sweep_v(
 #pragma unroll
             for (int r = 0; r < C; ++r) {
                 const bool valid = r >= start;             // start >= -base: rows before token 0 are never valid
-                s_x[r * SX + tid] = valid ? kr[r] * __expf(-bv[r]) : 0.0f;
-                s_y[r * SX + tid] = valid ? qr[r] * scale * __expf(bv[r]) : 0.0f;
+                const float xk = valid ? kr[r] * __expf(-bv[r]) : 0.0f;
+                const float yq = valid ? qr[r] * scale * __expf(bv[r]) : 0.0f;
+                if constexpr (kBf) {
+                    const bf16_t yb = f2bf(yq);
+                    bt.xb[r * SXB + tid] = f2bf(xk);
+                    bt.yb[r * SXB + tid] = yb;
+                    bt.yT[tid * ST + r] = yb;
+                } else {
+                    s_x[r * SX + tid] = xk;
+                    s_y[r * SX + tid] = yq;
+                }
             }
             s_dec[tid] = __expf(tot);
         }
         {
             const bool valid = vr >= start;
-            float* d = &s_z[vr * SZ + vc];
-            d[0] = valid ? zr.x : 0.0f; d[1] = valid ? zr.y : 0.0f;
-            d[2] = valid ? zr.z : 0.0f; d[3] = valid ? zr.w : 0.0f;
+            const float zv[4] = {valid ? zr.x : 0.0f, valid ? zr.y : 0.0f, valid ? zr.z : 0.0f, valid ? zr.w : 0.0f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (kBf) bt.zT[(vc + i) * ST + vr] = f2bf(zv[i]);
+                else s_z[vr * SZ + vc + i] = zv[i];
+            }
         }
         const int t_end = base + start;                   // tokens [0, t_end) remain
         const int nbase = t_end - C;
@@ -226,7 +317,9 @@ __device__ __forceinline__ void sweep_v(
         for (int p = 0; p < NT; ++p)                      // D = diag(e^{b_last}) dS_in
 #pragma unroll
             for (int r = 0; r < 4; ++r) R[p][r] *= s_dec[16 * p + 4 * lg + r];
-        const f32x4 acc = chunk_products<DK, true>(R, s_x, s_y, s_z, s_A, w, li, lg);
+        f32x4 acc;
+        if constexpr (kBf) acc = chunk_products_bf<DK, true>(R, bt, s_A, w, li, lg);
+        else acc = chunk_products<DK, true>(R, s_x, s_y, s_z, s_A, w, li, lg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * lg + r;
@@ -253,11 +346,16 @@ __device__ __forceinline__ void sweep_qk(
     const TG* __restrict__ gk, float* __restrict__ out32, const float* r0, int H, int T, int Dk,
     lina_bht_strides sx, lina_bht_strides sy, lina_bht_strides sz, lina_bht_strides sg, float scale) {
     constexpr int C = kBC, NT = DV / 16, SX = DV + 2, SZ = 64 + 16;
+    constexpr bool kBf = sizeof(TIO) == 2;                // bf16 I/O: bf16 MFMA operands
+    constexpr int SXB = DV + 8, ST = C + 8;
+    float* rest = smem + 2 * C * SX + C * SZ;
+    BfTiles bt{};
+    if constexpr (kBf) bt = carve_bf<DV>(smem, &rest);
     float* s_x = smem;
     float* s_y = s_x + C * SX;
     float* s_z = s_y + C * SX;
-    float (*s_b)[64 + 1] = reinterpret_cast<float (*)[64 + 1]>(s_z + C * SZ);
-    float* s_dec = s_z + C * SZ + C * (64 + 1);
+    float (*s_b)[64 + 1] = reinterpret_cast<float (*)[64 + 1]>(rest);
+    float* s_dec = rest + C * (64 + 1);
     float (*s_A)[C][C + 1] = reinterpret_cast<float (*)[C][C + 1]>(s_dec + 64);
     int* s_cut_p = reinterpret_cast<int*>(s_dec + 64 + 4 * C * (C + 1));
 #define s_cut (*s_cut_p)
@@ -312,8 +410,16 @@ __device__ __forceinline__ void sweep_qk(
 #pragma unroll
             for (int r = 0; r < C; ++r) {                 // X, Y rows outside the chunk only need to be finite: Z is zeroed
                 const bool in = base + r >= 0 && base + r < T;
-                s_x[r * SX + tid] = in ? xr[r] : 0.0f;
-                s_y[r * SX + tid] = in ? yr[r] : 0.0f;
+                const float xv = in ? xr[r] : 0.0f, yv = in ? yr[r] : 0.0f;
+                if constexpr (kBf) {
+                    const bf16_t yb = f2bf(yv);           // exact: the inputs are bf16
+                    bt.xb[r * SXB + tid] = f2bf(xv);
+                    bt.yb[r * SXB + tid] = yb;
+                    bt.yT[tid * ST + r] = yb;
+                } else {
+                    s_x[r * SX + tid] = xv;
+                    s_y[r * SX + tid] = yv;
+                }
             }
         }
         if (w == 0) {
@@ -342,11 +448,12 @@ __device__ __forceinline__ void sweep_qk(
         {
             const bool valid = (REV ? vr >= cut : vr < cut) && base + vr >= 0 && base + vr < T;
             const float zv[4] = {zr.x, zr.y, zr.z, zr.w};
-            float* d = &s_z[vr * SZ + vc];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float bb = s_b[vr][vc + i];
-                d[i] = valid ? (REV ? zv[i] * scale * __expf(bb) : zv[i] * __expf(-bb)) : 0.0f;
+                const float zs = valid ? (REV ? zv[i] * scale * __expf(bb) : zv[i] * __expf(-bb)) : 0.0f;
+                if constexpr (kBf) bt.zT[(vc + i) * ST + vr] = f2bf(zs);
+                else s_z[vr * SZ + vc + i] = zs;
             }
         }
         const int pos = base + cut;
@@ -361,7 +468,9 @@ __device__ __forceinline__ void sweep_qk(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) R[p][r] *= dcol;
         }
-        const f32x4 acc = chunk_products<DV, REV>(R, s_x, s_y, s_z, s_A, w, li, lg);
+        f32x4 acc;
+        if constexpr (kBf) acc = chunk_products_bf<DV, REV>(R, bt, s_A, w, li, lg);
+        else acc = chunk_products<DV, REV>(R, s_x, s_y, s_z, s_A, w, li, lg);
         if (!REV) {
 #pragma unroll
             for (int p = 0; p < NT; ++p)
@@ -388,7 +497,9 @@ __device__ __forceinline__ void sweep_qk(
 // (b,h) land on the same XCD when B*H is a multiple of 8 and re-use its q/k/v/do lines in that L2)
 constexpr int bwd_smem_floats(int DK, int DV) {
     const int dm = DK > DV ? DK : DV;
-    return 2 * kBC * (dm + 2) + kBC * 80 + kBC * 65 + dm + 4 * kBC * (kBC + 1) + 8;
+    const int f32_tiles = 2 * kBC * (dm + 2) + kBC * 80;
+    const int bf_tiles = (2 * kBC * (dm + 8) + dm * (kBC + 8) + 64 * (kBC + 8)) / 2;
+    return (f32_tiles > bf_tiles ? f32_tiles : bf_tiles) + kBC * 65 + dm + 4 * kBC * (kBC + 1) + 8;
 }
 
 template <int DK, int DV, typename TIO, typename TG>
