@@ -198,10 +198,10 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
             continue;
         }
         // q / k / v columns: conv step on the rolled cache (W = 4) + SiLU
-        const T* wsel; T* csel; int c, D;
-        if (n < Kd) { c = n; D = Kd; wsel = wq; csel = cq; }
-        else if (n < 2 * Kd) { c = n - Kd; D = Kd; wsel = wk; csel = ck; }
-        else { c = n - 2 * Kd; D = Vd; wsel = wv; csel = cv; }
+        T* csel; int c, D;
+        if (n < Kd) { c = n; D = Kd; csel = cq; }
+        else if (n < 2 * Kd) { c = n - Kd; D = Kd; csel = ck; }
+        else { c = n - 2 * Kd; D = Vd; csel = cv; }
         const float4 wj = pre_wj[j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
