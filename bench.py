@@ -117,7 +117,7 @@ def measure_chunk_bwd(dev, B=8, H=4, T=4096, Dk=256, Dv=256, reps=3):
     dt = ev0.elapsed_time(ev1) * 1e-3 / reps
     nbytes = B * H * T * 2 * (5 * Dk + 4 * Dv)
     return {"kernel": "lina::gla_bwd_sweeps_kernel<256,256> + dg scan", "shape": {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv},
-            "dtype": "bf16 I/O, fp32 MFMA", "ms": dt * 1e3, "bound": "hbm", "achieved": nbytes / dt / 1e9,
+            "dtype": "bf16 I/O, bf16 MFMA, fp32 accumulate", "ms": dt * 1e3, "bound": "hbm", "achieved": nbytes / dt / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS}
 
 
