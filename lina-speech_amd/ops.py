@@ -212,6 +212,9 @@ class _GLAFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_o, d_ht):
         q, k, v, gk, h0, ht = ctx.saved_tensors
+        if d_o is None:                                   # only the final state was used downstream
+            d_o = torch.zeros(q.shape[0], q.shape[2], q.shape[1], v.shape[-1], dtype=q.dtype,
+                              device=q.device).transpose(1, 2)
         dq, dk, dv, dg, dh0 = gla_chunk_bwd(q, k, v, gk, d_o, ctx.scale, h0, ht, d_ht, ctx.need_dh0)
         if dh0 is not None and h0 is not None and dh0.dtype != h0.dtype:
             dh0 = dh0.to(h0.dtype)

@@ -146,3 +146,24 @@ def test_dwconv7_ln(emu, C, dtype, ada):
 def test_istft_ola(emu, T, win, hop):
     from kernel_cases import check_istft_ola
     check_istft_ola(DEV, B=2, T=T, win=win, hop=hop)
+
+
+def test_chunk_bwd_through_the_final_state_only(emu):
+    # loss depends on the final state alone: the output gradient arrives as None
+    from kernel_cases import make_gla_inputs, assert_close
+    q, k, v, gk, h0 = make_gla_inputs(1, 1, 20, 64, 64, torch.float32, DEV, seed=8)
+    leaves = [x.detach().clone().requires_grad_(True) for x in (q, k, v, gk)]
+    _, S = O.naive_recurrent_gla(*[x.double() for x in leaves], initial_state=h0.double(), output_final_state=True,
+                                 compute_dtype=torch.float64)
+    S.sum().backward()
+    ref = [torch.zeros_like(x) if x.grad is None else x.grad.clone() for x in leaves]   # q does not reach the state
+    for x in leaves:
+        x.grad = None
+    from lina_speech_amd import ops
+    _, S2 = ops.chunk_gla(*leaves, initial_state=h0, output_final_state=True)
+    S2.sum().backward()
+    for name, x, r in zip(("dq", "dk", "dv", "dg"), leaves, ref):
+        if float(r.abs().max()) == 0.0:
+            assert float(x.grad.abs().max()) < 1e-6, name
+        else:
+            assert_close(x.grad, r, 2e-4, f"K2b {name} (final state only)")
