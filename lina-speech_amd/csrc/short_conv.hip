@@ -11,41 +11,73 @@ namespace lina {
 
 constexpr int kConvTT = 16;  // time steps per thread in the prefill kernel
 
-template <int W, typename T>
+// VEC channels per thread: 1, or 4 (8-byte bf16 / 16-byte fp32 accesses) when D and the strides allow it
+template <int VEC, typename T> struct VecIO;
+template <typename T> struct VecIO<1, T> {
+    static __device__ __forceinline__ void load(const T* p, float (&v)[1]) { v[0] = ld(p); }
+    static __device__ __forceinline__ void store(T* p, const float (&v)[1]) { st(p, v[0]); }
+};
+template <typename T> struct VecIO<4, T> {
+    static __device__ __forceinline__ void load(const T* p, float (&v)[4]) {
+        const float4 f = ld4(p);
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    }
+    static __device__ __forceinline__ void store(T* p, const float (&v)[4]) { st4(p, make_float4(v[0], v[1], v[2], v[3])); }
+};
+
+template <int W, typename T, int VEC>
 __global__ __launch_bounds__(256) void short_conv_fwd_kernel(
     const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias, const float* __restrict__ mask,
     T* cache, T* __restrict__ y, int Tn, int D, int64_t x_sb, int64_t x_st, int64_t y_sb, int64_t y_st, int act) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * VEC;
     const int t0 = blockIdx.y * kConvTT;
     const int b = blockIdx.z;
     if (c >= D) return;
-    float wv[W];
+    float wv[W][VEC], bv[VEC];
 #pragma unroll
-    for (int j = 0; j < W; ++j) wv[j] = ld(w + (int64_t)c * W + j);
-    const float bv = bias ? ld(bias + c) : 0.0f;
+    for (int i = 0; i < VEC; ++i) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) wv[j][i] = ld(w + (int64_t)(c + i) * W + j);
+        bv[i] = bias ? ld(bias + c + i) : 0.0f;
+    }
     const T* xb = x + b * x_sb + c;
     const float* mb = mask ? mask + (int64_t)b * Tn : nullptr;
-    float win[W];  // win[j] = x_{t-(W-1)+j}
-    win[0] = 0.0f;
+    float win[W][VEC];  // win[j] = x_{t-(W-1)+j}
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) win[0][i] = 0.0f;
 #pragma unroll
     for (int j = 0; j < W - 1; ++j) {
         const int tt = t0 - (W - 1) + j;
-        win[j + 1] = (tt >= 0) ? ld(xb + tt * x_st) * (mb ? mb[tt] : 1.0f) : 0.0f;
+        float v[VEC];
+        VecIO<VEC, T>::load(xb + max(tt, 0) * x_st, v);
+        const float m = (tt >= 0) ? (mb ? mb[tt] : 1.0f) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) win[j + 1][i] = v[i] * m;
     }
     const int t1 = min(t0 + kConvTT, Tn);
     for (int t = t0; t < t1; ++t) {
+        float v[VEC], o[VEC];
+        VecIO<VEC, T>::load(xb + t * x_st, v);
+        const float m = mb ? mb[t] : 1.0f;
 #pragma unroll
-        for (int j = 0; j < W - 1; ++j) win[j] = win[j + 1];
-        win[W - 1] = ld(xb + t * x_st) * (mb ? mb[t] : 1.0f);
-        float acc = bv;
+        for (int i = 0; i < VEC; ++i) {
 #pragma unroll
-        for (int j = 0; j < W; ++j) acc = fmaf(wv[j], win[j], acc);
-        st(y + b * y_sb + t * y_st + c, act ? silu(acc) : acc);
+            for (int j = 0; j < W - 1; ++j) win[j][i] = win[j + 1][i];
+            win[W - 1][i] = v[i] * m;
+            float acc = bv[i];
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc = fmaf(wv[j][i], win[j][i], acc);
+            o[i] = act ? silu(acc) : acc;
+        }
+        VecIO<VEC, T>::store(y + b * y_sb + t * y_st + c, o);
     }
     if (cache && t1 == Tn) {  // this thread saw the tail: win holds x_{Tn-W..Tn-1} (zeros left of 0)
-        T* cb = cache + ((int64_t)b * D + c) * W;
 #pragma unroll
-        for (int j = 0; j < W; ++j) st(cb + j, win[j]);
+        for (int i = 0; i < VEC; ++i) {
+            T* cb = cache + ((int64_t)b * D + c + i) * W;
+#pragma unroll
+            for (int j = 0; j < W; ++j) st(cb + j, win[j][i]);
+        }
     }
 }
 
@@ -74,11 +106,16 @@ template <typename T>
 static int conv_fwd_dispatch(const void* x, const void* w, const void* bias, const float* mask, void* cache, void* y,
                              int B, int Tn, int D, int W, int64_t x_sb, int64_t x_st, int64_t y_sb, int64_t y_st,
                              int act, lina_stream_t stream) {
-    dim3 grid((unsigned)((D + 255) / 256), (unsigned)((Tn + kConvTT - 1) / kConvTT), (unsigned)B);
+    const bool vec = D % 4 == 0 && x_sb % 4 == 0 && x_st % 4 == 0 && y_sb % 4 == 0 && y_st % 4 == 0 &&
+                     ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    const int per = vec ? 4 : 1;
+    dim3 grid((unsigned)((D + 256 * per - 1) / (256 * per)), (unsigned)((Tn + kConvTT - 1) / kConvTT), (unsigned)B);
+#define LINA_CONV_LAUNCH(WW, VV)                                                                                    \
+    LINA_LAUNCH((short_conv_fwd_kernel<WW, T, VV>), grid, dim3(256), 0, stream, (const T*)x, (const T*)w,          \
+                (const T*)bias, mask, (T*)cache, (T*)y, Tn, D, x_sb, x_st, y_sb, y_st, act)
 #define LINA_CONV_CASE(WW)                                                                                          \
     case WW:                                                                                                        \
-        LINA_LAUNCH((short_conv_fwd_kernel<WW, T>), grid, dim3(256), 0, stream, (const T*)x, (const T*)w,           \
-                    (const T*)bias, mask, (T*)cache, (T*)y, Tn, D, x_sb, x_st, y_sb, y_st, act);                    \
+        if (vec) LINA_CONV_LAUNCH(WW, 4); else LINA_CONV_LAUNCH(WW, 1);                                             \
         break;
     switch (W) {
         LINA_CONV_CASE(2) LINA_CONV_CASE(3) LINA_CONV_CASE(4) LINA_CONV_CASE(5)
@@ -86,6 +123,7 @@ static int conv_fwd_dispatch(const void* x, const void* w, const void* bias, con
         default: return fail(LINA_ERR_UNSUPPORTED, "lina_short_conv_fwd: W=%d not in 2..8", W);
     }
 #undef LINA_CONV_CASE
+#undef LINA_CONV_LAUNCH
     return check_launch("lina_short_conv_fwd");
 }
 
@@ -145,82 +183,110 @@ namespace lina {
 
 constexpr int kConvBwdTT = LINA_CONV_BWD_TT;
 
-template <int W, typename T>
+template <int W, typename T, int VEC>
 __global__ __launch_bounds__(256) void short_conv_bwd_kernel(
     const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias, const float* __restrict__ mask,
     const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ part, int Tn, int D, int64_t x_sb, int64_t x_st,
     int64_t dy_sb, int64_t dy_st, int64_t dx_sb, int64_t dx_st, int act) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * VEC;
     const int t0 = blockIdx.y * kConvBwdTT;
     const int b = blockIdx.z;
     if (c >= D) return;
-    float wv[W], dw[W], dzw[W];       // dzw[j] = dz_{u-j}
+    float wv[W][VEC], dw[W][VEC], dzw[W][VEC], db[VEC], bv[VEC];   // dzw[j] = dz_{u-j}
 #pragma unroll
-    for (int j = 0; j < W; ++j) {
-        wv[j] = ld(w + (int64_t)c * W + j);
-        dw[j] = 0.0f;
-        dzw[j] = 0.0f;
+    for (int i = 0; i < VEC; ++i) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            wv[j][i] = ld(w + (int64_t)(c + i) * W + j);
+            dw[j][i] = 0.0f;
+            dzw[j][i] = 0.0f;
+        }
+        db[i] = 0.0f;
+        bv[i] = bias ? ld(bias + c + i) : 0.0f;
     }
-    float db = 0.0f;
-    const float bv = bias ? ld(bias + c) : 0.0f;
     const T* xb = x + b * x_sb + c;
     const T* dyb = dy + b * dy_sb + c;
     const float* mb = mask ? mask + (int64_t)b * Tn : nullptr;
-    float win[W];
-    win[0] = 0.0f;
+    float win[W][VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) win[0][i] = 0.0f;
 #pragma unroll
     for (int j = 0; j < W - 1; ++j) {
         const int tt = t0 - (W - 1) + j;
-        win[j + 1] = (tt >= 0) ? ld(xb + tt * x_st) * (mb ? mb[tt] : 1.0f) : 0.0f;
+        float v[VEC];
+        VecIO<VEC, T>::load(xb + max(tt, 0) * x_st, v);
+        const float m = (tt >= 0) ? (mb ? mb[tt] : 1.0f) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) win[j + 1][i] = v[i] * m;
     }
     const int t1 = min(t0 + kConvBwdTT, Tn);
     for (int u = t0; u < t1 + W - 1; ++u) {
-        float dz = 0.0f;
+        float dz[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) dz[i] = 0.0f;
         if (u < Tn) {
+            float xv[VEC], dv[VEC];
+            VecIO<VEC, T>::load(xb + u * x_st, xv);
+            VecIO<VEC, T>::load(dyb + u * dy_st, dv);
+            const float m = mb ? mb[u] : 1.0f;
 #pragma unroll
-            for (int j = 0; j < W - 1; ++j) win[j] = win[j + 1];
-            win[W - 1] = ld(xb + u * x_st) * (mb ? mb[u] : 1.0f);
-            float z = bv;
+            for (int i = 0; i < VEC; ++i) {
 #pragma unroll
-            for (int j = 0; j < W; ++j) z = fmaf(wv[j], win[j], z);
-            dz = ld(dyb + u * dy_st);
-            if (act) {
-                const float sg = sigmoidf(z);
-                dz *= sg * (1.0f + z * (1.0f - sg));
-            }
-            if (u < t1) {
+                for (int j = 0; j < W - 1; ++j) win[j][i] = win[j + 1][i];
+                win[W - 1][i] = xv[i] * m;
+                float z = bv[i];
 #pragma unroll
-                for (int j = 0; j < W; ++j) dw[j] = fmaf(dz, win[j], dw[j]);
-                db += dz;
+                for (int j = 0; j < W; ++j) z = fmaf(wv[j][i], win[j][i], z);
+                float d = dv[i];
+                if (act) {
+                    const float sg = sigmoidf(z);
+                    d *= sg * (1.0f + z * (1.0f - sg));
+                }
+                dz[i] = d;
+                if (u < t1) {
+#pragma unroll
+                    for (int j = 0; j < W; ++j) dw[j][i] = fmaf(d, win[j][i], dw[j][i]);
+                    db[i] += d;
+                }
             }
         }
-#pragma unroll
-        for (int j = W - 1; j > 0; --j) dzw[j] = dzw[j - 1];
-        dzw[0] = dz;
         const int t = u - (W - 1);
-        if (t >= t0) {
-            float a = 0.0f;
+        float a[VEC];
 #pragma unroll
-            for (int j = 0; j < W; ++j) a = fmaf(wv[j], dzw[j], a);
-            st(dx + b * dx_sb + t * dx_st + c, a * (mb ? mb[t] : 1.0f));
+        for (int i = 0; i < VEC; ++i) {
+#pragma unroll
+            for (int j = W - 1; j > 0; --j) dzw[j][i] = dzw[j - 1][i];
+            dzw[0][i] = dz[i];
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc = fmaf(wv[j][i], dzw[j][i], acc);
+            a[i] = acc * ((mb && t >= 0) ? mb[t] : 1.0f);
         }
+        if (t >= t0) VecIO<VEC, T>::store(dx + b * dx_sb + t * dx_st + c, a);
     }
-    float* pp = part + (((int64_t)b * gridDim.y + blockIdx.y) * D + c) * (W + 1);
 #pragma unroll
-    for (int j = 0; j < W; ++j) pp[j] = dw[j];
-    pp[W] = db;
+    for (int i = 0; i < VEC; ++i) {
+        float* pp = part + (((int64_t)b * gridDim.y + blockIdx.y) * D + c + i) * (W + 1);
+#pragma unroll
+        for (int j = 0; j < W; ++j) pp[j] = dw[j][i];
+        pp[W] = db[i];
+    }
 }
 
 template <typename T>
 static int conv_bwd_dispatch(const void* x, const void* w, const void* bias, const float* mask, const void* dy,
                              void* dx, float* part, int B, int Tn, int D, int W, int64_t x_sb, int64_t x_st,
                              int64_t dy_sb, int64_t dy_st, int64_t dx_sb, int64_t dx_st, int act, lina_stream_t stream) {
-    dim3 grid((unsigned)((D + 255) / 256), (unsigned)((Tn + kConvBwdTT - 1) / kConvBwdTT), (unsigned)B);
+    const bool vec = D % 4 == 0 && x_sb % 4 == 0 && x_st % 4 == 0 && dy_sb % 4 == 0 && dy_st % 4 == 0 && dx_sb % 4 == 0 &&
+                     dx_st % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0);
+    const int per = vec ? 4 : 1;
+    dim3 grid((unsigned)((D + 256 * per - 1) / (256 * per)), (unsigned)((Tn + kConvBwdTT - 1) / kConvBwdTT), (unsigned)B);
+#define LINA_CONV_LAUNCH(WW, VV)                                                                                    \
+    LINA_LAUNCH((short_conv_bwd_kernel<WW, T, VV>), grid, dim3(256), 0, stream, (const T*)x, (const T*)w,          \
+                (const T*)bias, mask, (const T*)dy, (T*)dx, part, Tn, D, x_sb, x_st, dy_sb, dy_st, dx_sb, dx_st, act)
 #define LINA_CONV_CASE(WW)                                                                                          \
     case WW:                                                                                                        \
-        LINA_LAUNCH((short_conv_bwd_kernel<WW, T>), grid, dim3(256), 0, stream, (const T*)x, (const T*)w,           \
-                    (const T*)bias, mask, (const T*)dy, (T*)dx, part, Tn, D, x_sb, x_st, dy_sb, dy_st, dx_sb,        \
-                    dx_st, act);                                                                                    \
+        if (vec) LINA_CONV_LAUNCH(WW, 4); else LINA_CONV_LAUNCH(WW, 1);                                             \
         break;
     switch (W) {
         LINA_CONV_CASE(2) LINA_CONV_CASE(3) LINA_CONV_CASE(4) LINA_CONV_CASE(5)
@@ -228,6 +294,7 @@ static int conv_bwd_dispatch(const void* x, const void* w, const void* bias, con
         default: return fail(LINA_ERR_UNSUPPORTED, "lina_short_conv_bwd: W=%d not in 2..8", W);
     }
 #undef LINA_CONV_CASE
+#undef LINA_CONV_LAUNCH
     return check_launch("lina_short_conv_bwd");
 }
 
