@@ -18,7 +18,7 @@
 //      operands whose K dimension is the token axis) conflict-free.
 //   B  wave w owns state columns [16w, 16w+16), tiles p = rows [16p,16p+16) in C/D layout
 //      (col = lane&15, row = 4*(lane>>4)+reg):  (2) A^T = k~ . q~^T (32 x 32 as 2x2 tiles) once per workgroup
-//      (each wave: one tile, one K quarter; partials reduced through LDS into ready-made A operands);
+//      (waves 0..3: one whole tile each, stored masked straight into the A-operand layout of step (3));
 //      (1) o = q~ . S with the state tiles consumed DIRECTLY as the B operand (the A operand uses the matching
 //      k-slot -> channel map); (3) o += mask(A) . v with A^T's registers re-used as the A operand;
 //      (4) S += k~^T . v, rows scaled by e^{b_last}.  36 x v_mfma_f32_16x16x32_bf16 per wave per chunk.
@@ -61,7 +61,13 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     __shared__ __attribute__((aligned(16))) bf16_t s_A[2 * 64 * 8];     // mask(A) as ready-made A operands [nt][lane][8]
     __shared__ __attribute__((aligned(16))) bf16_t s_kT[DK * ST];
     __shared__ __attribute__((aligned(16))) bf16_t s_vT[DV * ST];
-    __shared__ __attribute__((aligned(16))) bf16_t s_raw[4][C * DK];     // next chunk's q,k,g,v, filled by DMA
+    // next chunk's q, k, g, v, filled by DMA.  FOUR SEPARATE objects: an LDS read that may alias a pending LDS-DMA
+    // destination makes the compiler wait for vmcnt(0); with one array the transposition pass's reads of the current v
+    // tile waited for the q,k,g prefetch issued just before them, i.e. the HBM latency was exposed in every chunk
+    __shared__ __attribute__((aligned(16))) bf16_t s_rq[C * DK];
+    __shared__ __attribute__((aligned(16))) bf16_t s_rk[C * DK];
+    __shared__ __attribute__((aligned(16))) bf16_t s_rg[C * DK];
+    __shared__ __attribute__((aligned(16))) bf16_t s_rv[C * DK];
     __shared__ __attribute__((aligned(16))) float s_ot[C * SQ / 2];      // gate-scan totals, later the o tile
     __shared__ __attribute__((aligned(16))) float s_dec[DK];
     __shared__ int s_flag, s_nw[16];
@@ -69,6 +75,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     bf16_t* s_o = reinterpret_cast<bf16_t*>(s_ot);        // [C][SQ] bf16    (phase B)
 
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int w_s = wave_uniform(w);                         // wave index in an SGPR for the whole kernel
     int li = lane & 15, lg = lane >> 4;
     int co = tid & 63, rg = tid >> 6;
     const int slot = blockIdx.x;                             // state slot: (b*H + h) * nseg + segment
@@ -100,14 +107,15 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 #pragma unroll
         for (int a = a_lo; a < a_hi; ++a) {
             const unsigned t = (unsigned)min(t_first + 2 * w + (lane >> 5), T - 1);
-            dma16_to_lds(gsrc[a] + (t * gst[a] + 8u * (unsigned)(lane & 31)), &s_raw[a][(2 * w) * DK]);   // uniform base + 32-bit lane offset
+            bf16_t* dst = a == 0 ? s_rq : a == 1 ? s_rk : a == 2 ? s_rg : s_rv;                     // a is a compile-time index
+            dma16_to_lds(gsrc[a] + (t * gst[a] + 8u * (unsigned)(lane & 31)), &dst[(2 * w) * DK]);   // uniform base + 32-bit lane offset
         }
     };
     // this thread's 2 rows x 4 channels of clamped gates, summed down the 2 rows (rows >= nrem count as 0)
     auto local_gates = [&](float (&bc)[2][4], int nrem) {
         float g0[4], g1[4];
-        unpack4(*reinterpret_cast<const uint2*>(&s_raw[2][(2 * rg) * DK + 4 * co]), g0);
-        unpack4(*reinterpret_cast<const uint2*>(&s_raw[2][(2 * rg + 1) * DK + 4 * co]), g1);
+        unpack4(*reinterpret_cast<const uint2*>(&s_rg[(2 * rg) * DK + 4 * co]), g0);
+        unpack4(*reinterpret_cast<const uint2*>(&s_rg[(2 * rg + 1) * DK + 4 * co]), g1);
         const bool in0 = 2 * rg < nrem, in1 = 2 * rg + 1 < nrem;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -144,12 +152,12 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             for (int c = 0; c < 4; ++c) e[c] = __expf(bc[rr][c]);
             uint2 pq, pk;
             if constexpr (!STATE_ONLY) {
-                unpack4(*reinterpret_cast<const uint2*>(&s_raw[0][row * DK + 4 * co]), f);
+                unpack4(*reinterpret_cast<const uint2*>(&s_rq[row * DK + 4 * co]), f);
                 pq.x = pack_bf16x2(valid ? f[0] * scale * e[0] : 0.0f, valid ? f[1] * scale * e[1] : 0.0f);
                 pq.y = pack_bf16x2(valid ? f[2] * scale * e[2] : 0.0f, valid ? f[3] * scale * e[3] : 0.0f);
                 *reinterpret_cast<uint2*>(&s_q[row * SQ + 4 * co]) = pq;
             }
-            unpack4(*reinterpret_cast<const uint2*>(&s_raw[1][row * DK + 4 * co]), f);
+            unpack4(*reinterpret_cast<const uint2*>(&s_rk[row * DK + 4 * co]), f);
             pk.x = pack_bf16x2(valid ? __fdividef(f[0], e[0]) : 0.0f, valid ? __fdividef(f[1], e[1]) : 0.0f);
             pk.y = pack_bf16x2(valid ? __fdividef(f[2], e[2]) : 0.0f, valid ? __fdividef(f[3], e[3]) : 0.0f);
             *reinterpret_cast<uint2*>(&s_k[row * SK + 4 * co]) = pk;
@@ -163,8 +171,11 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     while (t0 < T) {
         // keep the per-lane index arithmetic INSIDE the loop: hoisted, it would live in (and spill from) VGPRs
         // (only tid is carried across iterations; everything else is re-derived from it)
-        opaque(tid);
-        lane = tid & 63; w = tid >> 6; li = lane & 15; lg = lane >> 4; co = lane; rg = w;
+        // (the wave index sits in an SGPR, the lane index comes from v_mbcnt: nothing per-lane is carried -- a spilled
+        //  tid would be reloaded through vmcnt, the counter the in-flight DMA also uses, and stall on it)
+        lane = lane_id();
+        opaque(lane);
+        w = w_s; tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; co = lane; rg = w;
         const int nrem = T - t0;
         int n = min(C, nrem);
         // ---------------- phase A: gate scan, scaled operands ----------------
@@ -178,6 +189,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             write_tiles(bc, n);
         }
         __syncthreads();   // (2) row-major operand tiles ready; raw q,k,g consumed
+        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; co = lane;   // re-derive, do not carry
         if (s_flag) {
             // ---- rare: the decay inside this chunk exceeds e^-60 -> cut the chunk at the first such row ----
             float bc[2][4];                 // recomputed (s_tot is intact until the o tile is staged)
@@ -221,8 +233,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ra = r0 + 2 * j, rb = ra + 1;
-                const unsigned va = ra < n ? (unsigned)s_raw[3][ra * DK + ch] : 0u;
-                const unsigned vb_ = rb < n ? (unsigned)s_raw[3][rb * DK + ch] : 0u;
+                const unsigned va = ra < n ? (unsigned)s_rv[ra * DK + ch] : 0u;
+                const unsigned vb_ = rb < n ? (unsigned)s_rv[rb * DK + ch] : 0u;
                 w4[j] = va | (vb_ << 16);
             }
             *reinterpret_cast<uint4*>(&s_vT[ch * ST + r0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
@@ -233,18 +245,24 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (!STATE_ONLY) {
-            {
-                // (2) A^T[s][t] = k~_s . q~_t, computed ONCE per workgroup: wave w takes tile (mt = w&1: s block,
-                //     nt = (w>>1)&1: t block) and the K quarter w>>2 (2 MFMAs); the 4 partials per tile are summed
-                //     through LDS (s_tot's space, dead by now) in step (2c) below
-                const int mt = w & 1, nt = (w >> 1) & 1, kq = w >> 2;
+            if (w < 4) {
+                // (2) A^T[s][t] = k~_s . q~_t, computed ONCE per workgroup by waves 0..3: wave w takes the whole 16 x 16
+                //     tile (mt = w&1: s block, nt = w>>1: t block), 8 MFMAs over the 256 channels.  Its C/D layout
+                //     (col t = li, rows s = 4lg + r) is exactly where step (3)'s A operand wants the values: lane
+                //     (li = t&15, lg) slot j of tile nt holds A[t][s] with s = 4lg + j (s block 0) or 16 + 4lg + (j-4)
+                //     (s block 1) -- so each lane masks (s <= t) and stores its 4 values as one 8-byte piece.
+                const int mt = w & 1, nt = w >> 1;
                 f32x4 at = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int cc = 64 * kq + 32 * ks + 8 * lg;
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int cc = 32 * ks + 8 * lg;
                     at = mfma_bf16_16x16x32(frag16(&s_k[(16 * mt + li) * SK + cc]), frag16(&s_q[(16 * nt + li) * SQ + cc]), at);
                 }
-                *reinterpret_cast<float4*>(&s_tot[(w * 64 + lane) * 4]) = make_float4(at[0], at[1], at[2], at[3]);
+                const int t = 16 * nt + li, sb = 16 * mt + 4 * lg;
+                uint2 pa;
+                pa.x = pack_bf16x2(sb <= t ? at[0] : 0.0f, sb + 1 <= t ? at[1] : 0.0f);
+                pa.y = pack_bf16x2(sb + 2 <= t ? at[2] : 0.0f, sb + 3 <= t ? at[3] : 0.0f);
+                *reinterpret_cast<uint2*>(&s_A[(nt * 64 + lane) * 8 + 4 * mt]) = pa;
             }
             // (1) o = q~ . S_old : one K = 32 MFMA per pair of 16-row state tiles (converted to bf16 in registers)
 #pragma unroll
@@ -262,23 +280,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 }
             }
         }
-        __syncthreads();   // (2b) k~^T / v^T and the A^T partials complete; raw v consumed
+        __syncthreads();   // (2b) k~^T / v^T and mask(A) complete; raw v consumed
+        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; co = lane;   // re-derive, do not carry
         if (t0 + n < T) dma_chunk(t0 + n, 3, 4);
         if constexpr (!STATE_ONLY) {
-            // (2c) thread (tile = tid>>8 ... ) sums the 4 K-quarter partials of ONE A^T element, masks it (s <= t) and
-            //      stores it as bf16 where step (3)'s A operand expects it: lane (li = t&15, lg) slot j of tile nt
-            //      holds A[t][s] with s = 4lg + j (j < 4, s block 0) or 16 + 4lg + (j-4) (s block 1)
-            {
-                const int e = tid & 255, tile = tid >> 8;       // element (lane_e = e>>2, reg = e&3) of tile (mt,nt)
-                const int mt = tile & 1, nt = tile >> 1, le = e >> 2, r = e & 3;
-                float a = 0.0f;
-#pragma unroll
-                for (int kq = 0; kq < 4; ++kq) a += s_tot[((4 * kq + tile) * 64 + le) * 4 + r];
-                const int tl = le & 15, sg4 = le >> 4;           // D layout of the partial: col t = tl, row s = 4sg4 + r
-                const int t = 16 * nt + tl, srow = 16 * mt + 4 * sg4 + r;
-                s_A[(nt * 64 + sg4 * 16 + tl) * 8 + 4 * mt + r] = f2bf(srow <= t ? a : 0.0f);
-            }
-            __syncthreads();   // (2d) A ready
             // (3) o += mask(A) . v ; v fragments in the same token order as the C/D rows
             {
                 const bf16_t* vp = &s_vT[(16 * w + li) * ST + 4 * lg];
@@ -303,6 +308,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             }
         }
         __syncthreads();   // (3) o tile complete, operand tiles dead, next chunk's DMA landed
+        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; co = lane;   // re-derive, do not carry
         if constexpr (!STATE_ONLY) {
             {
                 const int row = tid >> 5, piece = tid & 31;    // 32 lanes x 16 B = one 512-byte output row

@@ -93,6 +93,11 @@ __device__ __forceinline__ int ticket_agent(int* counter) {
     return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// lane index from the hardware (v_mbcnt: no register has to stay live for it) and a wave-uniform value moved to an
+// SGPR: together they let a kernel re-derive threadIdx.x anywhere instead of carrying it in (or spilling it from) a VGPR
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // compiler-only fence: memory operations are not moved across it (keeps LDS-read hoisting, and with it
 // register pressure, bounded in the fully unrolled MFMA loops)
 __device__ __forceinline__ void cfence() { asm volatile("" ::: "memory"); }
