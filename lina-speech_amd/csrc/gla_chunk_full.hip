@@ -108,7 +108,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         for (int a = a_lo; a < a_hi; ++a) {
             const unsigned t = (unsigned)min(t_first + 2 * w + (lane >> 5), T - 1);
             bf16_t* dst = a == 0 ? s_rq : a == 1 ? s_rk : a == 2 ? s_rg : s_rv;                     // a is a compile-time index
-            dma16_to_lds(gsrc[a] + (t * gst[a] + 8u * (unsigned)(lane & 31)), &dst[(2 * w) * DK]);   // uniform base + 32-bit lane offset
+            // uniform base + 32-bit BYTE offset per lane (< 2^32: launcher guard): selects the SGPR-base addressing form,
+            // no 64-bit per-lane address arithmetic (whose zero high word the compiler kept in -- and spilled from -- a VGPR)
+            const unsigned boff = 2u * (t * gst[a] + 8u * (unsigned)(lane & 31));
+            dma16_to_lds_async(gsrc[a], boff, &dst[(2 * w) * DK]);
         }
     };
     // this thread's 2 rows x 4 channels of clamped gates, summed down the 2 rows (rows >= nrem count as 0)
@@ -166,7 +169,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     };
 
     dma_chunk(0, STATE_ONLY ? 1 : 0, 4);
-    __syncthreads();   // DMA of chunk 0 landed (hipcc drains vmcnt before the barrier)
+    wait_vmem();
+    __syncthreads();   // DMA of chunk 0 landed
     int t0 = 0;
     while (t0 < T) {
         // keep the per-lane index arithmetic INSIDE the loop: hoisted, it would live in (and spill from) VGPRs
@@ -280,7 +284,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 }
             }
         }
-        __syncthreads();   // (2b) k~^T / v^T and mask(A) complete; raw v consumed
+        lds_barrier();     // (2b) k~^T / v^T and mask(A) complete; raw v consumed.  LDS-only barrier: the q,k,g prefetch
+                           // issued after (2) stays in flight until the full barrier (3)
         lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; co = lane;   // re-derive, do not carry
         if (t0 + n < T) dma_chunk(t0 + n, 3, 4);
         if constexpr (!STATE_ONLY) {
@@ -307,7 +312,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 S[p][0] *= d.x; S[p][1] *= d.y; S[p][2] *= d.z; S[p][3] *= d.w;
             }
         }
-        __syncthreads();   // (3) o tile complete, operand tiles dead, next chunk's DMA landed
+        wait_vmem();       // the prefetch was issued through inline assembly: this wave's part has landed ...
+        __syncthreads();   // (3) ... and so has everybody's; o tile complete, operand tiles dead
         lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; co = lane;   // re-derive, do not carry
         if constexpr (!STATE_ONLY) {
             {

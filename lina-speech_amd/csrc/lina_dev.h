@@ -63,6 +63,20 @@ __device__ __forceinline__ void dma16_to_lds(const void* gsrc_lane, void* lds_wa
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same copy issued through inline assembly, addressed as (wave-uniform 64-bit base) + (32-bit byte offset per
+// lane).  The compiler does not see an LDS-DMA, so it does NOT make later LDS reads or barriers wait for it (with the
+// builtin every LDS read it cannot disambiguate drains vmcnt, i.e. stalls on the prefetch).  The CALLER owns the
+// ordering: wait_vmem() + a workgroup barrier before anyone reads the destination.
+__device__ __forceinline__ void dma16_to_lds_async(const void* base_uniform, unsigned lane_byte_off, void* lds_wave_base) {
+    const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :
+                 : "s"(lds), "v"(lane_byte_off), "s"(base_uniform)
+                 : "memory", "m0");
+}
+__device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // reinterpret 16 bytes of packed bf16 as an MFMA operand (no instructions)
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 u) { return __builtin_bit_cast(bf16x8, u); }
 __device__ __forceinline__ bf16x8 as_bf16x8(uint2 lo, uint2 hi) {
@@ -97,6 +111,11 @@ __device__ __forceinline__ int ticket_agent(int* counter) {
 // SGPR: together they let a kernel re-derive threadIdx.x anywhere instead of carrying it in (or spilling it from) a VGPR
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Workgroup barrier that orders LDS traffic only (ds_* via lgkmcnt) and leaves global / LDS-DMA operations in flight:
+// __syncthreads() also drains vmcnt, i.e. it would wait for an asynchronous global->LDS prefetch that nobody reads yet.
+// Use it only where no wave touches the DMA destination before the next full __syncthreads().
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // compiler-only fence: memory operations are not moved across it (keeps LDS-read hoisting, and with it
 // register pressure, bounded in the fully unrolled MFMA loops)

@@ -221,6 +221,11 @@ static inline void dma16_to_lds(const void* gsrc_lane, void* lds_wave_base) {
     memcpy((unsigned char*)lds_wave_base + 16 * lina_emu::cur_lane(), gsrc_lane, 16);
 }
 
+static inline void dma16_to_lds_async(const void* base_uniform, unsigned lane_byte_off, void* lds_wave_base) {
+    memcpy((unsigned char*)lds_wave_base + 16 * lina_emu::cur_lane(), (const unsigned char*)base_uniform + lane_byte_off, 16);
+}
+static inline void wait_vmem() {}
+
 static inline bf16x8 as_bf16x8(uint4 u) { bf16x8 r; memcpy(&r, &u, 16); return r; }
 static inline bf16x8 as_bf16x8(uint2 lo, uint2 hi) { bf16x8 r; memcpy(&r.v[0], &lo, 8); memcpy(&r.v[4], &hi, 8); return r; }
 
@@ -234,6 +239,7 @@ static inline float2 ld_agent8(const float* p) { return make_float2(p[0], p[1]);
 static inline void drain_stores() {}
 static inline int ticket_agent(int* counter) { return (*counter)++; }
 
+static inline void lds_barrier() { lina_emu::syncthreads(); }
 static inline int lane_id() { return lina_emu::cur_lane(); }
 static inline int wave_uniform(int v) { return v; }
 
