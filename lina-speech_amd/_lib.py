@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblina_gla.so")
+LIB_PATH = os.environ.get("LINA_GLA_LIB") or os.path.join(_HERE, "csrc", "liblina_gla.so")   # override: perf-analysis builds
 
 LINA_F32, LINA_BF16 = 0, 1
 CONV_BWD_TT = 64          # LINA_CONV_BWD_TT in include/lina_gla.h

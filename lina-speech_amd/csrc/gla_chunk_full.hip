@@ -26,6 +26,10 @@
 #include <lina_dev.h>
 #include "lina_common.h"
 
+#ifndef LINA_K2_ABL
+#define LINA_K2_ABL 0   // tools/k2_ablate.sh builds timing-only variants that skip one phase (results are WRONG there)
+#endif
+
 namespace lina {
 
 constexpr int kFullC = 32;
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     __shared__ __attribute__((aligned(16))) bf16_t s_rg[C * DK];
     __shared__ __attribute__((aligned(16))) bf16_t s_rv[C * DK];
     __shared__ __attribute__((aligned(16))) float s_ot[C * SQ / 2];      // gate-scan totals, later the o tile
-    __shared__ __attribute__((aligned(16))) float s_dec[DK];
+    __shared__ __attribute__((aligned(16))) float s_dec2[2][DK];   // e^{b_last} of the current / previous chunk (parity)
     __shared__ int s_flag, s_nw[16];
     float* s_tot = s_ot;                                  // [16][DK] fp32   (phase A)
     bf16_t* s_o = reinterpret_cast<bf16_t*>(s_ot);        // [C][SQ] bf16    (phase B)
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     auto add_prefix = [&](float (&bc)[2][4]) {
         float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
-        for (int r = 0; r < rg; ++r) {                      // rg is wave-uniform (= wave index)
+        for (int r = 0; r < (LINA_K2_ABL == 1 ? 0 : rg); ++r) {   // rg is wave-uniform (= wave index)
             const float4 x = *reinterpret_cast<const float4*>(&s_tot[r * DK + 4 * co]);
             pre.x += x.x; pre.y += x.y; pre.z += x.z; pre.w += x.w;
         }
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         return viol;
     };
     // rows >= nv are zeroed; the thread that owns row nv-1 publishes exp(b_last)
+    float* s_dec = s_dec2[0];                                 // current chunk's buffer; the other one holds the PENDING decay
     auto write_tiles = [&](const float (&bc)[2][4], int nv) {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             const bool valid = row < nv;
             float f[4], e[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) e[c] = __expf(bc[rr][c]);
+            for (int c = 0; c < 4; ++c) e[c] = LINA_K2_ABL == 6 ? 1.0f + bc[rr][c] : __expf(bc[rr][c]);
             uint2 pq, pk;
             if constexpr (!STATE_ONLY) {
                 unpack4(*reinterpret_cast<const uint2*>(&s_rq[row * DK + 4 * co]), f);
@@ -168,6 +173,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         }
     };
 
+    for (int c = tid; c < DK; c += 1024) s_dec2[1][c] = 1.0f;   // nothing pending before the first chunk
+    int par = 0;
     dma_chunk(0, STATE_ONLY ? 1 : 0, 4);
     wait_vmem();
     __syncthreads();   // DMA of chunk 0 landed
@@ -180,6 +187,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         lane = lane_id();
         opaque(lane);
         w = w_s; tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; co = lane; rg = w;
+        s_dec = s_dec2[par];
+        const float* s_dprev = s_dec2[par ^ 1];                // decay of the previous chunk, not yet applied to S (full kernel)
         const int nrem = T - t0;
         int n = min(C, nrem);
         // ---------------- phase A: gate scan, scaled operands ----------------
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         // ---------------- transposed operands: k~^T[c][t], v^T[col][t] ----------------
         // thread (ch = tid & 255, qr = tid >> 8) gathers 8 tokens of one channel/column (2-byte LDS reads, lanes
         // along ch: conflict-free) and writes them as one 16-byte piece (row stride 80 B: conflict-free)
-        {
+        if (LINA_K2_ABL != 2) {
             const int ch = tid & 255, r0 = 8 * (tid >> 8);
             unsigned w4[4];
 #pragma unroll
@@ -270,7 +279,15 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             }
             // (1) o = q~ . S_old : one K = 32 MFMA per pair of 16-row state tiles (converted to bf16 in registers)
 #pragma unroll
-            for (int pp = 0; pp < 8; ++pp) {
+            for (int pp = 0; pp < (LINA_K2_ABL == 3 ? 0 : 8); ++pp) {
+                // the previous chunk's row decay is applied HERE, where every state element is touched anyway for the
+                // bf16 copy (a separate pass after the update MFMAs waited on them and cost 21 % of the kernel)
+                {
+                    const float4 d0 = *reinterpret_cast<const float4*>(&s_dprev[32 * pp + 4 * lg]);
+                    const float4 d1 = *reinterpret_cast<const float4*>(&s_dprev[32 * pp + 16 + 4 * lg]);
+                    S[2 * pp][0] *= d0.x; S[2 * pp][1] *= d0.y; S[2 * pp][2] *= d0.z; S[2 * pp][3] *= d0.w;
+                    S[2 * pp + 1][0] *= d1.x; S[2 * pp + 1][1] *= d1.y; S[2 * pp + 1][2] *= d1.z; S[2 * pp + 1][3] *= d1.w;
+                }
                 bf16x8 bb;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -306,10 +323,12 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         {
             const bf16x8 vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
+            for (int p = 0; p < (LINA_K2_ABL == 4 ? 0 : 16); ++p) {
                 S[p] = mfma_bf16_16x16x32(frag16(&s_kT[(16 * p + li) * ST + 8 * lg]), vb2, S[p]);
-                const float4 d = *reinterpret_cast<const float4*>(&s_dec[16 * p + 4 * lg]);
-                S[p][0] *= d.x; S[p][1] *= d.y; S[p][2] *= d.z; S[p][3] *= d.w;
+                if constexpr (STATE_ONLY) {              // no q~.S pass there: decay applied right away
+                    const float4 d = *reinterpret_cast<const float4*>(&s_dec[16 * p + 4 * lg]);
+                    S[p][0] *= d.x; S[p][1] *= d.y; S[p][2] *= d.z; S[p][3] *= d.w;
+                }
             }
         }
         wait_vmem();       // the prefetch was issued through inline assembly: this wave's part has landed ...
@@ -318,18 +337,30 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         if constexpr (!STATE_ONLY) {
             {
                 const int row = tid >> 5, piece = tid & 31;    // 32 lanes x 16 B = one 512-byte output row
-                if (row < n)
-                    *reinterpret_cast<uint4*>(ob + ((unsigned)(t0 + row) * (unsigned)so.t + 8u * (unsigned)piece)) =
+                if (row < n && LINA_K2_ABL != 7) {   // uniform base + 32-bit byte offset (SGPR-base addressing, as for the DMA)
+                    const unsigned boff = 2u * ((unsigned)(t0 + row) * (unsigned)so.t + 8u * (unsigned)piece);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(ob) + boff) =
                         *reinterpret_cast<const uint4*>(&s_o[row * SQ + 8 * piece]);
+                }
             }
-            __syncthreads();   // (4) s_o (aliases the scan totals) has been read
+            lds_barrier();     // (4) s_o (aliases the scan totals) has been read.  LDS-only: a full barrier would wait for
+                               // the o stores just issued (a whole HBM write round trip per chunk, 19 % of the kernel)
         }
         t0 += n;
+        par ^= 1;
     }
 
     if (STATE_ONLY && dec_out && w == 0)
         *reinterpret_cast<float4*>(dec_out + (int64_t)slot * DK + 4 * lane) = decp;
     if (ht) {
+        if constexpr (!STATE_ONLY) {                         // the last chunk's decay is still pending
+            const float* dl = s_dec2[par ^ 1];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const float4 d = *reinterpret_cast<const float4*>(&dl[16 * p + 4 * lg]);
+                S[p][0] *= d.x; S[p][1] *= d.y; S[p][2] *= d.z; S[p][3] *= d.w;
+            }
+        }
         float* hp = ht + ((int64_t)slot * DK + 4 * lg) * DV + 16 * w + li;
 #pragma unroll
         for (int p = 0; p < 16; ++p)
