@@ -254,7 +254,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         }
 
         // ---------------- phase B ----------------
-        f32x4 acc[2];            // o for tokens [16nt, 16nt+16) x this wave's 16 columns
+        f32x4 acc[2];            // o^T: this wave's 16 columns (rows 4lg + r) x tokens [16nt, 16nt+16) (column li)
         acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (!STATE_ONLY) {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const bf16_t* qp = &s_q[(16 * nt + li) * SQ + 32 * pp + 4 * lg];
-                    acc[nt] = mfma_bf16_16x16x32(frag8x2(qp, qp + 16), bb, acc[nt]);
+                    acc[nt] = mfma_bf16_16x16x32(bb, frag8x2(qp, qp + 16), acc[nt]);   // o^T: rows = state columns, cols = tokens
                 }
             }
         }
@@ -310,14 +310,18 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             {
                 const bf16_t* vp = &s_vT[(16 * w + li) * ST + 4 * lg];
                 const bf16x8 vb = frag8x2(vp, vp + 16);
-                acc[0] = mfma_bf16_16x16x32(frag16(&s_A[(0 * 64 + lane) * 8]), vb, acc[0]);
-                acc[1] = mfma_bf16_16x16x32(frag16(&s_A[(1 * 64 + lane) * 8]), vb, acc[1]);
+                acc[0] = mfma_bf16_16x16x32(vb, frag16(&s_A[(0 * 64 + lane) * 8]), acc[0]);   // o^T += v^T . mask(A)^T
+                acc[1] = mfma_bf16_16x16x32(vb, frag16(&s_A[(1 * 64 + lane) * 8]), acc[1]);
             }
-            // stage o (this wave's 32 x 16 block)
+            // stage o (this wave's 32 x 16 block).  The products above are taken TRANSPOSED (state / v as the A operand),
+            // so a lane holds 4 consecutive columns of ONE token: one 8-byte LDS write per tile instead of four 2-byte ones
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s_o[(16 * nt + 4 * lg + r) * SQ + 16 * w + li] = f2bf(acc[nt][r]);
+            for (int nt = 0; nt < (LINA_K2_ABL == 8 ? 0 : 2); ++nt) {
+                uint2 po;
+                po.x = pack_bf16x2(acc[nt][0], acc[nt][1]);
+                po.y = pack_bf16x2(acc[nt][2], acc[nt][3]);
+                *reinterpret_cast<uint2*>(&s_o[(16 * nt + li) * SQ + 16 * w + 4 * lg]) = po;
+            }
         }
         // (4) S <- e^{b_last} (S + k~^T v)
         {
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         if constexpr (!STATE_ONLY) {
             {
                 const int row = tid >> 5, piece = tid & 31;    // 32 lanes x 16 B = one 512-byte output row
-                if (row < n && LINA_K2_ABL != 7) {   // uniform base + 32-bit byte offset (SGPR-base addressing, as for the DMA)
+                if (row < n && LINA_K2_ABL != 7 && LINA_K2_ABL != 8) {   // uniform base + 32-bit byte offset (SGPR-base addressing, as for the DMA)
                     const unsigned boff = 2u * ((unsigned)(t0 + row) * (unsigned)so.t + 8u * (unsigned)piece);
                     *reinterpret_cast<uint4*>(reinterpret_cast<char*>(ob) + boff) =
                         *reinterpret_cast<const uint4*>(&s_o[row * SQ + 8 * piece]);
