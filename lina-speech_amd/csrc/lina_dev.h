@@ -117,6 +117,9 @@ __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_rea
 // Use it only where no wave touches the DMA destination before the next full __syncthreads().
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// 1/x as one v_rcp_f32 (1 ulp)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // compiler-only fence: memory operations are not moved across it (keeps LDS-read hoisting, and with it
 // register pressure, bounded in the fully unrolled MFMA loops)
 __device__ __forceinline__ void cfence() { asm volatile("" ::: "memory"); }

@@ -243,6 +243,7 @@ static inline void lds_barrier() { lina_emu::syncthreads(); }
 static inline int lane_id() { return lina_emu::cur_lane(); }
 static inline int wave_uniform(int v) { return v; }
 
+static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void cfence() { asm volatile("" ::: "memory"); }
 
 static inline void opaque(int& x) { asm volatile("" : "+r"(x)); }
