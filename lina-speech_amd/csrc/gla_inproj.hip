@@ -151,8 +151,9 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
         const int row = 16 * w + 4 * lg + r;
         const float a = (s_st[0][row][0] + s_st[1][row][0]) + (s_st[2][row][0] + s_st[3][row][0]);
         const float b = (s_st[0][row][1] + s_st[1][row][1]) + (s_st[2][row][1] + s_st[3][row][1]);
-        mu[r] = a / (float)K;
-        rstd[r] = rsqrtf(fmaxf(b / (float)K - mu[r] * mu[r], 0.f) + ln_eps);
+        const float inv_k = fast_rcp((float)K);
+        mu[r] = a * inv_k;
+        rstd[r] = rsqrtf(fmaxf(b * inv_k - mu[r] * mu[r], 0.f) + ln_eps);
     }
 
     if (gate_wg) {

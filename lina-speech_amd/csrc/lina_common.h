@@ -53,8 +53,10 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     *reinterpret_cast<uint2*>(p) = u;
 }
 
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// sigmoid via v_exp_f32 + v_rcp_f32 (1 ulp): a `/` here expands to the ~10-instruction IEEE division sequence, which
+// made the per-element epilogues (short conv, norm-gate, SwiGLU) VALU-bound
+__device__ __forceinline__ float sigmoidf(float x) { return fast_rcp(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu(float x) { return x * sigmoidf(x); }
 // log(sigmoid(x)) = min(x,0) - log1p(exp(-|x|))   (the form torch's CPU kernel uses)
 __device__ __forceinline__ float logsigmoidf(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
 

@@ -164,8 +164,9 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
         if (LN) {
             const float a = (s_st[0][row][0] + s_st[1][row][0]) + (s_st[2][row][0] + s_st[3][row][0]);
             const float b = (s_st[0][row][1] + s_st[1][row][1]) + (s_st[2][row][1] + s_st[3][row][1]);
-            mu = a / (float)ln_dim;
-            rstd = rsqrtf(fmaxf(b / (float)ln_dim - mu * mu, 0.f) + ln_eps);
+            const float inv_d = fast_rcp((float)ln_dim);
+            mu = a * inv_d;
+            rstd = rsqrtf(fmaxf(b * inv_d - mu * mu, 0.f) + ln_eps);
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
