@@ -60,28 +60,26 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     constexpr int SQ = DK + 8;   // bf16 row stride of q~ / o tiles (528 B): 8-byte fragment reads conflict-free
     constexpr int SK = DK + 16;  // bf16 row stride of the k~ tile (544 B): 16-byte fragment reads conflict-free
     constexpr int ST = C + 8;    // bf16 row stride of the transposed tiles (80 B)
+    constexpr int PE = 2 * DK + 8;   // elements per ROW PAIR of a raw tile: one DMA instruction (2 rows, 1 KiB) + 16 B pad, so
+                                     // that the 16 row pairs read by one phase-A instruction start in different banks
     __shared__ __attribute__((aligned(16))) bf16_t s_q[C * SQ];
-    __shared__ __attribute__((aligned(16))) bf16_t s_k[C * SK];
-    __shared__ __attribute__((aligned(16))) bf16_t s_A[2 * 64 * 8];     // mask(A) as ready-made A operands [nt][lane][8]
+    __shared__ __attribute__((aligned(16))) bf16_t s_k[C * SK];         // row-major k~ (for mask(A)); later the o tile
+    __shared__ __attribute__((aligned(16))) bf16_t s_A[2 * 64 * 8];     // mask(A) as ready-made operands [nt][lane][8]
     __shared__ __attribute__((aligned(16))) bf16_t s_kT[DK * ST];
     __shared__ __attribute__((aligned(16))) bf16_t s_vT[DV * ST];
     // next chunk's q, k, g, v, filled by DMA.  FOUR SEPARATE objects: an LDS read that may alias a pending LDS-DMA
-    // destination makes the compiler wait for vmcnt(0); with one array the transposition pass's reads of the current v
-    // tile waited for the q,k,g prefetch issued just before them, i.e. the HBM latency was exposed in every chunk
-    __shared__ __attribute__((aligned(16))) bf16_t s_rq[C * DK];
-    __shared__ __attribute__((aligned(16))) bf16_t s_rk[C * DK];
-    __shared__ __attribute__((aligned(16))) bf16_t s_rg[C * DK];
-    __shared__ __attribute__((aligned(16))) bf16_t s_rv[C * DK];
-    __shared__ __attribute__((aligned(16))) float s_ot[C * SQ / 2];      // gate-scan totals, later the o tile
+    // destination makes the compiler wait for vmcnt(0)
+    __shared__ __attribute__((aligned(16))) bf16_t s_rq[(C / 2) * PE];
+    __shared__ __attribute__((aligned(16))) bf16_t s_rk[(C / 2) * PE];
+    __shared__ __attribute__((aligned(16))) bf16_t s_rg[(C / 2) * PE];
+    __shared__ __attribute__((aligned(16))) bf16_t s_rv[(C / 2) * PE];
     __shared__ __attribute__((aligned(16))) float s_dec2[2][DK];   // e^{b_last} of the current / previous chunk (parity)
     __shared__ int s_flag, s_nw[16];
-    float* s_tot = s_ot;                                  // [16][DK] fp32   (phase A)
-    bf16_t* s_o = reinterpret_cast<bf16_t*>(s_ot);        // [C][SQ] bf16    (phase B)
+    bf16_t* s_o = s_k;                                    // [C][SQ] bf16 (phase B, after mask(A) has consumed s_k)
 
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int w_s = wave_uniform(w);                         // wave index in an SGPR for the whole kernel
     int li = lane & 15, lg = lane >> 4;
-    int co = tid & 63, rg = tid >> 6;
     const int slot = blockIdx.x;                             // state slot: (b*H + h) * nseg + segment
     const int bh = slot / nseg, b = bh / H, h = bh % H;
     const int t_begin = (slot % nseg) * Tseg;
@@ -105,7 +103,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     bf16_t* ob = STATE_ONLY ? nullptr : o + b * so.b + h * so.h + t_begin * so.t;
     float4 decp = make_float4(1.f, 1.f, 1.f, 1.f);            // STATE_ONLY, wave 0: product of the chunk decays, channels 4*lane..+3
 
-    // wave w DMAs rows 2w, 2w+1 of each raw tile: one instruction = 2 rows x 512 B, 16 B per lane.
+    // wave w DMAs row pair w (rows 2w, 2w+1) of each raw tile: one instruction = 2 rows x 512 B, 16 B per lane.
     // Rows past the end of the sequence re-read row T-1 (always mapped); phase A masks them.
     auto dma_chunk = [&](int t_first, int a_lo, int a_hi) {
 #pragma unroll
@@ -115,111 +113,126 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             // uniform base + 32-bit BYTE offset per lane (< 2^32: launcher guard): selects the SGPR-base addressing form,
             // no 64-bit per-lane address arithmetic (whose zero high word the compiler kept in -- and spilled from -- a VGPR)
             const unsigned boff = 2u * (t * gst[a] + 8u * (unsigned)(lane & 31));
-            dma16_to_lds_async(gsrc[a], boff, &dst[(2 * w) * DK]);
+            dma16_to_lds_async(gsrc[a], boff, &dst[w * PE]);
         }
     };
-    // this thread's 2 rows x 4 channels of clamped gates, summed down the 2 rows (rows >= nrem count as 0)
-    auto local_gates = [&](float (&bc)[2][4], int nrem) {
+
+    // ---- phase A thread map: wave w <-> channels [16w, 16w+16); lane = (row pair rp = lane>>2, channel quad c4 = lane&3).
+    // The gate scan over the 16 row pairs is a wave-level prefix (shuffles): no cross-wave totals, no barrier, no
+    // serial prefix loop; the thread owns two ADJACENT tokens, so it writes k~^T / v^T directly (4-byte pieces).
+    int rp = lane >> 2, ch0 = 16 * w + 4 * (lane & 3);
+    // inclusive gate cumsum of this thread's 2 rows x 4 channels (rows >= nrem count as 0); true if the chunk's total
+    // decay is too large for one chunk
+    auto gate_scan = [&](float (&bc)[2][4], int nrem) {
         float g0[4], g1[4];
-        unpack4(*reinterpret_cast<const uint2*>(&s_rg[(2 * rg) * DK + 4 * co]), g0);
-        unpack4(*reinterpret_cast<const uint2*>(&s_rg[(2 * rg + 1) * DK + 4 * co]), g1);
-        const bool in0 = 2 * rg < nrem, in1 = 2 * rg + 1 < nrem;
+        unpack4(*reinterpret_cast<const uint2*>(&s_rg[rp * PE + ch0]), g0);
+        unpack4(*reinterpret_cast<const uint2*>(&s_rg[rp * PE + DK + ch0]), g1);
+        const bool in0 = 2 * rp < nrem, in1 = 2 * rp + 1 < nrem;
+        float tot[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             bc[0][c] = in0 ? fmaxf(g0[c], -kFullMaxDecay) : 0.0f;
             bc[1][c] = bc[0][c] + (in1 ? fmaxf(g1[c], -kFullMaxDecay) : 0.0f);
+            tot[c] = bc[1][c];
         }
-    };
-    // add the exclusive prefix over the 16 row groups (from s_tot); true if the chunk's total decay is too large
-    auto add_prefix = [&](float (&bc)[2][4]) {
-        float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 1
-        for (int r = 0; r < (LINA_K2_ABL == 1 ? 0 : rg); ++r) {   // rg is wave-uniform (= wave index)
-            const float4 x = *reinterpret_cast<const float4*>(&s_tot[r * DK + 4 * co]);
-            pre.x += x.x; pre.y += x.y; pre.z += x.z; pre.w += x.w;
+#pragma unroll
+        for (int d = 4; d < 64; d <<= 1) {                   // inclusive scan over the row pairs (lanes 4 apart)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float up = shfl_up(tot[c], d);
+                tot[c] += (lane >= d) ? up : 0.0f;
+            }
         }
-        const float pr[4] = {pre.x, pre.y, pre.z, pre.w};
         bool viol = false;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            bc[0][c] += pr[c];
-            bc[1][c] += pr[c];
-            viol |= (-bc[1][c] > kFullMaxDecay);            // b is monotone: the last row group sees the chunk total
+            const float pre = tot[c] - bc[1][c];             // exclusive prefix of this row pair
+            bc[0][c] += pre;
+            bc[1][c] += pre;
+            viol |= (-bc[1][c] > kFullMaxDecay);              // b is monotone: the last row pair sees the chunk total
         }
         return viol;
     };
     // rows >= nv are zeroed; the thread that owns row nv-1 publishes exp(b_last)
     float* s_dec = s_dec2[0];                                 // current chunk's buffer; the other one holds the PENDING decay
     auto write_tiles = [&](const float (&bc)[2][4], int nv) {
+        uint2 kk[2], vv[2];                                   // packed k~ / v of the two rows, for the transposed pieces
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
-            const int row = 2 * rg + rr;
+            const int row = 2 * rp + rr;
             const bool valid = row < nv;
             float f[4], e[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) e[c] = LINA_K2_ABL == 6 ? 1.0f + bc[rr][c] : __expf(bc[rr][c]);
-            uint2 pq, pk;
             if constexpr (!STATE_ONLY) {
-                unpack4(*reinterpret_cast<const uint2*>(&s_rq[row * DK + 4 * co]), f);
+                uint2 pq;
+                unpack4(*reinterpret_cast<const uint2*>(&s_rq[rp * PE + rr * DK + ch0]), f);
                 pq.x = pack_bf16x2(valid ? f[0] * scale * e[0] : 0.0f, valid ? f[1] * scale * e[1] : 0.0f);
                 pq.y = pack_bf16x2(valid ? f[2] * scale * e[2] : 0.0f, valid ? f[3] * scale * e[3] : 0.0f);
-                *reinterpret_cast<uint2*>(&s_q[row * SQ + 4 * co]) = pq;
+                *reinterpret_cast<uint2*>(&s_q[row * SQ + ch0]) = pq;
             }
-            unpack4(*reinterpret_cast<const uint2*>(&s_rk[row * DK + 4 * co]), f);
+            unpack4(*reinterpret_cast<const uint2*>(&s_rk[rp * PE + rr * DK + ch0]), f);
             // k e^{-b} = k * rcp(e^{b}): v_rcp_f32 (1 ulp) + multiply; `/` and __fdividef both expand to the ~10-instruction
             // IEEE division sequence here (160 VALU instructions per thread and chunk)
             float ri[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) ri[c] = fast_rcp(e[c]);
-            pk.x = pack_bf16x2(valid ? f[0] * ri[0] : 0.0f, valid ? f[1] * ri[1] : 0.0f);
-            pk.y = pack_bf16x2(valid ? f[2] * ri[2] : 0.0f, valid ? f[3] * ri[3] : 0.0f);
-            *reinterpret_cast<uint2*>(&s_k[row * SK + 4 * co]) = pk;
-            if (row == nv - 1) *reinterpret_cast<float4*>(&s_dec[4 * co]) = make_float4(e[0], e[1], e[2], e[3]);
+            kk[rr].x = pack_bf16x2(valid ? f[0] * ri[0] : 0.0f, valid ? f[1] * ri[1] : 0.0f);
+            kk[rr].y = pack_bf16x2(valid ? f[2] * ri[2] : 0.0f, valid ? f[3] * ri[3] : 0.0f);
+            if constexpr (!STATE_ONLY) *reinterpret_cast<uint2*>(&s_k[row * SK + ch0]) = kk[rr];
+            const uint2 rv = *reinterpret_cast<const uint2*>(&s_rv[rp * PE + rr * DK + ch0]);
+            vv[rr] = valid ? rv : make_uint2(0u, 0u);
+            if (row == nv - 1) *reinterpret_cast<float4*>(&s_dec[ch0]) = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        // transposed pieces: element (channel ch0+i, tokens 2rp, 2rp+1) = one 4-byte word
+        const unsigned k0[4] = {kk[0].x & 0xffffu, kk[0].x >> 16, kk[0].y & 0xffffu, kk[0].y >> 16};
+        const unsigned k1[4] = {kk[1].x & 0xffffu, kk[1].x >> 16, kk[1].y & 0xffffu, kk[1].y >> 16};
+        const unsigned v0[4] = {vv[0].x & 0xffffu, vv[0].x >> 16, vv[0].y & 0xffffu, vv[0].y >> 16};
+        const unsigned v1[4] = {vv[1].x & 0xffffu, vv[1].x >> 16, vv[1].y & 0xffffu, vv[1].y >> 16};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<unsigned*>(&s_kT[(ch0 + i) * ST + 2 * rp]) = k0[i] | (k1[i] << 16);
+            *reinterpret_cast<unsigned*>(&s_vT[(ch0 + i) * ST + 2 * rp]) = v0[i] | (v1[i] << 16);
         }
     };
 
     for (int c = tid; c < DK; c += 1024) s_dec2[1][c] = 1.0f;   // nothing pending before the first chunk
     int par = 0;
+    if (tid == 0) s_flag = 0;
     dma_chunk(0, STATE_ONLY ? 1 : 0, 4);
     wait_vmem();
     __syncthreads();   // DMA of chunk 0 landed
     int t0 = 0;
     while (t0 < T) {
-        // keep the per-lane index arithmetic INSIDE the loop: hoisted, it would live in (and spill from) VGPRs
-        // (only tid is carried across iterations; everything else is re-derived from it)
-        // (the wave index sits in an SGPR, the lane index comes from v_mbcnt: nothing per-lane is carried -- a spilled
-        //  tid would be reloaded through vmcnt, the counter the in-flight DMA also uses, and stall on it)
+        // nothing per-lane is carried across iterations: the wave index sits in an SGPR, the lane index comes from v_mbcnt
+        // (a spilled index would be reloaded through vmcnt, the counter the in-flight DMA also uses, and stall on it)
         lane = lane_id();
         opaque(lane);
-        w = w_s; tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; co = lane; rg = w;
+        w = w_s; tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; rp = lane >> 2; ch0 = 16 * w + 4 * (lane & 3);
         s_dec = s_dec2[par];
         const float* s_dprev = s_dec2[par ^ 1];                // decay of the previous chunk, not yet applied to S (full kernel)
         const int nrem = T - t0;
         int n = min(C, nrem);
-        // ---------------- phase A: gate scan, scaled operands ----------------
+        // ---------------- phase A: gate scan, scaled operands, transposed operands ----------------
         {
             float bc[2][4];
-            local_gates(bc, nrem);
-            *reinterpret_cast<float4*>(&s_tot[rg * DK + 4 * co]) = make_float4(bc[1][0], bc[1][1], bc[1][2], bc[1][3]);
-            if (tid == 0) s_flag = 0;
-            __syncthreads();   // (1)
-            if (add_prefix(bc)) s_flag = 1;
+            const bool viol = gate_scan(bc, nrem);
+            if (viol) s_flag = 1;
             write_tiles(bc, n);
         }
-        __syncthreads();   // (2) row-major operand tiles ready; raw q,k,g consumed
-        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; co = lane;   // re-derive, do not carry
+        __syncthreads();   // (2) operand tiles ready; raw q,k,g,v consumed
+        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; rp = lane >> 2; ch0 = 16 * w + 4 * (lane & 3);
         if (s_flag) {
             // ---- rare: the decay inside this chunk exceeds e^-60 -> cut the chunk at the first such row ----
-            float bc[2][4];                 // recomputed (s_tot is intact until the o tile is staged)
-            local_gates(bc, nrem);
-            add_prefix(bc);
+            float bc[2][4];
+            gate_scan(bc, nrem);
             int nc = C;
 #pragma unroll
             for (int rr = 1; rr >= 0; --rr) {
                 bool bad = false;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) bad |= (-bc[rr][c] > kFullMaxDecay);
-                if (bad) nc = 2 * rg + rr;
+                if (bad) nc = 2 * rp + rr;
             }
 #pragma unroll
             for (int m = 1; m < 64; m <<= 1) nc = min(nc, shfl_xor_i(nc, m));
@@ -228,34 +241,15 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 #pragma unroll
             for (int ww = 0; ww < 16; ++ww) n = min(n, s_nw[ww]);
             n = max(n, 1);
+            if (tid == 0) s_flag = 0;
             __syncthreads();   // everyone has read s_nw; the optimistic tiles are dead
             write_tiles(bc, n);
             __syncthreads();
         }
-        if (t0 + n < T) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 3);   // next chunk's raw q,k,g fly under phase B (v: see below)
+        if (t0 + n < T) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);   // next chunk's raw q,k,g,v fly under phase B
         if (STATE_ONLY && w == 0) {                                    // s_dec is stable between barriers (2) and (3)
             const float4 d = *reinterpret_cast<const float4*>(&s_dec[4 * lane]);
             decp.x *= d.x; decp.y *= d.y; decp.z *= d.z; decp.w *= d.w;
-        }
-
-        // ---------------- transposed operands: k~^T[c][t], v^T[col][t] ----------------
-        // thread (ch = tid & 255, qr = tid >> 8) gathers 8 tokens of one channel/column (2-byte LDS reads, lanes
-        // along ch: conflict-free) and writes them as one 16-byte piece (row stride 80 B: conflict-free)
-        if (LINA_K2_ABL != 2) {
-            const int ch = tid & 255, r0 = 8 * (tid >> 8);
-            unsigned w4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                w4[j] = (unsigned)s_k[(r0 + 2 * j) * SK + ch] | ((unsigned)s_k[(r0 + 2 * j + 1) * SK + ch] << 16);
-            *reinterpret_cast<uint4*>(&s_kT[ch * ST + r0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ra = r0 + 2 * j, rb = ra + 1;
-                const unsigned va = ra < n ? (unsigned)s_rv[ra * DK + ch] : 0u;
-                const unsigned vb_ = rb < n ? (unsigned)s_rv[rb * DK + ch] : 0u;
-                w4[j] = va | (vb_ << 16);
-            }
-            *reinterpret_cast<uint4*>(&s_vT[ch * ST + r0]) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
 
         // ---------------- phase B ----------------
@@ -306,10 +300,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 }
             }
         }
-        lds_barrier();     // (2b) k~^T / v^T and mask(A) complete; raw v consumed.  LDS-only barrier: the q,k,g prefetch
-                           // issued after (2) stays in flight until the full barrier (3)
-        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; co = lane;   // re-derive, do not carry
-        if (t0 + n < T) dma_chunk(t0 + n, 3, 4);
+        lds_barrier();     // (2b) mask(A) complete, s_k free for the o tile.  LDS-only barrier: the prefetch issued after (2)
+                           // stays in flight until the full barrier (3)
+        if (tid == 0) s_flag = 0;   // every wave has read it (right after (2)); the next chunk's phase A may set it again
+        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;   // re-derive, do not carry
         if constexpr (!STATE_ONLY) {
             // (3) o += mask(A) . v ; v fragments in the same token order as the C/D rows
             {
@@ -342,7 +336,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         }
         wait_vmem();       // the prefetch was issued through inline assembly: this wave's part has landed ...
         __syncthreads();   // (3) ... and so has everybody's; o tile complete, operand tiles dead
-        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; co = lane;   // re-derive, do not carry
+        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;   // re-derive, do not carry
         if constexpr (!STATE_ONLY) {
             {
                 const int row = tid >> 5, piece = tid & 31;    // 32 lanes x 16 B = one 512-byte output row
@@ -352,8 +346,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                         *reinterpret_cast<const uint4*>(&s_o[row * SQ + 8 * piece]);
                 }
             }
-            lds_barrier();     // (4) s_o (aliases the scan totals) has been read.  LDS-only: a full barrier would wait for
-                               // the o stores just issued (a whole HBM write round trip per chunk, 19 % of the kernel)
+            lds_barrier();     // (4) s_o (aliases the row-major k~ tile) has been read.  LDS-only: a full barrier would also
+                               // wait for the o stores just issued
         }
         t0 += n;
         par ^= 1;
