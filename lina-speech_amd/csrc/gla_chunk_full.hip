@@ -117,10 +117,11 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         }
     };
 
-    // ---- phase A thread map: wave w <-> channels [16w, 16w+16); lane = (row pair rp = lane>>2, channel quad c4 = lane&3).
-    // The gate scan over the 16 row pairs is a wave-level prefix (shuffles): no cross-wave totals, no barrier, no
-    // serial prefix loop; the thread owns two ADJACENT tokens, so it writes k~^T / v^T directly (4-byte pieces).
-    int rp = lane >> 2, ch0 = 16 * w + 4 * (lane & 3);
+    // ---- phase A thread map: wave w <-> channels [16w, 16w+16); lane = (channel quad c4 = lane>>4, row pair rp = lane&15).
+    // The 16 row pairs of a channel quad sit in ONE 16-lane row, so the gate scan is four DPP row_shr adds per value:
+    // no cross-wave totals, no barrier, no serial prefix loop; the thread owns two ADJACENT tokens, so it writes
+    // k~^T / v^T directly (4-byte pieces).
+    int rp = lane & 15, ch0 = 16 * w + 4 * (lane >> 4);
     // inclusive gate cumsum of this thread's 2 rows x 4 channels (rows >= nrem count as 0); true if the chunk's total
     // decay is too large for one chunk
     auto gate_scan = [&](float (&bc)[2][4], int nrem) {
@@ -136,12 +137,11 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             tot[c] = bc[1][c];
         }
 #pragma unroll
-        for (int d = 4; d < 64; d <<= 1) {                   // inclusive scan over the row pairs (lanes 4 apart)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float up = shfl_up(tot[c], d);
-                tot[c] += (lane >= d) ? up : 0.0f;
-            }
+        for (int c = 0; c < 4; ++c) {                        // inclusive scan over the 16 row pairs of this 16-lane row
+            tot[c] += dpp_row_shr<1>(tot[c]);
+            tot[c] += dpp_row_shr<2>(tot[c]);
+            tot[c] += dpp_row_shr<4>(tot[c]);
+            tot[c] += dpp_row_shr<8>(tot[c]);
         }
         bool viol = false;
 #pragma unroll
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         // (a spilled index would be reloaded through vmcnt, the counter the in-flight DMA also uses, and stall on it)
         lane = lane_id();
         opaque(lane);
-        w = w_s; tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; rp = lane >> 2; ch0 = 16 * w + 4 * (lane & 3);
+        w = w_s; tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; rp = lane & 15; ch0 = 16 * w + 4 * (lane >> 4);
         s_dec = s_dec2[par];
         const float* s_dprev = s_dec2[par ^ 1];                // decay of the previous chunk, not yet applied to S (full kernel)
         const int nrem = T - t0;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             write_tiles(bc, n);
         }
         __syncthreads();   // (2) operand tiles ready; raw q,k,g,v consumed
-        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; rp = lane >> 2; ch0 = 16 * w + 4 * (lane & 3);
+        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; rp = lane & 15; ch0 = 16 * w + 4 * (lane >> 4);
         if (s_flag) {
             // ---- rare: the decay inside this chunk exceeds e^-60 -> cut the chunk at the first such row ----
             float bc[2][4];

@@ -117,6 +117,13 @@ __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_rea
 // Use it only where no wave touches the DMA destination before the next full __syncthreads().
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// value of lane (l - n) of the same 16-lane row, 0 for the first n lanes of a row (v_*_dpp row_shr:n, bound_ctrl): one VALU
+// modifier instead of a ds_bpermute -- the building block of a 16-wide scan
+template <int N>
+__device__ __forceinline__ float dpp_row_shr(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
+}
+
 // 1/x as one v_rcp_f32 (1 ulp)
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

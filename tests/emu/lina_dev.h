@@ -243,6 +243,13 @@ static inline void lds_barrier() { lina_emu::syncthreads(); }
 static inline int lane_id() { return lina_emu::cur_lane(); }
 static inline int wave_uniform(int v) { return v; }
 
+template <int N>
+static inline float dpp_row_shr(float v) {
+    uint32_t mine = f2u(v), tab[64];
+    lina_emu::wave_exchange(&mine, 1, tab);
+    const int l = lina_emu::cur_lane();
+    return (l & 15) >= N ? u2f(tab[l - N]) : 0.0f;
+}
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void cfence() { asm volatile("" ::: "memory"); }
 
