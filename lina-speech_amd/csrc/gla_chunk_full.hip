@@ -34,6 +34,7 @@ namespace lina {
 
 constexpr int kFullC = 32;
 constexpr float kFullMaxDecay = 60.0f;
+constexpr float kRenorm = 20.0f;        // renormalise the state when a channel's accumulated log-decay passes -kRenorm
 
 __device__ __forceinline__ void unpack4(const uint2 u, float (&f)[4]) {
     f[0] = bf2f((bf16_t)(u.x & 0xffff)); f[1] = bf2f((bf16_t)(u.x >> 16));
@@ -73,8 +74,13 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     __shared__ __attribute__((aligned(16))) bf16_t s_rk[(C / 2) * PE];
     __shared__ __attribute__((aligned(16))) bf16_t s_rg[(C / 2) * PE];
     __shared__ __attribute__((aligned(16))) bf16_t s_rv[(C / 2) * PE];
-    __shared__ __attribute__((aligned(16))) float s_dec2[2][DK];   // e^{b_last} of the current / previous chunk (parity)
-    __shared__ int s_flag, s_nw[16];
+    // UN-NORMALISED state: the accumulators hold S' with S = diag(e^{R}) S', R[c] <= 0 the log-decay accumulated since the
+    // last renormalisation.  q~ and k~ absorb R (q^ = q~ e^{R}, k^ = k~ e^{-R}), so a chunk needs NO pass over the state
+    // for its decay; when some R drops below -kRenorm the state rows are rescaled once (S' <- e^{R} S', R <- 0).
+    __shared__ __attribute__((aligned(16))) float s_R[DK];      // R used by this chunk's phase A
+    __shared__ __attribute__((aligned(16))) float s_Rn[DK];     // R after this chunk (written by the owners of the last row)
+    __shared__ __attribute__((aligned(16))) float s_dec[DK];    // e^{b_last} of this chunk (STATE_ONLY: segment decay product)
+    __shared__ int s_flag, s_renorm, s_nw[16];
     bf16_t* s_o = s_k;                                    // [C][SQ] bf16 (phase B, after mask(A) has consumed s_k)
 
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -154,16 +160,17 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         return viol;
     };
     // rows >= nv are zeroed; the thread that owns row nv-1 publishes exp(b_last)
-    float* s_dec = s_dec2[0];                                 // current chunk's buffer; the other one holds the PENDING decay
     auto write_tiles = [&](const float (&bc)[2][4], int nv) {
         uint2 kk[2], vv[2];                                   // packed k~ / v of the two rows, for the transposed pieces
+        const float4 R4 = *reinterpret_cast<const float4*>(&s_R[ch0]);
+        const float Rc[4] = {R4.x, R4.y, R4.z, R4.w};
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int row = 2 * rp + rr;
             const bool valid = row < nv;
             float f[4], e[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) e[c] = LINA_K2_ABL == 6 ? 1.0f + bc[rr][c] : __expf(bc[rr][c]);
+            for (int c = 0; c < 4; ++c) e[c] = __expf(bc[rr][c] + Rc[c]);   // e^{b + R}: |b| <= 60, |R| <= kRenorm + 60
             if constexpr (!STATE_ONLY) {
                 uint2 pq;
                 unpack4(*reinterpret_cast<const uint2*>(&s_rq[rp * PE + rr * DK + ch0]), f);
@@ -182,7 +189,17 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             if constexpr (!STATE_ONLY) *reinterpret_cast<uint2*>(&s_k[row * SK + ch0]) = kk[rr];
             const uint2 rv = *reinterpret_cast<const uint2*>(&s_rv[rp * PE + rr * DK + ch0]);
             vv[rr] = valid ? rv : make_uint2(0u, 0u);
-            if (row == nv - 1) *reinterpret_cast<float4*>(&s_dec[ch0]) = make_float4(e[0], e[1], e[2], e[3]);
+            if (row == nv - 1) {                             // owner of the chunk's last row: R after the chunk, renorm request
+                float rn[4];
+                bool need = false;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { rn[c] = bc[rr][c] + Rc[c]; need |= rn[c] < -kRenorm; }
+                *reinterpret_cast<float4*>(&s_Rn[ch0]) = make_float4(rn[0], rn[1], rn[2], rn[3]);
+                if (need) s_renorm = 1;
+                if constexpr (STATE_ONLY)
+                    *reinterpret_cast<float4*>(&s_dec[ch0]) =
+                        make_float4(__expf(bc[rr][0]), __expf(bc[rr][1]), __expf(bc[rr][2]), __expf(bc[rr][3]));
+            }
         }
         // transposed pieces: element (channel ch0+i, tokens 2rp, 2rp+1) = one 4-byte word
         const unsigned k0[4] = {kk[0].x & 0xffffu, kk[0].x >> 16, kk[0].y & 0xffffu, kk[0].y >> 16};
@@ -196,9 +213,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         }
     };
 
-    for (int c = tid; c < DK; c += 1024) s_dec2[1][c] = 1.0f;   // nothing pending before the first chunk
-    int par = 0;
-    if (tid == 0) s_flag = 0;
+    for (int c = tid; c < DK; c += 1024) s_R[c] = 0.0f;
+    if (tid == 0) { s_flag = 0; s_renorm = 0; }
     dma_chunk(0, STATE_ONLY ? 1 : 0, 4);
     wait_vmem();
     __syncthreads();   // DMA of chunk 0 landed
@@ -209,8 +225,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         lane = lane_id();
         opaque(lane);
         w = w_s; tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; rp = lane & 15; ch0 = 16 * w + 4 * (lane >> 4);
-        s_dec = s_dec2[par];
-        const float* s_dprev = s_dec2[par ^ 1];                // decay of the previous chunk, not yet applied to S (full kernel)
         const int nrem = T - t0;
         int n = min(C, nrem);
         // ---------------- phase A: gate scan, scaled operands, transposed operands ----------------
@@ -246,6 +260,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             write_tiles(bc, n);
             __syncthreads();
         }
+        const bool renorm = s_renorm != 0;                    // workgroup-uniform: set in phase A, reset after (2b)
         if (t0 + n < T) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);   // next chunk's raw q,k,g,v fly under phase B
         if (STATE_ONLY && w == 0) {                                    // s_dec is stable between barriers (2) and (3)
             const float4 d = *reinterpret_cast<const float4*>(&s_dec[4 * lane]);
@@ -279,14 +294,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             // (1) o = q~ . S_old : one K = 32 MFMA per pair of 16-row state tiles (converted to bf16 in registers)
 #pragma unroll
             for (int pp = 0; pp < (LINA_K2_ABL == 3 ? 0 : 8); ++pp) {
-                // the previous chunk's row decay is applied HERE, where every state element is touched anyway for the
-                // bf16 copy (a separate pass after the update MFMAs waited on them and cost 21 % of the kernel)
-                {
-                    const float4 d0 = *reinterpret_cast<const float4*>(&s_dprev[32 * pp + 4 * lg]);
-                    const float4 d1 = *reinterpret_cast<const float4*>(&s_dprev[32 * pp + 16 + 4 * lg]);
-                    S[2 * pp][0] *= d0.x; S[2 * pp][1] *= d0.y; S[2 * pp][2] *= d0.z; S[2 * pp][3] *= d0.w;
-                    S[2 * pp + 1][0] *= d1.x; S[2 * pp + 1][1] *= d1.y; S[2 * pp + 1][2] *= d1.z; S[2 * pp + 1][3] *= d1.w;
-                }
                 bf16x8 bb;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -303,6 +310,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         lds_barrier();     // (2b) mask(A) complete, s_k free for the o tile.  LDS-only barrier: the prefetch issued after (2)
                            // stays in flight until the full barrier (3)
         if (tid == 0) s_flag = 0;   // every wave has read it (right after (2)); the next chunk's phase A may set it again
+        if (tid == 0) s_renorm = 0;
+        if (tid < DK) s_R[tid] = renorm ? 0.0f : s_Rn[tid];   // next chunk's R; phase A reads it after barrier (3)
         lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;   // re-derive, do not carry
         if constexpr (!STATE_ONLY) {
             // (3) o += mask(A) . v ; v fragments in the same token order as the C/D rows
@@ -326,11 +335,13 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         {
             const bf16x8 vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
 #pragma unroll
-            for (int p = 0; p < (LINA_K2_ABL == 4 ? 0 : 16); ++p) {
+            for (int p = 0; p < (LINA_K2_ABL == 4 ? 0 : 16); ++p)
                 S[p] = mfma_bf16_16x16x32(frag16(&s_kT[(16 * p + li) * ST + 8 * lg]), vb2, S[p]);
-                if constexpr (STATE_ONLY) {              // no q~.S pass there: decay applied right away
-                    const float4 d = *reinterpret_cast<const float4*>(&s_dec[16 * p + 4 * lg]);
-                    S[p][0] *= d.x; S[p][1] *= d.y; S[p][2] *= d.z; S[p][3] *= d.w;
+            if (renorm) {                                // rare: S' <- e^{R} S' (R = s_Rn, the value after this chunk)
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(&s_Rn[16 * p + 4 * lg]);
+                    S[p][0] *= __expf(r4.x); S[p][1] *= __expf(r4.y); S[p][2] *= __expf(r4.z); S[p][3] *= __expf(r4.w);
                 }
             }
         }
@@ -350,19 +361,16 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                                // wait for the o stores just issued
         }
         t0 += n;
-        par ^= 1;
     }
 
     if (STATE_ONLY && dec_out && w == 0)
         *reinterpret_cast<float4*>(dec_out + (int64_t)slot * DK + 4 * lane) = decp;
     if (ht) {
-        if constexpr (!STATE_ONLY) {                         // the last chunk's decay is still pending
-            const float* dl = s_dec2[par ^ 1];
+        __syncthreads();                                     // s_R of the last chunk is visible (STATE_ONLY has no barrier (4))
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const float4 d = *reinterpret_cast<const float4*>(&dl[16 * p + 4 * lg]);
-                S[p][0] *= d.x; S[p][1] *= d.y; S[p][2] *= d.z; S[p][3] *= d.w;
-            }
+        for (int p = 0; p < 16; ++p) {                       // S = diag(e^{R}) S'
+            const float4 r4 = *reinterpret_cast<const float4*>(&s_R[16 * p + 4 * lg]);
+            S[p][0] *= __expf(r4.x); S[p][1] *= __expf(r4.y); S[p][2] *= __expf(r4.z); S[p][3] *= __expf(r4.w);
         }
         float* hp = ht + ((int64_t)slot * DK + 4 * lg) * DV + 16 * w + li;
 #pragma unroll
