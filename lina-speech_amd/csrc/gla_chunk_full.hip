@@ -59,12 +59,14 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     lina_bht_strides sg, lina_bht_strides so, float scale) {
     constexpr int DK = 256, DV = 256, C = kFullC;
     constexpr int SQ = DK + 8;   // bf16 row stride of q~ / o tiles (528 B): 8-byte fragment reads conflict-free
-    constexpr int SK = DK + 16;  // bf16 row stride of the k~ tile (544 B): 16-byte fragment reads conflict-free
+    constexpr int SK = DK + 8;   // bf16 row stride of the row-major k~ tile (528 B, rows stay 16-byte aligned): it is written by ALL
+                                 // threads row-strided (16 row pairs per instruction: 544 B made that 8-way bank-conflicted, 528 B
+                                 // 4-way, the minimum for aligned rows) and read by 4 waves only
     constexpr int ST = C + 8;    // bf16 row stride of the transposed tiles (80 B)
     constexpr int PE = 2 * DK + 8;   // elements per ROW PAIR of a raw tile: one DMA instruction (2 rows, 1 KiB) + 16 B pad, so
                                      // that the 16 row pairs read by one phase-A instruction start in different banks
     __shared__ __attribute__((aligned(16))) bf16_t s_q[C * SQ];
-    __shared__ __attribute__((aligned(16))) bf16_t s_k[C * SK];         // row-major k~ (for mask(A)); later the o tile
+    __shared__ __attribute__((aligned(16))) bf16_t s_k[C * SQ];         // row-major k~, stride SK (for mask(A)); later the o tile, stride SQ
     __shared__ __attribute__((aligned(16))) bf16_t s_A[2 * 64 * 8];     // mask(A) as ready-made operands [nt][lane][8]
     __shared__ __attribute__((aligned(16))) bf16_t s_kT[DK * ST];
     __shared__ __attribute__((aligned(16))) bf16_t s_vT[DV * ST];
