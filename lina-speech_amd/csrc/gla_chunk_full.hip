@@ -62,7 +62,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     constexpr int SK = DK + 8;   // bf16 row stride of the row-major k~ tile (528 B, rows stay 16-byte aligned): it is written by ALL
                                  // threads row-strided (16 row pairs per instruction: 544 B made that 8-way bank-conflicted, 528 B
                                  // 4-way, the minimum for aligned rows) and read by 4 waves only
-    constexpr int ST = C + 8;    // bf16 row stride of the transposed tiles (80 B)
+    constexpr int ST = C + 16;   // bf16 row stride of the transposed tiles (96 B): conflict-free 16-byte fragment reads under the
+                                 // real ds_read_b128 lane grouping ({0-3,12-15,20-27}, ...); 80 B was 2-way there
     constexpr int PE = 2 * DK + 8;   // elements per ROW PAIR of a raw tile: one DMA instruction (2 rows, 1 KiB) + 16 B pad, so
                                      // that the 16 row pairs read by one phase-A instruction start in different banks
     __shared__ __attribute__((aligned(16))) bf16_t s_q[C * SQ];
