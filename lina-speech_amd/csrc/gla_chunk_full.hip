@@ -177,8 +177,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             if constexpr (!STATE_ONLY) {
                 uint2 pq;
                 unpack4(*reinterpret_cast<const uint2*>(&s_rq[rp * PE + rr * DK + ch0]), f);
-                pq.x = pack_bf16x2(valid ? f[0] * scale * e[0] : 0.0f, valid ? f[1] * scale * e[1] : 0.0f);
-                pq.y = pack_bf16x2(valid ? f[2] * scale * e[2] : 0.0f, valid ? f[3] * scale * e[3] : 0.0f);
+                pq.x = pack_bf16x2(f[0] * scale * e[0], f[1] * scale * e[1]);   // rows >= nv: finite values, zeroed as packed words
+                pq.y = pack_bf16x2(f[2] * scale * e[2], f[3] * scale * e[3]);
+                pq.x = valid ? pq.x : 0u;
+                pq.y = valid ? pq.y : 0u;
                 *reinterpret_cast<uint2*>(&s_q[row * SQ + ch0]) = pq;
             }
             unpack4(*reinterpret_cast<const uint2*>(&s_rk[rp * PE + rr * DK + ch0]), f);
@@ -187,8 +189,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             float ri[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) ri[c] = fast_rcp(e[c]);
-            kk[rr].x = pack_bf16x2(valid ? f[0] * ri[0] : 0.0f, valid ? f[1] * ri[1] : 0.0f);
-            kk[rr].y = pack_bf16x2(valid ? f[2] * ri[2] : 0.0f, valid ? f[3] * ri[3] : 0.0f);
+            kk[rr].x = pack_bf16x2(f[0] * ri[0], f[1] * ri[1]);
+            kk[rr].y = pack_bf16x2(f[2] * ri[2], f[3] * ri[3]);
+            kk[rr].x = valid ? kk[rr].x : 0u;
+            kk[rr].y = valid ? kk[rr].y : 0u;
             if constexpr (!STATE_ONLY) *reinterpret_cast<uint2*>(&s_k[row * SK + ch0]) = kk[rr];
             const uint2 rv = *reinterpret_cast<const uint2*>(&s_rv[rp * PE + rr * DK + ch0]);
             vv[rr] = valid ? rv : make_uint2(0u, 0u);
