@@ -67,7 +67,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     constexpr int PE = 2 * DK + 8;   // elements per ROW PAIR of a raw tile: one DMA instruction (2 rows, 1 KiB) + 16 B pad, so
                                      // that the 16 row pairs read by one phase-A instruction start in different banks
     __shared__ __attribute__((aligned(16))) bf16_t s_q[C * SQ];
-    __shared__ __attribute__((aligned(16))) bf16_t s_k[C * SQ];         // row-major k~, stride SK (for mask(A)); later the o tile, stride SQ
+    __shared__ __attribute__((aligned(16))) bf16_t s_k[C * SK];         // row-major k~ (for mask(A))
     __shared__ __attribute__((aligned(16))) bf16_t s_A[2 * 64 * 8];     // mask(A) as ready-made operands [nt][lane][8]
     __shared__ __attribute__((aligned(16))) bf16_t s_kT[DK * ST];
     __shared__ __attribute__((aligned(16))) bf16_t s_vT[DV * ST];
@@ -84,7 +84,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     __shared__ __attribute__((aligned(16))) float s_Rn[DK];     // R after this chunk (written by the owners of the last row)
     __shared__ __attribute__((aligned(16))) float s_dec[DK];    // e^{b_last} of this chunk (STATE_ONLY: segment decay product)
     __shared__ int s_flag, s_renorm, s_nw[16];
-    bf16_t* s_o = s_k;                                    // [C][SQ] bf16 (phase B, after mask(A) has consumed s_k)
 
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int w_s = wave_uniform(w);                         // wave index in an SGPR for the whole kernel
@@ -328,15 +327,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 acc[0] = mfma_bf16_16x16x32(vb, frag16(&s_A[(0 * 64 + lane) * 8]), acc[0]);   // o^T += v^T . mask(A)^T
                 acc[1] = mfma_bf16_16x16x32(vb, frag16(&s_A[(1 * 64 + lane) * 8]), acc[1]);
             }
-            // stage o (this wave's 32 x 16 block).  The products above are taken TRANSPOSED (state / v as the A operand),
-            // so a lane holds 4 consecutive columns of ONE token: one 8-byte LDS write per tile instead of four 2-byte ones
-#pragma unroll
-            for (int nt = 0; nt < (LINA_K2_ABL == 8 ? 0 : 2); ++nt) {
-                uint2 po;
-                po.x = pack_bf16x2(acc[nt][0], acc[nt][1]);
-                po.y = pack_bf16x2(acc[nt][2], acc[nt][3]);
-                *reinterpret_cast<uint2*>(&s_o[(16 * nt + li) * SQ + 16 * w + 4 * lg]) = po;
-            }
         }
         // (4) S <- e^{b_last} (S + k~^T v)
         {
@@ -353,19 +343,24 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             }
         }
         wait_vmem();       // the prefetch was issued through inline assembly: this wave's part has landed ...
-        __syncthreads();   // (3) ... and so has everybody's; o tile complete, operand tiles dead
-        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;   // re-derive, do not carry
+        __syncthreads();   // (3) ... and so has everybody's; operand tiles dead
         if constexpr (!STATE_ONLY) {
-            {
-                const int row = tid >> 5, piece = tid & 31;    // 32 lanes x 16 B = one 512-byte output row
-                if (row < n && LINA_K2_ABL != 7 && LINA_K2_ABL != 8) {   // uniform base + 32-bit byte offset (SGPR-base addressing, as for the DMA)
-                    const unsigned boff = 2u * ((unsigned)(t0 + row) * (unsigned)so.t + 8u * (unsigned)piece);
-                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(ob) + boff) =
-                        *reinterpret_cast<const uint4*>(&s_o[row * SQ + 8 * piece]);
+            // o straight from the accumulators, AFTER the barrier (so that the wait above does not include these stores: they
+            // drain under the next chunk's phase A).  The products were taken TRANSPOSED (state / v as the A operand), so a
+            // lane holds 4 consecutive columns of ONE token = one 8-byte store; the 16 waves' 32-byte pieces of a 512-byte
+            // row meet in L2.  No LDS staging, no read-back, no barrier (4).
+            lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
+#pragma unroll
+            for (int nt = 0; nt < (LINA_K2_ABL == 8 ? 0 : 2); ++nt) {
+                const int row = 16 * nt + li;
+                uint2 po;
+                po.x = pack_bf16x2(acc[nt][0], acc[nt][1]);
+                po.y = pack_bf16x2(acc[nt][2], acc[nt][3]);
+                if (row < n && LINA_K2_ABL != 7) {
+                    const unsigned boff = 2u * ((unsigned)(t0 + row) * (unsigned)so.t + 16u * (unsigned)w + 4u * (unsigned)lg);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) + boff) = po;
                 }
             }
-            lds_barrier();     // (4) s_o (aliases the row-major k~ tile) has been read.  LDS-only: a full barrier would also
-                               // wait for the o stores just issued
         }
         t0 += n;
     }
