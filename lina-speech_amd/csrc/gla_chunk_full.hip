@@ -23,11 +23,20 @@
 //      k-slot -> channel map); (3) o += mask(A) . v with A^T's registers re-used as the A operand;
 //      (4) S += k~^T . v, rows scaled by e^{b_last}.  36 x v_mfma_f32_16x16x32_bf16 per wave per chunk.
 //      o is staged through LDS and stored 16 B per lane.
+#include <type_traits>
 #include <lina_dev.h>
 #include "lina_common.h"
 
 #ifndef LINA_K2_ABL
 #define LINA_K2_ABL 0   // tools/k2_ablate.sh builds timing-only variants that skip one phase (results are WRONG there)
+#endif
+
+#ifdef LINA_K2_PROF
+// tools-only build (tools/k2_prof.sh): per-phase shader-clock totals of workgroup 0, [wave][slot]; NOT part of the product library
+__device__ unsigned long long lina_k2_prof[16 * 16 + 3 * 1024];   // + per workgroup: total, wait_vmem, bar(3) of wave 0
+#define K2_PROF(i) do { const unsigned long long now_ = clock64(); pacc[i] += now_ - plast; plast = now_; } while (0)
+#else
+#define K2_PROF(i) do { } while (0)
 #endif
 
 namespace lina {
@@ -58,32 +67,47 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     int T_total, int nseg, int Tseg, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
     lina_bht_strides sg, lina_bht_strides so, float scale) {
     constexpr int DK = 256, DV = 256, C = kFullC;
-    constexpr int SQ = DK + 8;   // bf16 row stride of q~ / o tiles (528 B): 8-byte fragment reads conflict-free
-    constexpr int SK = DK + 8;   // bf16 row stride of the row-major k~ tile (528 B, rows stay 16-byte aligned): it is written by ALL
-                                 // threads row-strided (16 row pairs per instruction: 544 B made that 8-way bank-conflicted, 528 B
-                                 // 4-way, the minimum for aligned rows) and read by 4 waves only
+    // q~ / k~ row-major tiles, 544-byte rows.  Two twists make EVERY operand read of them one conflict-free ds_read_b128
+    // (the two 8-byte reads step (1) needed before were merged by the compiler into ds_read2_b64: half rate, 32 banks,
+    // 2-way conflicted -- 4096 LDS cycles per chunk, the largest single cost of the kernel):
+    //  * channel order inside each group of 32: [0-3, 16-19, 4-7, 20-23, 8-11, 24-27, 12-15, 28-31], so that 16-byte piece
+    //    lg of a group holds exactly the channels the state tiles (C/D layout, rows 4lg+r of tiles 2pp, 2pp+1) give lane
+    //    group lg as k-slots 0..7; mask(A) reads both tiles the same way, so its contraction is unaffected;
+    //  * the piece index is XOR-ed with (row >> 2) & 3: 16 rows x 4 pieces of one read land on 64 distinct banks, and the
+    //    row-strided 8-byte writes of phase A are 2-way instead of 4-way conflicted (tools: bank model in DESIGN.md 4.2).
+    constexpr int SQ = DK + 16;
+    constexpr int SK = DK + 16;
     constexpr int ST = C + 16;   // bf16 row stride of the transposed tiles (96 B): conflict-free 16-byte fragment reads under the
                                  // real ds_read_b128 lane grouping ({0-3,12-15,20-27}, ...); 80 B was 2-way there
     constexpr int PE = 2 * DK + 8;   // elements per ROW PAIR of a raw tile: one DMA instruction (2 rows, 1 KiB) + 16 B pad, so
                                      // that the 16 row pairs read by one phase-A instruction start in different banks
-    __shared__ __attribute__((aligned(16))) bf16_t s_q[C * SQ];
-    __shared__ __attribute__((aligned(16))) bf16_t s_k[C * SK];         // row-major k~ (for mask(A))
+    // Tiles that phase A addresses together live in ONE object each, so that a thread needs one address register per
+    // object and every other tile / row is an immediate offset (the per-chunk address arithmetic was ~30 of phase A's
+    // VALU instructions, and phase A is VALU-issue bound).
+    __shared__ __attribute__((aligned(16))) bf16_t s_qk[2 * C * SQ];    // q~ | row-major k~ (for mask(A))
+    bf16_t* const s_q = s_qk;
+    bf16_t* const s_k = s_qk + C * SQ;
     __shared__ __attribute__((aligned(16))) bf16_t s_A[2 * 64 * 8];     // mask(A) as ready-made operands [nt][lane][8]
-    __shared__ __attribute__((aligned(16))) bf16_t s_kT[DK * ST];
-    __shared__ __attribute__((aligned(16))) bf16_t s_vT[DV * ST];
-    // next chunk's q, k, g, v, filled by DMA.  FOUR SEPARATE objects: an LDS read that may alias a pending LDS-DMA
-    // destination makes the compiler wait for vmcnt(0)
-    __shared__ __attribute__((aligned(16))) bf16_t s_rq[(C / 2) * PE];
-    __shared__ __attribute__((aligned(16))) bf16_t s_rk[(C / 2) * PE];
-    __shared__ __attribute__((aligned(16))) bf16_t s_rg[(C / 2) * PE];
-    __shared__ __attribute__((aligned(16))) bf16_t s_rv[(C / 2) * PE];
+    __shared__ __attribute__((aligned(16))) bf16_t s_T[(DK + DV) * ST];  // k~^T | v^T
+    bf16_t* const s_kT = s_T;
+    bf16_t* const s_vT = s_T + DK * ST;
+    // next chunk's q, k, g, v, filled by DMA (issued through inline assembly and waited for by hand: the compiler does not
+    // see these writes, so reads of the object are never held back by them)
+    constexpr int RAWT = (C / 2) * PE;
+    __shared__ __attribute__((aligned(16))) bf16_t s_raw[4 * RAWT];
+    bf16_t* const s_rq = s_raw;
+    bf16_t* const s_rk = s_raw + RAWT;
+    bf16_t* const s_rg = s_raw + 2 * RAWT;
+    bf16_t* const s_rv = s_raw + 3 * RAWT;
     // UN-NORMALISED state: the accumulators hold S' with S = diag(e^{R}) S', R[c] <= 0 the log-decay accumulated since the
     // last renormalisation.  q~ and k~ absorb R (q^ = q~ e^{R}, k^ = k~ e^{-R}), so a chunk needs NO pass over the state
     // for its decay; when some R drops below -kRenorm the state rows are rescaled once (S' <- e^{R} S', R <- 0).
-    __shared__ __attribute__((aligned(16))) float s_R[DK];      // R used by this chunk's phase A
-    __shared__ __attribute__((aligned(16))) float s_Rn[DK];     // R after this chunk (written by the owners of the last row)
-    __shared__ __attribute__((aligned(16))) float s_dec[DK];    // e^{b_last} of this chunk (STATE_ONLY: segment decay product)
-    __shared__ int s_flag, s_renorm, s_nw[16];
+    // R is kept in LOG2 units (R log2 e): the exponent argument is then one fma per value.
+    __shared__ __attribute__((aligned(16))) float s_Rs[3 * DK];
+    float* const s_R = s_Rs;              // R used by this chunk's phase A
+    float* const s_Rn = s_Rs + DK;        // R after this chunk (written by the owners of the last row)
+    float* const s_dec = s_Rs + 2 * DK;   // e^{b_last} of this chunk (STATE_ONLY: segment decay product)
+    __shared__ int s_flag[2], s_renorm[2], s_cut;   // flags: one set per chunk parity (reset one chunk later)
 
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int w_s = wave_uniform(w);                         // wave index in an SGPR for the whole kernel
@@ -131,58 +155,66 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // k~^T / v^T directly (4-byte pieces).
     int rp = lane & 15, ch0 = 16 * w + 4 * (lane >> 4);
     // inclusive gate cumsum of this thread's 2 rows x 4 channels (rows >= nrem count as 0); true if the chunk's total
-    // decay is too large for one chunk
-    auto gate_scan = [&](float (&bc)[2][4], int nrem) {
+    // decay is too large for one chunk.  FULL: all C rows are in the sequence (no masks).
+    auto gate_scan = [&](auto full_tag, float (&bc)[2][4], int nrem) {
+        constexpr bool FULL = decltype(full_tag)::value;
         float g0[4], g1[4];
-        unpack4(*reinterpret_cast<const uint2*>(&s_rg[rp * PE + ch0]), g0);
-        unpack4(*reinterpret_cast<const uint2*>(&s_rg[rp * PE + DK + ch0]), g1);
-        const bool in0 = 2 * rp < nrem, in1 = 2 * rp + 1 < nrem;
+        const bf16_t* gp = &s_rg[rp * PE + ch0];
+        unpack4(*reinterpret_cast<const uint2*>(gp), g0);
+        unpack4(*reinterpret_cast<const uint2*>(gp + DK), g1);
+        const bool in0 = FULL || 2 * rp < nrem, in1 = FULL || 2 * rp + 1 < nrem;
         float tot[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            bc[0][c] = in0 ? fmaxf(g0[c], -kFullMaxDecay) : 0.0f;
-            bc[1][c] = bc[0][c] + (in1 ? fmaxf(g1[c], -kFullMaxDecay) : 0.0f);
+            g0[c] = vmax_raw(g0[c], -kFullMaxDecay);
+            g1[c] = vmax_raw(g1[c], -kFullMaxDecay);
+            bc[0][c] = in0 ? g0[c] : 0.0f;
+            bc[1][c] = bc[0][c] + (in1 ? g1[c] : 0.0f);
             tot[c] = bc[1][c];
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {                        // inclusive scan over the 16 row pairs of this 16-lane row
-            tot[c] += dpp_row_shr<1>(tot[c]);
-            tot[c] += dpp_row_shr<2>(tot[c]);
-            tot[c] += dpp_row_shr<4>(tot[c]);
-            tot[c] += dpp_row_shr<8>(tot[c]);
-        }
+        row_scan4(tot[0], tot[1], tot[2], tot[3]);           // inclusive scan over the 16 row pairs of this 16-lane row
         bool viol = false;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float pre = tot[c] - bc[1][c];             // exclusive prefix of this row pair
             bc[0][c] += pre;
-            bc[1][c] += pre;
+            bc[1][c] = tot[c];
             viol |= (-bc[1][c] > kFullMaxDecay);              // b is monotone: the last row pair sees the chunk total
         }
         return viol;
     };
-    // rows >= nv are zeroed; the thread that owns row nv-1 publishes exp(b_last)
-    auto write_tiles = [&](const float (&bc)[2][4], int nv) {
+    // rows >= nv are zeroed; the thread that owns row nv-1 publishes R after the chunk.  FULL: nv == C.
+    // q~ carries NO 1/sqrt(Dk): the scale is applied to o (linear), one multiply per output instead of one per q element.
+    auto write_tiles = [&](auto full_tag, const float (&bc)[2][4], int nv, int par) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr float kLog2e = 1.4426950408889634f;
         uint2 kk[2], vv[2];                                   // packed k~ / v of the two rows, for the transposed pieces
+        // column (element index) of this thread's channel quad in the q~ / k~ tiles: group w/2, piece c4 ^ ((row>>2)&3) =
+        // c4 ^ ((rp>>1)&3) for both rows 2rp, 2rp+1, half w&1
+        bf16_t* const qkp = &s_qk[2 * rp * SQ + 32 * (w >> 1) + 8 * ((lane >> 4) ^ ((rp >> 1) & 3)) + 4 * (w & 1)];
+        const bf16_t* const rawp = &s_raw[rp * PE + ch0];
         const float4 R4 = *reinterpret_cast<const float4*>(&s_R[ch0]);
         const float Rc[4] = {R4.x, R4.y, R4.z, R4.w};
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int row = 2 * rp + rr;
-            const bool valid = row < nv;
-            float f[4], e[4];
+            const bool valid = FULL || row < nv;
+            float f[4], x[4], e[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) e[c] = __expf(bc[rr][c] + Rc[c]);   // e^{b + R}: |b| <= 60, |R| <= kRenorm + 60
+            for (int c = 0; c < 4; ++c) {
+                x[c] = __builtin_fmaf(bc[rr][c], kLog2e, Rc[c]);   // (b + R) log2 e, one fma: |b| <= 60, |R| <= kRenorm + 60
+                e[c] = fast_exp2(x[c]);
+            }
             if constexpr (!STATE_ONLY) {
                 uint2 pq;
-                unpack4(*reinterpret_cast<const uint2*>(&s_rq[rp * PE + rr * DK + ch0]), f);
-                pq.x = pack_bf16x2(f[0] * scale * e[0], f[1] * scale * e[1]);   // rows >= nv: finite values, zeroed as packed words
-                pq.y = pack_bf16x2(f[2] * scale * e[2], f[3] * scale * e[3]);
+                unpack4(*reinterpret_cast<const uint2*>(rawp + rr * DK), f);
+                pq.x = pack_bf16x2(f[0] * e[0], f[1] * e[1]);   // rows >= nv: finite values, zeroed as packed words
+                pq.y = pack_bf16x2(f[2] * e[2], f[3] * e[3]);
                 pq.x = valid ? pq.x : 0u;
                 pq.y = valid ? pq.y : 0u;
-                *reinterpret_cast<uint2*>(&s_q[row * SQ + ch0]) = pq;
+                *reinterpret_cast<uint2*>(qkp + rr * SQ) = pq;
             }
-            unpack4(*reinterpret_cast<const uint2*>(&s_rk[rp * PE + rr * DK + ch0]), f);
+            unpack4(*reinterpret_cast<const uint2*>(rawp + RAWT + rr * DK), f);
             // k e^{-b} = k * rcp(e^{b}): v_rcp_f32 (1 ulp) + multiply; `/` and __fdividef both expand to the ~10-instruction
             // IEEE division sequence here (160 VALU instructions per thread and chunk)
             float ri[4];
@@ -192,39 +224,45 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             kk[rr].y = pack_bf16x2(f[2] * ri[2], f[3] * ri[3]);
             kk[rr].x = valid ? kk[rr].x : 0u;
             kk[rr].y = valid ? kk[rr].y : 0u;
-            if constexpr (!STATE_ONLY) *reinterpret_cast<uint2*>(&s_k[row * SK + ch0]) = kk[rr];
-            const uint2 rv = *reinterpret_cast<const uint2*>(&s_rv[rp * PE + rr * DK + ch0]);
+            if constexpr (!STATE_ONLY) *reinterpret_cast<uint2*>(qkp + C * SQ + rr * SQ) = kk[rr];
+            const uint2 rv = *reinterpret_cast<const uint2*>(rawp + 3 * RAWT + rr * DK);
             vv[rr] = valid ? rv : make_uint2(0u, 0u);
-            if (row == nv - 1) {                             // owner of the chunk's last row: R after the chunk, renorm request
-                float rn[4];
+            if (FULL ? (rr == 1 && rp == C / 2 - 1) : (row == nv - 1)) {   // owner of the chunk's last row: R after the chunk
                 bool need = false;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { rn[c] = bc[rr][c] + Rc[c]; need |= rn[c] < -kRenorm; }
-                *reinterpret_cast<float4*>(&s_Rn[ch0]) = make_float4(rn[0], rn[1], rn[2], rn[3]);
-                if (need) s_renorm = 1;
+                for (int c = 0; c < 4; ++c) need |= x[c] < -kRenorm * kLog2e;
+                *reinterpret_cast<float4*>(&s_Rn[ch0]) = make_float4(x[0], x[1], x[2], x[3]);
+                if (need) s_renorm[par] = 1;
                 if constexpr (STATE_ONLY)
                     *reinterpret_cast<float4*>(&s_dec[ch0]) =
                         make_float4(__expf(bc[rr][0]), __expf(bc[rr][1]), __expf(bc[rr][2]), __expf(bc[rr][3]));
             }
         }
-        // transposed pieces: element (channel ch0+i, tokens 2rp, 2rp+1) = one 4-byte word
-        const unsigned k0[4] = {kk[0].x & 0xffffu, kk[0].x >> 16, kk[0].y & 0xffffu, kk[0].y >> 16};
-        const unsigned k1[4] = {kk[1].x & 0xffffu, kk[1].x >> 16, kk[1].y & 0xffffu, kk[1].y >> 16};
-        const unsigned v0[4] = {vv[0].x & 0xffffu, vv[0].x >> 16, vv[0].y & 0xffffu, vv[0].y >> 16};
-        const unsigned v1[4] = {vv[1].x & 0xffffu, vv[1].x >> 16, vv[1].y & 0xffffu, vv[1].y >> 16};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<unsigned*>(&s_kT[(ch0 + i) * ST + 2 * rp]) = k0[i] | (k1[i] << 16);
-            *reinterpret_cast<unsigned*>(&s_vT[(ch0 + i) * ST + 2 * rp]) = v0[i] | (v1[i] << 16);
-        }
+        // transposed pieces: element (channel ch0+i, tokens 2rp, 2rp+1) = one 4-byte word = one byte permute of the two rows
+        bf16_t* const tp = &s_T[ch0 * ST + 2 * rp];
+        *reinterpret_cast<unsigned*>(tp) = byte_perm(kk[1].x, kk[0].x, 0x05040100u);
+        *reinterpret_cast<unsigned*>(tp + ST) = byte_perm(kk[1].x, kk[0].x, 0x07060302u);
+        *reinterpret_cast<unsigned*>(tp + 2 * ST) = byte_perm(kk[1].y, kk[0].y, 0x05040100u);
+        *reinterpret_cast<unsigned*>(tp + 3 * ST) = byte_perm(kk[1].y, kk[0].y, 0x07060302u);
+        *reinterpret_cast<unsigned*>(tp + DK * ST) = byte_perm(vv[1].x, vv[0].x, 0x05040100u);
+        *reinterpret_cast<unsigned*>(tp + DK * ST + ST) = byte_perm(vv[1].x, vv[0].x, 0x07060302u);
+        *reinterpret_cast<unsigned*>(tp + DK * ST + 2 * ST) = byte_perm(vv[1].y, vv[0].y, 0x05040100u);
+        *reinterpret_cast<unsigned*>(tp + DK * ST + 3 * ST) = byte_perm(vv[1].y, vv[0].y, 0x07060302u);
     };
+    using FullT = std::true_type;
+    using PartT = std::false_type;
 
     for (int c = tid; c < DK; c += 1024) s_R[c] = 0.0f;
-    if (tid == 0) { s_flag = 0; s_renorm = 0; }
+    if (tid < 2) { s_flag[tid] = 0; s_renorm[tid] = 0; }
+    if (tid == 2) s_cut = 0;
     dma_chunk(0, STATE_ONLY ? 1 : 0, 4);
     wait_vmem();
     __syncthreads();   // DMA of chunk 0 landed
-    int t0 = 0;
+    int t0 = 0, par = 0;                                      // par: chunk parity
+#ifdef LINA_K2_PROF
+    unsigned long long pacc[16] = {}, plast = clock64();
+    const unsigned long long pstart = plast;
+#endif
     while (t0 < T) {
         // nothing per-lane is carried across iterations: the wave index sits in an SGPR, the lane index comes from v_mbcnt
         // (a spilled index would be reloaded through vmcnt, the counter the in-flight DMA also uses, and stall on it)
@@ -236,16 +274,22 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         // ---------------- phase A: gate scan, scaled operands, transposed operands ----------------
         {
             float bc[2][4];
-            const bool viol = gate_scan(bc, nrem);
-            if (viol) s_flag = 1;
-            write_tiles(bc, n);
+            if (nrem >= C) {                                   // workgroup-uniform: the mask-free form
+                if (gate_scan(FullT{}, bc, nrem)) s_flag[par] = 1;
+                write_tiles(FullT{}, bc, C, par);
+            } else {
+                if (gate_scan(PartT{}, bc, nrem)) s_flag[par] = 1;
+                write_tiles(PartT{}, bc, n, par);
+            }
         }
+        K2_PROF(0);
         __syncthreads();   // (2) operand tiles ready; raw q,k,g,v consumed
+        K2_PROF(1);
         lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; rp = lane & 15; ch0 = 16 * w + 4 * (lane >> 4);
-        if (s_flag) {
+        if (s_flag[par]) {
             // ---- rare: the decay inside this chunk exceeds e^-60 -> cut the chunk at the first such row ----
             float bc[2][4];
-            gate_scan(bc, nrem);
+            gate_scan(PartT{}, bc, nrem);
             int nc = C;
 #pragma unroll
             for (int rr = 1; rr >= 0; --rr) {
@@ -254,52 +298,93 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 for (int c = 0; c < 4; ++c) bad |= (-bc[rr][c] > kFullMaxDecay);
                 if (bad) nc = 2 * rp + rr;
             }
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) nc = min(nc, shfl_xor_i(nc, m));
-            if (lane == 0) s_nw[w] = nc;
+            // first bad row of the workgroup through ONE LDS atomic (a shuffle reduction here made the compiler keep its six
+            // lane-permutation addresses live across the whole main loop)
+            if (nc < C) lds_atomic_max(&s_cut, C - nc);
             __syncthreads();
-#pragma unroll
-            for (int ww = 0; ww < 16; ++ww) n = min(n, s_nw[ww]);
-            n = max(n, 1);
-            if (tid == 0) s_flag = 0;
-            __syncthreads();   // everyone has read s_nw; the optimistic tiles are dead
-            write_tiles(bc, n);
+            n = max(min(n, C - s_cut), 1);
+            __syncthreads();   // everyone has read s_cut; the optimistic tiles are dead
+            if (tid == 0) s_cut = 0;
+            write_tiles(PartT{}, bc, n, par);
             __syncthreads();
         }
-        const bool renorm = s_renorm != 0;                    // workgroup-uniform: set in phase A, reset after (2b)
+        const bool renorm = s_renorm[par] != 0;               // workgroup-uniform: set in phase A, reset one chunk later
         if (t0 + n < T) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);   // next chunk's raw q,k,g,v fly under phase B
         if (STATE_ONLY && w == 0) {                                    // s_dec is stable between barriers (2) and (3)
             const float4 d = *reinterpret_cast<const float4*>(&s_dec[4 * lane]);
             decp.x *= d.x; decp.y *= d.y; decp.z *= d.z; decp.w *= d.w;
         }
+        // next chunk's R: s_R is read by phase A only (before (2) / after (3)), s_Rn is stable between (2) and (3)
+        if (tid < DK) s_R[tid] = renorm ? 0.0f : s_Rn[tid];
+        K2_PROF(2);
 
         // ---------------- phase B ----------------
+        // Every LDS operand read below is issued SEVERAL MFMAs ahead of its use by hand (rings of fragment registers +
+        // sched_fence()): left to itself the compiler issues each read right before its MFMA under this register
+        // pressure and every MFMA then eats a full LDS round trip (3400 of 12400 clocks per chunk in step (1) alone).
         f32x4 acc[2];            // o^T: this wave's 16 columns (rows 4lg + r) x tokens [16nt, 16nt+16) (column li)
         acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (!STATE_ONLY) {
             if (w < 4) {
-                // (2) A^T[s][t] = k~_s . q~_t, computed ONCE per workgroup by waves 0..3: wave w takes the whole 16 x 16
-                //     tile (mt = w&1: s block, nt = w>>1: t block), 8 MFMAs over the 256 channels.  Its C/D layout
-                //     (col t = li, rows s = 4lg + r) is exactly where step (3)'s A operand wants the values: lane
+                // (2) A^T[s][t] = k~_s . q~_t, computed ONCE per workgroup by waves 0..3 (one per SIMD): wave w takes the
+                //     whole 16 x 16 tile (mt = w&1: s block, nt = w>>1: t block), 8 MFMAs over the 256 channels.  Its C/D
+                //     layout (col t = li, rows s = 4lg + r) is exactly where step (3)'s A operand wants the values: lane
                 //     (li = t&15, lg) slot j of tile nt holds A[t][s] with s = 4lg + j (s block 0) or 16 + 4lg + (j-4)
                 //     (s block 1) -- so each lane masks (s <= t) and stores its 4 values as one 8-byte piece.
+                wave_priority<2>();                            // the SIMD's one wave with extra work goes first
                 const int mt = w & 1, nt = w >> 1;
+                const int pc = 8 * (lg ^ ((li >> 2) & 3));    // swizzled piece of this lane's row
+                const bf16_t* kp = &s_k[(16 * mt + li) * SK + pc];
+                const bf16_t* qp = &s_q[(16 * nt + li) * SQ + pc];
+                bf16x8 kf[4], qf[4];                           // ring, 3 k-steps ahead
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) { kf[ks] = frag16(kp + 32 * ks); qf[ks] = frag16(qp + 32 * ks); }
                 f32x4 at = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    const int cc = 32 * ks + 8 * lg;
-                    at = mfma_bf16_16x16x32(frag16(&s_k[(16 * mt + li) * SK + cc]), frag16(&s_q[(16 * nt + li) * SQ + cc]), at);
+                    if (ks + 3 < 8) { kf[(ks + 3) & 3] = frag16(kp + 32 * (ks + 3)); qf[(ks + 3) & 3] = frag16(qp + 32 * (ks + 3)); }
+                    sched_fence();
+                    at = mfma_bf16_16x16x32(kf[ks & 3], qf[ks & 3], at);
+                    sched_fence();
                 }
                 const int t = 16 * nt + li, sb = 16 * mt + 4 * lg;
                 uint2 pa;
                 pa.x = pack_bf16x2(sb <= t ? at[0] : 0.0f, sb + 1 <= t ? at[1] : 0.0f);
                 pa.y = pack_bf16x2(sb + 2 <= t ? at[2] : 0.0f, sb + 3 <= t ? at[3] : 0.0f);
                 *reinterpret_cast<uint2*>(&s_A[(nt * 64 + lane) * 8 + 4 * mt]) = pa;
+                wave_priority<0>();
             }
+            K2_PROF(3);
+        }
+        const bf16_t* ktp = &s_kT[li * ST + 8 * lg];          // k~^T fragment of state tile p: + 16 p ST
+        bf16x8 tf[8];                                          // ring of k~^T fragments, 5 tiles ahead
+        bf16x8 vb2;                                            // v^T fragment of step (4) (tokens as k-slots 8lg..8lg+7)
+        if constexpr (!STATE_ONLY) {
             // (1) o = q~ . S_old : one K = 32 MFMA per pair of 16-row state tiles (converted to bf16 in registers)
+            const bf16_t* qp = &s_q[li * SQ + 8 * (lg ^ ((li >> 2) & 3))];
+            bf16x8 qf[4][2];                                   // ring, 3 tile pairs ahead
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) qf[pp][nt] = frag16(qp + 16 * nt * SQ + 32 * pp);
 #pragma unroll
             for (int pp = 0; pp < (LINA_K2_ABL == 3 ? 0 : 8); ++pp) {
+                if (pp + 3 < 8) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        qf[(pp + 3) & 3][nt] = frag16(qp + 16 * nt * SQ + 32 * (pp + 3));
+                } else if (pp == 5) {                          // the ring's free slots take step (4)'s first operands
+                    vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
+                    tf[0] = frag16(ktp);
+                } else if (pp == 6) {
+                    tf[1] = frag16(ktp + 16 * ST);
+                    tf[2] = frag16(ktp + 32 * ST);
+                } else {
+                    tf[3] = frag16(ktp + 48 * ST);
+                    tf[4] = frag16(ktp + 64 * ST);
+                }
+                sched_fence();
                 bf16x8 bb;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -307,63 +392,78 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                     bb[4 + r] = (short)f2bf(S[2 * pp + 1][r]);
                 }
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const bf16_t* qp = &s_q[(16 * nt + li) * SQ + 32 * pp + 4 * lg];
-                    acc[nt] = mfma_bf16_16x16x32(bb, frag8x2(qp, qp + 16), acc[nt]);   // o^T: rows = state columns, cols = tokens
-                }
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[nt] = mfma_bf16_16x16x32(bb, qf[pp & 3][nt], acc[nt]);   // o^T: rows = state columns, cols = tokens
+                sched_fence();
+            }
+        } else {
+            vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
+#pragma unroll
+            for (int p = 0; p < 5; ++p) tf[p] = frag16(ktp + 16 * p * ST);
+        }
+        K2_PROF(4);
+        // (4) S' += k^^T v
+#pragma unroll
+        for (int p = 0; p < (LINA_K2_ABL == 4 ? 0 : 16); ++p) {
+            if (p + 5 < 16) tf[(p + 5) & 7] = frag16(ktp + 16 * (p + 5) * ST);
+            sched_fence();
+            S[p] = mfma_bf16_16x16x32(tf[p & 7], vb2, S[p]);
+            sched_fence();
+        }
+        if (renorm) {                                    // rare: S' <- e^{R} S' (R = s_Rn, the value after this chunk)
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const float4 r4 = *reinterpret_cast<const float4*>(&s_Rn[16 * p + 4 * lg]);
+                S[p][0] *= fast_exp2(r4.x); S[p][1] *= fast_exp2(r4.y); S[p][2] *= fast_exp2(r4.z); S[p][3] *= fast_exp2(r4.w);
             }
         }
-        lds_barrier();     // (2b) mask(A) complete, s_k free for the o tile.  LDS-only barrier: the prefetch issued after (2)
-                           // stays in flight until the full barrier (3)
-        if (tid == 0) s_flag = 0;   // every wave has read it (right after (2)); the next chunk's phase A may set it again
-        if (tid == 0) s_renorm = 0;
-        if (tid < DK) s_R[tid] = renorm ? 0.0f : s_Rn[tid];   // next chunk's R; phase A reads it after barrier (3)
-        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;   // re-derive, do not carry
+        // v fragment of step (3) (same token order as the C/D rows of mask(A)): read before the tiles die at (3)
+        bf16x8 vb;
         if constexpr (!STATE_ONLY) {
-            // (3) o += mask(A) . v ; v fragments in the same token order as the C/D rows
-            {
-                const bf16_t* vp = &s_vT[(16 * w + li) * ST + 4 * lg];
-                const bf16x8 vb = frag8x2(vp, vp + 16);
-                acc[0] = mfma_bf16_16x16x32(vb, frag16(&s_A[(0 * 64 + lane) * 8]), acc[0]);   // o^T += v^T . mask(A)^T
-                acc[1] = mfma_bf16_16x16x32(vb, frag16(&s_A[(1 * 64 + lane) * 8]), acc[1]);
-            }
+            const bf16_t* vp = &s_vT[(16 * w + li) * ST + 4 * lg];
+            vb = frag8x2(vp, vp + 16);
         }
-        // (4) S <- e^{b_last} (S + k~^T v)
-        {
-            const bf16x8 vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
-#pragma unroll
-            for (int p = 0; p < (LINA_K2_ABL == 4 ? 0 : 16); ++p)
-                S[p] = mfma_bf16_16x16x32(frag16(&s_kT[(16 * p + li) * ST + 8 * lg]), vb2, S[p]);
-            if (renorm) {                                // rare: S' <- e^{R} S' (R = s_Rn, the value after this chunk)
-#pragma unroll
-                for (int p = 0; p < 16; ++p) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(&s_Rn[16 * p + 4 * lg]);
-                    S[p][0] *= __expf(r4.x); S[p][1] *= __expf(r4.y); S[p][2] *= __expf(r4.z); S[p][3] *= __expf(r4.w);
-                }
-            }
-        }
+        K2_PROF(5);
         wait_vmem();       // the prefetch was issued through inline assembly: this wave's part has landed ...
-        __syncthreads();   // (3) ... and so has everybody's; operand tiles dead
+        K2_PROF(8);
+        __syncthreads();   // (3) ... and so has everybody's; operand tiles dead; mask(A) complete (its own buffer)
+        K2_PROF(9);
+        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;   // re-derive, do not carry
+        if (tid == 0) { s_flag[par] = 0; s_renorm[par] = 0; }   // read by all before (3); set again two chunks later, after (2) of the next
         if constexpr (!STATE_ONLY) {
-            // o straight from the accumulators, AFTER the barrier (so that the wait above does not include these stores: they
-            // drain under the next chunk's phase A).  The products were taken TRANSPOSED (state / v as the A operand), so a
-            // lane holds 4 consecutive columns of ONE token = one 8-byte store; the 16 waves' 32-byte pieces of a 512-byte
-            // row meet in L2.  No LDS staging, no read-back, no barrier (4).
-            lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
+            // (3) o += mask(A) . v -- AFTER the barrier: no barrier of its own for mask(A); s_A is rewritten only after the
+            //     next chunk's barrier (2)
+            acc[0] = mfma_bf16_16x16x32(vb, frag16(&s_A[(0 * 64 + lane) * 8]), acc[0]);   // o^T += v^T . mask(A)^T
+            acc[1] = mfma_bf16_16x16x32(vb, frag16(&s_A[(1 * 64 + lane) * 8]), acc[1]);
+            K2_PROF(7);
+            // o straight from the accumulators (the stores drain under the next chunk's phase A).  The products were taken
+            // TRANSPOSED (state / v as the A operand), so a lane holds 4 consecutive columns of ONE token = one 8-byte
+            // store; the 16 waves' 32-byte pieces of a 512-byte row meet in L2.  No LDS staging, no read-back.
 #pragma unroll
             for (int nt = 0; nt < (LINA_K2_ABL == 8 ? 0 : 2); ++nt) {
                 const int row = 16 * nt + li;
                 uint2 po;
-                po.x = pack_bf16x2(acc[nt][0], acc[nt][1]);
-                po.y = pack_bf16x2(acc[nt][2], acc[nt][3]);
+                po.x = pack_bf16x2(acc[nt][0] * scale, acc[nt][1] * scale);
+                po.y = pack_bf16x2(acc[nt][2] * scale, acc[nt][3] * scale);
                 if (row < n && LINA_K2_ABL != 7) {
                     const unsigned boff = 2u * ((unsigned)(t0 + row) * (unsigned)so.t + 16u * (unsigned)w + 4u * (unsigned)lg);
                     *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) + boff) = po;
                 }
             }
         }
+        par ^= 1;
         t0 += n;
+        K2_PROF(10);
     }
+#ifdef LINA_K2_PROF
+    if (blockIdx.x == 0 && lane_id() == 0)
+        for (int i = 0; i < 16; ++i) lina_k2_prof[w_s * 16 + i] = pacc[i];
+    if (blockIdx.x < 1024 && w_s == 0 && lane_id() == 0) {
+        lina_k2_prof[256 + 3 * blockIdx.x] = clock64() - pstart;
+        lina_k2_prof[256 + 3 * blockIdx.x + 1] = pacc[8];
+        lina_k2_prof[256 + 3 * blockIdx.x + 2] = pacc[9];
+    }
+#endif
 
     if (STATE_ONLY && dec_out && w == 0)
         *reinterpret_cast<float4*>(dec_out + (int64_t)slot * DK + 4 * lane) = decp;
@@ -372,7 +472,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 #pragma unroll
         for (int p = 0; p < 16; ++p) {                       // S = diag(e^{R}) S'
             const float4 r4 = *reinterpret_cast<const float4*>(&s_R[16 * p + 4 * lg]);
-            S[p][0] *= __expf(r4.x); S[p][1] *= __expf(r4.y); S[p][2] *= __expf(r4.z); S[p][3] *= __expf(r4.w);
+            S[p][0] *= fast_exp2(r4.x); S[p][1] *= fast_exp2(r4.y); S[p][2] *= fast_exp2(r4.z); S[p][3] *= fast_exp2(r4.w);
         }
         float* hp = ht + ((int64_t)slot * DK + 4 * lg) * DV + 16 * w + li;
 #pragma unroll
@@ -475,3 +575,9 @@ extern "C" int lina_gla_chunk_fwd_seg(const void* q, const void* k, const void* 
                 T, ns, Tseg, sq, sk, sv, sg, so, scale);
     return check_launch("lina_gla_chunk_fwd_seg");
 }
+
+#ifdef LINA_K2_PROF
+extern "C" int lina_k2_prof_read(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lina_k2_prof), sizeof(unsigned long long) * (256 + 3 * 1024));
+}
+#endif

@@ -124,8 +124,43 @@ __device__ __forceinline__ float dpp_row_shr(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
 }
 
+// inclusive scan of FOUR values over the 16 lanes of a DPP row, every step ONE fused add per value (v_add_f32_dpp: the
+// compiler emits v_mov_dpp + add).  Lanes whose source is outside the row add 0.  The leading s_nop covers the
+// VALU-write -> DPP-read hazard against whatever instruction precedes the block (the compiler does not look inside);
+// within a block the four values are interleaved, so a register is re-read three instructions after its write.
+#define LINA_DPP_STEP4(N)                                                                                       \
+    asm("s_nop 1\n\t"                                                                                           \
+        "v_add_f32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                  \
+        "v_add_f32_dpp %1, %1, %1 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                  \
+        "v_add_f32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                  \
+        "v_add_f32_dpp %3, %3, %3 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1"                       \
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+__device__ __forceinline__ void row_scan4(float& a, float& b, float& c, float& d) {
+    LINA_DPP_STEP4(1);
+    LINA_DPP_STEP4(2);
+    LINA_DPP_STEP4(4);
+    LINA_DPP_STEP4(8);
+}
+#undef LINA_DPP_STEP4
+// max as ONE v_max_f32 (fmaxf first canonicalises an operand the compiler cannot prove quiet: two instructions)
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte value {hi:lo} (sel 0..3 -> lo, 4..7 -> hi)
+__device__ __forceinline__ unsigned byte_perm(unsigned hi, unsigned lo, unsigned sel) {
+    return __builtin_amdgcn_perm(hi, lo, sel);
+}
+// 2^x as one v_exp_f32
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // 1/x as one v_rcp_f32 (1 ulp)
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// scheduling fence: the compiler moves NO instruction across it (hand-placed software pipelines: LDS reads issued
+// several MFMAs ahead stay there); generates no code
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// instruction-issue priority of this wave among the waves of its SIMD (0 = default ... 3)
+template <int P> __device__ __forceinline__ void wave_priority() { __builtin_amdgcn_s_setprio(P); }
 
 // compiler-only fence: memory operations are not moved across it (keeps LDS-read hoisting, and with it
 // register pressure, bounded in the fully unrolled MFMA loops)

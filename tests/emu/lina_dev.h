@@ -250,7 +250,23 @@ static inline float dpp_row_shr(float v) {
     const int l = lina_emu::cur_lane();
     return (l & 15) >= N ? u2f(tab[l - N]) : 0.0f;
 }
+static inline void row_scan4(float& a, float& b, float& c, float& d) {
+    a += dpp_row_shr<1>(a); b += dpp_row_shr<1>(b); c += dpp_row_shr<1>(c); d += dpp_row_shr<1>(d);
+    a += dpp_row_shr<2>(a); b += dpp_row_shr<2>(b); c += dpp_row_shr<2>(c); d += dpp_row_shr<2>(d);
+    a += dpp_row_shr<4>(a); b += dpp_row_shr<4>(b); c += dpp_row_shr<4>(c); d += dpp_row_shr<4>(d);
+    a += dpp_row_shr<8>(a); b += dpp_row_shr<8>(b); c += dpp_row_shr<8>(c); d += dpp_row_shr<8>(d);
+}
+static inline float vmax_raw(float a, float b) { return a > b ? a : b; }
+static inline unsigned byte_perm(unsigned hi, unsigned lo, unsigned sel) {
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    unsigned r = 0;
+    for (int i = 0; i < 4; ++i) r |= (unsigned)((v >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
+    return r;
+}
+static inline float fast_exp2(float x) { return exp2f(x); }
 static inline float fast_rcp(float x) { return 1.0f / x; }
+static inline void sched_fence() {}
+template <int P> static inline void wave_priority() {}
 static inline void cfence() { asm volatile("" ::: "memory"); }
 
 static inline void opaque(int& x) { asm volatile("" : "+r"(x)); }

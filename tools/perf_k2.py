@@ -26,3 +26,23 @@ dt = e0.elapsed_time(e1) * 1e-3 / reps
 nbytes = B * H * T * 2 * (3 * Dk + 2 * Dv)
 print(f"K2 B={B} T={T}: {dt*1e3:.3f} ms  {nbytes/dt/1e9:.1f} GB/s ({nbytes/dt/8e12*100:.1f}% of 8 TB/s)  "
       f"{dt/(T/32)*2.4e9:.0f} clk/chunk @2.4GHz")
+if os.environ.get("K2_PROF"):
+    import ctypes, numpy as np
+    from lina_speech_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    ops.chunk_gla(q, k, v, gk, output_final_state=True)
+    torch.cuda.synchronize()
+    buf = np.zeros(256 + 3 * 1024, dtype=np.uint64)
+    rc = lib.lina_k2_prof_read(buf.ctypes.data_as(ctypes.c_void_p))
+    a = buf[:256].reshape(16, 16).astype(np.float64) / (T / 32)
+    names = ["phaseA", "bar(2)", "flag+dma", "maskA(w<4)", "step1 qS", "step4 upd", "-", "step3 Av", "wait_vmem",
+             "bar(3)", "o stores"]
+    print("clk/chunk per phase (shader clock), waves 0, 3, 4, 15 and mean:  rc =", rc)
+    for i, nm in enumerate(names):
+        print(f"  {nm:12s} " + " ".join(f"{a[w, i]:8.0f}" for w in (0, 3, 4, 15)) + f"   mean {a[:, i].mean():8.0f}")
+    print(f"  total        {a[0, :11].sum():8.0f}")
+    wg = buf[256:256 + 3 * B * H].reshape(-1, 3).astype(np.float64) / (T / 32)
+    print("per-workgroup clk/chunk (wave 0): total min/median/max", np.min(wg[:, 0]), np.median(wg[:, 0]), np.max(wg[:, 0]),
+          " wait_vmem median/max", np.median(wg[:, 1]), np.max(wg[:, 1]), " bar(3) median/max", np.median(wg[:, 2]), np.max(wg[:, 2]))
+    order = np.argsort(wg[:, 0])
+    print("slowest workgroups:", order[-8:], wg[order[-8:], 0].round(), " fastest:", order[:8], wg[order[:8], 0].round())
