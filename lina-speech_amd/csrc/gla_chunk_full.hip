@@ -135,17 +135,27 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     bf16_t* ob = STATE_ONLY ? nullptr : o + b * so.b + h * so.h + t_begin * so.t;
     float4 decp = make_float4(1.f, 1.f, 1.f, 1.f);            // STATE_ONLY, wave 0: product of the chunk decays, channels 4*lane..+3
 
-    // wave w DMAs row pair w (rows 2w, 2w+1) of each raw tile: one instruction = 2 rows x 512 B, 16 B per lane.
+    // One DMA instruction = one row pair (2 rows x 512 B, 16 B per lane) of one raw tile.  A DMA instruction blocks its wave
+    // for 30+ clocks and the 64 of a chunk queue up in the address unit (~1800 clocks): when every wave issued its own four
+    // after barrier (2), the waves at the end of that queue started their MFMAs ~1300 clocks late and everybody waited for
+    // them at (3).  So ONLY the last four waves (one per SIMD, the lowest issue priority) issue DMAs, 16 each (row pairs
+    // 4(w-12) .. +3); the other twelve go straight to their MFMAs and the four catch up on SIMDs the others have left.
     // Rows past the end of the sequence re-read row T-1 (always mapped); phase A masks them.
+    constexpr int kDmaWave0 = 12;
     auto dma_chunk = [&](int t_first, int a_lo, int a_hi) {
+        if (w < kDmaWave0) return;
 #pragma unroll
         for (int a = a_lo; a < a_hi; ++a) {
-            const unsigned t = (unsigned)min(t_first + 2 * w + (lane >> 5), T - 1);
-            bf16_t* dst = a == 0 ? s_rq : a == 1 ? s_rk : a == 2 ? s_rg : s_rv;                     // a is a compile-time index
-            // uniform base + 32-bit BYTE offset per lane (< 2^32: launcher guard): selects the SGPR-base addressing form,
-            // no 64-bit per-lane address arithmetic (whose zero high word the compiler kept in -- and spilled from -- a VGPR)
-            const unsigned boff = 2u * (t * gst[a] + 8u * (unsigned)(lane & 31));
-            dma16_to_lds_async(gsrc[a], boff, &dst[w * PE]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pair = 4 * (w - kDmaWave0) + j;
+                const unsigned t = (unsigned)min(t_first + 2 * pair + (lane >> 5), T - 1);
+                bf16_t* dst = a == 0 ? s_rq : a == 1 ? s_rk : a == 2 ? s_rg : s_rv;                 // a is a compile-time index
+                // uniform base + 32-bit BYTE offset per lane (< 2^32: launcher guard): selects the SGPR-base addressing form,
+                // no 64-bit per-lane address arithmetic (whose zero high word the compiler kept in -- and spilled from -- a VGPR)
+                const unsigned boff = 2u * (t * gst[a] + 8u * (unsigned)(lane & 31));
+                dma16_to_lds_async(gsrc[a], boff, &dst[pair * PE]);
+            }
         }
     };
 
@@ -259,6 +269,28 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     wait_vmem();
     __syncthreads();   // DMA of chunk 0 landed
     int t0 = 0, par = 0;                                      // par: chunk parity
+    int tp = 0, np = 0;                                       // previous chunk: its o is stored at the END of the next phase A
+    f32x4 acc[2] = {};       // o^T: this wave's 16 columns (rows 4lg + r) x tokens [16nt, 16nt+16) (column li)
+    // o straight from the accumulators.  The products were taken TRANSPOSED (state / v as the A operand), so a lane holds 4
+    // consecutive columns of ONE token = one 8-byte store; the 16 waves' 32-byte pieces of a 512-byte row meet in L2.  No LDS
+    // staging, no read-back.  Issued at the end of the NEXT chunk's phase A: a store blocks its wave while the address unit
+    // is busy, and right after barrier (3) all 32 of them queued up in front of phase A; a wave that finishes phase A early
+    // stores while the others still compute.
+    auto store_prev = [&]() {
+        if constexpr (!STATE_ONLY) {
+#pragma unroll
+            for (int nt = 0; nt < (LINA_K2_ABL == 8 ? 0 : 2); ++nt) {
+                const int row = 16 * nt + li;
+                uint2 po;
+                po.x = pack_bf16x2(acc[nt][0] * scale, acc[nt][1] * scale);
+                po.y = pack_bf16x2(acc[nt][2] * scale, acc[nt][3] * scale);
+                if (row < np && LINA_K2_ABL != 7) {
+                    const unsigned boff = 2u * ((unsigned)(tp + row) * (unsigned)so.t + 16u * (unsigned)w + 4u * (unsigned)lg);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) + boff) = po;
+                }
+            }
+        }
+    };
 #ifdef LINA_K2_PROF
     unsigned long long pacc[16] = {}, plast = clock64();
     const unsigned long long pstart = plast;
@@ -283,6 +315,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             }
         }
         K2_PROF(0);
+        if (np > 0) store_prev();
+        K2_PROF(10);
         __syncthreads();   // (2) operand tiles ready; raw q,k,g,v consumed
         K2_PROF(1);
         lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; rp = lane & 15; ch0 = 16 * w + 4 * (lane >> 4);
@@ -322,7 +356,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         // Every LDS operand read below is issued SEVERAL MFMAs ahead of its use by hand (rings of fragment registers +
         // sched_fence()): left to itself the compiler issues each read right before its MFMA under this register
         // pressure and every MFMA then eats a full LDS round trip (3400 of 12400 clocks per chunk in step (1) alone).
-        f32x4 acc[2];            // o^T: this wave's 16 columns (rows 4lg + r) x tokens [16nt, 16nt+16) (column li)
         acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (!STATE_ONLY) {
@@ -436,25 +469,13 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             acc[0] = mfma_bf16_16x16x32(vb, frag16(&s_A[(0 * 64 + lane) * 8]), acc[0]);   // o^T += v^T . mask(A)^T
             acc[1] = mfma_bf16_16x16x32(vb, frag16(&s_A[(1 * 64 + lane) * 8]), acc[1]);
             K2_PROF(7);
-            // o straight from the accumulators (the stores drain under the next chunk's phase A).  The products were taken
-            // TRANSPOSED (state / v as the A operand), so a lane holds 4 consecutive columns of ONE token = one 8-byte
-            // store; the 16 waves' 32-byte pieces of a 512-byte row meet in L2.  No LDS staging, no read-back.
-#pragma unroll
-            for (int nt = 0; nt < (LINA_K2_ABL == 8 ? 0 : 2); ++nt) {
-                const int row = 16 * nt + li;
-                uint2 po;
-                po.x = pack_bf16x2(acc[nt][0] * scale, acc[nt][1] * scale);
-                po.y = pack_bf16x2(acc[nt][2] * scale, acc[nt][3] * scale);
-                if (row < n && LINA_K2_ABL != 7) {
-                    const unsigned boff = 2u * ((unsigned)(t0 + row) * (unsigned)so.t + 16u * (unsigned)w + 4u * (unsigned)lg);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) + boff) = po;
-                }
-            }
         }
+        tp = t0; np = n;
         par ^= 1;
         t0 += n;
-        K2_PROF(10);
     }
+    lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
+    store_prev();                                              // the last chunk (T >= 1)
 #ifdef LINA_K2_PROF
     if (blockIdx.x == 0 && lane_id() == 0)
         for (int i = 0; i < 16; ++i) lina_k2_prof[w_s * 16 + i] = pacc[i];

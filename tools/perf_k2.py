@@ -35,7 +35,7 @@ if os.environ.get("K2_PROF"):
     buf = np.zeros(256 + 3 * 1024, dtype=np.uint64)
     rc = lib.lina_k2_prof_read(buf.ctypes.data_as(ctypes.c_void_p))
     a = buf[:256].reshape(16, 16).astype(np.float64) / (T / 32)
-    names = ["phaseA", "bar(2)", "flag+dma", "maskA(w<4)", "step1 qS", "step4 upd", "-", "step3 Av", "wait_vmem",
+    names = ["phaseA", "bar(2)", "flags/roll", "maskA(w<4)", "step1 qS", "step4 upd", "bar(1')+dma", "rawrd+step3", "wait_vmem",
              "bar(3)", "o stores"]
     print("clk/chunk per phase (shader clock), waves 0, 3, 4, 15 and mean:  rc =", rc)
     for i, nm in enumerate(names):
