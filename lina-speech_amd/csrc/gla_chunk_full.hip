@@ -107,7 +107,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     float* const s_R = s_Rs;              // R used by this chunk's phase A
     float* const s_Rn = s_Rs + DK;        // R after this chunk (written by the owners of the last row)
     float* const s_dec = s_Rs + 2 * DK;   // e^{b_last} of this chunk (STATE_ONLY: segment decay product)
-    __shared__ int s_flag[2], s_renorm[2], s_cut;   // flags: one set per chunk parity (reset one chunk later)
+    // flags {cut needed, renormalise} per chunk parity (reset one chunk later): adjacent, so that ONE 8-byte read right after
+    // barrier (2) fetches both (three dependent LDS round trips -- flag, flag, R -- sat in front of every wave's MFMAs)
+    __shared__ __attribute__((aligned(8))) unsigned s_flags[4];
+    __shared__ int s_cut;
 
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int w_s = wave_uniform(w);                         // wave index in an SGPR for the whole kernel
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 #pragma unroll
                 for (int c = 0; c < 4; ++c) need |= x[c] < -kRenorm * kLog2e;
                 *reinterpret_cast<float4*>(&s_Rn[ch0]) = make_float4(x[0], x[1], x[2], x[3]);
-                if (need) s_renorm[par] = 1;
+                if (need) s_flags[2 * par + 1] = 1;
                 if constexpr (STATE_ONLY)
                     *reinterpret_cast<float4*>(&s_dec[ch0]) =
                         make_float4(__expf(bc[rr][0]), __expf(bc[rr][1]), __expf(bc[rr][2]), __expf(bc[rr][3]));
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     using PartT = std::false_type;
 
     for (int c = tid; c < DK; c += 1024) s_R[c] = 0.0f;
-    if (tid < 2) { s_flag[tid] = 0; s_renorm[tid] = 0; }
+    if (tid < 4) s_flags[tid] = 0;
     if (tid == 2) s_cut = 0;
     dma_chunk(0, STATE_ONLY ? 1 : 0, 4);
     wait_vmem();
@@ -307,10 +310,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         {
             float bc[2][4];
             if (nrem >= C) {                                   // workgroup-uniform: the mask-free form
-                if (gate_scan(FullT{}, bc, nrem)) s_flag[par] = 1;
+                if (gate_scan(FullT{}, bc, nrem)) s_flags[2 * par] = 1;
                 write_tiles(FullT{}, bc, C, par);
             } else {
-                if (gate_scan(PartT{}, bc, nrem)) s_flag[par] = 1;
+                if (gate_scan(PartT{}, bc, nrem)) s_flags[2 * par] = 1;
                 write_tiles(PartT{}, bc, n, par);
             }
         }
@@ -320,7 +323,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         __syncthreads();   // (2) operand tiles ready; raw q,k,g,v consumed
         K2_PROF(1);
         lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; rp = lane & 15; ch0 = 16 * w + 4 * (lane >> 4);
-        if (s_flag[par]) {
+        uint2 fl = *reinterpret_cast<const uint2*>(&s_flags[2 * par]);   // workgroup-uniform
+        float rn = tid < DK ? s_Rn[tid] : 0.0f;                 // for the roll of R below, fetched in the same round trip
+        if (fl.x) {
             // ---- rare: the decay inside this chunk exceeds e^-60 -> cut the chunk at the first such row ----
             float bc[2][4];
             gate_scan(PartT{}, bc, nrem);
@@ -341,15 +346,17 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             if (tid == 0) s_cut = 0;
             write_tiles(PartT{}, bc, n, par);
             __syncthreads();
+            fl.y = s_flags[2 * par + 1];                       // the rewritten tiles may have changed both
+            rn = tid < DK ? s_Rn[tid] : 0.0f;
         }
-        const bool renorm = s_renorm[par] != 0;               // workgroup-uniform: set in phase A, reset one chunk later
+        const bool renorm = fl.y != 0;                         // workgroup-uniform: set in phase A, reset one chunk later
         if (t0 + n < T) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);   // next chunk's raw q,k,g,v fly under phase B
         if (STATE_ONLY && w == 0) {                                    // s_dec is stable between barriers (2) and (3)
             const float4 d = *reinterpret_cast<const float4*>(&s_dec[4 * lane]);
             decp.x *= d.x; decp.y *= d.y; decp.z *= d.z; decp.w *= d.w;
         }
         // next chunk's R: s_R is read by phase A only (before (2) / after (3)), s_Rn is stable between (2) and (3)
-        if (tid < DK) s_R[tid] = renorm ? 0.0f : s_Rn[tid];
+        if (tid < DK) s_R[tid] = renorm ? 0.0f : rn;
         K2_PROF(2);
 
         // ---------------- phase B ----------------
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         __syncthreads();   // (3) ... and so has everybody's; operand tiles dead; mask(A) complete (its own buffer)
         K2_PROF(9);
         lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;   // re-derive, do not carry
-        if (tid == 0) { s_flag[par] = 0; s_renorm[par] = 0; }   // read by all before (3); set again two chunks later, after (2) of the next
+        if (tid == 0) { s_flags[2 * par] = 0; s_flags[2 * par + 1] = 0; }   // read by all before (3); set again two chunks later, after (2) of the next
         if constexpr (!STATE_ONLY) {
             // (3) o += mask(A) . v -- AFTER the barrier: no barrier of its own for mask(A); s_A is rewritten only after the
             //     next chunk's barrier (2)
