@@ -8,21 +8,22 @@
 //     q~ = scale q e^{b}, k~ = k e^{-b}, o = q~ S + mask(q~ k~^T) v,  S <- e^{b_last} (S + k~^T v)
 // with chunks of C = 32 tokens, cut adaptively when the in-chunk decay would exceed e^-60.
 //
-// 1024 threads = 16 waves = 4 per SIMD at <= 128 VGPRs: enough waves to hide the LDS / barrier latency of
-// the phase structure below (the 8-wave / 32x32-tile predecessor of this kernel spent 63 % of its wave
-// cycles waiting and spilled registers; profiles/r01_k2_pmc.md).  Per chunk:
-//   A  the chunk's raw q,k,g,v tiles are already in LDS (asynchronous global->LDS DMA issued one chunk ahead,
-//      no staging registers); thread (rg = tid>>6, co = tid&63) owns rows {2rg,2rg+1} x channels 4co..4co+3:
-//      gate scan (2-row sums -> LDS -> exclusive scan over the 16 row groups), q~,k~ computed in registers and
-//      written to LDS as bf16 row-major tiles; a second pass gathers k~^T[c][t] and v^T[col][t] (the MFMA
-//      operands whose K dimension is the token axis) conflict-free.
-//   B  wave w owns state columns [16w, 16w+16), tiles p = rows [16p,16p+16) in C/D layout
-//      (col = lane&15, row = 4*(lane>>4)+reg):  (2) A^T = k~ . q~^T (32 x 32 as 2x2 tiles) once per workgroup
-//      (waves 0..3: one whole tile each, stored masked straight into the A-operand layout of step (3));
-//      (1) o = q~ . S with the state tiles consumed DIRECTLY as the B operand (the A operand uses the matching
-//      k-slot -> channel map); (3) o += mask(A) . v with A^T's registers re-used as the A operand;
-//      (4) S += k~^T . v, rows scaled by e^{b_last}.  36 x v_mfma_f32_16x16x32_bf16 per wave per chunk.
-//      o is staged through LDS and stored 16 B per lane.
+// 1024 threads = 16 waves = 4 per SIMD at <= 128 VGPRs (64 of them the state).  Per chunk, two barriers:
+//   A  the chunk's raw q,k,g,v tiles are already in LDS (asynchronous global->LDS DMA issued one chunk ahead by the last
+//      four waves, no staging registers).  Wave w <-> channels [16w, 16w+16); lane = (channel quad, row pair): the gate
+//      scan over the 16 row pairs is four fused DPP adds per value inside one 16-lane row; the thread scales its two
+//      tokens x four channels (q~ = q e^{b+R}, k~ = k e^{-b-R}; R = log-decay carried by the UN-normalised state) and
+//      writes q~ / k~ row-major (channel-permuted, XOR-swizzled: every later operand read is one conflict-free
+//      ds_read_b128) and k~^T / v^T (the operands whose K dimension is the token axis) as 4-byte pieces.  The previous
+//      chunk's o is stored at the end of this phase.                                             -- barrier (2) --
+//   B  wave w owns state columns [16w, 16w+16), tiles p = rows [16p,16p+16) in C/D layout (col = lane&15,
+//      row = 4*(lane>>4)+reg):  (2) A^T = k~ . q~^T (32 x 32 as 2x2 tiles) once per workgroup (waves 0..3: one whole
+//      tile each, stored masked straight into the A-operand layout of step (3)); (1) o^T = S'^T-tiles . q~^T with the
+//      state tiles consumed DIRECTLY as the A operand (converted to bf16 in registers); (4) S' += k~^T . v.  All LDS
+//      operand reads are issued 3-5 MFMAs ahead by hand (fragment rings + sched_fence()).  36 x
+//      v_mfma_f32_16x16x32_bf16 per wave per chunk.                                              -- barrier (3) --
+//      (3) o^T += v^T . mask(A)^T after the barrier (mask(A) has its own buffer), o carried in registers to the next
+//      phase A's end.  1/sqrt(Dk) is applied to o.  History and measurements: DESIGN.md 4.2.
 #include <type_traits>
 #include <lina_dev.h>
 #include "lina_common.h"
