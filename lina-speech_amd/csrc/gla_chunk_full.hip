@@ -177,22 +177,20 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         unpack4(*reinterpret_cast<const uint2*>(gp), g0);
         unpack4(*reinterpret_cast<const uint2*>(gp + DK), g1);
         const bool in0 = FULL || 2 * rp < nrem, in1 = FULL || 2 * rp + 1 < nrem;
-        float tot[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             g0[c] = vmax_raw(g0[c], -kFullMaxDecay);
             g1[c] = vmax_raw(g1[c], -kFullMaxDecay);
-            bc[0][c] = in0 ? g0[c] : 0.0f;
-            bc[1][c] = bc[0][c] + (in1 ? g1[c] : 0.0f);
-            tot[c] = bc[1][c];
+            g1[c] = in1 ? g1[c] : 0.0f;
+            bc[1][c] = (in0 ? g0[c] : 0.0f) + g1[c];         // the row pair's sum
         }
-        row_scan4(tot[0], tot[1], tot[2], tot[3]);           // inclusive scan over the 16 row pairs of this 16-lane row
+        // inclusive scan over the 16 row pairs of this 16-lane row, in place; the pair's first row is the pair's inclusive
+        // value minus the second row's gate
+        row_scan4(bc[1][0], bc[1][1], bc[1][2], bc[1][3]);
         bool viol = false;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float pre = tot[c] - bc[1][c];             // exclusive prefix of this row pair
-            bc[0][c] += pre;
-            bc[1][c] = tot[c];
+            bc[0][c] = bc[1][c] - g1[c];
             viol |= (-bc[1][c] > kFullMaxDecay);              // b is monotone: the last row pair sees the chunk total
         }
         return viol;

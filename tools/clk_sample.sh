@@ -6,7 +6,7 @@ pid=$!
 for i in $(seq 1 40); do
   sleep 0.7
   kill -0 $pid 2>/dev/null || break
-  rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Socket Power|Average" | tr '\n' ' '; echo
+  rocm-smi --showclocks --showpower 2>/dev/null | grep -iE "sclk|power" | tr '\n' ' '; echo
 done
 wait $pid
 tail -1 gpurun_out/clk_k2.log
