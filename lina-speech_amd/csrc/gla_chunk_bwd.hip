@@ -210,9 +210,14 @@ __device__ __forceinline__ f32x4 chunk_products_bf(f32x4 (&R)[D1 / 16], const Bf
 }
 
 // ===================================== sweep V : dv, dh0 ==========================================
-template <int DK, typename TIO, typename TG>
+// DMA = true (bf16 tensors AND gates, 16-byte aligned rows): the chunk's q,k,g rows do not come through 48 two-byte loads
+// per thread (one 128-byte load instruction per wave and row: 192 per chunk through an address unit that needs 16-30
+// clocks per instruction whatever its size) but as global->LDS DMA pieces of 1 KiB: wave w fetches the 16 rows x 64
+// channels IT reads (2 pieces per tensor: lane = (row, 16-byte piece), lane-linear in LDS) into a region of its own --
+// no barrier involved, the wave waits for its own pieces (wait_vmem) and reads its channel column with 2-byte LDS reads.
+template <int DK, typename TIO, typename TG, bool DMA>
 __device__ __forceinline__ void sweep_v(
-    float* smem, int slice, const TIO* __restrict__ q, const TIO* __restrict__ k, const TG* __restrict__ gk,
+    float* smem, float* stage, int slice, const TIO* __restrict__ q, const TIO* __restrict__ k, const TG* __restrict__ gk,
     const TIO* __restrict__ dout, TIO* __restrict__ dv, const float* dht, float* dh0, int H, int T, int Dv,
     lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sg, lina_bht_strides sdo, lina_bht_strides sdv,
     float scale) {
@@ -259,20 +264,46 @@ __device__ __forceinline__ void sweep_v(
     // LDS (its extent is known by then) and fly under chunk n's MFMA phase; barriers only wait for LDS traffic.
     float gr[C], qr[C], kr[C];
     float4 zr;
+    bf16_t* const stg = reinterpret_cast<bf16_t*>(stage) + w * (C * 64);   // DMA: [tensor][wave][row][64 channels]
     auto issue = [&](int bs) {
+        if constexpr (DMA) {
+            if (64 * w < DK) {                            // wave-uniform: this wave owns channels
 #pragma unroll
-        for (int r = 0; r < C; ++r) {
-            // unconditional loads from a clamped address (masked at use): no branch, all 48 loads in flight together
-            const int tc = max(bs + r, 0);
-            gr[r] = ld(gb + tc * sg.t + ch);
-            qr[r] = ld(qb + tc * sq.t + ch);
-            kr[r] = ld(kb + tc * sk.t + ch);
+                for (int j = 0; j < 2; ++j) {
+                    // clamped row (masked at use); lane = (row 8j + lane/8, 16-byte piece lane%8)
+                    const unsigned tc = (unsigned)max(bs + 8 * j + (lane >> 3), 0);
+                    const unsigned cb = 2u * (unsigned)(64 * w + 8 * (lane & 7));
+                    dma16_to_lds_async(gb, 2u * tc * (unsigned)sg.t + cb, stg + (0 * 4 * C + 8 * j) * 64);
+                    dma16_to_lds_async(qb, 2u * tc * (unsigned)sq.t + cb, stg + (1 * 4 * C + 8 * j) * 64);
+                    dma16_to_lds_async(kb, 2u * tc * (unsigned)sk.t + cb, stg + (2 * 4 * C + 8 * j) * 64);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < C; ++r) {
+                // unconditional loads from a clamped address (masked at use): no branch, all 48 loads in flight together
+                const int tc = max(bs + r, 0);
+                gr[r] = ld(gb + tc * sg.t + ch);
+                qr[r] = ld(qb + tc * sq.t + ch);
+                kr[r] = ld(kb + tc * sk.t + ch);
+            }
         }
         zr = ld4(dob + max(bs + vr, 0) * sdo.t + vc);
     };
     int base = T - C;                                     // tile row r <-> token base + r (may start before 0)
     issue(base);
     while (true) {
+        if constexpr (DMA) {
+            wait_vmem();                                  // this wave's pieces have landed (nobody else writes the region)
+            if (chan) {
+#pragma unroll
+                for (int r = 0; r < C; ++r) {
+                    gr[r] = bf2f(stg[(0 * 4 * C + r) * 64 + lane]);
+                    qr[r] = bf2f(stg[(1 * 4 * C + r) * 64 + lane]);
+                    kr[r] = bf2f(stg[(2 * 4 * C + r) * 64 + lane]);
+                }
+            }
+        }
         float gv[C];
 #pragma unroll
         for (int r = 0; r < C; ++r) gv[r] = (chan && base + r >= 0) ? gr[r] : 0.0f;
@@ -340,9 +371,9 @@ __device__ __forceinline__ void sweep_v(
 // ============================ sweeps Q (REV = false) and K (REV = true) ============================
 //   REV = false:  X = do, Y = v,  Z = k[:, slice] e^{-b},        out32 = scale e^{b} (.) out    (dq), R0 = h0^T
 //   REV = true :  X = v,  Y = do, Z = scale q[:, slice] e^{b},   out32 = e^{-b} (.) out         (dk), R0 = dht^T
-template <int DV, typename TIO, typename TG, bool REV>
+template <int DV, typename TIO, typename TG, bool REV, bool DMA>
 __device__ __forceinline__ void sweep_qk(
-    float* smem, int slice, const TIO* __restrict__ xin, const TIO* __restrict__ yin, const TIO* __restrict__ zin,
+    float* smem, float* stage, int slice, const TIO* __restrict__ xin, const TIO* __restrict__ yin, const TIO* __restrict__ zin,
     const TG* __restrict__ gk, float* __restrict__ out32, const float* r0, int H, int T, int Dk,
     lina_bht_strides sx, lina_bht_strides sy, lina_bht_strides sz, lina_bht_strides sg, float scale) {
     constexpr int C = kBC, NT = DV / 16, SX = DV + 2, SZ = 64 + 16;
@@ -389,22 +420,51 @@ __device__ __forceinline__ void sweep_qk(
     // Software pipeline as in sweep_v: chunk n+1's raw loads fly under chunk n's MFMA phase.
     float xr[C], yr[C], gr[C];
     float4 zr;
+    bf16_t* const stg = reinterpret_cast<bf16_t*>(stage) + w * (C * 64);   // DMA: [x | y | g][wave][row][64 channels]
     auto issue = [&](int bs) {
+        if constexpr (DMA) {
 #pragma unroll
-        for (int r = 0; r < C; ++r) {
-            const int tc = min(max(bs + r, 0), T - 1);    // clamped address, masked at use
-            xr[r] = ld(xb + tc * sx.t + ch);
-            yr[r] = ld(yb + tc * sy.t + ch);
+            for (int j = 0; j < 2; ++j) {
+                const unsigned tc = (unsigned)min(max(bs + 8 * j + (lane >> 3), 0), T - 1);   // clamped row, masked at use
+                if (64 * w < DV) {                        // wave-uniform
+                    const unsigned cb = 2u * (unsigned)(64 * w + 8 * (lane & 7));
+                    dma16_to_lds_async(xb, 2u * tc * (unsigned)sx.t + cb, stg + (0 * 4 * C + 8 * j) * 64);
+                    dma16_to_lds_async(yb, 2u * tc * (unsigned)sy.t + cb, stg + (1 * 4 * C + 8 * j) * 64);
+                }
+                if (w == 0)                               // the slice's 64 gate columns
+                    dma16_to_lds_async(gb, 2u * tc * (unsigned)sg.t + 2u * (unsigned)(8 * (lane & 7)), stg + (2 * 4 * C + 8 * j) * 64);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < C; ++r) {
+                const int tc = min(max(bs + r, 0), T - 1);    // clamped address, masked at use
+                xr[r] = ld(xb + tc * sx.t + ch);
+                yr[r] = ld(yb + tc * sy.t + ch);
+            }
+            if (w == 0) {
+#pragma unroll
+                for (int r = 0; r < C; ++r) gr[r] = ld(gb + min(max(bs + r, 0), T - 1) * sg.t + lane);
+            }
         }
         zr = ld4(zb + min(max(bs + vr, 0), T - 1) * sz.t + vc);
-        if (w == 0) {
-#pragma unroll
-            for (int r = 0; r < C; ++r) gr[r] = ld(gb + min(max(bs + r, 0), T - 1) * sg.t + lane);
-        }
     };
     int base = REV ? T - C : 0;                           // REV: tokens [0, base+cut) remain; else [base+cut, T)
     issue(base);
     while (true) {
+        if constexpr (DMA) {
+            wait_vmem();                                  // this wave's pieces have landed (nobody else writes the region)
+            if (chan) {
+#pragma unroll
+                for (int r = 0; r < C; ++r) {
+                    xr[r] = bf2f(stg[(0 * 4 * C + r) * 64 + lane]);
+                    yr[r] = bf2f(stg[(1 * 4 * C + r) * 64 + lane]);
+                }
+            }
+            if (w == 0) {
+#pragma unroll
+                for (int r = 0; r < C; ++r) gr[r] = bf2f(stg[(2 * 4 * C + r) * 64 + lane]);
+            }
+        }
         __syncthreads();   // (0) previous chunk's tiles, s_b and s_dec are dead
         if (chan) {
 #pragma unroll
@@ -495,6 +555,7 @@ __device__ __forceinline__ void sweep_qk(
 // one launch for the three sweeps: grid = (B*H, max(Dk,Dv)/64, 3); blockIdx.z picks the sweep, so the three
 // independent recurrences share the chip (3x the workgroups of one sweep; the slices and sweeps of one
 // (b,h) land on the same XCD when B*H is a multiple of 8 and re-use its q/k/v/do lines in that L2)
+constexpr int kBwdStageFloats = 3 * 4 * kBC * 64 / 2;   // DMA staging: 3 tensors x 4 waves x 16 rows x 64 bf16 = 24 KiB
 constexpr int bwd_smem_floats(int DK, int DV) {
     const int dm = DK > DV ? DK : DV;
     const int f32_tiles = 2 * kBC * (dm + 2) + kBC * 80;
@@ -502,20 +563,24 @@ constexpr int bwd_smem_floats(int DK, int DV) {
     return (f32_tiles > bf_tiles ? f32_tiles : bf_tiles) + kBC * 65 + dm + 4 * kBC * (kBC + 1) + 8;
 }
 
-template <int DK, int DV, typename TIO, typename TG>
+template <int DK, int DV, typename TIO, typename TG, bool DMA>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gla_bwd_sweeps_kernel(
     const TIO* __restrict__ q, const TIO* __restrict__ k, const TIO* __restrict__ v, const TG* __restrict__ gk,
     const TIO* __restrict__ dout, TIO* __restrict__ dv, float* __restrict__ dq32, float* __restrict__ dk32,
     const float* h0, const float* dht, float* dh0, int H, int T, lina_bht_strides sq, lina_bht_strides sk,
     lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides sdo, lina_bht_strides sdv, float scale) {
     __shared__ __attribute__((aligned(16))) float smem[bwd_smem_floats(DK, DV)];
+    __shared__ __attribute__((aligned(16))) float stage[DMA ? kBwdStageFloats : 4];
     const int slice = blockIdx.y;
     if (blockIdx.z == 0) {
-        if (slice < DV / 64) sweep_v<DK, TIO, TG>(smem, slice, q, k, gk, dout, dv, dht, dh0, H, T, DV, sq, sk, sg, sdo, sdv, scale);
+        if (slice < DV / 64)
+            sweep_v<DK, TIO, TG, DMA>(smem, stage, slice, q, k, gk, dout, dv, dht, dh0, H, T, DV, sq, sk, sg, sdo, sdv, scale);
     } else if (blockIdx.z == 1) {
-        if (slice < DK / 64) sweep_qk<DV, TIO, TG, false>(smem, slice, dout, v, k, gk, dq32, h0, H, T, DK, sdo, sv, sk, sg, scale);
+        if (slice < DK / 64)
+            sweep_qk<DV, TIO, TG, false, DMA>(smem, stage, slice, dout, v, k, gk, dq32, h0, H, T, DK, sdo, sv, sk, sg, scale);
     } else {
-        if (slice < DK / 64) sweep_qk<DV, TIO, TG, true>(smem, slice, v, dout, q, gk, dk32, dht, H, T, DK, sv, sdo, sq, sg, scale);
+        if (slice < DK / 64)
+            sweep_qk<DV, TIO, TG, true, DMA>(smem, stage, slice, v, dout, q, gk, dk32, dht, H, T, DK, sv, sdo, sq, sg, scale);
     }
 }
 
@@ -578,8 +643,25 @@ static int launch_bwd(const void* q, const void* k, const void* v, const void* g
     const TIO *qq = (const TIO*)q, *kk = (const TIO*)k, *vv = (const TIO*)v, *dd = (const TIO*)d_o;
     const TG* gg = (const TG*)gk;
     constexpr int NS = (DK > DV ? DK : DV) / 64;
-    LINA_LAUNCH((gla_bwd_sweeps_kernel<DK, DV, TIO, TG>), dim3((unsigned)(B * H), (unsigned)NS, 3u), dim3(256), 0, stream,
-                qq, kk, vv, gg, dd, (TIO*)dv, dq32, dk32, h0, dht, dh0, H, T, sq, sk, sv, sg, sdo, sdv, scale);
+    // the DMA front end needs bf16 tensors and gates, 16-byte aligned rows and 32-bit byte offsets inside a (b,h) plane
+    bool dma = sizeof(TIO) == 2 && sizeof(TG) == 2;
+    if (dma) {
+        auto ok = [T](const void* p, lina_bht_strides st) {
+            return ((uintptr_t)p & 15u) == 0 && st.b % 8 == 0 && st.h % 8 == 0 && st.t % 8 == 0 && st.t >= 0 &&
+                   (int64_t)T * st.t < (1LL << 30);
+        };
+        dma = ok(q, sq) && ok(k, sk) && ok(v, sv) && ok(gk, sg) && ok(d_o, sdo);
+    }
+    if constexpr (sizeof(TIO) == 2 && sizeof(TG) == 2) {
+        if (dma) {
+            LINA_LAUNCH((gla_bwd_sweeps_kernel<DK, DV, TIO, TG, true>), dim3((unsigned)(B * H), (unsigned)NS, 3u), dim3(256), 0,
+                        stream, qq, kk, vv, gg, dd, (TIO*)dv, dq32, dk32, h0, dht, dh0, H, T, sq, sk, sv, sg, sdo, sdv, scale);
+        }
+    }
+    if (!dma) {
+        LINA_LAUNCH((gla_bwd_sweeps_kernel<DK, DV, TIO, TG, false>), dim3((unsigned)(B * H), (unsigned)NS, 3u), dim3(256), 0,
+                    stream, qq, kk, vv, gg, dd, (TIO*)dv, dq32, dk32, h0, dht, dh0, H, T, sq, sk, sv, sg, sdo, sdv, scale);
+    }
     LINA_LAUNCH((gla_bwd_dg_totals_kernel<TIO>), dim3((unsigned)(B * H), (unsigned)nseg), dim3(DK), 0, stream, qq, kk,
                 dq32, dk32, tot, H, T, DK, nseg, sq, sk);
     LINA_LAUNCH((gla_bwd_dg_final_kernel<TIO, TG>), dim3((unsigned)(B * H), (unsigned)nseg), dim3(DK), 0, stream, qq, kk,

@@ -224,7 +224,12 @@ static inline void dma16_to_lds(const void* gsrc_lane, void* lds_wave_base) {
 static inline void dma16_to_lds_async(const void* base_uniform, unsigned lane_byte_off, void* lds_wave_base) {
     memcpy((unsigned char*)lds_wave_base + 16 * lina_emu::cur_lane(), (const unsigned char*)base_uniform + lane_byte_off, 16);
 }
-static inline void wait_vmem() {}
+// the wave's DMA pieces have landed: on the emulator every lane copies its own 16 bytes when it runs, so this is a
+// wave-wide meeting point (all lanes of a wave call it together, as on the hardware)
+static inline void wait_vmem() {
+    uint32_t mine = 0, tab[64];
+    lina_emu::wave_exchange(&mine, 1, tab);
+}
 
 static inline bf16x8 as_bf16x8(uint4 u) { bf16x8 r; memcpy(&r, &u, 16); return r; }
 static inline bf16x8 as_bf16x8(uint2 lo, uint2 hi) { bf16x8 r; memcpy(&r.v[0], &lo, 8); memcpy(&r.v[4], &hi, 8); return r; }
