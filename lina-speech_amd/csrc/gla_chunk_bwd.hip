@@ -314,6 +314,7 @@ __device__ __forceinline__ void sweep_v(
         const int start = max(max(max(s_nw[0], s_nw[1]), max(s_nw[2], s_nw[3])), -base);
         if (chan) {
             const float tot = finish_rev(bv, cs, start);
+            unsigned ypk[C / 2];                           // the thread's row of Y^T (16 tokens of its channel), packed
 #pragma unroll
             for (int r = 0; r < C; ++r) {
                 const bool valid = r >= start;             // start >= -base: rows before token 0 are never valid
@@ -323,11 +324,18 @@ __device__ __forceinline__ void sweep_v(
                     const bf16_t yb = f2bf(yq);
                     bt.xb[r * SXB + tid] = f2bf(xk);
                     bt.yb[r * SXB + tid] = yb;
-                    bt.yT[tid * ST + r] = yb;
+                    ypk[r >> 1] = (r & 1) ? (ypk[r >> 1] | ((unsigned)yb << 16)) : (unsigned)yb;
                 } else {
                     s_x[r * SX + tid] = xk;
                     s_y[r * SX + tid] = yq;
                 }
+            }
+            if constexpr (kBf) {
+                // Y^T row of this channel = 32 contiguous bytes: two 16-byte writes (48-byte row stride: conflict-free)
+                // instead of sixteen 2-byte ones (8-way bank-conflicted at that stride)
+                uint4* yp = reinterpret_cast<uint4*>(&bt.yT[tid * ST]);
+                yp[0] = make_uint4(ypk[0], ypk[1], ypk[2], ypk[3]);
+                yp[1] = make_uint4(ypk[4], ypk[5], ypk[6], ypk[7]);
             }
             s_dec[tid] = __expf(tot);
         }
@@ -467,6 +475,7 @@ __device__ __forceinline__ void sweep_qk(
         }
         __syncthreads();   // (0) previous chunk's tiles, s_b and s_dec are dead
         if (chan) {
+            unsigned ypk[C / 2];                           // the thread's row of Y^T, packed
 #pragma unroll
             for (int r = 0; r < C; ++r) {                 // X, Y rows outside the chunk only need to be finite: Z is zeroed
                 const bool in = base + r >= 0 && base + r < T;
@@ -475,11 +484,16 @@ __device__ __forceinline__ void sweep_qk(
                     const bf16_t yb = f2bf(yv);           // exact: the inputs are bf16
                     bt.xb[r * SXB + tid] = f2bf(xv);
                     bt.yb[r * SXB + tid] = yb;
-                    bt.yT[tid * ST + r] = yb;
+                    ypk[r >> 1] = (r & 1) ? (ypk[r >> 1] | ((unsigned)yb << 16)) : (unsigned)yb;
                 } else {
                     s_x[r * SX + tid] = xv;
                     s_y[r * SX + tid] = yv;
                 }
+            }
+            if constexpr (kBf) {
+                uint4* yp = reinterpret_cast<uint4*>(&bt.yT[tid * ST]);   // 32 contiguous bytes: two 16-byte writes
+                yp[0] = make_uint4(ypk[0], ypk[1], ypk[2], ypk[3]);
+                yp[1] = make_uint4(ypk[4], ypk[5], ypk[6], ypk[7]);
             }
         }
         if (w == 0) {
