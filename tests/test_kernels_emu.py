@@ -24,7 +24,8 @@ def test_chunk(emu, Dk, Dv, T, dtype):
 
 
 # T = 200: seven chunks with a ragged tail; the un-normalised state is renormalised several times (gates ~ -0.28 per token)
-@pytest.mark.parametrize("T,resets", [(5, False), (40, False), (70, True), (200, False)])
+@pytest.mark.parametrize("T,resets", [(1, False), (5, False), (32, False), (33, False), (40, False), (64, False), (65, True),
+                                      (70, True), (200, False)])
 def test_chunk_full_head_kernel(emu, T, resets):
     check_chunk(DEV, B=1, H=1, T=T, Dk=256, Dv=256, dtype=torch.bfloat16, resets=resets)
 
@@ -132,7 +133,7 @@ def test_topk_sample(emu, n, k, temp, dtype):
     check_topk_sample(DEV, rows=6, n=n, k=k, temp=temp, dtype=dtype, draws=60)
 
 
-@pytest.mark.parametrize("T,nseg,resets", [(100, 3, False), (70, 2, True)])
+@pytest.mark.parametrize("T,nseg,resets", [(100, 3, False), (70, 2, True), (64, 2, False), (33, 4, False)])
 def test_chunk_segment_parallel(emu, T, nseg, resets):
     check_chunk_segmented(DEV, B=1, H=1, T=T, nseg=nseg, resets=resets)
 
