@@ -6,16 +6,27 @@ layer numbering (decoder = n_layer+i, pos_net = 2*n_layer).
 """
 from __future__ import annotations
 
+import os
 from abc import abstractmethod
 from typing import Optional
 
 import torch
 import torch.nn as nn
+import torch.utils.checkpoint
 
 from .blind_attention import BlindCrossAttention
 from .blocks import MixingBlock, SwiGLU
 from .mixer import GatedLinearAttention
 from .modules import Cache
+
+
+def _maybe_grad_ckpt(blk):
+    """Activation checkpointing switch of the reference (model/gla.py:26-33,290-291,297-298): with ``GRAD_CKPT`` in
+    the environment every encoder / decoder block is recomputed in backward (non-reentrant checkpoint) while the
+    module is training.  Read at call time (the reference reads it at import time)."""
+    if "GRAD_CKPT" not in os.environ:
+        return blk
+    return lambda *a, **kw: torch.utils.checkpoint.checkpoint(blk, *a, **kw, use_reentrant=False)
 
 
 class AttentiveRNN(nn.Module):
@@ -59,11 +70,11 @@ class AttentiveGLA(AttentiveRNN):
                 init_state=None, crossatt_pos=None):
         kw = dict(use_cache=init_state is not None, past_key_values=init_state)
         for blk in self.encoder:
-            x = blk(x, **kw)
+            x = (_maybe_grad_ckpt(blk) if self.training else blk)(x, **kw)
         v, att = self.cross_att(x, ctx, mask=mask, reset_mask=reset_mask, pos=crossatt_pos)
         x = x + v
         for blk in self.decoder:
-            x = blk(x, **kw)
+            x = (_maybe_grad_ckpt(blk) if self.training else blk)(x, **kw)
         return x, att
 
     def init_state(self, max_seqlen: int = 1000, batch_size: int = 16) -> Cache:

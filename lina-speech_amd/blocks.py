@@ -42,27 +42,64 @@ class MixingBlock(nn.Module):
         return self.drop(x)
 
 
-class SelfAttention(nn.Module):
-    """Bidirectional multi-head self-attention of the text encoder (no rotary: the decode path of
-    this package never needs it; ask for rotary and it raises)."""
+class RotaryEmbedding(nn.Module):
+    """Rotary position embedding with the parameter name and arithmetic of ``rotary_embedding_torch.RotaryEmbedding``
+    (lucidrains; the reference imports it at model/base_blocks.py:6 and lists it un-pinned in requirements.txt:4; the
+    package is absent from this image, so this restates its published defaults: ``freqs = theta^(-2i/dim)``, theta
+    10000, kept as a non-trainable Parameter ``freqs`` -> state-dict key ``...rotary.freqs``; angles interleaved
+    pairwise; only the first ``dim`` channels of a head are rotated).  Runs once per utterance in the text encoder --
+    plain torch, not a kernel."""
 
-    def __init__(self, dim: int, heads: int, rotary: bool = False, is_causal: bool = False):
+    def __init__(self, dim: int, theta: float = 10000.0):
         super().__init__()
-        if rotary:
-            raise NotImplementedError("rotary text encoder is outside the generation hot path (SURVEY 2, #11)")
+        self.freqs = nn.Parameter(1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim)),
+                                  requires_grad=False)
+
+    def forward(self, pos):
+        """positions [...] -> angles [..., dim] (each frequency repeated for its channel pair)."""
+        return (pos.to(self.freqs.dtype)[..., None] * self.freqs).repeat_interleave(2, dim=-1)
+
+    def rotate_queries_or_keys(self, t, offset: int = 0):
+        pos = torch.arange(t.shape[-2], device=t.device) + offset
+        return apply_rotary_emb(self.forward(pos), t)
+
+
+def apply_rotary_emb(angles, t):
+    rot = angles.shape[-1]
+    a = angles.to(t.dtype)
+    head, rest = t[..., :rot], t[..., rot:]
+    pair = head.reshape(*head.shape[:-1], rot // 2, 2)
+    half = torch.stack((-pair[..., 1], pair[..., 0]), dim=-1).reshape(head.shape)
+    return torch.cat((head * a.cos() + half * a.sin(), rest), dim=-1)
+
+
+class SelfAttention(nn.Module):
+    """Bidirectional multi-head self-attention of the text encoder (reference model/base_blocks.py:9-40; rotary on
+    q and k by default like the reference)."""
+
+    def __init__(self, dim: int, heads: int, rotary: bool = True, is_causal: bool = False):
+        super().__init__()
         assert dim % heads == 0
         self.qkv = nn.Linear(dim, 3 * dim)
         self.heads, self.is_causal = heads, is_causal
+        self.rotary = RotaryEmbedding((dim // heads) // 2) if rotary else None
 
-    def forward(self, x, mask=None, pos=None, **kwargs):
+    def forward(self, x, mask=None, pos=None, time_step: int = 0, **kwargs):
         B, N, D = x.shape
         q, k, v = self.qkv(x).view(B, N, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
+        if self.rotary is not None:
+            if pos is not None:
+                ang = self.rotary(pos).unsqueeze(1)
+                q, k = apply_rotary_emb(ang, q), apply_rotary_emb(ang, k)
+            else:
+                q = self.rotary.rotate_queries_or_keys(q, offset=time_step)
+                k = self.rotary.rotate_queries_or_keys(k)
         y = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, is_causal=self.is_causal)
         return y.transpose(1, 2).reshape(B, N, D)
 
 
 class TextEncoder(nn.Module):
-    def __init__(self, dim: int, heads: int, n_layers: int = 4, dropout: float = 0.1, rotary: bool = False):
+    def __init__(self, dim: int, heads: int, n_layers: int = 4, dropout: float = 0.1, rotary: bool = True):
         super().__init__()
         self.sa = nn.ModuleList([
             MixingBlock(lambda: SelfAttention(dim, heads, rotary=rotary), lambda: SwiGLU(dim),

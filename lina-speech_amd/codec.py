@@ -14,7 +14,9 @@ class MultiEmbedding(nn.Module):
     """``n_level`` embedding tables of identical shape in one parameter ``weight [q, n_emb, d]``.
     ``forward(idx[q, ...]) -> [q, ..., d]`` (per-level gather, like the reference);
     ``embed_sum(idx) -> [..., d]`` is the fused gather + sum over levels the decode loop uses (K6a).
-    NB: ``padding_idx`` does not zero a row (reference initialises with normal_ afterwards)."""
+    NB: ``padding_idx`` does not zero a row (reference initialises with normal_ afterwards), but -- as in the
+    reference's ``F.embedding(padding_idx=...)`` under vmap (model/multiembed.py:21-23) -- that row receives NO
+    gradient."""
 
     def __init__(self, n_level: int, n_emb: int, d_emb: int, padding_idx=None):
         super().__init__()
@@ -23,10 +25,11 @@ class MultiEmbedding(nn.Module):
         nn.init.normal_(self.weight)
 
     def forward(self, idx):
-        return torch.stack([self.weight[q][idx[q]] for q in range(self.n_level)], dim=0)
+        return torch.stack([nn.functional.embedding(idx[q], self.weight[q], padding_idx=self.padding_idx)
+                            for q in range(self.n_level)], dim=0)
 
     def embed_sum(self, idx):
-        return ops.embed_sum(self.weight, idx)
+        return ops.embed_sum(self.weight, idx, padding_idx=self.padding_idx)
 
 
 class CodecHead(nn.Module):

@@ -148,7 +148,9 @@ __global__ __launch_bounds__(256) void topk_sample_rows_kernel(const T* __restri
         s_pick = pick;
     }
     __syncthreads();
-    if (s_pick < 0) {
+    const bool miss = s_pick < 0;      // snapshot: every thread reads the flag BEFORE anybody's atomic may change it
+    __syncthreads();
+    if (miss) {                        // workgroup-uniform (all threads read the same value between two barriers)
         // rounding put the target at/after the total: take the LAST kept entry (thread order = index order)
         int last = -1;
         for (int j = j0; j < j1; ++j)

@@ -56,7 +56,8 @@ def train_initial_state(model: LinaModel, batches: Iterable[Batch], n_steps: int
     torch.manual_seed(seed)
     model.attentive_rnn.to_mode("fused_recurrent")
     model.train()
-    for p in model.parameters():
+    frozen = [(p, p.requires_grad) for p in model.parameters()]
+    for p, _ in frozen:
         p.requires_grad_(False)
     params = model.attentive_rnn.get_init_state_tuning_params(lora=rank, device=device)
     flat = [t for layer in params for t in (layer if isinstance(layer, tuple) else (layer,))]
@@ -71,4 +72,6 @@ def train_initial_state(model: LinaModel, batches: Iterable[Batch], n_steps: int
             opt.step()
             opt.zero_grad()
     model.eval()
+    for p, was in frozen:                  # the reference leaves the model's requires_grad flags as they were
+        p.requires_grad_(was)
     return params, losses

@@ -71,8 +71,8 @@ def _ptr(t: Optional[torch.Tensor]):
 
 def _no_grad(*tensors):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError("lina_speech_amd: backward kernels (K2b/K3b/K5b) are not built yet; "
-                                  "call under torch.no_grad()/inference_mode()")
+        raise NotImplementedError("lina_speech_amd: this op has no backward kernel (inference-only: SwiGLU decode "
+                                  "epilogue, vocoder K8/K9); call it under torch.no_grad()/inference_mode()")
 
 
 def _inner_contig(t: torch.Tensor) -> torch.Tensor:
@@ -121,6 +121,21 @@ def _head_first_empty(B, H, T, D, dtype, device):
     return torch.empty(B, T, H, D, dtype=dtype, device=device).transpose(1, 2)
 
 
+_WORKSPACES = {}
+
+
+def _workspace(tag: str, nbytes: int, device) -> torch.Tensor:
+    """Scratch that is fully written before it is read inside ONE launch sequence on the current stream (segment
+    states of the segment-parallel K2): kept per (tag, device, stream) and grown on demand instead of a torch.empty
+    per layer per step.  Stream-ordered reuse is safe because consecutive users on one stream serialise."""
+    key = (tag, device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
 def _gla_launch(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inplace_state=False, nseg=None):
     B, H, T, Dk = q.shape
     Dv = v.shape[-1]
@@ -139,8 +154,7 @@ def _gla_launch(entry: str, q, k, v, gk, scale, initial_state, output_final_stat
     if entry == "lina_gla_chunk_fwd":
         nseg = chunk_segments(B * H, T) if nseg is None else nseg
         if (nseg > 1 and q.dtype == torch.bfloat16 and gk.dtype == torch.bfloat16 and Dk == 256 and Dv == 256):
-            ws = torch.empty(int(be.lib.lina_gla_chunk_fwd_seg_workspace(B, H, Dk, Dv, nseg)) // 4, dtype=torch.float32,
-                             device=q.device)
+            ws = _workspace("k2seg", int(be.lib.lina_gla_chunk_fwd_seg_workspace(B, H, Dk, Dv, nseg)), q.device)
             rc = be.lib.lina_gla_chunk_fwd_seg(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(o), _ptr(h0), _ptr(ht), _ptr(ws),
                                                nseg, B, H, T, Dk, Dv, _bht(q), _bht(k), _bht(v), _bht(gk), _bht(o),
                                                _dt(q), _dt(gk), scale, be.stream(q))
@@ -324,17 +338,26 @@ def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional
     act = 1 if activation in ("silu", "swish") else 0
     if activation not in ("silu", "swish", None):
         raise ValueError(f"activation {activation!r} not supported")
+    user_cache = None
     if cache is not None:
-        if tuple(cache.shape) != (B, D, W) or cache.dtype != x.dtype or not cache.is_contiguous():
-            raise ValueError(f"cache must be a contiguous {x.dtype} tensor [B,D,W]={B, D, W}")
+        if tuple(cache.shape) != (B, D, W) or not cache.is_contiguous():
+            raise ValueError(f"cache must be a contiguous tensor [B,D,W]={B, D, W}")
+        if cache.dtype != x.dtype:
+            # e.g. an fp32 cache from init_state() with bf16 activations under autocast: the reference's
+            # cache.copy_(...) casts; run on a cache of the activation dtype and cast back into the caller's tensor
+            user_cache, cache = cache, cache.to(x.dtype)
     m = None if mask is None else mask.to(torch.float32).contiguous()
     if _needs_grad(x, w, bias):
         if cache is not None and T == 1:
             raise NotImplementedError("short_conv: gradients are built for the prefill form (T > 1 or no cache) only")
-        return _ShortConvFunction.apply(x, w, bias, m, act, cache)
-    if cache is not None and T == 1:
-        m = mask
-    return _short_conv_launch(x, w, bias, m, cache, act)
+        y = _ShortConvFunction.apply(x, w, bias, m, act, cache)
+    else:
+        if cache is not None and T == 1:
+            m = mask
+        y = _short_conv_launch(x, w, bias, m, cache, act)
+    if user_cache is not None:
+        user_cache.copy_(cache)
+    return y
 
 
 # --------------------------------------------------------------------------- norm (K5)
@@ -430,9 +453,9 @@ class _EmbedSumFunction(torch.autograd.Function):
     (torch index_add_ in fp32 on the device -- plumbing, not a hand-written kernel)."""
 
     @staticmethod
-    def forward(ctx, table, flat):
+    def forward(ctx, table, flat, padding_idx=None):
         ctx.save_for_backward(flat)
-        ctx.tshape, ctx.tdtype = table.shape, table.dtype
+        ctx.tshape, ctx.tdtype, ctx.padding_idx = table.shape, table.dtype, padding_idx
         return _embed_sum_launch(table, flat)
 
     @staticmethod
@@ -443,13 +466,16 @@ class _EmbedSumFunction(torch.autograd.Function):
         src = dout.float()
         for qi in range(Q):
             dt[qi].index_add_(0, flat[qi], src)
-        return dt.to(ctx.tdtype), None
+        if ctx.padding_idx is not None:                   # F.embedding(padding_idx=...): that row gets no gradient
+            dt[:, ctx.padding_idx].zero_()
+        return dt.to(ctx.tdtype), None, None
 
 
-def embed_sum(table, idx, out=None):
+def embed_sum(table, idx, out=None, padding_idx=None):
     """table [Q,n_emb,d], idx int64 [Q,B,n] -> sum_q table[q, idx[q]] : [B,n,d]
     (MultiEmbedding + reduce over quantizers; reference modeling_lina.py:131,178-179).
-    ``out``: optional contiguous [B*n, d] destination (no-grad path)."""
+    ``out``: optional contiguous [B*n, d] destination (no-grad path).  ``padding_idx``: row that receives no
+    gradient (the forward value is gathered like any other row, as in the reference)."""
     be = _BACKEND
     be.require(table, idx)
     Q, n_emb, d = table.shape
@@ -457,7 +483,7 @@ def embed_sum(table, idx, out=None):
         raise ValueError("idx must be int64 [Q, ...]")
     flat = idx.reshape(Q, -1).contiguous()
     if _needs_grad(table):
-        return _EmbedSumFunction.apply(table, flat).view(*idx.shape[1:], d)
+        return _EmbedSumFunction.apply(table, flat, padding_idx).view(*idx.shape[1:], d)
     return _embed_sum_launch(table, flat, out).view(*idx.shape[1:], d)
 
 

@@ -15,6 +15,7 @@ MI355X-first:
 """
 from __future__ import annotations
 
+import math
 import os
 from dataclasses import dataclass
 from typing import Optional
@@ -63,9 +64,12 @@ def synthetic_batch(b: int, n: int, t_txt: int = 64, n_codebook: int = 4096, n_q
 class TrainStep:
     """forward + loss + backward + AdamW for one micro-batch per rank; data parallel when a process group is up."""
 
-    def __init__(self, model: LinaModel, lr: float = 2e-4, weight_decay: float = 0.1, betas=(0.9, 0.95),
+    def __init__(self, model: LinaModel, lr: float = 5e-4, weight_decay: float = 0.1, betas=(0.9, 0.999),
+                 n_warmup_steps: int = 500, n_training_steps: int = 300000,
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16, device: Optional[torch.device] = None,
-                 grad_clip: Optional[float] = 1.0, ddp: Optional[bool] = None):
+                 grad_clip: Optional[float] = None, ddp: Optional[bool] = None):
+        """Optimiser defaults are the reference's (train_lina.py:25-29,104-118): AdamW lr 5e-4, betas (0.9, 0.999),
+        weight decay 0.1, cosine schedule with 500 warm-up steps over 300 000 steps, no gradient clipping."""
         self.device = device if device is not None else next(model.parameters()).device
         self.model = model.to(self.device).train()
         self.autocast_dtype = autocast_dtype
@@ -80,6 +84,15 @@ class TrainStep:
         fused = self.device.type == "cuda"
         self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=weight_decay, betas=betas,
                                      fused=fused)
+
+        def cosine_with_warmup(step: int) -> float:          # transformers.get_cosine_schedule_with_warmup, half a cycle
+            if step < n_warmup_steps:
+                return step / max(1, n_warmup_steps)
+            progress = (step - n_warmup_steps) / max(1, n_training_steps - n_warmup_steps)
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
+
+        self.sched = (torch.optim.lr_scheduler.LambdaLR(self.opt, cosine_with_warmup)
+                      if n_training_steps and n_training_steps > 0 else None)
 
     def loss(self, batch: Batch) -> torch.Tensor:
         if self.autocast_dtype is not None and self.device.type == "cuda":
@@ -97,6 +110,8 @@ class TrainStep:
         if self.grad_clip is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
         self.opt.step()
+        if self.sched is not None:
+            self.sched.step()
         return loss.detach()
 
 

@@ -1,0 +1,135 @@
+"""Host-side behaviours that mirror reference glue (CPU, emulator backend where a kernel is involved)."""
+import math
+import os
+
+import pytest
+import torch
+
+from model_cases import build_lina
+
+
+def test_rotary_matches_closed_form_rotation():
+    """RotaryEmbedding / apply_rotary_emb (reference model/base_blocks.py:15,29-35 via rotary_embedding_torch):
+    channel pair (2i, 2i+1) of the first `dim` channels is rotated by angle pos * theta^(-2i/dim); the rest of the
+    head is untouched; the parameter is `freqs` (state-dict key `rotary.freqs`)."""
+    from lina_speech_amd.blocks import RotaryEmbedding, SelfAttention, TextEncoder
+    torch.manual_seed(0)
+    dim, n = 8, 5
+    rot = RotaryEmbedding(dim)
+    assert list(rot.state_dict()) == ["freqs"] and not rot.freqs.requires_grad
+    t = torch.randn(2, 3, n, 16, dtype=torch.float64)
+    got = rot.rotate_queries_or_keys(t, offset=2)
+    ref = t.clone()
+    for p in range(n):
+        for i in range(dim // 2):
+            a = (p + 2) * 10000.0 ** (-2 * i / dim)
+            x0, x1 = t[..., p, 2 * i], t[..., p, 2 * i + 1]
+            ref[..., p, 2 * i] = x0 * math.cos(a) - x1 * math.sin(a)
+            ref[..., p, 2 * i + 1] = x1 * math.cos(a) + x0 * math.sin(a)
+    assert (got - ref).abs().max() < 1e-6
+    assert torch.equal(got[..., dim:], t[..., dim:])
+    # relative-position property: <rot(q,p1), rot(k,p2)> depends on p1 - p2 only
+    q, k = torch.randn(1, 1, 1, 16, dtype=torch.float64), torch.randn(1, 1, 1, 16, dtype=torch.float64)
+    d1 = (rot.rotate_queries_or_keys(q, 7) * rot.rotate_queries_or_keys(k, 3)).sum()
+    d2 = (rot.rotate_queries_or_keys(q, 14) * rot.rotate_queries_or_keys(k, 10)).sum()
+    assert abs(d1 - d2) < 1e-6          # freqs are fp32
+    # default construction = the reference's (rotary on), checkpoint key present, forward runs with and without pos
+    enc = TextEncoder(32, 2, n_layers=1, dropout=0.0)
+    assert "sa.0.tmix.rotary.freqs" in enc.state_dict()
+    x = torch.randn(2, 6, 32)
+    y0 = enc(x)
+    y1 = enc(x, pos=torch.arange(6)[None, :].expand(2, -1))
+    assert (y0 - y1).abs().max() < 1e-5                     # explicit positions 0..n-1 == implicit ones
+    assert isinstance(enc.sa[0].tmix, SelfAttention)
+
+
+def test_multiembedding_padding_row_gets_no_gradient(emu):
+    """reference model/multiembed.py:21-23: F.embedding(padding_idx=0) under vmap -> no gradient for row 0, in both
+    the per-level forward (training) and the fused gather+sum."""
+    from lina_speech_amd.codec import MultiEmbedding
+    torch.manual_seed(0)
+    emb = MultiEmbedding(2, 7, 8, padding_idx=0)
+    idx = torch.tensor([[[0, 3, 0, 5]], [[2, 0, 0, 1]]])
+    emb(idx).sum().backward()
+    g1 = emb.weight.grad.clone()
+    emb.weight.grad = None
+    emb.embed_sum(idx).sum().backward()
+    g2 = emb.weight.grad.clone()
+    for g in (g1, g2):
+        assert float(g[:, 0].abs().max()) == 0.0
+        assert float(g[0, 3].abs().min()) == 1.0 and float(g[1, 2].abs().min()) == 1.0
+    assert torch.equal(g1, g2)
+    # the forward still gathers the (non-zero) padding row
+    assert float(emb.embed_sum(idx)[0, 0].abs().max()) > 0
+
+
+def test_short_conv_accepts_a_cache_of_another_dtype(emu):
+    """An fp32 cache (GatedLinearAttention.init_state with fp32 master weights) with bf16 activations (autocast):
+    the reference's cache.copy_(...) casts; so does ops.short_conv."""
+    from lina_speech_amd import ops
+    from oracle import gla_oracle as O
+    torch.manual_seed(0)
+    B, T, D, W = 2, 6, 16, 4
+    x = torch.randn(B, T, D).to(torch.bfloat16)
+    w = torch.randn(D, 1, W) * 0.5
+    cache = torch.zeros(B, D, W)
+    y = ops.short_conv(x, w, cache=cache)
+    ref_cache = torch.zeros(B, D, W, dtype=torch.float64)
+    ref = O.short_conv(x.double(), w.to(torch.bfloat16).double(), cache=ref_cache)
+    assert (y.double() - ref).abs().max() < 3e-2
+    assert cache.dtype == torch.float32 and (cache.double() - ref_cache).abs().max() < 1e-6
+    x1 = torch.randn(B, 1, D).to(torch.bfloat16)
+    y1 = ops.short_conv(x1, w, cache=cache)                      # step form reads AND writes the cache
+    ref1 = O.short_conv(x1.double(), w.to(torch.bfloat16).double(), cache=ref_cache)
+    assert (y1.double() - ref1).abs().max() < 3e-2
+    assert (cache.double() - ref_cache).abs().max() < 1e-6
+
+
+def test_grad_ckpt_switch_gives_identical_loss_and_gradients(emu, monkeypatch):
+    """GRAD_CKPT (reference model/gla.py:26-33,290-291,297-298): blocks recomputed in backward, same numbers."""
+    from lina_speech_amd.train import synthetic_batch
+    torch.manual_seed(0)
+    model = build_lina(d=64, n_layer=1).train()
+    batch = synthetic_batch(b=2, n=20, t_txt=9, n_codebook=253, seed=5)
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        loss = model(batch.x, batch.y, batch.encoder_mask, batch.crossatt_mask, logits_mask=batch.logits_mask)[1]
+        loss.backward()
+        return loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    monkeypatch.delenv("GRAD_CKPT", raising=False)
+    l0, g0 = run()
+    monkeypatch.setenv("GRAD_CKPT", "1")
+    calls = []
+    import torch.utils.checkpoint as ck
+    orig = ck.checkpoint
+    monkeypatch.setattr(ck, "checkpoint", lambda *a, **kw: (calls.append(1), orig(*a, **kw))[1])
+    l1, g1 = run()
+    assert len(calls) == 2                                     # one encoder + one decoder block
+    assert torch.equal(l0, l1)
+    assert set(g0) == set(g1)
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+
+
+def test_train_step_defaults_follow_the_reference(emu):
+    """train_lina.py:25-29,104-118: AdamW 5e-4, betas (0.9, 0.999), wd 0.1, cosine schedule with 500 warm-up steps."""
+    from lina_speech_amd.train import TrainStep
+    ts = TrainStep(build_lina(), autocast_dtype=None, ddp=False)
+    g = ts.opt.param_groups[0]
+    assert g["betas"] == (0.9, 0.999) and g["weight_decay"] == 0.1 and g["initial_lr"] == 5e-4
+    assert g["lr"] == 0.0 and ts.grad_clip is None
+    lam = ts.sched.lr_lambdas[0]
+    assert lam(250) == 0.5 and lam(500) == 1.0 and abs(lam(150250) - 0.5) < 1e-9 and lam(300000) == 0.0
+
+
+def test_train_initial_state_restores_requires_grad(emu):
+    from lina_speech_amd.initial_state import train_initial_state
+    from lina_speech_amd.train import synthetic_batch
+    model = build_lina()
+    model.txt_embed.weight.requires_grad_(False)
+    before = {n: p.requires_grad for n, p in model.named_parameters()}
+    batch = synthetic_batch(b=2, n=12, t_txt=7, n_codebook=253, seed=1)
+    train_initial_state(model, iter([batch] * 2), n_steps=2, grad_acc=1, device="cpu")
+    assert {n: p.requires_grad for n, p in model.named_parameters()} == before

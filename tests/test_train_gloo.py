@@ -39,7 +39,7 @@ def _worker(rank, world, port, out_path):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from lina_speech_amd.train import TrainStep
-    ts = TrainStep(_model(), autocast_dtype=None, grad_clip=None, lr=1e-3)
+    ts = TrainStep(_model(), autocast_dtype=None, grad_clip=None, lr=1e-3, n_warmup_steps=0)
     assert ts.net is not ts.model            # wrapped in DDP
     loss = ts.loss(_micro(rank))
     loss.backward()
@@ -80,7 +80,7 @@ def test_two_rank_ddp_gradients_equal_mean_of_microbatch_gradients(tmp_path, emu
 
 def test_train_step_decreases_loss(emu):
     from lina_speech_amd.train import TrainStep
-    ts = TrainStep(_model(), autocast_dtype=None, lr=3e-3, weight_decay=0.0)
+    ts = TrainStep(_model(), autocast_dtype=None, lr=3e-3, weight_decay=0.0, n_warmup_steps=0)
     batch = _micro(0)
     losses = [float(ts.step(batch)) for _ in range(4)]
     assert losses[-1] < losses[0], losses
