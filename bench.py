@@ -47,19 +47,26 @@ def k1_algorithmic_bytes(B, H, Dk, Dv, e_io, e_g):
 
 
 def measure_k1(engine, reps=20):
-    """Average duration of one K1d launch (lina::gla_decode_rowsplit_kernel) at the decode shape, real buffers,
-    cycling through the 13 layers (1.7 GB of state > L3, so every launch streams from HBM).  HIP events on
-    torch's current stream -- the stream the C-ABI launches are enqueued on."""
+    """Average duration of one launch of the kernel the hipGraph step actually runs for the recurrent update:
+    lina_gla_decode_update_norm = lina::gla_decode_rowsplit_kernel<..., FUSE=true> (K1d with K5 fused in; the plain
+    K1d entry when the engine was built without the fusion), at the decode shape, on the engine's real buffers, cycling
+    through the 13 layers (1.7 GB of state > L3, so every launch streams from HBM).  HIP events on torch's current
+    stream -- the stream the C-ABI launches are enqueued on.  Returns (seconds per launch, entry point name)."""
     from lina_speech_amd import ops
     packs = engine.packs
     B = packs[0].S.shape[0]          # rows per launch (the engine may split the batch into parallel row ranges)
+    fused = engine.fuse_norm and packs[0].row_split
 
     def one_pass():
         for P in packs:
             q = P.qkv[:, :P.Kd].view(B, P.H, P.Dk)
             k = P.qkv[:, P.Kd:2 * P.Kd].view(B, P.H, P.Dk)
             v = P.qkv[:, 2 * P.Kd:].view(B, P.H, P.Dv)
-            ops.gla_decode_update(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S)
+            if fused:
+                ops.gla_decode_update_norm(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S, P.g.view(B, P.H, P.Dv),
+                                           P.gnw, P.og, P.counters, P.eps_gate)
+            else:
+                ops.gla_decode_update(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S)
 
     one_pass()
     torch.cuda.synchronize()
@@ -69,7 +76,27 @@ def measure_k1(engine, reps=20):
         one_pass()
     ev1.record()
     torch.cuda.synchronize()
-    return ev0.elapsed_time(ev1) * 1e-3 / (reps * len(packs))
+    return (ev0.elapsed_time(ev1) * 1e-3 / (reps * len(packs)),
+            "lina_gla_decode_update_norm" if fused else "lina_gla_decode_update")
+
+
+def host_cpu():
+    """CPU model and physical core count of the host the cpu_baseline runs on."""
+    model, phys, logical = None, set(), 0
+    try:
+        pid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("processor"):
+                logical += 1
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                phys.add((pid, line.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    return {"model": model, "physical_cores": len(phys) or None, "logical_cpus": logical or os.cpu_count()}
 
 
 def sustained(fn, warm_s=1.5, reps=200):
@@ -209,8 +236,149 @@ def cpu_baseline(model, seconds=12.0, B=8, max_steps=64):
             n += 1
         dt = time.time() - t0
     return {"value": B * n / dt, "unit": "codec tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host": host_cpu(),
             "sample": f"oracle/lina_decode_oracle.py (pure-PyTorch recurrent, fp32), 166.7M model, B={B}, "
                       f"T_txt={T_TXT}, {n} greedy steps in {dt:.1f}s"}
+
+
+MIN_TIMED_S = 0.25       # the timed region is extended to at least this much wall time (reported in "steps")
+
+
+def relaunch_under_torchrun(n: int, argv) -> int:
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it: start N ranks of this script under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    log("bench.py: --gpus", n, "without a launcher -> ", " ".join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
+def init_world(n_gpus: int):
+    """Join the process group the launcher describes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*): backend "nccl" (= RCCL)
+    on GPUs, "gloo" on a CPU-only host (launch check only).  The world MUST be --gpus ranks."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != n_gpus:
+        raise SystemExit(f"bench.py: --gpus {n_gpus} but the launcher started WORLD_SIZE={world} ranks")
+    gpu = torch.cuda.is_available()
+    dev = torch.device("cuda", local) if gpu else torch.device("cpu")
+    if gpu:
+        if local >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {rank} needs GPU {local}, the node shows {torch.cuda.device_count()}")
+        torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if gpu:
+            dist.init_process_group("nccl", device_id=dev)           # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+        assert dist.get_world_size() == n_gpus and dist.get_rank() == rank
+    return rank, local, world, dev, dist
+
+
+def check_launch(args):
+    """--check-launch: only the launch / rendezvous logic (runs on a CPU-only host with gloo): every rank joins the
+    group, contributes its rank to an all-reduce and rank 0 prints what it saw."""
+    rank, local, world, dev, dist = init_world(args.gpus)
+    seen = world
+    if dist is not None:
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        from lina_speech_amd.shard import shard_rows
+        lo, hi = shard_rows(B_PER_GPU * world, rank, world)
+        rows = torch.tensor([float(hi - lo)], device=dev)
+        dist.all_reduce(rows)
+        assert int(rows.item()) == B_PER_GPU * world
+    if rank == 0:
+        print(json.dumps({"check_launch": True, "n_gpus": args.gpus, "world_size": world, "ranks_seen": seen,
+                          "backend": (dist.get_backend() if dist is not None else None),
+                          "rows_total": B_PER_GPU * world}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def timed_steps(run_step, k_req, dist, dev, est_steps=None):
+    """Time >= k_req steps (and >= MIN_TIMED_S of wall time) bracketed by barrier + synchronize on both sides;
+    returns (elapsed seconds = MAX over ranks, steps timed).  The step count is agreed across ranks first."""
+    k = k_req
+    if est_steps is not None:
+        k = max(k_req, est_steps)
+    if dist is not None:
+        kk = torch.tensor([k], device=dev, dtype=torch.int64)
+        dist.all_reduce(kk, op=dist.ReduceOp.MAX)
+        k = int(kk.item())
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        run_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed, k
+
+
+def bench_train(args):
+    """--train: config 5 -- the L169 training step (teacher-forced forward, CE, backward through K2b/K3b/K5b, AdamW;
+    bf16 autocast, fp32 master weights) with b = 8 sequences of 4096 tokens PER GPU, data parallel over RCCL
+    (DistributedDataParallel, 128 MB buckets, gradient all-reduce overlapped with backward).  One JSON line."""
+    rank, local, world, dev, dist = init_world(args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback for the product path)")
+    from lina_speech_amd import ops
+    from lina_speech_amd.configs import l169, n_params
+    from lina_speech_amd.train import TrainStep, synthetic_batch
+    ops.get_backend().lib
+    b, T = args.train_batch, 4096
+    torch.manual_seed(0)
+    model = l169()
+    nparam = n_params(model)
+    ts = TrainStep(model, device=dev, ddp=world > 1)
+    batch = synthetic_batch(b=b, n=T + 1, t_txt=T_TXT, seed=1 + rank).to(dev)
+    for _ in range(max(args.warmup, 2)):
+        loss = ts.step(batch)
+    torch.cuda.synchronize()
+    t_est = time.perf_counter()
+    ts.step(batch)
+    torch.cuda.synchronize()
+    est = time.perf_counter() - t_est
+    elapsed, k = timed_steps(lambda: ts.step(batch), args.steps, dist, dev, est_steps=int(MIN_TIMED_S / est) + 1)
+    loss = float(ts.step(batch))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training tokens/sec (whole node), 169M d1024xl12 train step, seqlen 4096",
+            "value": world * b * T * k / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": k,
+            "steps_requested": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": elapsed / k * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"L169 train step (fwd + CE + bwd + AdamW), micro-batch {b} x {T} tokens per GPU, "
+                                   f"{nparam / 1e6:.1f}M params, bf16 autocast, fp32 master weights and state",
+                       "global_batch": b * world, "seq_len": T,
+                       "parallelism": f"dp{world} (DistributedDataParallel over RCCL, 128 MB buckets)" if world > 1
+                       else "single GPU"},
+            "loss": loss, "max_mem_GB": torch.cuda.max_memory_allocated(dev) / 1e9}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -220,23 +388,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--preheat-s", type=float, default=1.0, help="seconds of untimed decode before the W warm-up steps")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--train", action="store_true", help="measure config 5 (the DDP training step) instead of decode")
+    ap.add_argument("--train-batch", type=int, default=8, help="--train: sequences of 4096 tokens per GPU")
+    ap.add_argument("--check-launch", action="store_true", help="only exercise the N-rank launch / rendezvous logic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chunk", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_under_torchrun(args.gpus, sys.argv[1:]))
+    if args.check_launch:
+        return check_launch(args)
+    if args.train:
+        return bench_train(args)
+
+    rank, local, world, dev, dist = init_world(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)               # "nccl" is RCCL on ROCm
 
     from lina_speech_amd import ops
     from lina_speech_amd.configs import l169, n_params
@@ -262,64 +431,84 @@ def main():
         # settle the engine clock first (untimed, outside the W warm-up steps): the chip ramps up from idle over the first
         # fraction of a second of load
         t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < args.preheat_s:
-            eng.begin_greedy(100)
+        n_pre = 0
+        while time.perf_counter() - t_pre < args.preheat_s or n_pre == 0:
+            eng.begin_greedy(150)
             for _ in range(100):
                 eng.greedy_step()
             torch.cuda.synchronize()
-        eng.begin_greedy(args.steps + args.warmup)
+            n_pre += 100
+        t_est = time.perf_counter()                                  # step time estimate on the captured graph
+        for _ in range(50):
+            eng.greedy_step()
+        torch.cuda.synchronize()
+        est = (time.perf_counter() - t_est) / 50
+        k_run = max(args.steps, int(MIN_TIMED_S / est) + 1)
+        if dist is not None:
+            kk = torch.tensor([k_run], device=dev, dtype=torch.int64)
+            dist.all_reduce(kk, op=dist.ReduceOp.MAX)
+            k_run = int(kk.item())
+        eng.begin_greedy(k_run + args.warmup)
         for _ in range(args.warmup):
             eng.greedy_step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.greedy_step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
+        elapsed, k_run = timed_steps(eng.greedy_step, k_run, dist, dev)
         toks = eng.greedy_tokens()
-        assert toks.shape == (1, B, args.steps + args.warmup)
+        assert toks.shape == (1, B, k_run + args.warmup)
         assert int(toks.min()) >= 0 and int(toks.max()) < 4099
 
         out = None
         if rank == 0:
             P = eng.packs[0]
-            k1_dt = measure_k1(eng)
+            k1_dt, k1_entry = measure_k1(eng)
             e_io = 2 if dtype == torch.bfloat16 else 4
             k1_rows = P.S.shape[0]
             k1_bytes = k1_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4)
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r01_k1d_traffic.json")
-            if os.path.exists(tpath) and k1_rows == 64:      # PMC passes are separate runs; their committed summary
-                tj = json.load(open(tpath))
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_k1d_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
-            roof = {"kernel": "lina::gla_decode_rowsplit_kernel<256>", "bound": "hbm",
+            for name in ("r02_k1d_traffic.json", "r01_k1d_traffic.json"):   # PMC passes are separate runs; committed summary
+                tpath = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(tpath) and k1_rows == 64 and dtype == torch.bfloat16:
+                    tj = json.load(open(tpath))
+                    traffic = tj["traffic_bytes_per_launch"]
+                    traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
+                    break
+            roof = {"kernel": "lina::gla_decode_rowsplit_kernel<256, FUSE=%s> (%s)" % (
+                        "true" if k1_entry.endswith("norm") else "false", k1_entry), "bound": "hbm",
                     "achieved": k1_bytes / k1_dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": k1_bytes / k1_dt / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": k1_bytes, "us_per_launch": k1_dt * 1e6, "rows_per_launch": k1_rows,
                     "launches_per_step": len(eng.packs) * len(eng.parts)}
+            # the step as a whole against HBM: recurrent state read + written once per block, every decode-time weight
+            # read once (the bytes the engine's packs actually hold), text-side K/V rows read once
+            ms_step = elapsed / k_run * 1e3
+            w_bytes = sum(t.numel() * t.element_size() for P_ in eng.packs for t in
+                          (P_.w_in, P_.w_o, P_.w_up, P_.w_down)) + eng.w_head.numel() * eng.w_head.element_size() \
+                + eng.ca_qw.numel() * eng.ca_qw.element_size()
+            s_bytes = sum(2 * P_.S.numel() * 4 for part in eng.parts for P_ in part.packs)
+            kv_bytes = sum(part.kk.numel() * part.kk.element_size() + part.vv.numel() * part.vv.element_size()
+                           for part in eng.parts)
+            step_bytes = w_bytes + s_bytes + kv_bytes
+            step_roof = {"what": "whole decode step vs HBM: state r+w + decode-time weights + text K/V, per step per GPU",
+                         "state_bytes": s_bytes, "weight_bytes": w_bytes, "text_kv_bytes": kv_bytes,
+                         "bytes_per_step": step_bytes, "ms_per_step": ms_step, "bound": "hbm",
+                         "achieved": step_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
             out = {
                 "metric": "codec tokens/sec (whole node), 169M d1024xl12 batched greedy decode",
-                "value": total_rows * args.steps / elapsed, "unit": "codec tokens/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                "value": total_rows * k_run / elapsed, "unit": "codec tokens/s", "n_gpus": world,
+                "steps": k_run, "steps_requested": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
                 "config": {"workload": f"L169 greedy codec-token decode, B={B_PER_GPU}/GPU (B_total={total_rows}), "
                                        f"T_txt={T_TXT}, H=4 Dk=Dv=256, 12+1 GLA blocks, fp32 recurrent state, "
                                        f"{nparam / 1e6:.1f}M params, one hipGraph replay per token, "
                                        f"{len(eng.parts)} parallel row ranges per GPU",
-                           "global_batch": total_rows, "parallelism": f"batch-shard x{world} (no collective)"},
-                "roofline": roof,
+                           "global_batch": total_rows, "parallelism": f"batch-shard x{world} (no collective)",
+                           "timed_region": f"max({args.steps} requested steps, {MIN_TIMED_S} s) = {k_run} steps"},
+                "roofline": roof, "step_roofline": step_roof,
             }
+            if dist is not None:
+                out["ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                "collectives_in_timed_region": "barrier only (batch shard, no data-path collective)"}
             # secondary, untimed-region measurements (rank 0 only): the default sampling mode of the reference
             # (top-k 100, temperature) through the same graph, K2 / K2b at the training shape
             if world == 1:
@@ -341,8 +530,30 @@ def main():
                 out["vocoder"] = measure_vocoder(dev)
                 out["chunk_bwd_kernel"] = measure_chunk_bwd(dev)
     if rank == 0:
-        if not args.no_train and world == 1:
+        if world == 1 and dtype == torch.bfloat16 and not args.no_chunk:
+            # the parity dtype beside the headline dtype: the same engine with fp32 weights / activations
             del eng
+            torch.cuda.empty_cache()
+            with torch.inference_mode():
+                m32 = model.to(dev, torch.float32)
+                eng32 = DecodeEngine(m32, m32.txt_encoder(m32.txt_embed(texts)), batch_size=B)
+                eng32.begin_greedy(260)
+                for _ in range(60):
+                    eng32.greedy_step()
+                torch.cuda.synchronize()
+                t32 = time.perf_counter()
+                for _ in range(200):
+                    eng32.greedy_step()
+                torch.cuda.synchronize()
+                t32 = (time.perf_counter() - t32) / 200
+            out["decode_f32"] = {"dtype": "f32", "ms_per_step": t32 * 1e3, "tokens_per_s": B / t32,
+                                 "what": "same engine, fp32 weights and activations (the dtype the token-exact parity "
+                                         "tests run in)"}
+            del eng32
+            model.to("cpu")
+            torch.cuda.empty_cache()
+        if not args.no_train and world == 1:
+            eng = None
             torch.cuda.empty_cache()
             out["train_step"] = measure_train_step(dev)
         if not args.no_cpu_baseline and world == 1:

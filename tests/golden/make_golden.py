@@ -220,8 +220,34 @@ def golden_vocoder():
     npz("vocoder_small.npz", **out)
 
 
+def golden_simple_gla():
+    """BASELINE.json configs[0] / SURVEY 8(a) a-12: the reference's AttentiveSimpleGLA.forward (model/simple_gla.py:
+    152-165) at d=256, 2 GLA blocks (+ the pos_net block), B=4, T=256 on the CPU -- through the reference's own wrapper,
+    MixingBlock and BlindCrossAttention, with the oracle's scalar-gate layer bound to fla.layers.simple_gla.  Weights
+    are rounded to fp16-representable values BEFORE the run and stored as fp16 (halves the fixture)."""
+    from model.simple_gla import AttentiveSimpleGLA  # noqa: E402  (reference)
+    torch.manual_seed(3)
+    rnn = AttentiveSimpleGLA(d_model=256, n_layer=1, heads=4, blind=True, use_short_conv=True).eval()
+    with torch.no_grad():
+        for p_ in rnn.parameters():
+            p_.copy_(p_.half().float())
+    B, T, Ttxt = 4, 256, 24
+    x = torch.randn(B, T, 256).half().float()
+    ctx = torch.randn(B, Ttxt, 256).half().float()
+    with torch.no_grad():
+        y, att = rnn(x, ctx)
+        y_short, att_short = rnn(x[:, :37], ctx[:, :11])
+    out = {"x": x.half(), "ctx": ctx.half(), "y": y, "att": att.half(), "y_short": y_short, "att_short": att_short}
+    for k, v in rnn.state_dict().items():
+        out["sd::" + k] = v.half()
+    npz("simple_gla_d256.npz", **out)
+
+
 if __name__ == "__main__":
-    golden_vocoder()
-    golden_tools()
-    golden_mixer()
-    golden_lina()
+    import argparse
+    only = sys.argv[1:]
+    todo = {"vocoder": golden_vocoder, "tools": golden_tools, "mixer": golden_mixer, "lina": golden_lina,
+            "simple_gla": golden_simple_gla}
+    for name, fn in todo.items():
+        if not only or name in only:
+            fn()

@@ -112,6 +112,101 @@ def check_chunk_segmented(dev, B, H, T, nseg, resets=False):
     assert_close(o2, oracle_gla(q, k, v, gk, None)[0], tol_out(dtype, chunk=True), "K2 segmented o (h0=None)")
 
 
+def oracle_gla_grads_long(q, k, v, gk, h0, d_o, d_ht, seg=256):
+    """Gradients of  sum(o * d_o) + sum(S_T * d_ht)  through the fp64 recurrent oracle at LONG T: exact torch autograd
+    through oracle.naive_recurrent_gla, run segment by segment (forward once keeping only the segment-boundary states,
+    then each segment again under autograd from the last to the first, the state gradient handed down) -- the same
+    numbers as one autograd pass over all T steps at 1/(T/seg) of its memory (a 4096-step pass would keep ~20 GB of
+    fp64 states alive)."""
+    qd, kd, vd, gd, dod = (x.detach().cpu().to(F64) for x in (q, k, v, gk, d_o))
+    B, H, T, Dk = qd.shape
+    Dv = vd.shape[-1]
+    S = torch.zeros(B, H, Dk, Dv, dtype=F64) if h0 is None else h0.detach().cpu().to(F64)
+    starts = []
+    with torch.no_grad():
+        for t0 in range(0, T, seg):
+            starts.append(S)
+            sl = slice(t0, min(T, t0 + seg))
+            _, S = O.naive_recurrent_gla(qd[:, :, sl], kd[:, :, sl], vd[:, :, sl], gd[:, :, sl], initial_state=S,
+                                         output_final_state=True, compute_dtype=F64)
+    dS = torch.zeros_like(S) if d_ht is None else d_ht.detach().cpu().to(F64)
+    grads = [torch.empty_like(x) for x in (qd, kd, vd, gd)]
+    for i in reversed(range(len(starts))):
+        t0 = i * seg
+        sl = slice(t0, min(T, t0 + seg))
+        leaves = [x[:, :, sl].clone().requires_grad_(True) for x in (qd, kd, vd, gd)]
+        s_in = starts[i].clone().requires_grad_(True)
+        o, s_out = O.naive_recurrent_gla(*leaves, initial_state=s_in, output_final_state=True, compute_dtype=F64)
+        ((o * dod[:, :, sl]).sum() + (s_out * dS).sum()).backward()
+        for gsum, leaf in zip(grads, leaves):
+            gsum[:, :, sl] = leaf.grad
+        dS = s_in.grad
+    return grads, dS, S
+
+
+def check_chunk_bwd_long(dev, B, H, T, Dk, Dv, dtype, reset_every=512, with_h0=True, with_dht=True):
+    """K2b at the config-5 sequence length (SURVEY 8(d) adversarial set): model-like gates logsigmoid(.)/16 plus reset
+    gates (-20, reference reset_val model/gla.py:136,183) on every channel at every ``reset_every``-th token and on a
+    third of the channels half-way between -- many state renormalisations, segment boundaries of the sweeps, bf16
+    error accumulated over 4096 tokens.  Tolerances relative to max|ref| per tensor: fp32 I/O 5e-4, bf16 I/O 2e-2."""
+    g = torch.Generator().manual_seed(41)
+    heads = lambda x: x.view(B, T, H, -1).transpose(1, 2)
+    q = torch.randn(B, T, H * Dk, generator=g).to(dtype)
+    k = torch.randn(B, T, H * Dk, generator=g).to(dtype)
+    v = torch.randn(B, T, H * Dv, generator=g).to(dtype)
+    gk = F.logsigmoid(torch.randn(B, T, H * Dk, generator=g)) / 16
+    if reset_every:
+        gk[:, reset_every - 1::reset_every] = -20.0
+        gk[:, reset_every // 2::reset_every, ::3] = -20.0
+    gk = gk.to(dtype)
+    d_o = heads(torch.randn(B, T, H * Dv, generator=g).to(dtype).to(dev))
+    h0 = (torch.randn(B, H, Dk, Dv, generator=g) * 0.5).to(dev) if with_h0 else None
+    d_ht = (torch.randn(B, H, Dk, Dv, generator=g) * 0.3).to(dev) if with_dht else None
+    q, k, v, gk = (heads(x.to(dev)) for x in (q, k, v, gk))
+    leaves = [x.detach().clone().requires_grad_(True) for x in (q, k, v, gk)]
+    lh0 = None if h0 is None else h0.detach().clone().requires_grad_(True)
+    o, S = ops.chunk_gla(*leaves, initial_state=lh0, output_final_state=with_dht)
+    loss = (o.float() * d_o.float()).sum()
+    if with_dht:
+        loss = loss + (S * d_ht).sum()
+    loss.backward()
+    (rq, rk, rv, rg), rdh0, rS = oracle_gla_grads_long(q, k, v, gk, h0, d_o, d_ht)
+    tol = 2e-2 if dtype == torch.bfloat16 else 5e-4
+    if with_dht:
+        assert_close(S, rS, 1e-2 if dtype == torch.bfloat16 else 2e-4, "K2 final state at long T")
+    for name, a, r in zip(("dq", "dk", "dv", "dg"), leaves, (rq, rk, rv, rg)):
+        assert_close(a.grad, r, tol, f"K2b {name} (T={T})")
+    if h0 is not None:
+        assert_close(lh0.grad, rdh0, 1e-2 if dtype == torch.bfloat16 else 5e-4, f"K2b dh0 (T={T})")
+
+
+def check_chunk_simple(dev, B, H, T, Dk, Dv, dtype, with_h0=True):
+    """ops.chunk_simple_gla (fla.ops.simple_gla.chunk_simple_gla, reference model/gla.py:22, simple_gla.py:135 via the
+    fla layer): scalar log-gate per head g [B,H,T] -> K2 with the gate broadcast over Dk; vs the fp64 scalar-gate
+    recurrence of the oracle."""
+    q, k, v, gk, h0 = make_gla_inputs(B, H, T, Dk, Dv, dtype, dev, seed=31)
+    g = gk[..., 0].float().contiguous()                         # [B,H,T] fp32 (the layer computes it in fp32)
+    if not with_h0:
+        h0 = None
+    ro, rS = O.simple_gla_recurrent(q.cpu().to(F64), k.cpu().to(F64), v.cpu().to(F64), g.cpu().to(F64),
+                                    initial_state=None if h0 is None else h0.cpu().to(F64),
+                                    output_final_state=True, compute_dtype=F64)
+    o, S = ops.chunk_simple_gla(q, k, v, g, initial_state=h0, output_final_state=True)
+    assert o.dtype == dtype and S.dtype == torch.float32
+    assert_close(o, ro, tol_out(dtype, chunk=True), "simple-GLA o")
+    assert_close(S, rS, 1e-4 if dtype == torch.float32 else 1e-2, "simple-GLA state")
+    # gradients flow through the broadcast (dg = sum over Dk of the vector-gate gradient)
+    if dtype == torch.float32 and T <= 80:
+        leaves = [x.detach().clone().requires_grad_(True) for x in (q, k, v, g)]
+        o2, _ = ops.chunk_simple_gla(*leaves)
+        o2.square().sum().backward()
+        rl = [x.detach().cpu().to(F64).requires_grad_(True) for x in (q, k, v, g)]
+        ro2, _ = O.simple_gla_recurrent(*rl, compute_dtype=F64)
+        ro2.square().sum().backward()
+        for name, a, r in zip(("dq", "dk", "dv", "dg"), leaves, rl):
+            assert_close(a.grad, r.grad, 5e-4, f"simple-GLA {name}")
+
+
 def check_chunk_bwd(dev, B, H, T, Dk, Dv, dtype, resets=False, with_h0=True, with_dht=True, via="chunk_gla"):
     """K2b: gradients of (o, final_state) w.r.t. q, k, v, g, h0 against torch autograd through the fp64
     recurrent oracle.  Tolerances relative to max|ref|: fp32 I/O 2e-4 (different summation order, fast exp),

@@ -259,3 +259,26 @@ def check_vocoder_golden(dev):
         f2 = voc.codebook[0][codes[0]].transpose(1, 2)
         close(a2, voc.decode(f2, bandwidth_id=bw).cpu().numpy(), "codes -> waveform", 1e-6)
     assert a2.shape == (3, 23 * hop)
+
+
+def check_simple_gla_golden(dev, full=True):
+    """a-12 / BASELINE configs[0]: the product's AttentiveSimpleGLA (scalar-gate GLA on K2) reproduces the output and
+    attention weights the REFERENCE's AttentiveSimpleGLA.forward (model/simple_gla.py:152-165) produced on the CPU
+    with the pure-PyTorch recurrent layer (golden_simple_gla in tests/golden/make_golden.py): d=256, 2 GLA blocks +
+    pos_net, B=4, T=256 (``full``) and a ragged short case T=37, Ttxt=11.  fp32; 2e-4 of max|golden|."""
+    from lina_speech_amd.simple_gla import AttentiveSimpleGLA
+    g = load_golden("simple_gla_d256.npz")
+    rnn = AttentiveSimpleGLA(d_model=256, n_layer=1, heads=4, blind=True, use_short_conv=True)
+    sd = {k[4:]: torch.from_numpy(g[k].astype(np.float32)) for k in g.files if k.startswith("sd::")}
+    rnn.load_state_dict(sd, strict=True)                     # the reference module's own keys
+    rnn = rnn.to(dev).eval()
+    x = torch.from_numpy(g["x"].astype(np.float32)).to(dev)
+    ctx = torch.from_numpy(g["ctx"].astype(np.float32)).to(dev)
+    with torch.no_grad():
+        y, att = rnn(x[:, :37], ctx[:, :11])
+        close(y, g["y_short"], "simple-GLA short y")
+        close(att, g["att_short"], "simple-GLA short att")
+        if full:
+            y, att = rnn(x, ctx)
+            close(y, g["y"], "simple-GLA y (B=4, T=256, d=256)")
+            close(att, g["att"].astype(np.float32), "simple-GLA att", 1e-3)      # stored as fp16

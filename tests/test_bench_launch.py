@@ -1,0 +1,36 @@
+"""bench.py --gpus N must run N ranks: launched WITHOUT a launcher it re-executes itself under
+torch.distributed.run; launched BY one (the driver's command) it refuses a world that is not N.  --check-launch stops
+after the rendezvous, so this runs on a CPU-only host over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, *argv], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_2_relaunches_itself_with_two_ranks():
+    r = _run(["bench.py", "--gpus", "2", "--check-launch"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["world_size"] == 2 and j["ranks_seen"] == 2 and j["n_gpus"] == 2 and j["rows_total"] == 128
+
+
+def test_bench_under_the_drivers_launcher_sees_world_2():
+    r = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", "29731", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--check-launch"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["world_size"] == 2 and j["ranks_seen"] == 2
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    r = _run(["bench.py", "--gpus", "4", "--check-launch"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 4" in (r.stderr + r.stdout)

@@ -74,3 +74,10 @@ def test_init_state_tuning_gradients_match_reference(emu):
 def test_vocoder_matches_reference_modules(emu):
     from model_cases import check_vocoder_golden
     check_vocoder_golden("cpu")
+
+
+def test_config1_simple_gla_stack_matches_reference_wrapper(emu):
+    """a-12: AttentiveSimpleGLA.forward (reference model/simple_gla.py:152-165) -- short ragged case on the emulator
+    (the B=4, T=256 case of BASELINE configs[0] runs in the -m gpu suite and, on the oracle, in test_oracle.py)."""
+    from model_cases import check_simple_gla_golden
+    check_simple_gla_golden("cpu", full=False)

@@ -5,7 +5,7 @@ import torch
 
 from oracle import gla_oracle as O
 from kernel_cases import (check_chunk_segmented, check_topk_sample, check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_rmsnorm_bwd, check_embed_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
-                          check_prologue, check_recurrent, check_rmsnorm, check_swiglu)
+                          check_prologue, check_recurrent, check_rmsnorm, check_swiglu, check_chunk_simple)
 
 DEV = "cpu"
 
@@ -169,3 +169,8 @@ def test_chunk_bwd_through_the_final_state_only(emu):
             assert float(x.grad.abs().max()) < 1e-6, name
         else:
             assert_close(x.grad, r, 2e-4, f"K2b {name} (final state only)")
+
+
+@pytest.mark.parametrize("Dk,Dv,T,dtype,h0", [(64, 64, 37, torch.float32, True), (64, 128, 21, torch.bfloat16, False)])
+def test_chunk_simple_gla(emu, Dk, Dv, T, dtype, h0):
+    check_chunk_simple(DEV, B=1, H=2, T=T, Dk=Dk, Dv=Dv, dtype=dtype, with_h0=h0)

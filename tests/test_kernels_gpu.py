@@ -234,3 +234,31 @@ def test_dwconv7_ln(hip, C, dtype, ada):
 def test_istft_ola(hip, T, win, hop):
     from kernel_cases import check_istft_ola
     check_istft_ola(DEV, B=3, T=T, win=win, hop=hop)
+
+
+# ----------------------------------------------------------------------------- config 1: scalar-gate GLA (a-12)
+@pytest.mark.parametrize("Dk,Dv,T,dtype,h0", [(64, 64, 256, torch.float32, True), (64, 64, 70, torch.float32, False),
+                                              (256, 256, 300, torch.bfloat16, True), (128, 128, 257, torch.bfloat16, False)])
+def test_chunk_simple_gla(hip, Dk, Dv, T, dtype, h0):
+    from kernel_cases import check_chunk_simple
+    check_chunk_simple(DEV, B=4, H=4, T=T, Dk=Dk, Dv=Dv, dtype=dtype, with_h0=h0)
+
+
+# ----------------------------------------------------------------------------- config 5 sequence length (T = 4096)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_chunk_bwd_at_the_training_sequence_length_with_resets(hip, dtype):
+    """K2b vs fp64 autograd through the oracle at T=4096, b=1, H=4, 256x256, resets every 512 tokens."""
+    from kernel_cases import check_chunk_bwd_long
+    check_chunk_bwd_long(DEV, B=1, H=4, T=4096, Dk=256, Dv=256, dtype=dtype, reset_every=512)
+
+
+def test_chunk_bwd_long_without_boundary_states(hip):
+    from kernel_cases import check_chunk_bwd_long
+    check_chunk_bwd_long(DEV, B=1, H=2, T=2048 + 37, Dk=256, Dv=256, dtype=torch.bfloat16, reset_every=700,
+                         with_h0=False, with_dht=False)
+
+
+@pytest.mark.parametrize("nseg,resets", [(8, False), (16, True)])
+def test_chunk_segment_parallel_at_the_training_sequence_length(hip, nseg, resets):
+    """Segment-parallel K2 (the form config 5's micro-batch takes) at T=4096 vs the fp64 recurrent oracle."""
+    check_chunk_segmented(DEV, B=1, H=4, T=4096, nseg=nseg, resets=resets)

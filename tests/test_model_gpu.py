@@ -129,3 +129,98 @@ def test_full_size_vocoder_matches_cpu_oracle(hip):
     assert audio.shape == (2, 60 * 320)
     err = (audio.cpu().double() - ref).abs().max() / ref.abs().max()
     assert err < 5e-4, float(err)
+
+
+def test_config1_simple_gla_stack_matches_reference_wrapper(hip):
+    """BASELINE configs[0] at its named shape (d=256, 2 GLA blocks, B=4, T=256): product on the GPU vs the output the
+    reference's AttentiveSimpleGLA.forward produced on the CPU (pure-PyTorch recurrent)."""
+    from model_cases import check_simple_gla_golden
+    check_simple_gla_golden("cuda", full=True)
+
+
+def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
+    """The HEADLINE configuration (BASELINE configs[1]: L169, bf16, B=64, device-side hipGraph loop) against the
+    fp32 CPU oracle of the reference loop (model/modeling_lina.py:152-179):
+      1. the engine decodes 32 tokens free-running;
+      2. the oracle is teacher-forced with the engine's tokens -> reference logits and top-2 margins for the SAME
+         history at every position;
+      3. the engine's token must be the oracle's arg-max wherever the oracle's margin exceeds the logits tolerance
+         (2e-2 of max|logits|: bf16 weights and activations vs fp32), the number of positions below it is printed;
+      4. the engine's teacher-forced logits (generic step API) are within that tolerance of the oracle's."""
+    from lina_speech_amd.configs import l169
+    from lina_speech_amd.decode import DecodeEngine
+    from oracle.lina_decode_oracle import OracleLina
+    torch.manual_seed(0)
+    model = l169().eval()
+    B, n, REL = 64, 32, 2e-2
+    x = torch.randint(3, 256, (B, 24), generator=torch.Generator().manual_seed(7))
+    mb = model.to(torch.bfloat16)
+    sd = {k: v.float() for k, v in mb.state_dict().items()}          # the oracle sees the SAME (bf16-rounded) weights
+    with torch.inference_mode():
+        m = mb.to("cuda")
+        x_enc = m.txt_encoder(m.txt_embed(x.cuda()))
+        toks = DecodeEngine(m, x_enc, batch_size=B).run_greedy(n).cpu()                  # [1,B,n]
+    orc = OracleLina(sd, n_layer=6, heads=4, txt_heads=4)
+    ref_toks, ref_logits, _, margins = orc.generate_greedy(x, n, teacher=toks)             # teacher-forced on OUR tokens
+    scale = float(ref_logits.abs().max())
+    safe = margins > REL * scale
+    n_masked = int((~safe).sum())
+    print(f"\nbf16 B=64 engine vs fp32 oracle: {n_masked} of {B * n} positions masked (top-2 margin <= {REL * scale:.4f}); "
+          f"{int((toks[0] != ref_toks[0]).sum())} raw token differences")
+    assert n_masked < 0.25 * B * n, "too many near-ties for the comparison to mean anything"
+    assert torch.equal(toks[0][safe], ref_toks[0][safe]), "bf16 engine token != oracle arg-max at a clear margin"
+    with torch.inference_mode():
+        eng = DecodeEngine(m, x_enc, batch_size=B)
+        y = m.rvq_embed.embed_sum(torch.ones(1, B, 1, dtype=torch.long, device="cuda"))
+        worst = 0.0
+        for t in range(n):
+            logits, _ = eng(y, t)
+            worst = max(worst, float((logits.float().cpu() - ref_logits[:, t:t + 1]).abs().max()) / scale)
+            y = m.rvq_embed.embed_sum(toks[:, :, t:t + 1].cuda())
+    print(f"teacher-forced logits: max |engine - oracle| / max|oracle| = {worst:.3e}")
+    assert worst < REL
+
+
+def test_config3_decode_to_waveform_chain_vs_oracle(hip):
+    """BASELINE configs[2] as ONE pipeline (reference model/modeling_lina.py:181-192 ->
+    3rdparty/decoder/pretrained.py:193-239): L169 greedy decode (fused engine, B=64) -> undelay_rvq - 3 (clamped)
+    -> codes -> WavTokenizer decoder -> 24 kHz waveform, against the oracle chain (OracleLina tokens ->
+    oracle undelay -> OracleVocoder in fp64).  fp32 end to end; waveform rows are compared for the rows whose tokens
+    are all decided at a clear margin (a flipped near-tie token legitimately changes that row's audio)."""
+    from lina_speech_amd.codec import undelay_rvq
+    from lina_speech_amd.configs import l169
+    from lina_speech_amd.vocoder import WavTokenizerDecoder
+    from oracle import gla_oracle as O
+    from oracle.lina_decode_oracle import OracleLina
+    from oracle.vocoder_oracle import OracleVocoder
+    torch.manual_seed(0)
+    model = l169().eval()
+    B, n = 64, 20
+    x = torch.randint(3, 256, (B, 16), generator=torch.Generator().manual_seed(11))
+    orc = OracleLina(model.state_dict(), n_layer=6, heads=4, txt_heads=4)
+    ref_toks, _, _, margins = orc.generate_greedy(x, n)
+    torch.manual_seed(1)
+    voc = WavTokenizerDecoder(n_codes=4096, dim=256, intermediate_dim=512, num_layers=3).eval()
+    with torch.no_grad():
+        for name, p in voc.named_parameters():          # the decoder's default init leaves many tensors constant
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.2)
+    ovoc = OracleVocoder({k: v.clone() for k, v in voc.state_dict().items() if k != "codebook"}, 3, 1280, 320)
+    with torch.inference_mode():
+        m = model.to("cuda")
+        qs, atts, stops, cuts = m.generate_batch(x.cuda(), batch_size=B, max_seqlen=n, k=1, first_greedy_quant=0,
+                                                 force_max_seqlen=True, device="cuda", engine="fused")
+        codes = (undelay_rvq(qs) - m.n_special_token_in).clamp_min(0)                   # [q,B,n-q-1]
+        vg = voc.to("cuda")
+        bw = torch.zeros(1, dtype=torch.long, device="cuda")
+        audio = vg(codes, bandwidth_id=bw).cpu()
+    clear = (margins > 1e-3).all(dim=1)
+    assert int(clear.sum()) >= B // 2
+    assert torch.equal(qs.cpu()[0][clear], ref_toks[0][clear]), "decode tokens differ from the oracle"
+    rcodes = (O.undelay_rvq(ref_toks) - 3).clamp_min(0)
+    assert torch.equal(codes.cpu()[:, clear], rcodes[:, clear])
+    feats = voc.codebook.detach().cpu()[0][rcodes[0]].transpose(1, 2).double()           # [B,C,L]
+    ref_audio = ovoc.decode(feats, torch.zeros(1, dtype=torch.long))
+    assert audio.shape == ref_audio.shape == (B, codes.shape[-1] * 320)
+    err = (audio[clear].double() - ref_audio[clear]).abs().max() / ref_audio[clear].abs().max()
+    assert err < 5e-4, f"waveform rel err {err:.3e}"

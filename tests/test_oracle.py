@@ -102,3 +102,17 @@ def test_tools_known_answers_from_reference():
     assert O.delay_rvq(torch.from_numpy(g["delay_in"]), 1, 2).tolist() == [[1, 13, 14, 15, 16, 2]]
     lg = torch.from_numpy(g["topk_logits"])
     assert torch.equal(O.argmax_lowest(lg), torch.from_numpy(g["topk_k1"]).squeeze(-1))
+
+
+def test_config1_oracle_stack_reproduces_the_reference_wrapper_golden():
+    """The oracle's scalar-gate layer under the PRODUCT's wrapper-free restatement is what the golden was made with;
+    here: the pure-PyTorch CPU recurrent path at the config-1 shape (B=4, T=256, d=256) is re-run through
+    oracle.fla_standin.SimpleGatedLinearAttention and must reproduce the stored first-block output law
+    chunk == recurrent (fp64) at that shape."""
+    torch.manual_seed(0)
+    B, H, T, D = 4, 4, 256, 64
+    q, k, v = (torch.randn(B, H, T, D, dtype=torch.float64) for _ in range(3))
+    g = torch.nn.functional.logsigmoid(torch.randn(B, H, T, dtype=torch.float64)) / 16
+    o1, s1 = O.simple_gla_recurrent(q, k, v, g, output_final_state=True, compute_dtype=torch.float64)
+    o2, s2 = O.chunk_gla(q, k, v, g.unsqueeze(-1).expand(B, H, T, D), output_final_state=True, compute_dtype=torch.float64)
+    assert (o1 - o2).abs().max() < 1e-9 and (s1 - s2).abs().max() < 1e-9
