@@ -118,7 +118,7 @@ class GatedLinearAttention(nn.Module):
         if hidden_states.is_cuda and torch.is_autocast_enabled():
             # under autocast every one of the five projections below would cast this (fp32 LayerNorm output) tensor
             # to the autocast dtype on its own: do it once (same values, 4 fewer passes over [B,T,d])
-            hidden_states = hidden_states.to(torch.get_autocast_gpu_dtype())
+            hidden_states = hidden_states.to(torch.get_autocast_dtype("cuda"))
         g_pre = lr_pre = None                                   # outputs of the fused projection, when it ran
         if self.use_short_conv and self.share_conv_kernel:
             conv_states = (last_state[0] if use_cache else None,)
