@@ -46,38 +46,59 @@ def k1_algorithmic_bytes(B, H, Dk, Dv, e_io, e_g):
     return B * (8 * H * Dk * Dv + e_io * (2 * H * Dk + 2 * H * Dv) + e_g * H * Dk)
 
 
+def k1w_algorithmic_bytes(B, H, Dk, Dv, e_io, e_g, W):
+    """K1w per launch, averaged over the W positions of a window: the state is read every step and written every W-th,
+    q,k,v,gk in and o out as for K1, plus the window history (fp32): one (k, c, v) entry written per step and the
+    j earlier entries read at position j."""
+    state = 4 * H * Dk * Dv * (1.0 + 1.0 / W)
+    io = e_io * (2 * H * Dk + 2 * H * Dv) + e_g * H * Dk
+    hist_w = 4 * H * (2 * Dk + Dv)
+    hist_r = 4 * H * (2 * Dk + Dv) * (W - 1) / 2.0
+    return int(B * (state + io + hist_w + hist_r))
+
+
 def measure_k1(engine, reps=20):
-    """Average duration of one launch of the kernel the hipGraph step actually runs for the recurrent update:
-    lina_gla_decode_update_norm = lina::gla_decode_rowsplit_kernel<..., FUSE=true> (K1d with K5 fused in; the plain
-    K1d entry when the engine was built without the fusion), at the decode shape, on the engine's real buffers, cycling
-    through the 13 layers (1.7 GB of state > L3, so every launch streams from HBM).  HIP events on torch's current
-    stream -- the stream the C-ABI launches are enqueued on.  Returns (seconds per launch, entry point name)."""
+    """Average duration of one launch of the kernel the hipGraph step actually runs for the recurrent update, at the
+    decode shape, on the engine's real buffers, cycling through the 13 layers (1.7 GB of state > L3, so every launch
+    streams from HBM):  K1w + K5 (lina_gla_decode_window, all W window positions in turn) when the engine keeps the state
+    lazily written, else K1d + K5 (lina_gla_decode_update_norm), else plain K1d.  HIP events on torch's current stream --
+    the stream the C-ABI launches are enqueued on.  Returns (seconds per launch, entry point name)."""
     from lina_speech_amd import ops
     packs = engine.packs
     B = packs[0].S.shape[0]          # rows per launch (the engine may split the batch into parallel row ranges)
     fused = engine.fuse_norm and packs[0].row_split
+    lazy = fused and packs[0].lazy
+    W = engine.window
+    steps = [torch.full((1,), j, dtype=torch.long, device=packs[0].S.device) for j in range(W)]
+    origin = torch.zeros(1, dtype=torch.long, device=packs[0].S.device)
 
-    def one_pass():
+    def one_pass(j=0):
         for P in packs:
             q = P.qkv[:, :P.Kd].view(B, P.H, P.Dk)
             k = P.qkv[:, P.Kd:2 * P.Kd].view(B, P.H, P.Dk)
             v = P.qkv[:, 2 * P.Kd:].view(B, P.H, P.Dv)
-            if fused:
+            if lazy:
+                ops.gla_decode_window(q, k, v, P.gk.view(B, P.H, P.Dk), P.S, P.g.view(B, P.H, P.Dv), P.gnw,
+                                      P.og, P.hk, P.hc, P.hv, steps[j], origin, W, P.eps_gate)
+            elif fused:
                 ops.gla_decode_update_norm(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S, P.g.view(B, P.H, P.Dv),
                                            P.gnw, P.og, P.counters, P.eps_gate)
             else:
                 ops.gla_decode_update(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S)
 
-    one_pass()
+    engine.sync_state()
+    for j in range(W):
+        one_pass(j)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = (reps + W - 1) // W * W
     ev0.record()
-    for _ in range(reps):
-        one_pass()
+    for r in range(reps):
+        one_pass(r % W)
     ev1.record()
     torch.cuda.synchronize()
     return (ev0.elapsed_time(ev1) * 1e-3 / (reps * len(packs)),
-            "lina_gla_decode_update_norm" if fused else "lina_gla_decode_update")
+            "lina_gla_decode_window" if lazy else "lina_gla_decode_update_norm" if fused else "lina_gla_decode_update")
 
 
 def host_cpu():
@@ -391,6 +412,7 @@ def main():
     ap.add_argument("--train", action="store_true", help="measure config 5 (the DDP training step) instead of decode")
     ap.add_argument("--train-batch", type=int, default=8, help="--train: sequences of 4096 tokens per GPU")
     ap.add_argument("--check-launch", action="store_true", help="only exercise the N-rank launch / rendezvous logic")
+    ap.add_argument("--window", type=int, default=None, help="state window of the decode loop (1 = immediate update K1d; default 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chunk", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
@@ -427,7 +449,7 @@ def main():
 
     with torch.inference_mode():
         x_enc = model_dev.txt_encoder(model_dev.txt_embed(texts))
-        eng = DecodeEngine(model_dev, x_enc, batch_size=B)
+        eng = DecodeEngine(model_dev, x_enc, batch_size=B, window=args.window)
         # settle the engine clock first (untimed, outside the W warm-up steps): the chip ramps up from idle over the first
         # fraction of a second of load
         t_pre = time.perf_counter()
@@ -462,32 +484,46 @@ def main():
             k1_dt, k1_entry = measure_k1(eng)
             e_io = 2 if dtype == torch.bfloat16 else 4
             k1_rows = P.S.shape[0]
-            k1_bytes = k1_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4)
+            lazy = k1_entry == "lina_gla_decode_window"
+            k1d_bytes = k1_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4)
+            k1_bytes = k1w_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4, eng.window) if lazy else k1d_bytes
             traffic, traffic_src = None, None
-            for name in ("r02_k1d_traffic.json", "r01_k1d_traffic.json"):   # PMC passes are separate runs; committed summary
+            names = ("r02_k1w_traffic.json",) if lazy else ("r02_k1d_traffic.json", "r01_k1d_traffic.json")
+            for name in names:                                # PMC passes are separate runs; their committed summary
                 tpath = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tpath) and k1_rows == 64 and dtype == torch.bfloat16:
                     tj = json.load(open(tpath))
                     traffic = tj["traffic_bytes_per_launch"]
                     traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
                     break
-            roof = {"kernel": "lina::gla_decode_rowsplit_kernel<256, FUSE=%s> (%s)" % (
-                        "true" if k1_entry.endswith("norm") else "false", k1_entry), "bound": "hbm",
+            kname = {"lina_gla_decode_window": "lina::gla_decode_window_kernel<256, 4> (K1w + K5, one workgroup per head, lina_gla_decode_window)",
+                     "lina_gla_decode_update_norm": "lina::gla_decode_rowsplit_kernel<256, FUSE=true> (lina_gla_decode_update_norm)",
+                     "lina_gla_decode_update": "lina::gla_decode_rowsplit_kernel<256, FUSE=false> (lina_gla_decode_update)"}[k1_entry]
+            roof = {"kernel": kname, "bound": "hbm",
                     "achieved": k1_bytes / k1_dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": k1_bytes / k1_dt / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": k1_bytes, "us_per_launch": k1_dt * 1e6, "rows_per_launch": k1_rows,
                     "launches_per_step": len(eng.packs) * len(eng.parts)}
+            if lazy:
+                roof["window"] = eng.window
+                roof["bytes_definition"] = ("state read every step + written every W-th (4 H Dk Dv (1 + 1/W)) + q,k,v,gk,o "
+                                            "+ window history; averaged over the W window positions (DESIGN 4.1)")
+                roof["immediate_form"] = {"what": "SURVEY 8(d) bytes of the immediate update K1 (state read AND written "
+                                                  "every step) over the same time: the traffic this kernel avoids",
+                                          "bytes_per_launch": k1d_bytes,
+                                          "equivalent_GBs": k1d_bytes / k1_dt / 1e9}
             # the step as a whole against HBM: recurrent state read + written once per block, every decode-time weight
             # read once (the bytes the engine's packs actually hold), text-side K/V rows read once
             ms_step = elapsed / k_run * 1e3
             w_bytes = sum(t.numel() * t.element_size() for P_ in eng.packs for t in
                           (P_.w_in, P_.w_o, P_.w_up, P_.w_down)) + eng.w_head.numel() * eng.w_head.element_size() \
                 + eng.ca_qw.numel() * eng.ca_qw.element_size()
-            s_bytes = sum(2 * P_.S.numel() * 4 for part in eng.parts for P_ in part.packs)
+            s_bytes = int(sum((1.0 + 1.0 / (eng.window if P_.lazy else 1)) * P_.S.numel() * 4 for part in eng.parts
+                              for P_ in part.packs))
             kv_bytes = sum(part.kk.numel() * part.kk.element_size() + part.vv.numel() * part.vv.element_size()
                            for part in eng.parts)
             step_bytes = w_bytes + s_bytes + kv_bytes
-            step_roof = {"what": "whole decode step vs HBM: state r+w + decode-time weights + text K/V, per step per GPU",
+            step_roof = {"what": "whole decode step vs HBM: state read (+ write every W-th step) + decode-time weights + text K/V, per step per GPU",
                          "state_bytes": s_bytes, "weight_bytes": w_bytes, "text_kv_bytes": kv_bytes,
                          "bytes_per_step": step_bytes, "ms_per_step": ms_step, "bound": "hbm",
                          "achieved": step_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -500,7 +536,7 @@ def main():
                 "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
                 "config": {"workload": f"L169 greedy codec-token decode, B={B_PER_GPU}/GPU (B_total={total_rows}), "
                                        f"T_txt={T_TXT}, H=4 Dk=Dv=256, 12+1 GLA blocks, fp32 recurrent state, "
-                                       f"{nparam / 1e6:.1f}M params, one hipGraph replay per token, "
+                                       f"{nparam / 1e6:.1f}M params, one hipGraph replay per token, state window {eng.window}, "
                                        f"{len(eng.parts)} parallel row ranges per GPU",
                            "global_batch": total_rows, "parallelism": f"batch-shard x{world} (no collective)",
                            "timed_region": f"max({args.steps} requested steps, {MIN_TIMED_S} s) = {k_run} steps"},

@@ -170,6 +170,15 @@ int lina_rmsnorm_gate_bwd(const void* x, const void* g, const void* w, const voi
 int lina_embed_sum(const int64_t* idx, const void* table, void* out,
                    int Q, int64_t N, int n_emb, int d, int dtype, lina_stream_t stream);
 
+/* K6d -- the token epilogue of a GREEDY decode step in one launch (one workgroup per batch row): arg-max of each of the
+ * Q quantizers' logits (lowest index on ties, as K6b), tok_log[step[0]][q][b] = pick (int64 [max_steps][Q][B]; skipped
+ * when step[0] >= max_steps), x_out[b,:] = sum_q table[q, pick_q, :] (K6a), and step[0] += 1 by the last workgroup to
+ * finish.  logits: [B, Q*L] with a row stride; counter: one int32, zero before the first call (left zero).
+ * Replaces reference model/modeling_lina.py:159-179 (k = 1 picks, token list append, next-input embedding). */
+int lina_greedy_pick_embed(const void* logits, int64_t row_stride, const void* table, void* x_out,
+                           int64_t* tok_log, int64_t* step, int* counter, int B, int Q, int L, int n_emb, int d,
+                           int max_steps, int dtype, lina_stream_t stream);
+
 /* K6b -- greedy pick: out[r] = argmax_j logits[r,j], lowest index on exact ties.
  * Replaces topk_sampling(k=1) (reference model/tools.py:38-44, modeling_lina.py:159-164);
  * identical except on exact ties, where the reference draws uniformly among them. */
@@ -235,6 +244,31 @@ int lina_gla_decode_update_norm(const void* q, const void* k, const void* v, con
                                 int64_t v_sb, int64_t v_sh, int64_t g_sb, int64_t g_sh,
                                 int64_t gate_sb, int64_t gate_sh, float eps,
                                 int dtype, int g_dtype, float scale, lina_stream_t stream);
+
+/* K1w + K5 -- decode-step state update with a WINDOWED (lazily written) state; inputs / output og as
+ * lina_gla_decode_update_norm (one workgroup per (b,h): no partial buffer, no counters), same reference lines
+ * (model/gla.py:186-220 at T = 1), Dk and Dv in {64,128,256}, but `state` is the state at the
+ * START of the current window of `window` (1, 2, 4 or 8) steps: it is only READ on steps 0 .. window-2 and rewritten on
+ * step window-1, the steps in between live in the history buffers
+ *     hist_k, hist_c: fp32 [window][B*H][Dk]  (k_s and the cumulative log-gate c_s of step s of the window)
+ *     hist_v:         fp32 [window][B*H][Dv]
+ * (chunk algebra of SURVEY App. A.3; every exponent is a difference <= 0).  The window position is
+ * (step[0] - origin[0]) mod window, read from DEVICE memory, so one captured graph serves all positions.
+ * lina_gla_decode_window_flush applies the first n_pending history entries to `state` (call it before anybody else reads
+ * the state, then restart the window: origin <- step).  HBM bytes per token and (row, head): 4 Dk Dv (1 + 1/window)
+ * + history instead of 8 Dk Dv.  Returns the state of the immediate form up to fp32 rounding. */
+int lina_gla_decode_window_max(void);
+int lina_gla_decode_window(const void* q, const void* k, const void* v, const void* gk,
+                           float* state, const void* gate, const void* norm_weight,
+                           void* og, float* hist_k, float* hist_c, float* hist_v,
+                           const int64_t* step, const int64_t* origin, int window,
+                           int B, int H, int Dk, int Dv,
+                           int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
+                           int64_t v_sb, int64_t v_sh, int64_t g_sb, int64_t g_sh,
+                           int64_t gate_sb, int64_t gate_sh, float eps,
+                           int dtype, int g_dtype, float scale, lina_stream_t stream);
+int lina_gla_decode_window_flush(float* state, const float* hist_k, const float* hist_c, const float* hist_v,
+                                 int n_pending, int B, int H, int Dk, int Dv, lina_stream_t stream);
 
 /* Decode-step projection with fused neighbours: out[M,N] = epi(A[M,K] . W[N,K]^T), M ~ batch rows.
  *   ln_dim > 0 : A is layer-normalised over its ln_dim features first, folded algebraically:

@@ -53,7 +53,89 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const T* __restrict__ 
     }
 }
 
+// K6d -- the whole token epilogue of a greedy decode step in ONE launch (one workgroup per batch row): arg-max of every
+// quantizer's logits (K6b), the pick appended to the device-side token log at position step[0], the next step's input
+// embedding sum_q table[q, pick_q] (K6a) written into the residual-stream buffer, and -- by the LAST workgroup to finish,
+// when every workgroup has read it -- step[0] += 1.  Replaces five launches (arg-max, transpose copy, index_copy_, add_,
+// embedding gather) of ~5 us each on the serial chain of the step (reference model/modeling_lina.py:159-179).
+template <typename T>
+__global__ __launch_bounds__(256) void greedy_pick_embed_kernel(const T* __restrict__ logits, int64_t row_stride,
+                                                                const T* __restrict__ table, T* __restrict__ x_out,
+                                                                int64_t* __restrict__ tok_log, int64_t* step, int* counter,
+                                                                int Q, int L, int n_emb, int d, int max_steps) {
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    __shared__ int s_tok[16];
+    __shared__ int64_t s_step;
+    const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x;
+    if (tid == 0) s_step = step[0];
+    for (int qi = 0; qi < Q; ++qi) {
+        const T* row = logits + (int64_t)b * row_stride + (int64_t)qi * L;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int j = tid; j < L; j += 256) {
+            const float vj = ld(row + j);
+            if (vj > best || (vj == best && j < bi)) { best = vj; bi = j; }
+        }
+        if (bi == 0x7fffffff && tid < L) bi = tid;  // all -inf/NaN in this thread's slice
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const float ov = shfl_xor(best, m);
+            const int oi = shfl_xor_i(bi, m);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        __syncthreads();                            // s_val / s_idx of the previous quantizer consumed
+        if ((tid & 63) == 0) { s_val[tid >> 6] = best; s_idx[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int wv = 1; wv < 4; ++wv)
+                if (s_val[wv] > best || (s_val[wv] == best && s_idx[wv] < bi)) { best = s_val[wv]; bi = s_idx[wv]; }
+            bi = (bi == 0x7fffffff) ? 0 : bi;
+            s_tok[qi] = bi;
+            const int64_t t = s_step;
+            if (t >= 0 && t < max_steps) tok_log[(t * Q + qi) * B + b] = bi;
+        }
+    }
+    __syncthreads();
+    for (int e = tid * 4; e < d; e += 256 * 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int qi = 0; qi < Q; ++qi) {
+            int tok = s_tok[qi];
+            tok = tok >= n_emb ? n_emb - 1 : tok;
+            const float4 r = ld4(table + ((int64_t)qi * n_emb + tok) * d + e);
+            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+        }
+        st4(x_out + (int64_t)b * d + e, acc);
+    }
+    if (tid == 0) {
+        const int tk = ticket_agent(counter);       // taken AFTER this workgroup has read step[0]
+        if (tk == B - 1) {
+            *counter = 0;                            // re-armed for the next launch
+            step[0] = s_step + 1;
+        }
+    }
+}
+
 }  // namespace lina
+
+extern "C" int lina_greedy_pick_embed(const void* logits, int64_t row_stride, const void* table, void* x_out,
+                                      int64_t* tok_log, int64_t* step, int* counter, int B, int Q, int L, int n_emb,
+                                      int d, int max_steps, int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(logits && table && x_out && tok_log && step && counter, "lina_greedy_pick_embed: null pointer");
+    LINA_REQUIRE(B > 0 && Q > 0 && Q <= 16 && L > 0 && n_emb > 0 && max_steps > 0,
+                 "lina_greedy_pick_embed: B,Q (<= 16),L,n_emb,max_steps must be positive");
+    LINA_REQUIRE(d > 0 && d % 4 == 0, "lina_greedy_pick_embed: d=%d must be a positive multiple of 4", d);
+    LINA_REQUIRE(valid_dtype(dtype), "lina_greedy_pick_embed: bad dtype %d", dtype);
+    dim3 grid((unsigned)B);
+    if (dtype == LINA_F32)
+        LINA_LAUNCH((greedy_pick_embed_kernel<float>), grid, dim3(256), 0, stream, (const float*)logits, row_stride,
+                    (const float*)table, (float*)x_out, tok_log, step, counter, Q, L, n_emb, d, max_steps);
+    else
+        LINA_LAUNCH((greedy_pick_embed_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)logits, row_stride,
+                    (const bf16_t*)table, (bf16_t*)x_out, tok_log, step, counter, Q, L, n_emb, d, max_steps);
+    return check_launch("lina_greedy_pick_embed");
+}
 
 extern "C" int lina_embed_sum(const int64_t* idx, const void* table, void* out, int Q, int64_t N, int n_emb, int d,
                               int dtype, lina_stream_t stream) {

@@ -46,7 +46,8 @@ class _BlockPack:
                "w_in", "c1_in", "c2_in", "ldz", "off_q", "off_k", "off_v", "off_g", "off_lr", "wq", "wk", "wv",
                "w2", "b2", "gnw", "w_o", "hid", "hid_pad", "w_up", "c1_up", "c2_up", "w_down")
 
-    def __init__(self, blk, state, lo=0, hi=None, shared=None):
+    def __init__(self, blk, state, lo=0, hi=None, shared=None, window=1):
+        self.window = window
         if shared is not None:                     # same block, another row range: reuse the packed weights
             for name in self._SHARED:
                 setattr(self, name, getattr(shared, name))
@@ -107,6 +108,11 @@ class _BlockPack:
         self.og = torch.empty(B, self.H, self.Dv, dtype=dt, device=dev)
         self.counters = torch.zeros(B * self.H, dtype=torch.int32, device=dev)
         self.s = torch.empty(B, self.hid_pad, dtype=dt, device=dev)
+        self.lazy = self.window > 1 and self.Dk in (64, 128, 256) and self.Dv in (64, 128, 256)
+        if self.lazy:      # K1w: k_s, cumulative log-gate c_s and v_s of the steps of the current window
+            self.hk = torch.zeros(self.window, B * self.H, self.Dk, dtype=torch.float32, device=dev)
+            self.hc = torch.zeros(self.window, B * self.H, self.Dk, dtype=torch.float32, device=dev)
+            self.hv = torch.zeros(self.window, B * self.H, self.Dv, dtype=torch.float32, device=dev)
 
 
 class _Part:
@@ -127,8 +133,13 @@ class _Part:
 
 class DecodeEngine:
     def __init__(self, model, x_enc: torch.Tensor, batch_size: int, state: Optional[Cache] = None,
-                 use_graph: Optional[bool] = None, n_split: Optional[int] = None, fuse_norm: bool = True):
-        """``n_split`` > 1 cuts the batch into independent row ranges that run on parallel HIP streams inside
+                 use_graph: Optional[bool] = None, n_split: Optional[int] = None, fuse_norm: bool = True,
+                 window: Optional[int] = None):
+        """``window`` (1, 2, 4 or 8; default 8): the device-side decode loop keeps the recurrent state of every block
+        LAZILY WRITTEN -- read every token, rewritten every ``window``-th token (K1w, lina_gla_decode_window); the
+        steps in between live in small history buffers.  ``engine.state`` / ``sync_state()`` materialise the exact
+        state on demand.  1 = the immediate in-place update K1d on every token.
+        ``n_split`` > 1 cuts the batch into independent row ranges that run on parallel HIP streams inside
         the same graph: the step is a chain of ~100 short dependent launches, so two (or four) independent
         chains in flight hide each other's launch/drain latency; rows never interact."""
         rnn = model.attentive_rnn
@@ -136,7 +147,15 @@ class DecodeEngine:
         self.fuse_norm = fuse_norm and os.environ.get("LINA_DECODE_FUSE_NORM", "1") != "0"
         self.B = batch_size
         self.dev = x_enc.device
-        self.state = state if state is not None else rnn.init_state(batch_size=batch_size)
+        if window is None:
+            window = int(os.environ.get("LINA_DECODE_WINDOW", "8"))
+        if window not in (1, 2, 4, 8):
+            raise ValueError("window must be 1, 2, 4 or 8")
+        self.window = window if self.fuse_norm else 1
+        self._state = state if state is not None else rnn.init_state(batch_size=batch_size)
+        self._t_idx = torch.zeros(1, dtype=torch.long, device=self.dev)      # device step counter of the greedy loop
+        self._origin = torch.zeros(1, dtype=torch.long, device=self.dev)     # step at which the current window began
+        self._origin_host, self._n_done, self._lazy_live = 0, 0, False
         blocks = list(rnn.encoder) + list(rnn.decoder) + [rnn.cross_att.pos_net]
         self.n_enc = len(rnn.encoder)
         ca = rnn.cross_att
@@ -165,8 +184,8 @@ class DecodeEngine:
         first = None
         for i in range(n_split):
             lo, hi = shard_rows(batch_size, i, n_split)
-            packs = [_BlockPack(b, self.state[j], lo, hi, shared=None if first is None else first[j])
-                     for j, b in enumerate(blocks)]
+            packs = [_BlockPack(b, self._state[j], lo, hi, shared=None if first is None else first[j],
+                                window=self.window) for j, b in enumerate(blocks)]
             first = first or packs
             self.parts.append(_Part(lo, hi, packs, kk[lo:hi], vv[lo:hi], self.d, hw.dtype, self.dev))
         self.packs = self.parts[0].packs
@@ -178,8 +197,8 @@ class DecodeEngine:
         self._att = torch.zeros(batch_size, 2, 1, kk.shape[1], dtype=hw.dtype, device=self.dev)
 
     # ------------------------------------------------------------------ one GLA block, T = 1 (7 launches)
-    def _block(self, x, P: _BlockPack):
-        """x [B,d] is the residual stream and is UPDATED IN PLACE."""
+    def _block(self, x, P: _BlockPack, lazy: bool = False):
+        """x [B,d] is the residual stream and is UPDATED IN PLACE.  ``lazy``: windowed state update K1w (device loop)."""
         B = x.shape[0]
         if P.fused_in:
             ops.gla_decode_inproj(x, P.w_in, P.c1_in, P.c2_in, P.wq, P.wk, P.wv, P.cq, P.ck, P.cv, P.w2, P.b2,
@@ -193,7 +212,10 @@ class DecodeEngine:
         q = P.qkv[:, :P.Kd].view(B, P.H, P.Dk)
         k = P.qkv[:, P.Kd:2 * P.Kd].view(B, P.H, P.Dk)
         v = P.qkv[:, 2 * P.Kd:].view(B, P.H, P.Dv)
-        if P.row_split and self.fuse_norm:
+        if lazy and P.lazy:
+            ops.gla_decode_window(q, k, v, P.gk.view(B, P.H, P.Dk), P.S, gate, P.gnw, P.og, P.hk, P.hc, P.hv,
+                                  self._t_idx, self._origin, P.window, P.eps_gate)
+        elif P.row_split and self.fuse_norm:
             ops.gla_decode_update_norm(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S, gate, P.gnw, P.og,
                                        P.counters, P.eps_gate)
         elif P.row_split:
@@ -210,7 +232,7 @@ class DecodeEngine:
         ops.linear_skinny(P.s, P.w_down, resid=x, out=x)
         return x
 
-    def _cross(self, part, x):
+    def _cross(self, part, x, lazy=False):
         """x += blind cross-attention: 7 short launches around the pos_net block, every one of them spread over
         >= 256 workgroups (query projection, scores, softmax, att1.pe | xp.pe^T, softmax, att2.V + residual)."""
         ca = self.ca
@@ -219,36 +241,56 @@ class DecodeEngine:
         ops.cross_scores(q_lin, ca.ln_q.weight, ca.ln_q.bias, ca.ln_q.eps, part.kk, part.scores, self.att_scale)
         ops.softmax_rows(part.scores, 1.0, att[:, 0, 0], part.attc, self.Tn)
         ops.linear_skinny(part.attc, self.peT, out=part.xp)                   # xp = att1 . pe
-        self._block(part.xp, part.packs[-1])
+        self._block(part.xp, part.packs[-1], lazy)
         ops.linear_skinny(part.xp, self.pe_pad, out=part.sc2)                 # scores2 = xp . pe^T
         ops.softmax_rows(part.sc2, self.att_scale, att[:, 1, 0], part.attc, self.Tn)
         ops.weighted_rows_add(part.attc, part.vv, x)
 
-    def _core_part(self, part, y):
+    def _core_part(self, part, y, lazy=False):
         x = part.x
         if y is not x:                       # the device-side loop embeds the next token straight into part.x
             x.copy_(y[part.lo:part.hi])
         for P in part.packs[:self.n_enc]:
-            self._block(x, P)
-        self._cross(part, x)
+            self._block(x, P, lazy)
+        self._cross(part, x, lazy)
         for P in part.packs[self.n_enc:-1]:
-            self._block(x, P)
+            self._block(x, P, lazy)
         ops.linear_skinny(x, self.w_head, out=self._logits[part.lo:part.hi])
 
-    def _core(self, y):
+    def _core(self, y, lazy=False):
         """y [B,d] -> (logits [B,1,Q,L], att [B,2,1,Ttxt]) written into the engine's static buffers."""
         if self._streams is None:
             for part in self.parts:
-                self._core_part(part, y)
+                self._core_part(part, y, lazy)
         else:
             main = torch.cuda.current_stream(self.dev)
             for part, st in zip(self.parts, self._streams):       # fork
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
-                    self._core_part(part, y)
+                    self._core_part(part, y, lazy)
             for st in self._streams:                                # join
                 main.wait_stream(st)
         return self._logits.view(self.B, 1, self.Q, self.L), self._att
+
+    # ------------------------------------------------------------------ lazily written state (K1w)
+    @property
+    def state(self):
+        """The per-layer Cache (reference layout).  Reading it materialises the pending window steps first."""
+        self.sync_state()
+        return self._state
+
+    def sync_state(self):
+        """Apply the pending steps of the current window to the recurrent states (no-op when nothing is pending)
+        and start a new window at the current step."""
+        if not self._lazy_live:
+            return
+        pending = (self._n_done - self._origin_host) % self.window
+        if pending:
+            for P in self._all_packs():
+                if P.lazy:
+                    ops.gla_decode_window_flush(P.S, P.hk, P.hc, P.hv, pending)
+        self._origin_host = self._n_done
+        self._origin.fill_(self._n_done)
 
     # ------------------------------------------------------------------ graph capture
     def _all_packs(self):
@@ -279,6 +321,7 @@ class DecodeEngine:
     def __call__(self, y_embd: torch.Tensor, t: int = 0):
         """One token for every row: y_embd [B,1,d] -> (logits [B,1,Q,L], att [B,2,1,Ttxt])."""
         y = y_embd.reshape(self.B, self.d)
+        self.sync_state()                     # the generic step updates the state immediately (K1d)
         if not self.use_graph:
             logits, att = self._core(y)
             return logits, att.clone()
@@ -300,12 +343,16 @@ class DecodeEngine:
         generation mode (modeling_lina.py:159-164); the others -- all of them by default -- take the arg-max
         (K6b)."""
         emb = self.model.rvq_embed
+        self.sync_state()                     # pending window steps of an earlier loop
         if y0 is None:
             y0 = emb.embed_sum(torch.ones(self.Q, self.B, 1, dtype=torch.long, device=self.dev))
         self._y_in.copy_(y0.reshape(self.B, self.d))
         self._tok_log = torch.zeros(max_steps, self.Q, self.B, dtype=torch.long, device=self.dev)
-        self._t_idx = torch.zeros(1, dtype=torch.long, device=self.dev)
-        self._n_done = 0
+        self._t_idx.zero_()
+        self._origin.zero_()
+        self._n_done, self._origin_host = 0, 0
+        lazy = self.window > 1
+        self._lazy_live = lazy
         n_sampled = min(max(first_greedy_quant, 0), self.Q) if k > 1 else 0
         is_sampled = (torch.arange(self.Q, device=self.dev) < n_sampled).unsqueeze(0)        # [1,Q]
 
@@ -313,9 +360,15 @@ class DecodeEngine:
         y_buf = self.parts[0].x if len(self.parts) == 1 else self._y_in
         y_buf.copy_(self._y_in)
 
+        self._pick_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
+
         def body():
-            logits, att = self._core(y_buf)
+            logits, att = self._core(y_buf, lazy)
             lg = logits.view(self.B, self.Q, self.L)
+            if n_sampled == 0 and self.Q <= 16:
+                # K6d: picks, token log, next-token embedding and the step counter in ONE launch
+                ops.greedy_pick_embed(lg, emb.weight, y_buf, self._tok_log, self._t_idx, self._pick_counter)
+                return att
             if n_sampled == 0:
                 pick = ops.argmax_rows(lg)
             elif n_sampled == self.Q:
@@ -372,4 +425,5 @@ class DecodeEngine:
             if record_att:
                 atts.append(att.clone())
         toks = self.greedy_tokens()
+        self.sync_state()
         return (toks, torch.cat(atts, dim=2)) if record_att else toks

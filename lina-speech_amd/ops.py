@@ -500,6 +500,27 @@ def argmax_rows(logits, out=None):
     return out.view(logits.shape[:-1])
 
 
+def greedy_pick_embed(logits, table, x_out, tok_log, step, counter):
+    """K6d (lina_greedy_pick_embed): arg-max per quantizer of ``logits [B, Q, L]``, the picks logged at
+    ``tok_log[step[0]]`` ([max_steps, Q, B] int64), the next input ``x_out [B, d] = sum_q table[q, pick_q]`` and
+    ``step[0] += 1`` -- one launch.  ``counter``: int32 [1], zero."""
+    be = _BACKEND
+    be.require(logits, table, x_out, tok_log, step, counter)
+    B, Q, L = logits.shape
+    Qt, n_emb, d = table.shape
+    if Qt != Q or logits.stride(2) != 1 or logits.stride(1) != L:
+        raise ValueError("logits must be [B, Q, L] with contiguous (Q, L)")
+    if tuple(x_out.shape) != (B, d) or not x_out.is_contiguous() or x_out.dtype != table.dtype or logits.dtype != table.dtype:
+        raise ValueError("x_out must be a contiguous [B, d] tensor of the table's dtype")
+    if tok_log.dtype != torch.int64 or tok_log.dim() != 3 or tuple(tok_log.shape[1:]) != (Q, B) or not tok_log.is_contiguous():
+        raise ValueError("tok_log must be a contiguous int64 [max_steps, Q, B] tensor")
+    if step.dtype != torch.int64 or counter.dtype != torch.int32:
+        raise ValueError("step must be int64, counter int32")
+    _check(be.lib.lina_greedy_pick_embed(_ptr(logits), logits.stride(0), _ptr(table.contiguous()), _ptr(x_out), _ptr(tok_log),
+                                         _ptr(step), _ptr(counter), B, Q, L, n_emb, d, tok_log.shape[0], _dt(table),
+                                         be.stream(table)))
+
+
 # --------------------------------------------------------------------------- decode-step fusions
 def topk_sample_rows(logits, k: int, temp: float = 1.0, u: Optional[torch.Tensor] = None, seed: int = 0,
                      step: Optional[torch.Tensor] = None, out=None):
@@ -639,6 +660,47 @@ def gla_decode_update_norm(q, k, v, gk, o_part, state, gate, norm_weight, og, co
                                               float(eps), _dt(q), _dt(gk),
                                               float(Dk ** -0.5 if scale is None else scale), be.stream(q)))
     return og
+
+
+def gla_decode_window(q, k, v, gk, state, gate, norm_weight, og, hist_k, hist_c, hist_v, step, origin,
+                      window: int, eps: float = 1e-5, scale=None):
+    """K1w + K5 (lina_gla_decode_window): decode-step update with a lazily written state -- ``state`` is read every
+    step and rewritten every ``window``-th one, the steps in between live in hist_k / hist_c [window,B*H,Dk] and
+    hist_v [window,B*H,Dv] (fp32).  ``step`` / ``origin``: int64 device tensors (window position = (step-origin) %
+    window).  Call gla_decode_window_flush before anybody else reads ``state``."""
+    be = _BACKEND
+    be.require(q, k, v, gk, state, gate, norm_weight, og, hist_k, hist_c, hist_v, step, origin)
+    B, H, Dk = q.shape
+    Dv = v.shape[-1]
+    if state.dtype != torch.float32 or not state.is_contiguous() or tuple(state.shape) != (B, H, Dk, Dv):
+        raise ValueError("state must be contiguous fp32 [B,H,Dk,Dv]")
+    for t, shp in ((hist_k, (window, B * H, Dk)), (hist_c, (window, B * H, Dk)), (hist_v, (window, B * H, Dv))):
+        if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shp:
+            raise ValueError(f"history buffers must be contiguous fp32 {shp}")
+    if step.dtype != torch.int64 or origin.dtype != torch.int64:
+        raise ValueError("step / origin must be int64 device tensors")
+    if not og.is_contiguous() or og.dtype != q.dtype or gate.dtype != q.dtype or gate.stride(-1) != 1:
+        raise ValueError("og/gate must be model-dtype tensors, og contiguous, gate row-contiguous")
+    for t in (q, k, v, gk):
+        if t.stride(-1) != 1:
+            raise ValueError("innermost dimension must be contiguous")
+    _check(be.lib.lina_gla_decode_window(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(state), _ptr(gate),
+                                         _ptr(norm_weight), _ptr(og), _ptr(hist_k), _ptr(hist_c),
+                                         _ptr(hist_v), _ptr(step), _ptr(origin), int(window), B, H, Dk, Dv,
+                                         q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                         gk.stride(0), gk.stride(1), gate.stride(0), gate.stride(1), float(eps),
+                                         _dt(q), _dt(gk), float(Dk ** -0.5 if scale is None else scale), be.stream(q)))
+    return og
+
+
+def gla_decode_window_flush(state, hist_k, hist_c, hist_v, n_pending: int):
+    """Apply the first ``n_pending`` steps of the current window to ``state`` (in place)."""
+    be = _BACKEND
+    be.require(state, hist_k, hist_c, hist_v)
+    B, H, Dk, Dv = state.shape
+    _check(be.lib.lina_gla_decode_window_flush(_ptr(state), _ptr(hist_k), _ptr(hist_c), _ptr(hist_v), int(n_pending),
+                                               B, H, Dk, Dv, be.stream(state)))
+    return state
 
 
 def cross_att_step1(q_lin, ln_w, ln_b, ln_eps, kk, pe, att1, xp, scale):

@@ -119,6 +119,15 @@ def oracle_gla_grads_long(q, k, v, gk, h0, d_o, d_ht, seg=256):
     numbers as one autograd pass over all T steps at 1/(T/seg) of its memory (a 4096-step pass would keep ~20 GB of
     fp64 states alive)."""
     qd, kd, vd, gd, dod = (x.detach().cpu().to(F64) for x in (q, k, v, gk, d_o))
+    n_thr = torch.get_num_threads()
+    torch.set_num_threads(min(n_thr, 8))       # thousands of tiny ops: a 256-thread pool only adds wake-up cost
+    try:
+        return _oracle_gla_grads_long(qd, kd, vd, gd, dod, h0, d_ht, seg)
+    finally:
+        torch.set_num_threads(n_thr)
+
+
+def _oracle_gla_grads_long(qd, kd, vd, gd, dod, h0, d_ht, seg):
     B, H, T, Dk = qd.shape
     Dv = vd.shape[-1]
     S = torch.zeros(B, H, Dk, Dv, dtype=F64) if h0 is None else h0.detach().cpu().to(F64)
@@ -172,10 +181,14 @@ def check_chunk_bwd_long(dev, B, H, T, Dk, Dv, dtype, reset_every=512, with_h0=T
     loss.backward()
     (rq, rk, rv, rg), rdh0, rS = oracle_gla_grads_long(q, k, v, gk, h0, d_o, d_ht)
     tol = 2e-2 if dtype == torch.bfloat16 else 5e-4
+    # dg_t = sum_{s >= t} (q_s (.) dq_s - k_s (.) dk_s): a suffix sum over up to T tokens of DIFFERENCES of products whose
+    # factors went through bf16 MFMA operands (2^-9 each) -- the rounding noise of thousands of cancelling terms adds up
+    # to a few per cent of max|dg| at T = 4096 (measured 2.4e-2; 1.5e-2 at T = 150); fp32 I/O (exact fp32 MFMA) stays 5e-4
+    tol_g = 4e-2 if dtype == torch.bfloat16 else 5e-4
     if with_dht:
         assert_close(S, rS, 1e-2 if dtype == torch.bfloat16 else 2e-4, "K2 final state at long T")
     for name, a, r in zip(("dq", "dk", "dv", "dg"), leaves, (rq, rk, rv, rg)):
-        assert_close(a.grad, r, tol, f"K2b {name} (T={T})")
+        assert_close(a.grad, r, tol_g if name == "dg" else tol, f"K2b {name} (T={T})")
     if h0 is not None:
         assert_close(lh0.grad, rdh0, 1e-2 if dtype == torch.bfloat16 else 5e-4, f"K2b dh0 (T={T})")
 
@@ -364,6 +377,30 @@ def check_embed(dev, Q, B, n, n_emb, d, dtype):
     ref = O.embed_sum(table.cpu().to(F64), idx.cpu())
     assert out.shape == (B, n, d)
     assert_close(out, ref, 1e-6 if dtype == torch.float32 else 1e-2, "K6a")
+
+
+def check_greedy_pick_embed(dev, B, Q, L, d, dtype, steps=3):
+    """K6d: arg-max per quantizer (lowest index on exact ties), token log at the device step, next-input embedding
+    sum and the step increment -- against the oracle helpers (reference tools.py:38-44 at k = 1, multiembed.py:21-23)."""
+    g = torch.Generator().manual_seed(17)
+    n_emb = L + 3
+    table = torch.randn(Q, n_emb, d, generator=g).to(dtype).to(dev)
+    tok_log = torch.full((steps + 1, Q, B), -1, dtype=torch.int64, device=dev)
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    for t in range(steps + 2):                                   # two steps past the end of the log: not written
+        logits = torch.randn(B, Q, L, generator=g).to(dtype)
+        logits[0, 0, 5] = logits[0, 0, 9] = 50.0                 # an exact tie: the lowest index wins
+        logits = logits.to(dev)
+        x = torch.full((B, d), float("nan"), dtype=dtype, device=dev)
+        ops.greedy_pick_embed(logits, table, x, tok_log, step, counter)
+        ref = O.argmax_lowest(logits.cpu().float().reshape(B * Q, L)).view(B, Q).t().contiguous()   # [Q,B]
+        assert int(step) == t + 1 and int(counter) == 0
+        if t <= steps:
+            assert torch.equal(tok_log[t].cpu(), ref), f"picks differ at step {t}"
+        assert int(ref[0, 0]) == 5
+        rx = O.embed_sum(table.cpu().to(F64), ref.unsqueeze(-1)).squeeze(1)
+        assert_close(x, rx, 1e-2 if dtype == torch.bfloat16 else 1e-6, "K6d next-input embedding")
 
 
 def check_argmax(dev, rows, n, dtype):
@@ -581,6 +618,55 @@ def check_decode_update_norm(dev, B, H, Dk, Dv, dtype, repeats=1):
         assert torch.equal(S_a, S_b), f"state differs (iteration {it})"
         assert torch.equal(og_a.reshape(B, H, Dv), og_b), f"fused norm output differs (iteration {it})"
         assert int(counters.abs().sum()) == 0, "arrival counters must be left at zero"
+
+
+def check_decode_window(dev, B, H, Dk, Dv, dtype, window=8, n_steps=19, resets=True, origin0=5):
+    """K1w + K5 (windowed, lazily written state) over ``n_steps`` decode steps -- several full windows plus a partial
+    one -- against the fp64 recurrence + norm-gate of the oracle at EVERY step, the flushed final state against the
+    oracle's, and against the immediate kernel K1d+K5 (same inputs): outputs within the kernel tolerance, state 1e-5.
+    Reset gates (-20, reference reset_val) sit inside and at the edge of a window."""
+    g = torch.Generator().manual_seed(14)
+    h0 = (torch.randn(B, H, Dk, Dv, generator=g) * 0.5).to(dev)
+    NP = Dk // 64
+    w = (1 + 0.1 * torch.randn(Dv, generator=g)).to(dtype).to(dev)
+    counters = torch.zeros(B * H, dtype=torch.int32, device=dev)
+    counters_i = torch.zeros(B * H, dtype=torch.int32, device=dev)
+    S_w, S_i = h0.clone(), h0.clone()
+    S_ref = h0.detach().cpu().to(F64)
+    hk = torch.full((window, B * H, Dk), float("nan"), device=dev)
+    hc = torch.full((window, B * H, Dk), float("nan"), device=dev)
+    hv = torch.full((window, B * H, Dv), float("nan"), device=dev)
+    step = torch.full((1,), origin0, dtype=torch.int64, device=dev)
+    origin = torch.full((1,), origin0, dtype=torch.int64, device=dev)
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    for t in range(n_steps):
+        q = torch.randn(B, H, Dk, generator=g).to(dtype).to(dev)
+        k = torch.randn(B, H, Dk, generator=g).to(dtype).to(dev)
+        v = torch.randn(B, H, Dv, generator=g).to(dtype).to(dev)
+        gk = (F.logsigmoid(torch.randn(B, H, Dk, generator=g) * 2.0) / 4.0)
+        if resets and t in (3, 7, 8, 12):
+            gk[:, :, ::2] = -20.0
+        gk = gk.to(dev)
+        gate = torch.randn(B, H, Dv, generator=g).to(dtype).to(dev)
+        og = torch.full((B, H, Dv), float("nan"), dtype=dtype, device=dev)
+        ops.gla_decode_window(q, k, v, gk, S_w, gate, w, og, hk, hc, hv, step, origin, window, 1e-5)
+        step += 1
+        op_i = torch.empty(NP, B, H, Dv, device=dev)
+        og_i = torch.empty(B, H, Dv, dtype=dtype, device=dev)
+        ops.gla_decode_update_norm(q, k, v, gk, op_i, S_i, gate, w, og_i, counters_i, 1e-5)
+        # oracle: one recurrence step + norm-gate in fp64
+        qd, kd, vd, gd = (x.cpu().to(F64) for x in (q, k, v, gk))
+        S_ref = S_ref * gd.exp().unsqueeze(-1) + kd.unsqueeze(-1) * vd.unsqueeze(-2)
+        o_ref = torch.einsum("bhk,bhkv->bhv", qd * Dk ** -0.5, S_ref)
+        og_ref = O.rmsnorm_swish_gate(o_ref, gate.cpu().to(F64), w.cpu().to(F64), 1e-5)
+        assert_close(og, og_ref, tol, f"K1w og (step {t}, window position {t % window})")
+        assert_close(og.float(), og_i.float(), tol, f"K1w vs K1d og (step {t})")
+        if (t + 1) % window == 0:                 # a completed window leaves the state fully written back
+            assert_close(S_w, S_ref, 1e-5, f"K1w state after window (step {t})")
+    pending = n_steps % window
+    ops.gla_decode_window_flush(S_w, hk, hc, hv, pending)
+    assert_close(S_w, S_ref, 1e-5, "K1w flushed state")
+    assert_close(S_w, S_i, 1e-5, "K1w flushed state vs K1d state")
 
 
 def check_cross_att(dev, B, Tn, d, dtype):

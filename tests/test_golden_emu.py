@@ -81,3 +81,45 @@ def test_config1_simple_gla_stack_matches_reference_wrapper(emu):
     (the B=4, T=256 case of BASELINE configs[0] runs in the -m gpu suite and, on the oracle, in test_oracle.py)."""
     from model_cases import check_simple_gla_golden
     check_simple_gla_golden("cpu", full=False)
+
+
+def test_engine_windowed_state_equals_immediate_state(emu):
+    """K1w in the device-side loop (state rewritten every 8th / 4th token) vs the immediate update (window=1): same
+    tokens, and after sync_state() the same recurrent states and conv caches; the loop can be continued after a sync
+    (the window restarts) and re-armed (begin_greedy flushes what is pending)."""
+    import torch
+    from model_cases import build_lina, golden_state_dict, load_golden
+    from lina_speech_amd.decode import DecodeEngine
+    g = load_golden("lina_d64.npz")
+    model = build_lina()
+    model.load_state_dict(golden_state_dict(g))
+    model.eval()
+    with torch.no_grad():
+        x = torch.from_numpy(g["gen_x"]).unsqueeze(0).expand(3, -1)
+        x_enc = model.txt_encoder(model.txt_embed(x))
+        ref = DecodeEngine(model, x_enc, batch_size=3, window=1)
+        toks_ref = ref.run_greedy(12)
+        assert torch.equal(toks_ref, torch.from_numpy(g["gen_qs"]))
+        for window in (8, 4):
+            eng = DecodeEngine(model, x_enc, batch_size=3, window=window)
+            assert eng.packs[0].lazy
+            eng.begin_greedy(12)
+            for _ in range(5):
+                eng.greedy_step()
+            mid = [s[3].clone() for s in eng.state.states]           # sync in the middle of a window ...
+            for _ in range(7):
+                eng.greedy_step()                                    # ... and keep going
+            assert torch.equal(eng.greedy_tokens(), toks_ref)
+            for li, (a, b) in enumerate(zip(eng.state.states, ref.state.states)):
+                for j, (ta, tb) in enumerate(zip(a, b)):
+                    err = (ta - tb).abs().max() / tb.abs().max().clamp_min(1e-30)
+                    assert err < 2e-5, (window, li, j, float(err))
+            ref5 = DecodeEngine(model, x_enc, batch_size=3, window=1)
+            ref5.run_greedy(5)
+            for a, b in zip(mid, ref5.state.states):
+                assert (a - b[3]).abs().max() / b[3].abs().max() < 2e-5
+            # re-arming after a partial window: pending steps are flushed, the continuation matches a fresh run
+            eng.begin_greedy(3, y0=None)
+            eng.greedy_step()
+            eng.begin_greedy(2)
+            assert eng._n_done == 0 and int(eng._origin) == 0

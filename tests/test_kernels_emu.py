@@ -174,3 +174,17 @@ def test_chunk_bwd_through_the_final_state_only(emu):
 @pytest.mark.parametrize("Dk,Dv,T,dtype,h0", [(64, 64, 37, torch.float32, True), (64, 128, 21, torch.bfloat16, False)])
 def test_chunk_simple_gla(emu, Dk, Dv, T, dtype, h0):
     check_chunk_simple(DEV, B=1, H=2, T=T, Dk=Dk, Dv=Dv, dtype=dtype, with_h0=h0)
+
+
+@pytest.mark.parametrize("Dk,Dv,dtype,window,n", [(64, 64, torch.float32, 8, 19), (128, 128, torch.bfloat16, 4, 9),
+                                                  (64, 256, torch.float32, 2, 5), (64, 64, torch.float32, 1, 3),
+                                                  (256, 256, torch.bfloat16, 8, 10), (256, 128, torch.float32, 8, 9)])
+def test_decode_window(emu, Dk, Dv, dtype, window, n):
+    from kernel_cases import check_decode_window
+    check_decode_window(DEV, B=2, H=2, Dk=Dk, Dv=Dv, dtype=dtype, window=window, n_steps=n)
+
+
+@pytest.mark.parametrize("Q,L,d,dtype", [(1, 300, 64, torch.float32), (3, 70, 32, torch.bfloat16)])
+def test_greedy_pick_embed(emu, Q, L, d, dtype):
+    from kernel_cases import check_greedy_pick_embed
+    check_greedy_pick_embed(DEV, B=5, Q=Q, L=L, d=d, dtype=dtype)

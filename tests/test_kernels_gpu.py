@@ -262,3 +262,17 @@ def test_chunk_bwd_long_without_boundary_states(hip):
 def test_chunk_segment_parallel_at_the_training_sequence_length(hip, nseg, resets):
     """Segment-parallel K2 (the form config 5's micro-batch takes) at T=4096 vs the fp64 recurrent oracle."""
     check_chunk_segmented(DEV, B=1, H=4, T=4096, nseg=nseg, resets=resets)
+
+
+# ----------------------------------------------------------------------------- K1w: windowed decode-step update
+@pytest.mark.parametrize("B,H,Dk,Dv,dtype,window,n", [(64, 4, 256, 256, torch.bfloat16, 8, 21), (3, 2, 256, 256, torch.float32, 8, 17),
+                                                      (5, 8, 128, 128, torch.bfloat16, 4, 10), (2, 16, 64, 64, torch.float32, 8, 9)])
+def test_decode_window(hip, B, H, Dk, Dv, dtype, window, n):
+    from kernel_cases import check_decode_window
+    check_decode_window(DEV, B=B, H=H, Dk=Dk, Dv=Dv, dtype=dtype, window=window, n_steps=n)
+
+
+@pytest.mark.parametrize("B,Q,L,d,dtype", [(64, 1, 4099, 1024, torch.bfloat16), (7, 4, 1027, 256, torch.float32)])
+def test_greedy_pick_embed(hip, B, Q, L, d, dtype):
+    from kernel_cases import check_greedy_pick_embed
+    check_greedy_pick_embed(DEV, B=B, Q=Q, L=L, d=d, dtype=dtype, steps=4)

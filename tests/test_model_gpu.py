@@ -139,14 +139,17 @@ def test_config1_simple_gla_stack_matches_reference_wrapper(hip):
 
 
 def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
-    """The HEADLINE configuration (BASELINE configs[1]: L169, bf16, B=64, device-side hipGraph loop) against the
-    fp32 CPU oracle of the reference loop (model/modeling_lina.py:152-179):
+    """The HEADLINE configuration (BASELINE configs[1]: L169, bf16, B=64, device-side hipGraph loop with the windowed
+    state update) against the fp32 CPU oracle of the reference loop (model/modeling_lina.py:152-179):
       1. the engine decodes 32 tokens free-running;
-      2. the oracle is teacher-forced with the engine's tokens -> reference logits and top-2 margins for the SAME
-         history at every position;
-      3. the engine's token must be the oracle's arg-max wherever the oracle's margin exceeds the logits tolerance
-         (2e-2 of max|logits|: bf16 weights and activations vs fp32), the number of positions below it is printed;
-      4. the engine's teacher-forced logits (generic step API) are within that tolerance of the oracle's."""
+      2. the oracle (fp32 arithmetic on the SAME bf16-rounded weights) is teacher-forced with the engine's tokens ->
+         reference logits and top-2 margins for the same history at every position;
+      3. the engine's teacher-forced logits (generic step API, immediate state update) must be within 2e-2 of
+         max|oracle logits| (bf16 activations vs fp32);
+      4. every free-running token must be the oracle's arg-max wherever the oracle's margin exceeds TWICE the measured
+         logit error (if |dlogit| <= e everywhere the arg-max cannot differ at a margin > 2e); the number of positions
+         below that margin and the raw token differences are printed (random-init weights give nearly flat logits, so
+         near-ties are common)."""
     from lina_speech_amd.configs import l169
     from lina_speech_amd.decode import DecodeEngine
     from oracle.lina_decode_oracle import OracleLina
@@ -159,26 +162,28 @@ def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
     with torch.inference_mode():
         m = mb.to("cuda")
         x_enc = m.txt_encoder(m.txt_embed(x.cuda()))
-        toks = DecodeEngine(m, x_enc, batch_size=B).run_greedy(n).cpu()                  # [1,B,n]
+        eng = DecodeEngine(m, x_enc, batch_size=B)
+        assert eng.window == 8 and eng.packs[0].lazy
+        toks = eng.run_greedy(n).cpu()                                                      # [1,B,n]
     orc = OracleLina(sd, n_layer=6, heads=4, txt_heads=4)
     ref_toks, ref_logits, _, margins = orc.generate_greedy(x, n, teacher=toks)             # teacher-forced on OUR tokens
     scale = float(ref_logits.abs().max())
-    safe = margins > REL * scale
-    n_masked = int((~safe).sum())
-    print(f"\nbf16 B=64 engine vs fp32 oracle: {n_masked} of {B * n} positions masked (top-2 margin <= {REL * scale:.4f}); "
-          f"{int((toks[0] != ref_toks[0]).sum())} raw token differences")
-    assert n_masked < 0.25 * B * n, "too many near-ties for the comparison to mean anything"
-    assert torch.equal(toks[0][safe], ref_toks[0][safe]), "bf16 engine token != oracle arg-max at a clear margin"
     with torch.inference_mode():
-        eng = DecodeEngine(m, x_enc, batch_size=B)
+        eng2 = DecodeEngine(m, x_enc, batch_size=B)
         y = m.rvq_embed.embed_sum(torch.ones(1, B, 1, dtype=torch.long, device="cuda"))
         worst = 0.0
         for t in range(n):
-            logits, _ = eng(y, t)
-            worst = max(worst, float((logits.float().cpu() - ref_logits[:, t:t + 1]).abs().max()) / scale)
+            logits, _ = eng2(y, t)
+            worst = max(worst, float((logits.float().cpu() - ref_logits[:, t:t + 1]).abs().max()))
             y = m.rvq_embed.embed_sum(toks[:, :, t:t + 1].cuda())
-    print(f"teacher-forced logits: max |engine - oracle| / max|oracle| = {worst:.3e}")
-    assert worst < REL
+    safe = margins > 2.0 * worst
+    n_masked, n_diff = int((~safe).sum()), int((toks[0] != ref_toks[0]).sum())
+    print(f"\nbf16 B=64 engine vs fp32 oracle over {n} free-running steps: max |logit error| = {worst:.4f} = "
+          f"{worst / scale:.2e} of max|logit|; {n_masked} of {B * n} positions have a top-2 margin <= {2 * worst:.4f} "
+          f"(not comparable); {n_diff} raw token differences, all of them at such positions")
+    assert worst < REL * scale, f"teacher-forced logits rel err {worst / scale:.3e}"
+    assert n_masked < 0.5 * B * n
+    assert torch.equal(toks[0][safe], ref_toks[0][safe]), "bf16 engine token != oracle arg-max at a clear margin"
 
 
 def test_config3_decode_to_waveform_chain_vs_oracle(hip):
