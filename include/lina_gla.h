@@ -174,10 +174,11 @@ int lina_embed_sum(const int64_t* idx, const void* table, void* out,
  * Q quantizers' logits (lowest index on ties, as K6b), tok_log[step[0]][q][b] = pick (int64 [max_steps][Q][B]; skipped
  * when step[0] >= max_steps), x_out[b,:] = sum_q table[q, pick_q, :] (K6a), and step[0] += 1 by the last workgroup to
  * finish.  logits: [B, Q*L] with a row stride; counter: one int32, zero before the first call (left zero).
+ * x_out_packed (optional): the same rows in the fragment-major layout of the packed projections (see below).
  * Replaces reference model/modeling_lina.py:159-179 (k = 1 picks, token list append, next-input embedding). */
 int lina_greedy_pick_embed(const void* logits, int64_t row_stride, const void* table, void* x_out,
-                           int64_t* tok_log, int64_t* step, int* counter, int B, int Q, int L, int n_emb, int d,
-                           int max_steps, int dtype, lina_stream_t stream);
+                           void* x_out_packed, int64_t* tok_log, int64_t* step, int* counter, int B, int Q, int L,
+                           int n_emb, int d, int max_steps, int dtype, lina_stream_t stream);
 
 /* K6b -- greedy pick: out[r] = argmax_j logits[r,j], lowest index on exact ties.
  * Replaces topk_sampling(k=1) (reference model/tools.py:38-44, modeling_lina.py:159-164);
@@ -245,6 +246,29 @@ int lina_gla_decode_update_norm(const void* q, const void* k, const void* v, con
                                 int64_t gate_sb, int64_t gate_sh, float eps,
                                 int dtype, int g_dtype, float scale, lina_stream_t stream);
 
+/* Fragment-major ("packed") operands of the decode-step projections.  A row-major MFMA operand costs sixteen cache
+ * lines per quarter wave (16 rows x 64 B per load instruction): ~30 GB/s per CU.  Packed, the 16 rows x KSTEP columns of
+ * one fragment (KSTEP = 32 bf16 / 16 fp32, KL = 8 / 4 elements per lane) are one contiguous 1 KiB block:
+ *     element (m, k) -> ((m/16 * K/KSTEP + k/KSTEP) * 64 + m%16 + 16*((k%KSTEP)/KL)) * KL + k%KL
+ * with the rows padded to a multiple of 64 (zero rows).  Weights are packed once; activations are written packed by the
+ * producing epilogue (out_packed below, og_packed of lina_gla_decode_window, x_out_packed of lina_greedy_pick_embed,
+ * lina_weighted_rows_add_packed).
+ *   lina_linear_skinny_ex = lina_linear_skinny with  in_packed != 0: A and W are packed (lda / ldw ignored; for SwiGLU
+ *   the two weight halves are packed separately, w_half_rows = padded rows of one half, else the padded row count);
+ *   out (row-major, may be NULL) and / or out_packed (packed copy, width out_packed_width >= N, whole k-steps).
+ *   lina_gla_decode_inproj_packed = lina_gla_decode_inproj with packed x and w_in.  Same arithmetic, bit-identical. */
+int lina_linear_skinny_ex(const void* A, int64_t lda, const void* W, int64_t ldw, int in_packed, int w_half_rows,
+                          const float* c1, const float* c2, const void* resid, int64_t ldr, void* out, int64_t ldo,
+                          void* out_packed, int out_packed_width, int M, int N, int K, int swiglu_hidden, int ln_dim,
+                          float ln_eps, int dtype, lina_stream_t stream);
+int lina_gla_decode_inproj_packed(const void* x_packed, const void* w_in_packed, const float* c1, const float* c2,
+                                  const void* wq, const void* wk, const void* wv, void* cq, void* ck, void* cv,
+                                  const void* w2, const void* b2, void* qkv, void* g_out, float* gk, int B, int K,
+                                  int Kd, int Vd, int W, int R, float ln_eps, float normalizer, float clamp_min,
+                                  int dtype, lina_stream_t stream);
+int lina_weighted_rows_add_packed(const void* attc, int Tp, const void* vv, void* x, void* x_packed, int B, int Tn, int d,
+                                  int dtype, lina_stream_t stream);
+
 /* K1w + K5 -- decode-step state update with a WINDOWED (lazily written) state; inputs / output og as
  * lina_gla_decode_update_norm (one workgroup per (b,h): no partial buffer, no counters), same reference lines
  * (model/gla.py:186-220 at T = 1), Dk and Dv in {64,128,256}, but `state` is the state at the
@@ -256,7 +280,8 @@ int lina_gla_decode_update_norm(const void* q, const void* k, const void* v, con
  * (step[0] - origin[0]) mod window, read from DEVICE memory, so one captured graph serves all positions.
  * lina_gla_decode_window_flush applies the first n_pending history entries to `state` (call it before anybody else reads
  * the state, then restart the window: origin <- step).  HBM bytes per token and (row, head): 4 Dk Dv (1 + 1/window)
- * + history instead of 8 Dk Dv.  Returns the state of the immediate form up to fp32 rounding. */
+ * + history instead of 8 Dk Dv.  Returns the state of the immediate form up to fp32 rounding.
+ * og_packed != 0: og is written fragment-major as the [B, H*Dv] A operand of lina_linear_skinny_ex (see there). */
 int lina_gla_decode_window_max(void);
 int lina_gla_decode_window(const void* q, const void* k, const void* v, const void* gk,
                            float* state, const void* gate, const void* norm_weight,
@@ -265,7 +290,7 @@ int lina_gla_decode_window(const void* q, const void* k, const void* v, const vo
                            int B, int H, int Dk, int Dv,
                            int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
                            int64_t v_sb, int64_t v_sh, int64_t g_sb, int64_t g_sh,
-                           int64_t gate_sb, int64_t gate_sh, float eps,
+                           int64_t gate_sb, int64_t gate_sh, float eps, int og_packed,
                            int dtype, int g_dtype, float scale, lina_stream_t stream);
 int lina_gla_decode_window_flush(float* state, const float* hist_k, const float* hist_c, const float* hist_v,
                                  int n_pending, int B, int H, int Dk, int Dv, lina_stream_t stream);

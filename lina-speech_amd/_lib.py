@@ -43,7 +43,7 @@ PROTOTYPES = {
     "lina_rmsnorm_gate_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i64,
                                         _f, _i, _i, _p]),
     "lina_embed_sum": (C.c_int, [_p, _p, _p, _i, _i64, _i, _i, _i, _p]),
-    "lina_greedy_pick_embed": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "lina_greedy_pick_embed": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "lina_argmax_rows": (C.c_int, [_p, _p, _i64, _i, _i64, _i, _p]),
     "lina_topk_sample_rows": (C.c_int, [_p, _p, _i64, _i, _i64, _i, _f, _p, C.c_uint64, _p, _i, _p]),
     "lina_dwconv7_ln": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _f, _i, _p]),
@@ -57,8 +57,11 @@ PROTOTYPES = {
                                               _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f,
                                               _i, _i, _f, _p]),
     "lina_gla_decode_window_max": (C.c_int, []),
-    "lina_gla_decode_window": (C.c_int, [_p] * 13 + [_i] * 5 + [_i64] * 10 + [_f, _i, _i, _f, _p]),
+    "lina_gla_decode_window": (C.c_int, [_p] * 13 + [_i] * 5 + [_i64] * 10 + [_f, _i, _i, _i, _f, _p]),
     "lina_gla_decode_window_flush": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "lina_linear_skinny_ex": (C.c_int, [_p, _i64, _p, _i64, _i, _i, _p, _p, _p, _i64, _p, _i64, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "lina_gla_decode_inproj_packed": (C.c_int, [_p] * 15 + [_i] * 6 + [_f, _f, _f, _i, _p]),
+    "lina_weighted_rows_add_packed": (C.c_int, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "lina_cross_att_step1": (C.c_int, [_p, _p, _p, _f, _p, _p, _p, _i64, _p, _i, _i, _i, _f, _i, _p]),
     "lina_cross_att_step2": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i, _i, _i, _f, _i, _p]),
     "lina_cross_scores": (C.c_int, [_p, _p, _p, _f, _p, _p, _i, _i, _i, _f, _i, _p]),

@@ -6,6 +6,7 @@
 // steps of the decode loop; they exist so the loop needs no host round trip.
 #include <lina_dev.h>
 #include "lina_common.h"
+#include "skinny_frag.h"
 
 namespace lina {
 
@@ -62,7 +63,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void greedy_pick_embed_kernel(const T* __restrict__ logits, int64_t row_stride,
                                                                 const T* __restrict__ table, T* __restrict__ x_out,
                                                                 int64_t* __restrict__ tok_log, int64_t* step, int* counter,
-                                                                int Q, int L, int n_emb, int d, int max_steps) {
+                                                                int Q, int L, int n_emb, int d, int max_steps,
+                                                                T* __restrict__ x_pk) {
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
     __shared__ int s_tok[16];
@@ -106,6 +108,11 @@ __global__ __launch_bounds__(256) void greedy_pick_embed_kernel(const T* __restr
             acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
         }
         st4(x_out + (int64_t)b * d + e, acc);
+        if (x_pk) {                                  // fragment-major copy (the model-dtype values just stored)
+            T tmp4[4];
+            st4(tmp4, acc);
+            st4(x_pk + packed_off<T>(b, e, d), ld4(tmp4));
+        }
     }
     if (tid == 0) {
         const int tk = ticket_agent(counter);       // taken AFTER this workgroup has read step[0]
@@ -119,21 +126,24 @@ __global__ __launch_bounds__(256) void greedy_pick_embed_kernel(const T* __restr
 }  // namespace lina
 
 extern "C" int lina_greedy_pick_embed(const void* logits, int64_t row_stride, const void* table, void* x_out,
-                                      int64_t* tok_log, int64_t* step, int* counter, int B, int Q, int L, int n_emb,
-                                      int d, int max_steps, int dtype, lina_stream_t stream) {
+                                      void* x_out_packed, int64_t* tok_log, int64_t* step, int* counter, int B, int Q,
+                                      int L, int n_emb, int d, int max_steps, int dtype, lina_stream_t stream) {
     using namespace lina;
     LINA_REQUIRE(logits && table && x_out && tok_log && step && counter, "lina_greedy_pick_embed: null pointer");
     LINA_REQUIRE(B > 0 && Q > 0 && Q <= 16 && L > 0 && n_emb > 0 && max_steps > 0,
                  "lina_greedy_pick_embed: B,Q (<= 16),L,n_emb,max_steps must be positive");
     LINA_REQUIRE(d > 0 && d % 4 == 0, "lina_greedy_pick_embed: d=%d must be a positive multiple of 4", d);
     LINA_REQUIRE(valid_dtype(dtype), "lina_greedy_pick_embed: bad dtype %d", dtype);
+    LINA_REQUIRE(!x_out_packed || d % (dtype == LINA_BF16 ? 32 : 16) == 0, "lina_greedy_pick_embed: packed copy needs whole k-steps");
     dim3 grid((unsigned)B);
     if (dtype == LINA_F32)
         LINA_LAUNCH((greedy_pick_embed_kernel<float>), grid, dim3(256), 0, stream, (const float*)logits, row_stride,
-                    (const float*)table, (float*)x_out, tok_log, step, counter, Q, L, n_emb, d, max_steps);
+                    (const float*)table, (float*)x_out, tok_log, step, counter, Q, L, n_emb, d, max_steps,
+                    (float*)x_out_packed);
     else
         LINA_LAUNCH((greedy_pick_embed_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)logits, row_stride,
-                    (const bf16_t*)table, (bf16_t*)x_out, tok_log, step, counter, Q, L, n_emb, d, max_steps);
+                    (const bf16_t*)table, (bf16_t*)x_out, tok_log, step, counter, Q, L, n_emb, d, max_steps,
+                    (bf16_t*)x_out_packed);
     return check_launch("lina_greedy_pick_embed");
 }
 

@@ -8,6 +8,7 @@
 // wave64 shuffle + LDS reduction), the weighted sums over the T_txt rows are column-parallel.
 #include <lina_dev.h>
 #include "lina_common.h"
+#include "skinny_frag.h"
 
 namespace lina {
 
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const TX* __restrict_
 // wave w takes text rows w, w+4, ... (8 row loads in flight per lane), the 4 partial sums meet in LDS
 template <typename T>
 __global__ __launch_bounds__(256) void weighted_rows_kernel(const T* __restrict__ attc, int Tp, const T* __restrict__ vv,
-                                                            T* x, int Tn, int d) {
+                                                            T* x, int Tn, int d, T* xpk) {
     __shared__ float s_a[kCaMaxT];
     __shared__ __attribute__((aligned(16))) float s_p[3][64][4];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -184,7 +185,9 @@ __global__ __launch_bounds__(256) void weighted_rows_kernel(const T* __restrict_
     T tmp4[4];
     st4(tmp4, acc);                                          // bmm result in the model dtype, then the residual add
     const float4 o = ld4(tmp4), r = ld4(x + (int64_t)b * d + e);
-    st4(x + (int64_t)b * d + e, make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w));
+    const float4 nx = make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w);
+    st4(x + (int64_t)b * d + e, nx);
+    if (xpk) st4(xpk + packed_off<T>(b, e, d), nx);           // fragment-major copy for the next projection
 }
 
 template <typename T>
@@ -340,9 +343,20 @@ extern "C" int lina_softmax_rows(const void* x, int64_t x_sb, int x_dtype, float
     return check_launch("lina_softmax_rows");
 }
 
+static int weighted_rows_impl(const void* attc, int Tp, const void* vv, void* x, void* x_packed, int B, int Tn, int d,
+                              int dtype, lina_stream_t stream);
 extern "C" int lina_weighted_rows_add(const void* attc, int Tp, const void* vv, void* x, int B, int Tn, int d, int dtype,
                                       lina_stream_t stream) {
+    return weighted_rows_impl(attc, Tp, vv, x, nullptr, B, Tn, d, dtype, stream);
+}
+extern "C" int lina_weighted_rows_add_packed(const void* attc, int Tp, const void* vv, void* x, void* x_packed, int B,
+                                             int Tn, int d, int dtype, lina_stream_t stream) {
+    return weighted_rows_impl(attc, Tp, vv, x, x_packed, B, Tn, d, dtype, stream);
+}
+static int weighted_rows_impl(const void* attc, int Tp, const void* vv, void* x, void* x_packed, int B, int Tn, int d,
+                              int dtype, lina_stream_t stream) {
     using namespace lina;
+    LINA_REQUIRE(!x_packed || d % (dtype == LINA_BF16 ? 32 : 16) == 0, "lina_weighted_rows_add: packed copy needs whole k-steps");
     LINA_REQUIRE(attc && vv && x, "lina_weighted_rows_add: null pointer");
     LINA_REQUIRE(B > 0 && Tn > 0 && Tn <= kCaMaxT && Tp >= Tn, "lina_weighted_rows_add: 0 < T_txt <= %d", kCaMaxT);
     LINA_REQUIRE(d > 0 && d % 4 == 0, "lina_weighted_rows_add: d must be a multiple of 4");
@@ -350,9 +364,9 @@ extern "C" int lina_weighted_rows_add(const void* attc, int Tp, const void* vv, 
     dim3 grid((unsigned)((d + 255) / 256), (unsigned)B);
     if (dtype == LINA_F32)
         LINA_LAUNCH((weighted_rows_kernel<float>), grid, dim3(256), 0, stream, (const float*)attc, Tp, (const float*)vv,
-                    (float*)x, Tn, d);
+                    (float*)x, Tn, d, (float*)x_packed);
     else
         LINA_LAUNCH((weighted_rows_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)attc, Tp,
-                    (const bf16_t*)vv, (bf16_t*)x, Tn, d);
+                    (const bf16_t*)vv, (bf16_t*)x, Tn, d, (bf16_t*)x_packed);
     return check_launch("lina_weighted_rows_add");
 }

@@ -21,6 +21,7 @@
 // (j = (step - origin) mod W), so one captured hipGraph serves every position of the window.
 #include <lina_dev.h>
 #include "lina_common.h"
+#include "skinny_frag.h"
 
 namespace lina {
 
@@ -32,7 +33,8 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
     float* hist_k, float* hist_c, float* hist_v, const int64_t* step, const int64_t* origin, int window, int flush_n,
     int H, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh, int64_t v_sb, int64_t v_sh, int64_t g_sb,
     int64_t g_sh, float scale, const TIO* __restrict__ gate, int64_t gate_sb, int64_t gate_sh,
-    const TIO* __restrict__ nw, float eps, TIO* __restrict__ og) {
+    const TIO* __restrict__ nw, float eps, TIO* __restrict__ og, int og_packed) {
+    // og_packed: og is written fragment-major (skinny_frag.h) as the [B, H*Dv] A operand of the output projection
     constexpr int RB = 64;            // rows per thread group
     constexpr int DK = RB * NRB;
     constexpr int CG = DV / 4;        // lanes per row
@@ -214,7 +216,8 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
             const float4 gg = ld4(gate + b * gate_sb + h * gate_sh + 4 * tid);
             r.x *= gg.x * sigmoidf(gg.x); r.y *= gg.y * sigmoidf(gg.y);
             r.z *= gg.z * sigmoidf(gg.z); r.w *= gg.w * sigmoidf(gg.w);
-            st4(og + (int64_t)bh * DV + 4 * tid, r);
+            if (og_packed) st4(og + packed_off<TIO>(b, h * DV + 4 * tid, H * DV), r);   // 4 | KL: one 8/16-byte piece
+            else st4(og + (int64_t)bh * DV + 4 * tid, r);
         }
     }
 }
@@ -223,13 +226,13 @@ template <typename TIO, typename TG>
 static int launch_window(const void* q, const void* k, const void* v, const void* gk, float* S, float* hk, float* hc,
                          float* hv, const int64_t* step, const int64_t* origin, int window, int flush_n, int B, int H,
                          int Dk, int Dv, const int64_t* st, float scale, lina_stream_t stream, const void* gate,
-                         int64_t gate_sb, int64_t gate_sh, const void* nw, float eps, void* og) {
+                         int64_t gate_sb, int64_t gate_sh, const void* nw, float eps, void* og, int og_packed = 0) {
     dim3 grid((unsigned)(B * H));
 #define LINA_WIN_ONE(DVV, NRBB)                                                                                        \
     LINA_LAUNCH((gla_decode_window_kernel<DVV, NRBB, TIO, TG>), grid, dim3(256 * NRBB), 0, stream, (const TIO*)q,      \
                 (const TIO*)k, (const TIO*)v, (const TG*)gk, S, hk, hc, hv, step, origin, window, flush_n, H, st[0],   \
                 st[1], st[2], st[3], st[4], st[5], st[6], st[7], scale, (const TIO*)gate, gate_sb, gate_sh,            \
-                (const TIO*)nw, eps, (TIO*)og)
+                (const TIO*)nw, eps, (TIO*)og, og_packed)
 #define LINA_WIN_CASE(DVV)                                                                                             \
     case DVV:                                                                                                          \
         if (Dk == 64) LINA_WIN_ONE(DVV, 1); else if (Dk == 128) LINA_WIN_ONE(DVV, 2); else LINA_WIN_ONE(DVV, 4);        \
@@ -254,8 +257,8 @@ extern "C" int lina_gla_decode_window(const void* q, const void* k, const void* 
                                       float* hist_k, float* hist_c, float* hist_v, const int64_t* step,
                                       const int64_t* origin, int window, int B, int H, int Dk, int Dv, int64_t q_sb,
                                       int64_t q_sh, int64_t k_sb, int64_t k_sh, int64_t v_sb, int64_t v_sh, int64_t g_sb,
-                                      int64_t g_sh, int64_t gate_sb, int64_t gate_sh, float eps, int dtype, int g_dtype,
-                                      float scale, lina_stream_t stream) {
+                                      int64_t g_sh, int64_t gate_sb, int64_t gate_sh, float eps, int og_packed, int dtype,
+                                      int g_dtype, float scale, lina_stream_t stream) {
     using namespace lina;
     LINA_REQUIRE(q && k && v && gk && state && gate && norm_weight && og && hist_k && hist_c && hist_v && step && origin,
                  "lina_gla_decode_window: null pointer");
@@ -267,13 +270,13 @@ extern "C" int lina_gla_decode_window(const void* q, const void* k, const void* 
     const int64_t st[8] = {q_sb, q_sh, k_sb, k_sh, v_sb, v_sh, g_sb, g_sh};
     if (dtype == LINA_F32 && g_dtype == LINA_F32)
         return launch_window<float, float>(q, k, v, gk, state, hist_k, hist_c, hist_v, step, origin, window, -1, B, H,
-                                           Dk, Dv, st, scale, stream, gate, gate_sb, gate_sh, norm_weight, eps, og);
+                                           Dk, Dv, st, scale, stream, gate, gate_sb, gate_sh, norm_weight, eps, og, og_packed);
     if (dtype == LINA_BF16 && g_dtype == LINA_F32)
         return launch_window<bf16_t, float>(q, k, v, gk, state, hist_k, hist_c, hist_v, step, origin, window, -1, B,
-                                            H, Dk, Dv, st, scale, stream, gate, gate_sb, gate_sh, norm_weight, eps, og);
+                                            H, Dk, Dv, st, scale, stream, gate, gate_sb, gate_sh, norm_weight, eps, og, og_packed);
     if (dtype == LINA_BF16 && g_dtype == LINA_BF16)
         return launch_window<bf16_t, bf16_t>(q, k, v, gk, state, hist_k, hist_c, hist_v, step, origin, window, -1, B,
-                                             H, Dk, Dv, st, scale, stream, gate, gate_sb, gate_sh, norm_weight, eps, og);
+                                             H, Dk, Dv, st, scale, stream, gate, gate_sb, gate_sh, norm_weight, eps, og, og_packed);
     return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_window: dtype=f32 with bf16 gates is not built");
 }
 

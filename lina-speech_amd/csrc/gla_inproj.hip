@@ -14,7 +14,7 @@
 
 namespace lina {
 
-template <typename T, int NT>
+template <typename T, int NT, bool PK>
 __global__ __launch_bounds__(256) void gla_inproj_kernel(
     const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw, const float* __restrict__ c1,
     const float* __restrict__ c2, const T* __restrict__ wq, const T* __restrict__ wk, const T* __restrict__ wv,
@@ -42,21 +42,26 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
     for (int i = 0; i < MT; ++i) { st1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; st2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     F f_ones;
     f_ones.ones();
+    // PK: A and W fragment-major (skinny_frag.h; rows padded to 64): one contiguous 1 KiB per fragment load
+    const int nks_all = K / F::KSTEP;
+    const int64_t kstr = PK ? 64 * F::KL : F::KSTEP;
     const T* wp[NT];
     bool g_on[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         g_on[j] = !gate_wg || j == 0;
-        const int wrow = gate_wg ? n_direct + li : tile0 + 16 * j + li;
-        wp[j] = W + (int64_t)wrow * ldw + F::KL * lg;
+        const int wrow0 = gate_wg ? n_direct : tile0 + 16 * j;
+        wp[j] = PK ? W + ((int64_t)(wrow0 >> 4) * nks_all * 64 + lane) * F::KL
+                   : W + (int64_t)(wrow0 + li) * ldw + F::KL * lg;
     }
     const T* ap[MT];
     bool m_ok[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = m0 + 16 * mt + li;
-        m_ok[mt] = m < M;
-        ap[mt] = A + (int64_t)(m_ok[mt] ? m : 0) * lda + F::KL * lg;
+        m_ok[mt] = PK || m < M;
+        ap[mt] = PK ? A + ((int64_t)((m0 >> 4) + mt) * nks_all * 64 + lane) * F::KL
+                    : A + (int64_t)(m < M ? m : 0) * lda + F::KL * lg;
     }
     // Epilogue operands that do not depend on the GEMM -- the rolled conv caches of this wave's 4 rows (wave w
     // finalises m-tile w), the conv taps and the LayerNorm-fold constants -- are requested NOW, so their
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
         F fb[U][NT], fa[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int k0 = kstep_of(w, ks + u) * F::KSTEP;
+            const int64_t k0 = kstep_of(w, ks + u) * kstr;
 #pragma unroll
             for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[u][j].load(wp[j] + k0); else fb[u][j].zero(); }
 #pragma unroll
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
             }
     }
     for (; kstep_of(w, ks) < nsteps; ++ks) {
-        const int k0 = kstep_of(w, ks) * F::KSTEP;
+        const int64_t k0 = kstep_of(w, ks) * kstr;
         F fb[NT], fa[MT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[j].load(wp[j] + k0); else fb[j].zero(); }
@@ -224,11 +229,10 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
 
 }  // namespace lina
 
-extern "C" int lina_gla_decode_inproj(const void* x, int64_t ldx, const void* w_in, int64_t ldw, const float* c1,
-                                      const float* c2, const void* wq, const void* wk, const void* wv, void* cq,
-                                      void* ck, void* cv, const void* w2, const void* b2, void* qkv, void* g_out,
-                                      float* gk, int B, int K, int Kd, int Vd, int W, int R, float ln_eps,
-                                      float normalizer, float clamp_min, int dtype, lina_stream_t stream) {
+static int inproj_impl(const void* x, int64_t ldx, const void* w_in, int64_t ldw, int packed, const float* c1,
+                       const float* c2, const void* wq, const void* wk, const void* wv, void* cq, void* ck, void* cv,
+                       const void* w2, const void* b2, void* qkv, void* g_out, float* gk, int B, int K, int Kd, int Vd,
+                       int W, int R, float ln_eps, float normalizer, float clamp_min, int dtype, lina_stream_t stream) {
     using namespace lina;
     LINA_REQUIRE(x && w_in && c1 && c2 && wq && wk && wv && cq && ck && cv && w2 && b2 && qkv && g_out && gk,
                  "lina_gla_decode_inproj: null pointer");
@@ -237,7 +241,7 @@ extern "C" int lina_gla_decode_inproj(const void* x, int64_t ldx, const void* w_
     if (W != 4 || R != 16) return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_inproj: needs conv width 4 and gate rank 16 (got %d, %d)", W, R);
     if (Kd <= 0 || Vd <= 0 || Kd % 16 || Vd % 16) return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_inproj: Kd,Vd must be positive multiples of 16");
     const int kstep = dtype == LINA_BF16 ? 32 : 16, al = dtype == LINA_BF16 ? 8 : 4;
-    LINA_REQUIRE(K % kstep == 0 && ldx % al == 0 && ldw % al == 0, "lina_gla_decode_inproj: K/ldx/ldw alignment");
+    LINA_REQUIRE(K % kstep == 0 && (packed || (ldx % al == 0 && ldw % al == 0)), "lina_gla_decode_inproj: K/ldx/ldw alignment");
     LINA_REQUIRE(normalizer != 0.0f, "lina_gla_decode_inproj: normalizer must be non-zero");
     const int has_clamp = (clamp_min == clamp_min) ? 1 : 0;
     // 64 rows x 32 columns per workgroup when the q|k|v|g regions allow it (fewer, fatter workgroups: one per CU at
@@ -245,12 +249,32 @@ extern "C" int lina_gla_decode_inproj(const void* x, int64_t ldx, const void* w_
     const bool wide = Kd % 32 == 0 && Vd % 32 == 0;
     const int cols = wide ? 32 : 16;
     dim3 grid((unsigned)((2 * Kd + 2 * Vd + Kd) / cols), (unsigned)((B + 63) / 64));
-#define LINA_INPROJ(TT, NTT)                                                                                         \
-    LINA_LAUNCH((gla_inproj_kernel<TT, NTT>), grid, dim3(256), 0, stream, (const TT*)x, ldx, (const TT*)w_in, ldw, c1, \
-                c2, (const TT*)wq, (const TT*)wk, (const TT*)wv, (TT*)cq, (TT*)ck, (TT*)cv, (const TT*)w2,            \
+#define LINA_INPROJ_PK(TT, NTT, PKK)                                                                                 \
+    LINA_LAUNCH((gla_inproj_kernel<TT, NTT, PKK>), grid, dim3(256), 0, stream, (const TT*)x, ldx, (const TT*)w_in, ldw, \
+                c1, c2, (const TT*)wq, (const TT*)wk, (const TT*)wv, (TT*)cq, (TT*)ck, (TT*)cv, (const TT*)w2,         \
                 (const TT*)b2, (TT*)qkv, (TT*)g_out, gk, B, K, Kd, Vd, ln_eps, 1.0f / normalizer, clamp_min, has_clamp)
+#define LINA_INPROJ(TT, NTT) do { if (packed) LINA_INPROJ_PK(TT, NTT, true); else LINA_INPROJ_PK(TT, NTT, false); } while (0)
     if (dtype == LINA_F32) { if (wide) LINA_INPROJ(float, 2); else LINA_INPROJ(float, 1); }
     else { if (wide) LINA_INPROJ(bf16_t, 2); else LINA_INPROJ(bf16_t, 1); }
 #undef LINA_INPROJ
+#undef LINA_INPROJ_PK
     return check_launch("lina_gla_decode_inproj");
+}
+
+extern "C" int lina_gla_decode_inproj(const void* x, int64_t ldx, const void* w_in, int64_t ldw, const float* c1,
+                                      const float* c2, const void* wq, const void* wk, const void* wv, void* cq,
+                                      void* ck, void* cv, const void* w2, const void* b2, void* qkv, void* g_out,
+                                      float* gk, int B, int K, int Kd, int Vd, int W, int R, float ln_eps,
+                                      float normalizer, float clamp_min, int dtype, lina_stream_t stream) {
+    return inproj_impl(x, ldx, w_in, ldw, 0, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_out, gk, B, K, Kd, Vd, W, R,
+                       ln_eps, normalizer, clamp_min, dtype, stream);
+}
+
+extern "C" int lina_gla_decode_inproj_packed(const void* x_packed, const void* w_in_packed, const float* c1,
+                                             const float* c2, const void* wq, const void* wk, const void* wv, void* cq,
+                                             void* ck, void* cv, const void* w2, const void* b2, void* qkv, void* g_out,
+                                             float* gk, int B, int K, int Kd, int Vd, int W, int R, float ln_eps,
+                                             float normalizer, float clamp_min, int dtype, lina_stream_t stream) {
+    return inproj_impl(x_packed, 0, w_in_packed, 0, 1, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_out, gk, B, K, Kd,
+                       Vd, W, R, ln_eps, normalizer, clamp_min, dtype, stream);
 }

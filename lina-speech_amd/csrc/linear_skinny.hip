@@ -22,11 +22,13 @@
 
 namespace lina {
 
-template <typename T, bool SWIGLU, bool LN, int MT, int NT>
+template <typename T, bool SWIGLU, bool LN, int MT, int NT, bool PK>
 __global__ __launch_bounds__(256) void linear_skinny_kernel(
     const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw, const float* __restrict__ c1,
     const float* __restrict__ c2, const T* resid, int64_t ldr, T* out, int64_t ldo, int M, int N, int K, int Hd,
-    int ln_dim, float ln_eps) {
+    int ln_dim, float ln_eps, T* outp, int Kp, int Hp) {
+    // PK: A and W are fragment-major (skinny_frag.h); Hp = padded rows per weight half.  outp (optional, any PK): a packed
+    // copy of the output for the next projection, Kp = its padded width.
     using F = Frag<T>;
     constexpr int NB = SWIGLU ? 2 : 1;      // weight-row halves (gate | value) per output column
     constexpr int G = NB * NT;              // 16-row groups of W per workgroup
@@ -50,21 +52,33 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
     F f_ones;
     f_ones.ones();
 
+    const int nks_all = K / F::KSTEP;
+    const int64_t kstr = PK ? 64 * F::KL : F::KSTEP;   // elements between consecutive k-steps of one fragment row block
     const T* wp[G];
     bool g_ok[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int n = n0 + 16 * (g % NT) + li;
-        g_ok[g] = n < n_rows;
-        wp[g] = W + (int64_t)(g_ok[g] ? (g / NT) * Hd + n : 0) * ldw + F::KL * lg;
+        if (PK) {                                       // padded with zero rows: every tile of the grid is readable
+            g_ok[g] = true;
+            wp[g] = W + ((int64_t)(((g / NT) * Hp + n0 + 16 * (g % NT)) >> 4) * nks_all * 64 + lane) * F::KL;
+        } else {
+            g_ok[g] = n < n_rows;
+            wp[g] = W + (int64_t)(g_ok[g] ? (g / NT) * Hd + n : 0) * ldw + F::KL * lg;
+        }
     }
     const T* ap[MT];
     bool m_ok[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = m0 + 16 * mt + li;
-        m_ok[mt] = m < M;
-        ap[mt] = A + (int64_t)(m_ok[mt] ? m : 0) * lda + F::KL * lg;
+        if (PK) {                                       // rows padded to 64: rows >= M feed only output rows >= M
+            m_ok[mt] = true;
+            ap[mt] = A + ((int64_t)((m0 >> 4) + mt) * nks_all * 64 + lane) * F::KL;
+        } else {
+            m_ok[mt] = m < M;
+            ap[mt] = A + (int64_t)(m_ok[mt] ? m : 0) * lda + F::KL * lg;
+        }
     }
 
     // epilogue operands that do not depend on the GEMM (residual, fold constants) are requested before the main loop:
@@ -93,7 +107,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
         F fb[U][G], fa[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int k0 = kstep_of(w, ks + u) * F::KSTEP;
+            const int64_t k0 = kstep_of(w, ks + u) * kstr;
 #pragma unroll
             for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[u][g].load(wp[g] + k0); else fb[u][g].zero(); }
 #pragma unroll
@@ -112,7 +126,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
             }
     }
     for (; kstep_of(w, ks) < nsteps; ++ks) {
-        const int k0 = kstep_of(w, ks) * F::KSTEP;
+        const int64_t k0 = kstep_of(w, ks) * kstr;
         F fb[G], fa[MT];
 #pragma unroll
         for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[g].load(wp[g] + k0); else fb[g].zero(); }
@@ -189,7 +203,8 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
             }
             if (m < M && n < N) {
                 if (resid) res += pre_res[j][r];
-                st(out + (int64_t)m * ldo + n, res);
+                if (out) st(out + (int64_t)m * ldo + n, res);
+                if (outp) st(outp + packed_off<T>(m, n, Kp), res);
             }
         }
     }
@@ -197,17 +212,19 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
 
 }  // namespace lina
 
-extern "C" int lina_linear_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, const float* c1,
-                                  const float* c2, const void* resid, int64_t ldr, void* out, int64_t ldo, int M,
-                                  int N, int K, int swiglu_hidden, int ln_dim, float ln_eps, int dtype,
-                                  lina_stream_t stream) {
+static int linear_skinny_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const float* c1, const float* c2,
+                              const void* resid, int64_t ldr, void* out, int64_t ldo, int M, int N, int K,
+                              int swiglu_hidden, int ln_dim, float ln_eps, int packed, void* outp, int Kp, int Hp,
+                              int dtype, lina_stream_t stream) {
     using namespace lina;
-    LINA_REQUIRE(A && W && out, "lina_linear_skinny: null pointer");
+    LINA_REQUIRE(A && W && (out || outp), "lina_linear_skinny: null pointer");
     LINA_REQUIRE(M > 0 && N > 0 && K > 0, "lina_linear_skinny: M,N,K must be positive");
     LINA_REQUIRE(valid_dtype(dtype), "lina_linear_skinny: bad dtype %d", dtype);
     const int kstep = dtype == LINA_BF16 ? 32 : 16, al = dtype == LINA_BF16 ? 8 : 4;
     LINA_REQUIRE(K % kstep == 0, "lina_linear_skinny: K=%d must be a multiple of %d (pad the operands)", K, kstep);
-    LINA_REQUIRE(lda % al == 0 && ldw % al == 0, "lina_linear_skinny: lda/ldw must keep rows 16-byte aligned");
+    LINA_REQUIRE(packed || (lda % al == 0 && ldw % al == 0), "lina_linear_skinny: lda/ldw must keep rows 16-byte aligned");
+    LINA_REQUIRE(!outp || (Kp > 0 && Kp % kstep == 0 && Kp >= N), "lina_linear_skinny: packed output width must be a multiple of %d and >= N", kstep);
+    LINA_REQUIRE(!packed || Hp % 64 == 0, "lina_linear_skinny: packed weights need rows padded to a multiple of 64");
     LINA_REQUIRE(ln_dim >= 0 && (ln_dim == 0 || c1), "lina_linear_skinny: LayerNorm folding needs c1");
     LINA_REQUIRE(swiglu_hidden >= 0 && swiglu_hidden <= N, "lina_linear_skinny: bad swiglu_hidden");
     // Tiling.  Measured on MI355X (tools/perf_skinny2.py): one CU ingests only ~30 GB/s on this access pattern,
@@ -233,10 +250,12 @@ extern "C" int lina_linear_skinny(const void* A, int64_t lda, const void* W, int
                 if (cand[c][0] == fm && cand[c][1] == fn) { best_mt = fm; best_nt = fn; }
     }
     dim3 grid((unsigned)((N + 16 * best_nt - 1) / (16 * best_nt)), (unsigned)((M + 16 * best_mt - 1) / (16 * best_mt)));
-#define LINA_LS_ONE(TT, SW, LNN, MTT, NTT)                                                                          \
-    LINA_LAUNCH((linear_skinny_kernel<TT, SW, LNN, MTT, NTT>), grid, dim3(256), 0, stream, (const TT*)A, lda,       \
+#define LINA_LS_PK(TT, SW, LNN, MTT, NTT, PKK)                                                                     \
+    LINA_LAUNCH((linear_skinny_kernel<TT, SW, LNN, MTT, NTT, PKK>), grid, dim3(256), 0, stream, (const TT*)A, lda,  \
                 (const TT*)W, ldw, c1, c2, (const TT*)resid, ldr, (TT*)out, ldo, M, N, K, swiglu_hidden, ln_dim,    \
-                ln_eps)
+                ln_eps, (TT*)outp, Kp, Hp)
+#define LINA_LS_ONE(TT, SW, LNN, MTT, NTT)                                                                          \
+    do { if (packed) LINA_LS_PK(TT, SW, LNN, MTT, NTT, true); else LINA_LS_PK(TT, SW, LNN, MTT, NTT, false); } while (0)
 #define LINA_LS(TT, SW, LNN)                                                                                        \
     do {                                                                                                            \
         if (best_nt == 1 && best_mt == 1) LINA_LS_ONE(TT, SW, LNN, 1, 1);                                           \
@@ -254,5 +273,22 @@ extern "C" int lina_linear_skinny(const void* A, int64_t lda, const void* W, int
     }
 #undef LINA_LS
 #undef LINA_LS_ONE
+#undef LINA_LS_PK
     return check_launch("lina_linear_skinny");
+}
+
+extern "C" int lina_linear_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, const float* c1,
+                                  const float* c2, const void* resid, int64_t ldr, void* out, int64_t ldo, int M,
+                                  int N, int K, int swiglu_hidden, int ln_dim, float ln_eps, int dtype,
+                                  lina_stream_t stream) {
+    return linear_skinny_impl(A, lda, W, ldw, c1, c2, resid, ldr, out, ldo, M, N, K, swiglu_hidden, ln_dim, ln_eps, 0,
+                              nullptr, 0, 0, dtype, stream);
+}
+
+extern "C" int lina_linear_skinny_ex(const void* A, int64_t lda, const void* W, int64_t ldw, int in_packed,
+                                     int w_half_rows, const float* c1, const float* c2, const void* resid, int64_t ldr,
+                                     void* out, int64_t ldo, void* out_packed, int out_packed_width, int M, int N, int K,
+                                     int swiglu_hidden, int ln_dim, float ln_eps, int dtype, lina_stream_t stream) {
+    return linear_skinny_impl(A, lda, W, ldw, c1, c2, resid, ldr, out, ldo, M, N, K, swiglu_hidden, ln_dim, ln_eps,
+                              in_packed ? 1 : 0, out_packed, out_packed_width, w_half_rows, dtype, stream);
 }

@@ -48,4 +48,17 @@ template <> struct Frag<float> {
     }
 };
 
+// ---- fragment-major ("packed") operand layout ---------------------------------------------------------------------
+// A row-major operand makes a fragment load touch 16 rows x 64 B: sixteen different cache lines per quarter wave, and the
+// vector memory pipe then moves ~16 B per clock per CU (measured: ~30 GB/s per CU, tools/micro/load_pattern2.hip).  In
+// the packed layout the 16 rows x KSTEP columns of one fragment are ONE contiguous 1 KiB block, lane-linear:
+//     element (m, k)  ->  ((m/16 * K/KSTEP + k/KSTEP) * 64 + (m%16) + 16*((k%KSTEP)/KL)) * KL + k%KL
+// so a wave instruction reads 1 KiB contiguous (2x the rate for L2-resident operands).  Weights are packed once at
+// engine construction; activations are written packed by the epilogue that produces them.  Rows are padded to 64.
+template <typename T>
+__device__ __forceinline__ int64_t packed_off(int m, int k, int K) {
+    constexpr int KL = Frag<T>::KL, KS = Frag<T>::KSTEP;
+    return (((int64_t)(m >> 4) * (K / KS) + (k / KS)) * 64 + (m & 15) + 16 * ((k % KS) / KL)) * KL + (k % KL);
+}
+
 }  // namespace lina

@@ -44,7 +44,8 @@ class _BlockPack:
 
     _SHARED = ("H", "Dk", "Dv", "Kd", "Vd", "d", "R", "normalizer", "clamp_min", "eps_gate", "n1_eps", "n2_eps",
                "w_in", "c1_in", "c2_in", "ldz", "off_q", "off_k", "off_v", "off_g", "off_lr", "wq", "wk", "wv",
-               "w2", "b2", "gnw", "w_o", "hid", "hid_pad", "w_up", "c1_up", "c2_up", "w_down")
+               "w2", "b2", "gnw", "w_o", "hid", "hid_pad", "w_up", "c1_up", "c2_up", "w_down",
+               "w_in_p", "w_o_p", "w_up_p", "w_down_p", "up_half_rows")
 
     def __init__(self, blk, state, lo=0, hi=None, shared=None, window=1):
         self.window = window
@@ -90,6 +91,13 @@ class _BlockPack:
         w_down[:, :self.hid] = c.p_out.weight
         w_down[:, self.hid] = c.p_out.bias                              # multiplied by the constant-1 column
         self.w_down = w_down
+        # fragment-major copies for the device-side loop (include/lina_gla.h "packed operands"): one contiguous 1 KiB
+        # per MFMA fragment load instead of 16 rows x 64 B
+        self.w_in_p = ops.pack_rows(self.w_in)
+        self.w_o_p = ops.pack_rows(self.w_o)
+        self.up_half_rows = (self.hid + 63) // 64 * 64
+        self.w_up_p = torch.cat([ops.pack_rows(self.w_up[:self.hid]), ops.pack_rows(self.w_up[self.hid:])])
+        self.w_down_p = ops.pack_rows(self.w_down)
         self._buffers(state, lo, hi, dt, dev)
 
     def _buffers(self, state, lo, hi, dt, dev):
@@ -109,6 +117,10 @@ class _BlockPack:
         self.counters = torch.zeros(B * self.H, dtype=torch.int32, device=dev)
         self.s = torch.empty(B, self.hid_pad, dtype=dt, device=dev)
         self.lazy = self.window > 1 and self.Dk in (64, 128, 256) and self.Dv in (64, 128, 256)
+        self.packed = self.lazy and self.fused_in
+        if self.packed:
+            self.og_p = torch.zeros(ops.packed_numel(B, self.Vd), dtype=dt, device=dev)
+            self.s_p = torch.zeros(ops.packed_numel(B, self.hid_pad), dtype=dt, device=dev)
         if self.lazy:      # K1w: k_s, cumulative log-gate c_s and v_s of the steps of the current window
             self.hk = torch.zeros(self.window, B * self.H, self.Dk, dtype=torch.float32, device=dev)
             self.hc = torch.zeros(self.window, B * self.H, self.Dk, dtype=torch.float32, device=dev)
@@ -123,6 +135,8 @@ class _Part:
         self.kk, self.vv = kk, vv
         self.x = torch.zeros(hi - lo, d, dtype=dtype, device=dev)       # residual stream
         self.xp = torch.zeros(hi - lo, d, dtype=dtype, device=dev)      # pos_net stream
+        self.x_p = torch.zeros(ops.packed_numel(hi - lo, d), dtype=dtype, device=dev)    # fragment-major copies
+        self.xp_p = torch.zeros(ops.packed_numel(hi - lo, d), dtype=dtype, device=dev)
         self.q_lin = torch.zeros(hi - lo, d, dtype=dtype, device=dev)   # projected cross-attention query
         Tn = kk.shape[1]
         Tp = (Tn + 31) // 32 * 32
@@ -156,6 +170,8 @@ class DecodeEngine:
         self._t_idx = torch.zeros(1, dtype=torch.long, device=self.dev)      # device step counter of the greedy loop
         self._origin = torch.zeros(1, dtype=torch.long, device=self.dev)     # step at which the current window began
         self._origin_host, self._n_done, self._lazy_live = 0, 0, False
+        self._skip_update = False
+        self._loop_packed = False
         blocks = list(rnn.encoder) + list(rnn.decoder) + [rnn.cross_att.pos_net]
         self.n_enc = len(rnn.encoder)
         ca = rnn.cross_att
@@ -173,6 +189,9 @@ class DecodeEngine:
         hw = model.logits_head.weight
         self.Q, self.L, self.d = hw.shape
         self.w_head = hw.reshape(self.Q * self.L, self.d).contiguous()
+        self.w_head_p = ops.pack_rows(self.w_head)
+        self.ca_qw_p = ops.pack_rows(self.ca_qw)
+        self.pe_pad_p = ops.pack_rows(self.pe_pad)
         self.use_graph = (self.dev.type == "cuda") if use_graph is None else use_graph
         if n_split is None:
             # measured on MI355X (B=64): 1 range 1.035 ms/step, 2 ranges 1.013 ms, 4 ranges 1.64 ms -- the forked
@@ -197,10 +216,16 @@ class DecodeEngine:
         self._att = torch.zeros(batch_size, 2, 1, kk.shape[1], dtype=hw.dtype, device=self.dev)
 
     # ------------------------------------------------------------------ one GLA block, T = 1 (7 launches)
-    def _block(self, x, P: _BlockPack, lazy: bool = False):
-        """x [B,d] is the residual stream and is UPDATED IN PLACE.  ``lazy``: windowed state update K1w (device loop)."""
+    def _block(self, x, P: _BlockPack, lazy: bool = False, x_p=None):
+        """x [B,d] is the residual stream and is UPDATED IN PLACE.  ``lazy``: windowed state update K1w (device loop);
+        ``x_p``: the fragment-major copy of x -- the projections then run on packed operands and keep it current."""
         B = x.shape[0]
-        if P.fused_in:
+        packed = x_p is not None
+        if packed:
+            ops.gla_decode_inproj_packed(x_p, P.w_in_p, B, P.d, P.c1_in, P.c2_in, P.wq, P.wk, P.wv, P.cq, P.ck, P.cv,
+                                         P.w2, P.b2, P.qkv, P.g, P.gk, P.n1_eps, P.normalizer, P.clamp_min)
+            gate = P.g.view(B, P.H, P.Dv)
+        elif P.fused_in:
             ops.gla_decode_inproj(x, P.w_in, P.c1_in, P.c2_in, P.wq, P.wk, P.wv, P.cq, P.ck, P.cv, P.w2, P.b2,
                                   P.qkv, P.g, P.gk, P.n1_eps, P.normalizer, P.clamp_min)
             gate = P.g.view(B, P.H, P.Dv)
@@ -212,9 +237,11 @@ class DecodeEngine:
         q = P.qkv[:, :P.Kd].view(B, P.H, P.Dk)
         k = P.qkv[:, P.Kd:2 * P.Kd].view(B, P.H, P.Dk)
         v = P.qkv[:, 2 * P.Kd:].view(B, P.H, P.Dv)
-        if lazy and P.lazy:
-            ops.gla_decode_window(q, k, v, P.gk.view(B, P.H, P.Dk), P.S, gate, P.gnw, P.og, P.hk, P.hc, P.hv,
-                                  self._t_idx, self._origin, P.window, P.eps_gate)
+        if self._skip_update:
+            pass                                  # measurement only (time_update_kernel): the step without K1w / K1d
+        elif lazy and P.lazy:
+            ops.gla_decode_window(q, k, v, P.gk.view(B, P.H, P.Dk), P.S, gate, P.gnw, P.og_p if packed else P.og,
+                                  P.hk, P.hc, P.hv, self._t_idx, self._origin, P.window, P.eps_gate, og_packed=packed)
         elif P.row_split and self.fuse_norm:
             ops.gla_decode_update_norm(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S, gate, P.gnw, P.og,
                                        P.counters, P.eps_gate)
@@ -226,48 +253,70 @@ class DecodeEngine:
                                            P.gk.view(B, P.H, 1, P.Dk), initial_state=P.S,
                                            output_final_state=True, inplace_state=True)
             ops.rmsnorm_swish_gate(o.reshape(B, P.H, P.Dv), gate, P.gnw, P.eps_gate, out=P.og)
+        if packed:
+            ops.linear_skinny_packed(P.og_p, P.w_o_p, B, P.d, P.Vd, resid=x, out=x, out_packed=x_p, out_packed_width=P.d)
+            ops.linear_skinny_packed(x_p, P.w_up_p, B, P.hid_pad, P.d, P.c1_up, P.c2_up, out_packed=P.s_p,
+                                     out_packed_width=P.hid_pad, swiglu_hidden=P.hid, ln_dim=P.d, ln_eps=P.n2_eps,
+                                     w_half_rows=P.up_half_rows)
+            ops.linear_skinny_packed(P.s_p, P.w_down_p, B, P.d, P.hid_pad, resid=x, out=x, out_packed=x_p,
+                                     out_packed_width=P.d)
+            return x
         ops.linear_skinny(P.og.view(B, P.Vd), P.w_o, resid=x, out=x)
         ops.linear_skinny(x, P.w_up, P.c1_up, P.c2_up, out=P.s, swiglu_hidden=P.hid, ln_dim=P.d, ln_eps=P.n2_eps,
                           n_out=P.hid_pad)
         ops.linear_skinny(P.s, P.w_down, resid=x, out=x)
         return x
 
-    def _cross(self, part, x, lazy=False):
+    def _cross(self, part, x, lazy=False, packed=False):
         """x += blind cross-attention: 7 short launches around the pos_net block, every one of them spread over
         >= 256 workgroups (query projection, scores, softmax, att1.pe | xp.pe^T, softmax, att2.V + residual)."""
         ca = self.ca
         att = self._att[part.lo:part.hi]
-        q_lin = ops.linear_skinny(x, self.ca_qw, c2=self.ca_qb, out=part.q_lin)
+        B = x.shape[0]
+        if packed:
+            q_lin = ops.linear_skinny_packed(part.x_p, self.ca_qw_p, B, self.d, self.d, c2=self.ca_qb, out=part.q_lin)
+        else:
+            q_lin = ops.linear_skinny(x, self.ca_qw, c2=self.ca_qb, out=part.q_lin)
         ops.cross_scores(q_lin, ca.ln_q.weight, ca.ln_q.bias, ca.ln_q.eps, part.kk, part.scores, self.att_scale)
         ops.softmax_rows(part.scores, 1.0, att[:, 0, 0], part.attc, self.Tn)
-        ops.linear_skinny(part.attc, self.peT, out=part.xp)                   # xp = att1 . pe
-        self._block(part.xp, part.packs[-1], lazy)
-        ops.linear_skinny(part.xp, self.pe_pad, out=part.sc2)                 # scores2 = xp . pe^T
+        if packed:
+            ops.linear_skinny(part.attc, self.peT, out=part.xp, out_packed=part.xp_p, out_packed_width=self.d)
+            self._block(part.xp, part.packs[-1], lazy, part.xp_p)
+            ops.linear_skinny_packed(part.xp_p, self.pe_pad_p, B, self.pe_pad.shape[0], self.d, out=part.sc2)
+        else:
+            ops.linear_skinny(part.attc, self.peT, out=part.xp)                   # xp = att1 . pe
+            self._block(part.xp, part.packs[-1], lazy)
+            ops.linear_skinny(part.xp, self.pe_pad, out=part.sc2)                 # scores2 = xp . pe^T
         ops.softmax_rows(part.sc2, self.att_scale, att[:, 1, 0], part.attc, self.Tn)
-        ops.weighted_rows_add(part.attc, part.vv, x)
+        ops.weighted_rows_add(part.attc, part.vv, x, x_packed=part.x_p if packed else None)
 
-    def _core_part(self, part, y, lazy=False):
+    def _core_part(self, part, y, lazy=False, packed=False):
         x = part.x
         if y is not x:                       # the device-side loop embeds the next token straight into part.x
             x.copy_(y[part.lo:part.hi])
+        x_p = part.x_p if packed else None   # packed: part.x_p already holds x (pick kernel / begin_greedy)
         for P in part.packs[:self.n_enc]:
-            self._block(x, P, lazy)
-        self._cross(part, x, lazy)
+            self._block(x, P, lazy, x_p)
+        self._cross(part, x, lazy, packed)
         for P in part.packs[self.n_enc:-1]:
-            self._block(x, P, lazy)
-        ops.linear_skinny(x, self.w_head, out=self._logits[part.lo:part.hi])
+            self._block(x, P, lazy, x_p)
+        if packed:
+            ops.linear_skinny_packed(x_p, self.w_head_p, x.shape[0], self.Q * self.L, self.d,
+                                     out=self._logits[part.lo:part.hi])
+        else:
+            ops.linear_skinny(x, self.w_head, out=self._logits[part.lo:part.hi])
 
-    def _core(self, y, lazy=False):
+    def _core(self, y, lazy=False, packed=False):
         """y [B,d] -> (logits [B,1,Q,L], att [B,2,1,Ttxt]) written into the engine's static buffers."""
         if self._streams is None:
             for part in self.parts:
-                self._core_part(part, y, lazy)
+                self._core_part(part, y, lazy, packed)
         else:
             main = torch.cuda.current_stream(self.dev)
             for part, st in zip(self.parts, self._streams):       # fork
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
-                    self._core_part(part, y, lazy)
+                    self._core_part(part, y, lazy, packed)
             for st in self._streams:                                # join
                 main.wait_stream(st)
         return self._logits.view(self.B, 1, self.Q, self.L), self._att
@@ -291,6 +340,58 @@ class DecodeEngine:
                     ops.gla_decode_window_flush(P.S, P.hk, P.hc, P.hv, pending)
         self._origin_host = self._n_done
         self._origin.fill_(self._n_done)
+
+    # ------------------------------------------------------------------ measurement
+    @torch.inference_mode()
+    def time_update_kernel(self, reps: int = 160):
+        """Duration of the recurrent-update kernel (K1w + K5, or K1d + K5) IN SITU: the captured step graph is timed
+        with and without its update launches (everything else identical); the difference divided by the number of
+        update launches is what one launch adds to the step -- its own run time between the kernels that really
+        surround it.  (Timing the kernel back to back with itself measures something else: every launch then starts
+        streaming while its predecessor's tail is still draining.)  Leaves the state untouched.
+        Returns (seconds per launch, launches per step, ms with, ms without)."""
+        if not self.use_graph:
+            raise RuntimeError("time_update_kernel needs the hipGraph path (a ROCm device)")
+        self.sync_state()
+        lazy = self.window > 1
+        snap = self._snapshot()
+        x_keep = [part.x.clone() for part in self.parts]
+        t_keep, o_keep, live = self._t_idx.clone(), self._origin.clone(), self._lazy_live
+        y = self.parts[0].x if len(self.parts) == 1 else self._y_in
+        times = []
+        for skip in (False, True):
+            self._skip_update = skip
+            self._t_idx.zero_()
+            self._origin.zero_()
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                self._core(y, lazy, self._loop_packed)
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._core(y, lazy, self._loop_packed)
+                self._t_idx.add_(1)                       # walks through the window positions
+            for _ in range(16):
+                g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) * 1e-3 / reps)
+        self._skip_update = False
+        self._loop_packed = False
+        self._restore(snap)
+        for part, xk in zip(self.parts, x_keep):
+            part.x.copy_(xk)
+        self._t_idx.copy_(t_keep)
+        self._origin.copy_(o_keep)
+        self._lazy_live = live
+        n = len(self._all_packs())
+        return (times[0] - times[1]) / n, n, times[0] * 1e3, times[1] * 1e3
 
     # ------------------------------------------------------------------ graph capture
     def _all_packs(self):
@@ -353,21 +454,29 @@ class DecodeEngine:
         self._n_done, self._origin_host = 0, 0
         lazy = self.window > 1
         self._lazy_live = lazy
+        n_sampled_ = min(max(first_greedy_quant, 0), self.Q) if k > 1 else 0
+        # fragment-major operands: the all-greedy device loop on one row range (the pick kernel K6d keeps x_p current)
+        packed = (lazy and len(self.parts) == 1 and n_sampled_ == 0 and self.Q <= 16
+                  and all(P.packed for P in self.packs) and os.environ.get("LINA_DECODE_PACKED", "1") != "0")
+        self._loop_packed = packed
         n_sampled = min(max(first_greedy_quant, 0), self.Q) if k > 1 else 0
         is_sampled = (torch.arange(self.Q, device=self.dev) < n_sampled).unsqueeze(0)        # [1,Q]
 
         # one row range: the residual-stream buffer itself is the step's input (no y -> x copy, no embed -> y copy)
         y_buf = self.parts[0].x if len(self.parts) == 1 else self._y_in
         y_buf.copy_(self._y_in)
+        if packed:
+            ops.pack_rows(y_buf, out=self.parts[0].x_p)
 
         self._pick_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
 
         def body():
-            logits, att = self._core(y_buf, lazy)
+            logits, att = self._core(y_buf, lazy, packed)
             lg = logits.view(self.B, self.Q, self.L)
             if n_sampled == 0 and self.Q <= 16:
                 # K6d: picks, token log, next-token embedding and the step counter in ONE launch
-                ops.greedy_pick_embed(lg, emb.weight, y_buf, self._tok_log, self._t_idx, self._pick_counter)
+                ops.greedy_pick_embed(lg, emb.weight, y_buf, self._tok_log, self._t_idx, self._pick_counter,
+                                      x_packed=self.parts[0].x_p if packed else None)
                 return att
             if n_sampled == 0:
                 pick = ops.argmax_rows(lg)
@@ -386,6 +495,7 @@ class DecodeEngine:
         self._greedy_graph = None
         if self.use_graph:
             snap, y_keep = self._snapshot(), y_buf.clone()
+            xp_keep = self.parts[0].x_p.clone() if packed else None
             side = torch.cuda.Stream(device=self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
@@ -394,6 +504,8 @@ class DecodeEngine:
             torch.cuda.current_stream(self.dev).wait_stream(side)
             self._restore(snap)
             y_buf.copy_(y_keep)
+            if packed:
+                self.parts[0].x_p.copy_(xp_keep)
             self._tok_log.zero_()
             self._t_idx.zero_()
             g = torch.cuda.CUDAGraph()

@@ -500,7 +500,7 @@ def argmax_rows(logits, out=None):
     return out.view(logits.shape[:-1])
 
 
-def greedy_pick_embed(logits, table, x_out, tok_log, step, counter):
+def greedy_pick_embed(logits, table, x_out, tok_log, step, counter, x_packed=None):
     """K6d (lina_greedy_pick_embed): arg-max per quantizer of ``logits [B, Q, L]``, the picks logged at
     ``tok_log[step[0]]`` ([max_steps, Q, B] int64), the next input ``x_out [B, d] = sum_q table[q, pick_q]`` and
     ``step[0] += 1`` -- one launch.  ``counter``: int32 [1], zero."""
@@ -516,7 +516,11 @@ def greedy_pick_embed(logits, table, x_out, tok_log, step, counter):
         raise ValueError("tok_log must be a contiguous int64 [max_steps, Q, B] tensor")
     if step.dtype != torch.int64 or counter.dtype != torch.int32:
         raise ValueError("step must be int64, counter int32")
-    _check(be.lib.lina_greedy_pick_embed(_ptr(logits), logits.stride(0), _ptr(table.contiguous()), _ptr(x_out), _ptr(tok_log),
+    be.require(x_packed)
+    if x_packed is not None and x_packed.numel() < packed_numel(B, d):
+        raise ValueError("packed x buffer is too small")
+    _check(be.lib.lina_greedy_pick_embed(_ptr(logits), logits.stride(0), _ptr(table.contiguous()), _ptr(x_out), _ptr(x_packed),
+                                         _ptr(tok_log),
                                          _ptr(step), _ptr(counter), B, Q, L, n_emb, d, tok_log.shape[0], _dt(table),
                                          be.stream(table)))
 
@@ -599,8 +603,74 @@ def gla_decode_update(q, k, v, gk, o_part, state, scale=None):
     return o_part
 
 
+def _kstep(dtype) -> tuple:
+    """(KSTEP, KL): contraction elements per MFMA step / per lane (16 bytes) for bf16 and fp32 fragments."""
+    return (32, 8) if dtype == torch.bfloat16 else (16, 4)
+
+
+def packed_numel(rows: int, cols: int) -> int:
+    return (rows + 63) // 64 * 64 * cols
+
+
+def pack_rows(t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[M, K] -> the fragment-major layout of include/lina_gla.h (flat tensor, rows zero-padded to a multiple of 64):
+    element (m, k) at ((m/16 * K/KSTEP + k/KSTEP) * 64 + m%16 + 16*((k%KSTEP)/KL)) * KL + k%KL.  Plain torch ops: used
+    once per weight at engine construction and to seed packed activation buffers."""
+    M, K = t.shape
+    ks, kl = _kstep(t.dtype)
+    if K % ks:
+        raise ValueError(f"K={K} must be a multiple of {ks}")
+    Mp = (M + 63) // 64 * 64
+    src = t
+    if Mp != M:
+        src = torch.zeros(Mp, K, dtype=t.dtype, device=t.device)
+        src[:M] = t
+    p = src.view(Mp // 16, 16, K // ks, 4, kl).permute(0, 2, 3, 1, 4).reshape(-1)
+    if out is None:
+        return p.contiguous()
+    out.view(-1)[:p.numel()].copy_(p)
+    return out
+
+
+def unpack_rows(p: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """Inverse of pack_rows (tests / debugging)."""
+    ks, kl = _kstep(p.dtype)
+    Mp = (rows + 63) // 64 * 64
+    return p.view(-1)[:Mp * cols].view(Mp // 16, cols // ks, 4, 16, kl).permute(0, 3, 1, 2, 4).reshape(Mp, cols)[:rows]
+
+
+def linear_skinny_packed(a_packed, w_packed, M: int, N: int, K: int, c1=None, c2=None, resid=None, out=None,
+                         out_packed=None, out_packed_width: int = 0, swiglu_hidden: int = 0, ln_dim: int = 0,
+                         ln_eps: float = 1e-5, w_half_rows: Optional[int] = None, dtype=None):
+    """lina_linear_skinny_ex with fragment-major A [M,K] and W (pack_rows; for SwiGLU both weight halves packed
+    separately and concatenated, ``w_half_rows`` = padded rows of one half).  ``out`` [M,N] row-major and / or
+    ``out_packed`` (the packed A operand of the next projection, width ``out_packed_width`` >= N)."""
+    be = _BACKEND
+    be.require(a_packed, w_packed, c1, c2, resid, out, out_packed)
+    dt = a_packed.dtype
+    if out is None and out_packed is None:
+        out = torch.empty(M, N, dtype=dt, device=a_packed.device)
+    for t in (c1, c2):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise ValueError("c1/c2 must be contiguous fp32 vectors")
+    if a_packed.numel() < packed_numel(M, K):
+        raise ValueError("packed A is too small for [M, K]")
+    n_w = 2 * swiglu_hidden if swiglu_hidden else N
+    half = w_half_rows if w_half_rows is not None else (n_w + 63) // 64 * 64
+    if w_packed.numel() < half * K * (2 if swiglu_hidden else 1):
+        raise ValueError("packed W is too small")
+    if out_packed is not None and out_packed.numel() < packed_numel(M, out_packed_width):
+        raise ValueError("packed output buffer is too small")
+    _check(be.lib.lina_linear_skinny_ex(_ptr(a_packed), 0, _ptr(w_packed), 0, 1, int(half), _ptr(c1), _ptr(c2),
+                                        _ptr(resid), 0 if resid is None else resid.stride(0), _ptr(out),
+                                        0 if out is None else out.stride(0), _ptr(out_packed), int(out_packed_width),
+                                        M, N, K, swiglu_hidden, ln_dim, float(ln_eps), _dt(a_packed),
+                                        be.stream(a_packed)))
+    return out if out is not None else out_packed
+
+
 def linear_skinny(a, w, c1=None, c2=None, resid=None, out=None, swiglu_hidden: int = 0, ln_dim: int = 0,
-                  ln_eps: float = 1e-5, n_out: Optional[int] = None):
+                  ln_eps: float = 1e-5, n_out: Optional[int] = None, out_packed=None, out_packed_width: int = 0):
     """Decode-step projection with fused LayerNorm fold / bias / residual / SwiGLU (see lina_gla.h).
     a [M,K] (row stride free), w [N_w,K]; returns out [M, n_out] (n_out defaults to N_w, or to the padded
     SwiGLU width the caller asks for)."""
@@ -615,6 +685,15 @@ def linear_skinny(a, w, c1=None, c2=None, resid=None, out=None, swiglu_hidden: i
     for t in (c1, c2):
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
             raise ValueError("c1/c2 must be contiguous fp32 vectors")
+    if out_packed is not None:
+        be.require(out_packed)
+        if out_packed.numel() < packed_numel(M, out_packed_width):
+            raise ValueError("packed output buffer is too small")
+        _check(be.lib.lina_linear_skinny_ex(_ptr(a), a.stride(0), _ptr(w), w.stride(0), 0, 0, _ptr(c1), _ptr(c2),
+                                            _ptr(resid), 0 if resid is None else resid.stride(0), _ptr(out),
+                                            out.stride(0), _ptr(out_packed), int(out_packed_width), M, N, K,
+                                            swiglu_hidden, ln_dim, float(ln_eps), _dt(a), be.stream(a)))
+        return out
     _check(be.lib.lina_linear_skinny(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(c1), _ptr(c2), _ptr(resid),
                                      0 if resid is None else resid.stride(0), _ptr(out), out.stride(0), M, N, K,
                                      swiglu_hidden, ln_dim, float(ln_eps), _dt(a), be.stream(a)))
@@ -636,6 +715,23 @@ def gla_decode_inproj(x, w_in, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_ou
                                          float(ln_eps), float(normalizer),
                                          float("nan") if clamp_min is None else float(clamp_min), _dt(x),
                                          be.stream(x)))
+
+
+def gla_decode_inproj_packed(x_packed, w_in_packed, B, K, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_out, gk,
+                             ln_eps: float = 1e-5, normalizer: float = 16.0, clamp_min: Optional[float] = None):
+    """gla_decode_inproj with the block input and the fused projection weight in the fragment-major layout."""
+    be = _BACKEND
+    be.require(x_packed, w_in_packed, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_out, gk)
+    Kd, W = wq.shape[0], wq.shape[-1]
+    Vd, R = wv.shape[0], w2.shape[1]
+    if x_packed.numel() < packed_numel(B, K) or w_in_packed.numel() < packed_numel(2 * Kd + 2 * Vd + R, K):
+        raise ValueError("packed operand too small")
+    _check(be.lib.lina_gla_decode_inproj_packed(_ptr(x_packed), _ptr(w_in_packed), _ptr(c1), _ptr(c2), _ptr(wq), _ptr(wk),
+                                                _ptr(wv), _ptr(cq), _ptr(ck), _ptr(cv), _ptr(w2), _ptr(b2), _ptr(qkv),
+                                                _ptr(g_out), _ptr(gk), B, K, Kd, Vd, W, R, float(ln_eps),
+                                                float(normalizer),
+                                                float("nan") if clamp_min is None else float(clamp_min), _dt(x_packed),
+                                                be.stream(x_packed)))
 
 
 def gla_decode_update_norm(q, k, v, gk, o_part, state, gate, norm_weight, og, counters, eps: float = 1e-5, scale=None):
@@ -663,7 +759,7 @@ def gla_decode_update_norm(q, k, v, gk, o_part, state, gate, norm_weight, og, co
 
 
 def gla_decode_window(q, k, v, gk, state, gate, norm_weight, og, hist_k, hist_c, hist_v, step, origin,
-                      window: int, eps: float = 1e-5, scale=None):
+                      window: int, eps: float = 1e-5, scale=None, og_packed: bool = False):
     """K1w + K5 (lina_gla_decode_window): decode-step update with a lazily written state -- ``state`` is read every
     step and rewritten every ``window``-th one, the steps in between live in hist_k / hist_c [window,B*H,Dk] and
     hist_v [window,B*H,Dv] (fp32).  ``step`` / ``origin``: int64 device tensors (window position = (step-origin) %
@@ -681,6 +777,8 @@ def gla_decode_window(q, k, v, gk, state, gate, norm_weight, og, hist_k, hist_c,
         raise ValueError("step / origin must be int64 device tensors")
     if not og.is_contiguous() or og.dtype != q.dtype or gate.dtype != q.dtype or gate.stride(-1) != 1:
         raise ValueError("og/gate must be model-dtype tensors, og contiguous, gate row-contiguous")
+    if og_packed and og.numel() < packed_numel(B, H * Dv):
+        raise ValueError("packed og buffer is too small")
     for t in (q, k, v, gk):
         if t.stride(-1) != 1:
             raise ValueError("innermost dimension must be contiguous")
@@ -689,7 +787,8 @@ def gla_decode_window(q, k, v, gk, state, gate, norm_weight, og, hist_k, hist_c,
                                          _ptr(hist_v), _ptr(step), _ptr(origin), int(window), B, H, Dk, Dv,
                                          q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
                                          gk.stride(0), gk.stride(1), gate.stride(0), gate.stride(1), float(eps),
-                                         _dt(q), _dt(gk), float(Dk ** -0.5 if scale is None else scale), be.stream(q)))
+                                         1 if og_packed else 0, _dt(q), _dt(gk),
+                                         float(Dk ** -0.5 if scale is None else scale), be.stream(q)))
     return og
 
 
@@ -742,12 +841,18 @@ def softmax_rows(x, scale, att, attc, Tn):
                                     Tn, attc.shape[1], _dt(attc), be.stream(x)))
 
 
-def weighted_rows_add(attc, vv, x):
-    """x[b,:] += sum_t attc[b,t] * vv[b,t,:]."""
+def weighted_rows_add(attc, vv, x, x_packed=None):
+    """x[b,:] += sum_t attc[b,t] * vv[b,t,:]  (``x_packed``: also the fragment-major copy of the new x)."""
     be = _BACKEND
-    be.require(attc, vv, x)
+    be.require(attc, vv, x, x_packed)
     B, Tn, d = vv.shape
-    _check(be.lib.lina_weighted_rows_add(_ptr(attc), attc.shape[1], _ptr(vv), _ptr(x), B, Tn, d, _dt(x), be.stream(x)))
+    if x_packed is None:
+        _check(be.lib.lina_weighted_rows_add(_ptr(attc), attc.shape[1], _ptr(vv), _ptr(x), B, Tn, d, _dt(x), be.stream(x)))
+        return
+    if x_packed.numel() < packed_numel(B, d):
+        raise ValueError("packed x buffer is too small")
+    _check(be.lib.lina_weighted_rows_add_packed(_ptr(attc), attc.shape[1], _ptr(vv), _ptr(x), _ptr(x_packed), B, Tn, d,
+                                                _dt(x), be.stream(x)))
 
 
 # --------------------------------------------------------------------------- codes -> waveform (f-3)

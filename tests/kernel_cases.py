@@ -547,6 +547,67 @@ def check_linear_skinny(dev, M, N, K, dtype, ln=False, bias=False, resid=False, 
         assert torch.equal(r2, out)
 
 
+def check_linear_skinny_packed(dev, M, N, K, dtype, ln=False, bias=False, resid=False, swiglu=0):
+    """Fragment-major operands (lina_linear_skinny_ex): the SAME arithmetic as the row-major call, so the result must be
+    BIT-identical to lina_linear_skinny on the same values -- row-major output and the packed copy (which is what the
+    next projection consumes)."""
+    g = torch.Generator().manual_seed(19)
+    kq = 32 if dtype == torch.bfloat16 else 16
+    a = (torch.randn(M, K, generator=g) * 1.5 + (0.7 if ln else 0.0)).to(dtype).to(dev)
+    n_w = 2 * swiglu if swiglu else N
+    w = (torch.randn(n_w, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+    c1 = (torch.randn(n_w, generator=g)).to(dev) if ln else None
+    c2 = torch.randn(n_w, generator=g).to(dev) if (bias or ln) else None
+    r = torch.randn(M, N, generator=g).to(dtype).to(dev) if resid else None
+    ref = ops.linear_skinny(a, w, c1, c2, resid=r, swiglu_hidden=swiglu, ln_dim=K if ln else 0, n_out=N)
+    a_p = ops.pack_rows(a)
+    if swiglu:
+        half = (swiglu + 63) // 64 * 64
+        w_p = torch.cat([ops.pack_rows(w[:swiglu]), ops.pack_rows(w[swiglu:])])
+    else:
+        half = None
+        w_p = ops.pack_rows(w)
+    Np = (N + kq - 1) // kq * kq
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=dev)
+    out_p = torch.zeros(ops.packed_numel(M, Np), dtype=dtype, device=dev)
+    ops.linear_skinny_packed(a_p, w_p, M, N, K, c1, c2, resid=r, out=out, out_packed=out_p, out_packed_width=Np,
+                             swiglu_hidden=swiglu, ln_dim=K if ln else 0, w_half_rows=half)
+    assert torch.equal(out, ref), "packed operands changed the result"
+    assert torch.equal(ops.unpack_rows(out_p, M, Np)[:, :N], ref), "packed output copy differs"
+    # row-major inputs + packed output copy
+    out_p2 = torch.zeros_like(out_p)
+    ops.linear_skinny(a, w, c1, c2, resid=r, swiglu_hidden=swiglu, ln_dim=K if ln else 0, n_out=N, out_packed=out_p2,
+                      out_packed_width=Np)
+    assert torch.equal(out_p2, out_p)
+
+
+def check_inproj_packed(dev, B, K, Kd, Vd, dtype):
+    """lina_gla_decode_inproj_packed == lina_gla_decode_inproj bit for bit (outputs AND the rolled conv caches)."""
+    g = torch.Generator().manual_seed(23)
+    R, W = 16, 4
+    x = (torch.randn(B, K, generator=g) + 0.3).to(dtype).to(dev)
+    w_in = (torch.randn(2 * Kd + 2 * Vd + R, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+    c1 = w_in.float().sum(1).contiguous()
+    c2 = torch.randn(w_in.shape[0], generator=g).to(dev)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dtype).to(dev)
+    wq, wk, wv, w2, b2 = mk(Kd, W), mk(Kd, W), mk(Vd, W), mk(Kd, R), mk(Kd)
+    caches = [mk(B, Kd, W), mk(B, Kd, W), mk(B, Vd, W)]
+    outs = []
+    for packed in (False, True):
+        cq, ck, cv = (c.clone() for c in caches)
+        qkv = torch.empty(B, 2 * Kd + Vd, dtype=dtype, device=dev)
+        go = torch.empty(B, Vd, dtype=dtype, device=dev)
+        gk = torch.empty(B, Kd, dtype=torch.float32, device=dev)
+        if packed:
+            ops.gla_decode_inproj_packed(ops.pack_rows(x), ops.pack_rows(w_in), B, K, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2,
+                                         qkv, go, gk)
+        else:
+            ops.gla_decode_inproj(x, w_in, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, go, gk)
+        outs.append((qkv, go, gk, cq, ck, cv))
+    for name, a, b in zip(("qkv", "g", "gk", "cq", "ck", "cv"), *outs):
+        assert torch.equal(a, b), f"packed in-projection: {name} differs"
+
+
 def check_inproj(dev, B, K, Kd, Vd, dtype):
     """lina_gla_decode_inproj == lina_linear_skinny(LayerNorm fold) + lina_gla_decode_prologue (both oracle-checked
     above), and == the oracle's LayerNorm -> projections -> conv step -> gate in fp64."""

@@ -104,6 +104,7 @@ def test_engine_windowed_state_equals_immediate_state(emu):
             eng = DecodeEngine(model, x_enc, batch_size=3, window=window)
             assert eng.packs[0].lazy
             eng.begin_greedy(12)
+            assert eng._loop_packed, "the device loop must run on fragment-major operands"
             for _ in range(5):
                 eng.greedy_step()
             mid = [s[3].clone() for s in eng.state.states]           # sync in the middle of a window ...

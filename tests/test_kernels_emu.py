@@ -188,3 +188,18 @@ def test_decode_window(emu, Dk, Dv, dtype, window, n):
 def test_greedy_pick_embed(emu, Q, L, d, dtype):
     from kernel_cases import check_greedy_pick_embed
     check_greedy_pick_embed(DEV, B=5, Q=Q, L=L, d=d, dtype=dtype)
+
+
+@pytest.mark.parametrize("M,N,K,dtype,ln,bias,resid,sw", [(5, 40, 64, torch.float32, False, True, True, 0),
+                                                          (20, 48, 64, torch.bfloat16, True, True, False, 0),
+                                                          (7, 32, 64, torch.bfloat16, True, True, False, 21),
+                                                          (64, 100, 96, torch.float32, False, False, True, 0)])
+def test_linear_skinny_packed(emu, M, N, K, dtype, ln, bias, resid, sw):
+    from kernel_cases import check_linear_skinny_packed
+    check_linear_skinny_packed(DEV, M, N, K, dtype, ln=ln, bias=bias, resid=resid, swiglu=sw)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_inproj_packed(emu, dtype):
+    from kernel_cases import check_inproj_packed
+    check_inproj_packed(DEV, B=5, K=64, Kd=32, Vd=32, dtype=dtype)

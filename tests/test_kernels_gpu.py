@@ -276,3 +276,21 @@ def test_decode_window(hip, B, H, Dk, Dv, dtype, window, n):
 def test_greedy_pick_embed(hip, B, Q, L, d, dtype):
     from kernel_cases import check_greedy_pick_embed
     check_greedy_pick_embed(DEV, B=B, Q=Q, L=L, d=d, dtype=dtype, steps=4)
+
+
+# ----------------------------------------------------------------------------- fragment-major (packed) projections
+@pytest.mark.parametrize("M,N,K,dtype,ln,bias,resid,sw", [(64, 1024, 1024, torch.bfloat16, False, False, True, 0),
+                                                          (64, 1376, 1024, torch.bfloat16, True, True, False, 1365),
+                                                          (64, 1024, 1376, torch.bfloat16, False, False, True, 0),
+                                                          (64, 4099, 1024, torch.bfloat16, False, False, False, 0),
+                                                          (33, 300, 256, torch.float32, True, True, True, 0),
+                                                          (64, 64, 1024, torch.bfloat16, False, False, False, 0)])
+def test_linear_skinny_packed(hip, M, N, K, dtype, ln, bias, resid, sw):
+    from kernel_cases import check_linear_skinny_packed
+    check_linear_skinny_packed(DEV, M, N, K, dtype, ln=ln, bias=bias, resid=resid, swiglu=sw)
+
+
+@pytest.mark.parametrize("B,dtype", [(64, torch.bfloat16), (9, torch.float32)])
+def test_inproj_packed(hip, B, dtype):
+    from kernel_cases import check_inproj_packed
+    check_inproj_packed(DEV, B=B, K=1024, Kd=1024, Vd=1024, dtype=dtype)
