@@ -255,7 +255,9 @@ int lina_gla_decode_update_norm(const void* q, const void* k, const void* v, con
  * lina_weighted_rows_add_packed).
  *   lina_linear_skinny_ex = lina_linear_skinny with  in_packed != 0: A and W are packed (lda / ldw ignored; for SwiGLU
  *   the two weight halves are packed separately, w_half_rows = padded rows of one half, else the padded row count);
- *   out (row-major, may be NULL) and / or out_packed (packed copy, width out_packed_width >= N, whole k-steps).
+ *   out (row-major, may be NULL) and / or out_packed (packed copy, width out_packed_width >= N, whole k-steps);
+ *   resid == out_packed (the same pointer): the residual is read from the packed buffer (in-place update of a
+ *   residual stream that exists only in packed form).
  *   lina_gla_decode_inproj_packed = lina_gla_decode_inproj with packed x and w_in.  Same arithmetic, bit-identical. */
 int lina_linear_skinny_ex(const void* A, int64_t lda, const void* W, int64_t ldw, int in_packed, int w_half_rows,
                           const float* c1, const float* c2, const void* resid, int64_t ldr, void* out, int64_t ldo,

@@ -184,10 +184,10 @@ __global__ __launch_bounds__(256) void weighted_rows_kernel(const T* __restrict_
     }
     T tmp4[4];
     st4(tmp4, acc);                                          // bmm result in the model dtype, then the residual add
-    const float4 o = ld4(tmp4), r = ld4(x + (int64_t)b * d + e);
-    const float4 nx = make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w);
-    st4(x + (int64_t)b * d + e, nx);
-    if (xpk) st4(xpk + packed_off<T>(b, e, d), nx);           // fragment-major copy for the next projection
+    // xpk given: the residual stream lives in the fragment-major buffer (read-modify-write there; x is not touched)
+    T* const xa = xpk ? xpk + packed_off<T>(b, e, d) : x + (int64_t)b * d + e;
+    const float4 o = ld4(tmp4), r = ld4(xa);
+    st4(xa, make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w));
 }
 
 template <typename T>

@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + 16 * w + 4 * lg + r, n = n0 + 16 * j + li;
-            pre_res[j][r] = (resid && w < MT && m < M && n < N) ? ld(resid + (int64_t)m * ldr + n) : 0.0f;
+            // resid == outp: the residual stream lives ONLY in the packed buffer (read-modify-write by the same thread)
+            pre_res[j][r] = (resid && w < MT && m < M && n < N)
+                                ? ld(resid == outp ? resid + packed_off<T>(m, n, Kp) : resid + (int64_t)m * ldr + n) : 0.0f;
         }
 
     const int nsteps = K / F::KSTEP;

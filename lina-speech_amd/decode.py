@@ -254,11 +254,12 @@ class DecodeEngine:
                                            output_final_state=True, inplace_state=True)
             ops.rmsnorm_swish_gate(o.reshape(B, P.H, P.Dv), gate, P.gnw, P.eps_gate, out=P.og)
         if packed:
-            ops.linear_skinny_packed(P.og_p, P.w_o_p, B, P.d, P.Vd, resid=x, out=x, out_packed=x_p, out_packed_width=P.d)
+            # the residual stream lives in x_p only (read-modify-write there); the row-major x is stale inside the loop
+            ops.linear_skinny_packed(P.og_p, P.w_o_p, B, P.d, P.Vd, resid=x_p, out_packed=x_p, out_packed_width=P.d)
             ops.linear_skinny_packed(x_p, P.w_up_p, B, P.hid_pad, P.d, P.c1_up, P.c2_up, out_packed=P.s_p,
                                      out_packed_width=P.hid_pad, swiglu_hidden=P.hid, ln_dim=P.d, ln_eps=P.n2_eps,
                                      w_half_rows=P.up_half_rows)
-            ops.linear_skinny_packed(P.s_p, P.w_down_p, B, P.d, P.hid_pad, resid=x, out=x, out_packed=x_p,
+            ops.linear_skinny_packed(P.s_p, P.w_down_p, B, P.d, P.hid_pad, resid=x_p, out_packed=x_p,
                                      out_packed_width=P.d)
             return x
         ops.linear_skinny(P.og.view(B, P.Vd), P.w_o, resid=x, out=x)
@@ -280,7 +281,7 @@ class DecodeEngine:
         ops.cross_scores(q_lin, ca.ln_q.weight, ca.ln_q.bias, ca.ln_q.eps, part.kk, part.scores, self.att_scale)
         ops.softmax_rows(part.scores, 1.0, att[:, 0, 0], part.attc, self.Tn)
         if packed:
-            ops.linear_skinny(part.attc, self.peT, out=part.xp, out_packed=part.xp_p, out_packed_width=self.d)
+            ops.linear_skinny(part.attc, self.peT, out=part.xp, out_packed=part.xp_p, out_packed_width=self.d)  # xp = att1 . pe
             self._block(part.xp, part.packs[-1], lazy, part.xp_p)
             ops.linear_skinny_packed(part.xp_p, self.pe_pad_p, B, self.pe_pad.shape[0], self.d, out=part.sc2)
         else:

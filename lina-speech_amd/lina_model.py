@@ -91,6 +91,8 @@ class LinaModel(nn.Module):
         if engine == "fused":
             from .decode import DecodeEngine
             step_fn = DecodeEngine(self, x_enc, batch_size=B, state=init_state)
+            state = step_fn.state
+            prepared = None
         else:
             state = init_state if init_state is not None else self.attentive_rnn.init_state(
                 max_seqlen=max_seqlen, batch_size=B)
@@ -100,11 +102,26 @@ class LinaModel(nn.Module):
                 h, att, _ = self.attentive_rnn.step(y, x_enc, t, state, prepared=prepared)
                 return self.logits_head(h), att
 
+        # ---- prompt prefill: the reference feeds the start token and the p_len prompt tokens one step at a time
+        # (modeling_lina.py:152-176); their inputs are known in advance, so all p_len + 1 positions go through the stack in
+        # ONE teacher-forced pass on the cached path (K2 chunk scan + conv prefill + cached pos_net block, the same
+        # recurrence as p_len + 1 single steps) and the per-position bookkeeping below consumes its logits.
+        pre_logits = pre_att = None
+        n_pre = 0
+        if prompt is not None and p_len > 0 and hasattr(self.attentive_rnn, "step"):
+            n_pre = min(p_len + 1, max_seqlen)
+            y_seq = torch.cat([y_embd, prompt[:, :n_pre - 1]], dim=1)
+            h, pre_att, _ = self.attentive_rnn.step(y_seq, x_enc, 0, state, prepared=prepared)
+            pre_logits = self.logits_head(h)                        # [B,n_pre,Q,L]
+
         all_stop = torch.zeros(B, 1, dtype=torch.bool, device=device)
         qs, atts, stop_tokens = [], [], []
         stop_at = None                      # first step index at which every row had stopped
         for t in range(max_seqlen):
-            logits, att = step_fn(y_embd, t)                    # [B,1,Q,L], [B,2,1,Ttxt]
+            if t < n_pre:
+                logits, att = pre_logits[:, t:t + 1], pre_att[:, :, t:t + 1]
+            else:
+                logits, att = step_fn(y_embd, t)                # [B,1,Q,L], [B,2,1,Ttxt]
             atts.append(att)
             per_q = logits.squeeze(1).transpose(0, 1)           # [Q,B,L]
             picks = [topk_sampling(per_q[i], k=k, temp=temp) if i < first_greedy_quant

@@ -662,7 +662,7 @@ def linear_skinny_packed(a_packed, w_packed, M: int, N: int, K: int, c1=None, c2
     if out_packed is not None and out_packed.numel() < packed_numel(M, out_packed_width):
         raise ValueError("packed output buffer is too small")
     _check(be.lib.lina_linear_skinny_ex(_ptr(a_packed), 0, _ptr(w_packed), 0, 1, int(half), _ptr(c1), _ptr(c2),
-                                        _ptr(resid), 0 if resid is None else resid.stride(0), _ptr(out),
+                                        _ptr(resid), 0 if (resid is None or resid.dim() < 2) else resid.stride(0), _ptr(out),
                                         0 if out is None else out.stride(0), _ptr(out_packed), int(out_packed_width),
                                         M, N, K, swiglu_hidden, ln_dim, float(ln_eps), _dt(a_packed),
                                         be.stream(a_packed)))
@@ -842,7 +842,8 @@ def softmax_rows(x, scale, att, attc, Tn):
 
 
 def weighted_rows_add(attc, vv, x, x_packed=None):
-    """x[b,:] += sum_t attc[b,t] * vv[b,t,:]  (``x_packed``: also the fragment-major copy of the new x)."""
+    """x[b,:] += sum_t attc[b,t] * vv[b,t,:].  With ``x_packed`` the residual stream is the fragment-major buffer: it is
+    updated in place there and ``x`` is not touched."""
     be = _BACKEND
     be.require(attc, vv, x, x_packed)
     B, Tn, d = vv.shape

@@ -574,6 +574,13 @@ def check_linear_skinny_packed(dev, M, N, K, dtype, ln=False, bias=False, resid=
                              swiglu_hidden=swiglu, ln_dim=K if ln else 0, w_half_rows=half)
     assert torch.equal(out, ref), "packed operands changed the result"
     assert torch.equal(ops.unpack_rows(out_p, M, Np)[:, :N], ref), "packed output copy differs"
+    if resid:   # the residual stream held ONLY in packed form, updated in place (resid is out_packed)
+        rp = torch.zeros(M, Np, dtype=dtype, device=dev)
+        rp[:, :N] = r
+        x_p = ops.pack_rows(rp)
+        ops.linear_skinny_packed(a_p, w_p, M, N, K, c1, c2, resid=x_p, out_packed=x_p, out_packed_width=Np,
+                                 swiglu_hidden=swiglu, ln_dim=K if ln else 0, w_half_rows=half)
+        assert torch.equal(ops.unpack_rows(x_p, M, Np)[:, :N], ref), "in-place packed residual update differs"
     # row-major inputs + packed output copy
     out_p2 = torch.zeros_like(out_p)
     ops.linear_skinny(a, w, c1, c2, resid=r, swiglu_hidden=swiglu, ln_dim=K if ln else 0, n_out=N, out_packed=out_p2,
