@@ -330,7 +330,7 @@ def check_launch(args):
         dist.destroy_process_group()
 
 
-def timed_steps(run_step, k_req, dist, dev, est_steps=None):
+def timed_steps(run_step, k_req, dist, dev, est_steps=None, batched=False):
     """Time >= k_req steps (and >= MIN_TIMED_S of wall time) bracketed by barrier + synchronize on both sides;
     returns (elapsed seconds = MAX over ranks, steps timed).  The step count is agreed across ranks first."""
     k = k_req
@@ -345,8 +345,11 @@ def timed_steps(run_step, k_req, dist, dev, est_steps=None):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(k):
-        run_step()
+    if batched:
+        run_step(k)                           # exactly k steps, enqueued as multi-token graph replays + a remainder
+    else:
+        for _ in range(k):
+            run_step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -470,12 +473,13 @@ def main():
             kk = torch.tensor([k_run], device=dev, dtype=torch.int64)
             dist.all_reduce(kk, op=dist.ReduceOp.MAX)
             k_run = int(kk.item())
-        eng.begin_greedy(k_run + args.warmup)
+        eng.begin_greedy(k_run + args.warmup + 8)
+        eng.greedy_steps(8)                                           # captures the multi-token graph (untimed)
         for _ in range(args.warmup):
             eng.greedy_step()
-        elapsed, k_run = timed_steps(eng.greedy_step, k_run, dist, dev)
+        elapsed, k_run = timed_steps(lambda n: eng.greedy_steps(n), k_run, dist, dev, batched=True)
         toks = eng.greedy_tokens()
-        assert toks.shape == (1, B, k_run + args.warmup)
+        assert toks.shape == (1, B, k_run + args.warmup + 8)
         assert int(toks.min()) >= 0 and int(toks.max()) < 4099
 
         out = None
@@ -541,7 +545,7 @@ def main():
                 "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
                 "config": {"workload": f"L169 greedy codec-token decode, B={B_PER_GPU}/GPU (B_total={total_rows}), "
                                        f"T_txt={T_TXT}, H=4 Dk=Dv=256, 12+1 GLA blocks, fp32 recurrent state, "
-                                       f"{nparam / 1e6:.1f}M params, one hipGraph replay per token, state window {eng.window}, "
+                                       f"{nparam / 1e6:.1f}M params, one hipGraph replay per {eng.GRAPH_STEPS} tokens, state window {eng.window}, "
                                        f"{len(eng.parts)} parallel row ranges per GPU",
                            "global_batch": total_rows, "parallelism": f"batch-shard x{world} (no collective)",
                            "timed_region": f"max({args.steps} requested steps, {MIN_TIMED_S} s) = {k_run} steps"},
@@ -572,9 +576,30 @@ def main():
                 out["chunk_bwd_kernel"] = measure_chunk_bwd(dev)
     if rank == 0:
         if world == 1 and dtype == torch.bfloat16 and not args.no_chunk:
-            # the parity dtype beside the headline dtype: the same engine with fp32 weights / activations
+            # other head shapes of the same width (the 169M hyper-parameters are inferred)
             del eng
             torch.cuda.empty_cache()
+            shapes = {}
+            for heads, ev in ((8, 1.0), (16, 1.0), (4, 2.0)):
+                with torch.inference_mode():
+                    torch.manual_seed(0)
+                    mh = l169(heads=heads, expand_v=ev).eval().to(dev, dtype)
+                    eh = DecodeEngine(mh, mh.txt_encoder(mh.txt_embed(texts)), batch_size=B)
+                    eh.begin_greedy(320)
+                    eh.greedy_steps(64)
+                    torch.cuda.synchronize()
+                    th = time.perf_counter()
+                    eh.greedy_steps(240)
+                    torch.cuda.synchronize()
+                    th = (time.perf_counter() - th) / 240
+                    shapes[f"H={heads},Dk={1024 // heads},Dv={int(1024 * ev) // heads}"] = {
+                        "ms_per_step": th * 1e3, "tokens_per_s": B / th, "params_M": n_params(mh) / 1e6,
+                        "update_kernel": "K1w (windowed)" if eh.packs[0].lazy else "generic K1 (head shape outside K1w)"}
+                    del eh, mh
+                    torch.cuda.empty_cache()
+            out["other_head_shapes"] = shapes
+            eng = None
+            # the parity dtype beside the headline dtype: the same engine with fp32 weights / activations
             with torch.inference_mode():
                 m32 = model.to(dev, torch.float32)
                 eng32 = DecodeEngine(m32, m32.txt_encoder(m32.txt_embed(texts)), batch_size=B)

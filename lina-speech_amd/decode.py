@@ -494,6 +494,7 @@ class DecodeEngine:
 
         self._greedy_body = body
         self._greedy_graph = None
+        self._greedy_graph_n = None
         if self.use_graph:
             snap, y_keep = self._snapshot(), y_buf.clone()
             xp_keep = self.parts[0].x_p.clone() if packed else None
@@ -522,6 +523,28 @@ class DecodeEngine:
             self._greedy_graph.replay()
             return self._greedy_att
         return self._greedy_body()
+
+    GRAPH_STEPS = 8          # tokens per replay of the multi-step graph (greedy_steps)
+
+    def greedy_steps(self, n: int):
+        """Enqueue ``n`` tokens for every row.  Whole groups of GRAPH_STEPS tokens go as ONE graph replay (a replay has a
+        fixed cost of its own -- a ~9 us kernel-argument copy on the stream plus the host launch -- that a one-token
+        graph pays per token); the remainder token by token.  The window position of K1w and the token log index come
+        from the device step counter, so the same captured graph is valid at any position."""
+        N = self.GRAPH_STEPS
+        if self._greedy_graph is not None and n >= N:
+            if self._greedy_graph_n is None:                 # captured on first use (stream capture executes nothing)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(N):
+                        self._greedy_body()
+                self._greedy_graph_n = g
+            while n >= N:
+                self._greedy_graph_n.replay()
+                self._n_done += N
+                n -= N
+        for _ in range(n):
+            self.greedy_step()
 
     def greedy_tokens(self):
         """Tokens produced so far: [Q,B,n]."""

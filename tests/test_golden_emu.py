@@ -119,6 +119,9 @@ def test_engine_windowed_state_equals_immediate_state(emu):
             ref5.run_greedy(5)
             for a, b in zip(mid, ref5.state.states):
                 assert (a - b[3]).abs().max() / b[3].abs().max() < 2e-5
+            eng.begin_greedy(12)
+            eng.greedy_steps(12)                                     # groups of GRAPH_STEPS + remainder (no graph on CPU)
+            assert torch.equal(eng.greedy_tokens(), toks_ref)
             # re-arming after a partial window: pending steps are flushed, the continuation matches a fresh run
             eng.begin_greedy(3, y0=None)
             eng.greedy_step()
