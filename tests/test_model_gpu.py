@@ -270,14 +270,14 @@ def test_l169_other_head_shapes_match_cpu_oracle(hip, heads, expand_v):
     B, n = 4, 10
     x = torch.randint(3, 256, (B, 16))
     orc = OracleLina(model.state_dict(), n_layer=6, heads=heads, txt_heads=4)
-    ref_toks, _, _, margins = orc.generate_greedy(x, n)
     with torch.inference_mode():
         m = model.to("cuda")
         x_enc = m.txt_encoder(m.txt_embed(x.cuda()))
         eng = DecodeEngine(m, x_enc, batch_size=B)
         assert eng.packs[0].lazy == (expand_v == 1.0)        # Dv = 512 is outside K1w's head shapes: generic path
         toks = eng.run_greedy(n).cpu()
-    for b in range(B):
-        ok = (margins[b] > 1e-3).long().cumprod(0).bool()
-        assert int(ok.sum()) >= 3
-        assert torch.equal(toks[0, b][ok], ref_toks[0, b][ok]), f"row {b}"
+    # the oracle teacher-forced on the engine's tokens: same history at every position, so every position is comparable
+    ref_toks, _, _, margins = orc.generate_greedy(x, n, teacher=toks)
+    safe = margins > 1e-3
+    assert int(safe.sum()) >= B * n // 2, "too many near-ties for the comparison to mean anything"
+    assert torch.equal(toks[0][safe], ref_toks[0][safe])
