@@ -79,7 +79,8 @@ def measure_k1(engine, reps=20):
             v = P.qkv[:, 2 * P.Kd:].view(B, P.H, P.Dv)
             if lazy:
                 ops.gla_decode_window(q, k, v, P.gk.view(B, P.H, P.Dk), P.S, P.g.view(B, P.H, P.Dv), P.gnw,
-                                      P.og, P.hk, P.hc, P.hv, steps[j], origin, W, P.eps_gate)
+                                      P.og, P.hk, P.hc, P.hv, steps[j], origin, W, P.eps_gate, o_exchange=P.o_x,
+                                      counters=P.counters)
             elif fused:
                 ops.gla_decode_update_norm(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S, P.g.view(B, P.H, P.Dv),
                                            P.gnw, P.og, P.counters, P.eps_gate)

@@ -273,7 +273,9 @@ int lina_weighted_rows_add_packed(const void* attc, int Tp, const void* vv, void
 
 /* K1w + K5 -- decode-step state update with a WINDOWED (lazily written) state; inputs / output og as
  * lina_gla_decode_update_norm (one workgroup per (b,h): no partial buffer, no counters), same reference lines
- * (model/gla.py:186-220 at T = 1), Dk and Dv in {64,128,256}, but `state` is the state at the
+ * (model/gla.py:186-220 at T = 1), Dk in {64,128,256}, Dv in {64,128,256,512}; Dv = 512 (expand_v = 2) splits a head's
+ * columns over two workgroups that meet in o_exchange (fp32 [B*H*Dv]) + counters (int32 [B*H], zero; left zero) for the
+ * norm -- both may be NULL for Dv <= 256.  `state` is the state at the
  * START of the current window of `window` (1, 2, 4 or 8) steps: it is only READ on steps 0 .. window-2 and rewritten on
  * step window-1, the steps in between live in the history buffers
  *     hist_k, hist_c: fp32 [window][B*H][Dk]  (k_s and the cumulative log-gate c_s of step s of the window)
@@ -287,7 +289,8 @@ int lina_weighted_rows_add_packed(const void* attc, int Tp, const void* vv, void
 int lina_gla_decode_window_max(void);
 int lina_gla_decode_window(const void* q, const void* k, const void* v, const void* gk,
                            float* state, const void* gate, const void* norm_weight,
-                           void* og, float* hist_k, float* hist_c, float* hist_v,
+                           void* og, float* o_exchange, int* counters,
+                           float* hist_k, float* hist_c, float* hist_v,
                            const int64_t* step, const int64_t* origin, int window,
                            int B, int H, int Dk, int Dv,
                            int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,

@@ -27,14 +27,18 @@ namespace lina {
 
 constexpr int kWinMax = 8;
 
-template <int DV, int NRB, typename TIO, typename TG>
+template <int DV, int NRB, int CS, typename TIO, typename TG>
 __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
     const TIO* __restrict__ q, const TIO* __restrict__ k, const TIO* __restrict__ v, const TG* __restrict__ gk, float* S,
     float* hist_k, float* hist_c, float* hist_v, const int64_t* step, const int64_t* origin, int window, int flush_n,
     int H, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh, int64_t v_sb, int64_t v_sh, int64_t g_sb,
     int64_t g_sh, float scale, const TIO* __restrict__ gate, int64_t gate_sb, int64_t gate_sh,
-    const TIO* __restrict__ nw, float eps, TIO* __restrict__ og, int og_packed) {
-    // og_packed: og is written fragment-major (skinny_frag.h) as the [B, H*Dv] A operand of the output projection
+    const TIO* __restrict__ nw, float eps, TIO* __restrict__ og, int og_packed, float* o_x, int* counters) {
+    // og_packed: og is written fragment-major (skinny_frag.h) as the [B, H*Dv] A operand of the output projection.
+    // CS > 1 (Dv = CS * DV, e.g. expand_v = 2: Dv = 512): the head's columns are split over CS workgroups (blockIdx.y);
+    // the recurrence is independent per column, only the RMS norm needs all of them: the halves' outputs meet in o_x
+    // (fp32 [B*H][Dv], 8-byte agent-scope atomics + one ticket per head, as in K1d + K5) and the last arriver normalises.
+    constexpr int DVT = DV * CS;      // the head's full value width
     constexpr int RB = 64;            // rows per thread group
     constexpr int DK = RB * NRB;
     constexpr int CG = DV / 4;        // lanes per row
@@ -51,7 +55,8 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int r0 = rb * RB;
     const int64_t BH = gridDim.x;
-    float* tile = S + ((int64_t)bh * DK + r0) * DV + 4 * cg;
+    const int col0 = CS > 1 ? (int)blockIdx.y * DV : 0;
+    float* tile = S + ((int64_t)bh * DK + r0) * DVT + col0 + 4 * cg;
 
     // window position: workgroup-uniform.  flush_n >= 0: apply the first flush_n history entries to the state, no output
     const bool flush_only = flush_n >= 0;
@@ -84,13 +89,13 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
         }
     } else if (vc < DV) {
 #pragma unroll
-        for (int s = 0; s < kWinMax; ++s) h1[s] = s < n_hist ? hist_v[((int64_t)s * BH + bh) * DV + vc] : 0.0f;
-        if (!flush_only) vj = ld(v + b * v_sb + h * v_sh + vc);
+        for (int s = 0; s < kWinMax; ++s) h1[s] = s < n_hist ? hist_v[((int64_t)s * BH + bh) * DVT + col0 + vc] : 0.0f;
+        if (!flush_only) vj = ld(v + b * v_sb + h * v_sh + col0 + vc);
     }
 
     float4 St[NP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) St[i] = ld_nt4(tile + (int64_t)(rg + RPI * i) * DV);
+    for (int i = 0; i < NP; ++i) St[i] = ld_nt4(tile + (int64_t)(rg + RPI * i) * DVT);
 
     // ---- per-row gate bookkeeping and the window's v rows
     if (row_wave) {
@@ -104,8 +109,10 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
 #pragma unroll
             for (int s = 0; s < kWinMax; ++s) cprev = (s == j - 1) ? h1[s] : cprev;
             cj = cprev + gj;
-            hist_c[(int64_t)j * BH * DK + hoff] = cj;
-            hist_k[(int64_t)j * BH * DK + hoff] = kj;
+            if (CS == 1 || blockIdx.y == 0) {                            // the column halves compute the same values
+                hist_c[(int64_t)j * BH * DK + hoff] = cj;
+                hist_k[(int64_t)j * BH * DK + hoff] = kj;
+            }
         }
         s_q[row] = qj;
         s_e[row] = __expf(cj);
@@ -125,16 +132,16 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
 #pragma unroll
             for (int s = 0; s < kWinMax; ++s)
                 if (s <= j) s_v[s][vc] = (!flush_only && s == j) ? vj : h1[s];
-            if (!flush_only) hist_v[((int64_t)j * BH + bh) * DV + vc] = vj;
+            if (!flush_only) hist_v[((int64_t)j * BH + bh) * DVT + col0 + vc] = vj;
         }
         for (int c = vc + NV; c < DV; c += NV) {            // only when Dv > 192 * Dk/64 (Dk = 64, Dv = 256)
             for (int s = 0; s <= j; ++s) {
                 float vs;
                 if (!flush_only && s == j) {
-                    vs = ld(v + b * v_sb + h * v_sh + c);
-                    hist_v[((int64_t)j * BH + bh) * DV + c] = vs;
+                    vs = ld(v + b * v_sb + h * v_sh + col0 + c);
+                    hist_v[((int64_t)j * BH + bh) * DVT + col0 + c] = vs;
                 } else {
-                    vs = hist_v[((int64_t)s * BH + bh) * DV + c];
+                    vs = hist_v[((int64_t)s * BH + bh) * DVT + col0 + c];
                 }
                 s_v[s][c] = vs;
             }
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
             }
         }
 #pragma unroll
-        for (int i = 0; i < NP; ++i) st_nt4(tile + (int64_t)(rg + RPI * i) * DV, St[i]);
+        for (int i = 0; i < NP; ++i) st_nt4(tile + (int64_t)(rg + RPI * i) * DVT, St[i]);
         if (flush_only) return;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -208,16 +215,53 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
         float ss = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
         ss += shfl_xor(ss, 1); ss += shfl_xor(ss, 2); ss += shfl_xor(ss, 4);
         ss += shfl_xor(ss, 8); ss += shfl_xor(ss, 16); ss += shfl_xor(ss, 32);
-        const float rs = rsqrtf(ss / (float)DV + eps);
-        if (tid < CG) {
-            r.x *= rs; r.y *= rs; r.z *= rs; r.w *= rs;
-            const float4 ww = ld4(nw + 4 * tid);
-            r.x *= ww.x; r.y *= ww.y; r.z *= ww.z; r.w *= ww.w;
-            const float4 gg = ld4(gate + b * gate_sb + h * gate_sh + 4 * tid);
-            r.x *= gg.x * sigmoidf(gg.x); r.y *= gg.y * sigmoidf(gg.y);
-            r.z *= gg.z * sigmoidf(gg.z); r.w *= gg.w * sigmoidf(gg.w);
-            if (og_packed) st4(og + packed_off<TIO>(b, h * DV + 4 * tid, H * DV), r);   // 4 | KL: one 8/16-byte piece
-            else st4(og + (int64_t)bh * DV + 4 * tid, r);
+        // finish columns [c0, c0 + DV) of the head from the un-normalised values r (lane = 4 columns)
+        auto finish = [&](float4 x, int c0, float rs) {
+            if (tid < CG) {
+                x.x *= rs; x.y *= rs; x.z *= rs; x.w *= rs;
+                const float4 ww = ld4(nw + c0 + 4 * tid);
+                x.x *= ww.x; x.y *= ww.y; x.z *= ww.z; x.w *= ww.w;
+                const float4 gg = ld4(gate + b * gate_sb + h * gate_sh + c0 + 4 * tid);
+                x.x *= gg.x * sigmoidf(gg.x); x.y *= gg.y * sigmoidf(gg.y);
+                x.z *= gg.z * sigmoidf(gg.z); x.w *= gg.w * sigmoidf(gg.w);
+                if (og_packed) st4(og + packed_off<TIO>(b, h * DVT + c0 + 4 * tid, H * DVT), x);   // 4 | KL: one piece
+                else st4(og + (int64_t)bh * DVT + c0 + 4 * tid, x);
+            }
+        };
+        if constexpr (CS == 1) {
+            finish(r, 0, rsqrtf(ss / (float)DV + eps));
+        } else {
+            // publish this half, take a ticket; the LAST arriver reads the other halves and normalises the whole head
+            float* ox = o_x + (int64_t)bh * DVT;
+            if (tid < CG) { st_agent8(ox + col0 + 4 * tid, r.x, r.y); st_agent8(ox + col0 + 4 * tid + 2, r.z, r.w); }
+            drain_stores();
+            int t = 0;
+            if (tid == 0) t = ticket_agent(&counters[bh]);
+            t = shfl_i(t, 0);
+            if (t == CS - 1) {
+                if (tid == 0) counters[bh] = 0;                     // re-armed for the next launch
+                float4 oth[CS];
+                float tot = ss;
+#pragma unroll
+                for (int c = 0; c < CS; ++c) {
+                    oth[c] = r;
+                    if (c != (int)blockIdx.y) {
+                        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (tid < CG) {
+                            const float2 lo = ld_agent8(ox + c * DV + 4 * tid), hi = ld_agent8(ox + c * DV + 4 * tid + 2);
+                            x = make_float4(lo.x, lo.y, hi.x, hi.y);
+                        }
+                        float s2 = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+                        s2 += shfl_xor(s2, 1); s2 += shfl_xor(s2, 2); s2 += shfl_xor(s2, 4);
+                        s2 += shfl_xor(s2, 8); s2 += shfl_xor(s2, 16); s2 += shfl_xor(s2, 32);
+                        tot += s2;
+                        oth[c] = x;
+                    }
+                }
+                const float rs = rsqrtf(tot / (float)DVT + eps);
+#pragma unroll
+                for (int c = 0; c < CS; ++c) finish(oth[c], c * DV, rs);
+            }
         }
     }
 }
@@ -226,22 +270,29 @@ template <typename TIO, typename TG>
 static int launch_window(const void* q, const void* k, const void* v, const void* gk, float* S, float* hk, float* hc,
                          float* hv, const int64_t* step, const int64_t* origin, int window, int flush_n, int B, int H,
                          int Dk, int Dv, const int64_t* st, float scale, lina_stream_t stream, const void* gate,
-                         int64_t gate_sb, int64_t gate_sh, const void* nw, float eps, void* og, int og_packed = 0) {
-    dim3 grid((unsigned)(B * H));
-#define LINA_WIN_ONE(DVV, NRBB)                                                                                        \
-    LINA_LAUNCH((gla_decode_window_kernel<DVV, NRBB, TIO, TG>), grid, dim3(256 * NRBB), 0, stream, (const TIO*)q,      \
+                         int64_t gate_sb, int64_t gate_sh, const void* nw, float eps, void* og, int og_packed = 0,
+                         float* o_x = nullptr, int* counters = nullptr) {
+    const int cs = Dv == 512 ? 2 : 1;                        // column splits: one workgroup streams <= 256 columns
+    dim3 grid((unsigned)(B * H), (unsigned)cs);
+#define LINA_WIN_ONE(DVV, NRBB, CSS)                                                                                   \
+    LINA_LAUNCH((gla_decode_window_kernel<DVV, NRBB, CSS, TIO, TG>), grid, dim3(256 * NRBB), 0, stream, (const TIO*)q, \
                 (const TIO*)k, (const TIO*)v, (const TG*)gk, S, hk, hc, hv, step, origin, window, flush_n, H, st[0],   \
                 st[1], st[2], st[3], st[4], st[5], st[6], st[7], scale, (const TIO*)gate, gate_sb, gate_sh,            \
-                (const TIO*)nw, eps, (TIO*)og, og_packed)
+                (const TIO*)nw, eps, (TIO*)og, og_packed, o_x, counters)
 #define LINA_WIN_CASE(DVV)                                                                                             \
     case DVV:                                                                                                          \
-        if (Dk == 64) LINA_WIN_ONE(DVV, 1); else if (Dk == 128) LINA_WIN_ONE(DVV, 2); else LINA_WIN_ONE(DVV, 4);        \
+        if (Dk == 64) LINA_WIN_ONE(DVV, 1, 1); else if (Dk == 128) LINA_WIN_ONE(DVV, 2, 1); else LINA_WIN_ONE(DVV, 4, 1); \
         break;
     if (Dk != 64 && Dk != 128 && Dk != 256)
         return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_window: Dk=%d not in {64,128,256}", Dk);
+    if (cs == 2 && flush_n < 0 && !(o_x && counters))
+        return fail(LINA_ERR_ARG, "lina_gla_decode_window: Dv=512 needs the o_exchange buffer and the counters");
     switch (Dv) {
         LINA_WIN_CASE(64) LINA_WIN_CASE(128) LINA_WIN_CASE(256)
-        default: return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_window: Dv=%d not in {64,128,256}", Dv);
+        case 512:
+            if (Dk == 64) LINA_WIN_ONE(256, 1, 2); else if (Dk == 128) LINA_WIN_ONE(256, 2, 2); else LINA_WIN_ONE(256, 4, 2);
+            break;
+        default: return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_window: Dv=%d not in {64,128,256,512}", Dv);
     }
 #undef LINA_WIN_CASE
 #undef LINA_WIN_ONE
@@ -254,7 +305,7 @@ extern "C" int lina_gla_decode_window_max(void) { return lina::kWinMax; }
 
 extern "C" int lina_gla_decode_window(const void* q, const void* k, const void* v, const void* gk,
                                       float* state, const void* gate, const void* norm_weight, void* og,
-                                      float* hist_k, float* hist_c, float* hist_v, const int64_t* step,
+                                      float* o_exchange, int* counters, float* hist_k, float* hist_c, float* hist_v, const int64_t* step,
                                       const int64_t* origin, int window, int B, int H, int Dk, int Dv, int64_t q_sb,
                                       int64_t q_sh, int64_t k_sb, int64_t k_sh, int64_t v_sb, int64_t v_sh, int64_t g_sb,
                                       int64_t g_sh, int64_t gate_sb, int64_t gate_sh, float eps, int og_packed, int dtype,
@@ -270,13 +321,16 @@ extern "C" int lina_gla_decode_window(const void* q, const void* k, const void* 
     const int64_t st[8] = {q_sb, q_sh, k_sb, k_sh, v_sb, v_sh, g_sb, g_sh};
     if (dtype == LINA_F32 && g_dtype == LINA_F32)
         return launch_window<float, float>(q, k, v, gk, state, hist_k, hist_c, hist_v, step, origin, window, -1, B, H,
-                                           Dk, Dv, st, scale, stream, gate, gate_sb, gate_sh, norm_weight, eps, og, og_packed);
+                                           Dk, Dv, st, scale, stream, gate, gate_sb, gate_sh, norm_weight, eps, og, og_packed,
+                                           o_exchange, counters);
     if (dtype == LINA_BF16 && g_dtype == LINA_F32)
         return launch_window<bf16_t, float>(q, k, v, gk, state, hist_k, hist_c, hist_v, step, origin, window, -1, B,
-                                            H, Dk, Dv, st, scale, stream, gate, gate_sb, gate_sh, norm_weight, eps, og, og_packed);
+                                            H, Dk, Dv, st, scale, stream, gate, gate_sb, gate_sh, norm_weight, eps, og, og_packed,
+                                           o_exchange, counters);
     if (dtype == LINA_BF16 && g_dtype == LINA_BF16)
         return launch_window<bf16_t, bf16_t>(q, k, v, gk, state, hist_k, hist_c, hist_v, step, origin, window, -1, B,
-                                             H, Dk, Dv, st, scale, stream, gate, gate_sb, gate_sh, norm_weight, eps, og, og_packed);
+                                             H, Dk, Dv, st, scale, stream, gate, gate_sb, gate_sh, norm_weight, eps, og, og_packed,
+                                           o_exchange, counters);
     return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_window: dtype=f32 with bf16 gates is not built");
 }
 

@@ -116,7 +116,8 @@ class _BlockPack:
         self.og = torch.empty(B, self.H, self.Dv, dtype=dt, device=dev)
         self.counters = torch.zeros(B * self.H, dtype=torch.int32, device=dev)
         self.s = torch.empty(B, self.hid_pad, dtype=dt, device=dev)
-        self.lazy = self.window > 1 and self.Dk in (64, 128, 256) and self.Dv in (64, 128, 256)
+        self.lazy = self.window > 1 and self.Dk in (64, 128, 256) and self.Dv in (64, 128, 256, 512)
+        self.o_x = torch.zeros(B * self.H * self.Dv, dtype=torch.float32, device=dev) if self.Dv > 256 else None
         self.packed = self.lazy and self.fused_in
         if self.packed:
             self.og_p = torch.zeros(ops.packed_numel(B, self.Vd), dtype=dt, device=dev)
@@ -241,7 +242,8 @@ class DecodeEngine:
             pass                                  # measurement only (time_update_kernel): the step without K1w / K1d
         elif lazy and P.lazy:
             ops.gla_decode_window(q, k, v, P.gk.view(B, P.H, P.Dk), P.S, gate, P.gnw, P.og_p if packed else P.og,
-                                  P.hk, P.hc, P.hv, self._t_idx, self._origin, P.window, P.eps_gate, og_packed=packed)
+                                  P.hk, P.hc, P.hv, self._t_idx, self._origin, P.window, P.eps_gate, og_packed=packed,
+                                  o_exchange=P.o_x, counters=P.counters)
         elif P.row_split and self.fuse_norm:
             ops.gla_decode_update_norm(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S, gate, P.gnw, P.og,
                                        P.counters, P.eps_gate)

@@ -759,7 +759,7 @@ def gla_decode_update_norm(q, k, v, gk, o_part, state, gate, norm_weight, og, co
 
 
 def gla_decode_window(q, k, v, gk, state, gate, norm_weight, og, hist_k, hist_c, hist_v, step, origin,
-                      window: int, eps: float = 1e-5, scale=None, og_packed: bool = False):
+                      window: int, eps: float = 1e-5, scale=None, og_packed: bool = False, o_exchange=None, counters=None):
     """K1w + K5 (lina_gla_decode_window): decode-step update with a lazily written state -- ``state`` is read every
     step and rewritten every ``window``-th one, the steps in between live in hist_k / hist_c [window,B*H,Dk] and
     hist_v [window,B*H,Dv] (fp32).  ``step`` / ``origin``: int64 device tensors (window position = (step-origin) %
@@ -782,8 +782,13 @@ def gla_decode_window(q, k, v, gk, state, gate, norm_weight, og, hist_k, hist_c,
     for t in (q, k, v, gk):
         if t.stride(-1) != 1:
             raise ValueError("innermost dimension must be contiguous")
+    be.require(o_exchange, counters)
+    if Dv > 256 and (o_exchange is None or counters is None or o_exchange.dtype != torch.float32
+                     or o_exchange.numel() < B * H * Dv or counters.dtype != torch.int32 or counters.numel() < B * H):
+        raise ValueError("Dv > 256 needs o_exchange (fp32 [B*H*Dv]) and counters (int32 [B*H], zero)")
     _check(be.lib.lina_gla_decode_window(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(state), _ptr(gate),
-                                         _ptr(norm_weight), _ptr(og), _ptr(hist_k), _ptr(hist_c),
+                                         _ptr(norm_weight), _ptr(og), _ptr(o_exchange), _ptr(counters), _ptr(hist_k),
+                                         _ptr(hist_c),
                                          _ptr(hist_v), _ptr(step), _ptr(origin), int(window), B, H, Dk, Dv,
                                          q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
                                          gk.stride(0), gk.stride(1), gate.stride(0), gate.stride(1), float(eps),

@@ -706,6 +706,7 @@ def check_decode_window(dev, B, H, Dk, Dv, dtype, window=8, n_steps=19, resets=T
     hv = torch.full((window, B * H, Dv), float("nan"), device=dev)
     step = torch.full((1,), origin0, dtype=torch.int64, device=dev)
     origin = torch.full((1,), origin0, dtype=torch.int64, device=dev)
+    o_x = torch.full((B * H * Dv,), float("nan"), device=dev) if Dv > 256 else None   # Dv = 512: column halves meet here
     tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
     for t in range(n_steps):
         q = torch.randn(B, H, Dk, generator=g).to(dtype).to(dev)
@@ -717,24 +718,29 @@ def check_decode_window(dev, B, H, Dk, Dv, dtype, window=8, n_steps=19, resets=T
         gk = gk.to(dev)
         gate = torch.randn(B, H, Dv, generator=g).to(dtype).to(dev)
         og = torch.full((B, H, Dv), float("nan"), dtype=dtype, device=dev)
-        ops.gla_decode_window(q, k, v, gk, S_w, gate, w, og, hk, hc, hv, step, origin, window, 1e-5)
+        ops.gla_decode_window(q, k, v, gk, S_w, gate, w, og, hk, hc, hv, step, origin, window, 1e-5,
+                              o_exchange=o_x, counters=counters)
+        assert int(counters.abs().sum()) == 0
         step += 1
-        op_i = torch.empty(NP, B, H, Dv, device=dev)
-        og_i = torch.empty(B, H, Dv, dtype=dtype, device=dev)
-        ops.gla_decode_update_norm(q, k, v, gk, op_i, S_i, gate, w, og_i, counters_i, 1e-5)
+        if Dv <= 256:
+            op_i = torch.empty(NP, B, H, Dv, device=dev)
+            og_i = torch.empty(B, H, Dv, dtype=dtype, device=dev)
+            ops.gla_decode_update_norm(q, k, v, gk, op_i, S_i, gate, w, og_i, counters_i, 1e-5)
         # oracle: one recurrence step + norm-gate in fp64
         qd, kd, vd, gd = (x.cpu().to(F64) for x in (q, k, v, gk))
         S_ref = S_ref * gd.exp().unsqueeze(-1) + kd.unsqueeze(-1) * vd.unsqueeze(-2)
         o_ref = torch.einsum("bhk,bhkv->bhv", qd * Dk ** -0.5, S_ref)
         og_ref = O.rmsnorm_swish_gate(o_ref, gate.cpu().to(F64), w.cpu().to(F64), 1e-5)
         assert_close(og, og_ref, tol, f"K1w og (step {t}, window position {t % window})")
-        assert_close(og.float(), og_i.float(), tol, f"K1w vs K1d og (step {t})")
+        if Dv <= 256:
+            assert_close(og.float(), og_i.float(), tol, f"K1w vs K1d og (step {t})")
         if (t + 1) % window == 0:                 # a completed window leaves the state fully written back
             assert_close(S_w, S_ref, 1e-5, f"K1w state after window (step {t})")
     pending = n_steps % window
     ops.gla_decode_window_flush(S_w, hk, hc, hv, pending)
     assert_close(S_w, S_ref, 1e-5, "K1w flushed state")
-    assert_close(S_w, S_i, 1e-5, "K1w flushed state vs K1d state")
+    if Dv <= 256:
+        assert_close(S_w, S_i, 1e-5, "K1w flushed state vs K1d state")
 
 
 def check_cross_att(dev, B, Tn, d, dtype):

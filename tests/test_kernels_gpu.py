@@ -266,7 +266,8 @@ def test_chunk_segment_parallel_at_the_training_sequence_length(hip, nseg, reset
 
 # ----------------------------------------------------------------------------- K1w: windowed decode-step update
 @pytest.mark.parametrize("B,H,Dk,Dv,dtype,window,n", [(64, 4, 256, 256, torch.bfloat16, 8, 21), (3, 2, 256, 256, torch.float32, 8, 17),
-                                                      (5, 8, 128, 128, torch.bfloat16, 4, 10), (2, 16, 64, 64, torch.float32, 8, 9)])
+                                                      (5, 8, 128, 128, torch.bfloat16, 4, 10), (2, 16, 64, 64, torch.float32, 8, 9),
+                                                      (64, 4, 256, 512, torch.bfloat16, 8, 18), (3, 2, 128, 512, torch.float32, 8, 9)])
 def test_decode_window(hip, B, H, Dk, Dv, dtype, window, n):
     from kernel_cases import check_decode_window
     check_decode_window(DEV, B=B, H=H, Dk=Dk, Dv=Dv, dtype=dtype, window=window, n_steps=n)
