@@ -5,7 +5,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 TAG=${1:-r02}
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 200 rocprofv3 --kernel-trace --pmc $C -d gpurun_out/${TAG}_pmc_$C -o ${TAG} --output-format csv -- python bench.py --steps 40 --warmup 8 --preheat-s 0.2 --no-cpu-baseline --no-chunk --no-train > gpurun_out/${TAG}_pmc_$C.log 2>&1; echo "$C=$?"
+  K1_REPS=16 timeout 300 rocprofv3 --kernel-trace --pmc $C -d gpurun_out/${TAG}_pmc_$C -o ${TAG} --output-format csv -- python tools/perf_k1w.py > gpurun_out/${TAG}_pmc_$C.log 2>&1; echo "$C=$?"
 done
 python - "$TAG" <<'PY'
 import csv, glob, json, sys
@@ -22,7 +22,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 rd = 2 * out["FETCH_SIZE"]["mean_KiB"] * 1024          # gfx950: 128-B streaming read requests tallied at 64 B
 wr = out["WRITE_SIZE"]["mean_KiB"] * 1024
 res = {"kernel": "lina::gla_decode_window_kernel<256, 4, bf16, float> (K1w + K5, window 8)",
-       "command": "rocprofv3 --kernel-trace --pmc <COUNTER> -- python bench.py --steps 40 --warmup 8 --preheat-s 0.2 --no-cpu-baseline --no-chunk --no-train (one counter per pass; tests/gpu_traffic.sh)",
+       "command": "rocprofv3 --kernel-trace --pmc <COUNTER> -- python tools/perf_k1w.py (the 13 layers' real buffers, all 8 window positions in turn; one counter per pass; tests/gpu_traffic.sh)",
        "counters": out,
        "correction": "gfx950 FETCH_SIZE counts the 128-B requests of a 16-B/lane streaming read at 64 B: doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE taken as is",
        "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr,

@@ -100,7 +100,7 @@ def test_engine_windowed_state_equals_immediate_state(emu):
         ref = DecodeEngine(model, x_enc, batch_size=3, window=1)
         toks_ref = ref.run_greedy(12)
         assert torch.equal(toks_ref, torch.from_numpy(g["gen_qs"]))
-        for window in (8, 4):
+        for window in (8,):           # other windows: kernel-level tests (test_decode_window)
             eng = DecodeEngine(model, x_enc, batch_size=3, window=window)
             assert eng.packs[0].lazy
             eng.begin_greedy(12)
