@@ -13,10 +13,16 @@ Inputs and state are resident in HBM when the timed region starts.  Synthetic da
 random-init weights from the reference initialisers.
 
 Prints ONE JSON line (rank 0) with the driver contract plus
-  roofline      the dominant kernel of the step (K1d, lina::gla_decode_rowsplit_kernel): algorithmic bytes per
-                launch / its average launch duration measured here with HIP events on the launch stream
-  chunk_kernel  the same accounting for K2 (lina::gla_chunk_*_kernel) at the training shape
-  cpu_baseline  the CPU oracle (pure-PyTorch recurrent port of the reference path) on a bounded sample
+  roofline      the dominant kernel of the step -- K1w + K5 (lina::gla_decode_window_kernel), the windowed recurrent-state
+                update: its bytes per launch / its launch duration measured IN SITU (the captured step graph
+                with and without its 13 update launches, HIP events around the replays), the back-to-back figure and the
+                immediate-form bytes beside it; traffic from the committed PMC passes
+  step_roofline the whole step's HBM bytes / ms_per_step (also priced with the immediate-form state bytes)
+  chunk_kernel  the same accounting for K2 (lina::gla_chunk_*_kernel) at the training shape (+ b=8, K2b, vocoder, train step)
+  other_head_shapes / decode_f32   the same engine at H=8, H=16, expand_v=2 and in fp32
+  cpu_baseline  the CPU oracle (pure-PyTorch recurrent port of the reference path) on a bounded sample, host CPU named
+`--gpus N` without a launcher starts N ranks under torch.distributed.run; `--train` measures config 5 (DDP train step).
+The timed region is max(--steps, 0.25 s of steps); "steps" reports what was timed.
 """
 from __future__ import annotations
 
