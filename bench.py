@@ -243,7 +243,7 @@ def measure_vocoder(dev, B=64, L=750, reps=3):
             "tokens_each": L, "ms": dt * 1e3, "codec_tokens_per_s": B * L / dt, "audio_seconds_per_s": B * L / 75.0 / dt}
 
 
-def cpu_baseline(model, seconds=12.0, B=8, max_steps=64):
+def cpu_baseline(model, seconds=15.0, B=8, max_steps=400):
     """The reference's pure-PyTorch recurrent path (mode='naive') restated in oracle/, timed on the host cores
     on a bounded sample of the same workload: same 166.7M weights (fp32), B=8 rows, T_txt=64, greedy."""
     from oracle.lina_decode_oracle import OracleLina

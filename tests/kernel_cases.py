@@ -52,6 +52,15 @@ def make_gla_inputs(B, H, T, Dk, Dv, dtype, dev, seed=0, resets=False):
 
 
 def oracle_gla(q, k, v, gk, h0):
+    n_thr = torch.get_num_threads()
+    torch.set_num_threads(min(n_thr, 8))       # a long python loop of tiny ops: a 256-thread pool only adds wake-up cost
+    try:
+        return _oracle_gla(q, k, v, gk, h0)
+    finally:
+        torch.set_num_threads(n_thr)
+
+
+def _oracle_gla(q, k, v, gk, h0):
     o, S = O.naive_recurrent_gla(q.cpu().to(F64), k.cpu().to(F64), v.cpu().to(F64), gk.cpu().to(F64),
                                  initial_state=None if h0 is None else h0.cpu().to(F64),
                                  output_final_state=True, compute_dtype=F64)

@@ -200,7 +200,7 @@ def test_config3_decode_to_waveform_chain_vs_oracle(hip):
     from oracle.vocoder_oracle import OracleVocoder
     torch.manual_seed(0)
     model = l169().eval()
-    B, n = 64, 20
+    B, n = 64, 14
     x = torch.randint(3, 256, (B, 16), generator=torch.Generator().manual_seed(11))
     orc = OracleLina(model.state_dict(), n_layer=6, heads=4, txt_heads=4)
     ref_toks, _, _, margins = orc.generate_greedy(x, n)
