@@ -581,6 +581,10 @@ def main():
                                          "tokens_per_s": B * 50 / (time.perf_counter() - ts0)}
             if not args.no_chunk and world == 1:
                 out["chunk_kernel"] = measure_chunk(dev)
+                for hh in (8, 16):                                   # the same width as 8 / 16 heads: 2 / 4 heads per workgroup
+                    ck = measure_chunk(dev, B=64, H=hh, Dk=1024 // hh, Dv=1024 // hh, reps=100)
+                    ck["kernel"] = f"lina::gla_chunk_bf16_h256_kernel<false, G={256 * hh // 1024}> ({256 * hh // 1024} heads per workgroup)"
+                    out[f"chunk_kernel_h{hh}"] = ck
                 small = measure_chunk(dev, B=8)                      # training micro-batch: segment-parallel form
                 small["kernel"] = "lina_gla_chunk_fwd_seg (state-only pass + combine + full pass, 8 segments)"
                 out["chunk_kernel_b8"] = small

@@ -61,13 +61,19 @@ __device__ __forceinline__ bf16x8 frag8x2(const bf16_t* p_lo, const bf16_t* p_hi
 // h0 / ht / dec_out indexed by blockIdx.x (nseg = 1: the plain one-workgroup-per-head form).  STATE_ONLY: no output,
 // only the segment's state transition -- final state from the given start (zero if h0 == NULL) and the product of
 // the chunk decays dec_out[blockIdx.x][Dk] -- used by the two-pass segment-parallel forward below.
-template <bool STATE_ONLY>
+// G heads of dimension D = 256 / G side by side in one workgroup (G = 1: the L169 head, 256 x 256; G = 2: 128 x 128; G = 4:
+// 64 x 64): in a [B,T,H,D] tensor the G heads of a group are one contiguous 512-byte row per token, so the DMA, phase A and
+// every tile are unchanged; the state is block-diagonal -- wave w belongs to head w / (16/G) and keeps only that head's
+// 16/G row tiles, the token contractions run over its head's channels only, mask(A) exists once per head.
+template <bool STATE_ONLY, int G>
 __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ gk, bf16_t* __restrict__ o, const float* h0, float* ht, float* dec_out, int H,
     int T_total, int nseg, int Tseg, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
     lina_bht_strides sg, lina_bht_strides so, float scale) {
-    constexpr int DK = 256, DV = 256, C = kFullC;
+    constexpr int DK = 256, DV = 256, C = kFullC;       // the WORKGROUP's channel / column width: G heads of D each
+    constexpr int D = 256 / G;                            // head dimension
+    constexpr int NTL = 16 / G;                           // waves per head = state row tiles per wave
     // q~ / k~ row-major tiles, 544-byte rows.  Two twists make EVERY operand read of them one conflict-free ds_read_b128
     // (the two 8-byte reads step (1) needed before were merged by the compiler into ds_read2_b64: half rate, 32 banks,
     // 2-way conflicted -- 4096 LDS cycles per chunk, the largest single cost of the kernel):
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     __shared__ __attribute__((aligned(16))) bf16_t s_qk[2 * C * SQ];    // q~ | row-major k~ (for mask(A))
     bf16_t* const s_q = s_qk;
     bf16_t* const s_k = s_qk + C * SQ;
-    __shared__ __attribute__((aligned(16))) bf16_t s_A[2 * 64 * 8];     // mask(A) as ready-made operands [nt][lane][8]
+    __shared__ __attribute__((aligned(16))) bf16_t s_A[G * 2 * 64 * 8]; // mask(A) as ready-made operands [head][nt][lane][8]
     __shared__ __attribute__((aligned(16))) bf16_t s_T[(DK + DV) * ST];  // k~^T | v^T
     bf16_t* const s_kT = s_T;
     bf16_t* const s_vT = s_T + DK * ST;
@@ -116,21 +122,22 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int w_s = wave_uniform(w);                         // wave index in an SGPR for the whole kernel
     int li = lane & 15, lg = lane >> 4;
-    const int slot = blockIdx.x;                             // state slot: (b*H + h) * nseg + segment
-    const int bh = slot / nseg, b = bh / H, h = bh % H;
+    const int slot = blockIdx.x;                             // state slot: (head group) * nseg + segment
+    const int bh = (slot / nseg) * G, b = bh / H, h = bh % H;   // first head of the group (H % G == 0: one batch row)
+    const int hw = w_s / NTL, wl = w_s % NTL;                // this wave's head inside the group, its index inside the head
     const int t_begin = (slot % nseg) * Tseg;
     const int T = min(Tseg, T_total - t_begin);              // tokens of this segment (>= 1 by construction)
 
     // ---- state: wave w owns columns [16w, 16w+16), tile p = rows [16p, 16p+16) ----
-    f32x4 S[16];
+    f32x4 S[NTL];                                            // local tile p <-> rows [16p, 16p+16) of this wave's head
 #pragma unroll
-    for (int p = 0; p < 16; ++p) S[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (h0) {
-        const float* hp = h0 + ((int64_t)slot * DK + 4 * lg) * DV + 16 * w + li;
+    for (int p = 0; p < NTL; ++p) S[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (h0) {                                                // state slot layout [G][D][D] (G = 1: [256][256])
+        const float* hp = h0 + (((int64_t)slot * G + hw) * D + 4 * lg) * D + 16 * wl + li;
 #pragma unroll
-        for (int p = 0; p < 16; ++p)
+        for (int p = 0; p < NTL; ++p)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) S[p][r] = hp[(16 * p + r) * DV];
+            for (int r = 0; r < 4; ++r) S[p][r] = hp[(16 * p + r) * D];
     }
 
     const bf16_t* gsrc[4] = {q + b * sq.b + h * sq.h + t_begin * sq.t, k + b * sk.b + h * sk.h + t_begin * sk.t,
@@ -379,27 +386,57 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 bf16x8 kf[4], qf[4];                           // ring, 3 k-steps ahead
 #pragma unroll
                 for (int ks = 0; ks < 3; ++ks) { kf[ks] = frag16(kp + 32 * ks); qf[ks] = frag16(qp + 32 * ks); }
-                f32x4 at = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 at[G];                                   // one A per head: k-steps [8g/G, 8(g+1)/G) are head g's channels
+#pragma unroll
+                for (int g2 = 0; g2 < G; ++g2) at[g2] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     if (ks + 3 < 8) { kf[(ks + 3) & 3] = frag16(kp + 32 * (ks + 3)); qf[(ks + 3) & 3] = frag16(qp + 32 * (ks + 3)); }
                     sched_fence();
-                    at = mfma_bf16_16x16x32(kf[ks & 3], qf[ks & 3], at);
+                    at[ks / (8 / G)] = mfma_bf16_16x16x32(kf[ks & 3], qf[ks & 3], at[ks / (8 / G)]);
                     sched_fence();
                 }
                 const int t = 16 * nt + li, sb = 16 * mt + 4 * lg;
-                uint2 pa;
-                pa.x = pack_bf16x2(sb <= t ? at[0] : 0.0f, sb + 1 <= t ? at[1] : 0.0f);
-                pa.y = pack_bf16x2(sb + 2 <= t ? at[2] : 0.0f, sb + 3 <= t ? at[3] : 0.0f);
-                *reinterpret_cast<uint2*>(&s_A[(nt * 64 + lane) * 8 + 4 * mt]) = pa;
+#pragma unroll
+                for (int g2 = 0; g2 < G; ++g2) {
+                    uint2 pa;
+                    pa.x = pack_bf16x2(sb <= t ? at[g2][0] : 0.0f, sb + 1 <= t ? at[g2][1] : 0.0f);
+                    pa.y = pack_bf16x2(sb + 2 <= t ? at[g2][2] : 0.0f, sb + 3 <= t ? at[g2][3] : 0.0f);
+                    *reinterpret_cast<uint2*>(&s_A[g2 * 1024 + (nt * 64 + lane) * 8 + 4 * mt]) = pa;
+                }
                 wave_priority<0>();
             }
             K2_PROF(3);
         }
-        const bf16_t* ktp = &s_kT[li * ST + 8 * lg];          // k~^T fragment of state tile p: + 16 p ST
+        const bf16_t* ktp = &s_kT[(16 * NTL * hw + li) * ST + 8 * lg];   // k~^T fragment of this head's state tile p: + 16 p ST
         bf16x8 tf[8];                                          // ring of k~^T fragments, 5 tiles ahead
         bf16x8 vb2;                                            // v^T fragment of step (4) (tokens as k-slots 8lg..8lg+7)
-        if constexpr (!STATE_ONLY) {
+        if constexpr (!STATE_ONLY && G > 1) {
+            // (1) for G heads per workgroup: the same products over this head's NTL/2 tile pairs (channels
+            //     [D hw, D hw + D)); everything is requested up front (the state is only 64/G registers)
+            constexpr int NPP = 8 / G;
+            const bf16_t* qp = &s_q[li * SQ + 32 * NPP * hw + 8 * (lg ^ ((li >> 2) & 3))];
+            bf16x8 qf[NPP][2];
+#pragma unroll
+            for (int pp = 0; pp < NPP; ++pp)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) qf[pp][nt] = frag16(qp + 16 * nt * SQ + 32 * pp);
+            vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
+#pragma unroll
+            for (int p = 0; p < (NTL < 5 ? NTL : 5); ++p) tf[p] = frag16(ktp + 16 * p * ST);
+            sched_fence();
+#pragma unroll
+            for (int pp = 0; pp < NPP; ++pp) {
+                bf16x8 bb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bb[r] = (short)f2bf(S[2 * pp][r]);
+                    bb[4 + r] = (short)f2bf(S[2 * pp + 1][r]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[nt] = mfma_bf16_16x16x32(bb, qf[pp][nt], acc[nt]);
+            }
+        } else if constexpr (!STATE_ONLY) {
             // (1) o = q~ . S_old : one K = 32 MFMA per pair of 16-row state tiles (converted to bf16 in registers)
             const bf16_t* qp = &s_q[li * SQ + 8 * (lg ^ ((li >> 2) & 3))];
             bf16x8 qf[4][2];                                   // ring, 3 tile pairs ahead
@@ -438,21 +475,21 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         } else {
             vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
 #pragma unroll
-            for (int p = 0; p < 5; ++p) tf[p] = frag16(ktp + 16 * p * ST);
+            for (int p = 0; p < (NTL < 5 ? NTL : 5); ++p) tf[p] = frag16(ktp + 16 * p * ST);
         }
         K2_PROF(4);
         // (4) S' += k^^T v
 #pragma unroll
-        for (int p = 0; p < (LINA_K2_ABL == 4 ? 0 : 16); ++p) {
-            if (p + 5 < 16) tf[(p + 5) & 7] = frag16(ktp + 16 * (p + 5) * ST);
+        for (int p = 0; p < (LINA_K2_ABL == 4 ? 0 : NTL); ++p) {
+            if (p + 5 < NTL) tf[(p + 5) & 7] = frag16(ktp + 16 * (p + 5) * ST);
             sched_fence();
             S[p] = mfma_bf16_16x16x32(tf[p & 7], vb2, S[p]);
             sched_fence();
         }
         if (renorm) {                                    // rare: S' <- e^{R} S' (R = s_Rn, the value after this chunk)
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const float4 r4 = *reinterpret_cast<const float4*>(&s_Rn[16 * p + 4 * lg]);
+            for (int p = 0; p < NTL; ++p) {
+                const float4 r4 = *reinterpret_cast<const float4*>(&s_Rn[16 * (NTL * hw + p) + 4 * lg]);
                 S[p][0] *= fast_exp2(r4.x); S[p][1] *= fast_exp2(r4.y); S[p][2] *= fast_exp2(r4.z); S[p][3] *= fast_exp2(r4.w);
             }
         }
@@ -472,8 +509,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         if constexpr (!STATE_ONLY) {
             // (3) o += mask(A) . v -- AFTER the barrier: no barrier of its own for mask(A); s_A is rewritten only after the
             //     next chunk's barrier (2)
-            acc[0] = mfma_bf16_16x16x32(vb, frag16(&s_A[(0 * 64 + lane) * 8]), acc[0]);   // o^T += v^T . mask(A)^T
-            acc[1] = mfma_bf16_16x16x32(vb, frag16(&s_A[(1 * 64 + lane) * 8]), acc[1]);
+            acc[0] = mfma_bf16_16x16x32(vb, frag16(&s_A[hw * 1024 + (0 * 64 + lane) * 8]), acc[0]);   // o^T += v^T . mask(A)^T
+            acc[1] = mfma_bf16_16x16x32(vb, frag16(&s_A[hw * 1024 + (1 * 64 + lane) * 8]), acc[1]);
             K2_PROF(7);
         }
         tp = t0; np = n;
@@ -497,23 +534,30 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     if (ht) {
         __syncthreads();                                     // s_R of the last chunk is visible (STATE_ONLY has no barrier (4))
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {                       // S = diag(e^{R}) S'
-            const float4 r4 = *reinterpret_cast<const float4*>(&s_R[16 * p + 4 * lg]);
+        for (int p = 0; p < NTL; ++p) {                      // S = diag(e^{R}) S'
+            const float4 r4 = *reinterpret_cast<const float4*>(&s_R[16 * (NTL * hw + p) + 4 * lg]);
             S[p][0] *= fast_exp2(r4.x); S[p][1] *= fast_exp2(r4.y); S[p][2] *= fast_exp2(r4.z); S[p][3] *= fast_exp2(r4.w);
         }
-        float* hp = ht + ((int64_t)slot * DK + 4 * lg) * DV + 16 * w + li;
+        float* hp = ht + (((int64_t)slot * G + hw) * D + 4 * lg) * D + 16 * wl + li;
 #pragma unroll
-        for (int p = 0; p < 16; ++p)
+        for (int p = 0; p < NTL; ++p)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hp[(16 * p + r) * DV] = S[p][r];
+            for (int r = 0; r < 4; ++r) hp[(16 * p + r) * D] = S[p][r];
     }
 }
 
-// true when the full-head kernel can take this call (16-byte aligned rows everywhere)
-static bool full_ok(int Dk, int Dv, int dtype, const void* q, const void* k, const void* v, const void* gk,
+// true when the full-head kernel can take this call (16-byte aligned rows everywhere); D = 128 / 64: groups of 2 / 4 heads
+// per workgroup, which must be adjacent in memory (head stride == D, the [B,T,H,D] layout) and inside one batch row
+static bool full_ok(int H, int Dk, int Dv, int dtype, const void* q, const void* k, const void* v, const void* gk,
                     const void* o, int g_dtype, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
                     lina_bht_strides sg, lina_bht_strides so) {
-    if (dtype != LINA_BF16 || g_dtype != LINA_BF16 || Dk != 256 || Dv != 256) return false;
+    if (dtype != LINA_BF16 || g_dtype != LINA_BF16 || Dk != Dv || (Dk != 256 && Dk != 128 && Dk != 64)) return false;
+    const int G = 256 / Dk;
+    if (G > 1) {
+        if (H % G) return false;
+        auto adj = [Dk](lina_bht_strides s) { return s.h == Dk; };
+        if (!adj(sq) || !adj(sk) || !adj(sv) || !adj(sg) || !adj(so)) return false;
+    }
     auto al = [](lina_bht_strides s, int m) { return s.b % m == 0 && s.h % m == 0 && s.t % m == 0; };
     if (!al(sq, 8) || !al(sk, 8) || !al(sv, 8) || !al(so, 8) || !al(sg, 8)) return false;
     auto small = [](lina_bht_strides s) { return s.t >= 0 && s.t < (1LL << 20); };   // 32-bit in-sequence offsets
@@ -527,13 +571,17 @@ int launch_chunk_full(const void* q, const void* k, const void* v, const void* g
                       lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides so, int dtype, int g_dtype,
                       float scale, lina_stream_t stream, bool* taken) {
     auto fits32 = [T](lina_bht_strides st) { return (int64_t)T * st.t < (1LL << 31); };
-    *taken = full_ok(Dk, Dv, dtype, q, k, v, gk, o, g_dtype, sq, sk, sv, sg, so) && fits32(sq) && fits32(sk) &&
+    *taken = full_ok(H, Dk, Dv, dtype, q, k, v, gk, o, g_dtype, sq, sk, sv, sg, so) && fits32(sq) && fits32(sk) &&
              fits32(sv) && fits32(sg) && fits32(so);
     if (!*taken) return LINA_OK;
-    dim3 grid((unsigned)(B * H));
-    LINA_LAUNCH(gla_chunk_bf16_h256_kernel<false>, grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
-                (const bf16_t*)v, (const bf16_t*)gk, (bf16_t*)o, h0, ht, (float*)nullptr, H, T, 1, T, sq, sk, sv, sg, so,
-                scale);
+    const int G = 256 / Dk;
+    dim3 grid((unsigned)(B * H / G));
+#define LINA_FULL(GG)                                                                                                  \
+    LINA_LAUNCH((gla_chunk_bf16_h256_kernel<false, GG>), grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k, \
+                (const bf16_t*)v, (const bf16_t*)gk, (bf16_t*)o, h0, ht, (float*)nullptr, H, T, 1, T, sq, sk, sv, sg, so, \
+                scale)
+    if (G == 1) LINA_FULL(1); else if (G == 2) LINA_FULL(2); else LINA_FULL(4);
+#undef LINA_FULL
     return check_launch("lina_gla_chunk_fwd(full)");
 }
 
@@ -546,22 +594,25 @@ int launch_chunk_full(const void* q, const void* k, const void* v, const void* g
 // Exact (the recurrence is linear in the state); costs one extra pass over k, g, v and 2 x nseg state tiles of
 // workspace traffic per head, buys nseg x the workgroups.
 // ------------------------------------------------------------------------------------------------------------
+// A slot's state block is [G][D][D] = 256 * D floats (G = 256 / D heads side by side); row c of that block (0 <= c < 256)
+// decays by P[slot][c].
 __global__ __launch_bounds__(256) void gla_seg_combine_kernel(const float* __restrict__ L, const float* __restrict__ P,
                                                               const float* h0, float* __restrict__ Sstart, float* ht,
-                                                              int nseg) {
-    constexpr int DK = 256, DV = 256;
-    const int bh = blockIdx.x;
-    const int e = (blockIdx.y * 256 + threadIdx.x) * 4;       // element of the [DK][DV] state, 4 columns per thread
-    const int c = e / DV;
-    float4 S = h0 ? *reinterpret_cast<const float4*>(h0 + (int64_t)bh * DK * DV + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                                                              int nseg, int D) {
+    constexpr int DK = 256;
+    const int64_t blk = (int64_t)DK * D;                      // floats per slot
+    const int bh = blockIdx.x;                                // head group
+    const int e = (blockIdx.y * 256 + threadIdx.x) * 4;       // element of the slot's state block, 4 columns per thread
+    const int c = e / D;
+    float4 S = h0 ? *reinterpret_cast<const float4*>(h0 + (int64_t)bh * blk + e) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < nseg; ++s) {
         const int64_t slot = (int64_t)bh * nseg + s;
-        *reinterpret_cast<float4*>(Sstart + slot * DK * DV + e) = S;
+        *reinterpret_cast<float4*>(Sstart + slot * blk + e) = S;
         const float p = P[slot * DK + c];
-        const float4 l = *reinterpret_cast<const float4*>(L + slot * DK * DV + e);
+        const float4 l = *reinterpret_cast<const float4*>(L + slot * blk + e);
         S.x = p * S.x + l.x; S.y = p * S.y + l.y; S.z = p * S.z + l.z; S.w = p * S.w + l.w;
     }
-    if (ht) *reinterpret_cast<float4*>(ht + (int64_t)bh * DK * DV + e) = S;
+    if (ht) *reinterpret_cast<float4*>(ht + (int64_t)bh * blk + e) = S;
 }
 
 }  // namespace lina
@@ -581,25 +632,29 @@ extern "C" int lina_gla_chunk_fwd_seg(const void* q, const void* k, const void* 
     LINA_REQUIRE(B > 0 && H > 0 && T > 0, "lina_gla_chunk_fwd_seg: B,H,T must be positive");
     LINA_REQUIRE(nseg >= 1, "lina_gla_chunk_fwd_seg: nseg must be >= 1");
     auto fits32 = [T](lina_bht_strides st) { return (int64_t)T * st.t < (1LL << 31); };
-    if (!(full_ok(Dk, Dv, dtype, q, k, v, gk, o, g_dtype, sq, sk, sv, sg, so) && fits32(sq) && fits32(sk) && fits32(sv) &&
+    if (!(full_ok(H, Dk, Dv, dtype, q, k, v, gk, o, g_dtype, sq, sk, sv, sg, so) && fits32(sq) && fits32(sk) && fits32(sv) &&
           fits32(sg) && fits32(so)))
-        return fail(LINA_ERR_UNSUPPORTED, "lina_gla_chunk_fwd_seg: needs bf16 tensors and gates, Dk = Dv = 256, "
-                                          "16-byte aligned rows (use lina_gla_chunk_fwd)");
+        return fail(LINA_ERR_UNSUPPORTED, "lina_gla_chunk_fwd_seg: needs bf16 tensors and gates, Dk = Dv in {64,128,256}, "
+                                          "adjacent heads, 16-byte aligned rows (use lina_gla_chunk_fwd)");
+    const int G = 256 / Dk;
     const int Tseg = ((T + nseg - 1) / nseg + kFullC - 1) / kFullC * kFullC;   // whole 32-token chunks per segment
     const int ns = (T + Tseg - 1) / Tseg;                                       // segments that hold tokens
-    const int64_t slots = (int64_t)B * H * ns;
+    const int64_t slots = (int64_t)(B * H / G) * ns;          // one slot = G heads x one segment: 256 * Dk state floats
     float* L = workspace;
-    float* Sstart = L + slots * Dk * Dv;
-    float* P = Sstart + slots * Dk * Dv;
+    float* Sstart = L + slots * 256 * Dk;
+    float* P = Sstart + slots * 256 * Dk;
     dim3 grid((unsigned)slots);
-    LINA_LAUNCH(gla_chunk_bf16_h256_kernel<true>, grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
-                (const bf16_t*)v, (const bf16_t*)gk, (bf16_t*)nullptr, (const float*)nullptr, L, P, H, T, ns, Tseg, sq, sk,
-                sv, sg, so, scale);
-    LINA_LAUNCH(gla_seg_combine_kernel, dim3((unsigned)(B * H), 64u), dim3(256), 0, stream, (const float*)L,
-                (const float*)P, h0, Sstart, ht, ns);
-    LINA_LAUNCH(gla_chunk_bf16_h256_kernel<false>, grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
-                (const bf16_t*)v, (const bf16_t*)gk, (bf16_t*)o, (const float*)Sstart, (float*)nullptr, (float*)nullptr, H,
-                T, ns, Tseg, sq, sk, sv, sg, so, scale);
+#define LINA_SEG(SO, GG, OO, H0, HT, PP)                                                                               \
+    LINA_LAUNCH((gla_chunk_bf16_h256_kernel<SO, GG>), grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k,  \
+                (const bf16_t*)v, (const bf16_t*)gk, (bf16_t*)(OO), (const float*)(H0), (float*)(HT), (float*)(PP), H, T, \
+                ns, Tseg, sq, sk, sv, sg, so, scale)
+    if (G == 1) LINA_SEG(true, 1, nullptr, nullptr, L, P); else if (G == 2) LINA_SEG(true, 2, nullptr, nullptr, L, P);
+    else LINA_SEG(true, 4, nullptr, nullptr, L, P);
+    LINA_LAUNCH(gla_seg_combine_kernel, dim3((unsigned)(B * H / G), (unsigned)(Dk / 4)), dim3(256), 0, stream,
+                (const float*)L, (const float*)P, h0, Sstart, ht, ns, Dk);
+    if (G == 1) LINA_SEG(false, 1, o, Sstart, nullptr, nullptr); else if (G == 2) LINA_SEG(false, 2, o, Sstart, nullptr, nullptr);
+    else LINA_SEG(false, 4, o, Sstart, nullptr, nullptr);
+#undef LINA_SEG
     return check_launch("lina_gla_chunk_fwd_seg");
 }
 

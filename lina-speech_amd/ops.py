@@ -152,8 +152,10 @@ def _gla_launch(entry: str, q, k, v, gk, scale, initial_state, output_final_stat
         ht = h0 if (inplace_state and h0 is not None) else torch.empty(B, H, Dk, Dv, dtype=torch.float32,
                                                                       device=q.device)
     if entry == "lina_gla_chunk_fwd":
-        nseg = chunk_segments(B * H, T) if nseg is None else nseg
-        if (nseg > 1 and q.dtype == torch.bfloat16 and gk.dtype == torch.bfloat16 and Dk == 256 and Dv == 256):
+        full = q.dtype == torch.bfloat16 and gk.dtype == torch.bfloat16 and Dk == Dv and Dk in (64, 128, 256)
+        groups = 256 // Dk if full else 1                       # heads per workgroup of the full-head kernel
+        nseg = chunk_segments(B * H // groups, T) if nseg is None else nseg
+        if nseg > 1 and full and H % groups == 0:
             ws = _workspace("k2seg", int(be.lib.lina_gla_chunk_fwd_seg_workspace(B, H, Dk, Dv, nseg)), q.device)
             rc = be.lib.lina_gla_chunk_fwd_seg(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(o), _ptr(h0), _ptr(ht), _ptr(ws),
                                                nseg, B, H, T, Dk, Dv, _bht(q), _bht(k), _bht(v), _bht(gk), _bht(o),

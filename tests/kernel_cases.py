@@ -105,11 +105,12 @@ def check_chunk(dev, B, H, T, Dk, Dv, dtype, resets=False):
     assert_close(o, o3.float(), 2 * tol_out(dtype, chunk=True), "K2 vs K1")
 
 
-def check_chunk_segmented(dev, B, H, T, nseg, resets=False):
+def check_chunk_segmented(dev, B, H, T, nseg, resets=False, D=256):
     """Segment-parallel K2 (state-only pass + combine + full pass) == the fp64 recurrent oracle and == the plain
-    one-workgroup-per-head kernel, with and without an initial state; bf16, Dk = Dv = 256."""
+    one-workgroup-per-head(-group) kernel, with and without an initial state; bf16, Dk = Dv = D (256, or 128 / 64 with
+    2 / 4 heads per workgroup)."""
     dtype = torch.bfloat16
-    q, k, v, gk, h0 = make_gla_inputs(B, H, T, 256, 256, dtype, dev, seed=21, resets=resets)
+    q, k, v, gk, h0 = make_gla_inputs(B, H, T, D, D, dtype, dev, seed=21, resets=resets)
     ro, rS = oracle_gla(q, k, v, gk, h0)
     o, S = ops.chunk_gla(q, k, v, gk, initial_state=h0, output_final_state=True, nseg=nseg)
     assert_close(o, ro, tol_out(dtype, chunk=True), f"K2 segmented o (nseg={nseg})")

@@ -204,3 +204,15 @@ def test_linear_skinny_packed(emu, M, N, K, dtype, ln, bias, resid, sw):
 def test_inproj_packed(emu, dtype):
     from kernel_cases import check_inproj_packed
     check_inproj_packed(DEV, B=5, K=64, Kd=32, Vd=32, dtype=dtype)
+
+
+# full-head K2 with 2 / 4 heads per workgroup (D = 128 / 64): block-diagonal state, one mask(A) per head
+@pytest.mark.parametrize("H,D,T,resets", [(2, 128, 70, True), (4, 64, 45, False), (4, 128, 33, False), (8, 64, 100, True),
+                                          (2, 128, 1, False)])
+def test_chunk_full_head_kernel_head_groups(emu, H, D, T, resets):
+    check_chunk(DEV, B=1, H=H, T=T, Dk=D, Dv=D, dtype=torch.bfloat16, resets=resets)
+
+
+@pytest.mark.parametrize("H,D,T,nseg", [(2, 128, 100, 3), (4, 64, 70, 2)])
+def test_chunk_segment_parallel_head_groups(emu, H, D, T, nseg):
+    check_chunk_segmented(DEV, B=1, H=H, T=T, nseg=nseg, resets=True, D=D)

@@ -295,3 +295,15 @@ def test_linear_skinny_packed(hip, M, N, K, dtype, ln, bias, resid, sw):
 def test_inproj_packed(hip, B, dtype):
     from kernel_cases import check_inproj_packed
     check_inproj_packed(DEV, B=B, K=1024, Kd=1024, Vd=1024, dtype=dtype)
+
+
+# ----------------------------------------------------------------------------- full-head K2 for D = 128 / 64 (2 / 4 heads per workgroup)
+@pytest.mark.parametrize("B,H,D,T,resets", [(2, 8, 128, 300, True), (1, 16, 64, 257, False), (3, 4, 64, 100, True),
+                                            (2, 2, 128, 1024, False)])
+def test_chunk_full_head_kernel_head_groups(hip, B, H, D, T, resets):
+    check_chunk(DEV, B=B, H=H, T=T, Dk=D, Dv=D, dtype=torch.bfloat16, resets=resets)
+
+
+@pytest.mark.parametrize("H,D,T,nseg", [(8, 128, 1024, 8), (16, 64, 300, 4)])
+def test_chunk_segment_parallel_head_groups(hip, H, D, T, nseg):
+    check_chunk_segmented(DEV, B=1, H=H, T=T, nseg=nseg, resets=True, D=D)
