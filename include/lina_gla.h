@@ -347,6 +347,20 @@ int lina_cross_att_step2(const void* xp, const void* pe, const void* vv, void* a
  *   lina_softmax_rows     : att[b, 0:Tn] = softmax(x[b, 0:Tn] * scale)  -> strided `att` rows AND a contiguous
  *                           zero-padded copy attc [B, Tp] (Tp >= Tn) that feeds the next projection
  *   lina_weighted_rows_add: x[b,:] += sum_t attc[b,t] * vv[b,t,:]                                              */
+/* Round-2 fusions of the same step (fewer launches on the serial chain):
+ *   lina_cross_scores_softmax      = lina_cross_scores + lina_softmax_rows(scale 1) in one launch (one 1024-thread
+ *                                    workgroup per utterance row): att rows (strided) + zero-padded attc [B,Tp];
+ *   lina_softmax_weighted_rows_add = lina_softmax_rows(scores * scale) + lina_weighted_rows_add in one launch: scores
+ *                                    [B, >= T_txt] in the model dtype; the weights are rounded to the model dtype as
+ *                                    lina_softmax_rows stores them; att rows written by one workgroup per row; x (or, if
+ *                                    x_packed != NULL, the fragment-major residual stream) += att . vv.
+ * Same reference lines: model/crossatt.py:114-155 (eager softmax(q k^T / sqrt d) v of :13-19). */
+int lina_cross_scores_softmax(const void* q_lin, const void* ln_w, const void* ln_b, float ln_eps, const void* kk,
+                              void* att, int64_t att_sb, void* attc, int B, int T_txt, int Tp, int d, float scale,
+                              int dtype, lina_stream_t stream);
+int lina_softmax_weighted_rows_add(const void* scores, int64_t scores_sb, float scale, void* att, int64_t att_sb,
+                                   const void* vv, void* x, void* x_packed, int B, int T_txt, int d, int dtype,
+                                   lina_stream_t stream);
 int lina_cross_scores(const void* q_lin, const void* ln_w, const void* ln_b, float ln_eps, const void* kk,
                       float* scores, int B, int T_txt, int d, float scale, int dtype, lina_stream_t stream);
 int lina_softmax_rows(const void* x, int64_t x_sb, int x_dtype, float scale, void* att, int64_t att_sb,

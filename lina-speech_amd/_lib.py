@@ -64,6 +64,8 @@ PROTOTYPES = {
     "lina_weighted_rows_add_packed": (C.c_int, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "lina_cross_att_step1": (C.c_int, [_p, _p, _p, _f, _p, _p, _p, _i64, _p, _i, _i, _i, _f, _i, _p]),
     "lina_cross_att_step2": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i, _i, _i, _f, _i, _p]),
+    "lina_cross_scores_softmax": (C.c_int, [_p, _p, _p, _f, _p, _p, _i64, _p, _i, _i, _i, _i, _f, _i, _p]),
+    "lina_softmax_weighted_rows_add": (C.c_int, [_p, _i64, _f, _p, _i64, _p, _p, _p, _i, _i, _i, _i, _p]),
     "lina_cross_scores": (C.c_int, [_p, _p, _p, _f, _p, _p, _i, _i, _i, _f, _i, _p]),
     "lina_softmax_rows": (C.c_int, [_p, _i64, _i, _f, _p, _i64, _p, _i, _i, _i, _i, _p]),
     "lina_weighted_rows_add": (C.c_int, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),

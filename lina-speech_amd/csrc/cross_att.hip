@@ -190,6 +190,150 @@ __global__ __launch_bounds__(256) void weighted_rows_kernel(const T* __restrict_
     st4(xa, make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w));
 }
 
+// ---- round-2 fusions: fewer launches on the serial chain of the decode step (a launch slot costs ~5 us there) ---------
+// scores + softmax in ONE launch: one workgroup of 1024 threads per utterance row (the whole row's T_txt scores are
+// needed for the softmax); wave w takes text rows w, w+16, ... -- a row's d elements are one contiguous run, read 8 or 16
+// bytes per lane -- and the first row of every wave is requested before the query's LayerNorm.
+//   att[b, 0:Tn] = softmax(scale * <LN(q_lin[b]), kk[b,t,:]>)  -> strided att rows + zero-padded contiguous attc [B,Tp]
+template <typename T>
+__global__ __launch_bounds__(1024) void cross_scores_softmax_kernel(
+    const T* __restrict__ qlin, const T* __restrict__ ln_w, const T* __restrict__ ln_b, float ln_eps,
+    const T* __restrict__ kk, T* __restrict__ att, int64_t att_sb, T* __restrict__ attc, int Tn, int Tp, int d,
+    float scale) {
+    LINA_DYN_SMEM(smem);
+    float* s_q = reinterpret_cast<float*>(smem);            // [d]
+    float* s_sc = s_q + d;                                    // [Tn]
+    __shared__ float s_red[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    auto wg_sum = [&](float v) {
+        v += shfl_xor(v, 1); v += shfl_xor(v, 2); v += shfl_xor(v, 4);
+        v += shfl_xor(v, 8); v += shfl_xor(v, 16); v += shfl_xor(v, 32);
+        __syncthreads();
+        if (lane == 0) s_red[w] = v;
+        __syncthreads();
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += s_red[i];
+        return t;
+    };
+    constexpr int kIt = 4;                                   // d <= 1024: a row = 4 pieces of 4 elements per lane
+    const bool pre = d <= 256 * kIt;
+    float4 m[kIt];
+    {
+        const int t = min(w, Tn - 1);
+        const T* row = kk + ((int64_t)b * Tn + t) * d;
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int e = lane * 4 + 256 * it;
+            m[it] = (pre && e < d) ? ld4(row + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float s = 0.0f;
+    for (int e = tid; e < d; e += 1024) { const float x = ld(qlin + (int64_t)b * d + e); s_q[e] = x; s += x; }
+    const float mu = wg_sum(s) / (float)d;
+    float vs = 0.0f;
+    for (int e = tid; e < d; e += 1024) { const float c = s_q[e] - mu; vs += c * c; }
+    const float rstd = rsqrtf(wg_sum(vs) / (float)d + ln_eps);
+    for (int e = tid; e < d; e += 1024) {
+        T tmp;                                               // the reference rounds the LN output to the model dtype
+        st(&tmp, (s_q[e] - mu) * rstd * ld(ln_w + e) + ld(ln_b + e));
+        s_q[e] = ld(&tmp);
+    }
+    __syncthreads();
+    for (int t = w; t < Tn; t += 16) {                       // wave-uniform
+        float acc = 0.0f;
+        if (pre && t == w) {
+#pragma unroll
+            for (int it = 0; it < kIt; ++it) {
+                const int e = lane * 4 + 256 * it;
+                if (e < d)
+                    acc = fmaf(m[it].x, s_q[e], fmaf(m[it].y, s_q[e + 1], fmaf(m[it].z, s_q[e + 2], fmaf(m[it].w, s_q[e + 3], acc))));
+            }
+        } else {
+            const T* row = kk + ((int64_t)b * Tn + t) * d;
+            for (int e = lane * 4; e < d; e += 256) {
+                const float4 mm = ld4(row + e);
+                acc = fmaf(mm.x, s_q[e], fmaf(mm.y, s_q[e + 1], fmaf(mm.z, s_q[e + 2], fmaf(mm.w, s_q[e + 3], acc))));
+            }
+        }
+        acc += shfl_xor(acc, 1); acc += shfl_xor(acc, 2); acc += shfl_xor(acc, 4);
+        acc += shfl_xor(acc, 8); acc += shfl_xor(acc, 16); acc += shfl_xor(acc, 32);
+        if (lane == 0) s_sc[t] = acc * scale;
+    }
+    __syncthreads();
+    if (w == 0) {                                            // softmax of the row by one wave (same arithmetic as softmax_rows)
+        float mx = -INFINITY;
+        for (int t = lane; t < Tn; t += 64) mx = fmaxf(mx, s_sc[t]);
+#pragma unroll
+        for (int mm = 1; mm < 64; mm <<= 1) mx = fmaxf(mx, shfl_xor(mx, mm));
+        float sum = 0.0f;
+        for (int t = lane; t < Tn; t += 64) sum += expf(s_sc[t] - mx);
+#pragma unroll
+        for (int mm = 1; mm < 64; mm <<= 1) sum += shfl_xor(sum, mm);
+        const float inv = 1.0f / sum;
+        for (int t = lane; t < Tp; t += 64) {
+            const float p = t < Tn ? expf(s_sc[t] - mx) * inv : 0.0f;
+            if (t < Tn) st(att + b * att_sb + t, p);
+            st(attc + (int64_t)b * Tp + t, p);
+        }
+    }
+}
+
+// softmax + weighted row sum + residual in ONE launch: as weighted_rows_kernel, but every workgroup first turns the
+// row's raw scores (model dtype, from the x_pos . pe^T projection) into the softmax weights itself (T_txt values: nothing
+// next to the 2 KiB it then pulls per text row); the slab-0 workgroup of a row also stores them as the attention output.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_weighted_rows_kernel(const T* __restrict__ scores, int64_t sc_sb, float scale,
+                                                                    T* __restrict__ att, int64_t att_sb,
+                                                                    const T* __restrict__ vv, T* x, int Tn, int d, T* xpk) {
+    __shared__ float s_a[kCaMaxT];
+    __shared__ float s_red[4];
+    __shared__ __attribute__((aligned(16))) float s_p[3][64][4];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float mx = -INFINITY;
+    for (int t = tid; t < Tn; t += 256) { const float v = ld(scores + b * sc_sb + t) * scale; s_a[t] = v; mx = fmaxf(mx, v); }
+    mx = block_max(mx, s_red);
+    float sum = 0.0f;
+    for (int t = tid; t < Tn; t += 256) sum += expf(s_a[t] - mx);
+    sum = block_sum(sum, s_red);
+    const float inv = 1.0f / sum;
+    for (int t = tid; t < Tn; t += 256) {
+        T tmp;                                               // the weights in the model dtype, as softmax_rows stores them
+        st(&tmp, expf(s_a[t] - mx) * inv);
+        s_a[t] = ld(&tmp);
+        if (blockIdx.x == 0) att[b * att_sb + t] = tmp;
+    }
+    __syncthreads();
+    const int e = blockIdx.x * 256 + lane * 4;
+    const bool live = e < d;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const T* base = vv + (int64_t)b * Tn * d + (live ? e : 0);
+    for (int t0 = w; t0 < Tn; t0 += 32) {
+        float4 p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = ld4(base + (int64_t)min(t0 + 4 * u, Tn - 1) * d);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float a = (t0 + 4 * u < Tn) ? s_a[min(t0 + 4 * u, Tn - 1)] : 0.0f;
+            acc.x = fmaf(a, p[u].x, acc.x); acc.y = fmaf(a, p[u].y, acc.y);
+            acc.z = fmaf(a, p[u].z, acc.z); acc.w = fmaf(a, p[u].w, acc.w);
+        }
+    }
+    if (w > 0) *reinterpret_cast<float4*>(&s_p[w - 1][lane][0]) = acc;
+    __syncthreads();
+    if (w > 0 || !live) return;
+#pragma unroll
+    for (int ww = 0; ww < 3; ++ww) {
+        const float4 o = *reinterpret_cast<const float4*>(&s_p[ww][lane][0]);
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    T tmp4[4];
+    st4(tmp4, acc);
+    T* const xa = xpk ? xpk + packed_off<T>(b, e, d) : x + (int64_t)b * d + e;
+    const float4 o = ld4(tmp4), r = ld4(xa);
+    st4(xa, make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void cross_att_step1_kernel(
     const T* __restrict__ qlin, const T* __restrict__ ln_w, const T* __restrict__ ln_b, float ln_eps,
@@ -369,4 +513,43 @@ static int weighted_rows_impl(const void* attc, int Tp, const void* vv, void* x,
         LINA_LAUNCH((weighted_rows_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)attc, Tp,
                     (const bf16_t*)vv, (bf16_t*)x, Tn, d, (bf16_t*)x_packed);
     return check_launch("lina_weighted_rows_add");
+}
+
+extern "C" int lina_cross_scores_softmax(const void* q_lin, const void* ln_w, const void* ln_b, float ln_eps,
+                                         const void* kk, void* att, int64_t att_sb, void* attc, int B, int Tn, int Tp,
+                                         int d, float scale, int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(q_lin && ln_w && ln_b && kk && att && attc, "lina_cross_scores_softmax: null pointer");
+    LINA_REQUIRE(B > 0 && Tn > 0 && Tn <= kCaMaxT && Tp >= Tn, "lina_cross_scores_softmax: 0 < T_txt <= %d", kCaMaxT);
+    LINA_REQUIRE(d > 0 && d % 4 == 0 && d <= 8192, "lina_cross_scores_softmax: d must be a multiple of 4, <= 8192");
+    LINA_REQUIRE(valid_dtype(dtype), "lina_cross_scores_softmax: bad dtype %d", dtype);
+    const size_t smem = sizeof(float) * ((size_t)d + (size_t)Tn);
+    if (dtype == LINA_F32)
+        LINA_LAUNCH((cross_scores_softmax_kernel<float>), dim3((unsigned)B), dim3(1024), smem, stream, (const float*)q_lin,
+                    (const float*)ln_w, (const float*)ln_b, ln_eps, (const float*)kk, (float*)att, att_sb, (float*)attc, Tn,
+                    Tp, d, scale);
+    else
+        LINA_LAUNCH((cross_scores_softmax_kernel<bf16_t>), dim3((unsigned)B), dim3(1024), smem, stream, (const bf16_t*)q_lin,
+                    (const bf16_t*)ln_w, (const bf16_t*)ln_b, ln_eps, (const bf16_t*)kk, (bf16_t*)att, att_sb,
+                    (bf16_t*)attc, Tn, Tp, d, scale);
+    return check_launch("lina_cross_scores_softmax");
+}
+
+extern "C" int lina_softmax_weighted_rows_add(const void* scores, int64_t scores_sb, float scale, void* att, int64_t att_sb,
+                                              const void* vv, void* x, void* x_packed, int B, int Tn, int d, int dtype,
+                                              lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(scores && att && vv && (x || x_packed), "lina_softmax_weighted_rows_add: null pointer");
+    LINA_REQUIRE(B > 0 && Tn > 0 && Tn <= kCaMaxT, "lina_softmax_weighted_rows_add: 0 < T_txt <= %d", kCaMaxT);
+    LINA_REQUIRE(d > 0 && d % 4 == 0, "lina_softmax_weighted_rows_add: d must be a multiple of 4");
+    LINA_REQUIRE(valid_dtype(dtype), "lina_softmax_weighted_rows_add: bad dtype %d", dtype);
+    LINA_REQUIRE(!x_packed || d % (dtype == LINA_BF16 ? 32 : 16) == 0, "lina_softmax_weighted_rows_add: packed x needs whole k-steps");
+    dim3 grid((unsigned)((d + 255) / 256), (unsigned)B);
+    if (dtype == LINA_F32)
+        LINA_LAUNCH((softmax_weighted_rows_kernel<float>), grid, dim3(256), 0, stream, (const float*)scores, scores_sb, scale,
+                    (float*)att, att_sb, (const float*)vv, (float*)x, Tn, d, (float*)x_packed);
+    else
+        LINA_LAUNCH((softmax_weighted_rows_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)scores, scores_sb,
+                    scale, (bf16_t*)att, att_sb, (const bf16_t*)vv, (bf16_t*)x, Tn, d, (bf16_t*)x_packed);
+    return check_launch("lina_softmax_weighted_rows_add");
 }

@@ -28,6 +28,9 @@
 #include <lina_dev.h>
 #include "lina_common.h"
 
+#ifndef LINA_K2_VAR
+#define LINA_K2_VAR 0   // experiment switch (tools/k2_variants.sh): 1 = the loader waves interleave their DMAs with step (1)
+#endif
 #ifndef LINA_K2_ABL
 #define LINA_K2_ABL 0   // tools/k2_ablate.sh builds timing-only variants that skip one phase (results are WRONG there)
 #endif
@@ -152,14 +155,15 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // them at (3).  So ONLY the last four waves (one per SIMD, the lowest issue priority) issue DMAs, 16 each (row pairs
     // 4(w-12) .. +3); the other twelve go straight to their MFMAs and the four catch up on SIMDs the others have left.
     // Rows past the end of the sequence re-read row T-1 (always mapped); phase A masks them.
-    constexpr int kDmaWave0 = 12;
+    constexpr int kLoaders = LINA_K2_VAR == 2 ? 8 : LINA_K2_VAR == 3 ? 2 : 4;   // loader waves (experiment: 8 / 2)
+    constexpr int kDmaWave0 = 16 - kLoaders, kPairsPer = 16 / kLoaders;
     auto dma_chunk = [&](int t_first, int a_lo, int a_hi) {
         if (w < kDmaWave0) return;
 #pragma unroll
         for (int a = a_lo; a < a_hi; ++a) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int pair = 4 * (w - kDmaWave0) + j;
+            for (int j = 0; j < kPairsPer; ++j) {
+                const int pair = kPairsPer * (w - kDmaWave0) + j;
                 const unsigned t = (unsigned)min(t_first + 2 * pair + (lane >> 5), T - 1);
                 bf16_t* dst = a == 0 ? s_rq : a == 1 ? s_rk : a == 2 ? s_rg : s_rv;                 // a is a compile-time index
                 // uniform base + 32-bit BYTE offset per lane (< 2^32: launcher guard): selects the SGPR-base addressing form,
@@ -268,6 +272,15 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         *reinterpret_cast<unsigned*>(tp + DK * ST + 2 * ST) = byte_perm(vv[1].y, vv[0].y, 0x05040100u);
         *reinterpret_cast<unsigned*>(tp + DK * ST + 3 * ST) = byte_perm(vv[1].y, vv[0].y, 0x07060302u);
     };
+    // ONE of a loader wave's 16 DMA instructions (idx = 4 * tensor + row-pair slot), for interleaving with its MFMAs
+    auto dma_piece = [&](int t_first, int idx) {
+        const int a = idx >> 2, j = idx & 3;
+        const int pair = 4 * (w - kDmaWave0) + j;
+        const unsigned t = (unsigned)min(t_first + 2 * pair + (lane >> 5), T - 1);
+        bf16_t* dst = a == 0 ? s_rq : a == 1 ? s_rk : a == 2 ? s_rg : s_rv;
+        const unsigned boff = 2u * (t * gst[a] + 8u * (unsigned)(lane & 31));
+        dma16_to_lds_async(gsrc[a], boff, &dst[pair * PE]);
+    };
     using FullT = std::true_type;
     using PartT = std::false_type;
 
@@ -356,7 +369,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             rn = tid < DK ? s_Rn[tid] : 0.0f;
         }
         const bool renorm = fl.y != 0;                         // workgroup-uniform: set in phase A, reset one chunk later
-        if (t0 + n < T) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);   // next chunk's raw q,k,g,v fly under phase B
+        constexpr bool kSpreadDma = LINA_K2_VAR == 1 && !STATE_ONLY && G == 1;
+        const bool more = t0 + n < T;
+        if (more && !kSpreadDma) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);   // next chunk's raw q,k,g,v fly under phase B
         if (STATE_ONLY && w == 0) {                                    // s_dec is stable between barriers (2) and (3)
             const float4 d = *reinterpret_cast<const float4*>(&s_dec[4 * lane]);
             decp.x *= d.x; decp.y *= d.y; decp.z *= d.z; decp.w *= d.w;
@@ -471,6 +486,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 for (int nt = 0; nt < 2; ++nt)
                     acc[nt] = mfma_bf16_16x16x32(bb, qf[pp & 3][nt], acc[nt]);   // o^T: rows = state columns, cols = tokens
                 sched_fence();
+                if constexpr (kSpreadDma) {                   // the loader waves' DMAs ride between their own MFMAs
+                    if (more && w >= kDmaWave0) { dma_piece(t0 + n, 2 * pp); dma_piece(t0 + n, 2 * pp + 1); }
+                    sched_fence();
+                }
             }
         } else {
             vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);

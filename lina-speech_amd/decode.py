@@ -271,8 +271,8 @@ class DecodeEngine:
         return x
 
     def _cross(self, part, x, lazy=False, packed=False):
-        """x += blind cross-attention: 7 short launches around the pos_net block, every one of them spread over
-        >= 256 workgroups (query projection, scores, softmax, att1.pe | xp.pe^T, softmax, att2.V + residual)."""
+        """x += blind cross-attention: 5 short launches around the pos_net block (query projection, scores + softmax,
+        att1.pe | xp.pe^T, softmax + att2.V + residual)."""
         ca = self.ca
         att = self._att[part.lo:part.hi]
         B = x.shape[0]
@@ -280,8 +280,8 @@ class DecodeEngine:
             q_lin = ops.linear_skinny_packed(part.x_p, self.ca_qw_p, B, self.d, self.d, c2=self.ca_qb, out=part.q_lin)
         else:
             q_lin = ops.linear_skinny(x, self.ca_qw, c2=self.ca_qb, out=part.q_lin)
-        ops.cross_scores(q_lin, ca.ln_q.weight, ca.ln_q.bias, ca.ln_q.eps, part.kk, part.scores, self.att_scale)
-        ops.softmax_rows(part.scores, 1.0, att[:, 0, 0], part.attc, self.Tn)
+        ops.cross_scores_softmax(q_lin, ca.ln_q.weight, ca.ln_q.bias, ca.ln_q.eps, part.kk, att[:, 0, 0], part.attc,
+                                 self.att_scale)
         if packed:
             ops.linear_skinny(part.attc, self.peT, out=part.xp, out_packed=part.xp_p, out_packed_width=self.d)  # xp = att1 . pe
             self._block(part.xp, part.packs[-1], lazy, part.xp_p)
@@ -290,8 +290,8 @@ class DecodeEngine:
             ops.linear_skinny(part.attc, self.peT, out=part.xp)                   # xp = att1 . pe
             self._block(part.xp, part.packs[-1], lazy)
             ops.linear_skinny(part.xp, self.pe_pad, out=part.sc2)                 # scores2 = xp . pe^T
-        ops.softmax_rows(part.sc2, self.att_scale, att[:, 1, 0], part.attc, self.Tn)
-        ops.weighted_rows_add(part.attc, part.vv, x, x_packed=part.x_p if packed else None)
+        ops.softmax_weighted_rows_add(part.sc2, self.att_scale, att[:, 1, 0], part.vv, x,
+                                      x_packed=part.x_p if packed else None)
 
     def _core_part(self, part, y, lazy=False, packed=False):
         x = part.x

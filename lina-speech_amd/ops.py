@@ -839,6 +839,30 @@ def cross_scores(q_lin, ln_w, ln_b, ln_eps, kk, scores, scale):
                                     kk.shape[1], d, float(scale), _dt(q_lin), be.stream(q_lin)))
 
 
+def cross_scores_softmax(q_lin, ln_w, ln_b, ln_eps, kk, att, attc, scale):
+    """att[b,:Tn] = softmax(scale * <LayerNorm(q_lin[b]), kk[b,t,:]>) into the strided ``att`` rows and the contiguous
+    zero-padded copy attc [B,Tp] -- cross_scores + softmax_rows in one launch (lina_cross_scores_softmax)."""
+    be = _BACKEND
+    be.require(q_lin, ln_w, ln_b, kk, att, attc)
+    B, d = q_lin.shape
+    Tn = kk.shape[1]
+    _check(be.lib.lina_cross_scores_softmax(_ptr(q_lin), _ptr(ln_w), _ptr(ln_b), float(ln_eps), _ptr(kk), _ptr(att),
+                                            att.stride(0), _ptr(attc), B, Tn, attc.shape[1], d, float(scale), _dt(q_lin),
+                                            be.stream(q_lin)))
+
+
+def softmax_weighted_rows_add(scores, scale, att, vv, x, x_packed=None):
+    """att[b,:Tn] = softmax(scores[b,:Tn] * scale);  x[b,:] += att[b,:] . vv[b]  -- softmax_rows + weighted_rows_add in
+    one launch.  With ``x_packed`` the residual stream is the fragment-major buffer (``x`` is not touched)."""
+    be = _BACKEND
+    be.require(scores, att, vv, x, x_packed)
+    B, Tn, d = vv.shape
+    if scores.dtype != vv.dtype or att.dtype != vv.dtype:
+        raise TypeError("scores / att / vv must share the model dtype")
+    _check(be.lib.lina_softmax_weighted_rows_add(_ptr(scores), scores.stride(0), float(scale), _ptr(att), att.stride(0),
+                                                 _ptr(vv), _ptr(x), _ptr(x_packed), B, Tn, d, _dt(vv), be.stream(vv)))
+
+
 def softmax_rows(x, scale, att, attc, Tn):
     """att[b,:Tn] = softmax(x[b,:Tn]*scale) into the strided `att` rows and the contiguous padded copy attc [B,Tp]."""
     be = _BACKEND

@@ -806,6 +806,41 @@ def check_cross_spread(dev, B, Tn, d, dtype):
     assert_close(x, c(x0) + torch.einsum("bt,btd->bd", c(attc[:, :Tn]), c(vv)), tol, "weighted rows add")
 
 
+def check_cross_fused(dev, B, Tn, d, dtype):
+    """Round-2 fusions of the cross-attention step vs the launches they replace: lina_cross_scores_softmax ==
+    cross_scores + softmax_rows (same arithmetic: bit-identical), lina_softmax_weighted_rows_add == softmax_rows +
+    weighted_rows_add (another reduction tree inside the softmax: 1 ulp of the model dtype), row-major and packed x."""
+    g = torch.Generator().manual_seed(29)
+    mk = lambda *s_: torch.randn(*s_, generator=g).to(dtype).to(dev)
+    q_lin, kk, vv = mk(B, d), mk(B, Tn, d), mk(B, Tn, d)
+    ln_w, ln_b = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype).to(dev), (0.1 * torch.randn(d, generator=g)).to(dtype).to(dev)
+    Tp = (Tn + 31) // 32 * 32
+    scale = d ** -0.5
+    scores = torch.empty(B, Tn, dtype=torch.float32, device=dev)
+    att_a = torch.zeros(B, 2, 1, Tn, dtype=dtype, device=dev)
+    attc_a = torch.full((B, Tp), float("nan"), dtype=dtype, device=dev)
+    ops.cross_scores(q_lin, ln_w, ln_b, 1e-5, kk, scores, scale)
+    ops.softmax_rows(scores, 1.0, att_a[:, 0, 0], attc_a, Tn)
+    att_b = torch.zeros_like(att_a)
+    attc_b = torch.full((B, Tp), float("nan"), dtype=dtype, device=dev)
+    ops.cross_scores_softmax(q_lin, ln_w, ln_b, 1e-5, kk, att_b[:, 0, 0], attc_b, scale)
+    assert torch.equal(att_a, att_b) and torch.equal(attc_a, attc_b), "fused scores + softmax differs"
+    sc2 = mk(B, Tp) * 3
+    x0 = mk(B, d)
+    x_a, x_b = x0.clone(), x0.clone()
+    ops.softmax_rows(sc2, scale, att_a[:, 1, 0], attc_a, Tn)
+    ops.weighted_rows_add(attc_a, vv, x_a)
+    ops.softmax_weighted_rows_add(sc2, scale, att_b[:, 1, 0], vv, x_b)
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    assert_close(att_b[:, 1, 0], att_a[:, 1, 0], tol, "fused softmax weights")
+    assert_close(x_b, x_a, tol, "fused softmax + weighted rows")
+    kq = 32 if dtype == torch.bfloat16 else 16
+    if d % kq == 0:
+        x_p = ops.pack_rows(x0)
+        ops.softmax_weighted_rows_add(sc2, scale, att_b[:, 1, 0], vv, x0.clone(), x_packed=x_p)
+        assert torch.equal(ops.unpack_rows(x_p, B, d), x_b), "packed residual form differs from the row-major one"
+
+
 def check_dwconv7_ln(dev, B, L, C, dtype, ada=False):
     """K8 vs the oracle (fp64 torch conv1d + layer_norm).  fp32 1e-5, bf16 2e-2 of max|ref|."""
     from oracle import vocoder_oracle as VO

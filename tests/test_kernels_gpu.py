@@ -307,3 +307,9 @@ def test_chunk_full_head_kernel_head_groups(hip, B, H, D, T, resets):
 @pytest.mark.parametrize("H,D,T,nseg", [(8, 128, 1024, 8), (16, 64, 300, 4)])
 def test_chunk_segment_parallel_head_groups(hip, H, D, T, nseg):
     check_chunk_segmented(DEV, B=1, H=H, T=T, nseg=nseg, resets=True, D=D)
+
+
+@pytest.mark.parametrize("B,Tn,d,dtype", [(64, 64, 1024, torch.bfloat16), (5, 100, 256, torch.float32), (64, 20, 1024, torch.float32)])
+def test_cross_attention_fusions(hip, B, Tn, d, dtype):
+    from kernel_cases import check_cross_fused
+    check_cross_fused(DEV, B, Tn, d, dtype)
