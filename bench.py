@@ -243,6 +243,38 @@ def measure_vocoder(dev, B=64, L=750, reps=3):
             "tokens_each": L, "ms": dt * 1e3, "codec_tokens_per_s": B * L / dt, "audio_seconds_per_s": B * L / 75.0 / dt}
 
 
+def measure_config3(eng, dev, B, L=750):
+    """BASELINE configs[2] as ONE pipeline: L greedy codec tokens for B utterances on the decode engine -> undelay_rvq - 3
+    (clamped) -> WavTokenizer-small decoder (random-init weights, bf16 backbone, fp32 ISTFT head) -> 24 kHz waveform
+    (reference model/modeling_lina.py:181-192 -> 3rdparty/decoder/pretrained.py:193-239); wall time of the whole chain."""
+    from lina_speech_amd.codec import undelay_rvq
+    from lina_speech_amd.vocoder import WavTokenizerDecoder
+    torch.manual_seed(0)
+    voc = WavTokenizerDecoder().eval().to(dev)
+    voc.backbone.to(torch.bfloat16)
+    voc.codebook.data = voc.codebook.data.to(torch.bfloat16)
+    bw = torch.zeros(1, dtype=torch.long, device=dev)
+
+    def run():
+        eng.begin_greedy(L)
+        eng.greedy_steps(L)
+        codes = (undelay_rvq(eng.greedy_tokens()) - 3).clamp_min(0)
+        return voc.head(voc.backbone(voc.codes_to_features(codes), bandwidth_id=bw).float())
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    audio = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_tok = audio.shape[1] // 320
+    assert audio.shape[0] == B and bool(torch.isfinite(audio).all())
+    del voc
+    return {"what": f"decode {L} tokens x {B} utterances -> undelay -> WavTokenizer decoder -> waveform, one chain",
+            "seconds": dt, "codec_tokens_per_s": B * L / dt, "audio_seconds_per_s": B * n_tok / 75.0 / dt,
+            "real_time_factor_per_utterance": (n_tok / 75.0) / dt}
+
+
 def cpu_baseline(model, seconds=15.0, B=8, max_steps=400):
     """The reference's pure-PyTorch recurrent path (mode='naive') restated in oracle/, timed on the host cores
     on a bounded sample of the same workload: same 166.7M weights (fp32), B=8 rows, T_txt=64, greedy."""
@@ -580,6 +612,7 @@ def main():
                 out["sampled_decode"] = {"k": 100, "temp": 1.0, "ms_per_step": (time.perf_counter() - ts0) / 50 * 1e3,
                                          "tokens_per_s": B * 50 / (time.perf_counter() - ts0)}
             if not args.no_chunk and world == 1:
+                out["config3_pipeline"] = measure_config3(eng, dev, B)
                 out["chunk_kernel"] = measure_chunk(dev)
                 for hh in (8, 16):                                   # the same width as 8 / 16 heads: 2 / 4 heads per workgroup
                     ck = measure_chunk(dev, B=64, H=hh, Dk=1024 // hh, Dv=1024 // hh, reps=100)

@@ -807,9 +807,9 @@ def check_cross_spread(dev, B, Tn, d, dtype):
 
 
 def check_cross_fused(dev, B, Tn, d, dtype):
-    """Round-2 fusions of the cross-attention step vs the launches they replace: lina_cross_scores_softmax ==
-    cross_scores + softmax_rows (same arithmetic: bit-identical), lina_softmax_weighted_rows_add == softmax_rows +
-    weighted_rows_add (another reduction tree inside the softmax: 1 ulp of the model dtype), row-major and packed x."""
+    """Round-2 fusions of the cross-attention step vs the launches they replace: lina_cross_scores_softmax vs
+    cross_scores + softmax_rows, lina_softmax_weighted_rows_add vs softmax_rows + weighted_rows_add (other reduction
+    trees inside the LayerNorm / softmax sums: fp32 1e-5, one ulp of bf16), row-major and packed x."""
     g = torch.Generator().manual_seed(29)
     mk = lambda *s_: torch.randn(*s_, generator=g).to(dtype).to(dev)
     q_lin, kk, vv = mk(B, d), mk(B, Tn, d), mk(B, Tn, d)
@@ -824,7 +824,11 @@ def check_cross_fused(dev, B, Tn, d, dtype):
     att_b = torch.zeros_like(att_a)
     attc_b = torch.full((B, Tp), float("nan"), dtype=dtype, device=dev)
     ops.cross_scores_softmax(q_lin, ln_w, ln_b, 1e-5, kk, att_b[:, 0, 0], attc_b, scale)
-    assert torch.equal(att_a, att_b) and torch.equal(attc_a, attc_b), "fused scores + softmax differs"
+    # the LayerNorm statistics are summed over 16 waves instead of 4: last-bit differences in fp32, none after bf16 rounding
+    tol0 = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    assert_close(att_b[:, 0, 0], att_a[:, 0, 0], tol0, "fused scores + softmax (att)")
+    assert_close(attc_b, attc_a, tol0, "fused scores + softmax (padded copy)")
+    assert float(attc_b[:, Tn:].abs().max()) == 0.0 if Tp > Tn else True
     sc2 = mk(B, Tp) * 3
     x0 = mk(B, d)
     x_a, x_b = x0.clone(), x0.clone()
