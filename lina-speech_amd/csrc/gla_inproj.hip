@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
         for (int u = 0; u < U; ++u) {
             const int64_t k0 = kstep_of(w, ks + u) * kstr;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[u][j].load(wp[j] + k0); else fb[u][j].zero(); }
+            for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[u][j].load_stream(wp[j] + k0); else fb[u][j].zero(); }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[u][mt].load(ap[mt] + k0); else fa[u][mt].zero(); }
         }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
         const int64_t k0 = kstep_of(w, ks) * kstr;
         F fb[NT], fa[MT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[j].load(wp[j] + k0); else fb[j].zero(); }
+        for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[j].load_stream(wp[j] + k0); else fb[j].zero(); }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[mt].load(ap[mt] + k0); else fa[mt].zero(); }
 #pragma unroll

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
         for (int u = 0; u < U; ++u) {
             const int64_t k0 = kstep_of(w, ks + u) * kstr;
 #pragma unroll
-            for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[u][g].load(wp[g] + k0); else fb[u][g].zero(); }
+            for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[u][g].load_stream(wp[g] + k0); else fb[u][g].zero(); }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[u][mt].load(ap[mt] + k0); else fa[u][mt].zero(); }
         }
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
         const int64_t k0 = kstep_of(w, ks) * kstr;
         F fb[G], fa[MT];
 #pragma unroll
-        for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[g].load(wp[g] + k0); else fb[g].zero(); }
+        for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[g].load_stream(wp[g] + k0); else fb[g].zero(); }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[mt].load(ap[mt] + k0); else fa[mt].zero(); }
 #pragma unroll

@@ -9,11 +9,24 @@ namespace lina {
 // split-K over the 4 waves of a workgroup: the i-th k-step of wave w (pairs of adjacent steps per wave)
 __device__ __forceinline__ int kstep_of(int w, int i) { return ((i >> 1) << 3) + 2 * w + (i & 1); }
 
+#ifndef LINA_SKINNY_W_NT
+#define LINA_SKINNY_W_NT 0      // experiment (tools/skinny_variants.sh): weight fragments with the non-temporal load hint
+#endif
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> {
     static constexpr int KSTEP = 32, KL = 8;  // k per step / k per lane
     uint4 v;
     __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+    // streamed operand (a weight fragment is read ONCE per launch): non-temporal hint
+    __device__ __forceinline__ void load_stream(const bf16_t* p) {
+#if LINA_SKINNY_W_NT
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        v = make_uint4(t[0], t[1], t[2], t[3]);
+#else
+        load(p);
+#endif
+    }
     __device__ __forceinline__ void zero() { v = make_uint4(0u, 0u, 0u, 0u); }
     __device__ __forceinline__ void ones() { v = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u); }
     __device__ __forceinline__ void stats(float& s1, float& s2) const {
@@ -33,6 +46,14 @@ template <> struct Frag<float> {
     static constexpr int KSTEP = 16, KL = 4;
     float4 v;
     __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void load_stream(const float* p) {
+#if LINA_SKINNY_W_NT
+        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+        v = make_float4(t[0], t[1], t[2], t[3]);
+#else
+        load(p);
+#endif
+    }
     __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ __forceinline__ void ones() { v = make_float4(1.f, 1.f, 1.f, 1.f); }
     __device__ __forceinline__ void stats(float& s1, float& s2) const {
