@@ -286,3 +286,29 @@ def test_l169_other_head_shapes_match_cpu_oracle(hip, heads, expand_v):
     safe = margins > 1e-3
     assert int(safe.sum()) >= B * n // 2, "too many near-ties for the comparison to mean anything"
     assert torch.equal(toks[0][safe], ref_toks[0][safe])
+
+
+def test_config5_train_step_at_sequence_length_4096(hip):
+    """BASELINE configs[4] at its sequence length (one rank's share, micro-batch 1): L169, 4096 codec tokens, bf16 autocast
+    -- K2 in its segment-parallel form, K2b, K3b, K5b, fused AdamW; with GRAD_CKPT the same loss (reference switch
+    model/gla.py:26-33).  The loss must be finite, reproducible under checkpointing and fall over three steps."""
+    import os
+    from lina_speech_amd import configs
+    from lina_speech_amd.train import TrainStep, synthetic_batch
+    batch = synthetic_batch(b=1, n=4097, t_txt=64, seed=3).to("cuda")
+    losses = {}
+    for ckpt in (False, True):
+        if ckpt:
+            os.environ["GRAD_CKPT"] = "1"
+        try:
+            torch.manual_seed(0)
+            ts = TrainStep(configs.l169(), device=torch.device("cuda", 0), lr=1e-3, ddp=False, n_warmup_steps=0, grad_clip=1.0)
+            losses[ckpt] = [float(ts.step(batch)) for _ in range(3)]
+            del ts
+            torch.cuda.empty_cache()
+        finally:
+            os.environ.pop("GRAD_CKPT", None)
+    for l in losses.values():
+        assert all(v == v and v < 1e4 for v in l), l
+        assert l[-1] < l[0], l
+    assert abs(losses[True][0] - losses[False][0]) < 1e-3 * abs(losses[False][0]), losses
