@@ -258,7 +258,10 @@ int lina_gla_decode_update_norm(const void* q, const void* k, const void* v, con
  *   out (row-major, may be NULL) and / or out_packed (packed copy, width out_packed_width >= N, whole k-steps);
  *   resid == out_packed (the same pointer): the residual is read from the packed buffer (in-place update of a
  *   residual stream that exists only in packed form).
- *   lina_gla_decode_inproj_packed = lina_gla_decode_inproj with packed x and w_in.  Same arithmetic, bit-identical. */
+ *   lina_gla_decode_inproj_packed = lina_gla_decode_inproj with packed x and w_in.  Same arithmetic, bit-identical.
+ *   in_packed bit 1 (value 2) / w_stream != 0: the WEIGHT fragments are loaded with the non-temporal hint -- a matrix
+ *   that is streamed this way does not displace the operands meant to stay in the 256 MB Infinity Cache between two
+ *   tokens (the decode engine streams the largest matrices and keeps the rest resident). */
 int lina_linear_skinny_ex(const void* A, int64_t lda, const void* W, int64_t ldw, int in_packed, int w_half_rows,
                           const float* c1, const float* c2, const void* resid, int64_t ldr, void* out, int64_t ldo,
                           void* out_packed, int out_packed_width, int M, int N, int K, int swiglu_hidden, int ln_dim,
@@ -267,7 +270,7 @@ int lina_gla_decode_inproj_packed(const void* x_packed, const void* w_in_packed,
                                   const void* wq, const void* wk, const void* wv, void* cq, void* ck, void* cv,
                                   const void* w2, const void* b2, void* qkv, void* g_out, float* gk, int B, int K,
                                   int Kd, int Vd, int W, int R, float ln_eps, float normalizer, float clamp_min,
-                                  int dtype, lina_stream_t stream);
+                                  int w_stream, int dtype, lina_stream_t stream);
 int lina_weighted_rows_add_packed(const void* attc, int Tp, const void* vv, void* x, void* x_packed, int B, int Tn, int d,
                                   int dtype, lina_stream_t stream);
 

@@ -23,9 +23,28 @@
 #include "lina_common.h"
 #include "skinny_frag.h"
 
+#ifndef LINA_K1W_HIST_NT
+#define LINA_K1W_HIST_NT 0     // experiment: window-history loads / stores with the non-temporal hint
+#endif
+
 namespace lina {
 
 constexpr int kWinMax = 8;
+
+__device__ __forceinline__ float ld_hist(const float* p) {
+#if LINA_K1W_HIST_NT
+    return ld_nt1(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_hist(float* p, float v) {
+#if LINA_K1W_HIST_NT
+    st_nt1(p, v);
+#else
+    *p = v;
+#endif
+}
 
 template <int DV, int NRB, int CS, typename TIO, typename TG>
 __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
@@ -79,8 +98,8 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
     if (row_wave) {
 #pragma unroll
         for (int s = 0; s < kWinMax; ++s) {
-            h1[s] = s < n_hist ? hist_c[(int64_t)s * BH * DK + hoff] : 0.0f;
-            h2[s] = s < n_hist ? hist_k[(int64_t)s * BH * DK + hoff] : 0.0f;
+            h1[s] = s < n_hist ? ld_hist(&hist_c[(int64_t)s * BH * DK + hoff]) : 0.0f;
+            h2[s] = s < n_hist ? ld_hist(&hist_k[(int64_t)s * BH * DK + hoff]) : 0.0f;
         }
         if (!flush_only) {
             gj = ld(gk + b * g_sb + h * g_sh + row);
@@ -89,7 +108,7 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
         }
     } else if (vc < DV) {
 #pragma unroll
-        for (int s = 0; s < kWinMax; ++s) h1[s] = s < n_hist ? hist_v[((int64_t)s * BH + bh) * DVT + col0 + vc] : 0.0f;
+        for (int s = 0; s < kWinMax; ++s) h1[s] = s < n_hist ? ld_hist(&hist_v[((int64_t)s * BH + bh) * DVT + col0 + vc]) : 0.0f;
         if (!flush_only) vj = ld(v + b * v_sb + h * v_sh + col0 + vc);
     }
 
@@ -110,8 +129,8 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
             for (int s = 0; s < kWinMax; ++s) cprev = (s == j - 1) ? h1[s] : cprev;
             cj = cprev + gj;
             if (CS == 1 || blockIdx.y == 0) {                            // the column halves compute the same values
-                hist_c[(int64_t)j * BH * DK + hoff] = cj;
-                hist_k[(int64_t)j * BH * DK + hoff] = kj;
+                st_hist(&hist_c[(int64_t)j * BH * DK + hoff], cj);
+                st_hist(&hist_k[(int64_t)j * BH * DK + hoff], kj);
             }
         }
         s_q[row] = qj;
@@ -132,7 +151,7 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
 #pragma unroll
             for (int s = 0; s < kWinMax; ++s)
                 if (s <= j) s_v[s][vc] = (!flush_only && s == j) ? vj : h1[s];
-            if (!flush_only) hist_v[((int64_t)j * BH + bh) * DVT + col0 + vc] = vj;
+            if (!flush_only) st_hist(&hist_v[((int64_t)j * BH + bh) * DVT + col0 + vc], vj);
         }
         for (int c = vc + NV; c < DV; c += NV) {            // only when Dv > 192 * Dk/64 (Dk = 64, Dv = 256)
             for (int s = 0; s <= j; ++s) {

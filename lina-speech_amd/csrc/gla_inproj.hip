@@ -14,14 +14,14 @@
 
 namespace lina {
 
-template <typename T, int NT, bool PK>
+template <typename T, int NT, bool PK, bool WNT>
 __global__ __launch_bounds__(256) void gla_inproj_kernel(
     const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw, const float* __restrict__ c1,
     const float* __restrict__ c2, const T* __restrict__ wq, const T* __restrict__ wk, const T* __restrict__ wv,
     T* cq, T* ck, T* cv, const T* __restrict__ w2, const T* __restrict__ b2, T* __restrict__ qkv,
     T* __restrict__ g_out, float* __restrict__ gk, int M, int K, int Kd, int Vd, float ln_eps, float inv_norm,
     float clamp_min, int has_clamp) {
-    using F = Frag<T>;
+    using F = Frag<T>;              // WNT: weight fragments with the non-temporal load hint
     constexpr int R = 16, MT = 4;
     constexpr int U = (NT + MT) * 8 <= 48 ? 8 : 4;
     __shared__ __attribute__((aligned(16))) float s_acc[4][NT * MT][64][4];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
         for (int u = 0; u < U; ++u) {
             const int64_t k0 = kstep_of(w, ks + u) * kstr;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[u][j].load_stream(wp[j] + k0); else fb[u][j].zero(); }
+            for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[u][j].template load_stream<WNT>(wp[j] + k0); else fb[u][j].zero(); }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[u][mt].load(ap[mt] + k0); else fa[u][mt].zero(); }
         }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
         const int64_t k0 = kstep_of(w, ks) * kstr;
         F fb[NT], fa[MT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[j].load_stream(wp[j] + k0); else fb[j].zero(); }
+        for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[j].template load_stream<WNT>(wp[j] + k0); else fb[j].zero(); }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[mt].load(ap[mt] + k0); else fa[mt].zero(); }
 #pragma unroll
@@ -241,7 +241,7 @@ static int inproj_impl(const void* x, int64_t ldx, const void* w_in, int64_t ldw
     if (W != 4 || R != 16) return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_inproj: needs conv width 4 and gate rank 16 (got %d, %d)", W, R);
     if (Kd <= 0 || Vd <= 0 || Kd % 16 || Vd % 16) return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_inproj: Kd,Vd must be positive multiples of 16");
     const int kstep = dtype == LINA_BF16 ? 32 : 16, al = dtype == LINA_BF16 ? 8 : 4;
-    LINA_REQUIRE(K % kstep == 0 && (packed || (ldx % al == 0 && ldw % al == 0)), "lina_gla_decode_inproj: K/ldx/ldw alignment");
+    LINA_REQUIRE(K % kstep == 0 && ((packed & 1) || (ldx % al == 0 && ldw % al == 0)), "lina_gla_decode_inproj: K/ldx/ldw alignment");
     LINA_REQUIRE(normalizer != 0.0f, "lina_gla_decode_inproj: normalizer must be non-zero");
     const int has_clamp = (clamp_min == clamp_min) ? 1 : 0;
     // 64 rows x 32 columns per workgroup when the q|k|v|g regions allow it (fewer, fatter workgroups: one per CU at
@@ -249,11 +249,16 @@ static int inproj_impl(const void* x, int64_t ldx, const void* w_in, int64_t ldw
     const bool wide = Kd % 32 == 0 && Vd % 32 == 0;
     const int cols = wide ? 32 : 16;
     dim3 grid((unsigned)((2 * Kd + 2 * Vd + Kd) / cols), (unsigned)((B + 63) / 64));
-#define LINA_INPROJ_PK(TT, NTT, PKK)                                                                                 \
-    LINA_LAUNCH((gla_inproj_kernel<TT, NTT, PKK>), grid, dim3(256), 0, stream, (const TT*)x, ldx, (const TT*)w_in, ldw, \
-                c1, c2, (const TT*)wq, (const TT*)wk, (const TT*)wv, (TT*)cq, (TT*)ck, (TT*)cv, (const TT*)w2,         \
+#define LINA_INPROJ_PK(TT, NTT, PKK, WNTT)                                                                           \
+    LINA_LAUNCH((gla_inproj_kernel<TT, NTT, PKK, WNTT>), grid, dim3(256), 0, stream, (const TT*)x, ldx, (const TT*)w_in, \
+                ldw, c1, c2, (const TT*)wq, (const TT*)wk, (const TT*)wv, (TT*)cq, (TT*)ck, (TT*)cv, (const TT*)w2,     \
                 (const TT*)b2, (TT*)qkv, (TT*)g_out, gk, B, K, Kd, Vd, ln_eps, 1.0f / normalizer, clamp_min, has_clamp)
-#define LINA_INPROJ(TT, NTT) do { if (packed) LINA_INPROJ_PK(TT, NTT, true); else LINA_INPROJ_PK(TT, NTT, false); } while (0)
+#define LINA_INPROJ(TT, NTT)                                                                                         \
+    do {                                                                                                             \
+        if (packed == 3) LINA_INPROJ_PK(TT, NTT, true, true);                                                        \
+        else if (packed & 1) LINA_INPROJ_PK(TT, NTT, true, false);                                                   \
+        else LINA_INPROJ_PK(TT, NTT, false, false);                                                                  \
+    } while (0)
     if (dtype == LINA_F32) { if (wide) LINA_INPROJ(float, 2); else LINA_INPROJ(float, 1); }
     else { if (wide) LINA_INPROJ(bf16_t, 2); else LINA_INPROJ(bf16_t, 1); }
 #undef LINA_INPROJ
@@ -274,7 +279,8 @@ extern "C" int lina_gla_decode_inproj_packed(const void* x_packed, const void* w
                                              const float* c2, const void* wq, const void* wk, const void* wv, void* cq,
                                              void* ck, void* cv, const void* w2, const void* b2, void* qkv, void* g_out,
                                              float* gk, int B, int K, int Kd, int Vd, int W, int R, float ln_eps,
-                                             float normalizer, float clamp_min, int dtype, lina_stream_t stream) {
-    return inproj_impl(x_packed, 0, w_in_packed, 0, 1, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_out, gk, B, K, Kd,
+                                             float normalizer, float clamp_min, int w_stream, int dtype,
+                                             lina_stream_t stream) {
+    return inproj_impl(x_packed, 0, w_in_packed, 0, w_stream ? 3 : 1, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_out, gk, B, K, Kd,
                        Vd, W, R, ln_eps, normalizer, clamp_min, dtype, stream);
 }

@@ -176,6 +176,14 @@ __device__ __forceinline__ float4 ld_nt4(const float* p) {
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
     return make_float4(v[0], v[1], v[2], v[3]);
 }
+// the same hint on one 16-byte piece of anything / on one float (streamed weights, window history)
+__device__ __forceinline__ uint4 ld_nt16(const void* p) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(t[0], t[1], t[2], t[3]);
+}
+__device__ __forceinline__ float ld_nt1(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_nt1(float* p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void st_nt4(float* p, float4 v) {
     f32x4 t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));

@@ -22,11 +22,12 @@
 
 namespace lina {
 
-template <typename T, bool SWIGLU, bool LN, int MT, int NT, bool PK>
+template <typename T, bool SWIGLU, bool LN, int MT, int NT, bool PK, bool WNT>
 __global__ __launch_bounds__(256) void linear_skinny_kernel(
     const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw, const float* __restrict__ c1,
     const float* __restrict__ c2, const T* resid, int64_t ldr, T* out, int64_t ldo, int M, int N, int K, int Hd,
     int ln_dim, float ln_eps, T* outp, int Kp, int Hp) {
+    // WNT: weight fragments with the non-temporal load hint (packed operands only)
     // PK: A and W are fragment-major (skinny_frag.h); Hp = padded rows per weight half.  outp (optional, any PK): a packed
     // copy of the output for the next projection, Kp = its padded width.
     using F = Frag<T>;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
         for (int u = 0; u < U; ++u) {
             const int64_t k0 = kstep_of(w, ks + u) * kstr;
 #pragma unroll
-            for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[u][g].load_stream(wp[g] + k0); else fb[u][g].zero(); }
+            for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[u][g].template load_stream<WNT>(wp[g] + k0); else fb[u][g].zero(); }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[u][mt].load(ap[mt] + k0); else fa[u][mt].zero(); }
         }
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
         const int64_t k0 = kstep_of(w, ks) * kstr;
         F fb[G], fa[MT];
 #pragma unroll
-        for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[g].load_stream(wp[g] + k0); else fb[g].zero(); }
+        for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[g].template load_stream<WNT>(wp[g] + k0); else fb[g].zero(); }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[mt].load(ap[mt] + k0); else fa[mt].zero(); }
 #pragma unroll
@@ -224,9 +225,9 @@ static int linear_skinny_impl(const void* A, int64_t lda, const void* W, int64_t
     LINA_REQUIRE(valid_dtype(dtype), "lina_linear_skinny: bad dtype %d", dtype);
     const int kstep = dtype == LINA_BF16 ? 32 : 16, al = dtype == LINA_BF16 ? 8 : 4;
     LINA_REQUIRE(K % kstep == 0, "lina_linear_skinny: K=%d must be a multiple of %d (pad the operands)", K, kstep);
-    LINA_REQUIRE(packed || (lda % al == 0 && ldw % al == 0), "lina_linear_skinny: lda/ldw must keep rows 16-byte aligned");
+    LINA_REQUIRE((packed & 1) || (lda % al == 0 && ldw % al == 0), "lina_linear_skinny: lda/ldw must keep rows 16-byte aligned");
     LINA_REQUIRE(!outp || (Kp > 0 && Kp % kstep == 0 && Kp >= N), "lina_linear_skinny: packed output width must be a multiple of %d and >= N", kstep);
-    LINA_REQUIRE(!packed || Hp % 64 == 0, "lina_linear_skinny: packed weights need rows padded to a multiple of 64");
+    LINA_REQUIRE(!(packed & 1) || Hp % 64 == 0, "lina_linear_skinny: packed weights need rows padded to a multiple of 64");
     LINA_REQUIRE(ln_dim >= 0 && (ln_dim == 0 || c1), "lina_linear_skinny: LayerNorm folding needs c1");
     LINA_REQUIRE(swiglu_hidden >= 0 && swiglu_hidden <= N, "lina_linear_skinny: bad swiglu_hidden");
     // Tiling.  Measured on MI355X (tools/perf_skinny2.py): one CU ingests only ~30 GB/s on this access pattern,
@@ -252,12 +253,16 @@ static int linear_skinny_impl(const void* A, int64_t lda, const void* W, int64_t
                 if (cand[c][0] == fm && cand[c][1] == fn) { best_mt = fm; best_nt = fn; }
     }
     dim3 grid((unsigned)((N + 16 * best_nt - 1) / (16 * best_nt)), (unsigned)((M + 16 * best_mt - 1) / (16 * best_mt)));
-#define LINA_LS_PK(TT, SW, LNN, MTT, NTT, PKK)                                                                     \
-    LINA_LAUNCH((linear_skinny_kernel<TT, SW, LNN, MTT, NTT, PKK>), grid, dim3(256), 0, stream, (const TT*)A, lda,  \
-                (const TT*)W, ldw, c1, c2, (const TT*)resid, ldr, (TT*)out, ldo, M, N, K, swiglu_hidden, ln_dim,    \
-                ln_eps, (TT*)outp, Kp, Hp)
+#define LINA_LS_PK(TT, SW, LNN, MTT, NTT, PKK, WNTT)                                                               \
+    LINA_LAUNCH((linear_skinny_kernel<TT, SW, LNN, MTT, NTT, PKK, WNTT>), grid, dim3(256), 0, stream, (const TT*)A, \
+                lda, (const TT*)W, ldw, c1, c2, (const TT*)resid, ldr, (TT*)out, ldo, M, N, K, swiglu_hidden,       \
+                ln_dim, ln_eps, (TT*)outp, Kp, Hp)
 #define LINA_LS_ONE(TT, SW, LNN, MTT, NTT)                                                                          \
-    do { if (packed) LINA_LS_PK(TT, SW, LNN, MTT, NTT, true); else LINA_LS_PK(TT, SW, LNN, MTT, NTT, false); } while (0)
+    do {                                                                                                            \
+        if (packed == 3) LINA_LS_PK(TT, SW, LNN, MTT, NTT, true, true);                                             \
+        else if (packed & 1) LINA_LS_PK(TT, SW, LNN, MTT, NTT, true, false);                                        \
+        else LINA_LS_PK(TT, SW, LNN, MTT, NTT, false, false);                                                       \
+    } while (0)
 #define LINA_LS(TT, SW, LNN)                                                                                        \
     do {                                                                                                            \
         if (best_nt == 1 && best_mt == 1) LINA_LS_ONE(TT, SW, LNN, 1, 1);                                           \
@@ -292,5 +297,5 @@ extern "C" int lina_linear_skinny_ex(const void* A, int64_t lda, const void* W, 
                                      void* out, int64_t ldo, void* out_packed, int out_packed_width, int M, int N, int K,
                                      int swiglu_hidden, int ln_dim, float ln_eps, int dtype, lina_stream_t stream) {
     return linear_skinny_impl(A, lda, W, ldw, c1, c2, resid, ldr, out, ldo, M, N, K, swiglu_hidden, ln_dim, ln_eps,
-                              in_packed ? 1 : 0, out_packed, out_packed_width, w_half_rows, dtype, stream);
+                              in_packed & 3, out_packed, out_packed_width, w_half_rows, dtype, stream);
 }

@@ -17,15 +17,13 @@ template <> struct Frag<bf16_t> {
     static constexpr int KSTEP = 32, KL = 8;  // k per step / k per lane
     uint4 v;
     __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
-    // streamed operand (a weight fragment is read ONCE per launch): non-temporal hint
+    // weight fragment, optionally with the non-temporal hint: a streamed weight matrix then does
+    // not displace the matrices that are meant to stay in the 256 MB Infinity Cache between two tokens
+    // (NT is a COMPILE-TIME choice: a launch-uniform runtime flag here cost the in-projection its load scheduling)
+    template <bool NT>
     __device__ __forceinline__ void load_stream(const bf16_t* p) {
-#if LINA_SKINNY_W_NT
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-        v = make_uint4(t[0], t[1], t[2], t[3]);
-#else
-        load(p);
-#endif
+        if constexpr (NT || LINA_SKINNY_W_NT) v = ld_nt16(p);
+        else load(p);
     }
     __device__ __forceinline__ void zero() { v = make_uint4(0u, 0u, 0u, 0u); }
     __device__ __forceinline__ void ones() { v = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u); }
@@ -46,13 +44,10 @@ template <> struct Frag<float> {
     static constexpr int KSTEP = 16, KL = 4;
     float4 v;
     __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    template <bool NT>
     __device__ __forceinline__ void load_stream(const float* p) {
-#if LINA_SKINNY_W_NT
-        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-        v = make_float4(t[0], t[1], t[2], t[3]);
-#else
-        load(p);
-#endif
+        if constexpr (NT || LINA_SKINNY_W_NT) v = ld_nt4(p);
+        else load(p);
     }
     __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ __forceinline__ void ones() { v = make_float4(1.f, 1.f, 1.f, 1.f); }

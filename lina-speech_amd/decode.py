@@ -173,6 +173,10 @@ class DecodeEngine:
         self._origin_host, self._n_done, self._lazy_live = 0, 0, False
         self._skip_update = False
         self._loop_packed = False
+        # which weight matrices of the device loop are STREAMED (non-temporal loads) instead of competing for the 256 MB
+        # Infinity Cache: per token the loop touches 0.87 GB of state (always streamed) + 0.26 GB of weights; streaming
+        # the largest matrices lets the others stay resident between two tokens.  LINA_DECODE_STREAM=in,up,...
+        self._stream = set(os.environ.get("LINA_DECODE_STREAM", "in,up").replace(" ", "").split(",")) - {""}
         blocks = list(rnn.encoder) + list(rnn.decoder) + [rnn.cross_att.pos_net]
         self.n_enc = len(rnn.encoder)
         ca = rnn.cross_att
@@ -224,7 +228,8 @@ class DecodeEngine:
         packed = x_p is not None
         if packed:
             ops.gla_decode_inproj_packed(x_p, P.w_in_p, B, P.d, P.c1_in, P.c2_in, P.wq, P.wk, P.wv, P.cq, P.ck, P.cv,
-                                         P.w2, P.b2, P.qkv, P.g, P.gk, P.n1_eps, P.normalizer, P.clamp_min)
+                                         P.w2, P.b2, P.qkv, P.g, P.gk, P.n1_eps, P.normalizer, P.clamp_min,
+                                         w_stream="in" in self._stream)
             gate = P.g.view(B, P.H, P.Dv)
         elif P.fused_in:
             ops.gla_decode_inproj(x, P.w_in, P.c1_in, P.c2_in, P.wq, P.wk, P.wv, P.cq, P.ck, P.cv, P.w2, P.b2,
@@ -257,12 +262,13 @@ class DecodeEngine:
             ops.rmsnorm_swish_gate(o.reshape(B, P.H, P.Dv), gate, P.gnw, P.eps_gate, out=P.og)
         if packed:
             # the residual stream lives in x_p only (read-modify-write there); the row-major x is stale inside the loop
-            ops.linear_skinny_packed(P.og_p, P.w_o_p, B, P.d, P.Vd, resid=x_p, out_packed=x_p, out_packed_width=P.d)
+            ops.linear_skinny_packed(P.og_p, P.w_o_p, B, P.d, P.Vd, resid=x_p, out_packed=x_p, out_packed_width=P.d,
+                                     w_stream="o" in self._stream)
             ops.linear_skinny_packed(x_p, P.w_up_p, B, P.hid_pad, P.d, P.c1_up, P.c2_up, out_packed=P.s_p,
                                      out_packed_width=P.hid_pad, swiglu_hidden=P.hid, ln_dim=P.d, ln_eps=P.n2_eps,
-                                     w_half_rows=P.up_half_rows)
+                                     w_half_rows=P.up_half_rows, w_stream="up" in self._stream)
             ops.linear_skinny_packed(P.s_p, P.w_down_p, B, P.d, P.hid_pad, resid=x_p, out_packed=x_p,
-                                     out_packed_width=P.d)
+                                     out_packed_width=P.d, w_stream="down" in self._stream)
             return x
         ops.linear_skinny(P.og.view(B, P.Vd), P.w_o, resid=x, out=x)
         ops.linear_skinny(x, P.w_up, P.c1_up, P.c2_up, out=P.s, swiglu_hidden=P.hid, ln_dim=P.d, ln_eps=P.n2_eps,
@@ -305,7 +311,7 @@ class DecodeEngine:
             self._block(x, P, lazy, x_p)
         if packed:
             ops.linear_skinny_packed(x_p, self.w_head_p, x.shape[0], self.Q * self.L, self.d,
-                                     out=self._logits[part.lo:part.hi])
+                                     out=self._logits[part.lo:part.hi], w_stream="head" in self._stream)
         else:
             ops.linear_skinny(x, self.w_head, out=self._logits[part.lo:part.hi])
 
@@ -387,6 +393,10 @@ class DecodeEngine:
             times.append(e0.elapsed_time(e1) * 1e-3 / reps)
         self._skip_update = False
         self._loop_packed = False
+        # which weight matrices of the device loop are STREAMED (non-temporal loads) instead of competing for the 256 MB
+        # Infinity Cache: per token the loop touches 0.87 GB of state (always streamed) + 0.26 GB of weights; streaming
+        # the largest matrices lets the others stay resident between two tokens.  LINA_DECODE_STREAM=in,up,...
+        self._stream = set(os.environ.get("LINA_DECODE_STREAM", "in,up").replace(" ", "").split(",")) - {""}
         self._restore(snap)
         for part, xk in zip(self.parts, x_keep):
             part.x.copy_(xk)

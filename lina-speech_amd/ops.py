@@ -643,7 +643,7 @@ def unpack_rows(p: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
 
 def linear_skinny_packed(a_packed, w_packed, M: int, N: int, K: int, c1=None, c2=None, resid=None, out=None,
                          out_packed=None, out_packed_width: int = 0, swiglu_hidden: int = 0, ln_dim: int = 0,
-                         ln_eps: float = 1e-5, w_half_rows: Optional[int] = None, dtype=None):
+                         ln_eps: float = 1e-5, w_half_rows: Optional[int] = None, dtype=None, w_stream: bool = False):
     """lina_linear_skinny_ex with fragment-major A [M,K] and W (pack_rows; for SwiGLU both weight halves packed
     separately and concatenated, ``w_half_rows`` = padded rows of one half).  ``out`` [M,N] row-major and / or
     ``out_packed`` (the packed A operand of the next projection, width ``out_packed_width`` >= N)."""
@@ -663,7 +663,7 @@ def linear_skinny_packed(a_packed, w_packed, M: int, N: int, K: int, c1=None, c2
         raise ValueError("packed W is too small")
     if out_packed is not None and out_packed.numel() < packed_numel(M, out_packed_width):
         raise ValueError("packed output buffer is too small")
-    _check(be.lib.lina_linear_skinny_ex(_ptr(a_packed), 0, _ptr(w_packed), 0, 1, int(half), _ptr(c1), _ptr(c2),
+    _check(be.lib.lina_linear_skinny_ex(_ptr(a_packed), 0, _ptr(w_packed), 0, 3 if w_stream else 1, int(half), _ptr(c1), _ptr(c2),
                                         _ptr(resid), 0 if (resid is None or resid.dim() < 2) else resid.stride(0), _ptr(out),
                                         0 if out is None else out.stride(0), _ptr(out_packed), int(out_packed_width),
                                         M, N, K, swiglu_hidden, ln_dim, float(ln_eps), _dt(a_packed),
@@ -720,7 +720,8 @@ def gla_decode_inproj(x, w_in, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_ou
 
 
 def gla_decode_inproj_packed(x_packed, w_in_packed, B, K, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_out, gk,
-                             ln_eps: float = 1e-5, normalizer: float = 16.0, clamp_min: Optional[float] = None):
+                             ln_eps: float = 1e-5, normalizer: float = 16.0, clamp_min: Optional[float] = None,
+                             w_stream: bool = False):
     """gla_decode_inproj with the block input and the fused projection weight in the fragment-major layout."""
     be = _BACKEND
     be.require(x_packed, w_in_packed, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_out, gk)
@@ -732,8 +733,8 @@ def gla_decode_inproj_packed(x_packed, w_in_packed, B, K, c1, c2, wq, wk, wv, cq
                                                 _ptr(wv), _ptr(cq), _ptr(ck), _ptr(cv), _ptr(w2), _ptr(b2), _ptr(qkv),
                                                 _ptr(g_out), _ptr(gk), B, K, Kd, Vd, W, R, float(ln_eps),
                                                 float(normalizer),
-                                                float("nan") if clamp_min is None else float(clamp_min), _dt(x_packed),
-                                                be.stream(x_packed)))
+                                                float("nan") if clamp_min is None else float(clamp_min),
+                                                1 if w_stream else 0, _dt(x_packed), be.stream(x_packed)))
 
 
 def gla_decode_update_norm(q, k, v, gk, o_part, state, gate, norm_weight, og, counters, eps: float = 1e-5, scale=None):

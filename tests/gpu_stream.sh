@@ -1,0 +1,7 @@
+cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+run() {  # lib, stream list
+  LINA_GLA_LIB=$1 LINA_DECODE_STREAM=$2 timeout 300 python bench.py --no-train --no-cpu-baseline --no-chunk 2>/dev/null | python -c "
+import json,sys; j=json.loads(sys.stdin.read()); print('lib=[$1] stream=[$2]', round(j['value']), round(j['ms_per_step'],4))"
+}
+for s in "none" "in" "in,up" "up,down" "in,up,down" "in,o" "in,head" "o,down"; do run "" "$s"; done
+for s in "in" "in,up" "up,down" "none"; do run tools/abl/liblina_histnt.so "$s"; done
