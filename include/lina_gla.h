@@ -109,6 +109,22 @@ int lina_gla_chunk_bwd(const void* q, const void* k, const void* v, const void* 
                        lina_bht_strides sdq, lina_bht_strides sdk, lina_bht_strides sdv, lina_bht_strides sdg,
                        int dtype, int g_dtype, float scale, lina_stream_t stream);
 
+/* K2b on the full-head kernel (bf16 tensors and gates, Dk = Dv in {64,128,256}, heads adjacent in memory for Dk < 256):
+ * the same contract and results as lina_gla_chunk_bwd, computed as three sweeps of K2's own kernel body
+ * (reverse key-gated sweep -> dv, dS; value-gated forward sweep -> dq; value-gated reverse sweep -> dk, dg), each sweep on
+ * all of nseg sequence segments concurrently from boundary states when nseg > 1 (small B*H).  Returns
+ * LINA_ERR_UNSUPPORTED for layouts the kernel does not take (call lina_gla_chunk_bwd then).
+ *   workspace: lina_gla_chunk_bwd_full_workspace(...) BYTES of fp32 scratch (boundary states, q (.) dq in fp32). */
+int64_t lina_gla_chunk_bwd_full_workspace(int B, int H, int T, int Dk, int Dv, int nseg);
+int lina_gla_chunk_bwd_full(const void* q, const void* k, const void* v, const void* gk, const void* d_o,
+                            const float* h0, const float* dht, const float* dg_tail,
+                            void* dq, void* dk, void* dv, void* dg, float* dh0, float* workspace, int nseg,
+                            int B, int H, int T, int Dk, int Dv,
+                            lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
+                            lina_bht_strides sg, lina_bht_strides sdo,
+                            lina_bht_strides sdq, lina_bht_strides sdk, lina_bht_strides sdv, lina_bht_strides sdg,
+                            int dtype, int g_dtype, float scale, lina_stream_t stream);
+
 /* K3 -- causal depthwise short convolution (+ optional SiLU), prefill form.
  * Replaces fla.modules.ShortConvolution.forward for T > 1 or cache == NULL
  * (ctor reference model/gla.py:106-108, calls :161-163).

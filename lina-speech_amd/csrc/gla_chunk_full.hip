@@ -68,12 +68,29 @@ __device__ __forceinline__ bf16x8 frag8x2(const bf16_t* p_lo, const bf16_t* p_hi
 // 64 x 64): in a [B,T,H,D] tensor the G heads of a group are one contiguous 512-byte row per token, so the DMA, phase A and
 // every tile are unchanged; the state is block-diagonal -- wave w belongs to head w / (16/G) and keeps only that head's
 // 16/G row tiles, the token contractions run over its head's channels only, mask(A) exists once per head.
-template <bool STATE_ONLY, int G>
+//
+// The same kernel body is the BACKWARD's three sweeps (K2b, lina_gla_chunk_bwd_full below):
+//   REV     the segment's tokens are visited last to first (row r of a chunk = token T-1-t0-r) and the gate of reversed
+//           row r is the gate of the token AFTER it in time (the decay between two tokens belongs to the later one), zero
+//           past the end of the sequence.  With (q,k,v) := (k,q,do) the forward body then yields dv and the state dS.
+//   MODE 1  "value-gated": the state is held TRANSPOSED (S'^T: rows = the contraction index of the sweep, columns = the
+//           gated channels c), out[t][c] = scale e^{b_t+R}[c] ( X_t . S'^T + mask(X Y^T) Z^ )[c],  S'^T += Y^T Z^,
+//           Z^ = Z e^{-b-R}: X, Y enter the MFMAs raw, Z is gated like k, and the gate factor is applied to the OUTPUT.
+//           (X,Y,Z) = (do,v,k) forward gives dq, (v,do,q) with REV gives dk.  The token columns of the products are
+//           permuted (column li of tile nt = token 2 li + nt) so that an output lane holds exactly the two tokens x four
+//           channels whose factors e^{b+R} it computed itself in phase A: nothing is exchanged.
+//   DG      1: also write d1 = aux (.) out (fp32; aux = q) ; 2: d = d1 - aux (.) out (aux = k), running sum of d over the
+//           visited tokens (+ carry[slot]) -> dg: with REV that is dg = reverse-cumsum(q dq - k dk), formed while dk is
+//           still fp32 in registers.
+template <bool STATE_ONLY, int G, int MODE = 0, bool REV = false, int DG = 0>
 __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ gk, bf16_t* __restrict__ o, const float* h0, float* ht, float* dec_out, int H,
     int T_total, int nseg, int Tseg, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
-    lina_bht_strides sg, lina_bht_strides so, float scale) {
+    lina_bht_strides sg, lina_bht_strides so, float scale, float h0_scale, const bf16_t* aux, lina_bht_strides saux,
+    float* d1, bf16_t* dg, lina_bht_strides sdg, const float* carry) {
+    static_assert(MODE == 0 || !STATE_ONLY, "the state-only pass exists in the key-gated form only");
+    static_assert(DG == 0 || MODE == 1, "dg is formed by the value-gated sweeps");
     constexpr int DK = 256, DV = 256, C = kFullC;       // the WORKGROUP's channel / column width: G heads of D each
     constexpr int D = 256 / G;                            // head dimension
     constexpr int NTL = 16 / G;                           // waves per head = state row tiles per wave
@@ -121,6 +138,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // barrier (2) fetches both (three dependent LDS round trips -- flag, flag, R -- sat in front of every wave's MFMAs)
     __shared__ __attribute__((aligned(8))) unsigned s_flags[4];
     __shared__ int s_cut;
+    __shared__ __attribute__((aligned(16))) float s_carry[DG == 2 ? DK : 4];   // DG 2: running sum of d per channel (wave-private quads)
 
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int w_s = wave_uniform(w);                         // wave index in an SGPR for the whole kernel
@@ -128,19 +146,30 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     const int slot = blockIdx.x;                             // state slot: (head group) * nseg + segment
     const int bh = (slot / nseg) * G, b = bh / H, h = bh % H;   // first head of the group (H % G == 0: one batch row)
     const int hw = w_s / NTL, wl = w_s % NTL;                // this wave's head inside the group, its index inside the head
-    const int t_begin = (slot % nseg) * Tseg;
+    const int seg_t = REV ? nseg - 1 - slot % nseg : slot % nseg;   // REV: slot order = visiting order = last segment first
+    const int t_begin = seg_t * Tseg;
     const int T = min(Tseg, T_total - t_begin);              // tokens of this segment (>= 1 by construction)
+    const bool rev_tail = REV && t_begin + T >= T_total;     // the first visited row has no later token: its gate is 0
 
     // ---- state: wave w owns columns [16w, 16w+16), tile p = rows [16p, 16p+16) ----
     f32x4 S[NTL];                                            // local tile p <-> rows [16p, 16p+16) of this wave's head
 #pragma unroll
     for (int p = 0; p < NTL; ++p) S[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (h0) {                                                // state slot layout [G][D][D] (G = 1: [256][256])
-        const float* hp = h0 + (((int64_t)slot * G + hw) * D + 4 * lg) * D + 16 * wl + li;
+        if constexpr (MODE == 1) {                           // transposed: tile element (row j, column c) = state[c][j]
+            const float* hp = h0 + (((int64_t)slot * G + hw) * D + 16 * wl + li) * D + 4 * lg;
 #pragma unroll
-        for (int p = 0; p < NTL; ++p)
+            for (int p = 0; p < NTL; ++p) {
+                const float4 t4 = *reinterpret_cast<const float4*>(hp + 16 * p);
+                S[p] = f32x4{t4.x * h0_scale, t4.y * h0_scale, t4.z * h0_scale, t4.w * h0_scale};
+            }
+        } else {
+            const float* hp = h0 + (((int64_t)slot * G + hw) * D + 4 * lg) * D + 16 * wl + li;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) S[p][r] = hp[(16 * p + r) * D];
+            for (int p = 0; p < NTL; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[p][r] = hp[(16 * p + r) * D] * h0_scale;
+        }
     }
 
     const bf16_t* gsrc[4] = {q + b * sq.b + h * sq.h + t_begin * sq.t, k + b * sk.b + h * sk.h + t_begin * sk.t,
@@ -157,6 +186,12 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // Rows past the end of the sequence re-read row T-1 (always mapped); phase A masks them.
     constexpr int kLoaders = LINA_K2_VAR == 2 ? 8 : LINA_K2_VAR == 3 ? 2 : 4;   // loader waves (experiment: 8 / 2)
     constexpr int kDmaWave0 = 16 - kLoaders, kPairsPer = 16 / kLoaders;
+    // memory row (relative to the segment's first token) of visited row tl <= T-1 of tensor a; REV: the gate (a == 2) of a
+    // visited row is the gate of the token after it, clamped to the sequence (the one row past it is zeroed in gate_scan)
+    auto src_row = [&](int a, int tl) -> unsigned {
+        if constexpr (!REV) return (unsigned)tl;
+        else return (unsigned)(a == 2 ? min(T - tl, T_total - 1 - t_begin) : T - 1 - tl);
+    };
     auto dma_chunk = [&](int t_first, int a_lo, int a_hi) {
         if (w < kDmaWave0) return;
 #pragma unroll
@@ -164,7 +199,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 #pragma unroll
             for (int j = 0; j < kPairsPer; ++j) {
                 const int pair = kPairsPer * (w - kDmaWave0) + j;
-                const unsigned t = (unsigned)min(t_first + 2 * pair + (lane >> 5), T - 1);
+                const unsigned t = src_row(a, min(t_first + 2 * pair + (lane >> 5), T - 1));
                 bf16_t* dst = a == 0 ? s_rq : a == 1 ? s_rk : a == 2 ? s_rg : s_rv;                 // a is a compile-time index
                 // uniform base + 32-bit BYTE offset per lane (< 2^32: launcher guard): selects the SGPR-base addressing form,
                 // no 64-bit per-lane address arithmetic (whose zero high word the compiler kept in -- and spilled from -- a VGPR)
@@ -179,6 +214,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // no cross-wave totals, no barrier, no serial prefix loop; the thread owns two ADJACENT tokens, so it writes
     // k~^T / v^T directly (4-byte pieces).
     int rp = lane & 15, ch0 = 16 * w + 4 * (lane >> 4);
+    bool gate_zero0 = rev_tail;                               // REV, first chunk of the sequence's last segment: row 0 has no gate
     // inclusive gate cumsum of this thread's 2 rows x 4 channels (rows >= nrem count as 0); true if the chunk's total
     // decay is too large for one chunk.  FULL: all C rows are in the sequence (no masks).
     auto gate_scan = [&](auto full_tag, float (&bc)[2][4], int nrem) {
@@ -192,6 +228,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         for (int c = 0; c < 4; ++c) {
             g0[c] = vmax_raw(g0[c], -kFullMaxDecay);
             g1[c] = vmax_raw(g1[c], -kFullMaxDecay);
+            if constexpr (REV) g0[c] = (gate_zero0 && rp == 0) ? 0.0f : g0[c];
             g1[c] = in1 ? g1[c] : 0.0f;
             bc[1][c] = (in0 ? g0[c] : 0.0f) + g1[c];         // the row pair's sum
         }
@@ -208,13 +245,18 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     };
     // rows >= nv are zeroed; the thread that owns row nv-1 publishes R after the chunk.  FULL: nv == C.
     // q~ carries NO 1/sqrt(Dk): the scale is applied to o (linear), one multiply per output instead of one per q element.
-    auto write_tiles = [&](auto full_tag, const float (&bc)[2][4], int nv, int par) {
+    // MODE 1: slot 0 (X) and slot 1 (Y) are copied raw, slot 3 (Z) is gated like k; X goes to tile row 16 rr + rp (token
+    // 2 rp + rr: the column permutation of the products, see the kernel header); Eo = the output factors e^{b+R} of this thread's
+    // two tokens x four channels.
+    auto write_tiles = [&](auto full_tag, const float (&bc)[2][4], int nv, int par, float (&Eo)[2][4]) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr float kLog2e = 1.4426950408889634f;
         uint2 kk[2], vv[2];                                   // packed k~ / v of the two rows, for the transposed pieces
         // column (element index) of this thread's channel quad in the q~ / k~ tiles: group w/2, piece c4 ^ ((row>>2)&3) =
         // c4 ^ ((rp>>1)&3) for both rows 2rp, 2rp+1, half w&1
         bf16_t* const qkp = &s_qk[2 * rp * SQ + 32 * (w >> 1) + 8 * ((lane >> 4) ^ ((rp >> 1) & 3)) + 4 * (w & 1)];
+        // MODE 1, X tile: rows rp and 16 + rp, piece c4 ^ ((row>>2)&3) = c4 ^ ((rp>>2)&3)
+        bf16_t* const xp = &s_qk[rp * SQ + 32 * (w >> 1) + 8 * ((lane >> 4) ^ ((rp >> 2) & 3)) + 4 * (w & 1)];
         const bf16_t* const rawp = &s_raw[rp * PE + ch0];
         const float4 R4 = *reinterpret_cast<const float4*>(&s_R[ch0]);
         const float Rc[4] = {R4.x, R4.y, R4.z, R4.w};
@@ -228,28 +270,43 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 x[c] = __builtin_fmaf(bc[rr][c], kLog2e, Rc[c]);   // (b + R) log2 e, one fma: |b| <= 60, |R| <= kRenorm + 60
                 e[c] = fast_exp2(x[c]);
             }
-            if constexpr (!STATE_ONLY) {
-                uint2 pq;
-                unpack4(*reinterpret_cast<const uint2*>(rawp + rr * DK), f);
-                pq.x = pack_bf16x2(f[0] * e[0], f[1] * e[1]);   // rows >= nv: finite values, zeroed as packed words
-                pq.y = pack_bf16x2(f[2] * e[2], f[3] * e[3]);
-                pq.x = valid ? pq.x : 0u;
-                pq.y = valid ? pq.y : 0u;
-                *reinterpret_cast<uint2*>(qkp + rr * SQ) = pq;
-            }
-            unpack4(*reinterpret_cast<const uint2*>(rawp + RAWT + rr * DK), f);
             // k e^{-b} = k * rcp(e^{b}): v_rcp_f32 (1 ulp) + multiply; `/` and __fdividef both expand to the ~10-instruction
             // IEEE division sequence here (160 VALU instructions per thread and chunk)
             float ri[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) ri[c] = fast_rcp(e[c]);
-            kk[rr].x = pack_bf16x2(f[0] * ri[0], f[1] * ri[1]);
-            kk[rr].y = pack_bf16x2(f[2] * ri[2], f[3] * ri[3]);
-            kk[rr].x = valid ? kk[rr].x : 0u;
-            kk[rr].y = valid ? kk[rr].y : 0u;
-            if constexpr (!STATE_ONLY) *reinterpret_cast<uint2*>(qkp + C * SQ + rr * SQ) = kk[rr];
-            const uint2 rv = *reinterpret_cast<const uint2*>(rawp + 3 * RAWT + rr * DK);
-            vv[rr] = valid ? rv : make_uint2(0u, 0u);
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Eo[rr][c] = e[c];
+                const uint2 rx = *reinterpret_cast<const uint2*>(rawp + rr * DK);
+                *reinterpret_cast<uint2*>(xp + 16 * rr * SQ) = valid ? rx : make_uint2(0u, 0u);
+                const uint2 ry = *reinterpret_cast<const uint2*>(rawp + RAWT + rr * DK);
+                kk[rr] = valid ? ry : make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(qkp + C * SQ + rr * SQ) = kk[rr];
+                unpack4(*reinterpret_cast<const uint2*>(rawp + 3 * RAWT + rr * DK), f);
+                vv[rr].x = pack_bf16x2(f[0] * ri[0], f[1] * ri[1]);
+                vv[rr].y = pack_bf16x2(f[2] * ri[2], f[3] * ri[3]);
+                vv[rr].x = valid ? vv[rr].x : 0u;
+                vv[rr].y = valid ? vv[rr].y : 0u;
+            } else {
+                if constexpr (!STATE_ONLY) {
+                    uint2 pq;
+                    unpack4(*reinterpret_cast<const uint2*>(rawp + rr * DK), f);
+                    pq.x = pack_bf16x2(f[0] * e[0], f[1] * e[1]);   // rows >= nv: finite values, zeroed as packed words
+                    pq.y = pack_bf16x2(f[2] * e[2], f[3] * e[3]);
+                    pq.x = valid ? pq.x : 0u;
+                    pq.y = valid ? pq.y : 0u;
+                    *reinterpret_cast<uint2*>(qkp + rr * SQ) = pq;
+                }
+                unpack4(*reinterpret_cast<const uint2*>(rawp + RAWT + rr * DK), f);
+                kk[rr].x = pack_bf16x2(f[0] * ri[0], f[1] * ri[1]);
+                kk[rr].y = pack_bf16x2(f[2] * ri[2], f[3] * ri[3]);
+                kk[rr].x = valid ? kk[rr].x : 0u;
+                kk[rr].y = valid ? kk[rr].y : 0u;
+                if constexpr (!STATE_ONLY) *reinterpret_cast<uint2*>(qkp + C * SQ + rr * SQ) = kk[rr];
+                const uint2 rv = *reinterpret_cast<const uint2*>(rawp + 3 * RAWT + rr * DK);
+                vv[rr] = valid ? rv : make_uint2(0u, 0u);
+            }
             if (FULL ? (rr == 1 && rp == C / 2 - 1) : (row == nv - 1)) {   // owner of the chunk's last row: R after the chunk
                 bool need = false;
 #pragma unroll
@@ -276,7 +333,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     auto dma_piece = [&](int t_first, int idx) {
         const int a = idx >> 2, j = idx & 3;
         const int pair = 4 * (w - kDmaWave0) + j;
-        const unsigned t = (unsigned)min(t_first + 2 * pair + (lane >> 5), T - 1);
+        const unsigned t = src_row(a, min(t_first + 2 * pair + (lane >> 5), T - 1));
         bf16_t* dst = a == 0 ? s_rq : a == 1 ? s_rk : a == 2 ? s_rg : s_rv;
         const unsigned boff = 2u * (t * gst[a] + 8u * (unsigned)(lane & 31));
         dma16_to_lds_async(gsrc[a], boff, &dst[pair * PE]);
@@ -285,6 +342,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     using PartT = std::false_type;
 
     for (int c = tid; c < DK; c += 1024) s_R[c] = 0.0f;
+    if constexpr (DG == 2)
+        for (int c = tid; c < DK; c += 1024) s_carry[c] = carry ? carry[(int64_t)slot * DK + c] : 0.0f;
     if (tid < 4) s_flags[tid] = 0;
     if (tid == 2) s_cut = 0;
     dma_chunk(0, STATE_ONLY ? 1 : 0, 4);
@@ -298,8 +357,29 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // staging, no read-back.  Issued at the end of the NEXT chunk's phase A: a store blocks its wave while the address unit
     // is busy, and right after barrier (3) all 32 of them queued up in front of phase A; a wave that finishes phase A early
     // stores while the others still compute.
+    // memory row (relative to the segment's first token) of visited row tl
+    auto out_row = [&](int tl) -> unsigned { return (unsigned)(REV ? T - 1 - tl : tl); };
+    float Ep[2][4];                                            // MODE 1: e^{b+R} of the PREVIOUS chunk's two tokens x four channels
+    uint2 auxr[2];                                             // DG: aux rows of the previous chunk's tokens (requested early)
+    float4 d1r[2];
+    const bf16_t* auxb = DG ? aux + b * saux.b + h * saux.h + t_begin * saux.t : nullptr;
+    bf16_t* dgb = DG == 2 ? dg + b * sdg.b + h * sdg.h + t_begin * sdg.t : nullptr;
+    // d1: dense fp32 [B][T_total][H/G][256]
+    float* d1b = DG ? d1 + (((int64_t)b * T_total + t_begin) * (H / G) + h / G) * DK : nullptr;
+    auto prefetch_prev = [&]() {                               // issued at the top of phase A, consumed by store_prev at its end
+        if constexpr (DG != 0) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const unsigned mr = out_row(min(tp + 2 * li + nt, T - 1));
+                auxr[nt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(auxb) +
+                                                           2u * (mr * (unsigned)saux.t + 16u * (unsigned)w + 4u * (unsigned)lg));
+                if constexpr (DG == 2)
+                    d1r[nt] = *reinterpret_cast<const float4*>(d1b + (int64_t)mr * (H / G) * DK + 16 * w + 4 * lg);
+            }
+        }
+    };
     auto store_prev = [&]() {
-        if constexpr (!STATE_ONLY) {
+        if constexpr (!STATE_ONLY && MODE == 0) {
 #pragma unroll
             for (int nt = 0; nt < (LINA_K2_ABL == 8 ? 0 : 2); ++nt) {
                 const int row = 16 * nt + li;
@@ -307,8 +387,63 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 po.x = pack_bf16x2(acc[nt][0] * scale, acc[nt][1] * scale);
                 po.y = pack_bf16x2(acc[nt][2] * scale, acc[nt][3] * scale);
                 if (row < np && LINA_K2_ABL != 7) {
-                    const unsigned boff = 2u * ((unsigned)(tp + row) * (unsigned)so.t + 16u * (unsigned)w + 4u * (unsigned)lg);
+                    const unsigned boff = 2u * (out_row(tp + row) * (unsigned)so.t + 16u * (unsigned)w + 4u * (unsigned)lg);
                     *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) + boff) = po;
+                }
+            }
+        }
+        if constexpr (MODE == 1) {
+            float ov[2][4], dd[2][4];                          // this lane: tokens 2 li + nt, channels 16 w + 4 lg + r
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const bool valid = 2 * li + nt < np;
+                float a4[4];
+                if constexpr (DG != 0) unpack4(auxr[nt], a4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ov[nt][r] = acc[nt][r] * (Ep[nt][r] * scale);
+                    if constexpr (DG == 1) dd[nt][r] = a4[r] * ov[nt][r];
+                    if constexpr (DG == 2) {
+                        const float d1v = r == 0 ? d1r[nt].x : r == 1 ? d1r[nt].y : r == 2 ? d1r[nt].z : d1r[nt].w;
+                        dd[nt][r] = valid ? d1v - a4[r] * ov[nt][r] : 0.0f;
+                    }
+                }
+                if (valid) {
+                    const unsigned mr = out_row(tp + 2 * li + nt);
+                    uint2 po;
+                    po.x = pack_bf16x2(ov[nt][0], ov[nt][1]);
+                    po.y = pack_bf16x2(ov[nt][2], ov[nt][3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) +
+                                              2u * (mr * (unsigned)so.t + 16u * (unsigned)w + 4u * (unsigned)lg)) = po;
+                    if constexpr (DG == 1)
+                        *reinterpret_cast<float4*>(d1b + (int64_t)mr * (H / G) * DK + 16 * w + 4 * lg) =
+                            make_float4(dd[nt][0], dd[nt][1], dd[nt][2], dd[nt][3]);
+                }
+            }
+            if constexpr (DG == 2) {
+                // running sum over the visited rows: pair sums, inclusive scan over the 16 row pairs (one 16-lane row per
+                // channel quad), + the carry of the earlier chunks; the last lane of the row publishes the new carry
+                float ps[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ps[r] = dd[0][r] + dd[1][r];
+                // (read before the scan: the scan is where the emulator's lanes meet, so no lane sees lane 15's new value)
+                const float4 c4v = *reinterpret_cast<const float4*>(&s_carry[16 * w + 4 * lg]);
+                row_scan4(ps[0], ps[1], ps[2], ps[3]);
+                const float cr[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
+                float g1v[4], g0v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { g1v[r] = cr[r] + ps[r]; g0v[r] = g1v[r] - dd[1][r]; }
+                if (li == 15) *reinterpret_cast<float4*>(&s_carry[16 * w + 4 * lg]) = make_float4(g1v[0], g1v[1], g1v[2], g1v[3]);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    if (2 * li + nt < np) {
+                        const unsigned mr = out_row(tp + 2 * li + nt);
+                        uint2 po;
+                        po.x = nt ? pack_bf16x2(g1v[0], g1v[1]) : pack_bf16x2(g0v[0], g0v[1]);
+                        po.y = nt ? pack_bf16x2(g1v[2], g1v[3]) : pack_bf16x2(g0v[2], g0v[3]);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(dgb) +
+                                                  2u * (mr * (unsigned)sdg.t + 16u * (unsigned)w + 4u * (unsigned)lg)) = po;
+                    }
                 }
             }
         }
@@ -326,18 +461,23 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         const int nrem = T - t0;
         int n = min(C, nrem);
         // ---------------- phase A: gate scan, scaled operands, transposed operands ----------------
+        // MODE 1: the previous chunk's output leaves BETWEEN the gate scan and the tile writes -- its accumulators, factors
+        // and the aux / d1 rows requested after barrier (3) are dead before the tile writes need their registers
+        float En[2][4];                                        // MODE 1: this chunk's output factors
         {
             float bc[2][4];
             if (nrem >= C) {                                   // workgroup-uniform: the mask-free form
                 if (gate_scan(FullT{}, bc, nrem)) s_flags[2 * par] = 1;
-                write_tiles(FullT{}, bc, C, par);
+                if (MODE == 1 && np > 0) store_prev();
+                write_tiles(FullT{}, bc, C, par, En);
             } else {
                 if (gate_scan(PartT{}, bc, nrem)) s_flags[2 * par] = 1;
-                write_tiles(PartT{}, bc, n, par);
+                if (MODE == 1 && np > 0) store_prev();
+                write_tiles(PartT{}, bc, n, par, En);
             }
         }
         K2_PROF(0);
-        if (np > 0) store_prev();
+        if (MODE == 0 && np > 0) store_prev();
         K2_PROF(10);
         __syncthreads();   // (2) operand tiles ready; raw q,k,g,v consumed
         K2_PROF(1);
@@ -363,7 +503,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             n = max(min(n, C - s_cut), 1);
             __syncthreads();   // everyone has read s_cut; the optimistic tiles are dead
             if (tid == 0) s_cut = 0;
-            write_tiles(PartT{}, bc, n, par);
+            write_tiles(PartT{}, bc, n, par, En);
             __syncthreads();
             fl.y = s_flags[2 * par + 1];                       // the rewritten tiles may have changed both
             rn = tid < DK ? s_Rn[tid] : 0.0f;
@@ -411,7 +551,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                     at[ks / (8 / G)] = mfma_bf16_16x16x32(kf[ks & 3], qf[ks & 3], at[ks / (8 / G)]);
                     sched_fence();
                 }
-                const int t = 16 * nt + li, sb = 16 * mt + 4 * lg;
+                const int t = MODE == 1 ? 2 * li + nt : 16 * nt + li, sb = 16 * mt + 4 * lg;   // MODE 1: permuted token columns
 #pragma unroll
                 for (int g2 = 0; g2 < G; ++g2) {
                     uint2 pa;
@@ -424,7 +564,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             K2_PROF(3);
         }
         const bf16_t* ktp = &s_kT[(16 * NTL * hw + li) * ST + 8 * lg];   // k~^T fragment of this head's state tile p: + 16 p ST
-        bf16x8 tf[8];                                          // ring of k~^T fragments, 5 tiles ahead
+        // ring of k~^T fragments, TA tiles ahead (MODE 1 carries its 8 output factors across this phase: a shallower ring
+        // instead of spills, whose reloads would wait on the loader waves' in-flight DMA)
+        constexpr int TA = MODE == 1 ? 3 : 5;
+        bf16x8 tf[8];
         bf16x8 vb2;                                            // v^T fragment of step (4) (tokens as k-slots 8lg..8lg+7)
         if constexpr (!STATE_ONLY && G > 1) {
             // (1) for G heads per workgroup: the same products over this head's NTL/2 tile pairs (channels
@@ -438,7 +581,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 for (int nt = 0; nt < 2; ++nt) qf[pp][nt] = frag16(qp + 16 * nt * SQ + 32 * pp);
             vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
 #pragma unroll
-            for (int p = 0; p < (NTL < 5 ? NTL : 5); ++p) tf[p] = frag16(ktp + 16 * p * ST);
+            for (int p = 0; p < (NTL < TA ? NTL : TA); ++p) tf[p] = frag16(ktp + 16 * p * ST);
             sched_fence();
 #pragma unroll
             for (int pp = 0; pp < NPP; ++pp) {
@@ -472,8 +615,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                     tf[1] = frag16(ktp + 16 * ST);
                     tf[2] = frag16(ktp + 32 * ST);
                 } else {
-                    tf[3] = frag16(ktp + 48 * ST);
-                    tf[4] = frag16(ktp + 64 * ST);
+                    if constexpr (TA > 3) {
+                        tf[3] = frag16(ktp + 48 * ST);
+                        tf[4] = frag16(ktp + 64 * ST);
+                    }
                 }
                 sched_fence();
                 bf16x8 bb;
@@ -494,18 +639,22 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         } else {
             vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
 #pragma unroll
-            for (int p = 0; p < (NTL < 5 ? NTL : 5); ++p) tf[p] = frag16(ktp + 16 * p * ST);
+            for (int p = 0; p < (NTL < TA ? NTL : TA); ++p) tf[p] = frag16(ktp + 16 * p * ST);
         }
         K2_PROF(4);
         // (4) S' += k^^T v
 #pragma unroll
         for (int p = 0; p < (LINA_K2_ABL == 4 ? 0 : NTL); ++p) {
-            if (p + 5 < NTL) tf[(p + 5) & 7] = frag16(ktp + 16 * (p + 5) * ST);
+            if (p + TA < NTL) tf[(p + TA) & 7] = frag16(ktp + 16 * (p + TA) * ST);
             sched_fence();
             S[p] = mfma_bf16_16x16x32(tf[p & 7], vb2, S[p]);
             sched_fence();
         }
-        if (renorm) {                                    // rare: S' <- e^{R} S' (R = s_Rn, the value after this chunk)
+        if (renorm && MODE == 1) {                       // rare: S'^T <- S'^T diag(e^{R}): the gated channel is the tile COLUMN
+            const float f = fast_exp2(s_Rn[16 * w + li]);
+#pragma unroll
+            for (int p = 0; p < NTL; ++p) { S[p][0] *= f; S[p][1] *= f; S[p][2] *= f; S[p][3] *= f; }
+        } else if (renorm) {                             // rare: S' <- e^{R} S' (R = s_Rn, the value after this chunk)
 #pragma unroll
             for (int p = 0; p < NTL; ++p) {
                 const float4 r4 = *reinterpret_cast<const float4*>(&s_Rn[16 * (NTL * hw + p) + 4 * lg]);
@@ -525,6 +674,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         K2_PROF(9);
         lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;   // re-derive, do not carry
         if (tid == 0) { s_flags[2 * par] = 0; s_flags[2 * par + 1] = 0; }   // read by all before (3); set again two chunks later, after (2) of the next
+        tp = t0; np = n;
+        if constexpr (DG != 0) prefetch_prev();                // aux / d1 rows of this chunk's tokens: in flight until the next phase A
         if constexpr (!STATE_ONLY) {
             // (3) o += mask(A) . v -- AFTER the barrier: no barrier of its own for mask(A); s_A is rewritten only after the
             //     next chunk's barrier (2)
@@ -532,9 +683,15 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             acc[1] = mfma_bf16_16x16x32(vb, frag16(&s_A[hw * 1024 + (1 * 64 + lane) * 8]), acc[1]);
             K2_PROF(7);
         }
-        tp = t0; np = n;
         par ^= 1;
         t0 += n;
+        if constexpr (REV) gate_zero0 = false;
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ep[nt][r] = En[nt][r];
+        }
     }
     lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
     store_prev();                                              // the last chunk (T >= 1)
@@ -567,6 +724,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 
 // true when the full-head kernel can take this call (16-byte aligned rows everywhere); D = 128 / 64: groups of 2 / 4 heads
 // per workgroup, which must be adjacent in memory (head stride == D, the [B,T,H,D] layout) and inside one batch row
+// kernel arguments that only the backward's sweeps use
+#define LINA_FWD_ONLY 1.0f, (const bf16_t*)nullptr, lina_bht_strides{}, (float*)nullptr, (bf16_t*)nullptr, lina_bht_strides{}, \
+                      (const float*)nullptr
+
 static bool full_ok(int H, int Dk, int Dv, int dtype, const void* q, const void* k, const void* v, const void* gk,
                     const void* o, int g_dtype, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
                     lina_bht_strides sg, lina_bht_strides so) {
@@ -598,7 +759,7 @@ int launch_chunk_full(const void* q, const void* k, const void* v, const void* g
 #define LINA_FULL(GG)                                                                                                  \
     LINA_LAUNCH((gla_chunk_bf16_h256_kernel<false, GG>), grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k, \
                 (const bf16_t*)v, (const bf16_t*)gk, (bf16_t*)o, h0, ht, (float*)nullptr, H, T, 1, T, sq, sk, sv, sg, so, \
-                scale)
+                scale, LINA_FWD_ONLY)
     if (G == 1) LINA_FULL(1); else if (G == 2) LINA_FULL(2); else LINA_FULL(4);
 #undef LINA_FULL
     return check_launch("lina_gla_chunk_fwd(full)");
@@ -615,18 +776,45 @@ int launch_chunk_full(const void* q, const void* k, const void* v, const void* g
 // ------------------------------------------------------------------------------------------------------------
 // A slot's state block is [G][D][D] = 256 * D floats (G = 256 / D heads side by side); row c of that block (0 <= c < 256)
 // decays by P[slot][c].
+// CARRY (the backward's reverse pass: slots in visiting order, s = 0 is the LAST segment of the sequence; S = dS / scale):
+// also the gate gradient that enters segment s from all later tokens, the telescoped form of reverse-cumsum(q dq - k dk):
+//     carry[slot][c] = scale e^{g_t[c]} sum_j S_{t-1}[c][j] dS_t[c][j],   t = first token after the segment
+// with S_{t-1} = SstartF of the following segment (forward pass) and dS_t = the state entering this slot; the last segment's
+// carry is dg_tail (the caller's sum_j final_state (.) dht) or 0.
+template <bool CARRY>
 __global__ __launch_bounds__(256) void gla_seg_combine_kernel(const float* __restrict__ L, const float* __restrict__ P,
-                                                              const float* h0, float* __restrict__ Sstart, float* ht,
-                                                              int nseg, int D) {
+                                                              const float* h0, float h0_scale, float* __restrict__ Sstart,
+                                                              float* ht, int nseg, int D, const float* __restrict__ SstartF,
+                                                              const bf16_t* __restrict__ gk, lina_bht_strides sg,
+                                                              const float* dg_tail, float* __restrict__ carry, int H,
+                                                              int Tseg, float scale) {
     constexpr int DK = 256;
     const int64_t blk = (int64_t)DK * D;                      // floats per slot
     const int bh = blockIdx.x;                                // head group
     const int e = (blockIdx.y * 256 + threadIdx.x) * 4;       // element of the slot's state block, 4 columns per thread
     const int c = e / D;
     float4 S = h0 ? *reinterpret_cast<const float4*>(h0 + (int64_t)bh * blk + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    S.x *= h0_scale; S.y *= h0_scale; S.z *= h0_scale; S.w *= h0_scale;
     for (int s = 0; s < nseg; ++s) {
         const int64_t slot = (int64_t)bh * nseg + s;
         *reinterpret_cast<float4*>(Sstart + slot * blk + e) = S;
+        if constexpr (CARRY) {
+            const bool lead = (e % D) == 0;                   // D/4 consecutive lanes hold one row
+            if (s == 0) {
+                if (lead) carry[slot * DK + c] = dg_tail ? dg_tail[(int64_t)bh * DK + c] : 0.0f;
+            } else {
+                const int seg_t = nseg - 1 - s;               // this slot's segment in time order; the next one starts at t
+                const float4 f = *reinterpret_cast<const float4*>(SstartF + ((int64_t)bh * nseg + seg_t + 1) * blk + e);
+                float dot = f.x * S.x + f.y * S.y + f.z * S.z + f.w * S.w;
+                for (int m = 1; m < D / 4; m <<= 1) dot += shfl_xor(dot, m);
+                if (lead) {
+                    const int G = DK / D, first = bh * G, t = (seg_t + 1) * Tseg;
+                    const float g = fmaxf(bf2f(gk[(int64_t)(first / H) * sg.b + (int64_t)(first % H + c / D) * sg.h +
+                                                 (int64_t)t * sg.t + c % D]), -kFullMaxDecay);
+                    carry[slot * DK + c] = scale * __expf(g) * dot;
+                }
+            }
+        }
         const float p = P[slot * DK + c];
         const float4 l = *reinterpret_cast<const float4*>(L + slot * blk + e);
         S.x = p * S.x + l.x; S.y = p * S.y + l.y; S.z = p * S.z + l.z; S.w = p * S.w + l.w;
@@ -666,15 +854,128 @@ extern "C" int lina_gla_chunk_fwd_seg(const void* q, const void* k, const void* 
 #define LINA_SEG(SO, GG, OO, H0, HT, PP)                                                                               \
     LINA_LAUNCH((gla_chunk_bf16_h256_kernel<SO, GG>), grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k,  \
                 (const bf16_t*)v, (const bf16_t*)gk, (bf16_t*)(OO), (const float*)(H0), (float*)(HT), (float*)(PP), H, T, \
-                ns, Tseg, sq, sk, sv, sg, so, scale)
+                ns, Tseg, sq, sk, sv, sg, so, scale, LINA_FWD_ONLY)
     if (G == 1) LINA_SEG(true, 1, nullptr, nullptr, L, P); else if (G == 2) LINA_SEG(true, 2, nullptr, nullptr, L, P);
     else LINA_SEG(true, 4, nullptr, nullptr, L, P);
-    LINA_LAUNCH(gla_seg_combine_kernel, dim3((unsigned)(B * H / G), (unsigned)(Dk / 4)), dim3(256), 0, stream,
-                (const float*)L, (const float*)P, h0, Sstart, ht, ns, Dk);
+    LINA_LAUNCH(gla_seg_combine_kernel<false>, dim3((unsigned)(B * H / G), (unsigned)(Dk / 4)), dim3(256), 0, stream,
+                (const float*)L, (const float*)P, h0, 1.0f, Sstart, ht, ns, Dk, (const float*)nullptr,
+                (const bf16_t*)nullptr, sg, (const float*)nullptr, (float*)nullptr, H, Tseg, scale);
     if (G == 1) LINA_SEG(false, 1, o, Sstart, nullptr, nullptr); else if (G == 2) LINA_SEG(false, 2, o, Sstart, nullptr, nullptr);
     else LINA_SEG(false, 4, o, Sstart, nullptr, nullptr);
 #undef LINA_SEG
     return check_launch("lina_gla_chunk_fwd_seg");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K2b on the full-head kernel (bf16, Dk = Dv in {64,128,256}): three sweeps of the body above, each at the forward's cost,
+//     V  (REV; q,k,v := k,q,do)            dv, dS            key-gated   = the forward kernel on the reversed sequence
+//     Q  (MODE 1; X,Y,Z := do,v,k)         dq, d1 = q dq     value-gated, state S^T
+//     K  (MODE 1, REV; X,Y,Z := v,do,q)    dk, dg            value-gated, state dS^T; dg = running sum of d1 - k dk
+// With nseg > 1 every sweep runs on all segments concurrently from boundary states: a state-only forward pass + combine
+// gives S at every segment start, a state-only reverse pass + combine gives dS at every segment end and the gate-gradient
+// carry of every segment (gla_seg_combine_kernel<true>).  The state is kept as dS / scale (the sweeps apply scale to
+// their outputs), so dht enters as dht / scale and dh0 leaves as scale e^{g_0} (.) state.
+// ------------------------------------------------------------------------------------------------------------
+namespace lina {
+// dh0[c][j] = scale e^{g_0[c]} R[c][j]  (R = the reverse sweep's end state: dS_0 / scale)
+__global__ __launch_bounds__(256) void gla_bwd_dh0_kernel(const float* __restrict__ R, const bf16_t* __restrict__ gk,
+                                                          lina_bht_strides sg, float* __restrict__ dh0, int H, int D,
+                                                          float scale) {
+    constexpr int DK = 256;
+    const int bh = blockIdx.x, G = DK / D, first = bh * G;
+    const int e = (blockIdx.y * 256 + threadIdx.x) * 4, c = e / D;
+    const float g = fmaxf(bf2f(gk[(int64_t)(first / H) * sg.b + (int64_t)(first % H + c / D) * sg.h + c % D]), -kFullMaxDecay);
+    const float f = scale * __expf(g);
+    const float4 r = *reinterpret_cast<const float4*>(R + (int64_t)bh * DK * D + e);
+    *reinterpret_cast<float4*>(dh0 + (int64_t)bh * DK * D + e) = make_float4(f * r.x, f * r.y, f * r.z, f * r.w);
+}
+}  // namespace lina
+
+static int64_t bwd_full_ws_floats(int B, int H, int T, int Dk, int nseg) {
+    const int64_t G = 256 / Dk, groups = (int64_t)B * H / G, slots = groups * nseg, blk = 256 * (int64_t)Dk;
+    // L | SstartF | SstartR | P | carry | end state of the reverse pass | d1
+    return 3 * slots * blk + 2 * slots * 256 + groups * blk + (int64_t)B * T * (H / G) * 256;
+}
+
+extern "C" int64_t lina_gla_chunk_bwd_full_workspace(int B, int H, int T, int Dk, int Dv, int nseg) {
+    if (B <= 0 || H <= 0 || T <= 0 || nseg <= 0 || Dk != Dv || (Dk != 64 && Dk != 128 && Dk != 256) || H % (256 / Dk)) return 0;
+    return (int64_t)sizeof(float) * bwd_full_ws_floats(B, H, T, Dk, nseg);
+}
+
+extern "C" int lina_gla_chunk_bwd_full(const void* q, const void* k, const void* v, const void* gk, const void* d_o,
+                                       const float* h0, const float* dht, const float* dg_tail, void* dq, void* dk,
+                                       void* dv, void* dg, float* dh0, float* workspace, int nseg, int B, int H, int T,
+                                       int Dk, int Dv, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
+                                       lina_bht_strides sg, lina_bht_strides sdo, lina_bht_strides sdq,
+                                       lina_bht_strides sdk, lina_bht_strides sdv, lina_bht_strides sdg, int dtype,
+                                       int g_dtype, float scale, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(q && k && v && gk && d_o && dq && dk && dv && dg && workspace, "lina_gla_chunk_bwd_full: null pointer");
+    LINA_REQUIRE(B > 0 && H > 0 && T > 0 && nseg >= 1, "lina_gla_chunk_bwd_full: B,H,T,nseg must be positive");
+    LINA_REQUIRE(scale != 0.0f, "lina_gla_chunk_bwd_full: scale must be non-zero");
+    LINA_REQUIRE(!dht == !dg_tail, "lina_gla_chunk_bwd_full: dht and dg_tail come together");
+    auto fits32 = [T](lina_bht_strides st) { return (int64_t)T * st.t < (1LL << 31); };
+    const bool ok = full_ok(H, Dk, Dv, dtype, q, k, v, gk, dv, g_dtype, sq, sk, sv, sg, sdv) &&
+                    full_ok(H, Dk, Dv, dtype, d_o, dq, dk, dg, dq, g_dtype, sdo, sdq, sdk, sdg, sdq) && fits32(sq) &&
+                    fits32(sk) && fits32(sv) && fits32(sg) && fits32(sdo) && fits32(sdq) && fits32(sdk) && fits32(sdv) &&
+                    fits32(sdg);
+    if (!ok)
+        return fail(LINA_ERR_UNSUPPORTED, "lina_gla_chunk_bwd_full: needs bf16 tensors and gates, Dk = Dv in {64,128,256}, "
+                                          "adjacent heads, 16-byte aligned rows (use lina_gla_chunk_bwd)");
+    const int G = 256 / Dk;
+    const int Tseg = ((T + nseg - 1) / nseg + kFullC - 1) / kFullC * kFullC;   // whole 32-token chunks per segment
+    const int ns = (T + Tseg - 1) / Tseg;
+    const int64_t groups = (int64_t)B * H / G, slots = groups * ns, blk = 256 * (int64_t)Dk;
+    float* L = workspace;
+    float* SF = L + slots * blk;
+    float* SR = SF + slots * blk;
+    float* P = SR + slots * blk;
+    float* carry = P + slots * 256;
+    float* endR = carry + slots * 256;
+    float* d1 = endR + groups * blk;
+    const float inv = 1.0f / scale;
+    const lina_bht_strides z{};
+    dim3 grid((unsigned)slots);
+    const bf16_t *Q = (const bf16_t*)q, *K = (const bf16_t*)k, *V = (const bf16_t*)v, *GK = (const bf16_t*)gk,
+                 *DO = (const bf16_t*)d_o;
+#define LINA_BW(SO, GG, MODE, REV, DGM, A0, A1, A3, OO, H0, HT, PP, S0, S1, S3, SOO, H0S, AUX, SAUX, CARRY)               \
+    LINA_LAUNCH((gla_chunk_bf16_h256_kernel<SO, GG, MODE, REV, DGM>), grid, dim3(1024), 0, stream, A0, A1, A3, GK,       \
+                (bf16_t*)(OO), (const float*)(H0), (float*)(HT), (float*)(PP), H, T, ns, Tseg, S0, S1, S3, sg, SOO, scale, \
+                H0S, (const bf16_t*)(AUX), SAUX, d1, (bf16_t*)dg, sdg, (const float*)(CARRY))
+#define LINA_BW_G(...)                                                                                                  \
+    do { if (G == 1) LINA_BW(__VA_ARGS__); } while (0)
+    const float* startF = h0;         // per-slot start states of sweep Q / of sweeps V, K
+    const float* startR = dht;
+    const float* carry_in = dg_tail;
+    float startR_scale = inv;
+    float* endV = dh0 ? endR : nullptr;
+#define LINA_BW_ALL(GG)                                                                                                 \
+    do {                                                                                                                \
+        if (ns > 1) {                                                                                                   \
+            LINA_BW(true, GG, 0, false, 0, Q, K, V, nullptr, nullptr, L, P, sq, sk, sv, z, 1.0f, nullptr, z, nullptr);  \
+            LINA_LAUNCH(gla_seg_combine_kernel<false>, dim3((unsigned)groups, (unsigned)(Dk / 4)), dim3(256), 0, stream, \
+                        (const float*)L, (const float*)P, h0, 1.0f, SF, (float*)nullptr, ns, Dk, (const float*)nullptr,  \
+                        (const bf16_t*)nullptr, sg, (const float*)nullptr, (float*)nullptr, H, Tseg, scale);            \
+            LINA_BW(true, GG, 0, true, 0, K, Q, DO, nullptr, nullptr, L, P, sk, sq, sdo, z, 1.0f, nullptr, z, nullptr); \
+            LINA_LAUNCH(gla_seg_combine_kernel<true>, dim3((unsigned)groups, (unsigned)(Dk / 4)), dim3(256), 0, stream,  \
+                        (const float*)L, (const float*)P, dht, inv, SR, dh0 ? endR : (float*)nullptr, ns, Dk,            \
+                        (const float*)SF, GK, sg, dg_tail, carry, H, Tseg, scale);                                      \
+            startF = SF; startR = SR; carry_in = carry; startR_scale = 1.0f; endV = nullptr;                            \
+        }                                                                                                               \
+        LINA_BW(false, GG, 0, true, 0, K, Q, DO, dv, startR, endV, nullptr, sk, sq, sdo, sdv, startR_scale, nullptr, z,  \
+                nullptr);                                                                                               \
+        LINA_BW(false, GG, 1, false, 1, DO, V, K, dq, startF, nullptr, nullptr, sdo, sv, sk, sdq, 1.0f, Q, sq, nullptr); \
+        LINA_BW(false, GG, 1, true, 2, V, DO, Q, dk, startR, nullptr, nullptr, sv, sdo, sq, sdk, startR_scale, K, sk,    \
+                carry_in);                                                                                              \
+    } while (0)
+    if (G == 1) LINA_BW_ALL(1); else if (G == 2) LINA_BW_ALL(2); else LINA_BW_ALL(4);
+#undef LINA_BW_ALL
+#undef LINA_BW_G
+#undef LINA_BW
+    if (dh0)
+        LINA_LAUNCH(gla_bwd_dh0_kernel, dim3((unsigned)groups, (unsigned)(Dk / 4)), dim3(256), 0, stream,
+                    (const float*)endR, GK, sg, dh0, H, Dk, scale);
+    return check_launch("lina_gla_chunk_bwd_full");
 }
 
 #ifdef LINA_K2_PROF

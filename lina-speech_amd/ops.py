@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -179,8 +180,10 @@ def chunk_segments(n_heads_total: int, T: int) -> int:
 
 
 def gla_chunk_bwd(q, k, v, gk, d_o, scale, initial_state=None, final_state=None, d_final_state=None,
-                  need_dh0=False):
-    """K2b through the C ABI (lina_gla_chunk_bwd): returns (dq, dk, dv, dg, dh0)."""
+                  need_dh0=False, nseg=None, path=None):
+    """K2b through the C ABI: returns (dq, dk, dv, dg, dh0).  bf16 tensors with Dk = Dv in {64,128,256} take the
+    full-head sweeps (lina_gla_chunk_bwd_full, ``nseg`` sequence segments); everything else -- and ``path="sweeps"`` /
+    LINA_K2B=sweeps -- the generic kernel (lina_gla_chunk_bwd)."""
     B, H, T, Dk = q.shape
     Dv = v.shape[-1]
     be = _BACKEND
@@ -201,6 +204,22 @@ def gla_chunk_bwd(q, k, v, gk, d_o, scale, initial_state=None, final_state=None,
     dv = _head_first_empty(B, H, T, Dv, q.dtype, q.device)
     dg = _head_first_empty(B, H, T, Dk, gk.dtype, q.device)
     dh0 = torch.empty(B, H, Dk, Dv, dtype=torch.float32, device=q.device) if need_dh0 else None
+    path = path or os.environ.get("LINA_K2B", "full")
+    full = (path == "full" and q.dtype == torch.bfloat16 and gk.dtype == torch.bfloat16 and Dk == Dv
+            and Dk in (64, 128, 256) and H % (256 // Dk) == 0)
+    if full:
+        v = _inner_contig(v)
+        ns = chunk_segments(B * H // (256 // Dk), T) if nseg is None else int(nseg)
+        ws = _workspace("k2b", int(be.lib.lina_gla_chunk_bwd_full_workspace(B, H, T, Dk, Dv, ns)), q.device)
+        rc = be.lib.lina_gla_chunk_bwd_full(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(d_o), _ptr(h0), _ptr(dht),
+                                            _ptr(dg_tail), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dg), _ptr(dh0), _ptr(ws),
+                                            ns, B, H, T, Dk, Dv, _bht(q), _bht(k), _bht(v), _bht(gk), _bht(d_o),
+                                            _bht(dq), _bht(dk), _bht(dv), _bht(dg), _dt(q), _dt(gk), float(scale),
+                                            be.stream(q))
+        if rc == 0:
+            return dq, dk, dv, dg, dh0
+        if rc != -2:                             # -2 = layout not eligible: the generic kernel below
+            _check(rc)
     nbytes = int(be.lib.lina_gla_chunk_bwd_workspace(B, H, T, Dk, Dv))
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
     _check(be.lib.lina_gla_chunk_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(d_o), _ptr(h0), _ptr(dht),

@@ -203,6 +203,41 @@ def check_chunk_bwd_long(dev, B, H, T, Dk, Dv, dtype, reset_every=512, with_h0=T
         assert_close(lh0.grad, rdh0, 1e-2 if dtype == torch.bfloat16 else 5e-4, f"K2b dh0 (T={T})")
 
 
+def check_chunk_bwd_full(dev, B, H, T, D, nseg, resets=False, with_h0=True, with_dht=True, seed=5):
+    """K2b on the full-head kernel (lina_gla_chunk_bwd_full: reverse sweep -> dv, value-gated sweeps -> dq / dk + dg, ``nseg``
+    sequence segments from boundary states) called directly, against torch autograd through the fp64 recurrent oracle.
+    bf16 I/O: 2e-2 of max|ref| per tensor (4e-2 for dg at T >= 2048, see check_chunk_bwd_long)."""
+    dtype = torch.bfloat16
+    q, k, v, gk, h0 = make_gla_inputs(B, H, T, D, D, dtype, dev, seed=seed, resets=resets)
+    if not with_h0:
+        h0 = None
+    g = torch.Generator().manual_seed(seed + 1)
+    d_o = torch.randn(B, T, H * D, generator=g).to(dtype).to(dev).view(B, T, H, D).transpose(1, 2)
+    d_ht = (torch.randn(B, H, D, D, generator=g) * 0.3).to(dev) if with_dht else None
+    scale = D ** -0.5
+    ht = None
+    if with_dht:
+        _, ht = ops.chunk_gla(q, k, v, gk, scale=scale, initial_state=h0, output_final_state=True)
+    dq, dk, dv, dg, dh0 = ops.gla_chunk_bwd(q, k, v, gk, d_o, scale, h0, ht, d_ht, need_dh0=with_h0, nseg=nseg,
+                                            path="full")
+    if T <= 512:
+        rl = [x.detach().cpu().to(F64).requires_grad_(True) for x in (q, k, v, gk)]
+        rh0 = None if h0 is None else h0.detach().cpu().to(F64).requires_grad_(True)
+        ro, rS = O.naive_recurrent_gla(*rl, initial_state=rh0, output_final_state=True, compute_dtype=F64)
+        rloss = (ro * d_o.cpu().to(F64)).sum()
+        if with_dht:
+            rloss = rloss + (rS * d_ht.cpu().to(F64)).sum()
+        rloss.backward()
+        refs, rdh0 = [x.grad for x in rl], None if rh0 is None else rh0.grad
+    else:
+        refs, rdh0, _ = oracle_gla_grads_long(q, k, v, gk, h0, d_o, d_ht)
+    tol_g = 4e-2 if T >= 2048 else 2e-2
+    for name, a, r in zip(("dq", "dk", "dv", "dg"), (dq, dk, dv, dg), refs):
+        assert_close(a, r, tol_g if name == "dg" else 2e-2, f"K2b(full, nseg={nseg}) {name}")
+    if h0 is not None:
+        assert_close(dh0, rdh0, 1e-2, f"K2b(full, nseg={nseg}) dh0")
+
+
 def check_chunk_simple(dev, B, H, T, Dk, Dv, dtype, with_h0=True):
     """ops.chunk_simple_gla (fla.ops.simple_gla.chunk_simple_gla, reference model/gla.py:22, simple_gla.py:135 via the
     fla layer): scalar log-gate per head g [B,H,T] -> K2 with the gate broadcast over Dk; vs the fp64 scalar-gate

@@ -5,7 +5,7 @@ import torch
 
 from oracle import gla_oracle as O
 from kernel_cases import (check_chunk_segmented, check_topk_sample, check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_rmsnorm_bwd, check_embed_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
-                          check_prologue, check_recurrent, check_rmsnorm, check_swiglu, check_chunk_simple)
+                          check_prologue, check_recurrent, check_rmsnorm, check_swiglu, check_chunk_simple, check_chunk_bwd_full)
 
 DEV = "cpu"
 
@@ -222,3 +222,21 @@ def test_chunk_segment_parallel_head_groups(emu, H, D, T, nseg):
 def test_cross_attention_fusions(emu, B, Tn, d, dtype):
     from kernel_cases import check_cross_fused
     check_cross_fused(DEV, B, Tn, d, dtype)
+
+
+# ----------------------------------------------------------------------------- K2b on the full-head kernel (three sweeps)
+@pytest.mark.parametrize("T,nseg,resets,h0,dht", [(40, 1, False, False, False), (33, 1, False, True, True),
+                                                   (70, 1, True, True, True), (100, 3, False, True, True),
+                                                   (96, 3, True, False, True), (33, 2, True, True, False)])
+def test_chunk_bwd_full_head_sweeps(emu, T, nseg, resets, h0, dht):
+    check_chunk_bwd_full(DEV, 1, 1, T, 256, nseg, resets=resets, with_h0=h0, with_dht=dht)
+
+
+@pytest.mark.parametrize("D,H,T,nseg", [(128, 2, 70, 1), (64, 4, 70, 2), (128, 4, 65, 2)])
+def test_chunk_bwd_full_head_sweeps_head_groups(emu, D, H, T, nseg):
+    check_chunk_bwd_full(DEV, 1, H, T, D, nseg, resets=True)
+
+
+def test_chunk_bwd_generic_kernel_still_reachable_for_bf16(emu, monkeypatch):
+    monkeypatch.setenv("LINA_K2B", "sweeps")
+    check_chunk_bwd(DEV, B=1, H=1, T=40, Dk=64, Dv=64, dtype=torch.bfloat16)

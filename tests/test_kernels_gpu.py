@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from kernel_cases import (check_chunk_segmented, check_topk_sample, assert_close, check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_embed_bwd, check_rmsnorm_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj,
+from kernel_cases import (check_chunk_bwd_full, check_chunk_segmented, check_topk_sample, assert_close, check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_embed_bwd, check_rmsnorm_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj,
                           check_linear_skinny, check_prologue, check_recurrent, check_rmsnorm, check_swiglu,
                           make_gla_inputs, oracle_gla)
 from lina_speech_amd import ops
@@ -171,6 +171,40 @@ def test_chunk_bwd_reset_gates(hip, dtype):
     check_chunk_bwd(DEV, B=2, H=2, T=70, Dk=128, Dv=64, dtype=dtype, resets=True)
     check_chunk_bwd(DEV, B=1, H=2, T=70, Dk=64, Dv=64, dtype=dtype, resets=True, with_h0=False, with_dht=False,
                     via="fused_chunk_gla")
+
+
+@pytest.mark.parametrize("T,nseg,resets,h0,dht", [(40, 1, False, False, False), (150, 1, True, True, True),
+                                                   (300, 4, True, True, True), (1000, 8, False, True, False)])
+def test_chunk_bwd_full_head_sweeps(hip, T, nseg, resets, h0, dht):
+    check_chunk_bwd_full(DEV, 2, 2, T, 256, nseg, resets=resets, with_h0=h0, with_dht=dht)
+
+
+@pytest.mark.parametrize("D,H,T,nseg", [(128, 2, 150, 1), (64, 4, 150, 2), (128, 4, 300, 4)])
+def test_chunk_bwd_full_head_sweeps_head_groups(hip, D, H, T, nseg):
+    check_chunk_bwd_full(DEV, 2, H, T, D, nseg, resets=True)
+
+
+@pytest.mark.parametrize("nseg", [1, 8])
+def test_chunk_bwd_full_head_sweeps_at_the_training_sequence_length(hip, nseg):
+    check_chunk_bwd_full(DEV, 1, 4, 4096, 256, nseg, resets=True, seed=43)
+
+
+def test_chunk_bwd_segments_agree_with_the_single_pass(hip):
+    # size-independent property at the training shape: the segment-parallel sweeps equal the one-segment sweeps
+    B, H, T, D = 2, 4, 4096, 256
+    q, k, v, gk, h0 = make_gla_inputs(B, H, T, D, D, torch.bfloat16, DEV, seed=19)
+    d_o = torch.randn(B, H, T, D, generator=torch.Generator().manual_seed(20)).to(torch.bfloat16).to(DEV)
+    a = ops.gla_chunk_bwd(q, k, v, gk, d_o, D ** -0.5, h0, need_dh0=True, nseg=1, path="full")
+    b = ops.gla_chunk_bwd(q, k, v, gk, d_o, D ** -0.5, h0, need_dh0=True, nseg=8, path="full")
+    for name, x, y in zip(("dq", "dk", "dv", "dg", "dh0"), a, b):
+        # dg: two differently-ordered suffix sums of cancelling bf16-noisy terms over 4096 tokens (see check_chunk_bwd_long)
+        assert_close(y.float(), x.float(), 4e-2 if name == "dg" else 2e-2, f"K2b segments vs single pass {name}")
+
+
+def test_chunk_bwd_generic_kernel_for_bf16(hip, monkeypatch):
+    monkeypatch.setenv("LINA_K2B", "sweeps")
+    check_chunk_bwd(DEV, B=2, H=2, T=150, Dk=256, Dv=256, dtype=torch.bfloat16)
+    check_chunk_bwd(DEV, B=2, H=2, T=70, Dk=64, Dv=64, dtype=torch.bfloat16, resets=True)
 
 
 def test_chunk_bwd_is_linear_in_the_output_gradient(hip):

@@ -15,7 +15,9 @@ q, k, v, do = mk(Dk), mk(Dk), mk(Dv), mk(Dv)
 gk = (torch.nn.functional.logsigmoid(torch.randn(B, T, H * Dk, generator=g)) / 16).to(torch.bfloat16).to(dev)
 gk = gk.view(B, T, H, Dk).transpose(1, 2)
 scale = Dk ** -0.5
-fn = lambda: ops.gla_chunk_bwd(q, k, v, gk, do, scale)
+PATH = os.environ.get("K2B_PATH", "full")                  # full | sweeps
+NSEG = os.environ.get("K2B_NSEG") or None                        # segments of the full-head sweeps (default: ops.chunk_segments)
+fn = lambda: ops.gla_chunk_bwd(q, k, v, gk, do, scale, nseg=None if NSEG is None else int(NSEG), path=PATH)
 fn()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -31,4 +33,4 @@ e1.record()
 torch.cuda.synchronize()
 dt = e0.elapsed_time(e1) * 1e-3 / reps
 nbytes = B * H * T * 2 * (5 * Dk + 4 * Dv)
-print(f"K2b B={B} T={T}: {dt*1e3:.3f} ms  {nbytes/dt/1e9:.1f} GB/s ({nbytes/dt/8e12*100:.1f}% of 8 TB/s)")
+print(f"K2b[{PATH},nseg={NSEG}] B={B} T={T}: {dt*1e3:.3f} ms  {nbytes/dt/1e9:.1f} GB/s ({nbytes/dt/8e12*100:.1f}% of 8 TB/s)")
