@@ -31,6 +31,9 @@
 #ifndef LINA_K2_VAR
 #define LINA_K2_VAR 0   // experiment switch (tools/k2_variants.sh): 1 = the loader waves interleave their DMAs with step (1)
 #endif
+#ifndef LINA_K2B_D1_F32
+#define LINA_K2B_D1_F32 0   // 1: q (.) dq travels between the value-gated sweeps as fp32 instead of bf16 (experiment switch)
+#endif
 #ifndef LINA_K2_ABL
 #define LINA_K2_ABL 0   // tools/k2_ablate.sh builds timing-only variants that skip one phase (results are WRONG there)
 #endif
@@ -359,13 +362,14 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // stores while the others still compute.
     // memory row (relative to the segment's first token) of visited row tl
     auto out_row = [&](int tl) -> unsigned { return (unsigned)(REV ? T - 1 - tl : tl); };
-    float Ep[2][4];                                            // MODE 1: e^{b+R} of the PREVIOUS chunk's two tokens x four channels
     uint2 auxr[2];                                             // DG: aux rows of the previous chunk's tokens (requested early)
-    float4 d1r[2];
+    using d1_t = std::conditional_t<LINA_K2B_D1_F32 != 0, float, bf16_t>;   // workspace element of q (.) dq
+    using d1v_t = std::conditional_t<LINA_K2B_D1_F32 != 0, float4, uint2>;  // four of them
+    d1v_t d1r[2];
     const bf16_t* auxb = DG ? aux + b * saux.b + h * saux.h + t_begin * saux.t : nullptr;
     bf16_t* dgb = DG == 2 ? dg + b * sdg.b + h * sdg.h + t_begin * sdg.t : nullptr;
     // d1: dense fp32 [B][T_total][H/G][256]
-    float* d1b = DG ? d1 + (((int64_t)b * T_total + t_begin) * (H / G) + h / G) * DK : nullptr;
+    d1_t* d1b = DG ? reinterpret_cast<d1_t*>(d1) + (((int64_t)b * T_total + t_begin) * (H / G) + h / G) * DK : nullptr;
     auto prefetch_prev = [&]() {                               // issued at the top of phase A, consumed by store_prev at its end
         if constexpr (DG != 0) {
 #pragma unroll
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 auxr[nt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(auxb) +
                                                            2u * (mr * (unsigned)saux.t + 16u * (unsigned)w + 4u * (unsigned)lg));
                 if constexpr (DG == 2)
-                    d1r[nt] = *reinterpret_cast<const float4*>(d1b + (int64_t)mr * (H / G) * DK + 16 * w + 4 * lg);
+                    d1r[nt] = *reinterpret_cast<const d1v_t*>(d1b + (int64_t)mr * (H / G) * DK + 16 * w + 4 * lg);
             }
         }
     };
@@ -397,15 +401,22 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const bool valid = 2 * li + nt < np;
-                float a4[4];
+                float a4[4], d4[4];
                 if constexpr (DG != 0) unpack4(auxr[nt], a4);
+                if constexpr (DG == 2) {
+                    if constexpr (LINA_K2B_D1_F32 != 0) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(&d1r[nt]);
+                        d4[0] = t4.x; d4[1] = t4.y; d4[2] = t4.z; d4[3] = t4.w;
+                    } else {
+                        unpack4(*reinterpret_cast<const uint2*>(&d1r[nt]), d4);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    ov[nt][r] = acc[nt][r] * (Ep[nt][r] * scale);
+                    ov[nt][r] = acc[nt][r];                    // already scaled by e^{b+R} / sqrt(Dk) (end of its iteration)
                     if constexpr (DG == 1) dd[nt][r] = a4[r] * ov[nt][r];
                     if constexpr (DG == 2) {
-                        const float d1v = r == 0 ? d1r[nt].x : r == 1 ? d1r[nt].y : r == 2 ? d1r[nt].z : d1r[nt].w;
-                        dd[nt][r] = valid ? d1v - a4[r] * ov[nt][r] : 0.0f;
+                        dd[nt][r] = valid ? d4[r] - a4[r] * ov[nt][r] : 0.0f;
                     }
                 }
                 if (valid) {
@@ -415,9 +426,14 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                     po.y = pack_bf16x2(ov[nt][2], ov[nt][3]);
                     *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) +
                                               2u * (mr * (unsigned)so.t + 16u * (unsigned)w + 4u * (unsigned)lg)) = po;
-                    if constexpr (DG == 1)
-                        *reinterpret_cast<float4*>(d1b + (int64_t)mr * (H / G) * DK + 16 * w + 4 * lg) =
-                            make_float4(dd[nt][0], dd[nt][1], dd[nt][2], dd[nt][3]);
+                    if constexpr (DG == 1) {
+                        d1_t* const dp = d1b + (int64_t)mr * (H / G) * DK + 16 * w + 4 * lg;
+                        if constexpr (LINA_K2B_D1_F32 != 0)
+                            *reinterpret_cast<float4*>(dp) = make_float4(dd[nt][0], dd[nt][1], dd[nt][2], dd[nt][3]);
+                        else
+                            *reinterpret_cast<uint2*>(dp) =
+                                make_uint2(pack_bf16x2(dd[nt][0], dd[nt][1]), pack_bf16x2(dd[nt][2], dd[nt][3]));
+                    }
                 }
             }
             if constexpr (DG == 2) {
@@ -597,21 +613,22 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         } else if constexpr (!STATE_ONLY) {
             // (1) o = q~ . S_old : one K = 32 MFMA per pair of 16-row state tiles (converted to bf16 in registers)
             const bf16_t* qp = &s_q[li * SQ + 8 * (lg ^ ((li >> 2) & 3))];
-            bf16x8 qf[4][2];                                   // ring, 3 tile pairs ahead
+            constexpr int QA = MODE == 1 ? 2 : 3;             // ring, QA tile pairs ahead (MODE 1: see TA)
+            bf16x8 qf[4][2];
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp)
+            for (int pp = 0; pp < QA; ++pp)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) qf[pp][nt] = frag16(qp + 16 * nt * SQ + 32 * pp);
 #pragma unroll
             for (int pp = 0; pp < (LINA_K2_ABL == 3 ? 0 : 8); ++pp) {
-                if (pp + 3 < 8) {
+                if (pp + QA < 8) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        qf[(pp + 3) & 3][nt] = frag16(qp + 16 * nt * SQ + 32 * (pp + 3));
-                } else if (pp == 5) {                          // the ring's free slots take step (4)'s first operands
+                        qf[(pp + QA) & 3][nt] = frag16(qp + 16 * nt * SQ + 32 * (pp + QA));
+                } else if (pp == 8 - QA) {                     // the ring's free slots take step (4)'s first operands
                     vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
                     tf[0] = frag16(ktp);
-                } else if (pp == 6) {
+                } else if (pp == 9 - QA) {
                     tf[1] = frag16(ktp + 16 * ST);
                     tf[2] = frag16(ktp + 32 * ST);
                 } else {
@@ -682,16 +699,16 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             acc[0] = mfma_bf16_16x16x32(vb, frag16(&s_A[hw * 1024 + (0 * 64 + lane) * 8]), acc[0]);   // o^T += v^T . mask(A)^T
             acc[1] = mfma_bf16_16x16x32(vb, frag16(&s_A[hw * 1024 + (1 * 64 + lane) * 8]), acc[1]);
             K2_PROF(7);
+            if constexpr (MODE == 1) {                         // the output factors die here, not in the next phase A
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[nt][r] *= En[nt][r] * scale;
+            }
         }
         par ^= 1;
         t0 += n;
         if constexpr (REV) gate_zero0 = false;
-        if constexpr (MODE == 1) {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Ep[nt][r] = En[nt][r];
-        }
     }
     lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
     store_prev();                                              // the last chunk (T >= 1)
