@@ -187,9 +187,18 @@ def measure_chunk_bwd(dev, B=8, H=4, T=4096, Dk=256, Dv=256, reps=100):
     gk = (torch.nn.functional.logsigmoid(torch.randn(B, T, H * Dk, generator=g)) / 16).to(torch.bfloat16).to(dev)
     gk = gk.view(B, T, H, Dk).transpose(1, 2)
     scale = Dk ** -0.5
-    dt, burst = sustained(lambda: ops.gla_chunk_bwd(q, k, v, gk, do, scale), warm_s=1.0, reps=reps)
+    nseg = ops.chunk_segments(B * H, T)
+    kept = []                    # as in a training step: the segment-parallel forward leaves its boundary states for the backward
+    if nseg > 1:
+        ops._gla_launch("lina_gla_chunk_fwd", q, k, v, gk, scale, None, False, nseg=nseg, keep_seg_states=kept)
+    seg_ws = kept[0][0] if kept else None
+    dt, burst = sustained(lambda: ops.gla_chunk_bwd(q, k, v, gk, do, scale, nseg=nseg, seg_states=seg_ws), warm_s=1.0,
+                          reps=reps)
     nbytes = B * H * T * 2 * (5 * Dk + 4 * Dv)
-    return {"kernel": "lina::gla_bwd_sweeps_kernel<256,256> + dg scan", "shape": {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv},
+    return {"kernel": "lina::gla_chunk_bf16_h256_kernel<MODE, REV, DG>: reverse sweep (dv, dS) + value-gated sweeps (dq | dk, dg)"
+                      + (f", {nseg} sequence segments from boundary states (forward's S, one state-only reverse pass for dS)"
+                         if nseg > 1 else ""),
+            "shape": {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv},
             "dtype": "bf16 I/O, bf16 MFMA, fp32 accumulate", "ms": dt * 1e3, "ms_burst_of_3": burst * 1e3, "bound": "hbm",
             "achieved": nbytes / dt / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS}
@@ -623,6 +632,7 @@ def main():
                 out["chunk_kernel_b8"] = small
                 out["vocoder"] = measure_vocoder(dev)
                 out["chunk_bwd_kernel"] = measure_chunk_bwd(dev)
+                out["chunk_bwd_kernel_b64"] = measure_chunk_bwd(dev, B=64, reps=20)   # one workgroup per head, no segments
     if rank == 0:
         if world == 1 and dtype == torch.bfloat16 and not args.no_chunk:
             # other head shapes of the same width (the 169M hyper-parameters are inferred)

@@ -80,7 +80,9 @@ int lina_gla_chunk_fwd(const void* q, const void* k, const void* v, const void* 
  * run concurrently (state-only pass, elementwise combine of the segment states, full pass) -- exact, nseg x the
  * workgroups of lina_gla_chunk_fwd.  bf16 tensors and gates, Dk = Dv = 256, 16-byte aligned rows only
  * (LINA_ERR_UNSUPPORTED otherwise: call lina_gla_chunk_fwd).
- *   workspace: fp32 scratch of lina_gla_chunk_fwd_seg_workspace(B, H, Dk, Dv, nseg) BYTES. */
+ *   workspace: fp32 scratch of lina_gla_chunk_fwd_seg_workspace(B, H, Dk, Dv, nseg) BYTES; after the call its head holds
+ *              the state at the start of every segment ([B*H*Dk/256][segments][256][Dk]), which lina_gla_chunk_bwd_full
+ *              accepts as seg_states. */
 int64_t lina_gla_chunk_fwd_seg_workspace(int B, int H, int Dk, int Dv, int nseg);
 int lina_gla_chunk_fwd_seg(const void* q, const void* k, const void* v, const void* gk, void* o,
                            const float* h0, float* ht, float* workspace, int nseg,
@@ -114,12 +116,14 @@ int lina_gla_chunk_bwd(const void* q, const void* k, const void* v, const void* 
  * (reverse key-gated sweep -> dv, dS; value-gated forward sweep -> dq; value-gated reverse sweep -> dk, dg), each sweep on
  * all of nseg sequence segments concurrently from boundary states when nseg > 1 (small B*H).  Returns
  * LINA_ERR_UNSUPPORTED for layouts the kernel does not take (call lina_gla_chunk_bwd then).
- *   workspace: lina_gla_chunk_bwd_full_workspace(...) BYTES of fp32 scratch (boundary states, q (.) dq in fp32). */
+ *   workspace: lina_gla_chunk_bwd_full_workspace(...) BYTES of fp32 scratch (boundary states, q (.) dq);
+ *   seg_states: NULL, or the segment start states that lina_gla_chunk_fwd_seg left at the head of ITS workspace for the
+ *               same inputs, T and nseg (the forward of this backward): the state-only forward pass is then skipped. */
 int64_t lina_gla_chunk_bwd_full_workspace(int B, int H, int T, int Dk, int Dv, int nseg);
 int lina_gla_chunk_bwd_full(const void* q, const void* k, const void* v, const void* gk, const void* d_o,
                             const float* h0, const float* dht, const float* dg_tail,
-                            void* dq, void* dk, void* dv, void* dg, float* dh0, float* workspace, int nseg,
-                            int B, int H, int T, int Dk, int Dv,
+                            void* dq, void* dk, void* dv, void* dg, float* dh0, float* workspace,
+                            const float* seg_states, int nseg, int B, int H, int T, int Dk, int Dv,
                             lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
                             lina_bht_strides sg, lina_bht_strides sdo,
                             lina_bht_strides sdq, lina_bht_strides sdk, lina_bht_strides sdv, lina_bht_strides sdg,

@@ -35,7 +35,7 @@ PROTOTYPES = {
     "lina_gla_chunk_bwd_workspace": (C.c_int64, [_i, _i, _i, _i, _i]),
     "lina_gla_chunk_bwd": (C.c_int, [_p] * 14 + [_i] * 5 + [BHT] * 9 + [_i, _i, _f, _p]),
     "lina_gla_chunk_bwd_full_workspace": (C.c_int64, [_i, _i, _i, _i, _i, _i]),
-    "lina_gla_chunk_bwd_full": (C.c_int, [_p] * 14 + [_i] * 6 + [BHT] * 9 + [_i, _i, _f, _p]),
+    "lina_gla_chunk_bwd_full": (C.c_int, [_p] * 15 + [_i] * 6 + [BHT] * 9 + [_i, _i, _f, _p]),
     "lina_short_conv_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _p]),
     "lina_short_conv_step": (C.c_int, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _i64, _i, _i, _p]),
     "lina_short_conv_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64,

@@ -799,8 +799,9 @@ int launch_chunk_full(const void* q, const void* k, const void* v, const void* g
 // with S_{t-1} = SstartF of the following segment (forward pass) and dS_t = the state entering this slot; the last segment's
 // carry is dg_tail (the caller's sum_j final_state (.) dht) or 0.
 template <bool CARRY>
-__global__ __launch_bounds__(256) void gla_seg_combine_kernel(const float* __restrict__ L, const float* __restrict__ P,
-                                                              const float* h0, float h0_scale, float* __restrict__ Sstart,
+// L and Sstart may be ONE buffer (every thread reads its element of L[slot] before it overwrites it with Sstart[slot]).
+__global__ __launch_bounds__(256) void gla_seg_combine_kernel(const float* L, const float* __restrict__ P,
+                                                              const float* h0, float h0_scale, float* Sstart,
                                                               float* ht, int nseg, int D, const float* __restrict__ SstartF,
                                                               const bf16_t* __restrict__ gk, lina_bht_strides sg,
                                                               const float* dg_tail, float* __restrict__ carry, int H,
@@ -814,6 +815,7 @@ __global__ __launch_bounds__(256) void gla_seg_combine_kernel(const float* __res
     S.x *= h0_scale; S.y *= h0_scale; S.z *= h0_scale; S.w *= h0_scale;
     for (int s = 0; s < nseg; ++s) {
         const int64_t slot = (int64_t)bh * nseg + s;
+        const float4 l = *reinterpret_cast<const float4*>(L + slot * blk + e);
         *reinterpret_cast<float4*>(Sstart + slot * blk + e) = S;
         if constexpr (CARRY) {
             const bool lead = (e % D) == 0;                   // D/4 consecutive lanes hold one row
@@ -833,7 +835,6 @@ __global__ __launch_bounds__(256) void gla_seg_combine_kernel(const float* __res
             }
         }
         const float p = P[slot * DK + c];
-        const float4 l = *reinterpret_cast<const float4*>(L + slot * blk + e);
         S.x = p * S.x + l.x; S.y = p * S.y + l.y; S.z = p * S.z + l.z; S.w = p * S.w + l.w;
     }
     if (ht) *reinterpret_cast<float4*>(ht + (int64_t)bh * blk + e) = S;
@@ -843,7 +844,7 @@ __global__ __launch_bounds__(256) void gla_seg_combine_kernel(const float* __res
 
 extern "C" int64_t lina_gla_chunk_fwd_seg_workspace(int B, int H, int Dk, int Dv, int nseg) {
     if (B <= 0 || H <= 0 || Dk <= 0 || Dv <= 0 || nseg <= 0) return 0;
-    return (int64_t)sizeof(float) * B * H * nseg * ((int64_t)2 * Dk * Dv + Dk);
+    return (int64_t)sizeof(float) * B * H * nseg * ((int64_t)Dk * Dv + Dk);
 }
 
 extern "C" int lina_gla_chunk_fwd_seg(const void* q, const void* k, const void* v, const void* gk, void* o,
@@ -864,8 +865,10 @@ extern "C" int lina_gla_chunk_fwd_seg(const void* q, const void* k, const void* 
     const int Tseg = ((T + nseg - 1) / nseg + kFullC - 1) / kFullC * kFullC;   // whole 32-token chunks per segment
     const int ns = (T + Tseg - 1) / Tseg;                                       // segments that hold tokens
     const int64_t slots = (int64_t)(B * H / G) * ns;          // one slot = G heads x one segment: 256 * Dk state floats
+    // workspace = [ states | decay products ]: the local end states of pass 1 become the segment START states in place, and
+    // stay there after the call -- lina_gla_chunk_bwd_full takes them as seg_states (same T and nseg) instead of recomputing
     float* L = workspace;
-    float* Sstart = L + slots * 256 * Dk;
+    float* Sstart = workspace;
     float* P = Sstart + slots * 256 * Dk;
     dim3 grid((unsigned)slots);
 #define LINA_SEG(SO, GG, OO, H0, HT, PP)                                                                               \
@@ -910,8 +913,8 @@ __global__ __launch_bounds__(256) void gla_bwd_dh0_kernel(const float* __restric
 
 static int64_t bwd_full_ws_floats(int B, int H, int T, int Dk, int nseg) {
     const int64_t G = 256 / Dk, groups = (int64_t)B * H / G, slots = groups * nseg, blk = 256 * (int64_t)Dk;
-    // L | SstartF | SstartR | P | carry | end state of the reverse pass | d1
-    return 3 * slots * blk + 2 * slots * 256 + groups * blk + (int64_t)B * T * (H / G) * 256;
+    // SstartF | SstartR | P | carry | end state of the reverse pass | d1
+    return 2 * slots * blk + 2 * slots * 256 + groups * blk + (int64_t)B * T * (H / G) * 256;
 }
 
 extern "C" int64_t lina_gla_chunk_bwd_full_workspace(int B, int H, int T, int Dk, int Dv, int nseg) {
@@ -921,7 +924,8 @@ extern "C" int64_t lina_gla_chunk_bwd_full_workspace(int B, int H, int T, int Dk
 
 extern "C" int lina_gla_chunk_bwd_full(const void* q, const void* k, const void* v, const void* gk, const void* d_o,
                                        const float* h0, const float* dht, const float* dg_tail, void* dq, void* dk,
-                                       void* dv, void* dg, float* dh0, float* workspace, int nseg, int B, int H, int T,
+                                       void* dv, void* dg, float* dh0, float* workspace, const float* seg_states,
+                                       int nseg, int B, int H, int T,
                                        int Dk, int Dv, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
                                        lina_bht_strides sg, lina_bht_strides sdo, lina_bht_strides sdq,
                                        lina_bht_strides sdk, lina_bht_strides sdv, lina_bht_strides sdg, int dtype,
@@ -943,8 +947,7 @@ extern "C" int lina_gla_chunk_bwd_full(const void* q, const void* k, const void*
     const int Tseg = ((T + nseg - 1) / nseg + kFullC - 1) / kFullC * kFullC;   // whole 32-token chunks per segment
     const int ns = (T + Tseg - 1) / Tseg;
     const int64_t groups = (int64_t)B * H / G, slots = groups * ns, blk = 256 * (int64_t)Dk;
-    float* L = workspace;
-    float* SF = L + slots * blk;
+    float* SF = workspace;            // local end states of a state-only pass, then the segment start states (in place)
     float* SR = SF + slots * blk;
     float* P = SR + slots * blk;
     float* carry = P + slots * 256;
@@ -969,15 +972,18 @@ extern "C" int lina_gla_chunk_bwd_full(const void* q, const void* k, const void*
 #define LINA_BW_ALL(GG)                                                                                                 \
     do {                                                                                                                \
         if (ns > 1) {                                                                                                   \
-            LINA_BW(true, GG, 0, false, 0, Q, K, V, nullptr, nullptr, L, P, sq, sk, sv, z, 1.0f, nullptr, z, nullptr);  \
-            LINA_LAUNCH(gla_seg_combine_kernel<false>, dim3((unsigned)groups, (unsigned)(Dk / 4)), dim3(256), 0, stream, \
-                        (const float*)L, (const float*)P, h0, 1.0f, SF, (float*)nullptr, ns, Dk, (const float*)nullptr,  \
-                        (const bf16_t*)nullptr, sg, (const float*)nullptr, (float*)nullptr, H, Tseg, scale);            \
-            LINA_BW(true, GG, 0, true, 0, K, Q, DO, nullptr, nullptr, L, P, sk, sq, sdo, z, 1.0f, nullptr, z, nullptr); \
+            if (!seg_states) {                                                                                          \
+                LINA_BW(true, GG, 0, false, 0, Q, K, V, nullptr, nullptr, SF, P, sq, sk, sv, z, 1.0f, nullptr, z, nullptr); \
+                LINA_LAUNCH(gla_seg_combine_kernel<false>, dim3((unsigned)groups, (unsigned)(Dk / 4)), dim3(256), 0, stream, \
+                            (const float*)SF, (const float*)P, h0, 1.0f, SF, (float*)nullptr, ns, Dk, (const float*)nullptr, \
+                            (const bf16_t*)nullptr, sg, (const float*)nullptr, (float*)nullptr, H, Tseg, scale);        \
+            }                                                                                                           \
+            const float* sf = seg_states ? seg_states : SF;                                                             \
+            LINA_BW(true, GG, 0, true, 0, K, Q, DO, nullptr, nullptr, SR, P, sk, sq, sdo, z, 1.0f, nullptr, z, nullptr); \
             LINA_LAUNCH(gla_seg_combine_kernel<true>, dim3((unsigned)groups, (unsigned)(Dk / 4)), dim3(256), 0, stream,  \
-                        (const float*)L, (const float*)P, dht, inv, SR, dh0 ? endR : (float*)nullptr, ns, Dk,            \
-                        (const float*)SF, GK, sg, dg_tail, carry, H, Tseg, scale);                                      \
-            startF = SF; startR = SR; carry_in = carry; startR_scale = 1.0f; endV = nullptr;                            \
+                        (const float*)SR, (const float*)P, dht, inv, SR, dh0 ? endR : (float*)nullptr, ns, Dk, sf, GK,   \
+                        sg, dg_tail, carry, H, Tseg, scale);                                                            \
+            startF = sf; startR = SR; carry_in = carry; startR_scale = 1.0f; endV = nullptr;                            \
         }                                                                                                               \
         LINA_BW(false, GG, 0, true, 0, K, Q, DO, dv, startR, endV, nullptr, sk, sq, sdo, sdv, startR_scale, nullptr, z,  \
                 nullptr);                                                                                               \

@@ -137,7 +137,10 @@ def _workspace(tag: str, nbytes: int, device) -> torch.Tensor:
     return ws
 
 
-def _gla_launch(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inplace_state=False, nseg=None):
+def _gla_launch(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inplace_state=False, nseg=None,
+                keep_seg_states: Optional[list] = None):
+    """``keep_seg_states``: a list that receives (workspace, nseg) when the segment-parallel kernel ran -- the workspace is
+    then a fresh tensor whose head holds the segment start states (the backward's seg_states), not the shared scratch."""
     B, H, T, Dk = q.shape
     Dv = v.shape[-1]
     be = _BACKEND
@@ -157,11 +160,15 @@ def _gla_launch(entry: str, q, k, v, gk, scale, initial_state, output_final_stat
         groups = 256 // Dk if full else 1                       # heads per workgroup of the full-head kernel
         nseg = chunk_segments(B * H // groups, T) if nseg is None else nseg
         if nseg > 1 and full and H % groups == 0:
-            ws = _workspace("k2seg", int(be.lib.lina_gla_chunk_fwd_seg_workspace(B, H, Dk, Dv, nseg)), q.device)
+            nbytes = int(be.lib.lina_gla_chunk_fwd_seg_workspace(B, H, Dk, Dv, nseg))
+            ws = (_workspace("k2seg", nbytes, q.device) if keep_seg_states is None
+                  else torch.empty(nbytes // 4, dtype=torch.float32, device=q.device))
             rc = be.lib.lina_gla_chunk_fwd_seg(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(o), _ptr(h0), _ptr(ht), _ptr(ws),
                                                nseg, B, H, T, Dk, Dv, _bht(q), _bht(k), _bht(v), _bht(gk), _bht(o),
                                                _dt(q), _dt(gk), scale, be.stream(q))
             if rc == 0:
+                if keep_seg_states is not None:
+                    keep_seg_states.append((ws, nseg))
                 return o, ht
             if rc != -2:                         # -2 = layout not eligible for the segmented kernel: use the plain one
                 _check(rc)
@@ -180,10 +187,11 @@ def chunk_segments(n_heads_total: int, T: int) -> int:
 
 
 def gla_chunk_bwd(q, k, v, gk, d_o, scale, initial_state=None, final_state=None, d_final_state=None,
-                  need_dh0=False, nseg=None, path=None):
+                  need_dh0=False, nseg=None, path=None, seg_states=None):
     """K2b through the C ABI: returns (dq, dk, dv, dg, dh0).  bf16 tensors with Dk = Dv in {64,128,256} take the
     full-head sweeps (lina_gla_chunk_bwd_full, ``nseg`` sequence segments); everything else -- and ``path="sweeps"`` /
-    LINA_K2B=sweeps -- the generic kernel (lina_gla_chunk_bwd)."""
+    LINA_K2B=sweeps -- the generic kernel (lina_gla_chunk_bwd).  ``seg_states``: the workspace the segment-parallel forward
+    left for the same inputs and ``nseg`` (its head holds the segment start states; skips one pass)."""
     B, H, T, Dk = q.shape
     Dv = v.shape[-1]
     be = _BACKEND
@@ -213,7 +221,7 @@ def gla_chunk_bwd(q, k, v, gk, d_o, scale, initial_state=None, final_state=None,
         ws = _workspace("k2b", int(be.lib.lina_gla_chunk_bwd_full_workspace(B, H, T, Dk, Dv, ns)), q.device)
         rc = be.lib.lina_gla_chunk_bwd_full(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(d_o), _ptr(h0), _ptr(dht),
                                             _ptr(dg_tail), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dg), _ptr(dh0), _ptr(ws),
-                                            ns, B, H, T, Dk, Dv, _bht(q), _bht(k), _bht(v), _bht(gk), _bht(d_o),
+                                            _ptr(seg_states if ns > 1 else None), ns, B, H, T, Dk, Dv, _bht(q), _bht(k), _bht(v), _bht(gk), _bht(d_o),
                                             _bht(dq), _bht(dk), _bht(dv), _bht(dg), _dt(q), _dt(gk), float(scale),
                                             be.stream(q))
         if rc == 0:
@@ -235,9 +243,12 @@ class _GLAFunction(torch.autograd.Function):
     the recurrence is the same and K2b recomputes the states chunk-wise."""
 
     @staticmethod
-    def forward(ctx, q, k, v, gk, scale, initial_state, output_final_state):
-        o, ht = _gla_launch("lina_gla_chunk_fwd", q, k, v, gk, scale, initial_state, output_final_state)
-        ctx.save_for_backward(q, k, v, gk, initial_state, ht)
+    def forward(ctx, q, k, v, gk, scale, initial_state, output_final_state, nseg=None):
+        kept: list = []
+        o, ht = _gla_launch("lina_gla_chunk_fwd", q, k, v, gk, scale, initial_state, output_final_state, nseg=nseg,
+                            keep_seg_states=kept)
+        seg_ws, ctx.nseg = kept[0] if kept else (None, nseg)
+        ctx.save_for_backward(q, k, v, gk, initial_state, ht, seg_ws)
         ctx.scale = scale
         ctx.need_dh0 = initial_state is not None and initial_state.requires_grad
         if ht is None:
@@ -246,14 +257,15 @@ class _GLAFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_o, d_ht):
-        q, k, v, gk, h0, ht = ctx.saved_tensors
+        q, k, v, gk, h0, ht, seg_ws = ctx.saved_tensors
         if d_o is None:                                   # only the final state was used downstream
             d_o = torch.zeros(q.shape[0], q.shape[2], q.shape[1], v.shape[-1], dtype=q.dtype,
                               device=q.device).transpose(1, 2)
-        dq, dk, dv, dg, dh0 = gla_chunk_bwd(q, k, v, gk, d_o, ctx.scale, h0, ht, d_ht, ctx.need_dh0)
+        dq, dk, dv, dg, dh0 = gla_chunk_bwd(q, k, v, gk, d_o, ctx.scale, h0, ht, d_ht, ctx.need_dh0, nseg=ctx.nseg,
+                                            seg_states=seg_ws)
         if dh0 is not None and h0 is not None and dh0.dtype != h0.dtype:
             dh0 = dh0.to(h0.dtype)
-        return dq, dk, dv, dg, None, dh0, None
+        return dq, dk, dv, dg, None, dh0, None, None
 
 
 def _needs_grad(*tensors) -> bool:
@@ -263,7 +275,7 @@ def _needs_grad(*tensors) -> bool:
 def _gla(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inplace_state=False, nseg=None):
     q, k, v, gk, scale = _gla_prepare(q, k, v, gk, scale, initial_state)
     if _needs_grad(q, k, v, gk, initial_state):
-        return _GLAFunction.apply(q, k, v, gk, scale, initial_state, bool(output_final_state))
+        return _GLAFunction.apply(q, k, v, gk, scale, initial_state, bool(output_final_state), nseg)
     return _gla_launch(entry, q, k, v, gk, scale, initial_state, output_final_state, inplace_state, nseg)
 
 

@@ -4,8 +4,10 @@ import pytest
 import torch
 
 from oracle import gla_oracle as O
-from kernel_cases import (check_chunk_segmented, check_topk_sample, check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_rmsnorm_bwd, check_embed_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
+from kernel_cases import (make_gla_inputs, check_chunk_segmented, check_topk_sample, check_argmax, check_chunk, check_chunk_bwd, check_conv_bwd, check_rmsnorm_bwd, check_embed_bwd, check_conv, check_cross_att, check_cross_spread, check_decode_update, check_decode_update_norm, check_embed, check_inproj, check_linear_skinny,
                           check_prologue, check_recurrent, check_rmsnorm, check_swiglu, check_chunk_simple, check_chunk_bwd_full)
+
+from lina_speech_amd import ops
 
 DEV = "cpu"
 
@@ -240,3 +242,16 @@ def test_chunk_bwd_full_head_sweeps_head_groups(emu, D, H, T, nseg):
 def test_chunk_bwd_generic_kernel_still_reachable_for_bf16(emu, monkeypatch):
     monkeypatch.setenv("LINA_K2B", "sweeps")
     check_chunk_bwd(DEV, B=1, H=1, T=40, Dk=64, Dv=64, dtype=torch.bfloat16)
+
+
+def test_chunk_autograd_hands_the_forward_segment_states_to_the_backward(emu):
+    # ops.chunk_gla under autograd with forced segments: the backward takes the forward's boundary states (seg_states)
+    B, H, T, D = 1, 1, 100, 256
+    q, k, v, gk, h0 = make_gla_inputs(B, H, T, D, D, torch.bfloat16, DEV, seed=12, resets=True)
+    d_o = torch.randn(B, H, T, D, generator=torch.Generator().manual_seed(13)).to(torch.bfloat16)
+    leaves = [x.detach().clone().requires_grad_(True) for x in (q, k, v, gk)]
+    o, _ = ops.chunk_gla(*leaves, initial_state=h0, nseg=3)
+    (o.float() * d_o.float()).sum().backward()
+    ref = ops.gla_chunk_bwd(q, k, v, gk, d_o, D ** -0.5, h0, nseg=3, path="full")      # recomputes the states itself
+    for name, a, r in zip(("dq", "dk", "dv", "dg"), leaves, ref):
+        assert torch.equal(a.grad, r), name

@@ -17,7 +17,12 @@ gk = gk.view(B, T, H, Dk).transpose(1, 2)
 scale = Dk ** -0.5
 PATH = os.environ.get("K2B_PATH", "full")                  # full | sweeps
 NSEG = os.environ.get("K2B_NSEG") or None                        # segments of the full-head sweeps (default: ops.chunk_segments)
-fn = lambda: ops.gla_chunk_bwd(q, k, v, gk, do, scale, nseg=None if NSEG is None else int(NSEG), path=PATH)
+nseg = ops.chunk_segments(B * H, T) if NSEG is None else int(NSEG)
+kept = []
+if PATH == "full" and nseg > 1 and os.environ.get("K2B_STATES", "1") != "0":   # as in training: the forward's boundary states
+    ops._gla_launch("lina_gla_chunk_fwd", q, k, v, gk, scale, None, False, nseg=nseg, keep_seg_states=kept)
+seg_ws = kept[0][0] if kept else None
+fn = lambda: ops.gla_chunk_bwd(q, k, v, gk, do, scale, nseg=nseg, path=PATH, seg_states=seg_ws)
 fn()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -33,4 +38,4 @@ e1.record()
 torch.cuda.synchronize()
 dt = e0.elapsed_time(e1) * 1e-3 / reps
 nbytes = B * H * T * 2 * (5 * Dk + 4 * Dv)
-print(f"K2b[{PATH},nseg={NSEG}] B={B} T={T}: {dt*1e3:.3f} ms  {nbytes/dt/1e9:.1f} GB/s ({nbytes/dt/8e12*100:.1f}% of 8 TB/s)")
+print(f"K2b[{PATH},nseg={nseg},fwd_states={seg_ws is not None}] B={B} T={T}: {dt*1e3:.3f} ms  {nbytes/dt/1e9:.1f} GB/s ({nbytes/dt/8e12*100:.1f}% of 8 TB/s)")
