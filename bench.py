@@ -162,7 +162,10 @@ def measure_chunk(dev, B=64, H=4, T=4096, Dk=256, Dv=256, reps=200):
     q, k, v = mk(Dk), mk(Dk), mk(Dv)
     gk = (torch.nn.functional.logsigmoid(torch.randn(B, T, H * Dk, generator=g)) / 16).to(torch.bfloat16).to(dev)
     gk = gk.view(B, T, H, Dk).transpose(1, 2)
-    dt, burst = sustained(lambda: ops.chunk_gla(q, k, v, gk, output_final_state=True), reps=reps)
+    # the training call (reference model/gla.py:193-195: output_final_state = use_cache = False); the prefill form that also
+    # returns the final state (67 MB more at B = 64, the shape of the committed PMC traffic figure) is timed beside it
+    dt, burst = sustained(lambda: ops.chunk_gla(q, k, v, gk, output_final_state=False), reps=reps)
+    dt_state, _ = sustained(lambda: ops.chunk_gla(q, k, v, gk, output_final_state=True), warm_s=0.5, reps=reps)
     nbytes = B * H * T * 2 * (3 * Dk + 2 * Dv)                       # e*(3Dk+2Dv) per (row,head,token)
     flops = B * H * T * (2 * 64 * (Dk + Dv) + 4 * Dk * Dv)            # nominal C=64 count of SURVEY 8(d)
     traffic, traffic_src = None, None
@@ -175,6 +178,8 @@ def measure_chunk(dev, B=64, H=4, T=4096, Dk=256, Dv=256, reps=200):
             "bytes_per_launch": nbytes, "traffic": traffic, "traffic_source": traffic_src,
             "dtype": "bf16", "ms": dt * 1e3, "ms_burst_of_3": burst * 1e3, "bound": "hbm", "achieved": nbytes / dt / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS, "tflops": flops / dt / 1e12,
+            "call": "output_final_state=False (the training call)",
+            "with_final_state": {"ms": dt_state * 1e3, "frac": nbytes / dt_state / 1e9 / HBM_PEAK_GBS},
             "tokens_per_s": B * T / dt, "timing": f"{reps} back-to-back launches after 1.5 s of the same (settled clock)"}
 
 
@@ -627,6 +632,9 @@ def main():
                     ck = measure_chunk(dev, B=64, H=hh, Dk=1024 // hh, Dv=1024 // hh, reps=100)
                     ck["kernel"] = f"lina::gla_chunk_bf16_h256_kernel<false, G={256 * hh // 1024}> ({256 * hh // 1024} heads per workgroup)"
                     out[f"chunk_kernel_h{hh}"] = ck
+                ck = measure_chunk(dev, B=64, H=4, Dk=256, Dv=512, reps=60)   # expand_v = 2: two 256-column blocks per head
+                ck["kernel"] = "lina::gla_chunk_bf16_h256_kernel<false, 1> x 2 (one launch per 256-column block of v / o)"
+                out["chunk_kernel_dv512"] = ck
                 small = measure_chunk(dev, B=8)                      # training micro-batch: segment-parallel form
                 small["kernel"] = "lina_gla_chunk_fwd_seg (state-only pass + combine + full pass, 8 segments)"
                 out["chunk_kernel_b8"] = small

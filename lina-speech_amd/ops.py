@@ -137,14 +137,39 @@ def _workspace(tag: str, nbytes: int, device) -> torch.Tensor:
     return ws
 
 
+def _value_blocks(q, v, gk) -> int:
+    """Dv = m * Dk with the L169 key width (``expand_v = 2``: 256 x 512 heads): the recurrence is independent per value
+    column, so the call runs as m calls of the full-head 256 x 256 kernel on column blocks of v / o / the states (same q, k,
+    g); the backward adds the blocks' dq, dk, dg.  Returns m (1 = no split)."""
+    Dk, Dv = q.shape[-1], v.shape[-1]
+    if q.dtype == torch.bfloat16 and gk.dtype == torch.bfloat16 and Dk == 256 and Dv > Dk and Dv % Dk == 0:
+        return Dv // Dk
+    return 1
+
+
 def _gla_launch(entry: str, q, k, v, gk, scale, initial_state, output_final_state, inplace_state=False, nseg=None,
-                keep_seg_states: Optional[list] = None):
+                keep_seg_states: Optional[list] = None, out: Optional[torch.Tensor] = None):
     """``keep_seg_states``: a list that receives (workspace, nseg) when the segment-parallel kernel ran -- the workspace is
     then a fresh tensor whose head holds the segment start states (the backward's seg_states), not the shared scratch."""
     B, H, T, Dk = q.shape
     Dv = v.shape[-1]
     be = _BACKEND
-    o = _head_first_empty(B, H, T, Dv, q.dtype, q.device)
+    m = _value_blocks(q, v, gk) if entry == "lina_gla_chunk_fwd" else 1
+    if m > 1:
+        o = _head_first_empty(B, H, T, Dv, q.dtype, q.device)
+        ht = torch.empty(B, H, Dk, Dv, dtype=torch.float32, device=q.device) if output_final_state else None
+        for j in range(m):
+            cols = slice(j * Dk, (j + 1) * Dk)
+            h0j = None if initial_state is None else initial_state[..., cols].float().contiguous()
+            _, htj = _gla_launch(entry, q, k, v[..., cols], gk, scale, h0j, output_final_state, False, nseg,
+                                 keep_seg_states, out=o[..., cols])
+            if ht is not None:
+                ht[..., cols] = htj
+        if inplace_state and ht is not None and initial_state is not None and initial_state.dtype == torch.float32:
+            initial_state.copy_(ht)
+            ht = initial_state
+        return o, ht
+    o = _head_first_empty(B, H, T, Dv, q.dtype, q.device) if out is None else out
     h0 = None
     if initial_state is not None:
         h0 = initial_state
@@ -196,6 +221,23 @@ def gla_chunk_bwd(q, k, v, gk, d_o, scale, initial_state=None, final_state=None,
     Dv = v.shape[-1]
     be = _BACKEND
     be.require(q, k, v, gk, d_o, initial_state, final_state, d_final_state)
+    m = _value_blocks(q, v, gk) if (path or os.environ.get("LINA_K2B", "full")) == "full" else 1
+    if m > 1:                                               # one 256 x 256 backward per value column block
+        dq = dk = dg = None
+        dvs, dh0s = [], []
+        states = list(seg_states) if isinstance(seg_states, (list, tuple)) else [None] * m
+        for j in range(m):
+            cols = slice(j * Dk, (j + 1) * Dk)
+            part = lambda t: None if t is None else t[..., cols].float().contiguous()
+            gq, gk_, gv, gg, gh = gla_chunk_bwd(q, k, v[..., cols], gk, d_o[..., cols], scale, part(initial_state),
+                                                part(final_state), part(d_final_state), need_dh0, nseg, path, states[j])
+            dq = gq.float() if dq is None else dq + gq.float()
+            dk = gk_.float() if dk is None else dk + gk_.float()
+            dg = gg.float() if dg is None else dg + gg.float()
+            dvs.append(gv)
+            dh0s.append(gh)
+        return (dq.to(q.dtype), dk.to(q.dtype), torch.cat(dvs, dim=-1), dg.to(gk.dtype),
+                torch.cat(dh0s, dim=-1) if need_dh0 else None)
     d_o = _inner_contig(d_o.to(q.dtype))
     if d_o.stride(0) % 4 or d_o.stride(1) % 4 or d_o.stride(2) % 4:
         d_o = d_o.contiguous()
@@ -247,8 +289,8 @@ class _GLAFunction(torch.autograd.Function):
         kept: list = []
         o, ht = _gla_launch("lina_gla_chunk_fwd", q, k, v, gk, scale, initial_state, output_final_state, nseg=nseg,
                             keep_seg_states=kept)
-        seg_ws, ctx.nseg = kept[0] if kept else (None, nseg)
-        ctx.save_for_backward(q, k, v, gk, initial_state, ht, seg_ws)
+        ctx.nseg = kept[0][1] if kept else nseg
+        ctx.save_for_backward(q, k, v, gk, initial_state, ht, *[ws for ws, _ in kept])   # one workspace per value block
         ctx.scale = scale
         ctx.need_dh0 = initial_state is not None and initial_state.requires_grad
         if ht is None:
@@ -257,7 +299,8 @@ class _GLAFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_o, d_ht):
-        q, k, v, gk, h0, ht, seg_ws = ctx.saved_tensors
+        q, k, v, gk, h0, ht, *seg_ws = ctx.saved_tensors
+        seg_ws = None if not seg_ws else (seg_ws[0] if len(seg_ws) == 1 else seg_ws)
         if d_o is None:                                   # only the final state was used downstream
             d_o = torch.zeros(q.shape[0], q.shape[2], q.shape[1], v.shape[-1], dtype=q.dtype,
                               device=q.device).transpose(1, 2)

@@ -255,3 +255,9 @@ def test_chunk_autograd_hands_the_forward_segment_states_to_the_backward(emu):
     ref = ops.gla_chunk_bwd(q, k, v, gk, d_o, D ** -0.5, h0, nseg=3, path="full")      # recomputes the states itself
     for name, a, r in zip(("dq", "dk", "dv", "dg"), leaves, ref):
         assert torch.equal(a.grad, r), name
+
+
+def test_chunk_and_its_backward_for_value_column_blocks(emu):
+    # expand_v = 2 heads (256 x 512): K2 / K2b run as two 256 x 256 calls on column blocks of v, o and the states
+    check_chunk(DEV, B=1, H=1, T=40, Dk=256, Dv=512, dtype=torch.bfloat16, resets=True)
+    check_chunk_bwd(DEV, B=1, H=1, T=40, Dk=256, Dv=512, dtype=torch.bfloat16, resets=True)

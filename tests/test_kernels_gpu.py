@@ -207,6 +207,14 @@ def test_chunk_bwd_generic_kernel_for_bf16(hip, monkeypatch):
     check_chunk_bwd(DEV, B=2, H=2, T=70, Dk=64, Dv=64, dtype=torch.bfloat16, resets=True)
 
 
+def test_chunk_and_its_backward_for_value_column_blocks(hip):
+    # expand_v = 2 heads (256 x 512): two full-head calls on column blocks; the long case also runs segment-parallel
+    check_chunk(DEV, B=2, H=2, T=300, Dk=256, Dv=512, dtype=torch.bfloat16, resets=True)
+    check_chunk_bwd(DEV, B=2, H=2, T=150, Dk=256, Dv=512, dtype=torch.bfloat16, resets=True)
+    from kernel_cases import check_chunk_bwd_long
+    check_chunk_bwd_long(DEV, B=1, H=2, T=2048, Dk=256, Dv=512, dtype=torch.bfloat16, reset_every=600)
+
+
 def test_chunk_bwd_is_linear_in_the_output_gradient(hip):
     # size-independent property at the training shape: grads(do1 + do2) == grads(do1) + grads(do2)
     B, H, T, D = 2, 4, 1024, 256

@@ -14,17 +14,26 @@ mk = lambda D: torch.randn(B, T, H * D, generator=g).to(torch.bfloat16).to(dev).
 q, k, v = mk(Dk), mk(Dk), mk(Dv)
 gk = (torch.nn.functional.logsigmoid(torch.randn(B, T, H * Dk, generator=g)) / 16).to(torch.bfloat16).to(dev)
 gk = gk.view(B, T, H, Dk).transpose(1, 2)
-ops.chunk_gla(q, k, v, gk, output_final_state=True)
+HT = os.environ.get("K2_HT", "1") != "0"                   # also return the final state (67 MB more at B = 64)
+NSEG = os.environ.get("K2_NSEG") or None
+run = lambda: ops.chunk_gla(q, k, v, gk, output_final_state=HT, nseg=None if NSEG is None else int(NSEG))
+run()
 torch.cuda.synchronize()
+if reps >= 100:                                            # settle the clocks first
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 1.5:
+        for _ in range(10):
+            run()
+        torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
-    ops.chunk_gla(q, k, v, gk, output_final_state=True)
+    run()
 e1.record()
 torch.cuda.synchronize()
 dt = e0.elapsed_time(e1) * 1e-3 / reps
 nbytes = B * H * T * 2 * (3 * Dk + 2 * Dv)
-print(f"K2 B={B} T={T}: {dt*1e3:.3f} ms  {nbytes/dt/1e9:.1f} GB/s ({nbytes/dt/8e12*100:.1f}% of 8 TB/s)  "
+print(f"K2[final_state={HT}] B={B} T={T}: {dt*1e3:.3f} ms  {nbytes/dt/1e9:.1f} GB/s ({nbytes/dt/8e12*100:.1f}% of 8 TB/s)  "
       f"{dt/(T/32)*2.4e9:.0f} clk/chunk @2.4GHz")
 if os.environ.get("K2_PROF"):
     import ctypes, numpy as np
