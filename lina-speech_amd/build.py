@@ -19,6 +19,30 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
 
+# Kernels that wait for their global->LDS DMA by COUNTING vector-memory operations (wait_vmem_but<N>: "all but the last N
+# loads"): a register spill the compiler adds would put scratch loads into that count, so these files must compile to
+# kernels without scratch -- checked from the compiler's own resource remarks at build time.
+NO_SCRATCH = {"gla_chunk_full.hip"}
+
+
+def _check_no_scratch(src: str, out: str) -> str:
+    """Fail the build if a kernel of ``src`` uses scratch; return the compiler output without the resource remarks."""
+    import re
+    name, keep, skip_note = None, [], 0
+    for line in out.splitlines():
+        if "-Rpass-analysis=kernel-resource-usage" in line or "remark:" in line:
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and int(m.group(1)) != 0:
+                raise RuntimeError(f"{os.path.basename(src)}: kernel {name} spills to scratch ({m.group(1)} bytes/lane); "
+                                   "its DMA wait counts vector-memory operations -- reduce register pressure")
+            continue
+        keep.append(line)
+    return "\n".join(keep)
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
@@ -40,11 +64,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in sources():
         obj = src[:-4] + ".o"
         cmd = [HIPCC, *[f for f in FLAGS if f != "-shared"], "-I", CSRC, "-c", src, "-o", obj]
+        if os.path.basename(src) in NO_SCRATCH:
+            cmd.append("-Rpass-analysis=kernel-resource-usage")
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
     bad = False
     for src, p in procs:
         out, _ = p.communicate()
+        if os.path.basename(src) in NO_SCRATCH:
+            out = _check_no_scratch(src, out)
         if p.returncode != 0 or (verbose and out.strip()):
             sys.stderr.write(f"--- hipcc {os.path.basename(src)}\n{out}\n")
         bad |= p.returncode != 0

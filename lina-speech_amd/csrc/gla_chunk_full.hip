@@ -370,6 +370,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     bf16_t* dgb = DG == 2 ? dg + b * sdg.b + h * sdg.h + t_begin * sdg.t : nullptr;
     // d1: dense fp32 [B][T_total][H/G][256]
     d1_t* d1b = DG ? reinterpret_cast<d1_t*>(d1) + (((int64_t)b * T_total + t_begin) * (H / G) + h / G) * DK : nullptr;
+    const unsigned d1_row = (unsigned)((H / G) * DK);         // d1 elements per token
     auto prefetch_prev = [&]() {                               // issued at the top of phase A, consumed by store_prev at its end
         if constexpr (DG != 0) {
 #pragma unroll
@@ -378,7 +379,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 auxr[nt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(auxb) +
                                                            2u * (mr * (unsigned)saux.t + 16u * (unsigned)w + 4u * (unsigned)lg));
                 if constexpr (DG == 2)
-                    d1r[nt] = *reinterpret_cast<const d1v_t*>(d1b + (int64_t)mr * (H / G) * DK + 16 * w + 4 * lg);
+                    d1r[nt] = *reinterpret_cast<const d1v_t*>(reinterpret_cast<const char*>(d1b) + (unsigned)sizeof(d1_t) *
+                              (mr * d1_row + 16u * (unsigned)w + 4u * (unsigned)lg));   // 32-bit offsets (launcher guard)
             }
         }
     };
@@ -427,7 +429,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                     *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) +
                                               2u * (mr * (unsigned)so.t + 16u * (unsigned)w + 4u * (unsigned)lg)) = po;
                     if constexpr (DG == 1) {
-                        d1_t* const dp = d1b + (int64_t)mr * (H / G) * DK + 16 * w + 4 * lg;
+                        d1_t* const dp = reinterpret_cast<d1_t*>(reinterpret_cast<char*>(d1b) + (unsigned)sizeof(d1_t) *
+                                                                 (mr * d1_row + 16u * (unsigned)w + 4u * (unsigned)lg));
                         if constexpr (LINA_K2B_D1_F32 != 0)
                             *reinterpret_cast<float4*>(dp) = make_float4(dd[nt][0], dd[nt][1], dd[nt][2], dd[nt][3]);
                         else
@@ -659,6 +662,11 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             for (int p = 0; p < (NTL < TA ? NTL : TA); ++p) tf[p] = frag16(ktp + 16 * p * ST);
         }
         K2_PROF(4);
+        // DG: the aux / d1 rows of THIS chunk's tokens are requested here -- the q~ ring's registers are free from now on, and
+        // the loads have step (4), barrier (3), step (3) and the next gate scan to land (requested after barrier (3) they were
+        // waited for with most of their latency exposed: SQ_WAIT_ANY 65 % of the wave cycles against 47 % for sweep V)
+        tp = t0; np = n;
+        if constexpr (DG == 2) { prefetch_prev(); sched_fence(); }
         // (4) S' += k^^T v
 #pragma unroll
         for (int p = 0; p < (LINA_K2_ABL == 4 ? 0 : NTL); ++p) {
@@ -667,6 +675,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             S[p] = mfma_bf16_16x16x32(tf[p & 7], vb2, S[p]);
             sched_fence();
         }
+        if constexpr (DG == 1) { prefetch_prev(); sched_fence(); }
         if (renorm && MODE == 1) {                       // rare: S'^T <- S'^T diag(e^{R}): the gated channel is the tile COLUMN
             const float f = fast_exp2(s_Rn[16 * w + li]);
 #pragma unroll
@@ -685,14 +694,13 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             vb = frag8x2(vp, vp + 16);
         }
         K2_PROF(5);
-        wait_vmem();       // the prefetch was issued through inline assembly: this wave's part has landed ...
+        // the DMA was issued through inline assembly: this wave's part has landed (the DG rows requested after it may not) ...
+        wait_vmem_but<DG == 0 ? 0 : DG == 1 ? 2 : 4>();
         K2_PROF(8);
         __syncthreads();   // (3) ... and so has everybody's; operand tiles dead; mask(A) complete (its own buffer)
         K2_PROF(9);
         lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;   // re-derive, do not carry
         if (tid == 0) { s_flags[2 * par] = 0; s_flags[2 * par + 1] = 0; }   // read by all before (3); set again two chunks later, after (2) of the next
-        tp = t0; np = n;
-        if constexpr (DG != 0) prefetch_prev();                // aux / d1 rows of this chunk's tokens: in flight until the next phase A
         if constexpr (!STATE_ONLY) {
             // (3) o += mask(A) . v -- AFTER the barrier: no barrier of its own for mask(A); s_A is rewritten only after the
             //     next chunk's barrier (2)
@@ -944,6 +952,7 @@ extern "C" int lina_gla_chunk_bwd_full(const void* q, const void* k, const void*
         return fail(LINA_ERR_UNSUPPORTED, "lina_gla_chunk_bwd_full: needs bf16 tensors and gates, Dk = Dv in {64,128,256}, "
                                           "adjacent heads, 16-byte aligned rows (use lina_gla_chunk_bwd)");
     const int G = 256 / Dk;
+    LINA_REQUIRE((int64_t)T * (H / G) * 256 * 4 < (1LL << 31), "lina_gla_chunk_bwd_full: T * H too large for 32-bit row offsets");
     const int Tseg = ((T + nseg - 1) / nseg + kFullC - 1) / kFullC * kFullC;   // whole 32-token chunks per segment
     const int ns = (T + Tseg - 1) / Tseg;
     const int64_t groups = (int64_t)B * H / G, slots = groups * ns, blk = 256 * (int64_t)Dk;

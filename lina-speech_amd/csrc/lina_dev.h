@@ -76,6 +76,10 @@ __device__ __forceinline__ void dma16_to_lds_async(const void* base_uniform, uns
                  : "memory", "m0");
 }
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ... all but the N most recently issued vector-memory LOADS of this wave (loads return in order among themselves, so
+// everything issued before the last N -- e.g. the DMA above -- has landed, whatever stores are still in flight)
+template <int N>
+__device__ __forceinline__ void wait_vmem_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // reinterpret 16 bytes of packed bf16 as an MFMA operand (no instructions)
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 u) { return __builtin_bit_cast(bf16x8, u); }

@@ -231,6 +231,7 @@ static inline void wait_vmem() {
     lina_emu::wave_exchange(&mine, 1, tab);
 }
 
+template <int N> static inline void wait_vmem_but() { wait_vmem(); }
 static inline bf16x8 as_bf16x8(uint4 u) { bf16x8 r; memcpy(&r, &u, 16); return r; }
 static inline bf16x8 as_bf16x8(uint2 lo, uint2 hi) { bf16x8 r; memcpy(&r.v[0], &lo, 8); memcpy(&r.v[4], &hi, 8); return r; }
 

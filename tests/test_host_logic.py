@@ -133,3 +133,13 @@ def test_train_initial_state_restores_requires_grad(emu):
     batch = synthetic_batch(b=2, n=12, t_txt=7, n_codebook=253, seed=1)
     train_initial_state(model, iter([batch] * 2), n_steps=2, grad_acc=1, device="cpu")
     assert {n: p.requires_grad for n, p in model.named_parameters()} == before
+
+
+def test_build_refuses_a_kernel_that_spills_where_the_dma_wait_counts_operations():
+    from lina_speech_amd import build
+    ok = ("a.hip:9:1: remark: Function Name: k1 [-Rpass-analysis=kernel-resource-usage]\n"
+          "a.hip:9:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]\nreal warning\n")
+    assert build._check_no_scratch("a.hip", ok) == "real warning"
+    bad = ok.replace("ScratchSize [bytes/lane]: 0", "ScratchSize [bytes/lane]: 20")
+    with pytest.raises(RuntimeError, match="k1 spills"):
+        build._check_no_scratch("a.hip", bad)
