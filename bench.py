@@ -169,11 +169,14 @@ def measure_chunk(dev, B=64, H=4, T=4096, Dk=256, Dv=256, reps=200):
     nbytes = B * H * T * 2 * (3 * Dk + 2 * Dv)                       # e*(3Dk+2Dv) per (row,head,token)
     flops = B * H * T * (2 * 64 * (Dk + Dv) + 4 * Dk * Dv)            # nominal C=64 count of SURVEY 8(d)
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r02_k2_traffic.json")   # PMC passes are separate runs; their committed summary
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("shape") == {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv}:
-            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r02_k2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected; includes the 67 MB final state)"
+    for name, note in (("r02_k2_traffic.json", "; includes the 67 MB final state of the prefill call"),
+                       ("r02_k2_b8_traffic.json", "; state-only pass + combine + full pass of the segment-parallel form")):
+        tpath = os.path.join(ROOT, "profiles", name)                 # PMC passes are separate runs; their committed summaries
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("shape") == {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv}:
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected{note})"
     return {"kernel": "lina::gla_chunk_bf16_h256_kernel", "shape": {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv},
             "bytes_per_launch": nbytes, "traffic": traffic, "traffic_source": traffic_src,
             "dtype": "bf16", "ms": dt * 1e3, "ms_burst_of_3": burst * 1e3, "bound": "hbm", "achieved": nbytes / dt / 1e9,
