@@ -113,10 +113,11 @@ int lina_gla_chunk_bwd(const void* q, const void* k, const void* v, const void* 
 
 /* K2b on the full-head kernel (bf16 tensors and gates, Dk = Dv in {64,128,256}, heads adjacent in memory for Dk < 256):
  * the same contract and results as lina_gla_chunk_bwd, computed as three sweeps of K2's own kernel body
- * (reverse key-gated sweep -> dv, dS; value-gated forward sweep -> dq; value-gated reverse sweep -> dk, dg), each sweep on
+ * (reverse key-gated sweep -> dv, dS; value-gated forward sweep -> dq; value-gated reverse sweep -> dk and, from its own q
+ * rows, the dq just written and k, dg), each sweep on
  * all of nseg sequence segments concurrently from boundary states when nseg > 1 (small B*H).  Returns
  * LINA_ERR_UNSUPPORTED for layouts the kernel does not take (call lina_gla_chunk_bwd then).
- *   workspace: lina_gla_chunk_bwd_full_workspace(...) BYTES of fp32 scratch (boundary states, q (.) dq);
+ *   workspace: lina_gla_chunk_bwd_full_workspace(...) BYTES of fp32 scratch (boundary states of the segments);
  *   seg_states: NULL, or the segment start states that lina_gla_chunk_fwd_seg left at the head of ITS workspace for the
  *               same inputs, T and nseg (the forward of this backward): the state-only forward pass is then skipped. */
 int64_t lina_gla_chunk_bwd_full_workspace(int B, int H, int T, int Dk, int Dv, int nseg);

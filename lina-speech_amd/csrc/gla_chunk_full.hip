@@ -31,9 +31,6 @@
 #ifndef LINA_K2_VAR
 #define LINA_K2_VAR 0   // experiment switch (tools/k2_variants.sh): 1 = the loader waves interleave their DMAs with step (1)
 #endif
-#ifndef LINA_K2B_D1_F32
-#define LINA_K2B_D1_F32 0   // 1: q (.) dq travels between the value-gated sweeps as fp32 instead of bf16 (experiment switch)
-#endif
 #ifndef LINA_K2_ABL
 #define LINA_K2_ABL 0   // tools/k2_ablate.sh builds timing-only variants that skip one phase (results are WRONG there)
 #endif
@@ -82,18 +79,19 @@ __device__ __forceinline__ bf16x8 frag8x2(const bf16_t* p_lo, const bf16_t* p_hi
 //           (X,Y,Z) = (do,v,k) forward gives dq, (v,do,q) with REV gives dk.  The token columns of the products are
 //           permuted (column li of tile nt = token 2 li + nt) so that an output lane holds exactly the two tokens x four
 //           channels whose factors e^{b+R} it computed itself in phase A: nothing is exchanged.
-//   DG      1: also write d1 = aux (.) out (fp32; aux = q) ; 2: d = d1 - aux (.) out (aux = k), running sum of d over the
-//           visited tokens (+ carry[slot]) -> dg: with REV that is dg = reverse-cumsum(q dq - k dk), formed while dk is
-//           still fp32 in registers.
-template <bool STATE_ONLY, int G, int MODE = 0, bool REV = false, int DG = 0>
+//   DG      (sweep K) d = z (.) aux2 - aux (.) out, running sum of d over the visited tokens (+ carry[slot]) -> dg: with
+//           z = q (this sweep's own Z rows: in MODE 1 a phase-A thread reads exactly the (token, channel) values whose output
+//           it will hold), aux2 = dq (sweep Q's output) and aux = k that is dg = reverse-cumsum(q dq - k dk), formed while dk
+//           is still fp32 in registers.
+template <bool STATE_ONLY, int G, int MODE = 0, bool REV = false, bool DG = false>
 __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ gk, bf16_t* __restrict__ o, const float* h0, float* ht, float* dec_out, int H,
     int T_total, int nseg, int Tseg, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
     lina_bht_strides sg, lina_bht_strides so, float scale, float h0_scale, const bf16_t* aux, lina_bht_strides saux,
-    float* d1, bf16_t* dg, lina_bht_strides sdg, const float* carry) {
+    const bf16_t* aux2, lina_bht_strides saux2, bf16_t* dg, lina_bht_strides sdg, const float* carry) {
     static_assert(MODE == 0 || !STATE_ONLY, "the state-only pass exists in the key-gated form only");
-    static_assert(DG == 0 || MODE == 1, "dg is formed by the value-gated sweeps");
+    static_assert(!DG || MODE == 1, "dg is formed by a value-gated sweep");
     constexpr int DK = 256, DV = 256, C = kFullC;       // the WORKGROUP's channel / column width: G heads of D each
     constexpr int D = 256 / G;                            // head dimension
     constexpr int NTL = 16 / G;                           // waves per head = state row tiles per wave
@@ -141,7 +139,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // barrier (2) fetches both (three dependent LDS round trips -- flag, flag, R -- sat in front of every wave's MFMAs)
     __shared__ __attribute__((aligned(8))) unsigned s_flags[4];
     __shared__ int s_cut;
-    __shared__ __attribute__((aligned(16))) float s_carry[DG == 2 ? DK : 4];   // DG 2: running sum of d per channel (wave-private quads)
+    __shared__ __attribute__((aligned(16))) float s_carry[DG ? DK : 4];   // DG: running sum of d per channel (wave-private quads)
 
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int w_s = wave_uniform(w);                         // wave index in an SGPR for the whole kernel
@@ -251,7 +249,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // MODE 1: slot 0 (X) and slot 1 (Y) are copied raw, slot 3 (Z) is gated like k; X goes to tile row 16 rr + rp (token
     // 2 rp + rr: the column permutation of the products, see the kernel header); Eo = the output factors e^{b+R} of this thread's
     // two tokens x four channels.
-    auto write_tiles = [&](auto full_tag, const float (&bc)[2][4], int nv, int par, float (&Eo)[2][4]) {
+    auto write_tiles = [&](auto full_tag, const float (&bc)[2][4], int nv, int par, float (&Eo)[2][4], uint2 (&Zq)[2]) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr float kLog2e = 1.4426950408889634f;
         uint2 kk[2], vv[2];                                   // packed k~ / v of the two rows, for the transposed pieces
@@ -261,6 +259,24 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         // MODE 1, X tile: rows rp and 16 + rp, piece c4 ^ ((row>>2)&3) = c4 ^ ((rp>>2)&3)
         bf16_t* const xp = &s_qk[rp * SQ + 32 * (w >> 1) + 8 * ((lane >> 4) ^ ((rp >> 2) & 3)) + 4 * (w & 1)];
         const bf16_t* const rawp = &s_raw[rp * PE + ch0];
+        bf16_t* const tp = &s_T[ch0 * ST + 2 * rp];          // transposed pieces: (channel ch0+i, tokens 2rp, 2rp+1) = one word
+        if constexpr (MODE == 1) {
+            // the raw operands first (copy X, copy + transpose Y): their registers are free before the gate arithmetic starts
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const bool valid = FULL || 2 * rp + rr < nv;
+                const uint2 rx = *reinterpret_cast<const uint2*>(rawp + rr * DK);
+                *reinterpret_cast<uint2*>(xp + 16 * rr * SQ) = valid ? rx : make_uint2(0u, 0u);
+                const uint2 ry = *reinterpret_cast<const uint2*>(rawp + RAWT + rr * DK);
+                kk[rr] = valid ? ry : make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(qkp + C * SQ + rr * SQ) = kk[rr];
+            }
+            *reinterpret_cast<unsigned*>(tp) = byte_perm(kk[1].x, kk[0].x, 0x05040100u);
+            *reinterpret_cast<unsigned*>(tp + ST) = byte_perm(kk[1].x, kk[0].x, 0x07060302u);
+            *reinterpret_cast<unsigned*>(tp + 2 * ST) = byte_perm(kk[1].y, kk[0].y, 0x05040100u);
+            *reinterpret_cast<unsigned*>(tp + 3 * ST) = byte_perm(kk[1].y, kk[0].y, 0x07060302u);
+            sched_fence();
+        }
         const float4 R4 = *reinterpret_cast<const float4*>(&s_R[ch0]);
         const float Rc[4] = {R4.x, R4.y, R4.z, R4.w};
 #pragma unroll
@@ -281,12 +297,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             if constexpr (MODE == 1) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) Eo[rr][c] = e[c];
-                const uint2 rx = *reinterpret_cast<const uint2*>(rawp + rr * DK);
-                *reinterpret_cast<uint2*>(xp + 16 * rr * SQ) = valid ? rx : make_uint2(0u, 0u);
-                const uint2 ry = *reinterpret_cast<const uint2*>(rawp + RAWT + rr * DK);
-                kk[rr] = valid ? ry : make_uint2(0u, 0u);
-                *reinterpret_cast<uint2*>(qkp + C * SQ + rr * SQ) = kk[rr];
-                unpack4(*reinterpret_cast<const uint2*>(rawp + 3 * RAWT + rr * DK), f);
+                Zq[rr] = *reinterpret_cast<const uint2*>(rawp + 3 * RAWT + rr * DK);   // raw Z rows (DG: q of these tokens)
+                unpack4(Zq[rr], f);
                 vv[rr].x = pack_bf16x2(f[0] * ri[0], f[1] * ri[1]);
                 vv[rr].y = pack_bf16x2(f[2] * ri[2], f[3] * ri[3]);
                 vv[rr].x = valid ? vv[rr].x : 0u;
@@ -322,11 +334,12 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             }
         }
         // transposed pieces: element (channel ch0+i, tokens 2rp, 2rp+1) = one 4-byte word = one byte permute of the two rows
-        bf16_t* const tp = &s_T[ch0 * ST + 2 * rp];
-        *reinterpret_cast<unsigned*>(tp) = byte_perm(kk[1].x, kk[0].x, 0x05040100u);
-        *reinterpret_cast<unsigned*>(tp + ST) = byte_perm(kk[1].x, kk[0].x, 0x07060302u);
-        *reinterpret_cast<unsigned*>(tp + 2 * ST) = byte_perm(kk[1].y, kk[0].y, 0x05040100u);
-        *reinterpret_cast<unsigned*>(tp + 3 * ST) = byte_perm(kk[1].y, kk[0].y, 0x07060302u);
+        if constexpr (MODE == 0) {
+            *reinterpret_cast<unsigned*>(tp) = byte_perm(kk[1].x, kk[0].x, 0x05040100u);
+            *reinterpret_cast<unsigned*>(tp + ST) = byte_perm(kk[1].x, kk[0].x, 0x07060302u);
+            *reinterpret_cast<unsigned*>(tp + 2 * ST) = byte_perm(kk[1].y, kk[0].y, 0x05040100u);
+            *reinterpret_cast<unsigned*>(tp + 3 * ST) = byte_perm(kk[1].y, kk[0].y, 0x07060302u);
+        }
         *reinterpret_cast<unsigned*>(tp + DK * ST) = byte_perm(vv[1].x, vv[0].x, 0x05040100u);
         *reinterpret_cast<unsigned*>(tp + DK * ST + ST) = byte_perm(vv[1].x, vv[0].x, 0x07060302u);
         *reinterpret_cast<unsigned*>(tp + DK * ST + 2 * ST) = byte_perm(vv[1].y, vv[0].y, 0x05040100u);
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     using PartT = std::false_type;
 
     for (int c = tid; c < DK; c += 1024) s_R[c] = 0.0f;
-    if constexpr (DG == 2)
+    if constexpr (DG)
         for (int c = tid; c < DK; c += 1024) s_carry[c] = carry ? carry[(int64_t)slot * DK + c] : 0.0f;
     if (tid < 4) s_flags[tid] = 0;
     if (tid == 2) s_cut = 0;
@@ -362,25 +375,20 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // stores while the others still compute.
     // memory row (relative to the segment's first token) of visited row tl
     auto out_row = [&](int tl) -> unsigned { return (unsigned)(REV ? T - 1 - tl : tl); };
-    uint2 auxr[2];                                             // DG: aux rows of the previous chunk's tokens (requested early)
-    using d1_t = std::conditional_t<LINA_K2B_D1_F32 != 0, float, bf16_t>;   // workspace element of q (.) dq
-    using d1v_t = std::conditional_t<LINA_K2B_D1_F32 != 0, float4, uint2>;  // four of them
-    d1v_t d1r[2];
+    uint2 auxr[2], aux2r[2];                                   // DG: aux / aux2 rows of this chunk's tokens (requested early)
+    uint2 zq[2];                                               // DG: this thread's raw Z rows of the chunk (kept from phase A)
     const bf16_t* auxb = DG ? aux + b * saux.b + h * saux.h + t_begin * saux.t : nullptr;
-    bf16_t* dgb = DG == 2 ? dg + b * sdg.b + h * sdg.h + t_begin * sdg.t : nullptr;
-    // d1: dense fp32 [B][T_total][H/G][256]
-    d1_t* d1b = DG ? reinterpret_cast<d1_t*>(d1) + (((int64_t)b * T_total + t_begin) * (H / G) + h / G) * DK : nullptr;
-    const unsigned d1_row = (unsigned)((H / G) * DK);         // d1 elements per token
-    auto prefetch_prev = [&]() {                               // issued at the top of phase A, consumed by store_prev at its end
-        if constexpr (DG != 0) {
+    const bf16_t* aux2b = DG ? aux2 + b * saux2.b + h * saux2.h + t_begin * saux2.t : nullptr;
+    bf16_t* dgb = DG ? dg + b * sdg.b + h * sdg.h + t_begin * sdg.t : nullptr;
+    auto prefetch_prev = [&]() {                               // issued before step (4), consumed by store_prev in the next phase A
+        if constexpr (DG) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const unsigned mr = out_row(min(tp + 2 * li + nt, T - 1));
                 auxr[nt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(auxb) +
                                                            2u * (mr * (unsigned)saux.t + 16u * (unsigned)w + 4u * (unsigned)lg));
-                if constexpr (DG == 2)
-                    d1r[nt] = *reinterpret_cast<const d1v_t*>(reinterpret_cast<const char*>(d1b) + (unsigned)sizeof(d1_t) *
-                              (mr * d1_row + 16u * (unsigned)w + 4u * (unsigned)lg));   // 32-bit offsets (launcher guard)
+                aux2r[nt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(aux2b) +
+                                                            2u * (mr * (unsigned)saux2.t + 16u * (unsigned)w + 4u * (unsigned)lg));
             }
         }
     };
@@ -403,24 +411,14 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const bool valid = 2 * li + nt < np;
-                float a4[4], d4[4];
-                if constexpr (DG != 0) unpack4(auxr[nt], a4);
-                if constexpr (DG == 2) {
-                    if constexpr (LINA_K2B_D1_F32 != 0) {
-                        const float4 t4 = *reinterpret_cast<const float4*>(&d1r[nt]);
-                        d4[0] = t4.x; d4[1] = t4.y; d4[2] = t4.z; d4[3] = t4.w;
-                    } else {
-                        unpack4(*reinterpret_cast<const uint2*>(&d1r[nt]), d4);
-                    }
-                }
+                float a4[4], p4[4], z4[4];
+                if constexpr (DG) { unpack4(auxr[nt], a4); unpack4(aux2r[nt], p4); unpack4(zq[nt], z4); }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     ov[nt][r] = acc[nt][r];                    // already scaled by e^{b+R} / sqrt(Dk) (end of its iteration)
-                    if constexpr (DG == 1) dd[nt][r] = a4[r] * ov[nt][r];
-                    if constexpr (DG == 2) {
-                        dd[nt][r] = valid ? d4[r] - a4[r] * ov[nt][r] : 0.0f;
-                    }
+                    if constexpr (DG) dd[nt][r] = valid ? z4[r] * p4[r] - a4[r] * ov[nt][r] : 0.0f;
                 }
+                if constexpr (DG) sched_fence();               // one token's unpacked operands at a time (register budget)
                 if (valid) {
                     const unsigned mr = out_row(tp + 2 * li + nt);
                     uint2 po;
@@ -428,18 +426,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                     po.y = pack_bf16x2(ov[nt][2], ov[nt][3]);
                     *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) +
                                               2u * (mr * (unsigned)so.t + 16u * (unsigned)w + 4u * (unsigned)lg)) = po;
-                    if constexpr (DG == 1) {
-                        d1_t* const dp = reinterpret_cast<d1_t*>(reinterpret_cast<char*>(d1b) + (unsigned)sizeof(d1_t) *
-                                                                 (mr * d1_row + 16u * (unsigned)w + 4u * (unsigned)lg));
-                        if constexpr (LINA_K2B_D1_F32 != 0)
-                            *reinterpret_cast<float4*>(dp) = make_float4(dd[nt][0], dd[nt][1], dd[nt][2], dd[nt][3]);
-                        else
-                            *reinterpret_cast<uint2*>(dp) =
-                                make_uint2(pack_bf16x2(dd[nt][0], dd[nt][1]), pack_bf16x2(dd[nt][2], dd[nt][3]));
-                    }
                 }
             }
-            if constexpr (DG == 2) {
+            if constexpr (DG) {
                 // running sum over the visited rows: pair sums, inclusive scan over the 16 row pairs (one 16-lane row per
                 // channel quad), + the carry of the earlier chunks; the last lane of the row publishes the new carry
                 float ps[4];
@@ -481,18 +470,19 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         int n = min(C, nrem);
         // ---------------- phase A: gate scan, scaled operands, transposed operands ----------------
         // MODE 1: the previous chunk's output leaves BETWEEN the gate scan and the tile writes -- its accumulators, factors
-        // and the aux / d1 rows requested after barrier (3) are dead before the tile writes need their registers
+        // (and, in sweep K, the aux rows requested before step (4)) are dead before the tile writes need their registers
         float En[2][4];                                        // MODE 1: this chunk's output factors
+        if (DG && np > 0) store_prev();                        // sweep K: before the gate scan (its registers: aux, aux2, q rows)
         {
             float bc[2][4];
             if (nrem >= C) {                                   // workgroup-uniform: the mask-free form
                 if (gate_scan(FullT{}, bc, nrem)) s_flags[2 * par] = 1;
-                if (MODE == 1 && np > 0) store_prev();
-                write_tiles(FullT{}, bc, C, par, En);
+                if (MODE == 1 && !DG && np > 0) store_prev();
+                write_tiles(FullT{}, bc, C, par, En, zq);
             } else {
                 if (gate_scan(PartT{}, bc, nrem)) s_flags[2 * par] = 1;
-                if (MODE == 1 && np > 0) store_prev();
-                write_tiles(PartT{}, bc, n, par, En);
+                if (MODE == 1 && !DG && np > 0) store_prev();
+                write_tiles(PartT{}, bc, n, par, En, zq);
             }
         }
         K2_PROF(0);
@@ -522,7 +512,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             n = max(min(n, C - s_cut), 1);
             __syncthreads();   // everyone has read s_cut; the optimistic tiles are dead
             if (tid == 0) s_cut = 0;
-            write_tiles(PartT{}, bc, n, par, En);
+            write_tiles(PartT{}, bc, n, par, En, zq);
             __syncthreads();
             fl.y = s_flags[2 * par + 1];                       // the rewritten tiles may have changed both
             rn = tid < DK ? s_Rn[tid] : 0.0f;
@@ -628,6 +618,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
                         qf[(pp + QA) & 3][nt] = frag16(qp + 16 * nt * SQ + 32 * (pp + QA));
+                } else if (DG) {                               // (sweep K carries 4 more registers: step (4)'s operands after step (1))
                 } else if (pp == 8 - QA) {                     // the ring's free slots take step (4)'s first operands
                     vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
                     tf[0] = frag16(ktp);
@@ -662,11 +653,19 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             for (int p = 0; p < (NTL < TA ? NTL : TA); ++p) tf[p] = frag16(ktp + 16 * p * ST);
         }
         K2_PROF(4);
-        // DG: the aux / d1 rows of THIS chunk's tokens are requested here -- the q~ ring's registers are free from now on, and
+        // DG: the aux (k) / aux2 (dq) rows of THIS chunk's tokens are requested here -- the q~ ring's registers are free from now on, and
         // the loads have step (4), barrier (3), step (3) and the next gate scan to land (requested after barrier (3) they were
         // waited for with most of their latency exposed: SQ_WAIT_ANY 65 % of the wave cycles against 47 % for sweep V)
         tp = t0; np = n;
-        if constexpr (DG == 2) { prefetch_prev(); sched_fence(); }
+        if constexpr (DG) {
+            if constexpr (!STATE_ONLY && G == 1) {
+                vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
+#pragma unroll
+                for (int p = 0; p < TA; ++p) tf[p] = frag16(ktp + 16 * p * ST);
+            }
+            prefetch_prev();
+            sched_fence();
+        }
         // (4) S' += k^^T v
 #pragma unroll
         for (int p = 0; p < (LINA_K2_ABL == 4 ? 0 : NTL); ++p) {
@@ -675,7 +674,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             S[p] = mfma_bf16_16x16x32(tf[p & 7], vb2, S[p]);
             sched_fence();
         }
-        if constexpr (DG == 1) { prefetch_prev(); sched_fence(); }
         if (renorm && MODE == 1) {                       // rare: S'^T <- S'^T diag(e^{R}): the gated channel is the tile COLUMN
             const float f = fast_exp2(s_Rn[16 * w + li]);
 #pragma unroll
@@ -695,7 +693,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         }
         K2_PROF(5);
         // the DMA was issued through inline assembly: this wave's part has landed (the DG rows requested after it may not) ...
-        wait_vmem_but<DG == 0 ? 0 : DG == 1 ? 2 : 4>();
+        wait_vmem_but<DG ? 4 : 0>();
         K2_PROF(8);
         __syncthreads();   // (3) ... and so has everybody's; operand tiles dead; mask(A) complete (its own buffer)
         K2_PROF(9);
@@ -750,8 +748,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 // true when the full-head kernel can take this call (16-byte aligned rows everywhere); D = 128 / 64: groups of 2 / 4 heads
 // per workgroup, which must be adjacent in memory (head stride == D, the [B,T,H,D] layout) and inside one batch row
 // kernel arguments that only the backward's sweeps use
-#define LINA_FWD_ONLY 1.0f, (const bf16_t*)nullptr, lina_bht_strides{}, (float*)nullptr, (bf16_t*)nullptr, lina_bht_strides{}, \
-                      (const float*)nullptr
+#define LINA_FWD_ONLY 1.0f, (const bf16_t*)nullptr, lina_bht_strides{}, (const bf16_t*)nullptr, lina_bht_strides{},        \
+                      (bf16_t*)nullptr, lina_bht_strides{}, (const float*)nullptr
 
 static bool full_ok(int H, int Dk, int Dv, int dtype, const void* q, const void* k, const void* v, const void* gk,
                     const void* o, int g_dtype, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
@@ -897,8 +895,8 @@ extern "C" int lina_gla_chunk_fwd_seg(const void* q, const void* k, const void* 
 // ------------------------------------------------------------------------------------------------------------
 // K2b on the full-head kernel (bf16, Dk = Dv in {64,128,256}): three sweeps of the body above, each at the forward's cost,
 //     V  (REV; q,k,v := k,q,do)            dv, dS            key-gated   = the forward kernel on the reversed sequence
-//     Q  (MODE 1; X,Y,Z := do,v,k)         dq, d1 = q dq     value-gated, state S^T
-//     K  (MODE 1, REV; X,Y,Z := v,do,q)    dk, dg            value-gated, state dS^T; dg = running sum of d1 - k dk
+//     Q  (MODE 1; X,Y,Z := do,v,k)         dq                value-gated, state S^T
+//     K  (MODE 1, REV; X,Y,Z := v,do,q)    dk, dg            value-gated, state dS^T; dg = running sum of q dq - k dk
 // With nseg > 1 every sweep runs on all segments concurrently from boundary states: a state-only forward pass + combine
 // gives S at every segment start, a state-only reverse pass + combine gives dS at every segment end and the gate-gradient
 // carry of every segment (gla_seg_combine_kernel<true>).  The state is kept as dS / scale (the sweeps apply scale to
@@ -921,8 +919,8 @@ __global__ __launch_bounds__(256) void gla_bwd_dh0_kernel(const float* __restric
 
 static int64_t bwd_full_ws_floats(int B, int H, int T, int Dk, int nseg) {
     const int64_t G = 256 / Dk, groups = (int64_t)B * H / G, slots = groups * nseg, blk = 256 * (int64_t)Dk;
-    // SstartF | SstartR | P | carry | end state of the reverse pass | d1
-    return 2 * slots * blk + 2 * slots * 256 + groups * blk + (int64_t)B * T * (H / G) * 256;
+    // SstartF | SstartR | P | carry | end state of the reverse pass
+    return 2 * slots * blk + 2 * slots * 256 + groups * blk;
 }
 
 extern "C" int64_t lina_gla_chunk_bwd_full_workspace(int B, int H, int T, int Dk, int Dv, int nseg) {
@@ -952,7 +950,6 @@ extern "C" int lina_gla_chunk_bwd_full(const void* q, const void* k, const void*
         return fail(LINA_ERR_UNSUPPORTED, "lina_gla_chunk_bwd_full: needs bf16 tensors and gates, Dk = Dv in {64,128,256}, "
                                           "adjacent heads, 16-byte aligned rows (use lina_gla_chunk_bwd)");
     const int G = 256 / Dk;
-    LINA_REQUIRE((int64_t)T * (H / G) * 256 * 4 < (1LL << 31), "lina_gla_chunk_bwd_full: T * H too large for 32-bit row offsets");
     const int Tseg = ((T + nseg - 1) / nseg + kFullC - 1) / kFullC * kFullC;   // whole 32-token chunks per segment
     const int ns = (T + Tseg - 1) / Tseg;
     const int64_t groups = (int64_t)B * H / G, slots = groups * ns, blk = 256 * (int64_t)Dk;
@@ -961,7 +958,6 @@ extern "C" int lina_gla_chunk_bwd_full(const void* q, const void* k, const void*
     float* P = SR + slots * blk;
     float* carry = P + slots * 256;
     float* endR = carry + slots * 256;
-    float* d1 = endR + groups * blk;
     const float inv = 1.0f / scale;
     const lina_bht_strides z{};
     dim3 grid((unsigned)slots);
@@ -970,7 +966,7 @@ extern "C" int lina_gla_chunk_bwd_full(const void* q, const void* k, const void*
 #define LINA_BW(SO, GG, MODE, REV, DGM, A0, A1, A3, OO, H0, HT, PP, S0, S1, S3, SOO, H0S, AUX, SAUX, CARRY)               \
     LINA_LAUNCH((gla_chunk_bf16_h256_kernel<SO, GG, MODE, REV, DGM>), grid, dim3(1024), 0, stream, A0, A1, A3, GK,       \
                 (bf16_t*)(OO), (const float*)(H0), (float*)(HT), (float*)(PP), H, T, ns, Tseg, S0, S1, S3, sg, SOO, scale, \
-                H0S, (const bf16_t*)(AUX), SAUX, d1, (bf16_t*)dg, sdg, (const float*)(CARRY))
+                H0S, (const bf16_t*)(AUX), SAUX, (const bf16_t*)dq, sdq, (bf16_t*)dg, sdg, (const float*)(CARRY))
 #define LINA_BW_G(...)                                                                                                  \
     do { if (G == 1) LINA_BW(__VA_ARGS__); } while (0)
     const float* startF = h0;         // per-slot start states of sweep Q / of sweeps V, K
@@ -982,22 +978,23 @@ extern "C" int lina_gla_chunk_bwd_full(const void* q, const void* k, const void*
     do {                                                                                                                \
         if (ns > 1) {                                                                                                   \
             if (!seg_states) {                                                                                          \
-                LINA_BW(true, GG, 0, false, 0, Q, K, V, nullptr, nullptr, SF, P, sq, sk, sv, z, 1.0f, nullptr, z, nullptr); \
+                LINA_BW(true, GG, 0, false, false, Q, K, V, nullptr, nullptr, SF, P, sq, sk, sv, z, 1.0f, nullptr, z, nullptr); \
                 LINA_LAUNCH(gla_seg_combine_kernel<false>, dim3((unsigned)groups, (unsigned)(Dk / 4)), dim3(256), 0, stream, \
                             (const float*)SF, (const float*)P, h0, 1.0f, SF, (float*)nullptr, ns, Dk, (const float*)nullptr, \
                             (const bf16_t*)nullptr, sg, (const float*)nullptr, (float*)nullptr, H, Tseg, scale);        \
             }                                                                                                           \
             const float* sf = seg_states ? seg_states : SF;                                                             \
-            LINA_BW(true, GG, 0, true, 0, K, Q, DO, nullptr, nullptr, SR, P, sk, sq, sdo, z, 1.0f, nullptr, z, nullptr); \
+            LINA_BW(true, GG, 0, true, false, K, Q, DO, nullptr, nullptr, SR, P, sk, sq, sdo, z, 1.0f, nullptr, z, nullptr); \
             LINA_LAUNCH(gla_seg_combine_kernel<true>, dim3((unsigned)groups, (unsigned)(Dk / 4)), dim3(256), 0, stream,  \
                         (const float*)SR, (const float*)P, dht, inv, SR, dh0 ? endR : (float*)nullptr, ns, Dk, sf, GK,   \
                         sg, dg_tail, carry, H, Tseg, scale);                                                            \
             startF = sf; startR = SR; carry_in = carry; startR_scale = 1.0f; endV = nullptr;                            \
         }                                                                                                               \
-        LINA_BW(false, GG, 0, true, 0, K, Q, DO, dv, startR, endV, nullptr, sk, sq, sdo, sdv, startR_scale, nullptr, z,  \
+        LINA_BW(false, GG, 0, true, false, K, Q, DO, dv, startR, endV, nullptr, sk, sq, sdo, sdv, startR_scale, nullptr, z,  \
                 nullptr);                                                                                               \
-        LINA_BW(false, GG, 1, false, 1, DO, V, K, dq, startF, nullptr, nullptr, sdo, sv, sk, sdq, 1.0f, Q, sq, nullptr); \
-        LINA_BW(false, GG, 1, true, 2, V, DO, Q, dk, startR, nullptr, nullptr, sv, sdo, sq, sdk, startR_scale, K, sk,    \
+        LINA_BW(false, GG, 1, false, false, DO, V, K, dq, startF, nullptr, nullptr, sdo, sv, sk, sdq, 1.0f, nullptr, z,  \
+                nullptr);                                                                                               \
+        LINA_BW(false, GG, 1, true, true, V, DO, Q, dk, startR, nullptr, nullptr, sv, sdo, sq, sdk, startR_scale, K, sk,    \
                 carry_in);                                                                                              \
     } while (0)
     if (G == 1) LINA_BW_ALL(1); else if (G == 2) LINA_BW_ALL(2); else LINA_BW_ALL(4);
