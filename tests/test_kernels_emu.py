@@ -234,6 +234,12 @@ def test_chunk_bwd_full_head_sweeps(emu, T, nseg, resets, h0, dht):
     check_chunk_bwd_full(DEV, 1, 1, T, 256, nseg, resets=resets, with_h0=h0, with_dht=dht)
 
 
+@pytest.mark.parametrize("T,nseg", [(1, 1), (2, 1), (5, 4), (32, 1), (65, 2)])
+def test_chunk_bwd_full_head_sweeps_edge_lengths(emu, T, nseg):
+    # one token, fewer tokens than segments asked for, exactly one chunk, one token past a segment boundary
+    check_chunk_bwd_full(DEV, 1, 1, T, 256, nseg)
+
+
 @pytest.mark.parametrize("D,H,T,nseg", [(128, 2, 70, 1), (64, 4, 70, 2), (128, 4, 65, 2)])
 def test_chunk_bwd_full_head_sweeps_head_groups(emu, D, H, T, nseg):
     check_chunk_bwd_full(DEV, 1, H, T, D, nseg, resets=True)
