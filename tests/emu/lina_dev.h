@@ -232,6 +232,22 @@ static inline void wait_vmem() {
 }
 
 template <int N> static inline void wait_vmem_but() { wait_vmem(); }
+// ds_read_b64_tr_b16 as measured on the hardware (tools/micro/tr_read.hip, profiles/r02_tr_read_probe.txt): every lane
+// supplies the LDS address of an 8-byte piece (4 x 16-bit); inside each group of 16 lanes
+//     result[lane i][j] = piece[lane 4 j + i / 4][element i % 4]            (a 4 x 16 -> 16 x 4 transpose per group)
+static inline uint2 lds_read_tr16_b64(const void* piece) {
+    const uint64_t a = (uint64_t)(uintptr_t)piece;
+    uint32_t mine[2] = {(uint32_t)a, (uint32_t)(a >> 32)}, tab[128];
+    lina_emu::wave_exchange(mine, 2, tab);
+    const int l = lina_emu::cur_lane(), g0 = l & ~15, i = l & 15;
+    unsigned short e[4];
+    for (int j = 0; j < 4; ++j) {
+        const int src = g0 + 4 * j + i / 4;
+        const unsigned short* p = (const unsigned short*)(uintptr_t)((uint64_t)tab[2 * src] | ((uint64_t)tab[2 * src + 1] << 32));
+        e[j] = p[i % 4];
+    }
+    return make_uint2((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16));
+}
 static inline bf16x8 as_bf16x8(uint4 u) { bf16x8 r; memcpy(&r, &u, 16); return r; }
 static inline bf16x8 as_bf16x8(uint2 lo, uint2 hi) { bf16x8 r; memcpy(&r.v[0], &lo, 8); memcpy(&r.v[4], &hi, 8); return r; }
 
