@@ -31,6 +31,11 @@
 #ifndef LINA_K2_VAR
 #define LINA_K2_VAR 0   // experiment switch (tools/k2_variants.sh): 1 = the loader waves interleave their DMAs with step (1)
 #endif
+#ifndef LINA_K2_TR
+#define LINA_K2_TR 0    // 1 (opt-in variant, not the default build): no transposed k~^T / v^T tiles -- the operands whose K dimension
+                        // is the token axis are read with ds_read_b64_tr_b16 from the ROW-MAJOR k~ tile and a row-major copy of v:
+                        // phase A loses its eight 4-byte transposed writes per thread, the workgroup 31 KB of LDS
+#endif
 #ifndef LINA_K2_ABL
 #define LINA_K2_ABL 0   // tools/k2_ablate.sh builds timing-only variants that skip one phase (results are WRONG there)
 #endif
@@ -116,9 +121,12 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     bf16_t* const s_q = s_qk;
     bf16_t* const s_k = s_qk + C * SQ;
     __shared__ __attribute__((aligned(16))) bf16_t s_A[G * 2 * 64 * 8]; // mask(A) as ready-made operands [head][nt][lane][8]
-    __shared__ __attribute__((aligned(16))) bf16_t s_T[(DK + DV) * ST];  // k~^T | v^T
+    constexpr bool kTR = LINA_K2_TR != 0;
+    constexpr int SV = DV + 16;  // kTR: row stride of the chunk-stable row-major v (MODE 1: gated Z) tile
+    __shared__ __attribute__((aligned(16))) bf16_t s_T[kTR ? C * SV : (DK + DV) * ST];  // k~^T | v^T   (kTR: row-major v)
     bf16_t* const s_kT = s_T;
-    bf16_t* const s_vT = s_T + DK * ST;
+    bf16_t* const s_vT = s_T + (kTR ? 0 : DK * ST);
+    bf16_t* const s_vr = s_T;
     // next chunk's q, k, g, v, filled by DMA (issued through inline assembly and waited for by hand: the compiler does not
     // see these writes, so reads of the object are never held back by them)
     constexpr int RAWT = (C / 2) * PE;
@@ -271,10 +279,12 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 kk[rr] = valid ? ry : make_uint2(0u, 0u);
                 *reinterpret_cast<uint2*>(qkp + C * SQ + rr * SQ) = kk[rr];
             }
-            *reinterpret_cast<unsigned*>(tp) = byte_perm(kk[1].x, kk[0].x, 0x05040100u);
-            *reinterpret_cast<unsigned*>(tp + ST) = byte_perm(kk[1].x, kk[0].x, 0x07060302u);
-            *reinterpret_cast<unsigned*>(tp + 2 * ST) = byte_perm(kk[1].y, kk[0].y, 0x05040100u);
-            *reinterpret_cast<unsigned*>(tp + 3 * ST) = byte_perm(kk[1].y, kk[0].y, 0x07060302u);
+            if constexpr (!kTR) {
+                *reinterpret_cast<unsigned*>(tp) = byte_perm(kk[1].x, kk[0].x, 0x05040100u);
+                *reinterpret_cast<unsigned*>(tp + ST) = byte_perm(kk[1].x, kk[0].x, 0x07060302u);
+                *reinterpret_cast<unsigned*>(tp + 2 * ST) = byte_perm(kk[1].y, kk[0].y, 0x05040100u);
+                *reinterpret_cast<unsigned*>(tp + 3 * ST) = byte_perm(kk[1].y, kk[0].y, 0x07060302u);
+            }
             sched_fence();
         }
         const float4 R4 = *reinterpret_cast<const float4*>(&s_R[ch0]);
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 kk[rr].y = pack_bf16x2(f[2] * ri[2], f[3] * ri[3]);
                 kk[rr].x = valid ? kk[rr].x : 0u;
                 kk[rr].y = valid ? kk[rr].y : 0u;
-                if constexpr (!STATE_ONLY) *reinterpret_cast<uint2*>(qkp + C * SQ + rr * SQ) = kk[rr];
+                if constexpr (!STATE_ONLY || kTR) *reinterpret_cast<uint2*>(qkp + C * SQ + rr * SQ) = kk[rr];
                 const uint2 rv = *reinterpret_cast<const uint2*>(rawp + 3 * RAWT + rr * DK);
                 vv[rr] = valid ? rv : make_uint2(0u, 0u);
             }
@@ -334,6 +344,11 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             }
         }
         // transposed pieces: element (channel ch0+i, tokens 2rp, 2rp+1) = one 4-byte word = one byte permute of the two rows
+        if constexpr (kTR) {                                  // the value operand stays row-major (rows >= nv are zero)
+            *reinterpret_cast<uint2*>(&s_vr[(2 * rp) * SV + ch0]) = vv[0];
+            *reinterpret_cast<uint2*>(&s_vr[(2 * rp + 1) * SV + ch0]) = vv[1];
+            return;
+        }
         if constexpr (MODE == 0) {
             *reinterpret_cast<unsigned*>(tp) = byte_perm(kk[1].x, kk[0].x, 0x05040100u);
             *reinterpret_cast<unsigned*>(tp + ST) = byte_perm(kk[1].x, kk[0].x, 0x07060302u);
@@ -573,6 +588,32 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             K2_PROF(3);
         }
         const bf16_t* ktp = &s_kT[(16 * NTL * hw + li) * ST + 8 * lg];   // k~^T fragment of this head's state tile p: + 16 p ST
+        // operand fragments whose K dimension is the token axis.  kTR: two transposing reads each (tokens T0 .. T0+3 and
+        // T0+4 .. T0+7 of 16 channels; a 16-lane group addresses row T0 + (li>>2), channel quad li&3 and lane li receives
+        // channel li) straight from the row-major tiles -- the k~ tile with its channel permutation and piece swizzle
+        auto tr8 = [&](const bf16_t* p0, const bf16_t* p1) { return as_bf16x8(lds_read_tr16_b64(p0), lds_read_tr16_b64(p1)); };
+        auto ld_kt = [&](int p) -> bf16x8 {                    // k~^T of this head's state row tile p, tokens 8 lg .. 8 lg + 7
+            if constexpr (!kTR) return frag16(ktp + 16 * p * ST);
+            else {
+                const int m16 = NTL * hw + p, t0 = 8 * lg + (li >> 2), t1 = t0 + 4;
+                const bf16_t* b = &s_k[32 * (m16 >> 1) + 4 * (m16 & 1)];
+                return tr8(b + t0 * SK + 8 * ((li & 3) ^ ((t0 >> 2) & 3)), b + t1 * SK + 8 * ((li & 3) ^ ((t1 >> 2) & 3)));
+            }
+        };
+        auto ld_v8 = [&]() -> bf16x8 {                         // v^T of this wave's 16 columns, tokens 8 lg .. 8 lg + 7
+            if constexpr (!kTR) return frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
+            else {
+                const bf16_t* b = &s_vr[(8 * lg + (li >> 2)) * SV + 16 * w + 4 * (li & 3)];
+                return tr8(b, b + 4 * SV);
+            }
+        };
+        auto ld_v4 = [&]() -> bf16x8 {                         // ... tokens 4 lg .. 4 lg + 3 and 16 + 4 lg .. 16 + 4 lg + 3
+            if constexpr (!kTR) { const bf16_t* vp = &s_vT[(16 * w + li) * ST + 4 * lg]; return frag8x2(vp, vp + 16); }
+            else {
+                const bf16_t* b = &s_vr[(4 * lg + (li >> 2)) * SV + 16 * w + 4 * (li & 3)];
+                return tr8(b, b + 16 * SV);
+            }
+        };
         // ring of k~^T fragments, TA tiles ahead (MODE 1 carries its 8 output factors across this phase: a shallower ring
         // instead of spills, whose reloads would wait on the loader waves' in-flight DMA)
         constexpr int TA = MODE == 1 ? 3 : 5;
@@ -588,9 +629,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             for (int pp = 0; pp < NPP; ++pp)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) qf[pp][nt] = frag16(qp + 16 * nt * SQ + 32 * pp);
-            vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
+            vb2 = ld_v8();
 #pragma unroll
-            for (int p = 0; p < (NTL < TA ? NTL : TA); ++p) tf[p] = frag16(ktp + 16 * p * ST);
+            for (int p = 0; p < (NTL < TA ? NTL : TA); ++p) tf[p] = ld_kt(p);
             sched_fence();
 #pragma unroll
             for (int pp = 0; pp < NPP; ++pp) {
@@ -620,15 +661,15 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                         qf[(pp + QA) & 3][nt] = frag16(qp + 16 * nt * SQ + 32 * (pp + QA));
                 } else if (DG) {                               // (sweep K carries 4 more registers: step (4)'s operands after step (1))
                 } else if (pp == 8 - QA) {                     // the ring's free slots take step (4)'s first operands
-                    vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
-                    tf[0] = frag16(ktp);
+                    vb2 = ld_v8();
+                    tf[0] = ld_kt(0);
                 } else if (pp == 9 - QA) {
-                    tf[1] = frag16(ktp + 16 * ST);
-                    tf[2] = frag16(ktp + 32 * ST);
+                    tf[1] = ld_kt(1);
+                    tf[2] = ld_kt(2);
                 } else {
                     if constexpr (TA > 3) {
-                        tf[3] = frag16(ktp + 48 * ST);
-                        tf[4] = frag16(ktp + 64 * ST);
+                        tf[3] = ld_kt(3);
+                        tf[4] = ld_kt(4);
                     }
                 }
                 sched_fence();
@@ -648,9 +689,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 }
             }
         } else {
-            vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
+            vb2 = ld_v8();
 #pragma unroll
-            for (int p = 0; p < (NTL < TA ? NTL : TA); ++p) tf[p] = frag16(ktp + 16 * p * ST);
+            for (int p = 0; p < (NTL < TA ? NTL : TA); ++p) tf[p] = ld_kt(p);
         }
         K2_PROF(4);
         // DG: the aux (k) / aux2 (dq) rows of THIS chunk's tokens are requested here -- the q~ ring's registers are free from now on, and
@@ -659,9 +700,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         tp = t0; np = n;
         if constexpr (DG) {
             if constexpr (!STATE_ONLY && G == 1) {
-                vb2 = frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
+                vb2 = ld_v8();
 #pragma unroll
-                for (int p = 0; p < TA; ++p) tf[p] = frag16(ktp + 16 * p * ST);
+                for (int p = 0; p < TA; ++p) tf[p] = ld_kt(p);
             }
             prefetch_prev();
             sched_fence();
@@ -669,7 +710,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         // (4) S' += k^^T v
 #pragma unroll
         for (int p = 0; p < (LINA_K2_ABL == 4 ? 0 : NTL); ++p) {
-            if (p + TA < NTL) tf[(p + TA) & 7] = frag16(ktp + 16 * (p + TA) * ST);
+            if (p + TA < NTL) tf[(p + TA) & 7] = ld_kt(p + TA);
             sched_fence();
             S[p] = mfma_bf16_16x16x32(tf[p & 7], vb2, S[p]);
             sched_fence();
@@ -688,8 +729,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         // v fragment of step (3) (same token order as the C/D rows of mask(A)): read before the tiles die at (3)
         bf16x8 vb;
         if constexpr (!STATE_ONLY) {
-            const bf16_t* vp = &s_vT[(16 * w + li) * ST + 4 * lg];
-            vb = frag8x2(vp, vp + 16);
+            vb = ld_v4();
         }
         K2_PROF(5);
         // the DMA was issued through inline assembly: this wave's part has landed (the DG rows requested after it may not) ...

@@ -76,18 +76,17 @@ __device__ __forceinline__ void dma16_to_lds_async(const void* base_uniform, uns
                  : "memory", "m0");
 }
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// ... all but the N most recently issued vector-memory LOADS of this wave (loads return in order among themselves, so
-// everything issued before the last N -- e.g. the DMA above -- has landed, whatever stores are still in flight)
 // ds_read_b64_tr_b16: transposing LDS read of 16-bit elements.  Every lane passes the address of an 8-byte piece; inside
 // each group of 16 lanes  result[lane i][j] = piece[lane 4 j + i / 4][element i % 4]  (probed: tools/micro/tr_read.hip,
-// profiles/r02_tr_read_probe.txt; the emulator's model is checked against that table).  Blocking form (waits for its data):
-// the building block for feeding token-contraction MFMA operands from ROW-MAJOR tiles.
+// profiles/r02_tr_read_probe.txt; the emulator's model is checked against that table): the building block for feeding
+// token-contraction MFMA operands from ROW-MAJOR tiles.
 __device__ __forceinline__ uint2 lds_read_tr16_b64(const void* piece) {
-    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)piece;
-    uint2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return v;
+    typedef short v4s_ __attribute__((ext_vector_type(4)));
+    const v4s_ r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_*)piece);
+    return __builtin_bit_cast(uint2, r);                // (a builtin: the compiler tracks lgkmcnt for it like any LDS read)
 }
+// ... all but the N most recently issued vector-memory LOADS of this wave (loads return in order among themselves, so
+// everything issued before the last N -- e.g. the DMA above -- has landed, whatever stores are still in flight)
 template <int N>
 __device__ __forceinline__ void wait_vmem_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

@@ -18,24 +18,27 @@ FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasin
          "-Wno-unknown-pragmas", "-Wno-attributes", "-Wno-sign-compare"]
 
 
-def stale() -> bool:
-    if not os.path.exists(LIB):
+def stale(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + \
         glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(HERE, "*.cpp")) + \
         glob.glob(os.path.join(ROOT, "include", "*.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False) -> str:
-    if not force and not stale():
-        return LIB
+def build(force: bool = False, defs=(), tag: str = "") -> str:
+    """``defs`` / ``tag``: an opt-in kernel variant (e.g. defs=("-DLINA_K2_TR=1",), tag="tr") built beside the default
+    library as liblina_gla_emu_<tag>.so, so that variants the product does not ship yet are still parity-tested."""
+    lib = LIB if not tag else LIB[:-3] + f"_{tag}.so"
+    if not force and not stale(lib):
+        return lib
     os.makedirs(OUT, exist_ok=True)
     procs, objs = [], []
     for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + [os.path.join(HERE, "emu_runtime.cpp")]:
-        obj = os.path.join(OUT, os.path.basename(src) + ".o")
-        cmd = [CXX, *FLAGS, "-I", HERE, "-I", CSRC, "-x", "c++", "-c", src, "-o", obj]
+        obj = os.path.join(OUT, os.path.basename(src) + (f".{tag}" if tag else "") + ".o")
+        cmd = [CXX, *FLAGS, *defs, "-I", HERE, "-I", CSRC, "-x", "c++", "-c", src, "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
     bad = False
@@ -46,8 +49,8 @@ def build(force: bool = False) -> str:
         bad |= p.returncode != 0
     if bad:
         raise RuntimeError("emulator build failed")
-    subprocess.run([CXX, "-shared", "-fPIC", *objs, "-o", LIB], check=True)
-    return LIB
+    subprocess.run([CXX, "-shared", "-fPIC", *objs, "-o", lib], check=True)
+    return lib
 
 
 if __name__ == "__main__":

@@ -1,0 +1,34 @@
+"""Opt-in kernel variants that the default build does not ship yet, parity-tested on the emulator so that the next GPU
+session can go straight to measuring them.  LINA_K2_TR: K2 / K2b without transposed operand tiles (ds_read_b64_tr_b16)."""
+import pytest
+import torch
+
+from kernel_cases import check_chunk, check_chunk_bwd_full, check_chunk_segmented
+
+DEV = "cpu"
+
+
+@pytest.fixture(scope="module")
+def emu_tr():
+    from conftest import EmuBackend
+    from emu import build_emu
+    from lina_speech_amd import _lib, ops
+    prev = ops.get_backend()
+    ops.set_backend(EmuBackend(_lib.bind(build_emu.build(defs=("-DLINA_K2_TR=1",), tag="tr"), hip_runtime=False)))
+    yield
+    ops.set_backend(prev)
+
+
+@pytest.mark.parametrize("T,resets", [(1, False), (33, False), (70, True), (200, False)])
+def test_tr_variant_chunk_forward(emu_tr, T, resets):
+    check_chunk(DEV, B=1, H=1, T=T, Dk=256, Dv=256, dtype=torch.bfloat16, resets=resets)
+
+
+def test_tr_variant_head_groups_and_segments(emu_tr):
+    check_chunk(DEV, B=1, H=4, T=70, Dk=64, Dv=64, dtype=torch.bfloat16, resets=True)
+    check_chunk_segmented(DEV, 1, 2, 100, 3, resets=True, D=128)
+
+
+@pytest.mark.parametrize("T,nseg,D,H", [(40, 1, 256, 1), (100, 3, 256, 1), (70, 2, 128, 2)])
+def test_tr_variant_backward_sweeps(emu_tr, T, nseg, D, H):
+    check_chunk_bwd_full(DEV, 1, H, T, D, nseg, resets=True)
