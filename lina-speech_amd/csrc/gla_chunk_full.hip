@@ -616,7 +616,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         };
         // ring of k~^T fragments, TA tiles ahead (MODE 1 carries its 8 output factors across this phase: a shallower ring
         // instead of spills, whose reloads would wait on the loader waves' in-flight DMA)
-        constexpr int TA = MODE == 1 ? 3 : 5;
+        constexpr int TA = MODE == 1 ? (kTR && DG ? 2 : 3) : (kTR ? 4 : 5);
         bf16x8 tf[8];
         bf16x8 vb2;                                            // v^T fragment of step (4) (tokens as k-slots 8lg..8lg+7)
         if constexpr (!STATE_ONLY && G > 1) {
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         } else if constexpr (!STATE_ONLY) {
             // (1) o = q~ . S_old : one K = 32 MFMA per pair of 16-row state tiles (converted to bf16 in registers)
             const bf16_t* qp = &s_q[li * SQ + 8 * (lg ^ ((li >> 2) & 3))];
-            constexpr int QA = MODE == 1 ? 2 : 3;             // ring, QA tile pairs ahead (MODE 1: see TA)
+            constexpr int QA = MODE == 1 ? (kTR && DG ? 1 : 2) : 3;             // ring, QA tile pairs ahead (MODE 1: see TA)
             bf16x8 qf[4][2];
 #pragma unroll
             for (int pp = 0; pp < QA; ++pp)
