@@ -32,3 +32,31 @@ def test_tr_variant_head_groups_and_segments(emu_tr):
 @pytest.mark.parametrize("T,nseg,D,H", [(40, 1, 256, 1), (100, 3, 256, 1), (70, 2, 128, 2)])
 def test_tr_variant_backward_sweeps(emu_tr, T, nseg, D, H):
     check_chunk_bwd_full(DEV, 1, H, T, D, nseg, resets=True)
+
+
+@pytest.fixture(scope="module")
+def emu_w32():
+    from conftest import EmuBackend
+    from emu import build_emu
+    from lina_speech_amd import _lib, ops
+    prev = ops.get_backend()
+    lib = build_emu.build(defs=("-DLINA_K2_TR=1", "-DLINA_K2_W32=1"), tag="w32")
+    ops.set_backend(EmuBackend(_lib.bind(lib, hip_runtime=False)))
+    yield
+    ops.set_backend(prev)
+
+
+# LINA_K2_W32: a wave owns 128 state rows x 32 columns (forward and the backward's sweep V at the L169 head shape)
+@pytest.mark.parametrize("T,resets", [(1, False), (17, False), (33, False), (70, True), (200, False)])
+def test_w32_variant_chunk_forward(emu_w32, T, resets):
+    check_chunk(DEV, B=1, H=1, T=T, Dk=256, Dv=256, dtype=torch.bfloat16, resets=resets)
+
+
+def test_w32_variant_segments_and_other_shapes(emu_w32):
+    check_chunk_segmented(DEV, 1, 1, 100, 3, resets=True, D=256)
+    check_chunk(DEV, B=1, H=2, T=40, Dk=128, Dv=128, dtype=torch.bfloat16, resets=True)    # G = 2 keeps the 256 x 16 form
+
+
+@pytest.mark.parametrize("T,nseg", [(40, 1), (100, 3)])
+def test_w32_variant_backward_sweeps(emu_w32, T, nseg):
+    check_chunk_bwd_full(DEV, 1, 1, T, 256, nseg, resets=True)
