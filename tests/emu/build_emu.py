@@ -28,15 +28,21 @@ def stale(lib: str = LIB) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, defs=(), tag: str = "") -> str:
+def build(force: bool = False, defs=(), tag: str = "", only=None) -> str:
     """``defs`` / ``tag``: an opt-in kernel variant (e.g. defs=("-DLINA_K2_TR=1",), tag="tr") built beside the default
-    library as liblina_gla_emu_<tag>.so, so that variants the product does not ship yet are still parity-tested."""
+    library as liblina_gla_emu_<tag>.so, so that variants the product does not ship yet are still parity-tested.
+    ``only``: the source files the definitions affect -- the others are linked from the default build's objects."""
     lib = LIB if not tag else LIB[:-3] + f"_{tag}.so"
+    if tag and only:
+        build(force)                                        # the default objects must exist and be current
     if not force and not stale(lib):
         return lib
     os.makedirs(OUT, exist_ok=True)
     procs, objs = [], []
     for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + [os.path.join(HERE, "emu_runtime.cpp")]:
+        if tag and only and os.path.basename(src) not in only:
+            objs.append(os.path.join(OUT, os.path.basename(src) + ".o"))
+            continue
         obj = os.path.join(OUT, os.path.basename(src) + (f".{tag}" if tag else "") + ".o")
         cmd = [CXX, *FLAGS, *defs, "-I", HERE, "-I", CSRC, "-x", "c++", "-c", src, "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

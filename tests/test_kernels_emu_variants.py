@@ -14,7 +14,7 @@ def emu_tr():
     from emu import build_emu
     from lina_speech_amd import _lib, ops
     prev = ops.get_backend()
-    ops.set_backend(EmuBackend(_lib.bind(build_emu.build(defs=("-DLINA_K2_TR=1",), tag="tr"), hip_runtime=False)))
+    ops.set_backend(EmuBackend(_lib.bind(build_emu.build(defs=("-DLINA_K2_TR=1",), tag="tr", only=("gla_chunk_full.hip",)), hip_runtime=False)))
     yield
     ops.set_backend(prev)
 
@@ -40,7 +40,7 @@ def emu_w32():
     from emu import build_emu
     from lina_speech_amd import _lib, ops
     prev = ops.get_backend()
-    lib = build_emu.build(defs=("-DLINA_K2_TR=1", "-DLINA_K2_W32=1"), tag="w32")
+    lib = build_emu.build(defs=("-DLINA_K2_TR=1", "-DLINA_K2_W32=1"), tag="w32", only=("gla_chunk_full.hip",))
     ops.set_backend(EmuBackend(_lib.bind(lib, hip_runtime=False)))
     yield
     ops.set_backend(prev)
