@@ -60,3 +60,19 @@ def test_w32_variant_segments_and_other_shapes(emu_w32):
 @pytest.mark.parametrize("T,nseg", [(40, 1), (100, 3)])
 def test_w32_variant_backward_sweeps(emu_w32, T, nseg):
     check_chunk_bwd_full(DEV, 1, 1, T, 256, nseg, resets=True)
+
+
+@pytest.mark.parametrize("defs", [("-DLINA_K2_TR=1",), ("-DLINA_K2_TR=1", "-DLINA_K2_W32=1")])
+def test_variants_cross_compile_for_gfx950_without_scratch(defs, tmp_path):
+    """The variants wait for their DMA by counting vector-memory operations like the default build: no kernel may spill."""
+    import os
+    import subprocess
+    from lina_speech_amd import build
+    if not os.path.exists(build.HIPCC):
+        pytest.skip("no hipcc")
+    src = os.path.join(build.CSRC, "gla_chunk_full.hip")
+    cmd = [build.HIPCC, *[f for f in build.FLAGS if f != "-shared"], *defs, "-I", build.CSRC, "-c", src,
+           "-o", str(tmp_path / "v.o"), "-Rpass-analysis=kernel-resource-usage"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    build._check_no_scratch(src, p.stdout + p.stderr)         # raises if a kernel uses scratch
