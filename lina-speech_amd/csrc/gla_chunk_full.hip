@@ -37,10 +37,11 @@
                         // phase A loses its eight 4-byte transposed writes per thread, the workgroup 31 KB of LDS
 #endif
 #ifndef LINA_K2_W32
-#define LINA_K2_W32 0   // 1 (opt-in variant on top of LINA_K2_TR, L169 head shape, forward / sweep V only): a wave owns 128 state rows
-                        // x 32 columns instead of 256 x 16 -- every q~ / k~^T fragment feeds two column tiles, so a wave reads
-                        // half of each operand tile per chunk; the two waves of a column pair add their partial outputs through
-                        // a 32 KB LDS exchange (the space LINA_K2_TR frees) and each finishes 16 of the chunk's 32 tokens
+#define LINA_K2_W32 0   // 1 (opt-in variant on top of LINA_K2_TR, L169 head shape, every sweep): a wave owns 128 state rows x 32
+                        // columns instead of 256 x 16 -- every q~ / k~^T fragment feeds two column tiles, so a wave reads half
+                        // of each operand tile per chunk; the two waves of a column pair swap the partial outputs of each
+                        // other's 16 columns through a 32 KB LDS buffer (the space LINA_K2_TR frees), after which every
+                        // wave holds the output of ITS 16 columns exactly as in the default form (same epilogue, same stores)
 #endif
 #ifndef LINA_K2_ABL
 #define LINA_K2_ABL 0   // tools/k2_ablate.sh builds timing-only variants that skip one phase (results are WRONG there)
@@ -128,9 +129,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     bf16_t* const s_k = s_qk + C * SQ;
     __shared__ __attribute__((aligned(16))) bf16_t s_A[G * 2 * 64 * 8]; // mask(A) as ready-made operands [head][nt][lane][8]
     constexpr bool kTR = LINA_K2_TR != 0;
-    constexpr bool kW32 = LINA_K2_W32 != 0 && G == 1 && MODE == 0 && !STATE_ONLY;
+    // (LINA_K2_W32 = 1: forward and sweep V; = 2: the value-gated sweeps too -- correct, but they do not fit 128 VGPRs yet)
+    constexpr bool kW32 = LINA_K2_W32 != 0 && G == 1 && !STATE_ONLY && (MODE == 0 || LINA_K2_W32 >= 2);
     static_assert(!kW32 || kTR, "LINA_K2_W32 needs the LDS that LINA_K2_TR frees");
-    __shared__ __attribute__((aligned(16))) float s_x[kW32 ? 16 * 2 * 64 * 4 : 4];   // kW32: partial o^T of the other token half
+    __shared__ __attribute__((aligned(16))) float s_x[kW32 ? 16 * 2 * 64 * 4 : 4];   // kW32: partial o^T of the partner's 16 columns
     constexpr int SV = DV + 16;  // kTR: row stride of the chunk-stable row-major v (MODE 1: gated Z) tile
     __shared__ __attribute__((aligned(16))) bf16_t s_T[kTR ? C * SV : (DK + DV) * ST];  // k~^T | v^T   (kTR: row-major v)
     bf16_t* const s_kT = s_T;
@@ -180,10 +182,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     for (int p = 0; p < NTL; ++p) S[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (h0) {                                                // state slot layout [G][D][D] (G = 1: [256][256])
         if constexpr (MODE == 1) {                           // transposed: tile element (row j, column c) = state[c][j]
-            const float* hp = h0 + (((int64_t)slot * G + hw) * D + 16 * wl + li) * D + 4 * lg;
+            const float* hp = h0 + (((int64_t)slot * G + hw) * D + li) * D + 4 * lg;
 #pragma unroll
             for (int p = 0; p < NTL; ++p) {
-                const float4 t4 = *reinterpret_cast<const float4*>(hp + 16 * p);
+                const float4 t4 = *reinterpret_cast<const float4*>(hp + tile_col(p) * D + tile_row(p));
                 S[p] = f32x4{t4.x * h0_scale, t4.y * h0_scale, t4.z * h0_scale, t4.w * h0_scale};
             }
         } else {
@@ -422,20 +424,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         }
     };
     auto store_prev = [&]() {
-        if constexpr (kW32) {                                  // acc[c]: column tile c of token 16 rh + li
-            const int row = 16 * rh + li;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                uint2 po;
-                po.x = pack_bf16x2(acc[c][0] * scale, acc[c][1] * scale);
-                po.y = pack_bf16x2(acc[c][2] * scale, acc[c][3] * scale);
-                if (row < np) {
-                    const unsigned boff = 2u * (out_row(tp + row) * (unsigned)so.t + 32u * (unsigned)cp + 16u * (unsigned)c +
-                                                4u * (unsigned)lg);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) + boff) = po;
-                }
-            }
-        } else
         if constexpr (!STATE_ONLY && MODE == 0) {
 #pragma unroll
             for (int nt = 0; nt < (LINA_K2_ABL == 8 ? 0 : 2); ++nt) {
@@ -647,17 +635,13 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         constexpr int TA = MODE == 1 ? (kTR && DG ? 2 : 3) : (kTR ? 4 : 5);
         bf16x8 tf[8];
         bf16x8 vb2;                                            // v^T fragment of step (4) (tokens as k-slots 8lg..8lg+7)
-        bf16x8 vbw[2];                                         // kW32: step (3)'s v^T fragments of the two column tiles
-        f32x4 accw[2] = {};                                    // kW32: o^T of column tile 1 (acc[] = column tile 0), per token tile
+        bf16x8 vb;                                             // v^T fragment of step (3), read before the tiles die at (3)
+        f32x4 xown[2];                                         // kW32: this wave's partial o^T of its own 16 columns, per token tile
         if constexpr (kW32) {
             // ---- the 128 x 32 block form: tiles S[2p + c], p = row tile of this wave's row half, c = column tile ----
             auto v8c = [&](int c) {                            // v^T of column tile c, tokens 8 lg .. 8 lg + 7
                 const bf16_t* b = &s_vr[(8 * lg + (li >> 2)) * SV + 32 * cp + 16 * c + 4 * (li & 3)];
                 return tr8(b, b + 4 * SV);
-            };
-            auto v4c = [&](int c) {                            // ... tokens 4 lg .. +3 and 16 + 4 lg .. +3 (step (3))
-                const bf16_t* b = &s_vr[(4 * lg + (li >> 2)) * SV + 32 * cp + 16 * c + 4 * (li & 3)];
-                return tr8(b, b + 16 * SV);
             };
             // (1) partial o^T over this wave's 128 rows: tile pairs pp = 0..3 = k-steps 4 rh + pp of the q~ tile; every q~
             //     fragment feeds BOTH column tiles
@@ -668,6 +652,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) qf[pp][nt] = frag16(qp + 16 * nt * SQ + 32 * pp);
             bf16x8 vbc[2];
+            f32x4 accw[2] = {};                                // o^T of column tile 1 (acc[] = column tile 0), per token tile
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
                 if (pp + 2 < 4) {
@@ -696,6 +681,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 sched_fence();
             }
             tp = t0; np = n;
+            if constexpr (DG) { prefetch_prev(); sched_fence(); }
             // (4) S' += k^^T v: every k~^T fragment feeds both column tiles
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
@@ -705,19 +691,28 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 S[2 * p + 1] = mfma_bf16_16x16x32(tf[p & 7], vbc[1], S[2 * p + 1]);
                 sched_fence();
             }
-            if (renorm) {                                      // rare: S' <- e^{R} S'
+            if (renorm && MODE == 1) {                         // rare: the gated channel is the tile COLUMN
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) {
+                    const float f = fast_exp2(s_Rn[tile_col(t) + li]);
+                    S[t][0] *= f; S[t][1] *= f; S[t][2] *= f; S[t][3] *= f;
+                }
+            } else if (renorm) {                               // rare: S' <- e^{R} S'
 #pragma unroll
                 for (int t = 0; t < NTL; ++t) {
                     const float4 r4 = *reinterpret_cast<const float4*>(&s_Rn[tile_ch(t) + 4 * lg]);
                     S[t][0] *= fast_exp2(r4.x); S[t][1] *= fast_exp2(r4.y); S[t][2] *= fast_exp2(r4.z); S[t][3] *= fast_exp2(r4.w);
                 }
             }
-            vbw[0] = v4c(0); vbw[1] = v4c(1);
-            // this wave finishes token tile nt = rh; the other token tile's partial sums go to the partner wave (w ^ 1)
+            vb = ld_v4();                                      // this wave's OWN 16 columns (column tile rh of the pair) = [16 w, 16 w + 16)
+            // the partial sums of the partner's 16 columns (column tile 1 - rh) cross to wave w ^ 1; this wave keeps its own
             float4* xw = reinterpret_cast<float4*>(&s_x[((w * 2) * 64 + lane) * 4]);
-            const f32x4 x0 = rh ? acc[0] : acc[1], x1 = rh ? accw[0] : accw[1];
-            xw[0] = make_float4(x0[0], x0[1], x0[2], x0[3]);
-            xw[64] = make_float4(x1[0], x1[1], x1[2], x1[3]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x4 give = rh ? acc[nt] : accw[nt];
+                xown[nt] = rh ? accw[nt] : acc[nt];
+                xw[64 * nt] = make_float4(give[0], give[1], give[2], give[3]);
+            }
         } else
         if constexpr (!STATE_ONLY && G > 1) {
             // (1) for G heads per workgroup: the same products over this head's NTL/2 tile pairs (channels
@@ -829,7 +824,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         }
         // v fragment of step (3) (same token order as the C/D rows of mask(A)): read before the tiles die at (3)
         }   // !kW32
-        bf16x8 vb;
         if constexpr (!STATE_ONLY && !kW32) {
             vb = ld_v4();
         }
@@ -841,17 +835,14 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         K2_PROF(9);
         lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;   // re-derive, do not carry
         if (tid == 0) { s_flags[2 * par] = 0; s_flags[2 * par + 1] = 0; }   // read by all before (3); set again two chunks later, after (2) of the next
-        if constexpr (kW32) {
-            // (3) for this wave's token tile (nt = rh) and both column tiles, + the partner's partial sums over the other 128 rows
-            const bf16x8 af = frag16(&s_A[(rh * 64 + lane) * 8]);
-            f32x4 o0 = rh ? acc[1] : acc[0], o1 = rh ? accw[1] : accw[0];
-            o0 = mfma_bf16_16x16x32(vbw[0], af, o0);
-            o1 = mfma_bf16_16x16x32(vbw[1], af, o1);
+        if constexpr (kW32) {                                  // + the partner's partial sums over the other 128 rows
             const float4* xr = reinterpret_cast<const float4*>(&s_x[(((w ^ 1) * 2) * 64 + lane) * 4]);
-            const float4 p0 = xr[0], p1 = xr[64];
-            acc[0] = f32x4{o0[0] + p0.x, o0[1] + p0.y, o0[2] + p0.z, o0[3] + p0.w};   // column tile 0 | 1 of token tile rh
-            acc[1] = f32x4{o1[0] + p1.x, o1[1] + p1.y, o1[2] + p1.z, o1[3] + p1.w};
-        } else
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float4 pt = xr[64 * nt];
+                acc[nt] = f32x4{xown[nt][0] + pt.x, xown[nt][1] + pt.y, xown[nt][2] + pt.z, xown[nt][3] + pt.w};
+            }
+        }
         if constexpr (!STATE_ONLY) {
             // (3) o += mask(A) . v -- AFTER the barrier: no barrier of its own for mask(A); s_A is rewritten only after the
             //     next chunk's barrier (2)

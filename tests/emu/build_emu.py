@@ -14,7 +14,10 @@ CSRC = os.path.join(ROOT, "lina-speech_amd", "csrc")
 OUT = os.path.join(ROOT, "tests", "_emu_build")
 LIB = os.path.join(OUT, "liblina_gla_emu.so")
 CXX = os.environ.get("CXX", "g++")
-FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasing", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+# -fno-gnu-unique: the kernels' `__shared__` arrays are function-local statics of template functions; with GNU unique symbols
+# two emulator libraries loaded into one process (the default build and an opt-in variant) would SHARE them, sized by
+# whichever was loaded first
+FLAGS = ["-O2", "-std=c++17", "-fPIC", "-fno-gnu-unique", "-ffp-contract=off", "-fno-strict-aliasing", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
          "-Wno-unknown-pragmas", "-Wno-attributes", "-Wno-sign-compare"]
 
 

@@ -40,13 +40,13 @@ def emu_w32():
     from emu import build_emu
     from lina_speech_amd import _lib, ops
     prev = ops.get_backend()
-    lib = build_emu.build(defs=("-DLINA_K2_TR=1", "-DLINA_K2_W32=1"), tag="w32", only=("gla_chunk_full.hip",))
+    lib = build_emu.build(defs=("-DLINA_K2_TR=1", "-DLINA_K2_W32=2"), tag="w32", only=("gla_chunk_full.hip",))   # 2: every sweep
     ops.set_backend(EmuBackend(_lib.bind(lib, hip_runtime=False)))
     yield
     ops.set_backend(prev)
 
 
-# LINA_K2_W32: a wave owns 128 state rows x 32 columns (forward and the backward's sweep V at the L169 head shape)
+# LINA_K2_W32: a wave owns 128 state rows x 32 columns (every sweep at the L169 head shape)
 @pytest.mark.parametrize("T,resets", [(1, False), (17, False), (33, False), (70, True), (200, False)])
 def test_w32_variant_chunk_forward(emu_w32, T, resets):
     check_chunk(DEV, B=1, H=1, T=T, Dk=256, Dv=256, dtype=torch.bfloat16, resets=resets)
@@ -57,9 +57,9 @@ def test_w32_variant_segments_and_other_shapes(emu_w32):
     check_chunk(DEV, B=1, H=2, T=40, Dk=128, Dv=128, dtype=torch.bfloat16, resets=True)    # G = 2 keeps the 256 x 16 form
 
 
-@pytest.mark.parametrize("T,nseg", [(40, 1), (100, 3)])
-def test_w32_variant_backward_sweeps(emu_w32, T, nseg):
-    check_chunk_bwd_full(DEV, 1, 1, T, 256, nseg, resets=True)
+@pytest.mark.parametrize("T,nseg,h0,dht", [(40, 1, True, True), (100, 3, True, True), (33, 1, False, False), (200, 2, True, False)])
+def test_w32_variant_backward_sweeps(emu_w32, T, nseg, h0, dht):
+    check_chunk_bwd_full(DEV, 1, 1, T, 256, nseg, resets=True, with_h0=h0, with_dht=dht)
 
 
 @pytest.mark.parametrize("defs", [("-DLINA_K2_TR=1",), ("-DLINA_K2_TR=1", "-DLINA_K2_W32=1")])
