@@ -129,8 +129,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     bf16_t* const s_k = s_qk + C * SQ;
     __shared__ __attribute__((aligned(16))) bf16_t s_A[G * 2 * 64 * 8]; // mask(A) as ready-made operands [head][nt][lane][8]
     constexpr bool kTR = LINA_K2_TR != 0;
-    // (LINA_K2_W32 = 1: forward and sweep V; = 2: the value-gated sweeps too -- correct, but they do not fit 128 VGPRs yet)
-    constexpr bool kW32 = LINA_K2_W32 != 0 && G == 1 && !STATE_ONLY && (MODE == 0 || LINA_K2_W32 >= 2);
+    constexpr bool kW32 = LINA_K2_W32 != 0 && G == 1 && !STATE_ONLY;
     static_assert(!kW32 || kTR, "LINA_K2_W32 needs the LDS that LINA_K2_TR frees");
     __shared__ __attribute__((aligned(16))) float s_x[kW32 ? 16 * 2 * 64 * 4 : 4];   // kW32: partial o^T of the partner's 16 columns
     constexpr int SV = DV + 16;  // kTR: row stride of the chunk-stable row-major v (MODE 1: gated Z) tile
@@ -646,19 +645,21 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             // (1) partial o^T over this wave's 128 rows: tile pairs pp = 0..3 = k-steps 4 rh + pp of the q~ tile; every q~
             //     fragment feeds BOTH column tiles
             const bf16_t* qp = &s_q[li * SQ + 8 * (lg ^ ((li >> 2) & 3)) + 128 * rh];
+            constexpr int WA = MODE == 1 ? 1 : 2;              // operand rings: WA tile pairs / k~^T tiles ahead (MODE 1 carries more)
             bf16x8 qf[4][2];
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp)
+            for (int pp = 0; pp < WA; ++pp)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) qf[pp][nt] = frag16(qp + 16 * nt * SQ + 32 * pp);
             bf16x8 vbc[2];
             f32x4 accw[2] = {};                                // o^T of column tile 1 (acc[] = column tile 0), per token tile
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
-                if (pp + 2 < 4) {
+                if (pp + WA < 4) {
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) qf[pp + 2][nt] = frag16(qp + 16 * nt * SQ + 32 * (pp + 2));
-                } else if (pp == 2) {                          // the free slots take step (4)'s first operands
+                    for (int nt = 0; nt < 2; ++nt) qf[pp + WA][nt] = frag16(qp + 16 * nt * SQ + 32 * (pp + WA));
+                } else if (MODE == 1) {                        // (value-gated sweeps: step (4)'s operands after step (1))
+                } else if (pp == 4 - WA) {                     // the free slots take step (4)'s first operands
                     vbc[0] = v8c(0); vbc[1] = v8c(1);
                 } else {
                     tf[0] = ld_kt(8 * rh); tf[1] = ld_kt(8 * rh + 1);
@@ -681,16 +682,17 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 sched_fence();
             }
             tp = t0; np = n;
-            if constexpr (DG) { prefetch_prev(); sched_fence(); }
+            if constexpr (MODE == 1) { vbc[0] = v8c(0); vbc[1] = v8c(1); tf[0] = ld_kt(8 * rh); }
             // (4) S' += k^^T v: every k~^T fragment feeds both column tiles
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                if (p + 2 < 8) tf[(p + 2) & 7] = ld_kt(8 * rh + p + 2);
+                if (p + WA < 8) tf[(p + WA) & 7] = ld_kt(8 * rh + p + WA);
                 sched_fence();
                 S[2 * p] = mfma_bf16_16x16x32(tf[p & 7], vbc[0], S[2 * p]);
                 S[2 * p + 1] = mfma_bf16_16x16x32(tf[p & 7], vbc[1], S[2 * p + 1]);
                 sched_fence();
             }
+            if constexpr (DG) { prefetch_prev(); sched_fence(); }   // (after step (4): its operands' registers are free)
             if (renorm && MODE == 1) {                         // rare: the gated channel is the tile COLUMN
 #pragma unroll
                 for (int t = 0; t < NTL; ++t) {

@@ -40,7 +40,7 @@ def emu_w32():
     from emu import build_emu
     from lina_speech_amd import _lib, ops
     prev = ops.get_backend()
-    lib = build_emu.build(defs=("-DLINA_K2_TR=1", "-DLINA_K2_W32=2"), tag="w32", only=("gla_chunk_full.hip",))   # 2: every sweep
+    lib = build_emu.build(defs=("-DLINA_K2_TR=1", "-DLINA_K2_W32=1"), tag="w32", only=("gla_chunk_full.hip",))
     ops.set_backend(EmuBackend(_lib.bind(lib, hip_runtime=False)))
     yield
     ops.set_backend(prev)
