@@ -681,6 +681,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 }
                 sched_fence();
             }
+            K2_PROF(11);                                       // (profile build: step (1) of this form; slot 4 then holds its step (4))
             tp = t0; np = n;
             if constexpr (MODE == 1) { vbc[0] = v8c(0); vbc[1] = v8c(1); tf[0] = ld_kt(8 * rh); }
             // (4) S' += k^^T v: every k~^T fragment feeds both column tiles

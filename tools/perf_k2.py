@@ -45,11 +45,11 @@ if os.environ.get("K2_PROF"):
     rc = lib.lina_k2_prof_read(buf.ctypes.data_as(ctypes.c_void_p))
     a = buf[:256].reshape(16, 16).astype(np.float64) / (T / 32)
     names = ["phaseA", "bar(2)", "flags/roll", "maskA(w<4)", "step1 qS", "step4 upd", "bar(1')+dma", "rawrd+step3", "wait_vmem",
-             "bar(3)", "o stores"]   # o stores: of the previous chunk, at the end of phase A
+             "bar(3)", "o stores", "w32 step1"]   # o stores: of the previous chunk, at the end of phase A; w32 step1: LINA_K2_W32 builds
     print("clk/chunk per phase (shader clock), waves 0, 3, 4, 15 and mean:  rc =", rc)
     for i, nm in enumerate(names):
         print(f"  {nm:12s} " + " ".join(f"{a[w, i]:8.0f}" for w in (0, 3, 4, 15)) + f"   mean {a[:, i].mean():8.0f}")
-    print(f"  total        {a[0, :11].sum():8.0f}")
+    print(f"  total        {a[0, :12].sum():8.0f}")
     wg = buf[256:256 + 3 * B * H].reshape(-1, 3).astype(np.float64) / (T / 32)
     print("per-workgroup clk/chunk (wave 0): total min/median/max", np.min(wg[:, 0]), np.median(wg[:, 0]), np.max(wg[:, 0]),
           " wait_vmem median/max", np.median(wg[:, 1]), np.max(wg[:, 1]), " bar(3) median/max", np.median(wg[:, 2]), np.max(wg[:, 2]))
