@@ -603,14 +603,17 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             K2_PROF(3);
         }
         const bf16_t* ktp = &s_kT[(16 * NTL * hw + li) * ST + 8 * lg];   // k~^T fragment of this head's state tile p: + 16 p ST
-        // operand fragments whose K dimension is the token axis.  kTR: two transposing reads each (tokens T0 .. T0+3 and
-        // T0+4 .. T0+7 of 16 channels; a 16-lane group addresses row T0 + (li>>2), channel quad li&3 and lane li receives
-        // channel li) straight from the row-major tiles -- the k~ tile with its channel permutation and piece swizzle
+        // operand fragments whose K dimension is the token axis.  kTR: two transposing reads each (four tokens of 16 channels
+        // per read; a 16-lane group addresses row T0 + (li>>2), channel quad li&3 and lane li receives channel li) straight
+        // from the row-major tiles -- the k~ tile through its channel permutation and piece swizzle.  The token <-> k-slot
+        // map of a product is free as long as both operands share it: under kTR lane group lg takes tokens 4 lg .. 4 lg + 3
+        // and 16 + 4 lg .. + 3 in BOTH step (3) and step (4) (a 32-lane service group of the read then touches 8 consecutive
+        // rows: distinct banks on the 544-byte rows, and step (4)'s v fragment is step (3)'s)
         auto tr8 = [&](const bf16_t* p0, const bf16_t* p1) { return as_bf16x8(lds_read_tr16_b64(p0), lds_read_tr16_b64(p1)); };
         auto ld_kt = [&](int p) -> bf16x8 {                    // k~^T of this head's state row tile p, tokens 8 lg .. 8 lg + 7
             if constexpr (!kTR) return frag16(ktp + 16 * p * ST);
             else {
-                const int m16 = NTL * hw + p, t0 = 8 * lg + (li >> 2), t1 = t0 + 4;
+                const int m16 = NTL * hw + p, t0 = 4 * lg + (li >> 2), t1 = t0 + 16;
                 const bf16_t* b = &s_k[32 * (m16 >> 1) + 4 * (m16 & 1)];
                 return tr8(b + t0 * SK + 8 * ((li & 3) ^ ((t0 >> 2) & 3)), b + t1 * SK + 8 * ((li & 3) ^ ((t1 >> 2) & 3)));
             }
@@ -618,8 +621,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         auto ld_v8 = [&]() -> bf16x8 {                         // v^T of this wave's 16 columns, tokens 8 lg .. 8 lg + 7
             if constexpr (!kTR) return frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
             else {
-                const bf16_t* b = &s_vr[(8 * lg + (li >> 2)) * SV + 16 * w + 4 * (li & 3)];
-                return tr8(b, b + 4 * SV);
+                const bf16_t* b = &s_vr[(4 * lg + (li >> 2)) * SV + 16 * w + 4 * (li & 3)];
+                return tr8(b, b + 16 * SV);
             }
         };
         auto ld_v4 = [&]() -> bf16x8 {                         // ... tokens 4 lg .. 4 lg + 3 and 16 + 4 lg .. 16 + 4 lg + 3
@@ -638,9 +641,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         f32x4 xown[2];                                         // kW32: this wave's partial o^T of its own 16 columns, per token tile
         if constexpr (kW32) {
             // ---- the 128 x 32 block form: tiles S[2p + c], p = row tile of this wave's row half, c = column tile ----
-            auto v8c = [&](int c) {                            // v^T of column tile c, tokens 8 lg .. 8 lg + 7
-                const bf16_t* b = &s_vr[(8 * lg + (li >> 2)) * SV + 32 * cp + 16 * c + 4 * (li & 3)];
-                return tr8(b, b + 4 * SV);
+            auto v8c = [&](int c) {                            // v^T of column tile c, tokens 4 lg .. + 3 and 16 + 4 lg .. + 3
+                const bf16_t* b = &s_vr[(4 * lg + (li >> 2)) * SV + 32 * cp + 16 * c + 4 * (li & 3)];
+                return tr8(b, b + 16 * SV);
             };
             // (1) partial o^T over this wave's 128 rows: tile pairs pp = 0..3 = k-steps 4 rh + pp of the q~ tile; every q~
             //     fragment feeds BOTH column tiles
@@ -707,7 +710,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                     S[t][0] *= fast_exp2(r4.x); S[t][1] *= fast_exp2(r4.y); S[t][2] *= fast_exp2(r4.z); S[t][3] *= fast_exp2(r4.w);
                 }
             }
-            vb = ld_v4();                                      // this wave's OWN 16 columns (column tile rh of the pair) = [16 w, 16 w + 16)
+            // step (3)'s v fragment: this wave's OWN 16 columns (column tile rh of the pair), same token map as step (4)
+            if constexpr (DG) vb = ld_v4();                    // (sweep K: re-read instead of keeping both tiles' fragments alive)
+            else vb = rh ? vbc[1] : vbc[0];
             // the partial sums of the partner's 16 columns (column tile 1 - rh) cross to wave w ^ 1; this wave keeps its own
             float4* xw = reinterpret_cast<float4*>(&s_x[((w * 2) * 64 + lane) * 4]);
 #pragma unroll
@@ -828,7 +833,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         // v fragment of step (3) (same token order as the C/D rows of mask(A)): read before the tiles die at (3)
         }   // !kW32
         if constexpr (!STATE_ONLY && !kW32) {
-            vb = ld_v4();
+            if constexpr (kTR) vb = vb2;                       // same columns, same token map
+            else vb = ld_v4();
         }
         K2_PROF(5);
         // the DMA was issued through inline assembly: this wave's part has landed (the DG rows requested after it may not) ...
