@@ -201,6 +201,15 @@ int lina_greedy_pick_embed(const void* logits, int64_t row_stride, const void* t
                            void* x_out_packed, int64_t* tok_log, int64_t* step, int* counter, int B, int Q, int L,
                            int n_emb, int d, int max_steps, int dtype, lina_stream_t stream);
 
+/* K6e -- K6d for the reference's DEFAULT generation mode (model/modeling_lina.py:119-121,159-164, tools.py:38-44):
+ * quantizers q < n_sampled are SAMPLED (top-k / temperature, K6c) and the others take the arg-max (K6b); everything else
+ * as lina_greedy_pick_embed.  The uniform number of (row b, quantizer q) is the one lina_topk_sample_rows hashes for row
+ * b*Q + q of a [B*Q]-row call at the same (seed, step[0]): the tokens equal those of the separate launches. */
+int lina_sample_pick_embed(const void* logits, int64_t row_stride, const void* table, void* x_out,
+                           void* x_out_packed, int64_t* tok_log, int64_t* step, int* counter, int B, int Q, int L,
+                           int n_emb, int d, int max_steps, int n_sampled, int k, float temp, uint64_t seed, int dtype,
+                           lina_stream_t stream);
+
 /* K6b -- greedy pick: out[r] = argmax_j logits[r,j], lowest index on exact ties.
  * Replaces topk_sampling(k=1) (reference model/tools.py:38-44, modeling_lina.py:159-164);
  * identical except on exact ties, where the reference draws uniformly among them. */

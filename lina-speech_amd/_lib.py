@@ -46,6 +46,8 @@ PROTOTYPES = {
                                         _f, _i, _i, _p]),
     "lina_embed_sum": (C.c_int, [_p, _p, _p, _i, _i64, _i, _i, _i, _p]),
     "lina_greedy_pick_embed": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "lina_sample_pick_embed": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, C.c_uint64,
+                                         _i, _p]),
     "lina_argmax_rows": (C.c_int, [_p, _p, _i64, _i, _i64, _i, _p]),
     "lina_topk_sample_rows": (C.c_int, [_p, _p, _i64, _i, _i64, _i, _f, _p, C.c_uint64, _p, _i, _p]),
     "lina_dwconv7_ln": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _f, _i, _p]),

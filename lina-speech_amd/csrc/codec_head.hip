@@ -4,8 +4,7 @@
 // model/modeling_lina.py:131,178-179); K6b replaces topk_sampling(k=1) (reference model/tools.py:38-44,
 // model/modeling_lina.py:159-164).  SURVEY.md 8(a) a-10.  Both are tiny, latency-bound device-side
 // steps of the decode loop; they exist so the loop needs no host round trip.
-#include <lina_dev.h>
-#include "lina_common.h"
+#include "sample_dev.h"
 #include "skinny_frag.h"
 
 namespace lina {
@@ -123,6 +122,69 @@ __global__ __launch_bounds__(256) void greedy_pick_embed_kernel(const T* __restr
     }
 }
 
+// K6e -- the token epilogue of a decode step in the reference's DEFAULT generation mode (model/modeling_lina.py:119-121,
+// 159-164: quantizers q < first_greedy_quant are SAMPLED with top-k / temperature, the others take the arg-max), in one
+// launch like K6d: per batch row the Q picks (K6c on the sampled quantizers with the uniform number of row b*Q + q of a
+// [B*Q]-row lina_topk_sample_rows call at the same (seed, step) -- the tokens are the ones the separate launches give --,
+// K6b on the others), the token log, the next-input embedding (row-major and, optionally, fragment-major) and step[0] += 1.
+template <typename T>
+__global__ __launch_bounds__(256) void sample_pick_embed_kernel(const T* __restrict__ logits, int64_t row_stride,
+                                                                const T* __restrict__ table, T* __restrict__ x_out,
+                                                                int64_t* __restrict__ tok_log, int64_t* step, int* counter,
+                                                                int Q, int L, int n_emb, int d, int max_steps,
+                                                                T* __restrict__ x_pk, int n_sampled, int k, float inv_temp,
+                                                                uint64_t seed) {
+    LINA_DYN_SMEM(smem_raw);
+    float* s_x = reinterpret_cast<float*>(smem_raw);            // [L] the row being sampled
+    __shared__ SampleScratch sc;
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    __shared__ int s_tok[16];
+    __shared__ int64_t s_step;
+    const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x;
+    if (tid == 0) s_step = step[0];
+    __syncthreads();
+    const int64_t t = s_step;
+    for (int qi = 0; qi < Q; ++qi) {
+        const T* row = logits + (int64_t)b * row_stride + (int64_t)qi * L;
+        int pick;
+        if (qi < n_sampled) {
+            for (int j = tid; j < L; j += 256) s_x[j] = ld(row + j);
+            const float u = hash_uniform(seed, (uint64_t)t, (uint64_t)b * Q + qi, (uint64_t)B * Q);
+            pick = topk_sample_block(s_x, L, k, inv_temp, u, sc);
+        } else {
+            pick = argmax_block(row, L, s_val, s_idx);
+        }
+        if (tid == 0) {
+            s_tok[qi] = pick;
+            if (t >= 0 && t < max_steps) tok_log[(t * Q + qi) * B + b] = pick;
+        }
+    }
+    __syncthreads();
+    for (int e = tid * 4; e < d; e += 256 * 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int qi = 0; qi < Q; ++qi) {
+            int tok = s_tok[qi];
+            tok = tok >= n_emb ? n_emb - 1 : tok;
+            const float4 r = ld4(table + ((int64_t)qi * n_emb + tok) * d + e);
+            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+        }
+        st4(x_out + (int64_t)b * d + e, acc);
+        if (x_pk) {                                  // fragment-major copy (the model-dtype values just stored)
+            T tmp4[4];
+            st4(tmp4, acc);
+            st4(x_pk + packed_off<T>(b, e, d), ld4(tmp4));
+        }
+    }
+    if (tid == 0) {
+        const int tk = ticket_agent(counter);       // taken AFTER this workgroup has read step[0]
+        if (tk == B - 1) {
+            *counter = 0;                            // re-armed for the next launch
+            step[0] = t + 1;
+        }
+    }
+}
+
 }  // namespace lina
 
 extern "C" int lina_greedy_pick_embed(const void* logits, int64_t row_stride, const void* table, void* x_out,
@@ -145,6 +207,33 @@ extern "C" int lina_greedy_pick_embed(const void* logits, int64_t row_stride, co
                     (const bf16_t*)table, (bf16_t*)x_out, tok_log, step, counter, Q, L, n_emb, d, max_steps,
                     (bf16_t*)x_out_packed);
     return check_launch("lina_greedy_pick_embed");
+}
+
+extern "C" int lina_sample_pick_embed(const void* logits, int64_t row_stride, const void* table, void* x_out,
+                                      void* x_out_packed, int64_t* tok_log, int64_t* step, int* counter, int B, int Q,
+                                      int L, int n_emb, int d, int max_steps, int n_sampled, int k, float temp,
+                                      uint64_t seed, int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(logits && table && x_out && tok_log && step && counter, "lina_sample_pick_embed: null pointer");
+    LINA_REQUIRE(B > 0 && Q > 0 && Q <= 16 && L > 0 && n_emb > 0 && max_steps > 0,
+                 "lina_sample_pick_embed: B,Q (<= 16),L,n_emb,max_steps must be positive");
+    LINA_REQUIRE(d > 0 && d % 4 == 0, "lina_sample_pick_embed: d=%d must be a positive multiple of 4", d);
+    LINA_REQUIRE(n_sampled >= 0 && n_sampled <= Q, "lina_sample_pick_embed: n_sampled must be in [0, Q]");
+    LINA_REQUIRE(k >= 1 && temp > 0.0f, "lina_sample_pick_embed: k must be >= 1 and temp positive");
+    LINA_REQUIRE(valid_dtype(dtype), "lina_sample_pick_embed: bad dtype %d", dtype);
+    LINA_REQUIRE(!x_out_packed || d % (dtype == LINA_BF16 ? 32 : 16) == 0, "lina_sample_pick_embed: packed copy needs whole k-steps");
+    if (L > kSampleMaxN) return fail(LINA_ERR_UNSUPPORTED, "lina_sample_pick_embed: L=%d exceeds %d", L, kSampleMaxN);
+    dim3 grid((unsigned)B);
+    const size_t smem = n_sampled > 0 ? (size_t)L * sizeof(float) : 0;
+    if (dtype == LINA_F32)
+        LINA_LAUNCH((sample_pick_embed_kernel<float>), grid, dim3(256), smem, stream, (const float*)logits, row_stride,
+                    (const float*)table, (float*)x_out, tok_log, step, counter, Q, L, n_emb, d, max_steps,
+                    (float*)x_out_packed, n_sampled, k, 1.0f / temp, seed);
+    else
+        LINA_LAUNCH((sample_pick_embed_kernel<bf16_t>), grid, dim3(256), smem, stream, (const bf16_t*)logits, row_stride,
+                    (const bf16_t*)table, (bf16_t*)x_out, tok_log, step, counter, Q, L, n_emb, d, max_steps,
+                    (bf16_t*)x_out_packed, n_sampled, k, 1.0f / temp, seed);
+    return check_launch("lina_sample_pick_embed");
 }
 
 extern "C" int lina_embed_sum(const int64_t* idx, const void* table, void* out, int Q, int64_t N, int n_emb, int d,

@@ -27,6 +27,19 @@
 #define LINA_K1W_HIST_NT 0     // experiment: window-history loads / stores with the non-temporal hint
 #endif
 
+// experiments (tools/probe_decode.py builds them into tools/abl/; the product build leaves both at 0)
+#ifndef LINA_K1W_STATE_PLAIN
+#define LINA_K1W_STATE_PLAIN 0  // state loads WITHOUT the non-temporal hint (is a cache-resident state any faster?)
+#endif
+#ifndef LINA_K1W_NO_TAIL_LOADS
+#define LINA_K1W_NO_TAIL_LOADS 0  // WRONG RESULTS: the K5 tail without its norm-weight / gate loads (what does their latency cost?)
+#endif
+#if LINA_K1W_STATE_PLAIN
+#define LINA_K1W_STATE_LOAD(p) (*reinterpret_cast<const float4*>(p))
+#else
+#define LINA_K1W_STATE_LOAD(p) ld_nt4(p)
+#endif
+
 namespace lina {
 
 constexpr int kWinMax = 8;
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
 
     float4 St[NP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) St[i] = ld_nt4(tile + (int64_t)(rg + RPI * i) * DVT);
+    for (int i = 0; i < NP; ++i) St[i] = LINA_K1W_STATE_LOAD(tile + (int64_t)(rg + RPI * i) * DVT);
 
     // ---- per-row gate bookkeeping and the window's v rows
     if (row_wave) {
@@ -238,9 +251,13 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
         auto finish = [&](float4 x, int c0, float rs) {
             if (tid < CG) {
                 x.x *= rs; x.y *= rs; x.z *= rs; x.w *= rs;
+#if LINA_K1W_NO_TAIL_LOADS
+                const float4 ww = make_float4(1.f, 1.f, 1.f, 1.f), gg = make_float4(eps, scale, eps, scale);
+#else
                 const float4 ww = ld4(nw + c0 + 4 * tid);
-                x.x *= ww.x; x.y *= ww.y; x.z *= ww.z; x.w *= ww.w;
                 const float4 gg = ld4(gate + b * gate_sb + h * gate_sh + c0 + 4 * tid);
+#endif
+                x.x *= ww.x; x.y *= ww.y; x.z *= ww.z; x.w *= ww.w;
                 x.x *= gg.x * sigmoidf(gg.x); x.y *= gg.y * sigmoidf(gg.y);
                 x.z *= gg.z * sigmoidf(gg.z); x.w *= gg.w * sigmoidf(gg.w);
                 if (og_packed) st4(og + packed_off<TIO>(b, h * DVT + c0 + 4 * tid, H * DVT), x);   // 4 | KL: one piece

@@ -11,21 +11,39 @@
 #include <lina_dev.h>
 #include "lina_common.h"
 #include "skinny_frag.h"
+#include <stdlib.h>
+
+#ifdef LINA_SKINNY_PROF
+// tools-only build (tools/skinny_prof.sh): time stamps of thread 0 of every workgroup, [workgroup][slot] (slots as in
+// linear_skinny.hip).  NOT part of the product library.
+__device__ unsigned long long lina_inproj_prof[1024 * 8];
+#define IP_PROF(i, expr) do { if (threadIdx.x == 0) pr_[i] = (expr); } while (0)
+#define IP_PROF_FLUSH() do { IP_PROF(5, clock64()); IP_PROF(6, wall_clock64()); if (threadIdx.x == 0 && blockIdx.x < 1024) \
+        for (int i_ = 0; i_ < 8; ++i_) lina_inproj_prof[blockIdx.x * 8 + i_] = pr_[i_]; } while (0)
+#else
+#define IP_PROF(i, expr) do { } while (0)
+#define IP_PROF_FLUSH() do { } while (0)
+#endif
 
 namespace lina {
 
-template <typename T, int NT, bool PK, bool WNT>
-__global__ __launch_bounds__(256) void gla_inproj_kernel(
+template <typename T, int NT, bool PK, bool WNT, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
     const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw, const float* __restrict__ c1,
     const float* __restrict__ c2, const T* __restrict__ wq, const T* __restrict__ wk, const T* __restrict__ wv,
     T* cq, T* ck, T* cv, const T* __restrict__ w2, const T* __restrict__ b2, T* __restrict__ qkv,
     T* __restrict__ g_out, float* __restrict__ gk, int M, int K, int Kd, int Vd, float ln_eps, float inv_norm,
     float clamp_min, int has_clamp) {
     using F = Frag<T>;              // WNT: weight fragments with the non-temporal load hint
+#ifdef LINA_SKINNY_PROF
+    unsigned long long pr_[8] = {};
+    IP_PROF(0, wall_clock64());
+    IP_PROF(1, clock64());
+#endif
     constexpr int R = 16, MT = 4;
-    constexpr int U = (NT + MT) * 8 <= 48 ? 8 : 4;
-    __shared__ __attribute__((aligned(16))) float s_acc[4][NT * MT][64][4];
-    __shared__ float s_st[4][64][2];
+    constexpr int U = NW > 8 ? 2 : (NW > 4 || (NT + MT) * 8 > 48) ? 4 : 8;   // NW: split-K width, see linear_skinny.hip
+    __shared__ __attribute__((aligned(16))) float s_acc[NW][NT * MT][64][4];
+    __shared__ float s_st[NW][64][2];
     __shared__ float s_lr[64][R + 1];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -76,7 +94,17 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
         pre_wj[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) pre_old[j][r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!gate_wg && n < 2 * Kd + Vd) {
+        if (w >= MT) continue;                              // waves beyond the first four only feed the split-K sum
+        if (gate_wg) {
+            // gate tiles: the rank-16 up-projection row of this lane's channel (16 contiguous elements) and its bias are
+            // epilogue operands too -- they travel in the registers the q/k/v tiles use for the conv cache
+            const int c = (tile0 - n_direct) + 16 * j + li;
+            if (c < Kd) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pre_old[j][r] = ld4(w2 + (int64_t)c * R + 4 * r);
+                pre_wj[j].x = ld(b2 + c);
+            }
+        } else if (n < 2 * Kd + Vd) {
             const T* wsel; const T* csel; int c, D;
             if (n < Kd) { c = n; D = Kd; wsel = wq; csel = cq; }
             else if (n < 2 * Kd) { c = n - Kd; D = Kd; wsel = wk; csel = ck; }
@@ -93,12 +121,12 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
     const int nsteps = K / F::KSTEP;
     // wave w takes k-steps {2w, 2w+1} + 8j: its two consecutive 64-byte (bf16) loads of a row are the two halves
     // of ONE 128-byte line, so every line is pulled into this CU's L1 by a single wave, back to back
-    int ks = 0;                                  // per-wave step counter; global k-step = kstep_of(w, ks)
-    for (; kstep_of(w, ks + U - 1) < nsteps; ks += U) {
+    int ks = 0;                                  // per-wave step counter; global k-step = kstep_of<NW>(w, ks)
+    for (; kstep_of<NW>(w, ks + U - 1) < nsteps; ks += U) {
         F fb[U][NT], fa[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t k0 = kstep_of(w, ks + u) * kstr;
+            const int64_t k0 = kstep_of<NW>(w, ks + u) * kstr;
 #pragma unroll
             for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[u][j].template load_stream<WNT>(wp[j] + k0); else fb[u][j].zero(); }
 #pragma unroll
@@ -113,9 +141,13 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[j * MT + mt] = F::mma(fa[u][mt], fb[u][j], acc[j * MT + mt]);
             }
+#ifdef LINA_SKINNY_PROF
+        if (ks == 0) IP_PROF(2, clock64());
+#endif
     }
-    for (; kstep_of(w, ks) < nsteps; ++ks) {
-        const int64_t k0 = kstep_of(w, ks) * kstr;
+    IP_PROF(3, clock64());
+    for (; kstep_of<NW>(w, ks) < nsteps; ++ks) {
+        const int64_t k0 = kstep_of<NW>(w, ks) * kstr;
         F fb[NT], fa[MT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[j].template load_stream<WNT>(wp[j] + k0); else fb[j].zero(); }
@@ -138,6 +170,11 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
         for (int r = 0; r < 4; ++r)
             if (li == 4 * lg + r) { s_st[w][16 * mt + li][0] = st1[mt][r]; s_st[w][16 * mt + li][1] = st2[mt][r]; }
     __syncthreads();
+    IP_PROF(4, clock64());
+    if (w >= MT) {                                          // NW > 4: the extra waves have delivered their partial sums
+        if (gate_wg) __syncthreads();                       // (the gate tiles' low-rank exchange below has one more barrier)
+        return;
+    }
 
     // wave w finalises m-tile w (rows m0 + 16w + 4lg + r, column li of each tile)
     float val[NT][4], mu[4], rstd[4];
@@ -145,7 +182,7 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
     for (int j = 0; j < NT; ++j) {
         float4 t = *reinterpret_cast<const float4*>(&s_acc[0][j * MT + w][lane][0]);
 #pragma unroll
-        for (int ww = 1; ww < 4; ++ww) {
+        for (int ww = 1; ww < NW; ++ww) {
             const float4 u = *reinterpret_cast<const float4*>(&s_acc[ww][j * MT + w][lane][0]);
             t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
@@ -154,8 +191,13 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 16 * w + 4 * lg + r;
-        const float a = (s_st[0][row][0] + s_st[1][row][0]) + (s_st[2][row][0] + s_st[3][row][0]);
-        const float b = (s_st[0][row][1] + s_st[1][row][1]) + (s_st[2][row][1] + s_st[3][row][1]);
+        float a = (s_st[0][row][0] + s_st[1][row][0]) + (s_st[2][row][0] + s_st[3][row][0]);
+        float b = (s_st[0][row][1] + s_st[1][row][1]) + (s_st[2][row][1] + s_st[3][row][1]);
+#pragma unroll
+        for (int ww = 4; ww < NW; ww += 4) {
+            a += (s_st[ww][row][0] + s_st[ww + 1][row][0]) + (s_st[ww + 2][row][0] + s_st[ww + 3][row][0]);
+            b += (s_st[ww][row][1] + s_st[ww + 1][row][1]) + (s_st[ww + 2][row][1] + s_st[ww + 3][row][1]);
+        }
         const float inv_k = fast_rcp((float)K);
         mu[r] = a * inv_k;
         rstd[r] = rsqrtf(fmaxf(b * inv_k - mu[r] * mu[r], 0.f) + ln_eps);
@@ -170,10 +212,11 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
         for (int j = 0; j < NT; ++j) {
             const int c = (tile0 - n_direct) + 16 * j + li;          // gate channel
             if (c >= Kd) continue;
-            float w2r[R];
-#pragma unroll
-            for (int jj = 0; jj < R; ++jj) w2r[jj] = ld(w2 + (int64_t)c * R + jj);
-            const float bias = ld(b2 + c);
+            const float w2r[R] = {pre_old[j][0].x, pre_old[j][0].y, pre_old[j][0].z, pre_old[j][0].w,
+                                  pre_old[j][1].x, pre_old[j][1].y, pre_old[j][1].z, pre_old[j][1].w,
+                                  pre_old[j][2].x, pre_old[j][2].y, pre_old[j][2].z, pre_old[j][2].w,
+                                  pre_old[j][3].x, pre_old[j][3].y, pre_old[j][3].z, pre_old[j][3].w};
+            const float bias = pre_wj[j].x;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * w + 4 * lg + r, m = m0 + row;
@@ -185,6 +228,7 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
                 if (m < M) gk[(int64_t)m * Kd + c] = gv;
             }
         }
+        IP_PROF_FLUSH();
         return;
     }
 #pragma unroll
@@ -225,6 +269,7 @@ __global__ __launch_bounds__(256) void gla_inproj_kernel(
             }
         }
     }
+    IP_PROF_FLUSH();
 }
 
 }  // namespace lina
@@ -246,22 +291,40 @@ static int inproj_impl(const void* x, int64_t ldx, const void* w_in, int64_t ldw
     const int has_clamp = (clamp_min == clamp_min) ? 1 : 0;
     // 64 rows x 32 columns per workgroup when the q|k|v|g regions allow it (fewer, fatter workgroups: one per CU at
     // L169 -- the busiest CU's byte count sets the time, see linear_skinny.hip); else 64 x 16
-    const bool wide = Kd % 32 == 0 && Vd % 32 == 0;
+    static const bool narrow = getenv("LINA_INPROJ_NARROW") != nullptr;      // tuning knob (tools/probe_decode.py)
+    const bool wide = Kd % 32 == 0 && Vd % 32 == 0 && !narrow;
     const int cols = wide ? 32 : 16;
     dim3 grid((unsigned)((2 * Kd + 2 * Vd + Kd) / cols), (unsigned)((B + 63) / 64));
-#define LINA_INPROJ_PK(TT, NTT, PKK, WNTT)                                                                           \
-    LINA_LAUNCH((gla_inproj_kernel<TT, NTT, PKK, WNTT>), grid, dim3(256), 0, stream, (const TT*)x, ldx, (const TT*)w_in, \
-                ldw, c1, c2, (const TT*)wq, (const TT*)wk, (const TT*)wv, (TT*)cq, (TT*)ck, (TT*)cv, (const TT*)w2,     \
-                (const TT*)b2, (TT*)qkv, (TT*)g_out, gk, B, K, Kd, Vd, ln_eps, 1.0f / normalizer, clamp_min, has_clamp)
+    // waves per workgroup (split-K width) of the packed kernel, see linear_skinny.hip; LINA_SKINNY_WAVES overrides
+    int nw = 4;
+    {
+        const char* forced_nw = getenv("LINA_SKINNY_WAVES");   // (read per call: tests switch it)
+        if (forced_nw) nw = atoi(forced_nw);
+        while (nw > 4 && K / kstep < 2 * nw) nw /= 2;
+        if (nw == 16 && (wide || dtype == LINA_F32)) nw = 8;   // 16 waves only on the bf16 16-column tiles (registers)
+        if (nw != 8 && nw != 16) nw = 4;
+    }
+#define LINA_INPROJ_PK(TT, NTT, PKK, WNTT, NWW)                                                                      \
+    LINA_LAUNCH((gla_inproj_kernel<TT, NTT, PKK, WNTT, NWW>), grid, dim3(64 * NWW), 0, stream, (const TT*)x, ldx,      \
+                (const TT*)w_in, ldw, c1, c2, (const TT*)wq, (const TT*)wk, (const TT*)wv, (TT*)cq, (TT*)ck, (TT*)cv,   \
+                (const TT*)w2, (const TT*)b2, (TT*)qkv, (TT*)g_out, gk, B, K, Kd, Vd, ln_eps, 1.0f / normalizer,        \
+                clamp_min, has_clamp)
+#define LINA_INPROJ_NW(TT, NTT, WNTT)                                                                                \
+    do {                                                                                                             \
+        if (nw == 16 && NTT == 1) LINA_INPROJ_PK(TT, 1, true, WNTT, 16);                                             \
+        else if (nw >= 8) LINA_INPROJ_PK(TT, NTT, true, WNTT, 8);                                                    \
+        else LINA_INPROJ_PK(TT, NTT, true, WNTT, 4);                                                                 \
+    } while (0)
 #define LINA_INPROJ(TT, NTT)                                                                                         \
     do {                                                                                                             \
-        if (packed == 3) LINA_INPROJ_PK(TT, NTT, true, true);                                                        \
-        else if (packed & 1) LINA_INPROJ_PK(TT, NTT, true, false);                                                   \
-        else LINA_INPROJ_PK(TT, NTT, false, false);                                                                  \
+        if (packed == 3) LINA_INPROJ_NW(TT, NTT, true);                                                              \
+        else if (packed & 1) LINA_INPROJ_NW(TT, NTT, false);                                                         \
+        else LINA_INPROJ_PK(TT, NTT, false, false, 4);                                                               \
     } while (0)
     if (dtype == LINA_F32) { if (wide) LINA_INPROJ(float, 2); else LINA_INPROJ(float, 1); }
     else { if (wide) LINA_INPROJ(bf16_t, 2); else LINA_INPROJ(bf16_t, 1); }
 #undef LINA_INPROJ
+#undef LINA_INPROJ_NW
 #undef LINA_INPROJ_PK
     return check_launch("lina_gla_decode_inproj");
 }
@@ -284,3 +347,9 @@ extern "C" int lina_gla_decode_inproj_packed(const void* x_packed, const void* w
     return inproj_impl(x_packed, 0, w_in_packed, 0, w_stream ? 3 : 1, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_out, gk, B, K, Kd,
                        Vd, W, R, ln_eps, normalizer, clamp_min, dtype, stream);
 }
+
+#ifdef LINA_SKINNY_PROF
+extern "C" int lina_inproj_prof_read(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lina_inproj_prof), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif

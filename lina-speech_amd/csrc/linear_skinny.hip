@@ -20,22 +20,41 @@
 #include "skinny_frag.h"
 #include <stdlib.h>
 
+#ifdef LINA_SKINNY_PROF
+// tools-only build (tools/skinny_prof.sh): time stamps of thread 0 of every workgroup, [kind][workgroup][slot]; kind 0 =
+// SwiGLU up-projection, 1 = K = 1024 with residual (o-projection), 2 = other with residual (down), 3 = the rest.
+// slots: 0 wall clock (100 MHz) at entry, 1 shader clock at entry, 2 after the first round of loads was consumed, 3 after
+// the main loop, 4 after the reduction barrier, 5 at the end, 6 wall clock at the end.  NOT part of the product library.
+__device__ unsigned long long lina_skinny_prof[4 * 1024 * 8];
+#define SK_PROF(i, expr) do { if (threadIdx.x == 0) pr_[i] = (expr); } while (0)
+#else
+#define SK_PROF(i, expr) do { } while (0)
+#endif
+
 namespace lina {
 
-template <typename T, bool SWIGLU, bool LN, int MT, int NT, bool PK, bool WNT>
-__global__ __launch_bounds__(256) void linear_skinny_kernel(
+template <typename T, bool SWIGLU, bool LN, int MT, int NT, bool PK, bool WNT, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
     const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw, const float* __restrict__ c1,
     const float* __restrict__ c2, const T* resid, int64_t ldr, T* out, int64_t ldo, int M, int N, int K, int Hd,
     int ln_dim, float ln_eps, T* outp, int Kp, int Hp) {
     // WNT: weight fragments with the non-temporal load hint (packed operands only)
+    // NW: waves per workgroup = width of the in-workgroup split-K.  The operands arrive at ~0.09 us per 1 KiB load instruction
+    // PER WAVE (time stamps of tools/probe_skinny_prof.py: the first load round of a wave with 16 / 32 / 48 loads in flight
+    // lands 2.3 / 4.4 / 5.6 us after entry), so the same bytes per workgroup spread over more waves arrive sooner.
     // PK: A and W are fragment-major (skinny_frag.h); Hp = padded rows per weight half.  outp (optional, any PK): a packed
     // copy of the output for the next projection, Kp = its padded width.
     using F = Frag<T>;
+#ifdef LINA_SKINNY_PROF
+    unsigned long long pr_[8] = {};
+    SK_PROF(0, wall_clock64());
+    SK_PROF(1, clock64());
+#endif
     constexpr int NB = SWIGLU ? 2 : 1;      // weight-row halves (gate | value) per output column
     constexpr int G = NB * NT;              // 16-row groups of W per workgroup
-    constexpr int U = (G + MT) * 8 <= 48 ? 8 : 4;   // k-steps in flight: (G + MT) * U 16-byte loads per lane
-    __shared__ __attribute__((aligned(16))) float s_acc[4][G * MT][64][4];   // [wave][group x m-tile][lane][reg]
-    __shared__ float s_st[4][16 * MT][2];
+    constexpr int U = NW > 8 ? 2 : (NW > 4 || (G + MT) * 8 > 48) ? 4 : 8;   // k-steps in flight: (G + MT) * U 16-byte loads per lane
+    __shared__ __attribute__((aligned(16))) float s_acc[NW][G * MT][64][4];  // [wave][group x m-tile][lane][reg]
+    __shared__ float s_st[NW][16 * MT][2];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
@@ -105,12 +124,12 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
     const int nsteps = K / F::KSTEP;
     // wave w takes k-steps {2w, 2w+1} + 8j: its two consecutive 64-byte (bf16) loads of a row are the two halves
     // of ONE 128-byte line, so every line is pulled into this CU's L1 by a single wave, back to back
-    int ks = 0;                                  // per-wave step counter; global k-step = kstep_of(w, ks)
-    for (; kstep_of(w, ks + U - 1) < nsteps; ks += U) {
+    int ks = 0;                                  // per-wave step counter; global k-step = kstep_of<NW>(w, ks)
+    for (; kstep_of<NW>(w, ks + U - 1) < nsteps; ks += U) {
         F fb[U][G], fa[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t k0 = kstep_of(w, ks + u) * kstr;
+            const int64_t k0 = kstep_of<NW>(w, ks + u) * kstr;
 #pragma unroll
             for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[u][g].template load_stream<WNT>(wp[g] + k0); else fb[u][g].zero(); }
 #pragma unroll
@@ -127,9 +146,13 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
 #pragma unroll
                 for (int g = 0; g < G; ++g) acc[g * MT + mt] = F::mma(fa[u][mt], fb[u][g], acc[g * MT + mt]);
             }
+#ifdef LINA_SKINNY_PROF
+        if (ks == 0) SK_PROF(2, clock64());
+#endif
     }
-    for (; kstep_of(w, ks) < nsteps; ++ks) {
-        const int64_t k0 = kstep_of(w, ks) * kstr;
+    SK_PROF(3, clock64());
+    for (; kstep_of<NW>(w, ks) < nsteps; ++ks) {
+        const int64_t k0 = kstep_of<NW>(w, ks) * kstr;
         F fb[G], fa[MT];
 #pragma unroll
         for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[g].template load_stream<WNT>(wp[g] + k0); else fb[g].zero(); }
@@ -159,6 +182,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
         }
     }
     __syncthreads();
+    SK_PROF(4, clock64());
     if (w >= MT) return;
 
     // wave w finalises m-tile w of every group: D layout -> rows m0 + 16w + 4*lg + r, column li of the tile
@@ -167,7 +191,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
     for (int g = 0; g < G; ++g) {
         float4 t = *reinterpret_cast<const float4*>(&s_acc[0][g * MT + w][lane][0]);
 #pragma unroll
-        for (int ww = 1; ww < 4; ++ww) {
+        for (int ww = 1; ww < NW; ++ww) {
             const float4 u = *reinterpret_cast<const float4*>(&s_acc[ww][g * MT + w][lane][0]);
             t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
@@ -179,8 +203,13 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
         const int m = m0 + row;
         float mu = 0.f, rstd = 1.f;
         if (LN) {
-            const float a = (s_st[0][row][0] + s_st[1][row][0]) + (s_st[2][row][0] + s_st[3][row][0]);
-            const float b = (s_st[0][row][1] + s_st[1][row][1]) + (s_st[2][row][1] + s_st[3][row][1]);
+            float a = (s_st[0][row][0] + s_st[1][row][0]) + (s_st[2][row][0] + s_st[3][row][0]);
+            float b = (s_st[0][row][1] + s_st[1][row][1]) + (s_st[2][row][1] + s_st[3][row][1]);
+#pragma unroll
+            for (int ww = 4; ww < NW; ww += 4) {
+                a += (s_st[ww][row][0] + s_st[ww + 1][row][0]) + (s_st[ww + 2][row][0] + s_st[ww + 3][row][0]);
+                b += (s_st[ww][row][1] + s_st[ww + 1][row][1]) + (s_st[ww + 2][row][1] + s_st[ww + 3][row][1]);
+            }
             const float inv_d = fast_rcp((float)ln_dim);
             mu = a * inv_d;
             rstd = rsqrtf(fmaxf(b * inv_d - mu * mu, 0.f) + ln_eps);
@@ -211,9 +240,38 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(
             }
         }
     }
+#ifdef LINA_SKINNY_PROF
+    SK_PROF(5, clock64());
+    SK_PROF(6, wall_clock64());
+    if (threadIdx.x == 0) {
+        const int kind = SWIGLU ? 0 : (resid ? (K == 1024 ? 1 : 2) : 3);
+        const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+        if (wg < 1024)
+            for (int i = 0; i < 8; ++i) lina_skinny_prof[(kind * 1024 + wg) * 8 + i] = pr_[i];
+    }
+#endif
 }
 
 }  // namespace lina
+
+// packed kernels: one launch helper per tiling that picks the split-K width.  16 waves only where a wave's accumulators and
+// in-flight fragments fit 128 registers (the plain N x K projections on 16-column tiles); the other shapes stop at 8.
+template <typename TT, bool SW, bool LNN, int MTT, int NTT, bool WNTT>
+static void launch_skinny_packed(int nw, dim3 grid, lina_stream_t stream, const void* A, int64_t lda, const void* W, int64_t ldw,
+                                 const float* c1, const float* c2, const void* resid, int64_t ldr, void* out, int64_t ldo,
+                                 int M, int N, int K, int swiglu_hidden, int ln_dim, float ln_eps, void* outp, int Kp, int Hp) {
+    using namespace lina;
+#define LINA_LS_GO(NWW)                                                                                              \
+    LINA_LAUNCH((linear_skinny_kernel<TT, SW, LNN, MTT, NTT, true, WNTT, NWW>), grid, dim3(64 * NWW), 0, stream,      \
+                (const TT*)A, lda, (const TT*)W, ldw, c1, c2, (const TT*)resid, ldr, (TT*)out, ldo, M, N, K,          \
+                swiglu_hidden, ln_dim, ln_eps, (TT*)outp, Kp, Hp)
+    if constexpr (!SW && NTT == 1) {
+        if (nw == 16) { LINA_LS_GO(16); return; }
+    }
+    if (nw >= 8) LINA_LS_GO(8);
+    else LINA_LS_GO(4);
+#undef LINA_LS_GO
+}
 
 static int linear_skinny_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const float* c1, const float* c2,
                               const void* resid, int64_t ldr, void* out, int64_t ldo, int M, int N, int K,
@@ -253,15 +311,27 @@ static int linear_skinny_impl(const void* A, int64_t lda, const void* W, int64_t
                 if (cand[c][0] == fm && cand[c][1] == fn) { best_mt = fm; best_nt = fn; }
     }
     dim3 grid((unsigned)((N + 16 * best_nt - 1) / (16 * best_nt)), (unsigned)((M + 16 * best_mt - 1) / (16 * best_mt)));
-#define LINA_LS_PK(TT, SW, LNN, MTT, NTT, PKK, WNTT)                                                               \
-    LINA_LAUNCH((linear_skinny_kernel<TT, SW, LNN, MTT, NTT, PKK, WNTT>), grid, dim3(256), 0, stream, (const TT*)A, \
-                lda, (const TT*)W, ldw, c1, c2, (const TT*)resid, ldr, (TT*)out, ldo, M, N, K, swiglu_hidden,       \
-                ln_dim, ln_eps, (TT*)outp, Kp, Hp)
+    // waves per workgroup (split-K width) of the packed kernels: more waves = fewer loads per wave for the same bytes per
+    // workgroup (see the kernel's NW note); each wave needs at least one pair of k-steps.  LINA_SKINNY_WAVES overrides.
+    int nw = 4;
+    {
+        const char* forced_nw = getenv("LINA_SKINNY_WAVES");   // (read per call: tests switch it)
+        if (forced_nw) nw = atoi(forced_nw);
+        while (nw > 4 && K / kstep < 2 * nw) nw /= 2;
+        if (nw != 8 && nw != 16) nw = 4;
+    }
+#define LINA_LS_PK(TT, SW, LNN, MTT, NTT, PKK, WNTT, NWW)                                                          \
+    LINA_LAUNCH((linear_skinny_kernel<TT, SW, LNN, MTT, NTT, PKK, WNTT, NWW>), grid, dim3(64 * NWW), 0, stream,      \
+                (const TT*)A, lda, (const TT*)W, ldw, c1, c2, (const TT*)resid, ldr, (TT*)out, ldo, M, N, K,         \
+                swiglu_hidden, ln_dim, ln_eps, (TT*)outp, Kp, Hp)
+#define LINA_LS_NW(TT, SW, LNN, MTT, NTT, WNTT)                                                                     \
+    launch_skinny_packed<TT, SW, LNN, MTT, NTT, WNTT>(nw, grid, stream, A, lda, W, ldw, c1, c2, resid, ldr, out, ldo, M, N, \
+                                                      K, swiglu_hidden, ln_dim, ln_eps, outp, Kp, Hp)
 #define LINA_LS_ONE(TT, SW, LNN, MTT, NTT)                                                                          \
     do {                                                                                                            \
-        if (packed == 3) LINA_LS_PK(TT, SW, LNN, MTT, NTT, true, true);                                             \
-        else if (packed & 1) LINA_LS_PK(TT, SW, LNN, MTT, NTT, true, false);                                        \
-        else LINA_LS_PK(TT, SW, LNN, MTT, NTT, false, false);                                                       \
+        if (packed == 3) LINA_LS_NW(TT, SW, LNN, MTT, NTT, true);                                                   \
+        else if (packed & 1) LINA_LS_NW(TT, SW, LNN, MTT, NTT, false);                                              \
+        else LINA_LS_PK(TT, SW, LNN, MTT, NTT, false, false, 4);                                                    \
     } while (0)
 #define LINA_LS(TT, SW, LNN)                                                                                        \
     do {                                                                                                            \
@@ -280,6 +350,7 @@ static int linear_skinny_impl(const void* A, int64_t lda, const void* W, int64_t
     }
 #undef LINA_LS
 #undef LINA_LS_ONE
+#undef LINA_LS_NW
 #undef LINA_LS_PK
     return check_launch("lina_linear_skinny");
 }
@@ -299,3 +370,9 @@ extern "C" int lina_linear_skinny_ex(const void* A, int64_t lda, const void* W, 
     return linear_skinny_impl(A, lda, W, ldw, c1, c2, resid, ldr, out, ldo, M, N, K, swiglu_hidden, ln_dim, ln_eps,
                               in_packed & 3, out_packed, out_packed_width, w_half_rows, dtype, stream);
 }
+
+#ifdef LINA_SKINNY_PROF
+extern "C" int lina_skinny_prof_read(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lina_skinny_prof), sizeof(unsigned long long) * 4 * 1024 * 8);
+}
+#endif

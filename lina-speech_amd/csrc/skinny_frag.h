@@ -6,8 +6,9 @@
 
 namespace lina {
 
-// split-K over the 4 waves of a workgroup: the i-th k-step of wave w (pairs of adjacent steps per wave)
-__device__ __forceinline__ int kstep_of(int w, int i) { return ((i >> 1) << 3) + 2 * w + (i & 1); }
+// split-K over the NW waves of a workgroup: the i-th k-step of wave w (pairs of adjacent steps per wave)
+template <int NW = 4>
+__device__ __forceinline__ int kstep_of(int w, int i) { return (i >> 1) * (2 * NW) + 2 * w + (i & 1); }
 
 #ifndef LINA_SKINNY_W_NT
 #define LINA_SKINNY_W_NT 0      // experiment (tools/skinny_variants.sh): weight fragments with the non-temporal load hint

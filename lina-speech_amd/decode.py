@@ -95,8 +95,15 @@ class _BlockPack:
         # per MFMA fragment load instead of 16 rows x 64 B
         self.w_in_p = ops.pack_rows(self.w_in)
         self.w_o_p = ops.pack_rows(self.w_o)
-        self.up_half_rows = (self.hid + 63) // 64 * 64
-        self.w_up_p = torch.cat([ops.pack_rows(self.w_up[:self.hid]), ops.pack_rows(self.w_up[self.hid:])])
+        # each half zero-padded to whole 64-row blocks covering the hid_pad output columns the launch sweeps (the K-padding
+        # columns beyond `hid` read weight rows too: with hid % 64 == 0 they would lie past a half padded to ceil64(hid))
+        self.up_half_rows = (self.hid_pad + 63) // 64 * 64
+        halves = []
+        for h in (self.w_up[:self.hid], self.w_up[self.hid:]):
+            hp = torch.zeros(self.up_half_rows, h.shape[1], dtype=dt, device=dev)
+            hp[:self.hid] = h
+            halves.append(ops.pack_rows(hp))
+        self.w_up_p = torch.cat(halves)
         self.w_down_p = ops.pack_rows(self.w_down)
         self._buffers(state, lo, hi, dt, dev)
 
@@ -392,11 +399,6 @@ class DecodeEngine:
             torch.cuda.synchronize()
             times.append(e0.elapsed_time(e1) * 1e-3 / reps)
         self._skip_update = False
-        self._loop_packed = False
-        # which weight matrices of the device loop are STREAMED (non-temporal loads) instead of competing for the 256 MB
-        # Infinity Cache: per token the loop touches 0.87 GB of state (always streamed) + 0.26 GB of weights; streaming
-        # the largest matrices lets the others stay resident between two tokens.  LINA_DECODE_STREAM=in,up,...
-        self._stream = set(os.environ.get("LINA_DECODE_STREAM", "in,up").replace(" ", "").split(",")) - {""}
         self._restore(snap)
         for part, xk in zip(self.parts, x_keep):
             part.x.copy_(xk)
@@ -410,12 +412,16 @@ class DecodeEngine:
     def _all_packs(self):
         return [P for part in self.parts for P in part.packs]
 
+    @staticmethod
+    def _live_buffers(P):
+        return (P.cq, P.ck, P.cv, P.S) + ((P.hk, P.hc, P.hv) if P.lazy else ())   # + the window history of K1w
+
     def _snapshot(self):
-        return [[t.clone() for t in (P.cq, P.ck, P.cv, P.S)] for P in self._all_packs()]
+        return [[t.clone() for t in self._live_buffers(P)] for P in self._all_packs()]
 
     def _restore(self, snap):
         for P, saved in zip(self._all_packs(), snap):
-            for dst, src in zip((P.cq, P.ck, P.cv, P.S), saved):
+            for dst, src in zip(self._live_buffers(P), saved):
                 dst.copy_(src)
 
     def _capture(self):
@@ -469,7 +475,9 @@ class DecodeEngine:
         self._lazy_live = lazy
         n_sampled_ = min(max(first_greedy_quant, 0), self.Q) if k > 1 else 0
         # fragment-major operands: the all-greedy device loop on one row range (the pick kernel K6d keeps x_p current)
-        packed = (lazy and len(self.parts) == 1 and n_sampled_ == 0 and self.Q <= 16
+        # (K6d / K6e keep x_p current; the unfused sampled epilogue, LINA_DECODE_FUSED_PICK=0, has no packed output)
+        fused_pick = self.Q <= 16 and (n_sampled_ == 0 or os.environ.get("LINA_DECODE_FUSED_PICK", "1") != "0")
+        packed = (lazy and len(self.parts) == 1 and fused_pick
                   and all(P.packed for P in self.packs) and os.environ.get("LINA_DECODE_PACKED", "1") != "0")
         self._loop_packed = packed
         n_sampled = min(max(first_greedy_quant, 0), self.Q) if k > 1 else 0
@@ -490,6 +498,11 @@ class DecodeEngine:
                 # K6d: picks, token log, next-token embedding and the step counter in ONE launch
                 ops.greedy_pick_embed(lg, emb.weight, y_buf, self._tok_log, self._t_idx, self._pick_counter,
                                       x_packed=self.parts[0].x_p if packed else None)
+                return att
+            if fused_pick:
+                # K6e: the same epilogue with the first n_sampled quantizers drawn by top-k / temperature sampling
+                ops.sample_pick_embed(lg, emb.weight, y_buf, self._tok_log, self._t_idx, self._pick_counter, n_sampled, k,
+                                      temp, seed=seed, x_packed=self.parts[0].x_p if packed else None)
                 return att
             if n_sampled == 0:
                 pick = ops.argmax_rows(lg)

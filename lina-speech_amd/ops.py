@@ -129,12 +129,21 @@ def _workspace(tag: str, nbytes: int, device) -> torch.Tensor:
     """Scratch that is fully written before it is read inside ONE launch sequence on the current stream (segment
     states of the segment-parallel K2): kept per (tag, device, stream) and grown on demand instead of a torch.empty
     per layer per step.  Stream-ordered reuse is safe because consecutive users on one stream serialise."""
+    if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        # inside a graph capture the allocation belongs to the graph's private pool: never hand it to eager launches
+        return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
     key = (tag, device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
         _WORKSPACES[key] = ws
     return ws
+
+
+def clear_workspaces() -> None:
+    """Release the cached kernel scratch (segment / boundary states of the segment-parallel K2 / K2b): at small B*H with
+    many segments it is the size of several activations and would otherwise stay pinned for the life of the process."""
+    _WORKSPACES.clear()
 
 
 def _value_blocks(q, v, gk) -> int:
@@ -601,6 +610,31 @@ def greedy_pick_embed(logits, table, x_out, tok_log, step, counter, x_packed=Non
                                          be.stream(table)))
 
 
+def sample_pick_embed(logits, table, x_out, tok_log, step, counter, n_sampled: int, k: int, temp: float = 1.0,
+                      seed: int = 0, x_packed=None):
+    """K6e (lina_sample_pick_embed): greedy_pick_embed for the reference's default generation mode -- quantizers
+    ``q < n_sampled`` are sampled (top-``k``, temperature, the draw of row ``b*Q + q`` of topk_sample_rows at the same
+    (seed, step)), the others take the arg-max; token log, next-input embedding and ``step[0] += 1`` in the same launch."""
+    be = _BACKEND
+    be.require(logits, table, x_out, tok_log, step, counter, x_packed)
+    B, Q, L = logits.shape
+    Qt, n_emb, d = table.shape
+    if Qt != Q or logits.stride(2) != 1 or logits.stride(1) != L:
+        raise ValueError("logits must be [B, Q, L] with contiguous (Q, L)")
+    if tuple(x_out.shape) != (B, d) or not x_out.is_contiguous() or x_out.dtype != table.dtype or logits.dtype != table.dtype:
+        raise ValueError("x_out must be a contiguous [B, d] tensor of the table's dtype")
+    if tok_log.dtype != torch.int64 or tok_log.dim() != 3 or tuple(tok_log.shape[1:]) != (Q, B) or not tok_log.is_contiguous():
+        raise ValueError("tok_log must be a contiguous int64 [max_steps, Q, B] tensor")
+    if step.dtype != torch.int64 or counter.dtype != torch.int32:
+        raise ValueError("step must be int64, counter int32")
+    if x_packed is not None and x_packed.numel() < packed_numel(B, d):
+        raise ValueError("packed x buffer is too small")
+    _check(be.lib.lina_sample_pick_embed(_ptr(logits), logits.stride(0), _ptr(table.contiguous()), _ptr(x_out),
+                                         _ptr(x_packed), _ptr(tok_log), _ptr(step), _ptr(counter), B, Q, L, n_emb, d,
+                                         tok_log.shape[0], int(n_sampled), int(k), float(temp),
+                                         int(seed) & 0xFFFFFFFFFFFFFFFF, _dt(table), be.stream(table)))
+
+
 # --------------------------------------------------------------------------- decode-step fusions
 def topk_sample_rows(logits, k: int, temp: float = 1.0, u: Optional[torch.Tensor] = None, seed: int = 0,
                      step: Optional[torch.Tensor] = None, out=None):
@@ -733,6 +767,8 @@ def linear_skinny_packed(a_packed, w_packed, M: int, N: int, K: int, c1=None, c2
         raise ValueError("packed A is too small for [M, K]")
     n_w = 2 * swiglu_hidden if swiglu_hidden else N
     half = w_half_rows if w_half_rows is not None else (n_w + 63) // 64 * 64
+    if half % 64 or half < (N + 31) // 32 * 32:        # the launch reads whole 16/32-row weight tiles up to column N
+        raise ValueError("packed W: rows per half must be a multiple of 64 covering the N output columns")
     if w_packed.numel() < half * K * (2 if swiglu_hidden else 1):
         raise ValueError("packed W is too small")
     if out_packed is not None and out_packed.numel() < packed_numel(M, out_packed_width):

@@ -55,6 +55,8 @@ class SimpleGatedLinearAttention(nn.Module):
             q, k, v = self.q_conv1d(q), self.k_conv1d(k), self.v_conv1d(v)
         heads = lambda t: t.view(B, T, H, -1).transpose(1, 2)
         g = (F.logsigmoid((glog + self.gk_proj.bias).float()) / self.gate_logit_normalizer).transpose(1, 2)
+        if q.dtype == torch.bfloat16:
+            g = g.to(q.dtype)      # the bf16 full-head / segment-parallel K2 and K2b take a bf16 gate (as mixer.py passes it)
         o, _ = ops.chunk_simple_gla(heads(q), heads(k), heads(v), g)
         o = self.g_norm_swish_gate(o.transpose(1, 2), gate.view(B, T, H, -1)).reshape(B, T, -1)
         return self.o_proj(o), None, past_key_values

@@ -193,9 +193,30 @@ def test_greedy_pick_embed(emu, Q, L, d, dtype):
     check_greedy_pick_embed(DEV, B=5, Q=Q, L=L, d=d, dtype=dtype)
 
 
+@pytest.mark.parametrize("nw", [8, 16])
+def test_projections_wider_split_k(emu, monkeypatch, nw):
+    """The packed projection kernels with 8 / 16 waves per workgroup (K = 1024: 32 k-steps): same products, another
+    summation order -- against the 4-wave row-major kernel within fp32 rounding of the partial sums."""
+    from kernel_cases import check_linear_skinny_packed, check_inproj_packed
+    monkeypatch.setenv("LINA_SKINNY_WAVES", str(nw))
+    check_linear_skinny_packed(DEV, 20, 48, 1024, torch.bfloat16, ln=False, bias=False, resid=True)
+    check_linear_skinny_packed(DEV, 33, 64, 1024, torch.bfloat16, ln=True, bias=True, swiglu=40)
+    check_linear_skinny_packed(DEV, 7, 16, 512, torch.float32, ln=True, bias=True, resid=True)
+    check_inproj_packed(DEV, 9, 1024, 32, 32, torch.bfloat16)
+    check_inproj_packed(DEV, 5, 1024, 16, 48, torch.bfloat16)
+
+
+@pytest.mark.parametrize("Q,L,d,dtype,ns", [(1, 300, 64, torch.float32, 1), (3, 70, 32, torch.bfloat16, 1),
+                                            (3, 70, 32, torch.bfloat16, 3), (2, 50, 20, torch.float32, 0)])
+def test_sample_pick_embed(emu, Q, L, d, dtype, ns):
+    from kernel_cases import check_sample_pick_embed
+    check_sample_pick_embed(DEV, B=5, Q=Q, L=L, d=d, dtype=dtype, n_sampled=ns)
+
+
 @pytest.mark.parametrize("M,N,K,dtype,ln,bias,resid,sw", [(5, 40, 64, torch.float32, False, True, True, 0),
                                                           (20, 48, 64, torch.bfloat16, True, True, False, 0),
                                                           (7, 32, 64, torch.bfloat16, True, True, False, 21),
+                                                          (9, 96, 64, torch.bfloat16, True, True, False, 64),
                                                           (64, 100, 96, torch.float32, False, False, True, 0)])
 def test_linear_skinny_packed(emu, M, N, K, dtype, ln, bias, resid, sw):
     from kernel_cases import check_linear_skinny_packed

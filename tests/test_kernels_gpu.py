@@ -322,9 +322,18 @@ def test_greedy_pick_embed(hip, B, Q, L, d, dtype):
     check_greedy_pick_embed(DEV, B=B, Q=Q, L=L, d=d, dtype=dtype, steps=4)
 
 
+@pytest.mark.parametrize("B,Q,L,d,dtype,ns,k", [(64, 1, 4099, 1024, torch.bfloat16, 1, 100),
+                                                (7, 4, 1027, 256, torch.float32, 2, 5),
+                                                (9, 3, 513, 64, torch.bfloat16, 0, 3)])
+def test_sample_pick_embed(hip, B, Q, L, d, dtype, ns, k):
+    from kernel_cases import check_sample_pick_embed
+    check_sample_pick_embed(DEV, B=B, Q=Q, L=L, d=d, dtype=dtype, n_sampled=ns, k=k, temp=1.0)
+
+
 # ----------------------------------------------------------------------------- fragment-major (packed) projections
 @pytest.mark.parametrize("M,N,K,dtype,ln,bias,resid,sw", [(64, 1024, 1024, torch.bfloat16, False, False, True, 0),
                                                           (64, 1376, 1024, torch.bfloat16, True, True, False, 1365),
+                                                          (64, 2080, 768, torch.bfloat16, True, True, False, 2048),
                                                           (64, 1024, 1376, torch.bfloat16, False, False, True, 0),
                                                           (64, 4099, 1024, torch.bfloat16, False, False, False, 0),
                                                           (33, 300, 256, torch.float32, True, True, True, 0),
