@@ -33,10 +33,7 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const T* __restrict__ 
     const T* row = logits + (int64_t)blockIdx.x * row_stride;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int j = threadIdx.x; j < n; j += 256) {
-        const float vj = ld(row + j);
-        if (vj > best || (vj == best && j < bi)) { best = vj; bi = j; }
-    }
+    argmax_scan(row, n, best, bi);
     if (bi == 0x7fffffff && threadIdx.x < n) bi = threadIdx.x;  // all -inf/NaN in this thread's slice
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -74,10 +71,7 @@ __global__ __launch_bounds__(256) void greedy_pick_embed_kernel(const T* __restr
         const T* row = logits + (int64_t)b * row_stride + (int64_t)qi * L;
         float best = -INFINITY;
         int bi = 0x7fffffff;
-        for (int j = tid; j < L; j += 256) {
-            const float vj = ld(row + j);
-            if (vj > best || (vj == best && j < bi)) { best = vj; bi = j; }
-        }
+        argmax_scan(row, L, best, bi);              // every load of the row in flight at once (sample_dev.h)
         if (bi == 0x7fffffff && tid < L) bi = tid;  // all -inf/NaN in this thread's slice
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) {
@@ -149,7 +143,7 @@ __global__ __launch_bounds__(256) void sample_pick_embed_kernel(const T* __restr
         const T* row = logits + (int64_t)b * row_stride + (int64_t)qi * L;
         int pick;
         if (qi < n_sampled) {
-            for (int j = tid; j < L; j += 256) s_x[j] = ld(row + j);
+            row_to_lds(row, L, s_x);
             const float u = hash_uniform(seed, (uint64_t)t, (uint64_t)b * Q + qi, (uint64_t)B * Q);
             pick = topk_sample_block(s_x, L, k, inv_temp, u, sc);
         } else {

@@ -217,15 +217,20 @@ __global__ __launch_bounds__(1024) void cross_scores_softmax_kernel(
         return t;
     };
     constexpr int kIt = 4;                                   // d <= 1024: a row = 4 pieces of 4 elements per lane
+    constexpr int kPre = 4;                                  // text rows per wave requested up front (T_txt <= 64: all of them)
     const bool pre = d <= 256 * kIt;
-    float4 m[kIt];
-    {
-        const int t = min(w, Tn - 1);
+    // every row a wave will need is requested NOW (the text keys are HBM-cold: 16.8 MB stream between two tokens): a loop
+    // that fetches row t + 16 after finishing row t pays a full memory round trip per row (3 of them on top of the first
+    // at T_txt = 64: 11.7 us per launch in the step's timeline, profiles/r03c_step_timeline.txt)
+    float4 m[kPre][kIt];
+#pragma unroll
+    for (int r = 0; r < kPre; ++r) {
+        const int t = min(w + 16 * r, Tn - 1);
         const T* row = kk + ((int64_t)b * Tn + t) * d;
 #pragma unroll
         for (int it = 0; it < kIt; ++it) {
             const int e = lane * 4 + 256 * it;
-            m[it] = (pre && e < d) ? ld4(row + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            m[r][it] = (pre && e < d) ? ld4(row + e) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     float s = 0.0f;
@@ -240,16 +245,24 @@ __global__ __launch_bounds__(1024) void cross_scores_softmax_kernel(
         s_q[e] = ld(&tmp);
     }
     __syncthreads();
-    for (int t = w; t < Tn; t += 16) {                       // wave-uniform
-        float acc = 0.0f;
-        if (pre && t == w) {
 #pragma unroll
-            for (int it = 0; it < kIt; ++it) {
-                const int e = lane * 4 + 256 * it;
-                if (e < d)
-                    acc = fmaf(m[it].x, s_q[e], fmaf(m[it].y, s_q[e + 1], fmaf(m[it].z, s_q[e + 2], fmaf(m[it].w, s_q[e + 3], acc))));
-            }
-        } else {
+    for (int r = 0; r < kPre; ++r) {                         // the prefetched rows (same arithmetic as the loop below)
+        const int t = w + 16 * r;
+        if (!pre || t >= Tn) break;                          // wave-uniform
+        float acc = 0.0f;
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int e = lane * 4 + 256 * it;
+            if (e < d)
+                acc = fmaf(m[r][it].x, s_q[e], fmaf(m[r][it].y, s_q[e + 1], fmaf(m[r][it].z, s_q[e + 2], fmaf(m[r][it].w, s_q[e + 3], acc))));
+        }
+        acc += shfl_xor(acc, 1); acc += shfl_xor(acc, 2); acc += shfl_xor(acc, 4);
+        acc += shfl_xor(acc, 8); acc += shfl_xor(acc, 16); acc += shfl_xor(acc, 32);
+        if (lane == 0) s_sc[t] = acc * scale;
+    }
+    for (int t = pre ? w + 16 * kPre : w; t < Tn; t += 16) { // wave-uniform: rows beyond the prefetch window / wide models
+        float acc = 0.0f;
+        {
             const T* row = kk + ((int64_t)b * Tn + t) * d;
             for (int e = lane * 4; e < d; e += 256) {
                 const float4 mm = ld4(row + e);

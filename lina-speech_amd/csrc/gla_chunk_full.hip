@@ -28,25 +28,6 @@
 #include <lina_dev.h>
 #include "lina_common.h"
 
-#ifndef LINA_K2_VAR
-#define LINA_K2_VAR 0   // experiment switch (tools/k2_variants.sh): 1 = the loader waves interleave their DMAs with step (1)
-#endif
-#ifndef LINA_K2_TR
-#define LINA_K2_TR 0    // 1 (opt-in variant, not the default build): no transposed k~^T / v^T tiles -- the operands whose K dimension
-                        // is the token axis are read with ds_read_b64_tr_b16 from the ROW-MAJOR k~ tile and a row-major copy of v:
-                        // phase A loses its eight 4-byte transposed writes per thread, the workgroup 31 KB of LDS
-#endif
-#ifndef LINA_K2_W32
-#define LINA_K2_W32 0   // 1 (opt-in variant on top of LINA_K2_TR, L169 head shape, every sweep): a wave owns 128 state rows x 32
-                        // columns instead of 256 x 16 -- every q~ / k~^T fragment feeds two column tiles, so a wave reads half
-                        // of each operand tile per chunk; the two waves of a column pair swap the partial outputs of each
-                        // other's 16 columns through a 32 KB LDS buffer (the space LINA_K2_TR frees), after which every
-                        // wave holds the output of ITS 16 columns exactly as in the default form (same epilogue, same stores)
-#endif
-#ifndef LINA_K2_ABL
-#define LINA_K2_ABL 0   // tools/k2_ablate.sh builds timing-only variants that skip one phase (results are WRONG there)
-#endif
-
 #ifdef LINA_K2_PROF
 // tools-only build (tools/k2_prof.sh): per-phase shader-clock totals of workgroup 0, [wave][slot]; NOT part of the product library
 __device__ unsigned long long lina_k2_prof[16 * 16 + 3 * 1024];   // + per workgroup: total, wait_vmem, bar(3) of wave 0
@@ -128,15 +109,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     bf16_t* const s_q = s_qk;
     bf16_t* const s_k = s_qk + C * SQ;
     __shared__ __attribute__((aligned(16))) bf16_t s_A[G * 2 * 64 * 8]; // mask(A) as ready-made operands [head][nt][lane][8]
-    constexpr bool kTR = LINA_K2_TR != 0;
-    constexpr bool kW32 = LINA_K2_W32 != 0 && G == 1 && !STATE_ONLY;
-    static_assert(!kW32 || kTR, "LINA_K2_W32 needs the LDS that LINA_K2_TR frees");
-    __shared__ __attribute__((aligned(16))) float s_x[kW32 ? 16 * 2 * 64 * 4 : 4];   // kW32: partial o^T of the partner's 16 columns
-    constexpr int SV = DV + 16;  // kTR: row stride of the chunk-stable row-major v (MODE 1: gated Z) tile
-    __shared__ __attribute__((aligned(16))) bf16_t s_T[kTR ? C * SV : (DK + DV) * ST];  // k~^T | v^T   (kTR: row-major v)
+    __shared__ __attribute__((aligned(16))) bf16_t s_T[(DK + DV) * ST];  // k~^T | v^T
     bf16_t* const s_kT = s_T;
-    bf16_t* const s_vT = s_T + (kTR ? 0 : DK * ST);
-    bf16_t* const s_vr = s_T;
+    bf16_t* const s_vT = s_T + DK * ST;
     // next chunk's q, k, g, v, filled by DMA (issued through inline assembly and waited for by hand: the compiler does not
     // see these writes, so reads of the object are never held back by them)
     constexpr int RAWT = (C / 2) * PE;
@@ -171,11 +146,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     const bool rev_tail = REV && t_begin + T >= T_total;     // the first visited row has no later token: its gate is 0
 
     // ---- state: wave w owns columns [16w, 16w+16), tile p = rows [16p, 16p+16) ----
-    // kW32: wave w owns columns [32 (w>>1), +32) and rows [128 (w&1), +128): tile t = (row tile t>>1, column tile t&1)
-    const int cp = w_s >> 1, rh = w_s & 1;
-    auto tile_row = [&](int t) { return kW32 ? 128 * rh + 16 * (t >> 1) : 16 * t; };                // first row inside the head
-    auto tile_col = [&](int t) { return kW32 ? 32 * cp + 16 * (t & 1) : 16 * wl; };                 // first column inside the head
-    auto tile_ch = [&](int t) { return kW32 ? 128 * rh + 16 * (t >> 1) : 16 * (NTL * hw + t); };   // first channel of the workgroup
+    auto tile_row = [&](int t) { return 16 * t; };                       // first row inside the head
+    auto tile_col = [&](int t) { return 16 * wl; };                      // first column inside the head
+    auto tile_ch = [&](int t) { return 16 * (NTL * hw + t); };           // first channel of the workgroup
     f32x4 S[NTL];                                            // local tile p <-> rows [16p, 16p+16) of this wave's head
 #pragma unroll
     for (int p = 0; p < NTL; ++p) S[p] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -208,7 +181,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // them at (3).  So ONLY the last four waves (one per SIMD, the lowest issue priority) issue DMAs, 16 each (row pairs
     // 4(w-12) .. +3); the other twelve go straight to their MFMAs and the four catch up on SIMDs the others have left.
     // Rows past the end of the sequence re-read row T-1 (always mapped); phase A masks them.
-    constexpr int kLoaders = LINA_K2_VAR == 2 ? 8 : LINA_K2_VAR == 3 ? 2 : 4;   // loader waves (experiment: 8 / 2)
+    constexpr int kLoaders = 4;   // loader waves (measured on the final kernel: 8 loaders 0.598 ms, 2 loaders 0.612, 4 loaders 0.592)
     constexpr int kDmaWave0 = 16 - kLoaders, kPairsPer = 16 / kLoaders;
     // memory row (relative to the segment's first token) of visited row tl <= T-1 of tensor a; REV: the gate (a == 2) of a
     // visited row is the gate of the token after it, clamped to the sequence (the one row past it is zeroed in gate_scan)
@@ -294,12 +267,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 kk[rr] = valid ? ry : make_uint2(0u, 0u);
                 *reinterpret_cast<uint2*>(qkp + C * SQ + rr * SQ) = kk[rr];
             }
-            if constexpr (!kTR) {
-                *reinterpret_cast<unsigned*>(tp) = byte_perm(kk[1].x, kk[0].x, 0x05040100u);
-                *reinterpret_cast<unsigned*>(tp + ST) = byte_perm(kk[1].x, kk[0].x, 0x07060302u);
-                *reinterpret_cast<unsigned*>(tp + 2 * ST) = byte_perm(kk[1].y, kk[0].y, 0x05040100u);
-                *reinterpret_cast<unsigned*>(tp + 3 * ST) = byte_perm(kk[1].y, kk[0].y, 0x07060302u);
-            }
+            *reinterpret_cast<unsigned*>(tp) = byte_perm(kk[1].x, kk[0].x, 0x05040100u);
+            *reinterpret_cast<unsigned*>(tp + ST) = byte_perm(kk[1].x, kk[0].x, 0x07060302u);
+            *reinterpret_cast<unsigned*>(tp + 2 * ST) = byte_perm(kk[1].y, kk[0].y, 0x05040100u);
+            *reinterpret_cast<unsigned*>(tp + 3 * ST) = byte_perm(kk[1].y, kk[0].y, 0x07060302u);
             sched_fence();
         }
         const float4 R4 = *reinterpret_cast<const float4*>(&s_R[ch0]);
@@ -343,7 +314,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 kk[rr].y = pack_bf16x2(f[2] * ri[2], f[3] * ri[3]);
                 kk[rr].x = valid ? kk[rr].x : 0u;
                 kk[rr].y = valid ? kk[rr].y : 0u;
-                if constexpr (!STATE_ONLY || kTR) *reinterpret_cast<uint2*>(qkp + C * SQ + rr * SQ) = kk[rr];
+                if constexpr (!STATE_ONLY) *reinterpret_cast<uint2*>(qkp + C * SQ + rr * SQ) = kk[rr];
                 const uint2 rv = *reinterpret_cast<const uint2*>(rawp + 3 * RAWT + rr * DK);
                 vv[rr] = valid ? rv : make_uint2(0u, 0u);
             }
@@ -359,11 +330,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             }
         }
         // transposed pieces: element (channel ch0+i, tokens 2rp, 2rp+1) = one 4-byte word = one byte permute of the two rows
-        if constexpr (kTR) {                                  // the value operand stays row-major (rows >= nv are zero)
-            *reinterpret_cast<uint2*>(&s_vr[(2 * rp) * SV + ch0]) = vv[0];
-            *reinterpret_cast<uint2*>(&s_vr[(2 * rp + 1) * SV + ch0]) = vv[1];
-            return;
-        }
         if constexpr (MODE == 0) {
             *reinterpret_cast<unsigned*>(tp) = byte_perm(kk[1].x, kk[0].x, 0x05040100u);
             *reinterpret_cast<unsigned*>(tp + ST) = byte_perm(kk[1].x, kk[0].x, 0x07060302u);
@@ -374,15 +340,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         *reinterpret_cast<unsigned*>(tp + DK * ST + ST) = byte_perm(vv[1].x, vv[0].x, 0x07060302u);
         *reinterpret_cast<unsigned*>(tp + DK * ST + 2 * ST) = byte_perm(vv[1].y, vv[0].y, 0x05040100u);
         *reinterpret_cast<unsigned*>(tp + DK * ST + 3 * ST) = byte_perm(vv[1].y, vv[0].y, 0x07060302u);
-    };
-    // ONE of a loader wave's 16 DMA instructions (idx = 4 * tensor + row-pair slot), for interleaving with its MFMAs
-    auto dma_piece = [&](int t_first, int idx) {
-        const int a = idx >> 2, j = idx & 3;
-        const int pair = 4 * (w - kDmaWave0) + j;
-        const unsigned t = src_row(a, min(t_first + 2 * pair + (lane >> 5), T - 1));
-        bf16_t* dst = a == 0 ? s_rq : a == 1 ? s_rk : a == 2 ? s_rg : s_rv;
-        const unsigned boff = 2u * (t * gst[a] + 8u * (unsigned)(lane & 31));
-        dma16_to_lds_async(gsrc[a], boff, &dst[pair * PE]);
     };
     using FullT = std::true_type;
     using PartT = std::false_type;
@@ -425,12 +382,12 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     auto store_prev = [&]() {
         if constexpr (!STATE_ONLY && MODE == 0) {
 #pragma unroll
-            for (int nt = 0; nt < (LINA_K2_ABL == 8 ? 0 : 2); ++nt) {
+            for (int nt = 0; nt < 2; ++nt) {
                 const int row = 16 * nt + li;
                 uint2 po;
                 po.x = pack_bf16x2(acc[nt][0] * scale, acc[nt][1] * scale);
                 po.y = pack_bf16x2(acc[nt][2] * scale, acc[nt][3] * scale);
-                if (row < np && LINA_K2_ABL != 7) {
+                if (row < np) {
                     const unsigned boff = 2u * (out_row(tp + row) * (unsigned)so.t + 16u * (unsigned)w + 4u * (unsigned)lg);
                     *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) + boff) = po;
                 }
@@ -548,9 +505,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             rn = tid < DK ? s_Rn[tid] : 0.0f;
         }
         const bool renorm = fl.y != 0;                         // workgroup-uniform: set in phase A, reset one chunk later
-        constexpr bool kSpreadDma = LINA_K2_VAR == 1 && !STATE_ONLY && G == 1;
         const bool more = t0 + n < T;
-        if (more && !kSpreadDma) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);   // next chunk's raw q,k,g,v fly under phase B
+        // (the loader waves interleaving their 16 DMA instructions with their own step-(1) MFMAs instead: 0.644 ms vs 0.592 --
+        //  the pieces land later and everybody waits at (3); measured round 2, tests/gpu_k2var.sh)
+        if (more) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);   // next chunk's raw q,k,g,v fly under phase B
         if (STATE_ONLY && w == 0) {                                    // s_dec is stable between barriers (2) and (3)
             const float4 d = *reinterpret_cast<const float4*>(&s_dec[4 * lane]);
             decp.x *= d.x; decp.y *= d.y; decp.z *= d.z; decp.w *= d.w;
@@ -603,125 +561,23 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             K2_PROF(3);
         }
         const bf16_t* ktp = &s_kT[(16 * NTL * hw + li) * ST + 8 * lg];   // k~^T fragment of this head's state tile p: + 16 p ST
-        // operand fragments whose K dimension is the token axis.  kTR: two transposing reads each (four tokens of 16 channels
-        // per read; a 16-lane group addresses row T0 + (li>>2), channel quad li&3 and lane li receives channel li) straight
-        // from the row-major tiles -- the k~ tile through its channel permutation and piece swizzle.  The token <-> k-slot
-        // map of a product is free as long as both operands share it: under kTR lane group lg takes tokens 4 lg .. 4 lg + 3
-        // and 16 + 4 lg .. + 3 in BOTH step (3) and step (4) (a 32-lane service group of the read then touches 8 consecutive
-        // rows: distinct banks on the 544-byte rows, and step (4)'s v fragment is step (3)'s)
-        auto tr8 = [&](const bf16_t* p0, const bf16_t* p1) { return as_bf16x8(lds_read_tr16_b64(p0), lds_read_tr16_b64(p1)); };
-        auto ld_kt = [&](int p) -> bf16x8 {                    // k~^T of this head's state row tile p, tokens 8 lg .. 8 lg + 7
-            if constexpr (!kTR) return frag16(ktp + 16 * p * ST);
-            else {
-                const int m16 = NTL * hw + p, t0 = 4 * lg + (li >> 2), t1 = t0 + 16;
-                const bf16_t* b = &s_k[32 * (m16 >> 1) + 4 * (m16 & 1)];
-                return tr8(b + t0 * SK + 8 * ((li & 3) ^ ((t0 >> 2) & 3)), b + t1 * SK + 8 * ((li & 3) ^ ((t1 >> 2) & 3)));
-            }
-        };
-        auto ld_v8 = [&]() -> bf16x8 {                         // v^T of this wave's 16 columns, tokens 8 lg .. 8 lg + 7
-            if constexpr (!kTR) return frag16(&s_vT[(16 * w + li) * ST + 8 * lg]);
-            else {
-                const bf16_t* b = &s_vr[(4 * lg + (li >> 2)) * SV + 16 * w + 4 * (li & 3)];
-                return tr8(b, b + 16 * SV);
-            }
-        };
+        // operand fragments whose K dimension is the token axis, from the transposed tiles (one ds_read_b128 each).
+        // (Round 3 measured the alternative built in round 2 -- NO transposed tiles, the fragments read with ds_read_b64_tr_b16
+        //  from the row-major tiles, optionally with a 128 x 32 state block per wave that halves the q~ / k~^T operand reads:
+        //  0.586 / 0.584 ms against 0.577 ms for this form at B=64,H=4,T=4096 (tests/gpu_k2tr.sh, profiles/r03_k2_variants.txt);
+        //  removed.)
+        auto ld_kt = [&](int p) -> bf16x8 { return frag16(ktp + 16 * p * ST); };   // k~^T of this head's state row tile p, tokens 8 lg .. + 7
+        auto ld_v8 = [&]() -> bf16x8 { return frag16(&s_vT[(16 * w + li) * ST + 8 * lg]); };   // v^T of this wave's 16 columns, tokens 8 lg .. + 7
         auto ld_v4 = [&]() -> bf16x8 {                         // ... tokens 4 lg .. 4 lg + 3 and 16 + 4 lg .. 16 + 4 lg + 3
-            if constexpr (!kTR) { const bf16_t* vp = &s_vT[(16 * w + li) * ST + 4 * lg]; return frag8x2(vp, vp + 16); }
-            else {
-                const bf16_t* b = &s_vr[(4 * lg + (li >> 2)) * SV + 16 * w + 4 * (li & 3)];
-                return tr8(b, b + 16 * SV);
-            }
+            const bf16_t* vp = &s_vT[(16 * w + li) * ST + 4 * lg];
+            return frag8x2(vp, vp + 16);
         };
         // ring of k~^T fragments, TA tiles ahead (MODE 1 carries its 8 output factors across this phase: a shallower ring
         // instead of spills, whose reloads would wait on the loader waves' in-flight DMA)
-        constexpr int TA = MODE == 1 ? (kTR && DG ? 2 : 3) : (kTR ? 4 : 5);
+        constexpr int TA = MODE == 1 ? 3 : 5;
         bf16x8 tf[8];
         bf16x8 vb2;                                            // v^T fragment of step (4) (tokens as k-slots 8lg..8lg+7)
         bf16x8 vb;                                             // v^T fragment of step (3), read before the tiles die at (3)
-        f32x4 xown[2];                                         // kW32: this wave's partial o^T of its own 16 columns, per token tile
-        if constexpr (kW32) {
-            // ---- the 128 x 32 block form: tiles S[2p + c], p = row tile of this wave's row half, c = column tile ----
-            auto v8c = [&](int c) {                            // v^T of column tile c, tokens 4 lg .. + 3 and 16 + 4 lg .. + 3
-                const bf16_t* b = &s_vr[(4 * lg + (li >> 2)) * SV + 32 * cp + 16 * c + 4 * (li & 3)];
-                return tr8(b, b + 16 * SV);
-            };
-            // (1) partial o^T over this wave's 128 rows: tile pairs pp = 0..3 = k-steps 4 rh + pp of the q~ tile; every q~
-            //     fragment feeds BOTH column tiles
-            const bf16_t* qp = &s_q[li * SQ + 8 * (lg ^ ((li >> 2) & 3)) + 128 * rh];
-            constexpr int WA = MODE == 1 ? 1 : 2;              // operand rings: WA tile pairs / k~^T tiles ahead (MODE 1 carries more)
-            bf16x8 qf[4][2];
-#pragma unroll
-            for (int pp = 0; pp < WA; ++pp)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) qf[pp][nt] = frag16(qp + 16 * nt * SQ + 32 * pp);
-            bf16x8 vbc[2];
-            f32x4 accw[2] = {};                                // o^T of column tile 1 (acc[] = column tile 0), per token tile
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                if (pp + WA < 4) {
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) qf[pp + WA][nt] = frag16(qp + 16 * nt * SQ + 32 * (pp + WA));
-                } else if (MODE == 1) {                        // (value-gated sweeps: step (4)'s operands after step (1))
-                } else if (pp == 4 - WA) {                     // the free slots take step (4)'s first operands
-                    vbc[0] = v8c(0); vbc[1] = v8c(1);
-                } else {
-                    tf[0] = ld_kt(8 * rh); tf[1] = ld_kt(8 * rh + 1);
-                }
-                sched_fence();
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    bf16x8 bb;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        bb[r] = (short)f2bf(S[2 * (2 * pp) + c][r]);
-                        bb[4 + r] = (short)f2bf(S[2 * (2 * pp + 1) + c][r]);
-                    }
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        if (c == 0) acc[nt] = mfma_bf16_16x16x32(bb, qf[pp][nt], acc[nt]);
-                        else accw[nt] = mfma_bf16_16x16x32(bb, qf[pp][nt], accw[nt]);
-                    }
-                }
-                sched_fence();
-            }
-            K2_PROF(11);                                       // (profile build: step (1) of this form; slot 4 then holds its step (4))
-            tp = t0; np = n;
-            if constexpr (MODE == 1) { vbc[0] = v8c(0); vbc[1] = v8c(1); tf[0] = ld_kt(8 * rh); }
-            // (4) S' += k^^T v: every k~^T fragment feeds both column tiles
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                if (p + WA < 8) tf[(p + WA) & 7] = ld_kt(8 * rh + p + WA);
-                sched_fence();
-                S[2 * p] = mfma_bf16_16x16x32(tf[p & 7], vbc[0], S[2 * p]);
-                S[2 * p + 1] = mfma_bf16_16x16x32(tf[p & 7], vbc[1], S[2 * p + 1]);
-                sched_fence();
-            }
-            if constexpr (DG) { prefetch_prev(); sched_fence(); }   // (after step (4): its operands' registers are free)
-            if (renorm && MODE == 1) {                         // rare: the gated channel is the tile COLUMN
-#pragma unroll
-                for (int t = 0; t < NTL; ++t) {
-                    const float f = fast_exp2(s_Rn[tile_col(t) + li]);
-                    S[t][0] *= f; S[t][1] *= f; S[t][2] *= f; S[t][3] *= f;
-                }
-            } else if (renorm) {                               // rare: S' <- e^{R} S'
-#pragma unroll
-                for (int t = 0; t < NTL; ++t) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(&s_Rn[tile_ch(t) + 4 * lg]);
-                    S[t][0] *= fast_exp2(r4.x); S[t][1] *= fast_exp2(r4.y); S[t][2] *= fast_exp2(r4.z); S[t][3] *= fast_exp2(r4.w);
-                }
-            }
-            // step (3)'s v fragment: this wave's OWN 16 columns (column tile rh of the pair), same token map as step (4)
-            if constexpr (DG) vb = ld_v4();                    // (sweep K: re-read instead of keeping both tiles' fragments alive)
-            else vb = rh ? vbc[1] : vbc[0];
-            // the partial sums of the partner's 16 columns (column tile 1 - rh) cross to wave w ^ 1; this wave keeps its own
-            float4* xw = reinterpret_cast<float4*>(&s_x[((w * 2) * 64 + lane) * 4]);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const f32x4 give = rh ? acc[nt] : accw[nt];
-                xown[nt] = rh ? accw[nt] : acc[nt];
-                xw[64 * nt] = make_float4(give[0], give[1], give[2], give[3]);
-            }
-        } else
         if constexpr (!STATE_ONLY && G > 1) {
             // (1) for G heads per workgroup: the same products over this head's NTL/2 tile pairs (channels
             //     [D hw, D hw + D)); everything is requested up front (the state is only 64/G registers)
@@ -750,14 +606,14 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         } else if constexpr (!STATE_ONLY) {
             // (1) o = q~ . S_old : one K = 32 MFMA per pair of 16-row state tiles (converted to bf16 in registers)
             const bf16_t* qp = &s_q[li * SQ + 8 * (lg ^ ((li >> 2) & 3))];
-            constexpr int QA = MODE == 1 ? (kTR && DG ? 1 : 2) : 3;             // ring, QA tile pairs ahead (MODE 1: see TA)
+            constexpr int QA = MODE == 1 ? 2 : 3;                               // ring, QA tile pairs ahead (MODE 1: see TA)
             bf16x8 qf[4][2];
 #pragma unroll
             for (int pp = 0; pp < QA; ++pp)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) qf[pp][nt] = frag16(qp + 16 * nt * SQ + 32 * pp);
 #pragma unroll
-            for (int pp = 0; pp < (LINA_K2_ABL == 3 ? 0 : 8); ++pp) {
+            for (int pp = 0; pp < 8; ++pp) {
                 if (pp + QA < 8) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
@@ -786,10 +642,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 for (int nt = 0; nt < 2; ++nt)
                     acc[nt] = mfma_bf16_16x16x32(bb, qf[pp & 3][nt], acc[nt]);   // o^T: rows = state columns, cols = tokens
                 sched_fence();
-                if constexpr (kSpreadDma) {                   // the loader waves' DMAs ride between their own MFMAs
-                    if (more && w >= kDmaWave0) { dma_piece(t0 + n, 2 * pp); dma_piece(t0 + n, 2 * pp + 1); }
-                    sched_fence();
-                }
             }
         } else {
             vb2 = ld_v8();
@@ -797,7 +649,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             for (int p = 0; p < (NTL < TA ? NTL : TA); ++p) tf[p] = ld_kt(p);
         }
         K2_PROF(4);
-        if constexpr (!kW32) {
         // DG: the aux (k) / aux2 (dq) rows of THIS chunk's tokens are requested here -- the q~ ring's registers are free from now on, and
         // the loads have step (4), barrier (3), step (3) and the next gate scan to land (requested after barrier (3) they were
         // waited for with most of their latency exposed: SQ_WAIT_ANY 65 % of the wave cycles against 47 % for sweep V)
@@ -813,7 +664,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         }
         // (4) S' += k^^T v
 #pragma unroll
-        for (int p = 0; p < (LINA_K2_ABL == 4 ? 0 : NTL); ++p) {
+        for (int p = 0; p < NTL; ++p) {
             if (p + TA < NTL) tf[(p + TA) & 7] = ld_kt(p + TA);
             sched_fence();
             S[p] = mfma_bf16_16x16x32(tf[p & 7], vb2, S[p]);
@@ -831,11 +682,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             }
         }
         // v fragment of step (3) (same token order as the C/D rows of mask(A)): read before the tiles die at (3)
-        }   // !kW32
-        if constexpr (!STATE_ONLY && !kW32) {
-            if constexpr (kTR) vb = vb2;                       // same columns, same token map
-            else vb = ld_v4();
-        }
+        if constexpr (!STATE_ONLY) vb = ld_v4();
         K2_PROF(5);
         // the DMA was issued through inline assembly: this wave's part has landed (the DG rows requested after it may not) ...
         wait_vmem_but<DG ? 4 : 0>();
@@ -844,14 +691,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         K2_PROF(9);
         lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;   // re-derive, do not carry
         if (tid == 0) { s_flags[2 * par] = 0; s_flags[2 * par + 1] = 0; }   // read by all before (3); set again two chunks later, after (2) of the next
-        if constexpr (kW32) {                                  // + the partner's partial sums over the other 128 rows
-            const float4* xr = reinterpret_cast<const float4*>(&s_x[(((w ^ 1) * 2) * 64 + lane) * 4]);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const float4 pt = xr[64 * nt];
-                acc[nt] = f32x4{xown[nt][0] + pt.x, xown[nt][1] + pt.y, xown[nt][2] + pt.z, xown[nt][3] + pt.w};
-            }
-        }
         if constexpr (!STATE_ONLY) {
             // (3) o += mask(A) . v -- AFTER the barrier: no barrier of its own for mask(A); s_A is rewritten only after the
             //     next chunk's barrier (2)

@@ -46,7 +46,11 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
     __shared__ float s_st[NW][64][2];
     __shared__ float s_lr[64][R + 1];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index in an SGPR: everything that depends on it (k-step ownership, remainder rounds, who finalises what) is
+    // then a SCALAR branch.  With w in a VGPR the compiler predicates such code with EXEC -- and an MFMA issued under
+    // EXEC = 0 still executes, on whatever its (unwritten) operand registers hold: non-finite sums on the hardware.
+    const int w = wave_uniform(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const int m0 = blockIdx.y * 64;
     const int n_direct = 2 * Kd + 2 * Vd;               // q | k | v | g columns; low-rank rows follow in W
@@ -296,7 +300,9 @@ static int inproj_impl(const void* x, int64_t ldx, const void* w_in, int64_t ldw
     const int cols = wide ? 32 : 16;
     dim3 grid((unsigned)((2 * Kd + 2 * Vd + Kd) / cols), (unsigned)((B + 63) / 64));
     // waves per workgroup (split-K width) of the packed kernel, see linear_skinny.hip; LINA_SKINNY_WAVES overrides
-    int nw = 4;
+    // Measured in the L169 decode step (tests/gpu_r03e.sh, ms per token): 4 waves 0.660, 8 waves 0.624, 16 waves on the plain
+    // 16-column projections + 8 elsewhere 0.617.
+    int nw = 16;
     {
         const char* forced_nw = getenv("LINA_SKINNY_WAVES");   // (read per call: tests switch it)
         if (forced_nw) nw = atoi(forced_nw);

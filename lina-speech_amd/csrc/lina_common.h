@@ -57,8 +57,16 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
 // made the per-element epilogues (short conv, norm-gate, SwiGLU) VALU-bound
 __device__ __forceinline__ float sigmoidf(float x) { return fast_rcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu(float x) { return x * sigmoidf(x); }
-// log(sigmoid(x)) = min(x,0) - log1p(exp(-|x|))   (the form torch's CPU kernel uses)
-__device__ __forceinline__ float logsigmoidf(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
+// log(sigmoid(x)) = min(x,0) - log1p(exp(-|x|))   (the form torch's CPU kernel uses), on the hardware transcendentals:
+// e = v_exp_f32, log1p(e) = v_log_f32(1 + e) above 1/64 and the series e - e^2/2 + e^3/3 below (where 1 + e would round
+// e away): absolute error < 1e-7 everywhere, relative error of the small values < 2e-6.  The precise libm forms (log1pf,
+// expf: ~100 instructions per call) made the gate tiles the slowest workgroups of the in-projection launch -- 8 calls per
+// thread, a ~2.5 us tail on a 10.5 us kernel (time stamps of tools/probe_skinny_prof.py).
+__device__ __forceinline__ float logsigmoidf(float x) {
+    const float e = __expf(-fabsf(x));
+    const float l = e < 0.015625f ? e * (1.0f - e * (0.5f - e * 0.33333334f)) : __logf(1.0f + e);
+    return fminf(x, 0.0f) - l;
+}
 
 static inline bool valid_dtype(int d) { return d == LINA_F32 || d == LINA_BF16; }
 

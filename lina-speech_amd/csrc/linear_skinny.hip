@@ -56,7 +56,11 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
     __shared__ __attribute__((aligned(16))) float s_acc[NW][G * MT][64][4];  // [wave][group x m-tile][lane][reg]
     __shared__ float s_st[NW][16 * MT][2];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index in an SGPR: everything that depends on it (k-step ownership, remainder rounds, who finalises what) is
+    // then a SCALAR branch.  With w in a VGPR the compiler predicates such code with EXEC -- and an MFMA issued under
+    // EXEC = 0 still executes, on whatever its (unwritten) operand registers hold: non-finite sums on the hardware.
+    const int w = wave_uniform(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * (16 * MT);
     const int n_rows = SWIGLU ? Hd : N;     // weight rows per half
@@ -66,6 +70,9 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
     for (int i = 0; i < G * MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // LayerNorm statistics without VALU work: sum_k a = (A . 1)[i][*], sum_k a^2 = diag(A . A^T) -- the A
     // fragment is also a valid B fragment (same lane layout with i <-> n), so both are two more MFMAs per step
+    // (16-wave workgroups have 128 registers per lane: there the two statistics are per-lane dot products of the lane's own
+    // fragment elements -- 2 registers per m-tile instead of 8 -- summed over the four lane groups of a row at the end)
+    constexpr bool VST = LN && NW == 16;
     f32x4 st1[MT], st2[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) { st1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; st2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -139,7 +146,12 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                if (LN) {
+                if (LN && VST) {
+                    float s1_ = st1[mt][0], s2_ = st2[mt][0];
+                    fa[u][mt].stats(s1_, s2_);
+                    st1[mt][0] = s1_; st2[mt][0] = s2_;
+                }
+                if (LN && !VST) {
                     st1[mt] = F::mma(fa[u][mt], f_ones, st1[mt]);
                     st2[mt] = F::mma(fa[u][mt], fa[u][mt], st2[mt]);
                 }
@@ -151,21 +163,37 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
 #endif
     }
     SK_PROF(3, clock64());
-    for (; kstep_of<NW>(w, ks) < nsteps; ++ks) {
-        const int64_t k0 = kstep_of<NW>(w, ks) * kstr;
-        F fb[G], fa[MT];
+    if (kstep_of<NW>(w, ks) < nsteps) {
+        // remainder (fewer than U steps for this wave, e.g. K = 1376: 43 k-steps): ONE more round with every load in flight --
+        // a loop of single steps pays a full memory round trip per step (+1.1 us on the down-projection, time stamps of
+        // tools/probe_skinny_prof.py).  Steps past the end contribute zero fragments: the sums are unchanged bit for bit.
+        F fb[U][G], fa[U][MT];
 #pragma unroll
-        for (int g = 0; g < G; ++g) { if (g_ok[g]) fb[g].template load_stream<WNT>(wp[g] + k0); else fb[g].zero(); }
+        for (int u = 0; u < U; ++u) {
+            const bool on = kstep_of<NW>(w, ks + u) < nsteps;           // wave-uniform
+            const int64_t k0 = kstep_of<NW>(w, ks + u) * kstr;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[mt].load(ap[mt] + k0); else fa[mt].zero(); }
+            for (int g = 0; g < G; ++g) { if (on && g_ok[g]) fb[u][g].template load_stream<WNT>(wp[g] + k0); else fb[u][g].zero(); }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (LN) {
-                st1[mt] = F::mma(fa[mt], f_ones, st1[mt]);
-                st2[mt] = F::mma(fa[mt], fa[mt], st2[mt]);
+            for (int mt = 0; mt < MT; ++mt) { if (on && m_ok[mt]) fa[u][mt].load(ap[mt] + k0); else fa[u][mt].zero(); }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (kstep_of<NW>(w, ks + u) >= nsteps) break;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (LN && VST) {
+                    float s1_ = st1[mt][0], s2_ = st2[mt][0];
+                    fa[u][mt].stats(s1_, s2_);
+                    st1[mt][0] = s1_; st2[mt][0] = s2_;
+                }
+                if (LN && !VST) {
+                    st1[mt] = F::mma(fa[u][mt], f_ones, st1[mt]);
+                    st2[mt] = F::mma(fa[u][mt], fa[u][mt], st2[mt]);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g * MT + mt] = F::mma(fa[u][mt], fb[u][g], acc[g * MT + mt]);
             }
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[g * MT + mt] = F::mma(fa[mt], fb[g], acc[g * MT + mt]);
         }
     }
 
@@ -176,6 +204,13 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
     if (LN) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {   // D layout: lane (col li, rows 4lg+r); the diagonal sits at li == 4lg+r
+            if (VST) {                           // lane (li, lg) holds row li's sums over its own 8 (4) k-slots of every step
+                float a = st1[mt][0], b = st2[mt][0];
+                a += shfl_xor(a, 16); b += shfl_xor(b, 16);
+                a += shfl_xor(a, 32); b += shfl_xor(b, 32);
+                if (lg == 0) { s_st[w][16 * mt + li][0] = a; s_st[w][16 * mt + li][1] = b; }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (li == 4 * lg + r) { s_st[w][16 * mt + li][0] = st1[mt][r]; s_st[w][16 * mt + li][1] = st2[mt][r]; }
@@ -190,7 +225,7 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         float4 t = *reinterpret_cast<const float4*>(&s_acc[0][g * MT + w][lane][0]);
-#pragma unroll
+#pragma unroll 4                          // (all NW reads in flight at once would cost 4 NW registers per group)
         for (int ww = 1; ww < NW; ++ww) {
             const float4 u = *reinterpret_cast<const float4*>(&s_acc[ww][g * MT + w][lane][0]);
             t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
@@ -265,11 +300,15 @@ static void launch_skinny_packed(int nw, dim3 grid, lina_stream_t stream, const 
     LINA_LAUNCH((linear_skinny_kernel<TT, SW, LNN, MTT, NTT, true, WNTT, NWW>), grid, dim3(64 * NWW), 0, stream,      \
                 (const TT*)A, lda, (const TT*)W, ldw, c1, c2, (const TT*)resid, ldr, (TT*)out, ldo, M, N, K,          \
                 swiglu_hidden, ln_dim, ln_eps, (TT*)outp, Kp, Hp)
-    if constexpr (!SW && NTT == 1) {
+    if constexpr (NTT == 1 && MTT <= 2) {
         if (nw == 16) { LINA_LS_GO(16); return; }
     }
-    if (nw >= 8) LINA_LS_GO(8);
-    else LINA_LS_GO(4);
+    if constexpr (SW && MTT == 4 && NTT == 2) {       // 16 accumulator tiles per wave: 8 waves would spill
+        LINA_LS_GO(4);
+    } else {
+        if (nw >= 8) LINA_LS_GO(8);
+        else LINA_LS_GO(4);
+    }
 #undef LINA_LS_GO
 }
 
@@ -313,7 +352,9 @@ static int linear_skinny_impl(const void* A, int64_t lda, const void* W, int64_t
     dim3 grid((unsigned)((N + 16 * best_nt - 1) / (16 * best_nt)), (unsigned)((M + 16 * best_mt - 1) / (16 * best_mt)));
     // waves per workgroup (split-K width) of the packed kernels: more waves = fewer loads per wave for the same bytes per
     // workgroup (see the kernel's NW note); each wave needs at least one pair of k-steps.  LINA_SKINNY_WAVES overrides.
-    int nw = 4;
+    // Measured in the L169 decode step (tests/gpu_r03e.sh, ms per token): 4 waves 0.660, 8 waves 0.624, 16 waves on the plain
+    // 16-column projections + 8 elsewhere 0.617.
+    int nw = 16;
     {
         const char* forced_nw = getenv("LINA_SKINNY_WAVES");   // (read per call: tests switch it)
         if (forced_nw) nw = atoi(forced_nw);

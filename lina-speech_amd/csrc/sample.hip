@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void topk_sample_rows_kernel(const T* __restri
     const int tid = threadIdx.x;
     const int64_t row = blockIdx.x;
     const T* x = logits + row * row_stride;
-    for (int j = tid; j < n; j += 256) s_x[j] = ld(x + j);
+    row_to_lds(x, n, s_x);
     const float u = u_ext ? u_ext[row] : hash_uniform(seed, step ? (uint64_t)step[0] : 0ull, (uint64_t)row, gridDim.x);
     const int pick = topk_sample_block(s_x, n, k, inv_temp, u, sc);
     if (tid == 0) out[row] = pick;

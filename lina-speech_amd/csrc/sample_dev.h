@@ -152,6 +152,47 @@ __device__ __forceinline__ int topk_sample_block(const float* s_x, int n, int k,
     return pick;
 }
 
+// thread-local part of a row arg-max: elements tid, tid + 256, ... in ascending order (lowest index wins a tie).  The
+// loads go out in rounds of kArgmaxInFlight per thread -- 20 x 256 covers the 4099 codec logits in ONE round trip; the plain
+// loop (one 2-byte load per iteration, the compare chain behind it) paid one L2 round trip per 256 elements.
+constexpr int kArgmaxInFlight = 20;
+template <typename T>
+__device__ __forceinline__ void argmax_scan(const T* row, int n, float& best, int& bi) {
+    const int tid = threadIdx.x;
+    for (int j0 = tid; j0 < n; j0 += 256 * kArgmaxInFlight) {
+        float v[kArgmaxInFlight];
+#pragma unroll
+        for (int u = 0; u < kArgmaxInFlight; ++u) {
+            const int j = j0 + 256 * u;
+            v[u] = j < n ? ld(row + j) : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < kArgmaxInFlight; ++u) {
+            const int j = j0 + 256 * u;
+            if (j < n && (v[u] > best || (v[u] == best && j < bi))) { best = v[u]; bi = j; }
+        }
+    }
+}
+
+// row[0..n) -> s_x (fp32, LDS) by the 256 threads, every load in flight at once like argmax_scan
+template <typename T>
+__device__ __forceinline__ void row_to_lds(const T* row, int n, float* s_x) {
+    const int tid = threadIdx.x;
+    for (int j0 = tid; j0 < n; j0 += 256 * kArgmaxInFlight) {
+        float v[kArgmaxInFlight];
+#pragma unroll
+        for (int u = 0; u < kArgmaxInFlight; ++u) {
+            const int j = j0 + 256 * u;
+            v[u] = j < n ? ld(row + j) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < kArgmaxInFlight; ++u) {
+            const int j = j0 + 256 * u;
+            if (j < n) s_x[j] = v[u];
+        }
+    }
+}
+
 // arg-max of row[0..n) (first index on ties; 0 when every entry is -inf / NaN) by the 256 threads of the workgroup;
 // s_val / s_idx: 4-entry LDS scratch.  Every thread returns the index.  Ends with a barrier.
 template <typename T>
@@ -159,10 +200,7 @@ __device__ __forceinline__ int argmax_block(const T* row, int n, float* s_val, i
     const int tid = threadIdx.x;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int j = tid; j < n; j += 256) {
-        const float vj = ld(row + j);
-        if (vj > best || (vj == best && j < bi)) { best = vj; bi = j; }
-    }
+    argmax_scan(row, n, best, bi);
     if (bi == 0x7fffffff && tid < n) bi = tid;      // all -inf/NaN in this thread's slice
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {

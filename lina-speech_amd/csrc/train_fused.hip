@@ -1,0 +1,280 @@
+// train_fused.hip -- K10 / K11: the elementwise glue of the TRAINING step around the mixer:
+//   K10   x' = x (+ r);  y = LayerNorm(x') * gamma + beta        forward and backward   (reference model/base_blocks.py:65-69:
+//         `x = tmix(norm1(x)) + x; x = cmix(norm2(x)) + x` -- the residual add that precedes a norm rides in the norm's pass)
+//   K11b  backward of the SwiGLU gate  s = silu(a) * b                                    (reference model/base_blocks.py:48-50)
+// Why: in the L169 train step (b = 8 x 4096 tokens, bf16 autocast) the vendor LayerNorm runs in fp32 with separate cast
+// and residual-add passes, 35 % of the step was torch elementwise / LayerNorm / cast kernels
+// (profiles/r02r_train_step_kernel_stats.csv).  These kernels read the fp32 residual stream once and write the model-dtype
+// operand of the next GEMM directly; the backward forms dx, the residual's pass-through gradient and per-workgroup
+// partials of dgamma / dbeta (summed by the caller: deterministic, no atomics) in one pass.
+// Work split: one wave per row (a row's D elements are contiguous: 16 B per lane and piece), 4 rows per 256-thread
+// workgroup, grid-stride over the rows; all reductions are wave shuffles.  HBM-bound streaming kernels.
+#include <lina_dev.h>
+#include "lina_common.h"
+
+namespace lina {
+
+constexpr int kLnMaxPieces = 8;        // D <= 64 lanes * 4 elements * 8 pieces = 2048
+
+__device__ __forceinline__ float wave_sum(float v) {
+    v += shfl_xor(v, 1); v += shfl_xor(v, 2); v += shfl_xor(v, 4);
+    v += shfl_xor(v, 8); v += shfl_xor(v, 16); v += shfl_xor(v, 32);
+    return v;
+}
+
+// TX: residual-stream dtype (x, xsum, dx);  TR: dtype of the added branch r (and of its gradient);  TY: output dtype
+template <typename TX, typename TR, typename TY, int NP>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TX* __restrict__ x, const TR* __restrict__ r,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            TX* __restrict__ xsum, TY* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int64_t N,
+                                                            int D, float eps) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float inv_d = 1.0f / (float)D;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < N; row += (int64_t)gridDim.x * 4) {
+        float4 v[NP];
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int e = 4 * lane + 256 * i;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < D) {
+                v[i] = ld4(x + row * D + e);
+                if (r) {
+                    const float4 a = ld4(r + row * D + e);
+                    v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
+                    if (xsum) {                              // the value the stream carries on (rounded to its dtype first)
+                        st4(xsum + row * D + e, v[i]);
+                        if (!std::is_same<TX, float>::value) {
+                            TX t4[4];
+                            st4(t4, v[i]);
+                            v[i] = ld4(t4);
+                        }
+                    }
+                }
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+        }
+        const float mu = wave_sum(s) * inv_d;
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int e = 4 * lane + 256 * i;
+            if (e < D) {
+                const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+                q += (a * a + b * b) + (c * c + d * d);
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) * inv_d + eps);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int e = 4 * lane + 256 * i;
+            if (e < D) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + e), bb = *reinterpret_cast<const float4*>(beta + e);
+                st4(y + row * D + e, make_float4((v[i].x - mu) * rs * g.x + bb.x, (v[i].y - mu) * rs * g.y + bb.y,
+                                                 (v[i].z - mu) * rs * g.z + bb.z, (v[i].w - mu) * rs * g.w + bb.w));
+            }
+        }
+    }
+}
+
+// dx = dpass + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd
+// dpass (optional): the gradient that reaches x' through the residual path; dr (optional): the same dx in the branch's
+// dtype (the gradient of the added branch r).  dgamma / dbeta partials per workgroup: [gridDim.x][D].
+template <typename TX, typename TR, typename TY, int NP>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TY* __restrict__ dy, const TX* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const TX* __restrict__ dpass,
+                                                            TX* __restrict__ dx, TR* __restrict__ dr,
+                                                            float* __restrict__ dg_part, float* __restrict__ db_part,
+                                                            int64_t N, int D) {
+    __shared__ __attribute__((aligned(16))) float s_part[2][3][64][4];       // [dgamma|dbeta][waves 1..3][lane][4]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float inv_d = 1.0f / (float)D;
+    float4 ag[NP], ab[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < N; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float4 g[NP], xh[NP];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int e = 4 * lane + 256 * i;
+            g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xh[i] = g[i];
+            if (e < D) {
+                const float4 d = ld4(dy + row * D + e), xv = ld4(x + row * D + e);
+                const float4 gm = *reinterpret_cast<const float4*>(gamma + e);
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+                ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+                g[i] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+            }
+        }
+        const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int e = 4 * lane + 256 * i;
+            if (e < D) {
+                float4 o = make_float4(rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2),
+                                       rs * (g[i].z - m1 - xh[i].z * m2), rs * (g[i].w - m1 - xh[i].w * m2));
+                if (dpass) {
+                    const float4 p = ld4(dpass + row * D + e);
+                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+                }
+                st4(dx + row * D + e, o);
+                if (dr) st4(dr + row * D + e, o);
+            }
+        }
+    }
+    // dgamma / dbeta of this workgroup's rows: waves 1..3 hand their sums to wave 0 through LDS, piece by piece
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (4 * lane + 256 * i >= D && i > 0) break;
+        __syncthreads();
+        if (w > 0) {
+            *reinterpret_cast<float4*>(&s_part[0][w - 1][lane][0]) = ag[i];
+            *reinterpret_cast<float4*>(&s_part[1][w - 1][lane][0]) = ab[i];
+        }
+        __syncthreads();
+        if (w == 0) {
+            const int e = 4 * lane + 256 * i;
+            float4 a = ag[i], b = ab[i];
+#pragma unroll
+            for (int ww = 0; ww < 3; ++ww) {
+                const float4 pa = *reinterpret_cast<const float4*>(&s_part[0][ww][lane][0]);
+                const float4 pb = *reinterpret_cast<const float4*>(&s_part[1][ww][lane][0]);
+                a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
+                b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+            }
+            if (e < D) {
+                *reinterpret_cast<float4*>(dg_part + (int64_t)blockIdx.x * D + e) = a;
+                *reinterpret_cast<float4*>(db_part + (int64_t)blockIdx.x * D + e) = b;
+            }
+        }
+    }
+}
+
+// ds [rows, Hd], u [rows, 2 Hd] (row stride ld_u)  ->  du [rows, 2 Hd]:  d/da (silu(a) b) = b sig(a) (1 + a (1 - sig(a))),
+// d/db = silu(a)
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ ds, const T* __restrict__ u, T* __restrict__ du,
+                                                         int64_t rows, int Hd, int64_t ld_u, int64_t ld_ds, int64_t ld_du) {
+    const int64_t n4 = (int64_t)rows * (Hd / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / (Hd / 4);
+        const int j = (int)(i % (Hd / 4)) * 4;
+        const float4 a = ld4(u + row * ld_u + j), b = ld4(u + row * ld_u + Hd + j), d = ld4(ds + row * ld_ds + j);
+        float4 da, db;
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, dv[4] = {d.x, d.y, d.z, d.w};
+        float oa[4], ob[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float sg = sigmoidf(av[c]);
+            oa[c] = dv[c] * bv[c] * sg * (1.0f + av[c] * (1.0f - sg));
+            ob[c] = dv[c] * av[c] * sg;
+        }
+        da = make_float4(oa[0], oa[1], oa[2], oa[3]);
+        db = make_float4(ob[0], ob[1], ob[2], ob[3]);
+        st4(du + row * ld_du + j, da);
+        st4(du + row * ld_du + Hd + j, db);
+    }
+}
+
+}  // namespace lina
+
+extern "C" int lina_layernorm_bwd_partials(int64_t rows) {
+    const int64_t wgs = (rows + 3) / 4;
+    return (int)(wgs < 1024 ? wgs : 1024);
+}
+
+namespace {
+template <typename TX, typename TR, typename TY>
+int ln_fwd_launch(int np, dim3 grid, lina_stream_t stream, const void* x, const void* r, const float* gamma, const float* beta,
+                  void* xsum, void* y, float* mean, float* rstd, int64_t N, int D, float eps) {
+    using namespace lina;
+#define LINA_LN_F(NPP)                                                                                               \
+    LINA_LAUNCH((layernorm_fwd_kernel<TX, TR, TY, NPP>), grid, dim3(256), 0, stream, (const TX*)x, (const TR*)r, gamma, beta, \
+                (TX*)xsum, (TY*)y, mean, rstd, N, D, eps)
+    if (np <= 1) LINA_LN_F(1); else if (np <= 2) LINA_LN_F(2); else if (np <= 4) LINA_LN_F(4); else LINA_LN_F(8);
+#undef LINA_LN_F
+    return check_launch("lina_layernorm_fwd");
+}
+template <typename TX, typename TR, typename TY>
+int ln_bwd_launch(int np, dim3 grid, lina_stream_t stream, const void* dy, const void* x, const float* mean, const float* rstd,
+                  const float* gamma, const void* dpass, void* dx, void* dr, float* dg, float* db, int64_t N, int D) {
+    using namespace lina;
+#define LINA_LN_B(NPP)                                                                                               \
+    LINA_LAUNCH((layernorm_bwd_kernel<TX, TR, TY, NPP>), grid, dim3(256), 0, stream, (const TY*)dy, (const TX*)x, mean, rstd, \
+                gamma, (const TX*)dpass, (TX*)dx, (TR*)dr, dg, db, N, D)
+    if (np <= 1) LINA_LN_B(1); else if (np <= 2) LINA_LN_B(2); else if (np <= 4) LINA_LN_B(4); else LINA_LN_B(8);
+#undef LINA_LN_B
+    return check_launch("lina_layernorm_bwd");
+}
+}  // namespace
+
+// dtype triple (x_dtype, r_dtype, y_dtype): the combinations the train step produces -- fp32 stream with bf16 or fp32
+// branches and outputs, and the all-bf16 stream of a model cast to bf16
+#define LINA_LN_DISPATCH(CALL)                                                                                        \
+    do {                                                                                                              \
+        if (x_dtype == LINA_F32 && r_dtype == LINA_F32 && y_dtype == LINA_F32) return CALL(float, float, float);      \
+        if (x_dtype == LINA_F32 && r_dtype == LINA_BF16 && y_dtype == LINA_BF16) return CALL(float, bf16_t, bf16_t);  \
+        if (x_dtype == LINA_F32 && r_dtype == LINA_F32 && y_dtype == LINA_BF16) return CALL(float, float, bf16_t);    \
+        if (x_dtype == LINA_BF16 && r_dtype == LINA_BF16 && y_dtype == LINA_BF16) return CALL(bf16_t, bf16_t, bf16_t); \
+        return fail(LINA_ERR_UNSUPPORTED, "lina_layernorm: dtype combination (%d, %d, %d) is not built", x_dtype, r_dtype, y_dtype); \
+    } while (0)
+
+extern "C" int lina_layernorm_fwd(const void* x, const void* r, const float* gamma, const float* beta, void* xsum, void* y,
+                                  float* mean, float* rstd, int64_t N, int D, float eps, int x_dtype, int r_dtype,
+                                  int y_dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(x && gamma && beta && y && mean && rstd, "lina_layernorm_fwd: null pointer");
+    LINA_REQUIRE(N > 0 && D > 0 && D % 4 == 0, "lina_layernorm_fwd: N, D must be positive, D a multiple of 4");
+    LINA_REQUIRE(!xsum || r, "lina_layernorm_fwd: xsum needs the added branch r");
+    LINA_REQUIRE(valid_dtype(x_dtype) && valid_dtype(r_dtype) && valid_dtype(y_dtype), "lina_layernorm_fwd: bad dtype enum");
+    if (D > 256 * kLnMaxPieces) return fail(LINA_ERR_UNSUPPORTED, "lina_layernorm_fwd: D=%d exceeds %d", D, 256 * kLnMaxPieces);
+    const int np = (D + 255) / 256;
+    const int64_t wgs = (N + 3) / 4;
+    dim3 grid((unsigned)(wgs < 16384 ? wgs : 16384));
+#define LINA_LN_CALL(A, B, C) ln_fwd_launch<A, B, C>(np, grid, stream, x, r, gamma, beta, xsum, y, mean, rstd, N, D, eps)
+    LINA_LN_DISPATCH(LINA_LN_CALL);
+#undef LINA_LN_CALL
+}
+
+extern "C" int lina_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                  const void* dpass, void* dx, void* dr, float* dgamma_part, float* dbeta_part, int64_t N,
+                                  int D, int x_dtype, int r_dtype, int y_dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma_part && dbeta_part, "lina_layernorm_bwd: null pointer");
+    LINA_REQUIRE(N > 0 && D > 0 && D % 4 == 0, "lina_layernorm_bwd: N, D must be positive, D a multiple of 4");
+    LINA_REQUIRE(valid_dtype(x_dtype) && valid_dtype(r_dtype) && valid_dtype(y_dtype), "lina_layernorm_bwd: bad dtype enum");
+    if (D > 256 * kLnMaxPieces) return fail(LINA_ERR_UNSUPPORTED, "lina_layernorm_bwd: D=%d exceeds %d", D, 256 * kLnMaxPieces);
+    const int np = (D + 255) / 256;
+    dim3 grid((unsigned)lina_layernorm_bwd_partials(N));
+#define LINA_LN_CALL(A, B, C) ln_bwd_launch<A, B, C>(np, grid, stream, dy, x, mean, rstd, gamma, dpass, dx, dr, dgamma_part, dbeta_part, N, D)
+    LINA_LN_DISPATCH(LINA_LN_CALL);
+#undef LINA_LN_CALL
+}
+
+extern "C" int lina_swiglu_bwd(const void* ds, const void* u, void* du, int64_t rows, int Hd, int64_t ld_u, int64_t ld_ds,
+                               int64_t ld_du, int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(ds && u && du, "lina_swiglu_bwd: null pointer");
+    LINA_REQUIRE(rows > 0 && Hd > 0 && Hd % 4 == 0, "lina_swiglu_bwd: rows, Hd must be positive, Hd a multiple of 4");
+    LINA_REQUIRE(ld_u % 4 == 0 && ld_ds % 4 == 0 && ld_du % 4 == 0, "lina_swiglu_bwd: row strides must be multiples of 4");
+    LINA_REQUIRE(valid_dtype(dtype), "lina_swiglu_bwd: bad dtype %d", dtype);
+    const int64_t n4 = rows * (Hd / 4);
+    const int64_t wgs = (n4 + 255) / 256;
+    dim3 grid((unsigned)(wgs < 65536 ? wgs : 65536));
+    if (dtype == LINA_F32)
+        LINA_LAUNCH((swiglu_bwd_kernel<float>), grid, dim3(256), 0, stream, (const float*)ds, (const float*)u, (float*)du, rows,
+                    Hd, ld_u, ld_ds, ld_du);
+    else
+        LINA_LAUNCH((swiglu_bwd_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)ds, (const bf16_t*)u, (bf16_t*)du,
+                    rows, Hd, ld_u, ld_ds, ld_du);
+    return check_launch("lina_swiglu_bwd");
+}

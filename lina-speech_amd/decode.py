@@ -39,6 +39,12 @@ def _fold_layernorm(weight, ln, bias=None):
     return w_ln, c1, c2.contiguous()
 
 
+# hipGraph capture next to a live process group (bench.py --gpus N, DDP): RCCL's watchdog thread polls its events while
+# this thread captures -- legal only when the capture does not claim the whole process ("thread_local": other threads' runtime
+# calls neither join nor invalidate the capture).  Nothing the engine captures depends on another thread's work.
+_CAPTURE_MODE = "thread_local"
+
+
 class _BlockPack:
     """Decode-time weights of one MixingBlock(GatedLinearAttention, SwiGLU, LayerNorm)."""
 
@@ -385,7 +391,7 @@ class DecodeEngine:
                 self._core(y, lazy, self._loop_packed)
             torch.cuda.current_stream(self.dev).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
                 self._core(y, lazy, self._loop_packed)
                 self._t_idx.add_(1)                       # walks through the window positions
             for _ in range(16):
@@ -434,7 +440,7 @@ class DecodeEngine:
         torch.cuda.current_stream(self.dev).wait_stream(side)
         self._restore(snap)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
             self._core(self._y_in)
         self._graph = g
 
@@ -536,7 +542,7 @@ class DecodeEngine:
             self._tok_log.zero_()
             self._t_idx.zero_()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
                 self._greedy_att = body()
             self._greedy_graph = g
 
@@ -560,7 +566,7 @@ class DecodeEngine:
         if self._greedy_graph is not None and n >= N:
             if self._greedy_graph_n is None:                 # captured on first use (stream capture executes nothing)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
                     for _ in range(N):
                         self._greedy_body()
                 self._greedy_graph_n = g

@@ -32,7 +32,7 @@ def stale(lib: str = LIB) -> bool:
 
 
 def build(force: bool = False, defs=(), tag: str = "", only=None) -> str:
-    """``defs`` / ``tag``: an opt-in kernel variant (e.g. defs=("-DLINA_K2_TR=1",), tag="tr") built beside the default
+    """``defs`` / ``tag``: an opt-in kernel variant (e.g. defs=("-DSOME_EXPERIMENT=1",), tag="exp") built beside the default
     library as liblina_gla_emu_<tag>.so, so that variants the product does not ship yet are still parity-tested.
     ``only``: the source files the definitions affect -- the others are linked from the default build's objects."""
     lib = LIB if not tag else LIB[:-3] + f"_{tag}.so"

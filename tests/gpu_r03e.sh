@@ -20,3 +20,4 @@ for nw in 8 16; do
 import os, subprocess, sys
 PY
 done
+for nw in 8 16; do echo "== time stamps NW=$nw"; LINA_SKINNY_WAVES=$nw timeout 300 python tools/probe_skinny_prof.py 2>&1 | grep -v amdgpu.ids | head -16 | tee -a gpurun_out/r03e_skprof.log; done

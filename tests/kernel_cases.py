@@ -23,11 +23,20 @@ def tol_out(dtype, chunk=False):
     return 1e-4 if chunk else 1e-5
 
 
+PARITY_LOG = []          # (label, achieved max rel err, tolerance) of every assert_close / record_parity of this session;
+                         # tests/conftest.py tags the entries with the running test and writes them out after a GPU session
+
+
+def record_parity(what, achieved, tol=None, **extra):
+    PARITY_LOG.append({"what": what, "achieved": float(achieved), "tolerance": None if tol is None else float(tol), **extra})
+
+
 def assert_close(got, ref, rel, what):
     got, ref = got.detach().cpu().to(F64), ref.detach().cpu().to(F64)
     assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
     scale = ref.abs().max().clamp_min(1e-30)
     err = (got - ref).abs().max() / scale
+    record_parity(what, err, rel)
     assert torch.isfinite(got).all(), f"{what}: non-finite values"
     assert err <= rel, f"{what}: max rel err {err:.3e} > {rel:.1e}"
 
@@ -685,7 +694,7 @@ def check_linear_skinny_packed(dev, M, N, K, dtype, ln=False, bias=False, resid=
 def _skinny_waves(K, kq):
     """Split-K width the packed projection kernels pick for this K (mirrors linear_skinny_impl / inproj_impl)."""
     import os
-    nw = int(os.environ.get("LINA_SKINNY_WAVES", "4") or 4)
+    nw = int(os.environ.get("LINA_SKINNY_WAVES", "16") or 16)
     while nw > 4 and K // kq < 2 * nw:
         nw //= 2
     return nw if nw in (8, 16) else 4

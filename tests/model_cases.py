@@ -49,6 +49,8 @@ def close(got, ref, what, rel=REL):
     ref = torch.as_tensor(ref).float()
     assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
     err = (got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)
+    from kernel_cases import record_parity
+    record_parity(what, err, rel)
     assert err <= rel, f"{what}: rel err {err:.3e} > {rel:.1e}"
 
 

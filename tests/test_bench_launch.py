@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -34,3 +36,24 @@ def test_bench_under_the_drivers_launcher_sees_world_2():
 def test_bench_refuses_a_world_that_is_not_gpus():
     r = _run(["bench.py", "--gpus", "4", "--check-launch"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "--gpus 4" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_decode_bench_under_a_live_rccl_process_group_on_one_gpu():
+    """The multi-GPU launch path as far as ONE GPU can take it: bench.py under torch.distributed.run
+    with --nproc-per-node 1 and a FORCED process group (backend "nccl" = RCCL): RCCL initialises, the barrier / max-over-ranks
+    collectives of the timed region run, and the decode loop's hipGraph is captured and replayed next to the live
+    communicator.  The JSON line must carry the ranks block (per-rank times, RCCL's own log summary)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    r = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+              "--master-port", "29741", "bench.py", "--gpus", "1", "--steps", "24", "--warmup", "4", "--preheat-s", "0.2",
+              "--no-chunk", "--no-train", "--no-cpu-baseline"],
+             {"LINA_BENCH_FORCE_PG": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["steps"] == 24 and j["value"] > 0
+    rk = j["ranks"]
+    assert rk["backend"] == "nccl" and rk["world_size"] == 1 and len(rk["per_rank_ms"]["all"]) == 1
+    assert rk["rccl"] is not None and rk["rccl"]["library_version"], rk      # (one rank: RCCL may build no communicator -> no log)

@@ -2,6 +2,7 @@
 and the 166.7M model's greedy tokens against the CPU oracle."""
 import pytest
 import torch
+from kernel_cases import record_parity
 
 from model_cases import check_lina_golden, check_mixer_golden
 
@@ -48,6 +49,7 @@ def test_l169_greedy_tokens_match_cpu_oracle(hip):
             safe = margins[:, t] > 1e-3
             assert torch.equal(pick[safe], ref_toks[0, :, t][safe]), f"token mismatch at step {t}"
             y = m.rvq_embed.embed_sum(ref_toks[:, :, t:t + 1].cuda())
+        record_parity("L169 fp32 engine (generic step API), teacher-forced logits vs fp64-checked oracle", worst, 5e-4)
         assert worst < 5e-4, f"logits rel err {worst:.2e}"
         # free-running device-side loop on a fresh state
         eng2 = DecodeEngine(m, x_enc, batch_size=B)
@@ -72,6 +74,7 @@ def test_bf16_engine_runs_and_tracks_fp32(hip):
         mb = model.to(torch.bfloat16)
         lb, _ = DecodeEngine(mb, x_enc.bfloat16(), batch_size=8)(y.bfloat16(), 0)
     err = (lb.float() - l32).abs().max() / l32.abs().max()
+    record_parity("tiny model: bf16 engine logits vs fp32 engine logits", err, 5e-2)
     assert torch.isfinite(lb.float()).all() and err < 5e-2, f"bf16 vs fp32 logits rel err {err:.3e}"
 
 
@@ -128,6 +131,7 @@ def test_full_size_vocoder_matches_cpu_oracle(hip):
     audio = voc(codes.cuda(), bandwidth_id=bw.cuda())
     assert audio.shape == (2, 60 * 320)
     err = (audio.cpu().double() - ref).abs().max() / ref.abs().max()
+    record_parity("WavTokenizer decode: waveform vs fp64 oracle", err, 5e-4)
     assert err < 5e-4, float(err)
 
 
@@ -156,6 +160,7 @@ def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
     torch.manual_seed(0)
     model = l169().eval()
     B, n, REL = 64, 32, 2e-2
+    MASK_CAP = 0.45          # measured on MI355X: 33-36 % of the positions are near-ties at 2 x the logit error (random-init weights)
     x = torch.randint(3, 256, (B, 24), generator=torch.Generator().manual_seed(7))
     mb = model.to(torch.bfloat16)
     sd = {k: v.float() for k, v in mb.state_dict().items()}          # the oracle sees the SAME (bf16-rounded) weights
@@ -164,7 +169,17 @@ def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
         x_enc = m.txt_encoder(m.txt_embed(x.cuda()))
         eng = DecodeEngine(m, x_enc, batch_size=B)
         assert eng.window == 8 and eng.packs[0].lazy
-        toks = eng.run_greedy(n).cpu()                                                      # [1,B,n]
+        # the bench's own loop (K1w windowed state, packed projections, K6d epilogue inside the hipGraph), one replay per
+        # token; the head's output buffer is copied out after every step: these ARE the logits the loop picked from
+        eng.begin_greedy(n)
+        assert eng._loop_packed and eng._greedy_graph is not None
+        loop_logits = []
+        for _ in range(n):
+            eng.greedy_step()
+            loop_logits.append(eng._logits.view(B, 1, eng.Q, eng.L).float().cpu())
+        toks = eng.greedy_tokens().cpu()                                                    # [1,B,n]
+        eng.sync_state()
+        loop_logits = torch.cat(loop_logits, dim=1)                                         # [B,n,Q,L]
     orc = OracleLina(sd, n_layer=6, heads=4, txt_heads=4)
     n_thr = torch.get_num_threads()
     torch.set_num_threads(min(n_thr, 32))        # small-op decode on a 256-thread host: more threads only add sync cost
@@ -181,13 +196,22 @@ def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
             logits, _ = eng2(y, t)
             worst = max(worst, float((logits.float().cpu() - ref_logits[:, t:t + 1]).abs().max()))
             y = m.rvq_embed.embed_sum(toks[:, :, t:t + 1].cuda())
+    # the windowed device loop's OWN logits (free-running on its own tokens == the oracle's teacher-forced inputs)
+    worst_loop = float((loop_logits - ref_logits).abs().max())
+    per_step = (loop_logits - ref_logits).abs().amax(dim=(0, 2, 3))
+    worst = max(worst, worst_loop)
     safe = margins > 2.0 * worst
     n_masked, n_diff = int((~safe).sum()), int((toks[0] != ref_toks[0]).sum())
-    print(f"\nbf16 B=64 engine vs fp32 oracle over {n} free-running steps: max |logit error| = {worst:.4f} = "
-          f"{worst / scale:.2e} of max|logit|; {n_masked} of {B * n} positions have a top-2 margin <= {2 * worst:.4f} "
-          f"(not comparable); {n_diff} raw token differences, all of them at such positions")
-    assert worst < REL * scale, f"teacher-forced logits rel err {worst / scale:.3e}"
-    assert n_masked < 0.5 * B * n
+    print(f"\nbf16 B=64 engine vs fp32 oracle over {n} free-running steps: max |logit error| of the windowed loop = "
+          f"{worst_loop:.4f} = {worst_loop / scale:.2e} of max|logit| (generic step API {worst / scale:.2e}); {n_masked} of "
+          f"{B * n} positions have a top-2 margin <= {2 * worst:.4f} (not comparable); {n_diff} raw token differences, "
+          f"all of them at such positions")
+    record_parity("L169 bf16 B=64 windowed device loop: its own logits vs fp32 oracle (teacher-forced on the loop's tokens)",
+                  worst_loop / scale, REL, steps=n, first_step=float(per_step[0] / scale), last_step=float(per_step[-1] / scale))
+    record_parity("L169 bf16 B=64: positions with a top-2 margin <= 2 x max logit error (excluded from the token comparison)",
+                  n_masked / (B * n), MASK_CAP, n_masked=n_masked, positions=B * n, raw_token_differences=n_diff)
+    assert worst < REL * scale, f"logits rel err {worst / scale:.3e}"
+    assert n_masked < MASK_CAP * B * n
     assert torch.equal(toks[0][safe], ref_toks[0][safe]), "bf16 engine token != oracle arg-max at a clear margin"
 
 
@@ -233,6 +257,7 @@ def test_config3_decode_to_waveform_chain_vs_oracle(hip):
     ref_audio = ovoc.decode(feats, torch.zeros(1, dtype=torch.long))
     assert audio.shape == ref_audio.shape == (B, codes.shape[-1] * 320)
     err = (audio[clear].double() - ref_audio[clear]).abs().max() / ref_audio[clear].abs().max()
+    record_parity("config 3 chain: waveform of the clear-margin rows vs oracle chain", err, 5e-4, clear_rows=int(clear.sum()), rows=B)
     assert err < 5e-4, f"waveform rel err {err:.3e}"
 
 

@@ -3,7 +3,7 @@
 # with -DLINA_K2_PROF (clock64() reads around every barrier / step; each read also waits for the wave's LDS traffic, so the
 # build is ~5 % slower than the product).  Run on the GPU box:
 #   K2_PROF=1 LINA_GLA_LIB=tools/abl/liblina_k2prof.so python tools/perf_k2.py
-# Variants: K2_EXTRA="-DLINA_K2_TR=1 -DLINA_K2_W32=1" K2_TAG=_w32 tools/k2_prof.sh -> liblina_k2prof_w32.so
+# (K2_EXTRA / K2_TAG: extra -D flags and a library suffix for experiment builds)
 cd "$(dirname "$0")/.."
 mkdir -p tools/abl
 CS=lina-speech_amd/csrc

@@ -45,7 +45,7 @@ if os.environ.get("K2_PROF"):
     rc = lib.lina_k2_prof_read(buf.ctypes.data_as(ctypes.c_void_p))
     a = buf[:256].reshape(16, 16).astype(np.float64) / (T / 32)
     names = ["phaseA", "bar(2)", "flags/roll", "maskA(w<4)", "step1 qS", "step4 upd", "bar(1')+dma", "rawrd+step3", "wait_vmem",
-             "bar(3)", "o stores", "w32 step1"]   # o stores: of the previous chunk, at the end of phase A; w32 step1: LINA_K2_W32 builds
+             "bar(3)", "o stores", "(unused)"]   # o stores: of the previous chunk, at the end of phase A
     print("clk/chunk per phase (shader clock), waves 0, 3, 4, 15 and mean:  rc =", rc)
     for i, nm in enumerate(names):
         print(f"  {nm:12s} " + " ".join(f"{a[w, i]:8.0f}" for w in (0, 3, 4, 15)) + f"   mean {a[:, i].mean():8.0f}")
