@@ -250,6 +250,29 @@ int lina_gla_decode_prologue(const void* z, int64_t ldz, int off_q, int off_k, i
 int lina_swiglu(const void* u, void* y, int64_t rows, int Hd, int64_t ld_u, int64_t ld_y,
                 int dtype, lina_stream_t stream);
 
+/* K11b -- backward of the SwiGLU gate:  du[r, j] = ds[r, j] u[r, Hd + j] sig(a)(1 + a(1 - sig(a))),  a = u[r, j];
+ *   du[r, Hd + j] = ds[r, j] silu(a).   ds: [rows, Hd], u / du: [rows, 2 Hd] (row strides in elements, multiples of 4).
+ * Replaces autograd through `F.silu(a) * b` (reference model/base_blocks.py:48-50) in the training step. */
+int lina_swiglu_bwd(const void* ds, const void* u, void* du, int64_t rows, int Hd, int64_t ld_u, int64_t ld_ds,
+                    int64_t ld_du, int dtype, lina_stream_t stream);
+
+/* K10 -- LayerNorm over the last dimension with the residual add that precedes it in a pre-norm block
+ * (reference model/base_blocks.py:65-69: `x = tmix(norm1(x)) + x; x = cmix(norm2(x)) + x`), for the TRAINING step:
+ *   forward:  x' = x + r (r optional; x' written to xsum when given);  y = (x' - mean) rstd gamma + beta;  mean / rstd
+ *             (fp32 [N]) are kept for the backward.   x, xsum, dx, dpass: x_dtype;  r, dr: r_dtype;  y, dy: y_dtype.
+ *   backward: dx = dpass + rstd (g - mean(g) - xhat mean(g xhat)),  g = dy gamma  (dpass optional: the gradient reaching x'
+ *             through the residual path);  dr (optional) = dx in r_dtype;  dgamma_part / dbeta_part: fp32
+ *             [lina_layernorm_bwd_partials(N)][D] per-workgroup sums, added up by the caller (deterministic, no atomics).
+ * [N, D] contiguous, D % 4 == 0, D <= 2048.  Built dtype triples (x, r, y): (f32,f32,f32), (f32,bf16,bf16), (f32,f32,bf16),
+ * (bf16,bf16,bf16).  Replaces nn.LayerNorm + the elementwise add / cast passes around it under bf16 autocast. */
+int lina_layernorm_fwd(const void* x, const void* r, const float* gamma, const float* beta, void* xsum, void* y,
+                       float* mean, float* rstd, int64_t N, int D, float eps, int x_dtype, int r_dtype, int y_dtype,
+                       lina_stream_t stream);
+int lina_layernorm_bwd_partials(int64_t rows);
+int lina_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                       const void* dpass, void* dx, void* dr, float* dgamma_part, float* dbeta_part, int64_t N, int D,
+                       int x_dtype, int r_dtype, int y_dtype, lina_stream_t stream);
+
 /* K1d -- decode-step (T = 1) state update, row-split: same arithmetic as K1, but each workgroup
  * streams a contiguous 64-row block of the fp32 state (in place) and the q.S products of the Dk/64
  * row blocks are returned as fp32 PARTIALS  o_part[Dk/64][B*H][Dv]  for K5 to add (n_partial).
@@ -380,6 +403,12 @@ int lina_cross_att_step2(const void* xp, const void* pe, const void* vv, void* a
  *   lina_softmax_rows     : att[b, 0:Tn] = softmax(x[b, 0:Tn] * scale)  -> strided `att` rows AND a contiguous
  *                           zero-padded copy attc [B, Tp] (Tp >= Tn) that feeds the next projection
  *   lina_weighted_rows_add: x[b,:] += sum_t attc[b,t] * vv[b,t,:]                                              */
+/* Blind cross-attention step, first half after the scores (reference model/crossatt.py:117-127) in one launch:
+ *   att[b,:Tn] = softmax(scores[b,:Tn])  (scores fp32, already scaled: lina_cross_scores);  xp[b,:] = att[b,:] . pe[:Tn,:]
+ *   (pe [Tn,d] shared by all rows) -> xp [B,d] row-major and, when xp_packed is given, its fragment-major copy. */
+int lina_softmax_pe_rows(const float* scores, int64_t scores_sb, void* att, int64_t att_sb, const void* pe, void* xp,
+                         void* xp_packed, int B, int Tn, int d, int dtype, lina_stream_t stream);
+
 /* Round-2 fusions of the same step (fewer launches on the serial chain):
  *   lina_cross_scores_softmax      = lina_cross_scores + lina_softmax_rows(scale 1) in one launch (one 1024-thread
  *                                    workgroup per utterance row): att rows (strided) + zero-padded attc [B,Tp];

@@ -55,6 +55,10 @@ PROTOTYPES = {
     "lina_gla_decode_prologue": (C.c_int, [_p, _i64, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                            _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "lina_swiglu": (C.c_int, [_p, _p, _i64, _i, _i64, _i64, _i, _p]),
+    "lina_swiglu_bwd": (C.c_int, [_p, _p, _p, _i64, _i, _i64, _i64, _i64, _i, _p]),
+    "lina_layernorm_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _i, _i, _i, _p]),
+    "lina_layernorm_bwd_partials": (C.c_int, [_i64]),
+    "lina_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p]),
     "lina_gla_decode_update": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64,
                                          _i64, _i64, _i, _i, _f, _p]),
     "lina_gla_decode_update_norm": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i,
@@ -70,6 +74,7 @@ PROTOTYPES = {
     "lina_cross_att_step2": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i, _i, _i, _f, _i, _p]),
     "lina_cross_scores_softmax": (C.c_int, [_p, _p, _p, _f, _p, _p, _i64, _p, _i, _i, _i, _i, _f, _i, _p]),
     "lina_softmax_weighted_rows_add": (C.c_int, [_p, _i64, _f, _p, _i64, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "lina_softmax_pe_rows": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _i, _p]),
     "lina_cross_scores": (C.c_int, [_p, _p, _p, _f, _p, _p, _i, _i, _i, _f, _i, _p]),
     "lina_softmax_rows": (C.c_int, [_p, _i64, _i, _f, _p, _i64, _p, _i, _i, _i, _i, _p]),
     "lina_weighted_rows_add": (C.c_int, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),

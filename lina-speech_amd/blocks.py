@@ -22,8 +22,8 @@ class SwiGLU(nn.Module):
         self.p_out = nn.Linear(self.hidden, d_model)
 
     def forward(self, x):
-        a, b = self.p_in(x).chunk(2, dim=-1)
-        return self.p_out(F.silu(a) * b)
+        from . import ops
+        return self.p_out(ops.swiglu_gate(self.p_in(x)))       # K11 / K11b: one pass each way (torch fallback off-device)
 
 
 class MixingBlock(nn.Module):
@@ -36,9 +36,20 @@ class MixingBlock(nn.Module):
         self.drop = nn.Dropout(dropout)
 
     def forward(self, x, **kwargs):
-        y = self.tmix(self.norm1(x), **kwargs)
-        x = (y[0] if type(y) is tuple else y) + x
-        x = self.cmix(self.norm2(x)) + x
+        from . import ops
+        ln = isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm) and ops.fused_ops_available(x)
+        if not ln:
+            y = self.tmix(self.norm1(x), **kwargs)
+            x = (y[0] if type(y) is tuple else y) + x
+            x = self.cmix(self.norm2(x)) + x
+            return self.drop(x)
+        # K10: the norms run on the HIP kernel (fp32 stream in, GEMM-dtype operand out) and the residual add that
+        # precedes norm2 rides in its pass -- same arithmetic as the lines above (reference base_blocks.py:65-69)
+        n1, n2 = self.norm1, self.norm2
+        y = self.tmix(ops.layer_norm(x, n1.weight, n1.bias, n1.eps), **kwargs)
+        y = y[0] if type(y) is tuple else y
+        h, x = ops.layer_norm(x, n2.weight, n2.bias, n2.eps, residual=y)
+        x = self.cmix(h) + x
         return self.drop(x)
 
 

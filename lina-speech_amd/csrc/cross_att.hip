@@ -61,6 +61,16 @@ __device__ __forceinline__ void scores_softmax(const float* s_vec, const T* __re
 // ---- spread versions (one workgroup per utterance row pulls 256 KiB through a single CU: 30-40 us; these
 // ---- put >= 256 workgroups on the text-side tensors) ----------------------------------------------------------
 
+#ifdef LINA_SKINNY_PROF
+// tools-only build (tools/skinny_prof.sh): time stamps of thread 0 of every cross_scores workgroup, [workgroup][slot]:
+// 0 wall clock at entry, 1 shader clock at entry, 2 query + parameters arrived, 3 LayerNorm done (barrier), 4 dots done, 5 end,
+// 6 wall clock at the end.  NOT part of the product library.
+__device__ unsigned long long lina_cross_prof[1024 * 8];
+#define CS_PROF(i, expr) do { if (threadIdx.x == 0) pr_[i] = (expr); } while (0)
+#else
+#define CS_PROF(i, expr) do { } while (0)
+#endif
+
 // scores[b,t] = scale * <LN(q_lin[b]), kk[b,t,:]>   grid (ceil(Tn/16), B): 4 waves x 4 text rows each
 template <typename T>
 __global__ __launch_bounds__(256) void cross_scores_kernel(
@@ -70,10 +80,30 @@ __global__ __launch_bounds__(256) void cross_scores_kernel(
     float* s_q = reinterpret_cast<float*>(smem);            // [d]
     __shared__ float s_red[4];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#ifdef LINA_SKINNY_PROF
+    unsigned long long pr_[8] = {};
+    CS_PROF(0, wall_clock64());
+    CS_PROF(1, clock64());
+#endif
     // the text rows of this wave are requested FIRST (d <= 1024: 4 rows x 4 pieces of 4 elements per lane), so their
     // HBM latency runs under the LayerNorm of the query below
     constexpr int kIt = 4;
     const bool pre = d <= 256 * kIt;
+    // A wave's loads RETURN IN ORDER: the query and the LayerNorm parameters are requested BEFORE the (HBM-cold) text rows, so
+    // the LayerNorm runs while the rows stream in.  Requested behind them (as this kernel did until round 3) they arrived
+    // only after the whole 32 KiB burst, and the LayerNorm chain -- two workgroup reductions and the parameter loads -- ran
+    // exposed after it: 11.7 us per launch against 4.7 us for the weighted-row kernel that moves the same bytes.
+    float qv[kIt], gw[kIt], gb[kIt];
+#pragma unroll
+    for (int i = 0; i < kIt; ++i) {
+        const int e = tid + 256 * i;
+        const bool ok = pre && e < d;
+        const int ec = e < d ? e : d - 1;                    // unconditional loads on clamped indices (a predicated load
+        const float a0 = ld(qlin + (int64_t)b * d + ec), a1 = ld(ln_w + ec), a2 = ld(ln_b + ec);   // is waited for at once)
+        qv[i] = ok ? a0 : 0.0f;
+        gw[i] = ok ? a1 : 0.0f;
+        gb[i] = ok ? a2 : 0.0f;
+    }
     float4 m[4][kIt];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -82,21 +112,49 @@ __global__ __launch_bounds__(256) void cross_scores_kernel(
 #pragma unroll
         for (int it = 0; it < kIt; ++it) {
             const int e = lane * 4 + 256 * it;
-            m[i][it] = (pre && e < d) ? ld4(row + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v4 = ld4(row + (e < d ? e : d - 4));
+            m[i][it] = (pre && e < d) ? v4 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     float s = 0.0f;
-    for (int e = tid; e < d; e += 256) { const float x = ld(qlin + (int64_t)b * d + e); s_q[e] = x; s += x; }
+    if (pre) {
+#pragma unroll
+        for (int i = 0; i < kIt; ++i) s += qv[i];
+#ifdef LINA_SKINNY_PROF
+        if (s == 1.2345e30f) s_q[0] = s;                     // (consume the loads before the stamp)
+        CS_PROF(2, clock64());
+#endif
+    } else {
+        for (int e = tid; e < d; e += 256) { const float x = ld(qlin + (int64_t)b * d + e); s_q[e] = x; s += x; }
+    }
     const float mu = block_sum(s, s_red) / (float)d;
     float vs = 0.0f;
-    for (int e = tid; e < d; e += 256) { const float c = s_q[e] - mu; vs += c * c; }
+    if (pre) {
+#pragma unroll
+        for (int i = 0; i < kIt; ++i) { const float c = qv[i] - mu; vs += (tid + 256 * i < d) ? c * c : 0.0f; }
+    } else {
+        for (int e = tid; e < d; e += 256) { const float c = s_q[e] - mu; vs += c * c; }
+    }
     const float rstd = rsqrtf(block_sum(vs, s_red) / (float)d + ln_eps);
-    for (int e = tid; e < d; e += 256) {
-        T tmp;                                               // the reference rounds the LN output to the model dtype
-        st(&tmp, (s_q[e] - mu) * rstd * ld(ln_w + e) + ld(ln_b + e));
-        s_q[e] = ld(&tmp);
+    if (pre) {
+#pragma unroll
+        for (int i = 0; i < kIt; ++i) {
+            const int e = tid + 256 * i;
+            if (e < d) {
+                T tmp;                                       // the reference rounds the LN output to the model dtype
+                st(&tmp, (qv[i] - mu) * rstd * gw[i] + gb[i]);
+                s_q[e] = ld(&tmp);
+            }
+        }
+    } else {
+        for (int e = tid; e < d; e += 256) {
+            T tmp;
+            st(&tmp, (s_q[e] - mu) * rstd * ld(ln_w + e) + ld(ln_b + e));
+            s_q[e] = ld(&tmp);
+        }
     }
     __syncthreads();
+    CS_PROF(3, clock64());
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int t = blockIdx.x * 16 + 4 * w + i;           // wave-uniform
@@ -122,6 +180,16 @@ __global__ __launch_bounds__(256) void cross_scores_kernel(
         acc += shfl_xor(acc, 8); acc += shfl_xor(acc, 16); acc += shfl_xor(acc, 32);
         if (lane == 0) scores[(int64_t)b * Tn + t] = acc * scale;
     }
+#ifdef LINA_SKINNY_PROF
+    CS_PROF(4, clock64());
+    CS_PROF(5, clock64());
+    CS_PROF(6, wall_clock64());
+    if (threadIdx.x == 0) {
+        const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+        if (wg < 1024)
+            for (int i = 0; i < 8; ++i) lina_cross_prof[wg * 8 + i] = pr_[i];
+    }
+#endif
 }
 
 // row softmax of x[b, 0:Tn] * scale; written (model dtype) to the strided attention buffer AND to a contiguous
@@ -230,7 +298,8 @@ __global__ __launch_bounds__(1024) void cross_scores_softmax_kernel(
 #pragma unroll
         for (int it = 0; it < kIt; ++it) {
             const int e = lane * 4 + 256 * it;
-            m[r][it] = (pre && e < d) ? ld4(row + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v4 = ld4(row + (e < d ? e : d - 4));        // unconditional, clamped (see cross_scores_kernel)
+            m[r][it] = (pre && e < d) ? v4 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     float s = 0.0f;
@@ -345,6 +414,71 @@ __global__ __launch_bounds__(256) void softmax_weighted_rows_kernel(const T* __r
     T* const xa = xpk ? xpk + packed_off<T>(b, e, d) : x + (int64_t)b * d + e;
     const float4 o = ld4(tmp4), r = ld4(xa);
     st4(xa, make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w));
+}
+
+// softmax + att . pe in ONE launch (the first half of the blind cross-attention, reference model/crossatt.py:117-127):
+//   att[b, :Tn] = softmax(scores[b, :Tn])  (scores: fp32, already scaled -- lina_cross_scores' output);
+//   xp[b, :]    = att[b, :] . pe[:Tn, :]    (pe shared by all rows; att rounded to the model dtype first, as the reference's
+//                                            bmm sees it)  -> row-major xp and, optionally, its fragment-major copy.
+// grid (ceil(d / 256), B) like softmax_weighted_rows_kernel: with lina_cross_scores in front (256 workgroups on the text
+// keys) this replaces {scores + softmax in ONE 1024-thread workgroup per row, then a K = T_txt skinny GEMM}: the row-wide
+// workgroups of that form put 64 CUs on 8.4 MB of HBM-cold keys (11.5 us per launch in the step's timeline).
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_pe_rows_kernel(const float* __restrict__ scores, int64_t sc_sb,
+                                                              T* __restrict__ att, int64_t att_sb, const T* __restrict__ pe,
+                                                              T* __restrict__ xp, T* __restrict__ xpk, int Tn, int d) {
+    __shared__ float s_a[kCaMaxT];
+    __shared__ float s_red[4];
+    __shared__ __attribute__((aligned(16))) float s_p[3][64][4];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int e = blockIdx.x * 256 + lane * 4;
+    const bool live = e < d;
+    // the scores first (a wave's loads return in order), then the first pe rows of this wave: they do not depend on the softmax
+    const T* base = pe + (live ? e : 0);
+    const float sc0 = tid < Tn ? scores[b * sc_sb + tid] : -INFINITY;
+    float4 p0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p0[u] = ld4(base + (int64_t)min(w + 4 * u, Tn - 1) * d);
+    float mx = -INFINITY;
+    for (int t = tid; t < Tn; t += 256) { const float v = t == tid ? sc0 : scores[b * sc_sb + t]; s_a[t] = v; mx = fmaxf(mx, v); }
+    mx = block_max(mx, s_red);
+    float sum = 0.0f;
+    for (int t = tid; t < Tn; t += 256) sum += expf(s_a[t] - mx);
+    sum = block_sum(sum, s_red);
+    const float inv = 1.0f / sum;
+    for (int t = tid; t < Tn; t += 256) {
+        T tmp;                                               // the weights in the model dtype, as softmax_rows stores them
+        st(&tmp, expf(s_a[t] - mx) * inv);
+        s_a[t] = ld(&tmp);
+        if (blockIdx.x == 0) att[b * att_sb + t] = tmp;
+    }
+    __syncthreads();
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t0 = w; t0 < Tn; t0 += 32) {
+        float4 p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = t0 == w ? p0[u] : ld4(base + (int64_t)min(t0 + 4 * u, Tn - 1) * d);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float a = (t0 + 4 * u < Tn) ? s_a[min(t0 + 4 * u, Tn - 1)] : 0.0f;
+            acc.x = fmaf(a, p[u].x, acc.x); acc.y = fmaf(a, p[u].y, acc.y);
+            acc.z = fmaf(a, p[u].z, acc.z); acc.w = fmaf(a, p[u].w, acc.w);
+        }
+    }
+    if (w > 0) *reinterpret_cast<float4*>(&s_p[w - 1][lane][0]) = acc;
+    __syncthreads();
+    if (w > 0 || !live) return;
+#pragma unroll
+    for (int ww = 0; ww < 3; ++ww) {
+        const float4 o = *reinterpret_cast<const float4*>(&s_p[ww][lane][0]);
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    st4(xp + (int64_t)b * d + e, acc);
+    if (xpk) {                                               // fragment-major copy (the model-dtype values just stored)
+        T tmp4[4];
+        st4(tmp4, acc);
+        st4(xpk + packed_off<T>(b, e, d), ld4(tmp4));
+    }
 }
 
 template <typename T>
@@ -548,6 +682,24 @@ extern "C" int lina_cross_scores_softmax(const void* q_lin, const void* ln_w, co
     return check_launch("lina_cross_scores_softmax");
 }
 
+extern "C" int lina_softmax_pe_rows(const float* scores, int64_t scores_sb, void* att, int64_t att_sb, const void* pe, void* xp,
+                                   void* xp_packed, int B, int Tn, int d, int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(scores && att && pe && xp, "lina_softmax_pe_rows: null pointer");
+    LINA_REQUIRE(B > 0 && Tn > 0 && Tn <= kCaMaxT, "lina_softmax_pe_rows: 0 < T_txt <= %d", kCaMaxT);
+    LINA_REQUIRE(d > 0 && d % 4 == 0, "lina_softmax_pe_rows: d must be a multiple of 4");
+    LINA_REQUIRE(valid_dtype(dtype), "lina_softmax_pe_rows: bad dtype %d", dtype);
+    LINA_REQUIRE(!xp_packed || d % (dtype == LINA_BF16 ? 32 : 16) == 0, "lina_softmax_pe_rows: packed copy needs whole k-steps");
+    dim3 grid((unsigned)((d + 255) / 256), (unsigned)B);
+    if (dtype == LINA_F32)
+        LINA_LAUNCH((softmax_pe_rows_kernel<float>), grid, dim3(256), 0, stream, scores, scores_sb, (float*)att, att_sb,
+                    (const float*)pe, (float*)xp, (float*)xp_packed, Tn, d);
+    else
+        LINA_LAUNCH((softmax_pe_rows_kernel<bf16_t>), grid, dim3(256), 0, stream, scores, scores_sb, (bf16_t*)att, att_sb,
+                    (const bf16_t*)pe, (bf16_t*)xp, (bf16_t*)xp_packed, Tn, d);
+    return check_launch("lina_softmax_pe_rows");
+}
+
 extern "C" int lina_softmax_weighted_rows_add(const void* scores, int64_t scores_sb, float scale, void* att, int64_t att_sb,
                                               const void* vv, void* x, void* x_packed, int B, int Tn, int d, int dtype,
                                               lina_stream_t stream) {
@@ -566,3 +718,9 @@ extern "C" int lina_softmax_weighted_rows_add(const void* scores, int64_t scores
                     scale, (bf16_t*)att, att_sb, (const bf16_t*)vv, (bf16_t*)x, Tn, d, (bf16_t*)x_packed);
     return check_launch("lina_softmax_weighted_rows_add");
 }
+
+#ifdef LINA_SKINNY_PROF
+extern "C" int lina_cross_prof_read(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lina::lina_cross_prof), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif

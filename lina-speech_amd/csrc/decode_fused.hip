@@ -55,19 +55,20 @@ __global__ __launch_bounds__(256) void decode_prologue_kernel(
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ u, T* __restrict__ y, int Hd, int64_t ld_u,
-                                                     int64_t ld_y) {
-    const int64_t r = blockIdx.y;
+__global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ u, T* __restrict__ y, int64_t rows, int Hd,
+                                                     int64_t ld_u, int64_t ld_y) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= ld_y) return;
-    float out;
-    if (j < Hd) {
-        const float gate = ld(u + r * ld_u + j), val = ld(u + r * ld_u + Hd + j);
-        out = silu(gate) * val;
-    } else {
-        out = (j == Hd) ? 1.0f : 0.0f;
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {        // (grid.y is capped: training calls have > 65535 rows)
+        float out;
+        if (j < Hd) {
+            const float gate = ld(u + r * ld_u + j), val = ld(u + r * ld_u + Hd + j);
+            out = silu(gate) * val;
+        } else {
+            out = (j == Hd) ? 1.0f : 0.0f;
+        }
+        st(y + r * ld_y + j, out);
     }
-    st(y + r * ld_y + j, out);
 }
 
 }  // namespace lina
@@ -105,10 +106,10 @@ extern "C" int lina_swiglu(const void* u, void* y, int64_t rows, int Hd, int64_t
     LINA_REQUIRE(u && y, "lina_swiglu: null pointer");
     LINA_REQUIRE(rows > 0 && Hd > 0 && ld_u >= 2 * (int64_t)Hd && ld_y >= Hd, "lina_swiglu: bad shape");
     LINA_REQUIRE(valid_dtype(dtype), "lina_swiglu: bad dtype %d", dtype);
-    dim3 grid((unsigned)((ld_y + 255) / 256), (unsigned)rows);
+    dim3 grid((unsigned)((ld_y + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
     if (dtype == LINA_F32)
-        LINA_LAUNCH((swiglu_kernel<float>), grid, dim3(256), 0, stream, (const float*)u, (float*)y, Hd, ld_u, ld_y);
+        LINA_LAUNCH((swiglu_kernel<float>), grid, dim3(256), 0, stream, (const float*)u, (float*)y, rows, Hd, ld_u, ld_y);
     else
-        LINA_LAUNCH((swiglu_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)u, (bf16_t*)y, Hd, ld_u, ld_y);
+        LINA_LAUNCH((swiglu_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)u, (bf16_t*)y, rows, Hd, ld_u, ld_y);
     return check_launch("lina_swiglu");
 }

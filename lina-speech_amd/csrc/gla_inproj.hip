@@ -44,6 +44,7 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
     constexpr int U = NW > 8 ? 2 : (NW > 4 || (NT + MT) * 8 > 48) ? 4 : 8;   // NW: split-K width, see linear_skinny.hip
     __shared__ __attribute__((aligned(16))) float s_acc[NW][NT * MT][64][4];
     __shared__ float s_st[NW][64][2];
+    __shared__ float s_fin[NW > 4 ? 64 : 1][2];           // NW > 4: the rows' LayerNorm sums, added up once (linear_skinny.hip)
     __shared__ float s_lr[64][R + 1];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -88,39 +89,50 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
     // Epilogue operands that do not depend on the GEMM -- the rolled conv caches of this wave's 4 rows (wave w
     // finalises m-tile w), the conv taps and the LayerNorm-fold constants -- are requested NOW, so their
     // (HBM-cold) latency is hidden under the main loop instead of sitting exposed after the reduction.
-    float4 pre_old[NT][4], pre_wj[NT];
+    typedef typename raw4<T>::type raw_t;   // RAW bits of the epilogue operands, converted where they are used (lina_common.h)
+    raw_t pre_old[NT][4], pre_wj[NT];
+    T pre_b2[NT];
     float pre_c1[NT], pre_c2[NT];
+    // Which tensor a TILE needs is decided per tile (Kd, Vd are multiples of 16: a 16-column tile never straddles q|k|v|g):
+    // scalar branches, and inside them every load is unconditional on a clamped address -- a per-lane `ok ? ld(p) : 0`
+    // compiles to one EXEC-masked region + `s_waitcnt vmcnt(0)` per load, i.e. one memory round trip after the other.
+    // Requested BEHIND the first round of fragment loads (loads return in order; the fragments are needed first).
+    auto preload = [&]() {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = gate_wg ? n_direct + li : tile0 + 16 * j + li;
-        pre_c1[j] = c1[n];
-        pre_c2[j] = c2[n];
-        pre_wj[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < NT; ++j) {
+            const int n = gate_wg ? n_direct + li : tile0 + 16 * j + li;
+            pre_c1[j] = c1[n];
+            pre_c2[j] = c2[n];
+            pre_wj[j] = raw_t();
+            pre_b2[j] = T();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pre_old[j][r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (w >= MT) continue;                              // waves beyond the first four only feed the split-K sum
-        if (gate_wg) {
-            // gate tiles: the rank-16 up-projection row of this lane's channel (16 contiguous elements) and its bias are
-            // epilogue operands too -- they travel in the registers the q/k/v tiles use for the conv cache
-            const int c = (tile0 - n_direct) + 16 * j + li;
-            if (c < Kd) {
+            for (int r = 0; r < 4; ++r) pre_old[j][r] = raw_t();
+            if (w >= MT) continue;                              // waves beyond the first four only feed the split-K sum
+            const int tn0 = tile0 + 16 * j;                     // first column of this tile: workgroup-uniform
+            if (gate_wg) {
+                // gate tiles: the rank-16 up-projection row of this lane's channel (16 contiguous elements) and its bias are
+                // epilogue operands too -- they travel in the registers the q/k/v tiles use for the conv cache
+                if (tn0 - n_direct < Kd) {                      // (Kd % 16 == 0: the whole tile is inside)
+                    const int c = (tn0 - n_direct) + li;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pre_old[j][r] = ld4(w2 + (int64_t)c * R + 4 * r);
-                pre_wj[j].x = ld(b2 + c);
-            }
-        } else if (n < 2 * Kd + Vd) {
-            const T* wsel; const T* csel; int c, D;
-            if (n < Kd) { c = n; D = Kd; wsel = wq; csel = cq; }
-            else if (n < 2 * Kd) { c = n - Kd; D = Kd; wsel = wk; csel = ck; }
-            else { c = n - 2 * Kd; D = Vd; wsel = wv; csel = cv; }
-            pre_wj[j] = ld4(wsel + (int64_t)c * 4);
+                    for (int r = 0; r < 4; ++r) pre_old[j][r] = ld4_raw(w2 + (int64_t)c * R + 4 * r);
+                    pre_b2[j] = ld_raw(b2 + c);
+                }
+            } else if (tn0 < 2 * Kd + Vd) {
+                const T* wsel; const T* csel; int c, D;
+                if (tn0 < Kd) { c = tn0 + li; D = Kd; wsel = wq; csel = cq; }
+                else if (tn0 < 2 * Kd) { c = tn0 - Kd + li; D = Kd; wsel = wk; csel = ck; }
+                else { c = tn0 - 2 * Kd + li; D = Vd; wsel = wv; csel = cv; }
+                pre_wj[j] = ld4_raw(wsel + (int64_t)c * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 16 * w + 4 * lg + r;
-                pre_old[j][r] = ld4(csel + ((int64_t)(m < M ? m : 0) * D + c) * 4);
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + 16 * w + 4 * lg + r;
+                    pre_old[j][r] = ld4_raw(csel + ((int64_t)(m < M ? m : 0) * D + c) * 4);
+                }
             }
         }
-    }
+    };
+    bool pre_done = false;
 
     const int nsteps = K / F::KSTEP;
     // wave w takes k-steps {2w, 2w+1} + 8j: its two consecutive 64-byte (bf16) loads of a row are the two halves
@@ -136,6 +148,7 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[u][mt].load(ap[mt] + k0); else fa[u][mt].zero(); }
         }
+        if (ks == 0) { sched_fence(); preload(); sched_fence(); pre_done = true; }   // behind the first round's fragments
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -150,6 +163,7 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
 #endif
     }
     IP_PROF(3, clock64());
+    if (!pre_done) preload();                                   // (a K shorter than one round)
     for (; kstep_of<NW>(w, ks) < nsteps; ++ks) {
         const int64_t k0 = kstep_of<NW>(w, ks) * kstr;
         F fb[NT], fa[MT];
@@ -174,6 +188,17 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
         for (int r = 0; r < 4; ++r)
             if (li == 4 * lg + r) { s_st[w][16 * mt + li][0] = st1[mt][r]; s_st[w][16 * mt + li][1] = st2[mt][r]; }
     __syncthreads();
+    if (NW > 4) {
+        if (tid < 128) {
+            const int row = tid >> 1, c = tid & 1;
+            float a = (s_st[0][row][c] + s_st[1][row][c]) + (s_st[2][row][c] + s_st[3][row][c]);
+#pragma unroll
+            for (int ww = 4; ww < NW; ww += 4)
+                a += (s_st[ww][row][c] + s_st[ww + 1][row][c]) + (s_st[ww + 2][row][c] + s_st[ww + 3][row][c]);
+            s_fin[row][c] = a;
+        }
+        __syncthreads();
+    }
     IP_PROF(4, clock64());
     if (w >= MT) {                                          // NW > 4: the extra waves have delivered their partial sums
         if (gate_wg) __syncthreads();                       // (the gate tiles' low-rank exchange below has one more barrier)
@@ -195,12 +220,11 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 16 * w + 4 * lg + r;
-        float a = (s_st[0][row][0] + s_st[1][row][0]) + (s_st[2][row][0] + s_st[3][row][0]);
-        float b = (s_st[0][row][1] + s_st[1][row][1]) + (s_st[2][row][1] + s_st[3][row][1]);
-#pragma unroll
-        for (int ww = 4; ww < NW; ww += 4) {
-            a += (s_st[ww][row][0] + s_st[ww + 1][row][0]) + (s_st[ww + 2][row][0] + s_st[ww + 3][row][0]);
-            b += (s_st[ww][row][1] + s_st[ww + 1][row][1]) + (s_st[ww + 2][row][1] + s_st[ww + 3][row][1]);
+        float a, b;
+        if (NW > 4) { a = s_fin[row][0]; b = s_fin[row][1]; }
+        else {
+            a = (s_st[0][row][0] + s_st[1][row][0]) + (s_st[2][row][0] + s_st[3][row][0]);
+            b = (s_st[0][row][1] + s_st[1][row][1]) + (s_st[2][row][1] + s_st[3][row][1]);
         }
         const float inv_k = fast_rcp((float)K);
         mu[r] = a * inv_k;
@@ -216,11 +240,9 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
         for (int j = 0; j < NT; ++j) {
             const int c = (tile0 - n_direct) + 16 * j + li;          // gate channel
             if (c >= Kd) continue;
-            const float w2r[R] = {pre_old[j][0].x, pre_old[j][0].y, pre_old[j][0].z, pre_old[j][0].w,
-                                  pre_old[j][1].x, pre_old[j][1].y, pre_old[j][1].z, pre_old[j][1].w,
-                                  pre_old[j][2].x, pre_old[j][2].y, pre_old[j][2].z, pre_old[j][2].w,
-                                  pre_old[j][3].x, pre_old[j][3].y, pre_old[j][3].z, pre_old[j][3].w};
-            const float bias = pre_wj[j].x;
+            const float4 q0 = cvt4(pre_old[j][0]), q1 = cvt4(pre_old[j][1]), q2 = cvt4(pre_old[j][2]), q3 = cvt4(pre_old[j][3]);
+            const float w2r[R] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            const float bias = cvt1(pre_b2[j]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * w + 4 * lg + r, m = m0 + row;
@@ -256,13 +278,13 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
         if (n < Kd) { c = n; D = Kd; csel = cq; }
         else if (n < 2 * Kd) { c = n - Kd; D = Kd; csel = ck; }
         else { c = n - 2 * Kd; D = Vd; csel = cv; }
-        const float4 wj = pre_wj[j];
+        const float4 wj = cvt4(pre_wj[j]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + 16 * w + 4 * lg + r;
             if (m < M) {
                 T* cb = csel + ((int64_t)m * D + c) * 4;
-                const float4 old = pre_old[j][r];
+                const float4 old = cvt4(pre_old[j][r]);
                 T tmp;                                       // the conv sees the projection in the model dtype
                 st(&tmp, z[r]);
                 const float xn = ld(&tmp);

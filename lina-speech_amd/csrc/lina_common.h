@@ -53,6 +53,24 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     *reinterpret_cast<uint2*>(p) = u;
 }
 
+// RAW forms of the 4-element load: a load whose value is only needed much later must not be converted where it is issued --
+// the bf16 -> fp32 conversion is a USE of the loaded register, i.e. an `s_waitcnt` for this load and for every load issued
+// before it.  Keep the raw bits, convert at the point of use.
+template <typename T> struct raw4;
+template <> struct raw4<float> { typedef float4 type; };
+template <> struct raw4<bf16_t> { typedef uint2 type; };
+__device__ __forceinline__ float4 ld4_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ uint2 ld4_raw(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ float4 cvt4(float4 v) { return v; }
+__device__ __forceinline__ float4 cvt4(uint2 u) {
+    return make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)),
+                       bf2f((bf16_t)(u.y >> 16)));
+}
+__device__ __forceinline__ float ld_raw(const float* p) { return *p; }
+__device__ __forceinline__ bf16_t ld_raw(const bf16_t* p) { return *p; }
+__device__ __forceinline__ float cvt1(float v) { return v; }
+__device__ __forceinline__ float cvt1(bf16_t v) { return bf2f(v); }
+
 // sigmoid via v_exp_f32 + v_rcp_f32 (1 ulp): a `/` here expands to the ~10-instruction IEEE division sequence, which
 // made the per-element epilogues (short conv, norm-gate, SwiGLU) VALU-bound
 __device__ __forceinline__ float sigmoidf(float x) { return fast_rcp(1.0f + __expf(-x)); }

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
     constexpr int U = NW > 8 ? 2 : (NW > 4 || (G + MT) * 8 > 48) ? 4 : 8;   // k-steps in flight: (G + MT) * U 16-byte loads per lane
     __shared__ __attribute__((aligned(16))) float s_acc[NW][G * MT][64][4];  // [wave][group x m-tile][lane][reg]
     __shared__ float s_st[NW][16 * MT][2];
+    __shared__ float s_fin[NW > 4 ? 16 * MT : 1][2];   // NW > 4: the rows' LayerNorm sums, added up once (see the reduction)
 
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index in an SGPR: everything that depends on it (k-step ownership, remainder rounds, who finalises what) is
@@ -110,23 +111,44 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
 
     // epilogue operands that do not depend on the GEMM (residual, fold constants) are requested before the main loop:
     // their latency hides under it instead of sitting exposed after the reduction
-    float pre_res[NT][4], pre_c1[G], pre_c2[G];
+    T pre_res[NT][4];                     // RAW residual values (converted where they are used: lina_common.h raw4)
+    float pre_c1[G], pre_c2[G];
+    // Every load below is UNCONDITIONAL on a clamped (always readable) address and the value is selected afterwards; what
+    // decides whether a tensor exists at all is a kernel argument (a scalar branch).  The predicated form
+    // `ok ? ld(p) : 0` compiles to an EXEC-masked region per load with `s_waitcnt vmcnt(0)` behind it -- the loads ran one
+    // memory round trip after the other (4 + 2 of them in front of the main loop's first fragment load).
+    // They are requested BEHIND the first round of fragment loads: a wave's loads return in order, and the fragments are
+    // needed first (A/B in the L169 step: 0.609 -> 0.583 ms per token, tests/gpu_r03m.sh).
+    auto preload = [&]() {
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int n = n0 + 16 * (g % NT) + li;
-        const bool ok = n < n_rows;
-        pre_c1[g] = (LN && ok) ? c1[(g / NT) * Hd + n] : 0.0f;
-        pre_c2[g] = (c2 && ok) ? c2[(g / NT) * Hd + n] : 0.0f;
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + 16 * w + 4 * lg + r, n = n0 + 16 * j + li;
-            // resid == outp: the residual stream lives ONLY in the packed buffer (read-modify-write by the same thread)
-            pre_res[j][r] = (resid && w < MT && m < M && n < N)
-                                ? ld(resid == outp ? resid + packed_off<T>(m, n, Kp) : resid + (int64_t)m * ldr + n) : 0.0f;
+        for (int g = 0; g < G; ++g) {
+            const int n = n0 + 16 * (g % NT) + li;
+            const bool ok = n < n_rows;
+            const int idx = (g / NT) * Hd + (ok ? n : n_rows - 1);
+            // (no select on the loaded value here: it would be a USE, i.e. a wait for this load -- and for every fragment load
+            //  in front of it; columns past the end get a neighbour's constant and are never stored)
+            pre_c1[g] = 0.0f;
+            pre_c2[g] = 0.0f;
+            if (LN) pre_c1[g] = c1[idx];
+            if (c2) pre_c2[g] = c2[idx];
         }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pre_res[j][r] = T();
+        if (resid) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + 16 * (w < MT ? w : 0) + 4 * lg + r, n = n0 + 16 * j + li;
+                    const int mc = m < M ? m : M - 1, nc = n < N ? n : N - 1;
+                    // resid == outp: the residual stream lives ONLY in the packed buffer (read-modify-write by the same thread)
+                    pre_res[j][r] = ld_raw(resid == outp ? resid + packed_off<T>(mc, nc, Kp) : resid + (int64_t)mc * ldr + nc);
+                }
+        }
+    };
+    bool pre_done = false;
 
     const int nsteps = K / F::KSTEP;
     // wave w takes k-steps {2w, 2w+1} + 8j: its two consecutive 64-byte (bf16) loads of a row are the two halves
@@ -142,6 +164,7 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[u][mt].load(ap[mt] + k0); else fa[u][mt].zero(); }
         }
+        if (ks == 0) { sched_fence(); preload(); sched_fence(); pre_done = true; }   // behind the first round's fragments
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -163,6 +186,7 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
 #endif
     }
     SK_PROF(3, clock64());
+    if (!pre_done) preload();                                     // (a K shorter than one round)
     if (kstep_of<NW>(w, ks) < nsteps) {
         // remainder (fewer than U steps for this wave, e.g. K = 1376: 43 k-steps): ONE more round with every load in flight --
         // a loop of single steps pays a full memory round trip per step (+1.1 us on the down-projection, time stamps of
@@ -217,6 +241,19 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
         }
     }
     __syncthreads();
+    if (LN && NW > 4) {
+        // with 8 / 16 partial sets a finalising lane would add 2 x 4 x NW dependent LDS values for its four rows (~1000 clocks
+        // of the epilogue): one thread per (row, statistic) adds them once instead, in the same pairwise order
+        if (tid < 32 * MT) {
+            const int row = tid >> 1, c = tid & 1;
+            float a = (s_st[0][row][c] + s_st[1][row][c]) + (s_st[2][row][c] + s_st[3][row][c]);
+#pragma unroll
+            for (int ww = 4; ww < NW; ww += 4)
+                a += (s_st[ww][row][c] + s_st[ww + 1][row][c]) + (s_st[ww + 2][row][c] + s_st[ww + 3][row][c]);
+            s_fin[row][c] = a;
+        }
+        __syncthreads();
+    }
     SK_PROF(4, clock64());
     if (w >= MT) return;
 
@@ -238,12 +275,11 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
         const int m = m0 + row;
         float mu = 0.f, rstd = 1.f;
         if (LN) {
-            float a = (s_st[0][row][0] + s_st[1][row][0]) + (s_st[2][row][0] + s_st[3][row][0]);
-            float b = (s_st[0][row][1] + s_st[1][row][1]) + (s_st[2][row][1] + s_st[3][row][1]);
-#pragma unroll
-            for (int ww = 4; ww < NW; ww += 4) {
-                a += (s_st[ww][row][0] + s_st[ww + 1][row][0]) + (s_st[ww + 2][row][0] + s_st[ww + 3][row][0]);
-                b += (s_st[ww][row][1] + s_st[ww + 1][row][1]) + (s_st[ww + 2][row][1] + s_st[ww + 3][row][1]);
+            float a, b;
+            if (NW > 4) { a = s_fin[row][0]; b = s_fin[row][1]; }
+            else {
+                a = (s_st[0][row][0] + s_st[1][row][0]) + (s_st[2][row][0] + s_st[3][row][0]);
+                b = (s_st[0][row][1] + s_st[1][row][1]) + (s_st[2][row][1] + s_st[3][row][1]);
             }
             const float inv_d = fast_rcp((float)ln_dim);
             mu = a * inv_d;
@@ -269,7 +305,7 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
                 }
             }
             if (m < M && n < N) {
-                if (resid) res += pre_res[j][r];
+                if (resid) res += cvt1(pre_res[j][r]);
                 if (out) st(out + (int64_t)m * ldo + n, res);
                 if (outp) st(outp + packed_off<T>(m, n, Kp), res);
             }

@@ -12,54 +12,79 @@ namespace lina {
 
 constexpr int kNormMaxTrips = 8;  // D <= 8 * 256 = 2048
 
-template <typename TX, typename T>
+// TR = pieces of 256 elements per row (D <= 256 TR); a wave works on RG = 8 / TR rows at once: its 8 register slots are
+// (row r, piece p) pairs.  EVERY load of the group -- x (all partials), g, w -- is unconditional on a clamped offset and
+// issued before anything uses it: with one row per wave and the gate / weight loads behind the reduction a wave had a single
+// 8-byte load in flight per memory round trip (L169, D = 256: 1.9 TB/s in the train step's profile).
+template <typename TX, typename T, int TR>
 __global__ __launch_bounds__(256) void rmsnorm_gate_kernel(
     const TX* __restrict__ x, const T* __restrict__ g, const T* __restrict__ w, T* __restrict__ y,
     int64_t rows, int rows_inner, int D, int64_t x_outer, int64_t x_inner, int64_t g_outer, int64_t g_inner,
     int64_t y_outer, int64_t y_inner, int n_partial, int64_t x_part, float eps) {
+    constexpr int RG = kNormMaxTrips / TR;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool live = row < rows;  // whole wave uniform
-    const int64_t ro = row / rows_inner, ri = row % rows_inner;
-    const int64_t x_off = ro * x_outer + ri * x_inner, g_off = ro * g_outer + ri * g_inner,
-                  y_off = ro * y_outer + ri * y_inner;
-    float4 xv[kNormMaxTrips];
-    float ss = 0.0f;
-    const int trips = (D + 255) / 256;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave_uniform(threadIdx.x >> 6)) * RG;
+    if (row0 >= rows) return;                                // wave-uniform
+    int64_t x_off[RG], g_off[RG], y_off[RG];
 #pragma unroll
-    for (int i = 0; i < kNormMaxTrips; ++i) {
-        const int e = i * 256 + lane * 4;
-        xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live && i < trips && e < D) {
-            const TX* xp = x + x_off + e;
-            float4 a = ld4(xp);
-            for (int p = 1; p < n_partial; ++p) {
-                const float4 c = ld4(xp + p * x_part);
-                a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
-            }
-            xv[i] = a;
-            ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    for (int r = 0; r < RG; ++r) {
+        const int64_t row = min(row0 + r, rows - 1);         // rows past the end re-read the last row (not stored)
+        const int64_t ro = row / rows_inner, ri = row % rows_inner;
+        x_off[r] = ro * x_outer + ri * x_inner;
+        g_off[r] = ro * g_outer + ri * g_inner;
+        y_off[r] = ro * y_outer + ri * y_inner;
+    }
+    typename raw4<TX>::type xr[kNormMaxTrips];
+    typename raw4<T>::type gr[kNormMaxTrips], wr[TR];
+#pragma unroll
+    for (int p = 0; p < TR; ++p) {
+        const int e = p * 256 + lane * 4, ec = e < D ? e : D - 4;
+        if (w) wr[p] = ld4_raw(w + ec);
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            xr[r * TR + p] = ld4_raw(x + x_off[r] + ec);
+            if (g) gr[r * TR + p] = ld4_raw(g + g_off[r] + ec);
         }
     }
-    ss += shfl_xor(ss, 1); ss += shfl_xor(ss, 2); ss += shfl_xor(ss, 4);
-    ss += shfl_xor(ss, 8); ss += shfl_xor(ss, 16); ss += shfl_xor(ss, 32);
-    const float rs = rsqrtf(ss / (float)D + eps);
+    float4 xv[kNormMaxTrips];
+    float ss[RG];
 #pragma unroll
-    for (int i = 0; i < kNormMaxTrips; ++i) {
-        const int e = i * 256 + lane * 4;
-        if (live && i < trips && e < D) {
-            float4 a = xv[i];
+    for (int r = 0; r < RG; ++r) {
+        ss[r] = 0.0f;
+#pragma unroll
+        for (int p = 0; p < TR; ++p) {
+            const int e = p * 256 + lane * 4, ec = e < D ? e : D - 4;
+            float4 a = cvt4(xr[r * TR + p]);
+            for (int q = 1; q < n_partial; ++q) {            // decode path: fp32 partial sums of the row
+                const float4 c = ld4(x + x_off[r] + ec + q * x_part);
+                a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+            }
+            xv[r * TR + p] = a;
+            ss[r] += e < D ? a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        float t = ss[r];
+        t += shfl_xor(t, 1); t += shfl_xor(t, 2); t += shfl_xor(t, 4);
+        t += shfl_xor(t, 8); t += shfl_xor(t, 16); t += shfl_xor(t, 32);
+        const float rs = rsqrtf(t / (float)D + eps);
+        if (row0 + r >= rows) break;                         // wave-uniform
+#pragma unroll
+        for (int p = 0; p < TR; ++p) {
+            const int e = p * 256 + lane * 4;
+            float4 a = xv[r * TR + p];
             a.x *= rs; a.y *= rs; a.z *= rs; a.w *= rs;
             if (w) {
-                const float4 ww = ld4(w + e);
+                const float4 ww = cvt4(wr[p]);
                 a.x *= ww.x; a.y *= ww.y; a.z *= ww.z; a.w *= ww.w;
             }
             if (g) {
-                const float4 gg = ld4(g + g_off + e);
+                const float4 gg = cvt4(gr[r * TR + p]);
                 a.x *= gg.x * sigmoidf(gg.x); a.y *= gg.y * sigmoidf(gg.y);
                 a.z *= gg.z * sigmoidf(gg.z); a.w *= gg.w * sigmoidf(gg.w);
             }
-            st4(y + y_off + e, a);
+            if (e < D) st4(y + y_off[r] + e, a);
         }
     }
 }
@@ -81,20 +106,23 @@ extern "C" int lina_rmsnorm_gate_fwd(const void* x, const void* g, const void* w
                  "lina_rmsnorm_gate_fwd: row strides must be multiples of 4 elements");
     LINA_REQUIRE(valid_dtype(dtype) && valid_dtype(x_dtype), "lina_rmsnorm_gate_fwd: bad dtype");
     LINA_REQUIRE(n_partial >= 1, "lina_rmsnorm_gate_fwd: n_partial must be >= 1");
-    dim3 grid((unsigned)((rows + 3) / 4));
-    if (x_dtype == LINA_F32 && dtype == LINA_F32) {
-        LINA_LAUNCH((rmsnorm_gate_kernel<float, float>), grid, dim3(256), 0, stream, (const float*)x, (const float*)g,
-                    (const float*)w, (float*)y, rows, rows_inner, D, x_outer, x_inner, g_outer, g_inner, y_outer, y_inner, n_partial, x_part_stride, eps);
-    } else if (x_dtype == LINA_F32 && dtype == LINA_BF16) {
-        LINA_LAUNCH((rmsnorm_gate_kernel<float, bf16_t>), grid, dim3(256), 0, stream, (const float*)x, (const bf16_t*)g,
-                    (const bf16_t*)w, (bf16_t*)y, rows, rows_inner, D, x_outer, x_inner, g_outer, g_inner, y_outer, y_inner, n_partial, x_part_stride, eps);
-    } else if (x_dtype == LINA_BF16 && dtype == LINA_BF16) {
-        LINA_LAUNCH((rmsnorm_gate_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)x,
-                    (const bf16_t*)g, (const bf16_t*)w, (bf16_t*)y, rows, rows_inner, D, x_outer, x_inner, g_outer,
-                    g_inner, y_outer, y_inner, n_partial, x_part_stride, eps);
-    } else {
-        return fail(LINA_ERR_UNSUPPORTED, "lina_rmsnorm_gate_fwd: x bf16 with f32 output is not built");
-    }
+    const int tr = D <= 256 ? 1 : D <= 512 ? 2 : D <= 1024 ? 4 : 8;       // pieces per row; a wave takes 8 / tr rows at a time
+    const int64_t groups = (rows + (kNormMaxTrips / tr) - 1) / (kNormMaxTrips / tr);
+    dim3 grid((unsigned)((groups + 3) / 4));
+#define LINA_RN_F(TXX, TT, TRR)                                                                                        \
+    LINA_LAUNCH((rmsnorm_gate_kernel<TXX, TT, TRR>), grid, dim3(256), 0, stream, (const TXX*)x, (const TT*)g, (const TT*)w, \
+                (TT*)y, rows, rows_inner, D, x_outer, x_inner, g_outer, g_inner, y_outer, y_inner, n_partial, x_part_stride, eps)
+#define LINA_RN_FT(TXX, TT)                                                                                            \
+    do {                                                                                                               \
+        if (tr == 1) LINA_RN_F(TXX, TT, 1); else if (tr == 2) LINA_RN_F(TXX, TT, 2);                                   \
+        else if (tr == 4) LINA_RN_F(TXX, TT, 4); else LINA_RN_F(TXX, TT, 8);                                           \
+    } while (0)
+    if (x_dtype == LINA_F32 && dtype == LINA_F32) LINA_RN_FT(float, float);
+    else if (x_dtype == LINA_F32 && dtype == LINA_BF16) LINA_RN_FT(float, bf16_t);
+    else if (x_dtype == LINA_BF16 && dtype == LINA_BF16) LINA_RN_FT(bf16_t, bf16_t);
+    else return fail(LINA_ERR_UNSUPPORTED, "lina_rmsnorm_gate_fwd: x bf16 with f32 output is not built");
+#undef LINA_RN_FT
+#undef LINA_RN_F
     return check_launch("lina_rmsnorm_gate_fwd");
 }
 
@@ -111,46 +139,60 @@ namespace lina {
 
 constexpr int kNormBwdMaxWG = LINA_NORM_BWD_MAX_WG;
 
-template <typename T>
+template <typename T, int TR>
 __global__ __launch_bounds__(256) void rmsnorm_gate_bwd_kernel(
     const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ w, const T* __restrict__ dy,
     T* __restrict__ dx, T* __restrict__ dg, float* __restrict__ dw_partial, int64_t rows, int D, float eps) {
-    __shared__ float4 s_dw[3][kNormMaxTrips * 64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int trips = (D + 255) / 256;
-    float4 dwa[kNormMaxTrips];
+    // slots (row r, piece p) as in the forward: RG = 8 / TR rows per wave and iteration, every load of the group first
+    constexpr int RG = kNormMaxTrips / TR;
+    __shared__ float4 s_dw[3][TR * 64];
+    const int lane = threadIdx.x & 63, wv = wave_uniform(threadIdx.x >> 6);
+    float4 dwa[TR], w4[TR];
 #pragma unroll
-    for (int i = 0; i < kNormMaxTrips; ++i) dwa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < rows; row += (int64_t)gridDim.x * 4) {
-        const int64_t off = row * D;
-        float4 xv[kNormMaxTrips], dn[kNormMaxTrips];
-        float ss = 0.0f;
+    for (int p = 0; p < TR; ++p) {
+        const int e = p * 256 + lane * 4;
+        dwa[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        w4[p] = w ? ld4(w + (e < D ? e : D - 4)) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wv) * RG; row0 < rows; row0 += (int64_t)gridDim.x * 4 * RG) {
+        typename raw4<T>::type xr[kNormMaxTrips], dr[kNormMaxTrips], gr[kNormMaxTrips];
 #pragma unroll
-        for (int i = 0; i < kNormMaxTrips; ++i) {
-            const int e = i * 256 + lane * 4;
-            xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < trips && e < D) {
-                xv[i] = ld4(x + off + e);
-                ss += xv[i].x * xv[i].x + xv[i].y * xv[i].y + xv[i].z * xv[i].z + xv[i].w * xv[i].w;
+        for (int r = 0; r < RG; ++r) {
+            const int64_t off = min(row0 + r, rows - 1) * D;
+#pragma unroll
+            for (int p = 0; p < TR; ++p) {
+                const int e = p * 256 + lane * 4, ec = e < D ? e : D - 4;
+                xr[r * TR + p] = ld4_raw(x + off + ec);
+                dr[r * TR + p] = ld4_raw(dy + off + ec);
+                if (g) gr[r * TR + p] = ld4_raw(g + off + ec);
             }
         }
-        ss += shfl_xor(ss, 1); ss += shfl_xor(ss, 2); ss += shfl_xor(ss, 4);
-        ss += shfl_xor(ss, 8); ss += shfl_xor(ss, 16); ss += shfl_xor(ss, 32);
-        const float rs = rsqrtf(ss / (float)D + eps);
-        float dot = 0.0f;   // sum dn n
 #pragma unroll
-        for (int i = 0; i < kNormMaxTrips; ++i) {
-            const int e = i * 256 + lane * 4;
-            dn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < trips && e < D) {
-                const float4 d4 = ld4(dy + off + e);
-                const float4 w4 = w ? ld4(w + e) : make_float4(1.f, 1.f, 1.f, 1.f);
-                const float nn[4] = {xv[i].x * rs, xv[i].y * rs, xv[i].z * rs, xv[i].w * rs};
-                const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
-                const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+        for (int r = 0; r < RG; ++r) {
+            if (row0 + r >= rows) break;                     // wave-uniform
+            const int64_t off = (row0 + r) * D;
+            float4 xv[TR], dn[TR];
+            float ss = 0.0f;
+#pragma unroll
+            for (int p = 0; p < TR; ++p) {
+                xv[p] = cvt4(xr[r * TR + p]);
+                ss += (p * 256 + lane * 4 < D) ? xv[p].x * xv[p].x + xv[p].y * xv[p].y + xv[p].z * xv[p].z + xv[p].w * xv[p].w : 0.0f;
+            }
+            ss += shfl_xor(ss, 1); ss += shfl_xor(ss, 2); ss += shfl_xor(ss, 4);
+            ss += shfl_xor(ss, 8); ss += shfl_xor(ss, 16); ss += shfl_xor(ss, 32);
+            const float rs = rsqrtf(ss / (float)D + eps);
+            float dot = 0.0f;   // sum dn n
+#pragma unroll
+            for (int p = 0; p < TR; ++p) {
+                const int e = p * 256 + lane * 4;
+                const bool ok = e < D;
+                const float4 d4 = cvt4(dr[r * TR + p]);
+                const float nn[4] = {xv[p].x * rs, xv[p].y * rs, xv[p].z * rs, xv[p].w * rs};
+                const float dd[4] = {ok ? d4.x : 0.f, ok ? d4.y : 0.f, ok ? d4.z : 0.f, ok ? d4.w : 0.f};
+                const float ww[4] = {w4[p].x, w4[p].y, w4[p].z, w4[p].w};
                 float sv[4] = {1.f, 1.f, 1.f, 1.f}, dgo[4];
                 if (g) {
-                    const float4 g4 = ld4(g + off + e);
+                    const float4 g4 = cvt4(gr[r * TR + p]);
                     const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -158,7 +200,7 @@ __global__ __launch_bounds__(256) void rmsnorm_gate_bwd_kernel(
                         sv[c] = gg[c] * sg;
                         dgo[c] = dd[c] * nn[c] * ww[c] * sg * (1.0f + gg[c] * (1.0f - sg));
                     }
-                    st4(dg + off + e, make_float4(dgo[0], dgo[1], dgo[2], dgo[3]));
+                    if (ok) st4(dg + off + e, make_float4(dgo[0], dgo[1], dgo[2], dgo[3]));
                 }
                 float dnn[4], dwv[4];
 #pragma unroll
@@ -168,38 +210,38 @@ __global__ __launch_bounds__(256) void rmsnorm_gate_bwd_kernel(
                     dnn[c] = du * ww[c];
                     dot += dnn[c] * nn[c];
                 }
-                dwa[i].x += dwv[0]; dwa[i].y += dwv[1]; dwa[i].z += dwv[2]; dwa[i].w += dwv[3];
-                dn[i] = make_float4(dnn[0], dnn[1], dnn[2], dnn[3]);
+                dwa[p].x += dwv[0]; dwa[p].y += dwv[1]; dwa[p].z += dwv[2]; dwa[p].w += dwv[3];
+                dn[p] = make_float4(dnn[0], dnn[1], dnn[2], dnn[3]);
             }
-        }
-        dot += shfl_xor(dot, 1); dot += shfl_xor(dot, 2); dot += shfl_xor(dot, 4);
-        dot += shfl_xor(dot, 8); dot += shfl_xor(dot, 16); dot += shfl_xor(dot, 32);
-        const float m = dot / (float)D;
+            dot += shfl_xor(dot, 1); dot += shfl_xor(dot, 2); dot += shfl_xor(dot, 4);
+            dot += shfl_xor(dot, 8); dot += shfl_xor(dot, 16); dot += shfl_xor(dot, 32);
+            const float m = dot / (float)D;
 #pragma unroll
-        for (int i = 0; i < kNormMaxTrips; ++i) {
-            const int e = i * 256 + lane * 4;
-            if (i < trips && e < D) {
-                float4 a;
-                a.x = rs * (dn[i].x - xv[i].x * rs * m); a.y = rs * (dn[i].y - xv[i].y * rs * m);
-                a.z = rs * (dn[i].z - xv[i].z * rs * m); a.w = rs * (dn[i].w - xv[i].w * rs * m);
-                st4(dx + off + e, a);
+            for (int p = 0; p < TR; ++p) {
+                const int e = p * 256 + lane * 4;
+                if (e < D) {
+                    float4 a;
+                    a.x = rs * (dn[p].x - xv[p].x * rs * m); a.y = rs * (dn[p].y - xv[p].y * rs * m);
+                    a.z = rs * (dn[p].z - xv[p].z * rs * m); a.w = rs * (dn[p].w - xv[p].w * rs * m);
+                    st4(dx + off + e, a);
+                }
             }
         }
     }
     if (wv > 0) {
 #pragma unroll
-        for (int i = 0; i < kNormMaxTrips; ++i) s_dw[wv - 1][i * 64 + lane] = dwa[i];
+        for (int p = 0; p < TR; ++p) s_dw[wv - 1][p * 64 + lane] = dwa[p];
     }
     __syncthreads();
     if (wv == 0) {
 #pragma unroll
-        for (int i = 0; i < kNormMaxTrips; ++i) {
-            const int e = i * 256 + lane * 4;
-            if (i < trips && e < D) {
-                float4 a = dwa[i];
+        for (int p = 0; p < TR; ++p) {
+            const int e = p * 256 + lane * 4;
+            if (e < D) {
+                float4 a = dwa[p];
 #pragma unroll
                 for (int o = 0; o < 3; ++o) {
-                    const float4 c = s_dw[o][i * 64 + lane];
+                    const float4 c = s_dw[o][p * 64 + lane];
                     a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
                 }
                 *reinterpret_cast<float4*>(dw_partial + (int64_t)blockIdx.x * D + e) = a;
@@ -227,12 +269,17 @@ extern "C" int lina_rmsnorm_gate_bwd(const void* x, const void* g, const void* w
                  "lina_rmsnorm_gate_bwd: D=%d must be a multiple of 4 and <= %d", D, kNormMaxTrips * 256);
     LINA_REQUIRE(valid_dtype(dtype), "lina_rmsnorm_gate_bwd: bad dtype");
     dim3 grid((unsigned)lina_rmsnorm_gate_bwd_partials(rows));
-    if (dtype == LINA_F32) {
-        LINA_LAUNCH((rmsnorm_gate_bwd_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, (const float*)g,
-                    (const float*)w, (const float*)dy, (float*)dx, (float*)dg, dw_partial, rows, D, eps);
-    } else {
-        LINA_LAUNCH((rmsnorm_gate_bwd_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)g,
-                    (const bf16_t*)w, (const bf16_t*)dy, (bf16_t*)dx, (bf16_t*)dg, dw_partial, rows, D, eps);
-    }
+    const int tr = D <= 256 ? 1 : D <= 512 ? 2 : D <= 1024 ? 4 : 8;
+#define LINA_RN_B(TT, TRR)                                                                                           \
+    LINA_LAUNCH((rmsnorm_gate_bwd_kernel<TT, TRR>), grid, dim3(256), 0, stream, (const TT*)x, (const TT*)g, (const TT*)w, \
+                (const TT*)dy, (TT*)dx, (TT*)dg, dw_partial, rows, D, eps)
+#define LINA_RN_BT(TT)                                                                                               \
+    do {                                                                                                             \
+        if (tr == 1) LINA_RN_B(TT, 1); else if (tr == 2) LINA_RN_B(TT, 2); else if (tr == 4) LINA_RN_B(TT, 4);       \
+        else LINA_RN_B(TT, 8);                                                                                       \
+    } while (0)
+    if (dtype == LINA_F32) LINA_RN_BT(float); else LINA_RN_BT(bf16_t);
+#undef LINA_RN_BT
+#undef LINA_RN_B
     return check_launch("lina_rmsnorm_gate_bwd");
 }

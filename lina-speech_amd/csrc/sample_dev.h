@@ -162,9 +162,9 @@ __device__ __forceinline__ void argmax_scan(const T* row, int n, float& best, in
     for (int j0 = tid; j0 < n; j0 += 256 * kArgmaxInFlight) {
         float v[kArgmaxInFlight];
 #pragma unroll
-        for (int u = 0; u < kArgmaxInFlight; ++u) {
-            const int j = j0 + 256 * u;
-            v[u] = j < n ? ld(row + j) : -INFINITY;
+        for (int u = 0; u < kArgmaxInFlight; ++u) {          // unconditional loads on clamped indices: a predicated load
+            const int j = j0 + 256 * u;                        // (`j < n ? ld : x`) waits for its data before the next is issued
+            v[u] = ld(row + (j < n ? j : n - 1));
         }
 #pragma unroll
         for (int u = 0; u < kArgmaxInFlight; ++u) {
@@ -183,7 +183,7 @@ __device__ __forceinline__ void row_to_lds(const T* row, int n, float* s_x) {
 #pragma unroll
         for (int u = 0; u < kArgmaxInFlight; ++u) {
             const int j = j0 + 256 * u;
-            v[u] = j < n ? ld(row + j) : 0.0f;
+            v[u] = ld(row + (j < n ? j : n - 1));
         }
 #pragma unroll
         for (int u = 0; u < kArgmaxInFlight; ++u) {

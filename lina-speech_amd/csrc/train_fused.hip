@@ -9,6 +9,7 @@
 // partials of dgamma / dbeta (summed by the caller: deterministic, no atomics) in one pass.
 // Work split: one wave per row (a row's D elements are contiguous: 16 B per lane and piece), 4 rows per 256-thread
 // workgroup, grid-stride over the rows; all reductions are wave shuffles.  HBM-bound streaming kernels.
+#include <type_traits>
 #include <lina_dev.h>
 #include "lina_common.h"
 
@@ -23,6 +24,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // TX: residual-stream dtype (x, xsum, dx);  TR: dtype of the added branch r (and of its gradient);  TY: output dtype
+// All loads of a row are UNCONDITIONAL on clamped element offsets and issued before anything uses them (a load under a
+// per-lane `if (e < D)` is waited for on the spot: one memory round trip per piece); the tail pieces are masked at the sums
+// and at the stores.
 template <typename TX, typename TR, typename TY, int NP>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TX* __restrict__ x, const TR* __restrict__ r,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -31,50 +35,58 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TX* __restrict
                                                             int D, float eps) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float inv_d = 1.0f / (float)D;
+    float4 gm[NP], bt[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int e = 4 * lane + 256 * i, ec = e < D ? e : D - 4;
+        gm[i] = *reinterpret_cast<const float4*>(gamma + ec);
+        bt[i] = *reinterpret_cast<const float4*>(beta + ec);
+    }
     for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < N; row += (int64_t)gridDim.x * 4) {
+        typename raw4<TX>::type xr[NP];
+        typename raw4<TR>::type rr[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int e = 4 * lane + 256 * i, ec = e < D ? e : D - 4;
+            xr[i] = ld4_raw(x + row * D + ec);
+            if (r) rr[i] = ld4_raw(r + row * D + ec);            // (r: a kernel argument -- scalar branch)
+        }
         float4 v[NP];
         float s = 0.0f;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int e = 4 * lane + 256 * i;
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < D) {
-                v[i] = ld4(x + row * D + e);
-                if (r) {
-                    const float4 a = ld4(r + row * D + e);
-                    v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
-                    if (xsum) {                              // the value the stream carries on (rounded to its dtype first)
-                        st4(xsum + row * D + e, v[i]);
-                        if (!std::is_same<TX, float>::value) {
-                            TX t4[4];
-                            st4(t4, v[i]);
-                            v[i] = ld4(t4);
-                        }
+            const bool ok = e < D;
+            v[i] = cvt4(xr[i]);
+            if (r) {
+                const float4 a = cvt4(rr[i]);
+                v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
+                if (xsum) {                                  // the value the stream carries on (rounded to its dtype first)
+                    if (ok) st4(xsum + row * D + e, v[i]);
+                    if (!std::is_same<TX, float>::value) {
+                        TX t4[4];
+                        st4(t4, v[i]);
+                        v[i] = ld4(t4);
                     }
                 }
-                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
             }
+            s += ok ? (v[i].x + v[i].y) + (v[i].z + v[i].w) : 0.0f;
         }
         const float mu = wave_sum(s) * inv_d;
         float q = 0.0f;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int e = 4 * lane + 256 * i;
-            if (e < D) {
-                const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
-                q += (a * a + b * b) + (c * c + d * d);
-            }
+            const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+            q += (4 * lane + 256 * i < D) ? (a * a + b * b) + (c * c + d * d) : 0.0f;
         }
         const float rs = rsqrtf(wave_sum(q) * inv_d + eps);
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int e = 4 * lane + 256 * i;
-            if (e < D) {
-                const float4 g = *reinterpret_cast<const float4*>(gamma + e), bb = *reinterpret_cast<const float4*>(beta + e);
-                st4(y + row * D + e, make_float4((v[i].x - mu) * rs * g.x + bb.x, (v[i].y - mu) * rs * g.y + bb.y,
-                                                 (v[i].z - mu) * rs * g.z + bb.z, (v[i].w - mu) * rs * g.w + bb.w));
-            }
+            if (e < D)
+                st4(y + row * D + e, make_float4((v[i].x - mu) * rs * gm[i].x + bt[i].x, (v[i].y - mu) * rs * gm[i].y + bt[i].y,
+                                                 (v[i].z - mu) * rs * gm[i].z + bt[i].z, (v[i].w - mu) * rs * gm[i].w + bt[i].w));
         }
     }
 }
@@ -92,40 +104,50 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TY* __restrict
     __shared__ __attribute__((aligned(16))) float s_part[2][3][64][4];       // [dgamma|dbeta][waves 1..3][lane][4]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float inv_d = 1.0f / (float)D;
-    float4 ag[NP], ab[NP];
+    float4 ag[NP], ab[NP], gm[NP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
+    for (int i = 0; i < NP; ++i) {
+        const int e = 4 * lane + 256 * i;
+        ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ab[i] = ag[i];
+        gm[i] = *reinterpret_cast<const float4*>(gamma + (e < D ? e : D - 4));
+    }
     for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < N; row += (int64_t)gridDim.x * 4) {
+        typename raw4<TY>::type dr_[NP];
+        typename raw4<TX>::type xr[NP], pr[NP];
         const float mu = mean[row], rs = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {                       // every load of the row first (unconditional, clamped)
+            const int e = 4 * lane + 256 * i, ec = e < D ? e : D - 4;
+            dr_[i] = ld4_raw(dy + row * D + ec);
+            xr[i] = ld4_raw(x + row * D + ec);
+            if (dpass) pr[i] = ld4_raw(dpass + row * D + ec);
+        }
         float4 g[NP], xh[NP];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int e = 4 * lane + 256 * i;
-            g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            xh[i] = g[i];
-            if (e < D) {
-                const float4 d = ld4(dy + row * D + e), xv = ld4(x + row * D + e);
-                const float4 gm = *reinterpret_cast<const float4*>(gamma + e);
-                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
-                ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
-                g[i] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
-                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
-                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
-            }
+            const bool ok = 4 * lane + 256 * i < D;
+            const float4 d0 = cvt4(dr_[i]), xv = cvt4(xr[i]);
+            const float4 d = ok ? d0 : make_float4(0.f, 0.f, 0.f, 0.f);
+            xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+            ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+            ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+            g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+            s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+            s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
         }
         const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int e = 4 * lane + 256 * i;
+            float4 o = make_float4(rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2),
+                                   rs * (g[i].z - m1 - xh[i].z * m2), rs * (g[i].w - m1 - xh[i].w * m2));
+            if (dpass) {
+                const float4 p = cvt4(pr[i]);
+                o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+            }
             if (e < D) {
-                float4 o = make_float4(rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2),
-                                       rs * (g[i].z - m1 - xh[i].z * m2), rs * (g[i].w - m1 - xh[i].w * m2));
-                if (dpass) {
-                    const float4 p = ld4(dpass + row * D + e);
-                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
-                }
                 st4(dx + row * D + e, o);
                 if (dr) st4(dr + row * D + e, o);
             }
@@ -134,7 +156,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TY* __restrict
     // dgamma / dbeta of this workgroup's rows: waves 1..3 hand their sums to wave 0 through LDS, piece by piece
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        if (4 * lane + 256 * i >= D && i > 0) break;
+        if (256 * i >= D) break;                             // workgroup-uniform (the barriers below)
         __syncthreads();
         if (w > 0) {
             *reinterpret_cast<float4*>(&s_part[0][w - 1][lane][0]) = ag[i];
@@ -156,6 +178,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TY* __restrict
                 *reinterpret_cast<float4*>(db_part + (int64_t)blockIdx.x * D + e) = b;
             }
         }
+    }
+}
+
+// scalar form for widths / strides that are not multiples of 4 (L169: Hd = 1365): one element per thread
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd_scalar_kernel(const T* __restrict__ ds, const T* __restrict__ u,
+                                                                T* __restrict__ du, int64_t rows, int Hd, int64_t ld_u,
+                                                                int64_t ld_ds, int64_t ld_du) {
+    const int64_t n = rows * Hd;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / Hd;
+        const int j = (int)(i % Hd);
+        const float a = ld(u + row * ld_u + j), b = ld(u + row * ld_u + Hd + j), d = ld(ds + row * ld_ds + j);
+        const float sg = sigmoidf(a);
+        st(du + row * ld_du + j, d * b * sg * (1.0f + a * (1.0f - sg)));
+        st(du + row * ld_du + Hd + j, d * a * sg);
     }
 }
 
@@ -264,9 +302,19 @@ extern "C" int lina_swiglu_bwd(const void* ds, const void* u, void* du, int64_t 
                                int64_t ld_du, int dtype, lina_stream_t stream) {
     using namespace lina;
     LINA_REQUIRE(ds && u && du, "lina_swiglu_bwd: null pointer");
-    LINA_REQUIRE(rows > 0 && Hd > 0 && Hd % 4 == 0, "lina_swiglu_bwd: rows, Hd must be positive, Hd a multiple of 4");
-    LINA_REQUIRE(ld_u % 4 == 0 && ld_ds % 4 == 0 && ld_du % 4 == 0, "lina_swiglu_bwd: row strides must be multiples of 4");
+    LINA_REQUIRE(rows > 0 && Hd > 0, "lina_swiglu_bwd: rows, Hd must be positive");
     LINA_REQUIRE(valid_dtype(dtype), "lina_swiglu_bwd: bad dtype %d", dtype);
+    if (Hd % 4 || ld_u % 4 || ld_ds % 4 || ld_du % 4) {           // e.g. L169: Hd = 1365
+        const int64_t wgs1 = (rows * Hd + 255) / 256;
+        dim3 grid1((unsigned)(wgs1 < 262144 ? wgs1 : 262144));
+        if (dtype == LINA_F32)
+            LINA_LAUNCH((swiglu_bwd_scalar_kernel<float>), grid1, dim3(256), 0, stream, (const float*)ds, (const float*)u,
+                        (float*)du, rows, Hd, ld_u, ld_ds, ld_du);
+        else
+            LINA_LAUNCH((swiglu_bwd_scalar_kernel<bf16_t>), grid1, dim3(256), 0, stream, (const bf16_t*)ds, (const bf16_t*)u,
+                        (bf16_t*)du, rows, Hd, ld_u, ld_ds, ld_du);
+        return check_launch("lina_swiglu_bwd");
+    }
     const int64_t n4 = rows * (Hd / 4);
     const int64_t wgs = (n4 + 255) / 256;
     dim3 grid((unsigned)(wgs < 65536 ? wgs : 65536));

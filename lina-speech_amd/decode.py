@@ -190,6 +190,9 @@ class DecodeEngine:
         # Infinity Cache: per token the loop touches 0.87 GB of state (always streamed) + 0.26 GB of weights; streaming
         # the largest matrices lets the others stay resident between two tokens.  LINA_DECODE_STREAM=in,up,...
         self._stream = set(os.environ.get("LINA_DECODE_STREAM", "in,up").replace(" ", "").split(",")) - {""}
+        # first half of the cross-attention: scores on 256 workgroups + {softmax, att1 . pe} in one launch (default), or the
+        # round-2 form {scores + softmax in one workgroup per row} + skinny GEMM (LINA_DECODE_CROSS=fused; A/B: DESIGN 4.4)
+        self._cross_spread = os.environ.get("LINA_DECODE_CROSS", "spread") != "fused"
         blocks = list(rnn.encoder) + list(rnn.decoder) + [rnn.cross_att.pos_net]
         self.n_enc = len(rnn.encoder)
         ca = rnn.cross_att
@@ -299,14 +302,21 @@ class DecodeEngine:
             q_lin = ops.linear_skinny_packed(part.x_p, self.ca_qw_p, B, self.d, self.d, c2=self.ca_qb, out=part.q_lin)
         else:
             q_lin = ops.linear_skinny(x, self.ca_qw, c2=self.ca_qb, out=part.q_lin)
-        ops.cross_scores_softmax(q_lin, ca.ln_q.weight, ca.ln_q.bias, ca.ln_q.eps, part.kk, att[:, 0, 0], part.attc,
-                                 self.att_scale)
+        if self._cross_spread:
+            # scores on 256 workgroups (4 per row), then softmax + att1 . pe in one launch (K = T_txt: no MFMA needed)
+            ops.cross_scores(q_lin, ca.ln_q.weight, ca.ln_q.bias, ca.ln_q.eps, part.kk, part.scores, self.att_scale)
+            ops.softmax_pe_rows(part.scores, att[:, 0, 0], self.pe, part.xp, part.xp_p if packed else None)
+        else:
+            ops.cross_scores_softmax(q_lin, ca.ln_q.weight, ca.ln_q.bias, ca.ln_q.eps, part.kk, att[:, 0, 0], part.attc,
+                                     self.att_scale)
         if packed:
-            ops.linear_skinny(part.attc, self.peT, out=part.xp, out_packed=part.xp_p, out_packed_width=self.d)  # xp = att1 . pe
+            if not self._cross_spread:
+                ops.linear_skinny(part.attc, self.peT, out=part.xp, out_packed=part.xp_p, out_packed_width=self.d)  # xp = att1 . pe
             self._block(part.xp, part.packs[-1], lazy, part.xp_p)
             ops.linear_skinny_packed(part.xp_p, self.pe_pad_p, B, self.pe_pad.shape[0], self.d, out=part.sc2)
         else:
-            ops.linear_skinny(part.attc, self.peT, out=part.xp)                   # xp = att1 . pe
+            if not self._cross_spread:
+                ops.linear_skinny(part.attc, self.peT, out=part.xp)               # xp = att1 . pe
             self._block(part.xp, part.packs[-1], lazy)
             ops.linear_skinny(part.xp, self.pe_pad, out=part.sc2)                 # scores2 = xp . pe^T
         ops.softmax_weighted_rows_add(part.sc2, self.att_scale, att[:, 1, 0], part.vv, x,

@@ -519,6 +519,120 @@ def rmsnorm(x, weight=None, eps: float = 1e-5):
     return rmsnorm_swish_gate(x, None, weight, eps)
 
 
+# --------------------------------------------------------------------------- training glue (K10 / K11)
+class _LayerNormFunction(torch.autograd.Function):
+    """K10: y = LayerNorm(x [+ r]) (and x + r when a branch is added), contiguous rows [N, D]; see lina_gla.h."""
+
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, eps, y_dtype):
+        be = _BACKEND
+        N, D = x.shape
+        y = torch.empty(N, D, dtype=y_dtype, device=x.device)
+        xsum = torch.empty_like(x) if r is not None else None
+        mean = torch.empty(N, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        rdt = _dt(r) if r is not None else _dt(y)
+        _check(be.lib.lina_layernorm_fwd(_ptr(x), _ptr(r), _ptr(gamma), _ptr(beta), _ptr(xsum), _ptr(y), _ptr(mean),
+                                         _ptr(rstd), N, D, float(eps), _dt(x), rdt, _dt(y), be.stream(x)))
+        ctx.save_for_backward(xsum if r is not None else x, mean, rstd, gamma)
+        ctx.has_r, ctx.r_dtype, ctx.rdt = r is not None, (r.dtype if r is not None else None), rdt
+        ctx.mark_non_differentiable(mean, rstd)
+        if r is not None:
+            return y, xsum
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, dxsum=None):
+        xs, mean, rstd, gamma = ctx.saved_tensors
+        be = _BACKEND
+        N, D = xs.shape
+        dy = dy.contiguous()
+        dpass = None if dxsum is None else dxsum.to(xs.dtype).contiguous()
+        dx = torch.empty_like(xs)
+        dr = torch.empty(N, D, dtype=ctx.r_dtype, device=xs.device) if ctx.has_r and ctx.r_dtype != xs.dtype else None
+        npart = int(be.lib.lina_layernorm_bwd_partials(N))
+        part = torch.empty(2, npart, D, dtype=torch.float32, device=xs.device)
+        _check(be.lib.lina_layernorm_bwd(_ptr(dy), _ptr(xs), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dpass), _ptr(dx),
+                                         _ptr(dr), _ptr(part[0]), _ptr(part[1]), N, D, _dt(xs), ctx.rdt, _dt(dy),
+                                         be.stream(xs)))
+        sums = part.sum(1)
+        d_r = None
+        if ctx.has_r:
+            d_r = dr if dr is not None else dx          # same values: the add passes the gradient through unchanged
+        return dx, d_r, sums[0], sums[1], None, None
+
+
+_LN_TRIPLES = {(torch.float32, torch.float32, torch.float32), (torch.float32, torch.bfloat16, torch.bfloat16),
+               (torch.float32, torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16, torch.bfloat16)}
+
+
+def fused_ops_available(x: torch.Tensor) -> bool:
+    """True when the HIP (or emulated) ops can take ``x``: a ROCm tensor, or a CPU tensor under the test emulator."""
+    return x.is_cuda if _BACKEND.name == "hip" else not x.is_cuda
+
+
+def layer_norm(x, weight, bias, eps: float = 1e-5, residual=None, out_dtype=None):
+    """K10: ``LayerNorm(x [+ residual])`` over the last dimension (reference model/base_blocks.py:65-69).  Returns ``y``, or
+    ``(y, x + residual)`` when a residual branch is given -- the add rides in the norm's pass, forward and backward.
+    ``out_dtype``: dtype of ``y`` (default: the CUDA autocast dtype when autocast is on, else x.dtype).  Falls back to
+    torch for shapes / dtype combinations the kernel is not built for."""
+    be = _BACKEND
+    D = x.shape[-1]
+    if out_dtype is None:
+        out_dtype = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled()) else x.dtype
+    rdt = residual.dtype if residual is not None else out_dtype
+    ok = (fused_ops_available(x) and D % 4 == 0 and D <= 2048 and weight is not None and bias is not None
+          and (x.dtype, rdt, out_dtype) in _LN_TRIPLES and (residual is None or residual.shape == x.shape))
+    if not ok:
+        xs = x if residual is None else x + residual
+        y = torch.nn.functional.layer_norm(xs, (D,), weight, bias, eps)
+        return y if residual is None else (y, xs)
+    be.require(x, residual, weight, bias)
+    x2 = x.reshape(-1, D).contiguous()
+    r2 = None if residual is None else residual.reshape(-1, D).contiguous()
+    g32, b32 = weight.float().contiguous(), bias.float().contiguous()
+    out = _LayerNormFunction.apply(x2, r2, g32, b32, float(eps), out_dtype)
+    if residual is None:
+        return out.view(x.shape)
+    return out[0].view(x.shape), out[1].view(x.shape)
+
+
+class _SwiGLUFunction(torch.autograd.Function):
+    """K11 forward (lina_swiglu) + K11b backward on rows [N, 2 Hd] -> [N, Hd]."""
+
+    @staticmethod
+    def forward(ctx, u, hidden):
+        be = _BACKEND
+        N = u.shape[0]
+        y = torch.empty(N, hidden, dtype=u.dtype, device=u.device)
+        _check(be.lib.lina_swiglu(_ptr(u), _ptr(y), N, hidden, u.stride(0), y.stride(0), _dt(u), be.stream(u)))
+        ctx.save_for_backward(u)
+        ctx.hidden = hidden
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (u,) = ctx.saved_tensors
+        be = _BACKEND
+        dy = dy.to(u.dtype).contiguous()
+        du = torch.empty_like(u)
+        _check(be.lib.lina_swiglu_bwd(_ptr(dy), _ptr(u), _ptr(du), u.shape[0], ctx.hidden, u.stride(0), dy.stride(0),
+                                      du.stride(0), _dt(u), be.stream(u)))
+        return du, None
+
+
+def swiglu_gate(u):
+    """``silu(a) * b`` with ``(a, b) = u.chunk(2, -1)`` (reference model/base_blocks.py:48-50), differentiable: one pass
+    forward, one pass backward (autograd through chunk / silu / mul makes five, all unvectorised at L169's odd width)."""
+    hidden = u.shape[-1] // 2
+    if not fused_ops_available(u) or u.dtype not in (torch.float32, torch.bfloat16) or u.shape[-1] % 2:
+        a, b = u.chunk(2, dim=-1)
+        return torch.nn.functional.silu(a) * b
+    _BACKEND.require(u)
+    u2 = u.reshape(-1, u.shape[-1]).contiguous()
+    return _SwiGLUFunction.apply(u2, hidden).view(*u.shape[:-1], hidden)
+
+
 # --------------------------------------------------------------------------- codec head (K6)
 def _embed_sum_launch(table, flat, out=None):
     be = _BACKEND
@@ -972,6 +1086,23 @@ def softmax_weighted_rows_add(scores, scale, att, vv, x, x_packed=None):
         raise TypeError("scores / att / vv must share the model dtype")
     _check(be.lib.lina_softmax_weighted_rows_add(_ptr(scores), scores.stride(0), float(scale), _ptr(att), att.stride(0),
                                                  _ptr(vv), _ptr(x), _ptr(x_packed), B, Tn, d, _dt(vv), be.stream(vv)))
+
+
+def softmax_pe_rows(scores, att, pe, xp, xp_packed=None):
+    """att[b,:Tn] = softmax(scores[b,:Tn]) (fp32 scores, already scaled);  xp[b,:] = att[b,:] . pe[:Tn,:] -- one launch;
+    ``xp_packed``: also the fragment-major copy of xp (the A operand of the next projection)."""
+    be = _BACKEND
+    be.require(scores, att, pe, xp, xp_packed)
+    B, Tn = scores.shape
+    d = pe.shape[1]
+    if scores.dtype != torch.float32 or scores.stride(1) != 1:
+        raise TypeError("scores must be fp32 [B, Tn] with contiguous rows")
+    if att.dtype != pe.dtype or xp.dtype != pe.dtype or pe.shape[0] < Tn or not pe.is_contiguous() or not xp.is_contiguous():
+        raise TypeError("att / pe / xp must share the model dtype; pe [>= Tn, d] and xp [B, d] contiguous")
+    if xp_packed is not None and xp_packed.numel() < packed_numel(B, d):
+        raise ValueError("packed xp buffer is too small")
+    _check(be.lib.lina_softmax_pe_rows(_ptr(scores), scores.stride(0), _ptr(att), att.stride(0), _ptr(pe), _ptr(xp),
+                                       _ptr(xp_packed), B, Tn, d, _dt(pe), be.stream(pe)))
 
 
 def softmax_rows(x, scale, att, attc, Tn):

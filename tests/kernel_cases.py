@@ -495,6 +495,60 @@ def check_sample_pick_embed(dev, B, Q, L, d, dtype, n_sampled, k=7, temp=0.8, se
         assert torch.equal(log2[0], tok_log[steps - 1]) and torch.equal(x2, x)
 
 
+def check_layer_norm(dev, N, D, x_dtype, r_dtype, y_dtype):
+    """K10 forward + backward against fp64 autograd through  y = LayerNorm(x + r) * gamma + beta,  loss = <y, wy> + <x + r, ws>
+    (the second term sends a pass-through gradient into the residual stream, as the next block does)."""
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(N, D, generator=g) * 2 + 0.5).to(x_dtype)
+    r = None if r_dtype is None else torch.randn(N, D, generator=g).to(r_dtype)
+    gamma = 1 + 0.3 * torch.randn(D, generator=g)
+    beta = 0.2 * torch.randn(D, generator=g)
+    wy = torch.randn(N, D, generator=g).to(y_dtype)
+    ws = torch.randn(N, D, generator=g).to(x_dtype)
+    # reference in fp64 on the SAME (dtype-rounded) inputs
+    x64, r64 = x.to(F64).requires_grad_(), (None if r is None else r.to(F64).requires_grad_())
+    g64, b64 = gamma.to(F64).requires_grad_(), beta.to(F64).requires_grad_()
+    xs64 = x64 if r is None else x64 + r64
+    y64 = F.layer_norm(xs64, (D,), g64, b64, 1e-5)
+    loss = (y64 * wy.to(F64)).sum() + ((xs64 * ws.to(F64)).sum() if r is not None else 0.0)
+    loss.backward()
+    xd, rd = x.to(dev).requires_grad_(), (None if r is None else r.to(dev).requires_grad_())
+    gd, bd = gamma.to(dev).requires_grad_(), beta.to(dev).requires_grad_()
+    out = ops.layer_norm(xd, gd, bd, 1e-5, residual=rd, out_dtype=y_dtype)
+    y, xs = (out, None) if r is None else out
+    assert y.dtype == y_dtype and (xs is None or xs.dtype == x_dtype)
+    lo = y_dtype == torch.bfloat16 or x_dtype == torch.bfloat16
+    assert_close(y, y64.detach(), 1e-2 if lo else 2e-6, "K10 y")
+    if xs is not None:
+        assert_close(xs, xs64.detach(), 8e-3 if x_dtype == torch.bfloat16 else 1e-6, "K10 x + r")
+    l2 = (y.float() * wy.to(dev).float()).sum() + ((xs.float() * ws.to(dev).float()).sum() if xs is not None else 0.0)
+    l2.backward()
+    tol = 2e-2 if lo else 2e-5
+    assert_close(xd.grad, x64.grad, tol, "K10 dx")
+    if r is not None:
+        assert rd.grad.dtype == r_dtype
+        assert_close(rd.grad, r64.grad, tol, "K10 dr")
+    assert_close(gd.grad, g64.grad, tol, "K10 dgamma")
+    assert_close(bd.grad, b64.grad, tol, "K10 dbeta")
+
+
+def check_swiglu_gate(dev, N, H, dtype):
+    """K11 / K11b: silu(a) * b and its gradient against fp64 autograd (odd widths take the scalar kernels)."""
+    g = torch.Generator().manual_seed(37)
+    u = (torch.randn(N, 2 * H, generator=g) * 1.5).to(dtype)
+    w = torch.randn(N, H, generator=g).to(dtype)
+    u64 = u.to(F64).requires_grad_()
+    a, b = u64.chunk(2, -1)
+    y64 = F.silu(a) * b
+    (y64 * w.to(F64)).sum().backward()
+    ud = u.to(dev).requires_grad_()
+    y = ops.swiglu_gate(ud)
+    lo = dtype == torch.bfloat16
+    assert_close(y, y64.detach(), 1e-2 if lo else 2e-6, "K11 silu(a) b")
+    (y.float() * w.to(dev).float()).sum().backward()
+    assert_close(ud.grad, u64.grad, 1.5e-2 if lo else 2e-6, "K11b du")
+
+
 def check_argmax(dev, rows, n, dtype):
     g = torch.Generator().manual_seed(5)
     lg = torch.randn(rows, n, generator=g).to(dtype)
@@ -949,6 +1003,27 @@ def check_cross_fused(dev, B, Tn, d, dtype):
         x_p = ops.pack_rows(x0)
         ops.softmax_weighted_rows_add(sc2, scale, att_b[:, 1, 0], vv, x0.clone(), x_packed=x_p)
         assert torch.equal(ops.unpack_rows(x_p, B, d), x_b), "packed residual form differs from the row-major one"
+
+
+def check_softmax_pe_rows(dev, B, Tn, d, dtype):
+    """lina_softmax_pe_rows (softmax + att . pe in one launch) vs fp64 torch on the same fp32 scores -- the reference's
+    first cross-attention half after the scores (crossatt.py:117-127: softmax in the model dtype, then the bmm with pe)."""
+    g = torch.Generator().manual_seed(41)
+    scores = (torch.randn(B, Tn, generator=g) * 2).to(dev)
+    pe = torch.randn(Tn + 3, d, generator=g).to(dtype).to(dev)            # more rows than Tn: only the first Tn count
+    att = torch.zeros(B, 2, 1, Tn, dtype=dtype, device=dev)
+    xp = torch.full((B, d), float("nan"), dtype=dtype, device=dev)
+    kq = 32 if dtype == torch.bfloat16 else 16
+    xp_p = torch.zeros(ops.packed_numel(B, d), dtype=dtype, device=dev) if d % kq == 0 else None
+    ops.softmax_pe_rows(scores, att[:, 0, 0], pe, xp, xp_p)
+    a64 = torch.softmax(scores.cpu().to(F64), -1)
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    assert_close(att[:, 0, 0], a64, tol, "softmax_pe_rows att")
+    assert float(att[:, 1].abs().max()) == 0.0
+    a_model = att[:, 0, 0].cpu().to(F64)                                    # the bmm sees the model-dtype weights
+    assert_close(xp, a_model @ pe[:Tn].cpu().to(F64), tol, "softmax_pe_rows xp")
+    if xp_p is not None:
+        assert torch.equal(ops.unpack_rows(xp_p, B, d), xp), "packed copy of xp differs"
 
 
 def check_dwconv7_ln(dev, B, L, C, dtype, ada=False):

@@ -193,6 +193,24 @@ def test_greedy_pick_embed(emu, Q, L, d, dtype):
     check_greedy_pick_embed(DEV, B=5, Q=Q, L=L, d=d, dtype=dtype)
 
 
+@pytest.mark.parametrize("N,D,xd,rd,yd", [(9, 64, torch.float32, None, torch.float32),
+                                           (13, 320, torch.float32, torch.float32, torch.float32),
+                                           (7, 256, torch.float32, torch.bfloat16, torch.bfloat16),
+                                           (5, 1024, torch.float32, torch.float32, torch.bfloat16),
+                                           (6, 128, torch.bfloat16, torch.bfloat16, torch.bfloat16),
+                                           (4, 2048, torch.float32, None, torch.bfloat16)])
+def test_layer_norm(emu, N, D, xd, rd, yd):
+    from kernel_cases import check_layer_norm
+    check_layer_norm(DEV, N, D, xd, rd, yd)
+
+
+@pytest.mark.parametrize("N,H,dtype", [(5, 64, torch.float32), (7, 85, torch.float32), (3, 85, torch.bfloat16),
+                                       (9, 128, torch.bfloat16)])
+def test_swiglu_gate(emu, N, H, dtype):
+    from kernel_cases import check_swiglu_gate
+    check_swiglu_gate(DEV, N, H, dtype)
+
+
 @pytest.mark.parametrize("nw", [8, 16])
 def test_projections_wider_split_k(emu, monkeypatch, nw):
     """The packed projection kernels with 8 / 16 waves per workgroup (K = 1024: 32 k-steps): same products, another
@@ -243,8 +261,9 @@ def test_chunk_segment_parallel_head_groups(emu, H, D, T, nseg):
 
 @pytest.mark.parametrize("B,Tn,d,dtype", [(3, 11, 64, torch.float32), (2, 40, 128, torch.bfloat16)])
 def test_cross_attention_fusions(emu, B, Tn, d, dtype):
-    from kernel_cases import check_cross_fused
+    from kernel_cases import check_cross_fused, check_softmax_pe_rows
     check_cross_fused(DEV, B, Tn, d, dtype)
+    check_softmax_pe_rows(DEV, B, Tn, d, dtype)
 
 
 # ----------------------------------------------------------------------------- K2b on the full-head kernel (three sweeps)

@@ -330,6 +330,22 @@ def test_sample_pick_embed(hip, B, Q, L, d, dtype, ns, k):
     check_sample_pick_embed(DEV, B=B, Q=Q, L=L, d=d, dtype=dtype, n_sampled=ns, k=k, temp=1.0)
 
 
+@pytest.mark.parametrize("N,D,xd,rd,yd", [(32768, 1024, torch.float32, torch.bfloat16, torch.bfloat16),
+                                           (4099, 1024, torch.float32, None, torch.bfloat16),
+                                           (1000, 256, torch.float32, torch.float32, torch.float32),
+                                           (777, 1024, torch.bfloat16, torch.bfloat16, torch.bfloat16),
+                                           (130, 2048, torch.float32, torch.float32, torch.bfloat16)])
+def test_layer_norm(hip, N, D, xd, rd, yd):
+    from kernel_cases import check_layer_norm
+    check_layer_norm(DEV, N, D, xd, rd, yd)
+
+
+@pytest.mark.parametrize("N,H,dtype", [(32768, 1365, torch.bfloat16), (70000, 64, torch.float32), (513, 1365, torch.float32)])
+def test_swiglu_gate(hip, N, H, dtype):
+    from kernel_cases import check_swiglu_gate
+    check_swiglu_gate(DEV, N, H, dtype)
+
+
 # ----------------------------------------------------------------------------- fragment-major (packed) projections
 @pytest.mark.parametrize("M,N,K,dtype,ln,bias,resid,sw", [(64, 1024, 1024, torch.bfloat16, False, False, True, 0),
                                                           (64, 1376, 1024, torch.bfloat16, True, True, False, 1365),
@@ -363,5 +379,6 @@ def test_chunk_segment_parallel_head_groups(hip, H, D, T, nseg):
 
 @pytest.mark.parametrize("B,Tn,d,dtype", [(64, 64, 1024, torch.bfloat16), (5, 100, 256, torch.float32), (64, 20, 1024, torch.float32)])
 def test_cross_attention_fusions(hip, B, Tn, d, dtype):
-    from kernel_cases import check_cross_fused
+    from kernel_cases import check_cross_fused, check_softmax_pe_rows
     check_cross_fused(DEV, B, Tn, d, dtype)
+    check_softmax_pe_rows(DEV, B, Tn, d, dtype)

@@ -45,7 +45,19 @@ def report(name, a):
 buf = np.zeros(1024 * 8, dtype=np.uint64)
 rc = lib.lina_inproj_prof_read(buf.ctypes.data_as(ctypes.c_void_p))
 report("in-projection (last launch)", buf.reshape(1024, 8))
+a_ = buf.reshape(1024, 8)[:160].astype(np.float64)                  # 160 workgroups at L169: q | k | v | g | gate, 32 each
+if a_[:, 1].min() > 0:
+    w0 = a_[:, 0].min()
+    for nm, lo in (("q tiles", 0), ("k tiles", 32), ("v tiles", 64), ("g tiles", 96), ("gate tiles", 128)):
+        e_ = (a_[lo:lo + 32, 6] - w0) / 100.0
+        b_ = (a_[lo:lo + 32, 4] - a_[lo:lo + 32, 1])
+        print(f"   {nm:10s}: end after the first start min/med/max {e_.min():5.2f}/{np.median(e_):5.2f}/{e_.max():5.2f} us")
 buf = np.zeros(4 * 1024 * 8, dtype=np.uint64)
 rc = lib.lina_skinny_prof_read(buf.ctypes.data_as(ctypes.c_void_p))
 for kind, nm in enumerate(("LN-2 + up + SwiGLU", "o-projection (K=1024, residual)", "down (residual)", "other (head / cross)")):
     report(nm, buf.reshape(4, 1024, 8)[kind])
+if hasattr(lib, "lina_cross_prof_read"):
+    buf = np.zeros(1024 * 8, dtype=np.uint64)
+    lib.lina_cross_prof_read(buf.ctypes.data_as(ctypes.c_void_p))
+    print("(cross_scores slots: 2 = query + LayerNorm parameters arrived, 3 = LayerNorm done, 4 = dot products done)")
+    report("cross_scores", buf.reshape(1024, 8))
