@@ -55,8 +55,12 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
     const int li = lane & 15, lg = lane >> 4;
     const int m0 = blockIdx.y * 64;
     const int n_direct = 2 * Kd + 2 * Vd;               // q | k | v | g columns; low-rank rows follow in W
-    const int tile0 = blockIdx.x * (16 * NT);           // first output column of this workgroup
-    const bool gate_wg = tile0 >= n_direct;             // block-uniform: NT tiles of gate channels, ONE lr tile
+    // q | k | v | g workgroups take 16 NT columns; a GATE workgroup takes 16 gate channels (one low-rank tile to multiply, but
+    // the heaviest epilogue -- 16 FMAs + a log-sigmoid per element: with 32 channels the gate workgroups finished ~1.5 us
+    // after everybody else, time stamps of tools/probe_skinny_prof.py; there are idle CUs for the extra workgroups)
+    const int nb_direct = n_direct / (16 * NT);
+    const bool gate_wg = (int)blockIdx.x >= nb_direct;  // block-uniform
+    const int tile0 = gate_wg ? n_direct + ((int)blockIdx.x - nb_direct) * 16 : (int)blockIdx.x * (16 * NT);
 
     f32x4 acc[NT * MT], st1[MT], st2[MT];
 #pragma unroll
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
             if (gate_wg) {
                 // gate tiles: the rank-16 up-projection row of this lane's channel (16 contiguous elements) and its bias are
                 // epilogue operands too -- they travel in the registers the q/k/v tiles use for the conv cache
-                if (tn0 - n_direct < Kd) {                      // (Kd % 16 == 0: the whole tile is inside)
+                if (j == 0 && tn0 - n_direct < Kd) {            // (Kd % 16 == 0: the whole tile is inside)
                     const int c = (tn0 - n_direct) + li;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pre_old[j][r] = ld4_raw(w2 + (int64_t)c * R + 4 * r);
@@ -237,8 +241,8 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
         for (int r = 0; r < 4; ++r) s_lr[16 * w + 4 * lg + r][li] = rstd[r] * (val[0][r] - mu[r] * cc1) + cc2;
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int c = (tile0 - n_direct) + 16 * j + li;          // gate channel
+        for (int j = 0; j < 1; ++j) {                              // (one 16-channel tile per gate workgroup)
+            const int c = (tile0 - n_direct) + li;                   // gate channel
             if (c >= Kd) continue;
             const float4 q0 = cvt4(pre_old[j][0]), q1 = cvt4(pre_old[j][1]), q2 = cvt4(pre_old[j][2]), q3 = cvt4(pre_old[j][3]);
             const float w2r[R] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
@@ -320,7 +324,7 @@ static int inproj_impl(const void* x, int64_t ldx, const void* w_in, int64_t ldw
     static const bool narrow = getenv("LINA_INPROJ_NARROW") != nullptr;      // tuning knob (tools/probe_decode.py)
     const bool wide = Kd % 32 == 0 && Vd % 32 == 0 && !narrow;
     const int cols = wide ? 32 : 16;
-    dim3 grid((unsigned)((2 * Kd + 2 * Vd + Kd) / cols), (unsigned)((B + 63) / 64));
+    dim3 grid((unsigned)((2 * Kd + 2 * Vd) / cols + Kd / 16), (unsigned)((B + 63) / 64));
     // waves per workgroup (split-K width) of the packed kernel, see linear_skinny.hip; LINA_SKINNY_WAVES overrides
     // Measured in the L169 decode step (tests/gpu_r03e.sh, ms per token): 4 waves 0.660, 8 waves 0.624, 16 waves on the plain
     // 16-column projections + 8 elsewhere 0.617.

@@ -25,6 +25,23 @@ template <typename T> struct VecIO<4, T> {
     static __device__ __forceinline__ void store(T* p, const float (&v)[4]) { st4(p, make_float4(v[0], v[1], v[2], v[3])); }
 };
 
+// RAW loads (bits only, converted where they are used): a block of time steps is requested in one go -- a load that is
+// converted (or sits under a per-step branch) where it is issued is waited for on the spot, one memory round trip per step.
+template <int VEC, typename T> struct RawIO;
+template <typename T> struct RawIO<1, T> {
+    typedef T type;
+    static __device__ __forceinline__ type load(const T* p) { return ld_raw(p); }
+    static __device__ __forceinline__ void cvt(type r, float (&v)[1]) { v[0] = cvt1(r); }
+};
+template <typename T> struct RawIO<4, T> {
+    typedef typename raw4<T>::type type;
+    static __device__ __forceinline__ type load(const T* p) { return ld4_raw(p); }
+    static __device__ __forceinline__ void cvt(type r, float (&v)[4]) {
+        const float4 f = cvt4(r);
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    }
+};
+
 template <int W, typename T, int VEC>
 __global__ __launch_bounds__(256) void short_conv_fwd_kernel(
     const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias, const float* __restrict__ mask,
@@ -55,10 +72,21 @@ __global__ __launch_bounds__(256) void short_conv_fwd_kernel(
         for (int i = 0; i < VEC; ++i) win[j + 1][i] = v[i] * m;
     }
     const int t1 = min(t0 + kConvTT, Tn);
-    for (int t = t0; t < t1; ++t) {
+    typename RawIO<VEC, T>::type xr[kConvTT];               // all of this thread's steps in flight (rows past the end: row Tn-1)
+    float mr[kConvTT];
+#pragma unroll
+    for (int k = 0; k < kConvTT; ++k) {
+        const int tc = min(t0 + k, Tn - 1);
+        xr[k] = RawIO<VEC, T>::load(xb + tc * x_st);
+        mr[k] = mb ? mb[tc] : 1.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < kConvTT; ++k) {
+        const int t = t0 + k;
+        if (t >= t1) break;
         float v[VEC], o[VEC];
-        VecIO<VEC, T>::load(xb + t * x_st, v);
-        const float m = mb ? mb[t] : 1.0f;
+        RawIO<VEC, T>::cvt(xr[k], v);
+        const float m = mr[k];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
 #pragma unroll
@@ -220,15 +248,29 @@ __global__ __launch_bounds__(256) void short_conv_bwd_kernel(
         for (int i = 0; i < VEC; ++i) win[j + 1][i] = v[i] * m;
     }
     const int t1 = min(t0 + kConvBwdTT, Tn);
-    for (int u = t0; u < t1 + W - 1; ++u) {
+    constexpr int KB = 8;                                    // steps requested per block (x and dy: 2 KB loads in flight)
+    for (int u0 = t0; u0 < t1 + W - 1; u0 += KB) {
+    typename RawIO<VEC, T>::type xr[KB], dr[KB];
+    float mr[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        const int uc = min(u0 + k, Tn - 1);
+        xr[k] = RawIO<VEC, T>::load(xb + uc * x_st);
+        dr[k] = RawIO<VEC, T>::load(dyb + uc * dy_st);
+        mr[k] = mb ? mb[uc] : 1.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        const int u = u0 + k;
+        if (u >= t1 + W - 1) break;
         float dz[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) dz[i] = 0.0f;
         if (u < Tn) {
             float xv[VEC], dv[VEC];
-            VecIO<VEC, T>::load(xb + u * x_st, xv);
-            VecIO<VEC, T>::load(dyb + u * dy_st, dv);
-            const float m = mb ? mb[u] : 1.0f;
+            RawIO<VEC, T>::cvt(xr[k], xv);
+            RawIO<VEC, T>::cvt(dr[k], dv);
+            const float m = mr[k];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
 #pragma unroll
@@ -263,6 +305,7 @@ __global__ __launch_bounds__(256) void short_conv_bwd_kernel(
             a[i] = acc * ((mb && t >= 0) ? mb[t] : 1.0f);
         }
         if (t >= t0) VecIO<VEC, T>::store(dx + b * dx_sb + t * dx_st + c, a);
+    }
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {

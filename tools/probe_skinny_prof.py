@@ -45,12 +45,11 @@ def report(name, a):
 buf = np.zeros(1024 * 8, dtype=np.uint64)
 rc = lib.lina_inproj_prof_read(buf.ctypes.data_as(ctypes.c_void_p))
 report("in-projection (last launch)", buf.reshape(1024, 8))
-a_ = buf.reshape(1024, 8)[:160].astype(np.float64)                  # 160 workgroups at L169: q | k | v | g | gate, 32 each
+a_ = buf.reshape(1024, 8)[:192].astype(np.float64)                  # L169: q | k | v | g (32 workgroups each) | gate (64)
 if a_[:, 1].min() > 0:
     w0 = a_[:, 0].min()
-    for nm, lo in (("q tiles", 0), ("k tiles", 32), ("v tiles", 64), ("g tiles", 96), ("gate tiles", 128)):
-        e_ = (a_[lo:lo + 32, 6] - w0) / 100.0
-        b_ = (a_[lo:lo + 32, 4] - a_[lo:lo + 32, 1])
+    for nm, lo, cnt in (("q tiles", 0, 32), ("k tiles", 32, 32), ("v tiles", 64, 32), ("g tiles", 96, 32), ("gate tiles", 128, 64)):
+        e_ = (a_[lo:lo + cnt, 6] - w0) / 100.0
         print(f"   {nm:10s}: end after the first start min/med/max {e_.min():5.2f}/{np.median(e_):5.2f}/{e_.max():5.2f} us")
 buf = np.zeros(4 * 1024 * 8, dtype=np.uint64)
 rc = lib.lina_skinny_prof_read(buf.ctypes.data_as(ctypes.c_void_p))
