@@ -42,6 +42,8 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
 #endif
     constexpr int R = 16, MT = 4;
     constexpr int U = NW > 8 ? 2 : (NW > 4 || (NT + MT) * 8 > 48) ? 4 : 8;   // NW: split-K width, see linear_skinny.hip
+    constexpr int RS = NW >= 4 * MT ? 4 : NW >= 2 * MT ? 2 : 1;              // finalising waves per m-tile (row split), see there
+    constexpr int RPW = 4 / RS;
     __shared__ __attribute__((aligned(16))) float s_acc[NW][NT * MT][64][4];
     __shared__ float s_st[NW][64][2];
     __shared__ float s_fin[NW > 4 ? 64 : 1][2];           // NW > 4: the rows' LayerNorm sums, added up once (linear_skinny.hip)
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
             pre_b2[j] = T();
 #pragma unroll
             for (int r = 0; r < 4; ++r) pre_old[j][r] = raw_t();
-            if (w >= MT) continue;                              // waves beyond the first four only feed the split-K sum
+            if (w >= MT * RS) continue;                         // the other waves only feed the split-K sum
             const int tn0 = tile0 + 16 * j;                     // first column of this tile: workgroup-uniform
             if (gate_wg) {
                 // gate tiles: the rank-16 up-projection row of this lane's channel (16 contiguous elements) and its bias are
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
                 else { c = tn0 - 2 * Kd + li; D = Vd; wsel = wv; csel = cv; }
                 pre_wj[j] = ld4_raw(wsel + (int64_t)c * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + 16 * w + 4 * lg + r;
+                for (int r = 0; r < RPW; ++r) {                  // this wave's rows of m-tile w / RS
+                    const int m = m0 + 16 * (w / RS) + 4 * lg + (w % RS) * RPW + r;
                     pre_old[j][r] = ld4_raw(csel + ((int64_t)(m < M ? m : 0) * D + c) * 4);
                 }
             }
@@ -204,26 +206,28 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
         __syncthreads();
     }
     IP_PROF(4, clock64());
-    if (w >= MT) {                                          // NW > 4: the extra waves have delivered their partial sums
+    if (w >= MT * RS) {                                     // the extra waves have delivered their partial sums
         if (gate_wg) __syncthreads();                       // (the gate tiles' low-rank exchange below has one more barrier)
         return;
     }
 
-    // wave w finalises m-tile w (rows m0 + 16w + 4lg + r, column li of each tile)
-    float val[NT][4], mu[4], rstd[4];
+    // wave w finalises rows [rq RPW, rq RPW + RPW) of every lane's four rows of m-tile mtf (rows m0 + 16 mtf + 4 lg + r,
+    // column li of each tile): the same sums in the same order as one wave per m-tile
+    const int mtf = w / RS, rq = w % RS;
+    float val[NT][RPW], mu[RPW], rstd[RPW];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        float4 t = *reinterpret_cast<const float4*>(&s_acc[0][j * MT + w][lane][0]);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) val[j][r] = s_acc[0][j * MT + mtf][lane][rq * RPW + r];
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww) {
-            const float4 u = *reinterpret_cast<const float4*>(&s_acc[ww][j * MT + w][lane][0]);
-            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) val[j][r] += s_acc[ww][j * MT + mtf][lane][rq * RPW + r];
         }
-        val[j][0] = t.x; val[j][1] = t.y; val[j][2] = t.z; val[j][3] = t.w;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 16 * w + 4 * lg + r;
+    for (int r = 0; r < RPW; ++r) {
+        const int row = 16 * mtf + 4 * lg + rq * RPW + r;
         float a, b;
         if (NW > 4) { a = s_fin[row][0]; b = s_fin[row][1]; }
         else {
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
     if (gate_wg) {
         const float cc1 = pre_c1[0], cc2 = pre_c2[0];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_lr[16 * w + 4 * lg + r][li] = rstd[r] * (val[0][r] - mu[r] * cc1) + cc2;
+        for (int r = 0; r < RPW; ++r) s_lr[16 * mtf + 4 * lg + rq * RPW + r][li] = rstd[r] * (val[0][r] - mu[r] * cc1) + cc2;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 1; ++j) {                              // (one 16-channel tile per gate workgroup)
@@ -248,8 +252,8 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
             const float w2r[R] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
             const float bias = cvt1(pre_b2[j]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * w + 4 * lg + r, m = m0 + row;
+            for (int r = 0; r < RPW; ++r) {
+                const int row = 16 * mtf + 4 * lg + rq * RPW + r, m = m0 + row;
                 float accg = bias;
 #pragma unroll
                 for (int jj = 0; jj < R; ++jj) accg = fmaf(s_lr[row][jj], w2r[jj], accg);
@@ -265,14 +269,14 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
     for (int j = 0; j < NT; ++j) {
         const int n = tile0 + 16 * j + li;
         const float cc1 = pre_c1[j], cc2 = pre_c2[j];
-        float z[4];
+        float z[RPW];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z[r] = rstd[r] * (val[j][r] - mu[r] * cc1) + cc2;   // projected value z[m, n]
+        for (int r = 0; r < RPW; ++r) z[r] = rstd[r] * (val[j][r] - mu[r] * cc1) + cc2;   // projected value z[m, n]
         if (n >= 2 * Kd + Vd) {                              // g columns
             const int c = n - (2 * Kd + Vd);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 16 * w + 4 * lg + r;
+            for (int r = 0; r < RPW; ++r) {
+                const int m = m0 + 16 * mtf + 4 * lg + rq * RPW + r;
                 if (m < M) st(g_out + (int64_t)m * Vd + c, z[r]);
             }
             continue;
@@ -284,8 +288,8 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
         else { c = n - 2 * Kd; D = Vd; csel = cv; }
         const float4 wj = cvt4(pre_wj[j]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + 16 * w + 4 * lg + r;
+        for (int r = 0; r < RPW; ++r) {
+            const int m = m0 + 16 * mtf + 4 * lg + rq * RPW + r;
             if (m < M) {
                 T* cb = csel + ((int64_t)m * D + c) * 4;
                 const float4 old = cvt4(pre_old[j][r]);

@@ -74,6 +74,11 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
     // (16-wave workgroups have 128 registers per lane: there the two statistics are per-lane dot products of the lane's own
     // fragment elements -- 2 registers per m-tile instead of 8 -- summed over the four lane groups of a row at the end)
     constexpr bool VST = LN && NW == 16;
+    // Finalisation: MT * RS waves, each takes 4 / RS of a lane's four output rows of one m-tile.  With one wave per m-tile
+    // the epilogue of the 16-wave kernels was a single wave adding 16 partial tiles and storing four rows with every
+    // latency exposed (0.4 + 0.6 us of the o-projection's 3.0 us, 0.8 + 0.9 us of the up-projection's 5.4: time stamps).
+    constexpr int RS = NW >= 4 * MT ? 4 : NW >= 2 * MT ? 2 : 1;
+    constexpr int RPW = 4 / RS;
     f32x4 st1[MT], st2[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) { st1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; st2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -136,12 +141,12 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) pre_res[j][r] = T();
-        if (resid) {
+        if (resid && w < MT * RS) {                          // (only the finalising waves; w is wave-uniform)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + 16 * (w < MT ? w : 0) + 4 * lg + r, n = n0 + 16 * j + li;
+                for (int r = 0; r < RPW; ++r) {
+                    const int m = m0 + 16 * (w / RS) + 4 * lg + (w % RS) * RPW + r, n = n0 + 16 * j + li;
                     const int mc = m < M ? m : M - 1, nc = n < N ? n : N - 1;
                     // resid == outp: the residual stream lives ONLY in the packed buffer (read-modify-write by the same thread)
                     pre_res[j][r] = ld_raw(resid == outp ? resid + packed_off<T>(mc, nc, Kp) : resid + (int64_t)mc * ldr + nc);
@@ -255,23 +260,29 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
         __syncthreads();
     }
     SK_PROF(4, clock64());
-    if (w >= MT) return;
+    if (w >= MT * RS) return;
 
-    // wave w finalises m-tile w of every group: D layout -> rows m0 + 16w + 4*lg + r, column li of the tile
-    float val[G][4];
+    // wave w finalises rows [rq RPW, rq RPW + RPW) of every lane's four rows of m-tile mtf, for every group:
+    // D layout -> rows m0 + 16 mtf + 4 lg + r, column li of the tile.  Same sums in the same order as with RS = 1.
+    const int mtf = w / RS, rq = w % RS;
+    float val[G][RPW];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        float4 t = *reinterpret_cast<const float4*>(&s_acc[0][g * MT + w][lane][0]);
-#pragma unroll 4                          // (all NW reads in flight at once would cost 4 NW registers per group)
-        for (int ww = 1; ww < NW; ++ww) {
-            const float4 u = *reinterpret_cast<const float4*>(&s_acc[ww][g * MT + w][lane][0]);
-            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-        }
-        val[g][0] = t.x; val[g][1] = t.y; val[g][2] = t.z; val[g][3] = t.w;
-    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 16 * w + 4 * lg + r;
+        for (int r = 0; r < RPW; ++r) val[g][r] = s_acc[0][g * MT + mtf][lane][rq * RPW + r];
+#pragma unroll 4                          // (all NW reads in flight at once would cost RPW NW registers per group)
+        for (int ww = 1; ww < NW; ++ww) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) val[g][r] += s_acc[ww][g * MT + mtf][lane][rq * RPW + r];
+        }
+    }
+#ifdef LINA_SKINNY_PROF
+    if (val[0][0] == 1.2345e30f) s_fin[0][0] = 1.0f;             // (consume the sums before the stamp)
+    SK_PROF(7, clock64());
+#endif
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = 16 * mtf + 4 * lg + rq * RPW + r;
         const int m = m0 + row;
         float mu = 0.f, rstd = 1.f;
         if (LN) {

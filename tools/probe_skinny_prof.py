@@ -40,6 +40,8 @@ def report(name, a):
     print(f"   entry -> first load round consumed: {q(rel(2))}   -> main loop done: {q(rel(3))}   -> reduction barrier: {q(rel(4))}"
           f"   -> end: {q(rel(5))}")
     print(f"   end (wall) after the first start: {q((a[:, 6] - wall0) / 100.0)}")
+    if a[:, 7].max() > 0:
+        print(f"   entry -> partial sums added (slot 7): {q(rel(7))}")
 
 
 buf = np.zeros(1024 * 8, dtype=np.uint64)
