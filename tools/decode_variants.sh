@@ -16,8 +16,3 @@ git show d856931:lina-speech_amd/csrc/gla_inproj.hip > tools/abl/inproj_r02.hip
 /opt/rocm/bin/hipcc $FL -c tools/abl/inproj_r02.hip -o tools/abl/inproj_r02.o || exit 1
 link gla_inproj tools/abl/inproj_r02.o tools/abl/liblina_inproj_r02.so
 ls -la tools/abl/liblina_k1w_*.so tools/abl/liblina_inproj_r02.so
-#   tools/abl/liblina_preafter.so    projections with the epilogue operands requested BEHIND the first fragment round
-/opt/rocm/bin/hipcc $FL -DLINA_SKINNY_PRE_AFTER=1 -c $CS/linear_skinny.hip -o tools/abl/ls_preafter.o || exit 1
-/opt/rocm/bin/hipcc $FL -DLINA_SKINNY_PRE_AFTER=1 -c $CS/gla_inproj.hip -o tools/abl/ip_preafter.o || exit 1
-g++ -shared -fPIC $(ls $CS/*.o | grep -v "linear_skinny.o\|gla_inproj.o") tools/abl/ls_preafter.o tools/abl/ip_preafter.o -o tools/abl/liblina_preafter.so
-ls -la tools/abl/liblina_preafter.so
