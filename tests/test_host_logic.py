@@ -143,3 +143,37 @@ def test_build_refuses_a_kernel_that_spills_where_the_dma_wait_counts_operations
     bad = ok.replace("ScratchSize [bytes/lane]: 0", "ScratchSize [bytes/lane]: 20")
     with pytest.raises(RuntimeError, match="k1 spills"):
         build._check_no_scratch("a.hip", bad)
+
+
+def test_isa_audit_flags_an_mfma_under_an_unskipped_exec_mask():
+    """tools/isa_mfma_exec.py (the audit behind the round-3 finding: an MFMA issued under EXEC = 0 still executes on
+    unwritten operand registers): the scanner must flag an MFMA inside an s_and_saveexec region without s_cbranch_execz,
+    accept the skipped form and a scalar branch, and follow masks restored out of order."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "isa_mfma_exec", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "isa_mfma_exec.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = """_Z3badv:
+        s_and_saveexec_b64 s[4:5], vcc
+        v_mov_b32_e32 v18, v61
+        v_mfma_f32_16x16x32_bf16 v[2:5], v[18:21], v[6:9], v[2:5]
+        s_or_b64 exec, exec, s[4:5]
+        s_endpgm""".splitlines()
+    assert mod.scan(bad) == {"_Z3badv": 1}
+    good = """_Z4goodv:
+        s_and_saveexec_b64 s[4:5], vcc
+        s_cbranch_execz .LBB0_2
+        v_mfma_f32_16x16x32_bf16 v[2:5], v[18:21], v[6:9], v[2:5]
+    .LBB0_2:
+        s_or_b64 exec, exec, s[4:5]
+        s_cbranch_scc1 .LBB0_4
+        v_mfma_f32_16x16x32_bf16 v[2:5], v[18:21], v[6:9], v[2:5]
+    .LBB0_4:
+        s_and_saveexec_b64 s[4:5], vcc
+        s_and_saveexec_b64 s[6:7], vcc
+        s_or_b64 exec, exec, s[4:5]
+        v_mfma_f32_16x16x32_bf16 v[2:5], v[18:21], v[6:9], v[2:5]
+        s_endpgm""".splitlines()
+    assert mod.scan(good) == {}
