@@ -628,9 +628,9 @@ def main():
         k_run = max(args.steps, int(args.min_timed_s / est) + 1) if args.min_timed_s > 0 else args.steps
         k_sus = max(args.steps, int(SUSTAINED_S / est) + 1)
         if dist is not None:
-            kk = torch.tensor([k_run], device=dev, dtype=torch.int64)
+            kk = torch.tensor([k_run, k_sus], device=dev, dtype=torch.int64)   # every rank sizes its token log for the same counts
             dist.all_reduce(kk, op=dist.ReduceOp.MAX)
-            k_run = int(kk.item())
+            k_run, k_sus = int(kk[0].item()), int(kk[1].item())
         eng.begin_greedy(k_run + k_sus + args.warmup + 8)
         eng.greedy_steps(8)                                           # captures the multi-token graph (untimed)
         for _ in range(args.warmup):
