@@ -175,14 +175,18 @@ int lina_rmsnorm_gate_fwd(const void* x, const void* g, const void* w, void* y,
                           int n_partial, int64_t x_part_stride,
                           float eps, int x_dtype, int dtype, lina_stream_t stream);
 
-/* K5b -- backward of K5 over contiguous rows [rows][D], all tensors of `dtype` (training path).
+/* K5b -- backward of K5 over contiguous rows x, dy, dx [rows][D], all tensors of `dtype` (training path).
  * Replaces the autograd backward of FusedRMSNormSwishGate / RMSNorm (reference model/gla.py:219,222).
  *   g, dg: both given (swish gate) or both NULL; w may be NULL;
+ *   row r of g / dg sits at (r / rows_inner) * outer + (r % rows_inner) * inner elements (strides multiples of 4): the
+ *   gate is read from, and its gradient written into, head slices of wider rows in place (the stacked projection's
+ *   output and the gradient slab of that projection);
  *   dw_partial: fp32 [lina_rmsnorm_gate_bwd_partials(rows)][D], summed over dim 0 by the caller. */
 #define LINA_NORM_BWD_MAX_WG 512
 int lina_rmsnorm_gate_bwd_partials(int64_t rows);
 int lina_rmsnorm_gate_bwd(const void* x, const void* g, const void* w, const void* dy, void* dx, void* dg,
-                          float* dw_partial, int64_t rows, int D, float eps, int dtype, lina_stream_t stream);
+                          float* dw_partial, int64_t rows, int rows_inner, int D, int64_t g_outer, int64_t g_inner,
+                          int64_t dg_outer, int64_t dg_inner, float eps, int dtype, lina_stream_t stream);
 
 /* K6a -- codec-token embedding gather-sum: out[n,:] = sum_q table[q, idx[q,n], :].
  * Replaces MultiEmbedding.forward + reduce('q b n d -> b n d','sum')
@@ -255,6 +259,12 @@ int lina_swiglu(const void* u, void* y, int64_t rows, int Hd, int64_t ld_u, int6
  * Replaces autograd through `F.silu(a) * b` (reference model/base_blocks.py:48-50) in the training step. */
 int lina_swiglu_bwd(const void* ds, const void* u, void* du, int64_t rows, int Hd, int64_t ld_u, int64_t ld_ds,
                     int64_t ld_du, int dtype, lina_stream_t stream);
+
+/* K12 -- the mixer's gate for a whole sequence (reference model/gla.py:174-180): out = logsigmoid(x) / normalizer, clamped
+ * from below when clamp_min is not NaN (dy == NULL); with dy: out = dy (1 - sigmoid(x)) / normalizer, 0 where the clamp is
+ * active -- the gradient w.r.t. x.  n elements (multiple of 4), contiguous. */
+int lina_gate_logsigmoid(const void* x, const void* dy, void* out, int64_t n, float normalizer, float clamp_min, int dtype,
+                         lina_stream_t stream);
 
 /* K10 -- LayerNorm over the last dimension with the residual add that precedes it in a pre-norm block
  * (reference model/base_blocks.py:65-69: `x = tmix(norm1(x)) + x; x = cmix(norm2(x)) + x`), for the TRAINING step:

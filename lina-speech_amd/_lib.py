@@ -41,7 +41,7 @@ PROTOTYPES = {
     "lina_short_conv_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64,
                                       _i, _i, _p]),
     "lina_rmsnorm_gate_bwd_partials": (C.c_int, [_i64]),
-    "lina_rmsnorm_gate_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _i, _p]),
+    "lina_rmsnorm_gate_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _i, _p]),
     "lina_rmsnorm_gate_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i64,
                                         _f, _i, _i, _p]),
     "lina_embed_sum": (C.c_int, [_p, _p, _p, _i, _i64, _i, _i, _i, _p]),
@@ -56,6 +56,7 @@ PROTOTYPES = {
                                            _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "lina_swiglu": (C.c_int, [_p, _p, _i64, _i, _i64, _i64, _i, _p]),
     "lina_swiglu_bwd": (C.c_int, [_p, _p, _p, _i64, _i, _i64, _i64, _i64, _i, _p]),
+    "lina_gate_logsigmoid": (C.c_int, [_p, _p, _p, _i64, _f, _f, _i, _p]),
     "lina_layernorm_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _i, _i, _i, _p]),
     "lina_layernorm_bwd_partials": (C.c_int, [_i64]),
     "lina_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p]),

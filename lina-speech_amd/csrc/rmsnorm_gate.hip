@@ -142,8 +142,10 @@ constexpr int kNormBwdMaxWG = LINA_NORM_BWD_MAX_WG;
 template <typename T, int TR>
 __global__ __launch_bounds__(256) void rmsnorm_gate_bwd_kernel(
     const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ w, const T* __restrict__ dy,
-    T* __restrict__ dx, T* __restrict__ dg, float* __restrict__ dw_partial, int64_t rows, int D, float eps) {
-    // slots (row r, piece p) as in the forward: RG = 8 / TR rows per wave and iteration, every load of the group first
+    T* __restrict__ dx, T* __restrict__ dg, float* __restrict__ dw_partial, int64_t rows, int D, float eps,
+    int rows_inner, int64_t g_outer, int64_t g_inner, int64_t dg_outer, int64_t dg_inner) {
+    // slots (row r, piece p) as in the forward: RG = 8 / TR rows per wave and iteration, every load of the group first.
+    // g / dg row r sits at (r / rows_inner) * outer + (r % rows_inner) * inner: head slices of wider rows, in place
     constexpr int RG = kNormMaxTrips / TR;
     __shared__ float4 s_dw[3][TR * 64];
     const int lane = threadIdx.x & 63, wv = wave_uniform(threadIdx.x >> 6);
@@ -158,19 +160,21 @@ __global__ __launch_bounds__(256) void rmsnorm_gate_bwd_kernel(
         typename raw4<T>::type xr[kNormMaxTrips], dr[kNormMaxTrips], gr[kNormMaxTrips];
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
-            const int64_t off = min(row0 + r, rows - 1) * D;
+            const int64_t rr = min(row0 + r, rows - 1), off = rr * D;
+            const int64_t goff = (rr / rows_inner) * g_outer + (rr % rows_inner) * g_inner;
 #pragma unroll
             for (int p = 0; p < TR; ++p) {
                 const int e = p * 256 + lane * 4, ec = e < D ? e : D - 4;
                 xr[r * TR + p] = ld4_raw(x + off + ec);
                 dr[r * TR + p] = ld4_raw(dy + off + ec);
-                if (g) gr[r * TR + p] = ld4_raw(g + off + ec);
+                if (g) gr[r * TR + p] = ld4_raw(g + goff + ec);
             }
         }
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
             if (row0 + r >= rows) break;                     // wave-uniform
             const int64_t off = (row0 + r) * D;
+            const int64_t dgoff = ((row0 + r) / rows_inner) * dg_outer + ((row0 + r) % rows_inner) * dg_inner;
             float4 xv[TR], dn[TR];
             float ss = 0.0f;
 #pragma unroll
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void rmsnorm_gate_bwd_kernel(
                         sv[c] = gg[c] * sg;
                         dgo[c] = dd[c] * nn[c] * ww[c] * sg * (1.0f + gg[c] * (1.0f - sg));
                     }
-                    if (ok) st4(dg + off + e, make_float4(dgo[0], dgo[1], dgo[2], dgo[3]));
+                    if (ok) st4(dg + dgoff + e, make_float4(dgo[0], dgo[1], dgo[2], dgo[3]));
                 }
                 float dnn[4], dwv[4];
 #pragma unroll
@@ -259,12 +263,17 @@ extern "C" int lina_rmsnorm_gate_bwd_partials(int64_t rows) {
 }
 
 extern "C" int lina_rmsnorm_gate_bwd(const void* x, const void* g, const void* w, const void* dy, void* dx, void* dg,
-                                     float* dw_partial, int64_t rows, int D, float eps, int dtype,
-                                     lina_stream_t stream) {
+                                     float* dw_partial, int64_t rows, int rows_inner, int D, int64_t g_outer, int64_t g_inner,
+                                     int64_t dg_outer, int64_t dg_inner, float eps, int dtype, lina_stream_t stream) {
     using namespace lina;
     LINA_REQUIRE(x && dy && dx && dw_partial, "lina_rmsnorm_gate_bwd: null pointer");
     LINA_REQUIRE(!g == !dg, "lina_rmsnorm_gate_bwd: g and dg must both be given or both be NULL");
     LINA_REQUIRE(rows > 0, "lina_rmsnorm_gate_bwd: rows must be positive");
+    LINA_REQUIRE(rows_inner >= 1 && rows % rows_inner == 0, "lina_rmsnorm_gate_bwd: rows=%lld is not a multiple of rows_inner=%d",
+                 (long long)rows, rows_inner);
+    LINA_REQUIRE(!g || ((g_outer | g_inner | dg_outer | dg_inner) % 4 == 0 && g_outer >= 0 && g_inner >= 0 && dg_outer > 0 &&
+                        (rows_inner == 1 || dg_inner >= D)),
+                 "lina_rmsnorm_gate_bwd: gate strides must be multiples of 4 elements and dg rows must not overlap");
     LINA_REQUIRE(D > 0 && D % 4 == 0 && D <= kNormMaxTrips * 256,
                  "lina_rmsnorm_gate_bwd: D=%d must be a multiple of 4 and <= %d", D, kNormMaxTrips * 256);
     LINA_REQUIRE(valid_dtype(dtype), "lina_rmsnorm_gate_bwd: bad dtype");
@@ -272,7 +281,7 @@ extern "C" int lina_rmsnorm_gate_bwd(const void* x, const void* g, const void* w
     const int tr = D <= 256 ? 1 : D <= 512 ? 2 : D <= 1024 ? 4 : 8;
 #define LINA_RN_B(TT, TRR)                                                                                           \
     LINA_LAUNCH((rmsnorm_gate_bwd_kernel<TT, TRR>), grid, dim3(256), 0, stream, (const TT*)x, (const TT*)g, (const TT*)w, \
-                (const TT*)dy, (TT*)dx, (TT*)dg, dw_partial, rows, D, eps)
+                (const TT*)dy, (TT*)dx, (TT*)dg, dw_partial, rows, D, eps, rows_inner, g_outer, g_inner, dg_outer, dg_inner)
 #define LINA_RN_BT(TT)                                                                                               \
     do {                                                                                                             \
         if (tr == 1) LINA_RN_B(TT, 1); else if (tr == 2) LINA_RN_B(TT, 2); else if (tr == 4) LINA_RN_B(TT, 4);       \

@@ -223,7 +223,56 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ d
     }
 }
 
+// K12 -- the gate of the mixer for a whole sequence (reference model/gla.py:174-180): y = logsigmoid(x) / normalizer
+// (optionally clamped from below), and its gradient dx = dy (1 - sigmoid(x)) / normalizer (0 where the clamp is active).
+// Elementwise over n4 groups of 4 elements; torch's chain (log_sigmoid with its second output, the division, their two
+// backward kernels) moved 4.5x the bytes.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void gate_logsigmoid_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out,
+                                                              int64_t n4, float inv_norm, float clamp_min, int has_clamp) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 a = ld4(x + 4 * i);
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        float o[4];
+        if (BWD) {
+            const float4 d = ld4(dy + 4 * i);
+            const float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool clamped = has_clamp && logsigmoidf(av[c]) * inv_norm < clamp_min;
+                o[c] = clamped ? 0.0f : dv[c] * inv_norm * sigmoidf(-av[c]);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                o[c] = logsigmoidf(av[c]) * inv_norm;
+                if (has_clamp) o[c] = fmaxf(o[c], clamp_min);
+            }
+        }
+        st4(out + 4 * i, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
 }  // namespace lina
+
+extern "C" int lina_gate_logsigmoid(const void* x, const void* dy, void* out, int64_t n, float normalizer, float clamp_min,
+                                    int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(x && out, "lina_gate_logsigmoid: null pointer");
+    LINA_REQUIRE(n > 0 && n % 4 == 0, "lina_gate_logsigmoid: n must be a positive multiple of 4");
+    LINA_REQUIRE(normalizer != 0.0f, "lina_gate_logsigmoid: normalizer must be non-zero");
+    LINA_REQUIRE(valid_dtype(dtype), "lina_gate_logsigmoid: bad dtype %d", dtype);
+    const int has_clamp = (clamp_min == clamp_min) ? 1 : 0;          // NaN = no clamp
+    const int64_t n4 = n / 4, wgs = (n4 + 255) / 256;
+    dim3 grid((unsigned)(wgs < 65536 ? wgs : 65536));
+#define LINA_GL(TT, BB)                                                                                              \
+    LINA_LAUNCH((gate_logsigmoid_kernel<TT, BB>), grid, dim3(256), 0, stream, (const TT*)x, (const TT*)dy, (TT*)out, n4, \
+                1.0f / normalizer, clamp_min, has_clamp)
+    if (dtype == LINA_F32) { if (dy) LINA_GL(float, true); else LINA_GL(float, false); }
+    else { if (dy) LINA_GL(bf16_t, true); else LINA_GL(bf16_t, false); }
+#undef LINA_GL
+    return check_launch("lina_gate_logsigmoid");
+}
 
 extern "C" int lina_layernorm_bwd_partials(int64_t rows) {
     const int64_t wgs = (rows + 3) / 4;

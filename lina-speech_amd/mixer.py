@@ -74,9 +74,8 @@ class GatedLinearAttention(nn.Module):
 
     def _gates(self, hidden_states, reset_mask, reset_val, low_rank=None):
         pre = self.gk_proj(hidden_states) if low_rank is None else self.gk_proj[1](low_rank)
-        gk = F.logsigmoid(self._heads(pre)) / self.gate_logit_normalizer
-        if self.clamp_min is not None:
-            gk = torch.clamp_min(gk, self.clamp_min)
+        # K12: logsigmoid / normalizer (+ clamp) in one pass each way (the head split is a view of the result)
+        gk = self._heads(ops.gate_logsigmoid(pre, self.gate_logit_normalizer, self.clamp_min))
         if reset_mask is not None:
             gk = gk.masked_fill(reset_mask.unsqueeze(1).unsqueeze(3), reset_val)
         return gk
@@ -119,7 +118,7 @@ class GatedLinearAttention(nn.Module):
             # under autocast every one of the five projections below would cast this (fp32 LayerNorm output) tensor
             # to the autocast dtype on its own: do it once (same values, 4 fewer passes over [B,T,d])
             hidden_states = hidden_states.to(torch.get_autocast_dtype("cuda"))
-        g_pre = lr_pre = None                                   # outputs of the fused projection, when it ran
+        g_pre = lr_pre = slab = None                            # outputs of the fused projection, when it ran
         if self.use_short_conv and self.share_conv_kernel:
             conv_states = (last_state[0] if use_cache else None,)
             hidden_states = self.h_conv1d(hidden_states, attention_mask, conv_states[0])
@@ -131,15 +130,17 @@ class GatedLinearAttention(nn.Module):
                 # the outputs are strided views of its result
                 w_cat = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.g_proj.weight,
                                    self.gk_proj[0].weight], dim=0)
-                q, k, v, g_pre, lr_pre = F.linear(hidden_states, w_cat).split(
-                    [self.key_dim, self.key_dim, self.value_dim, self.value_dim, self.gk_proj[0].weight.shape[0]], dim=-1)
+                # (training: the consumers of the slices write their input gradients into ONE slab -- no concat pass)
+                (q, k, v, g_pre, lr_pre), slab = ops.split_slab(F.linear(hidden_states, w_cat), [
+                    self.key_dim, self.key_dim, self.value_dim, self.value_dim, self.gk_proj[0].weight.shape[0]])
             else:
                 q, k, v = self.q_proj(hidden_states), self.k_proj(hidden_states), self.v_proj(hidden_states)
             if self.use_short_conv:
                 conv_states = tuple(last_state[i] if use_cache else None for i in range(3))
-                q = self.q_conv1d(q, attention_mask, conv_states[0])
-                k = self.k_conv1d(k, attention_mask, conv_states[1])
-                v = self.v_conv1d(v, attention_mask, conv_states[2])
+                gs = [None] * 3 if slab is None else [(slab, 0), (slab, 1), (slab, 2)]
+                q = self.q_conv1d(q, attention_mask, conv_states[0], grad_slab=gs[0])
+                k = self.k_conv1d(k, attention_mask, conv_states[1], grad_slab=gs[1])
+                v = self.v_conv1d(v, attention_mask, conv_states[2], grad_slab=gs[2])
         if attention_mask is not None:  # left padding
             v = v * attention_mask.unsqueeze(-1).to(v.dtype)
         q, k, v = self._heads(q), self._heads(k), self._heads(v)
@@ -155,7 +156,8 @@ class GatedLinearAttention(nn.Module):
         o = o.transpose(1, 2)                                   # [B,T,H,Dv] (contiguous by construction)
         g = self.g_proj(hidden_states) if g_pre is None else g_pre
         if self.fuse_norm_and_gate:
-            o = self.g_norm_swish_gate(o, g.view(B, T, H, Dv)).reshape(B, T, H * Dv)
+            o = self.g_norm_swish_gate(o, g.view(B, T, H, Dv),
+                                       grad_slab=None if slab is None else (slab, 3)).reshape(B, T, H * Dv)
         else:
             o = self.g_norm(o).reshape(B, T, H * Dv) * self.gate_fn(g)
         return self.o_proj(o)

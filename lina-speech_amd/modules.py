@@ -44,8 +44,8 @@ class ShortConvolution(nn.Module):
     def state_size(self) -> int:
         return self.hidden_size * self.kernel_size[0]
 
-    def forward(self, x, mask=None, cache=None):
-        return ops.short_conv(x, self.weight, self.bias, mask, cache, self.activation)
+    def forward(self, x, mask=None, cache=None, *, grad_slab=None):
+        return ops.short_conv(x, self.weight, self.bias, mask, cache, self.activation, grad_slab=grad_slab)
 
     def extra_repr(self):
         return f"{self.hidden_size}, kernel_size={self.kernel_size[0]}, activation={self.activation}"
@@ -59,10 +59,10 @@ class FusedRMSNormSwishGate(nn.Module):
         self.hidden_size, self.eps = hidden_size, eps
         self.weight = nn.Parameter(torch.ones(hidden_size)) if elementwise_affine else None
 
-    def forward(self, x, o, residual=None, prenorm=False, residual_in_fp32=False):
+    def forward(self, x, o, residual=None, prenorm=False, residual_in_fp32=False, *, grad_slab=None):
         if residual is not None or prenorm:
             raise NotImplementedError("residual/prenorm form is not used on the Lina path")
-        return ops.rmsnorm_swish_gate(x, o, self.weight, self.eps)
+        return ops.rmsnorm_swish_gate(x, o, self.weight, self.eps, grad_slab=grad_slab)
 
 
 class RMSNorm(nn.Module):

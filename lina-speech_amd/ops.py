@@ -379,13 +379,75 @@ def _short_conv_launch(x, w, bias, mask, cache, act):
     return y
 
 
+class GradSlab:
+    """Backward-time buffer [..., sum(sizes)] for the output gradient of a stacked projection: the consumers of its column
+    slices write their input gradients straight into their columns (``part``), so the projection's backward finds dZ
+    assembled -- torch's split backward concatenated the pieces in one more pass over all of them."""
+
+    def __init__(self, lead_shape, sizes, dtype, device):
+        self.lead_shape, self.sizes, self.dtype, self.device = tuple(lead_shape), list(sizes), dtype, device
+        self.offsets = [sum(self.sizes[:i]) for i in range(len(self.sizes))]
+        self.buf = None
+        self.copied = []                   # slices the last backward had to copy in (not written in place): diagnostics
+
+    def part(self, i):
+        if self.buf is None:
+            self.buf = torch.empty(*self.lead_shape, sum(self.sizes), dtype=self.dtype, device=self.device)
+        return self.buf[..., self.offsets[i]:self.offsets[i] + self.sizes[i]]
+
+    def take(self):
+        buf, self.buf = self.buf, None
+        return buf
+
+
+def _slab_part(grad_slab, like):
+    """The slab columns for a gradient shaped like ``like`` ([..., size] with the slab's leading shape), or None."""
+    slab, i = grad_slab
+    if (like.dtype != slab.dtype or like.device != slab.device or like.shape[-1] != slab.sizes[i]
+            or tuple(like.shape[:-1]) != slab.lead_shape):
+        return None
+    return slab.part(i)
+
+
+class _SplitSlabFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, slab):
+        ctx.slab = slab
+        ctx.set_materialize_grads(False)
+        return tuple(z.split(slab.sizes, dim=-1))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        slab = ctx.slab
+        slab.copied = []
+        for i, g in enumerate(grads):
+            part = slab.part(i)
+            if g is None:
+                part.zero_()
+            elif not (g.data_ptr() == part.data_ptr() and g.shape == part.shape and g.stride() == part.stride()):
+                part.copy_(g)                      # a consumer that did not write in place (or an accumulated gradient)
+                slab.copied.append(i)
+        return slab.take(), None
+
+
+def split_slab(z, sizes):
+    """``z.split(sizes, -1)`` plus the ``GradSlab`` its consumers may write their input gradients into (``grad_slab=(slab,
+    i)`` of ``short_conv`` / ``rmsnorm_swish_gate``); slices whose consumers do not are copied in by the backward.  Without
+    gradients (or off the fused-op devices) this is the plain split and the slab is None."""
+    if not (torch.is_grad_enabled() and z.requires_grad and fused_ops_available(z)):
+        return z.split(list(sizes), dim=-1), None
+    slab = GradSlab(z.shape[:-1], sizes, z.dtype, z.device)
+    return _SplitSlabFunction.apply(z, slab), slab
+
+
 class _ShortConvFunction(torch.autograd.Function):
     """K3 forward + K3b backward (cache-less prefill form, the training path)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, mask, act, cache=None):
+    def forward(ctx, x, w, bias, mask, act, cache=None, grad_slab=None):
         ctx.save_for_backward(x, w, bias, mask)
         ctx.act = act
+        ctx.grad_slab = grad_slab
         # a cache given to the prefill form only RECEIVES the last W inputs (training with an initial state,
         # reference model/gla.py:146-163 with use_cache=True): it does not enter y, so the backward is the same
         return _short_conv_launch(x, w, bias, mask, cache, act)
@@ -397,7 +459,9 @@ class _ShortConvFunction(torch.autograd.Function):
         W = w.shape[1]
         be = _BACKEND
         dy = _inner_contig(dy.to(x.dtype))
-        dx = torch.empty(B, T, D, dtype=x.dtype, device=x.device)
+        dx = _slab_part(ctx.grad_slab, x) if ctx.grad_slab is not None else None
+        if dx is None:
+            dx = torch.empty(B, T, D, dtype=x.dtype, device=x.device)
         nblk = B * ((T + _lib.CONV_BWD_TT - 1) // _lib.CONV_BWD_TT)
         part = torch.empty(nblk, D, W + 1, dtype=torch.float32, device=x.device)
         _check(be.lib.lina_short_conv_bwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(mask), _ptr(dy), _ptr(dx), _ptr(part),
@@ -406,12 +470,14 @@ class _ShortConvFunction(torch.autograd.Function):
         red = part.sum(0)
         dw = red[:, :W].to(w.dtype)
         db = None if bias is None else red[:, W].to(bias.dtype)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional[str] = "silu"):
+def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional[str] = "silu", grad_slab=None):
     """ShortConvolution.forward semantics: x [B,T,D], weight [D,1,W]|[D,W],
-    mask [B,T]|None, cache [B,D,W]|None (mutated in place).  Differentiable when cache is None."""
+    mask [B,T]|None, cache [B,D,W]|None (mutated in place).  Differentiable when cache is None.
+    ``grad_slab``: ``(GradSlab, index)`` when ``x`` is column slice ``index`` of a stacked projection (``split_slab``):
+    the backward then writes dx into the slab in place."""
     B, T, D = x.shape
     w = weight.reshape(D, -1)
     W = w.shape[1]
@@ -435,7 +501,7 @@ def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional
     if _needs_grad(x, w, bias):
         if cache is not None and T == 1:
             raise NotImplementedError("short_conv: gradients are built for the prefill form (T > 1 or no cache) only")
-        y = _ShortConvFunction.apply(x, w, bias, m, act, cache)
+        y = _ShortConvFunction.apply(x, w, bias, m, act, cache, grad_slab)
     else:
         if cache is not None and T == 1:
             m = mask
@@ -447,17 +513,26 @@ def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional
 
 # --------------------------------------------------------------------------- norm (K5)
 class _RMSNormGateFunction(torch.autograd.Function):
-    """K5 forward + K5b backward on contiguous rows [rows, D]."""
+    """K5 forward + K5b backward on contiguous rows x [rows, D]; the gate is [rows, D] or a strided [R, H, D] view (head
+    slices of wider rows, rows = R H) read in place, its gradient written the same way (into a GradSlab if given)."""
 
     @staticmethod
-    def forward(ctx, x, g, w, eps):
+    def _gate_strides(g, D):
+        if g is None or g.dim() == 2:
+            return 1, D, 0
+        return g.shape[1], g.stride(0), g.stride(1)
+
+    @staticmethod
+    def forward(ctx, x, g, w, eps, grad_slab=None):
         be = _BACKEND
         rows, D = x.shape
         y = torch.empty_like(x)
-        _check(be.lib.lina_rmsnorm_gate_fwd(_ptr(x), _ptr(g), _ptr(w), _ptr(y), rows, 1, D, D, 0, D, 0, D, 0, 1, 0,
-                                            eps, _dt(x), _dt(y), be.stream(x)))
+        ri, go, gi = _RMSNormGateFunction._gate_strides(g, D)
+        _check(be.lib.lina_rmsnorm_gate_fwd(_ptr(x), _ptr(g), _ptr(w), _ptr(y), rows, ri, D, D * ri, D if ri > 1 else 0,
+                                            go, gi, D * ri, D if ri > 1 else 0, 1, 0, eps, _dt(x), _dt(y), be.stream(x)))
         ctx.save_for_backward(x, g, w)
         ctx.eps = eps
+        ctx.grad_slab = grad_slab
         return y
 
     @staticmethod
@@ -467,19 +542,43 @@ class _RMSNormGateFunction(torch.autograd.Function):
         rows, D = x.shape
         dy = dy.to(x.dtype).contiguous()
         dx = torch.empty_like(x)
-        dg = None if g is None else torch.empty_like(g)
+        dg = None
+        ri, go, gi = _RMSNormGateFunction._gate_strides(g, D)
+        dgo, dgi = D * ri, (D if ri > 1 else 0)
+        if g is not None:
+            if ctx.grad_slab is not None and g.dim() == 3:
+                slab, i = ctx.grad_slab
+                if g.dtype == slab.dtype and slab.sizes[i] == ri * D and math.prod(slab.lead_shape) == g.shape[0]:
+                    dg = slab.part(i).view(g.shape)              # [lead..., H D] columns of the slab as [R, H, D]
+                    dgo, dgi = dg.stride(0), dg.stride(1)
+            if dg is None:
+                dg = torch.empty(g.shape, dtype=g.dtype, device=g.device)
         npart = int(be.lib.lina_rmsnorm_gate_bwd_partials(rows))
         part = torch.empty(npart, D, dtype=torch.float32, device=x.device)
         _check(be.lib.lina_rmsnorm_gate_bwd(_ptr(x), _ptr(g), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dg), _ptr(part),
-                                            rows, D, ctx.eps, _dt(x), be.stream(x)))
+                                            rows, ri, D, go, gi, dgo, dgi, ctx.eps, _dt(x), be.stream(x)))
         dw = None if w is None else part.sum(0).to(w.dtype)
-        return dx, dg, dw, None
+        return dx, dg, dw, None, None
 
 
-def rmsnorm_swish_gate(x, g=None, weight=None, eps: float = 1e-5, n_partial: int = 1, out_dtype=None, out=None):
+def _gate_rows_view(g, D):
+    """``g`` [..., H, D] as a [R, H, D] VIEW with 4-element-aligned strides (head slices of wider rows), or None."""
+    H = g.shape[-2]
+    if g.stride(-1) != 1 or g.stride(-2) % 4 or g.is_contiguous():
+        return None
+    try:
+        v = g.view(-1, H, D)
+    except RuntimeError:
+        return None
+    return v if v.stride(0) % 4 == 0 else None
+
+
+def rmsnorm_swish_gate(x, g=None, weight=None, eps: float = 1e-5, n_partial: int = 1, out_dtype=None, out=None,
+                       grad_slab=None):
     """FusedRMSNormSwishGate / RMSNorm forward over the last dim.
     ``n_partial`` > 1: ``x`` is [n_partial, ..., D] partial sums (fp32) that are added first.
-    A gate ``g`` that is a strided 3-D view [R, H, D] (head slices of a wider row) is read in place."""
+    A gate ``g`` whose rows are head slices of wider rows ([..., H, D] view of a column slice) is read in place.
+    ``grad_slab``: ``(GradSlab, index)`` when ``g`` is column slice ``index`` of a stacked projection (``split_slab``)."""
     be = _BACKEND
     be.require(x, g, weight)
     if _needs_grad(x, g, weight):
@@ -488,9 +587,13 @@ def rmsnorm_swish_gate(x, g=None, weight=None, eps: float = 1e-5, n_partial: int
         odt = out_dtype or (g.dtype if g is not None else x.dtype)
         D = x.shape[-1]
         x2 = x.to(odt).reshape(-1, D).contiguous()
-        g2 = None if g is None else g.to(odt).reshape(-1, D).contiguous()
+        g2 = None
+        if g is not None:
+            g2 = g.to(odt)
+            g3 = _gate_rows_view(g2, D) if g2.shape == x.shape and g2.dim() >= 3 else None
+            g2 = g3 if g3 is not None else g2.reshape(-1, D).contiguous()
         w2 = None if weight is None else weight.to(odt).contiguous()
-        return _RMSNormGateFunction.apply(x2, g2, w2, float(eps)).view(x.shape)
+        return _RMSNormGateFunction.apply(x2, g2, w2, float(eps), grad_slab).view(x.shape)
     xs = x.contiguous()
     part_stride = xs.stride(0) if n_partial > 1 else 0
     shape = xs.shape[1:] if n_partial > 1 else xs.shape
@@ -631,6 +734,40 @@ def swiglu_gate(u):
     _BACKEND.require(u)
     u2 = u.reshape(-1, u.shape[-1]).contiguous()
     return _SwiGLUFunction.apply(u2, hidden).view(*u.shape[:-1], hidden)
+
+
+class _GateLogSigmoidFunction(torch.autograd.Function):
+    """K12: logsigmoid(x) / normalizer (optionally clamped) and its gradient, one pass each."""
+
+    @staticmethod
+    def forward(ctx, x, normalizer, clamp_min):
+        be = _BACKEND
+        y = torch.empty_like(x)
+        cm = float("nan") if clamp_min is None else float(clamp_min)
+        _check(be.lib.lina_gate_logsigmoid(_ptr(x), None, _ptr(y), x.numel(), float(normalizer), cm, _dt(x), be.stream(x)))
+        ctx.save_for_backward(x)
+        ctx.args = (float(normalizer), cm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        be = _BACKEND
+        dy = dy.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        _check(be.lib.lina_gate_logsigmoid(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), ctx.args[0], ctx.args[1], _dt(x),
+                                           be.stream(x)))
+        return dx, None, None
+
+
+def gate_logsigmoid(x, normalizer: float = 16.0, clamp_min: Optional[float] = None):
+    """``logsigmoid(x) / normalizer`` (clamped from below when ``clamp_min`` is given) -- the mixer's gate (reference
+    model/gla.py:174-180), differentiable, one pass each way; torch fallback off-device / for other dtypes."""
+    if (not fused_ops_available(x) or x.dtype not in (torch.float32, torch.bfloat16) or x.numel() % 4 or x.numel() == 0):
+        g = torch.nn.functional.logsigmoid(x) / normalizer
+        return g if clamp_min is None else torch.clamp_min(g, clamp_min)
+    _BACKEND.require(x)
+    return _GateLogSigmoidFunction.apply(x.contiguous(), float(normalizer), clamp_min).view(x.shape)
 
 
 # --------------------------------------------------------------------------- codec head (K6)

@@ -410,6 +410,44 @@ def check_rmsnorm_bwd(dev, rows, D, dtype, gate=True, affine=True):
         assert_close(mw.grad, rw.grad, tol, "K5b dw")
 
 
+def check_split_slab(dev, B, T, H, D, dtype, in_place=True):
+    """split_slab: the consumers of a stacked projection's column slices (K3b conv backward, K5b norm-gate backward, one
+    plain torch op) against torch autograd over the plain split: same dZ, same outputs; and the slab is REALLY written in
+    place by the two kernels (one torch copy -- the plain consumer's slice -- in the backward, not three)."""
+    g = torch.Generator().manual_seed(29)
+    Kd, W, L = H * D, 4, 16
+    z = torch.randn(B, T, 2 * Kd + L + 4, generator=g)
+    o = torch.randn(B, T, H, D, generator=g) * 2
+    cw = torch.randn(Kd, W, generator=g) * 0.5
+    nw = 1 + 0.1 * torch.randn(D, generator=g)
+    dq = torch.randn(B, T, Kd, generator=g).to(dtype)
+    do = torch.randn(B, T, H, D, generator=g).to(dtype)
+    (mz, mo, mcw, mnw), (rz, ro, rcw, rnw) = _grad_pair(dev, dtype, z, o, cw, nw)
+    sizes = [Kd, L, Kd, 4]
+    (q, lr, gt, rest), slab = ops.split_slab(mz, sizes)
+    assert slab is not None
+    qc = ops.short_conv(q, mcw, None, None, None, "silu", grad_slab=(slab, 0) if in_place else None)
+    on = ops.rmsnorm_swish_gate(mo, gt.view(B, T, H, D), mnw, 1e-5, grad_slab=(slab, 2) if in_place else None)
+    loss = ((qc.float() * dq.to(dev).float()).sum() + (on.float() * do.to(dev).float()).sum()
+            + (lr.float() ** 2).sum() * 0.5)                  # `rest` gets no gradient: its columns must come out zero
+    loss.backward()
+    rq, rlr, rgt, _ = rz.split(sizes, dim=-1)
+    rqc = O.short_conv(rq, rcw, None, None, "silu")
+    ron = O.rmsnorm_swish_gate(ro, rgt.view(B, T, H, D), rnw, 1e-5)
+    ((rqc * dq.float()).sum() + (ron * do.float()).sum() + (rlr ** 2).sum() * 0.5).backward()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert_close(qc, rqc, tol, "slab conv y")
+    assert_close(on, ron, tol, "slab norm y")
+    assert mz.grad.shape == z.shape and mz.grad.is_contiguous()
+    assert_close(mz.grad, rz.grad, tol, "slab dZ")
+    assert torch.count_nonzero(mz.grad[..., -4:]) == 0
+    assert_close(mo.grad, ro.grad, tol, "slab do")
+    assert_close(mcw.grad, rcw.grad, tol, "slab dw conv")
+    assert_close(mnw.grad, rnw.grad, tol, "slab dw norm")
+    assert slab.buf is None                                   # handed over to autograd, not kept alive by the holder
+    assert slab.copied == ([1] if in_place else [0, 1, 2]), slab.copied
+
+
 def check_embed_bwd(dev, Q, B, n, n_emb, d, dtype):
     g = torch.Generator().manual_seed(14)
     table = torch.randn(Q, n_emb, d, generator=g)
@@ -547,6 +585,31 @@ def check_swiglu_gate(dev, N, H, dtype):
     assert_close(y, y64.detach(), 1e-2 if lo else 2e-6, "K11 silu(a) b")
     (y.float() * w.to(dev).float()).sum().backward()
     assert_close(ud.grad, u64.grad, 1.5e-2 if lo else 2e-6, "K11b du")
+
+
+def check_gate_logsigmoid(dev, n, dtype, clamp):
+    """K12: logsigmoid(x) / normalizer (+ clamp) and its gradient against fp64 autograd, over the range the fast
+    log1p / exp forms switch in."""
+    g = torch.Generator().manual_seed(41)
+    x = (torch.randn(n, generator=g) * 6).to(dtype)
+    x[:8] = torch.tensor([-90.0, -20.0, -4.2, -1e-3, 0.0, 4.2, 20.0, 90.0]).to(dtype)
+    w = torch.randn(n, generator=g).to(dtype)
+    x64 = x.to(F64).requires_grad_()
+    y64 = F.logsigmoid(x64) / 16.0
+    if clamp is not None:
+        y64 = torch.clamp_min(y64, clamp)
+    (y64 * w.to(F64)).sum().backward()
+    xd = x.to(dev).requires_grad_()
+    y = ops.gate_logsigmoid(xd, 16.0, clamp)
+    assert y.dtype == dtype and y.shape == x.shape
+    lo = dtype == torch.bfloat16
+    assert_close(y, y64.detach(), 8e-3 if lo else 2e-6, "K12 gate")
+    (y.float() * w.to(dev).float()).sum().backward()
+    gd, g64 = xd.grad.double().cpu(), x64.grad
+    if clamp is not None:                      # elements within rounding of the clamp edge may take either side
+        edge = (F.logsigmoid(x.to(F64)) / 16.0 - clamp).abs() < (2e-2 if lo else 1e-6)
+        gd, g64 = gd[~edge], g64[~edge]
+    assert_close(gd, g64, 8e-3 if lo else 2e-6, "K12 dx")
 
 
 def check_argmax(dev, rows, n, dtype):

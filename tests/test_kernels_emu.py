@@ -307,3 +307,19 @@ def test_chunk_and_its_backward_for_value_column_blocks(emu):
     # expand_v = 2 heads (256 x 512): K2 / K2b run as two 256 x 256 calls on column blocks of v, o and the states
     check_chunk(DEV, B=1, H=1, T=40, Dk=256, Dv=512, dtype=torch.bfloat16, resets=True)
     check_chunk_bwd(DEV, B=1, H=1, T=40, Dk=256, Dv=512, dtype=torch.bfloat16, resets=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("clamp", [None, -0.2])
+@pytest.mark.parametrize("n", [1024, 4100])
+def test_gate_logsigmoid(emu, n, dtype, clamp):
+    from kernel_cases import check_gate_logsigmoid
+    check_gate_logsigmoid(DEV, n, dtype, clamp)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("in_place", [True, False])
+@pytest.mark.parametrize("B,T,H,D", [(2, 70, 2, 64)])
+def test_split_slab(emu, B, T, H, D, dtype, in_place):
+    from kernel_cases import check_split_slab
+    check_split_slab(DEV, B, T, H, D, dtype, in_place)

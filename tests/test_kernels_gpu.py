@@ -382,3 +382,19 @@ def test_cross_attention_fusions(hip, B, Tn, d, dtype):
     from kernel_cases import check_cross_fused, check_softmax_pe_rows
     check_cross_fused(DEV, B, Tn, d, dtype)
     check_softmax_pe_rows(DEV, B, Tn, d, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("clamp", [None, -0.2])
+@pytest.mark.parametrize("n", [4096, 64 * 1024 * 512 + 4])
+def test_gate_logsigmoid(hip, n, dtype, clamp):
+    from kernel_cases import check_gate_logsigmoid
+    check_gate_logsigmoid(DEV, n, dtype, clamp)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("in_place", [True, False])
+@pytest.mark.parametrize("B,T,H,D", [(2, 70, 2, 64), (3, 515, 4, 256)])
+def test_split_slab(hip, B, T, H, D, dtype, in_place):
+    from kernel_cases import check_split_slab
+    check_split_slab(DEV, B, T, H, D, dtype, in_place)
