@@ -23,7 +23,10 @@ class SwiGLU(nn.Module):
 
     def forward(self, x):
         from . import ops
-        return self.p_out(ops.swiglu_gate(self.p_in(x)))       # K11 / K11b: one pass each way (torch fallback off-device)
+        # K11 / K11b: the gate in one pass each way (torch fallback off-device); ops.linear: F.linear whose weight
+        # gradient is posed to the GEMM library split over the tokens
+        h = ops.swiglu_gate(ops.linear(x, self.p_in.weight, self.p_in.bias))
+        return ops.linear(h, self.p_out.weight, self.p_out.bias)
 
 
 class MixingBlock(nn.Module):

@@ -73,7 +73,9 @@ class GatedLinearAttention(nn.Module):
         return x.view(B, T, self.num_heads, -1).transpose(1, 2)  # 'b l (h d) -> b h l d' as a view
 
     def _gates(self, hidden_states, reset_mask, reset_val, low_rank=None):
-        pre = self.gk_proj(hidden_states) if low_rank is None else self.gk_proj[1](low_rank)
+        if low_rank is None:
+            low_rank = self.gk_proj[0](hidden_states)
+        pre = ops.linear(low_rank, self.gk_proj[1].weight, self.gk_proj[1].bias)
         # K12: logsigmoid / normalizer (+ clamp) in one pass each way (the head split is a view of the result)
         gk = self._heads(ops.gate_logsigmoid(pre, self.gate_logit_normalizer, self.clamp_min))
         if reset_mask is not None:
@@ -131,7 +133,7 @@ class GatedLinearAttention(nn.Module):
                 w_cat = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.g_proj.weight,
                                    self.gk_proj[0].weight], dim=0)
                 # (training: the consumers of the slices write their input gradients into ONE slab -- no concat pass)
-                (q, k, v, g_pre, lr_pre), slab = ops.split_slab(F.linear(hidden_states, w_cat), [
+                (q, k, v, g_pre, lr_pre), slab = ops.split_slab(ops.linear(hidden_states, w_cat), [
                     self.key_dim, self.key_dim, self.value_dim, self.value_dim, self.gk_proj[0].weight.shape[0]])
             else:
                 q, k, v = self.q_proj(hidden_states), self.k_proj(hidden_states), self.v_proj(hidden_states)
@@ -160,7 +162,7 @@ class GatedLinearAttention(nn.Module):
                                        grad_slab=None if slab is None else (slab, 3)).reshape(B, T, H * Dv)
         else:
             o = self.g_norm(o).reshape(B, T, H * Dv) * self.gate_fn(g)
-        return self.o_proj(o)
+        return ops.linear(o, self.o_proj.weight, self.o_proj.bias)
 
     # ------------------------------------------------------------------ state
     def init_state(self, batch_size: int) -> Tuple[torch.Tensor, ...]:

@@ -17,6 +17,7 @@ import os
 from typing import Optional, Tuple
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib
 from ._lib import BHT, LINA_BF16, LINA_F32
@@ -734,6 +735,83 @@ def swiglu_gate(u):
     _BACKEND.require(u)
     u2 = u.reshape(-1, u.shape[-1]).contiguous()
     return _SwiGLUFunction.apply(u2, hidden).view(*u.shape[:-1], hidden)
+
+
+# --------------------------------------------------------------------------- projections of the train path
+# The GEMMs stay on the vendor library (hipBLASLt through torch); what is ours is how the WEIGHT GRADIENT is posed to it.
+# dW = dY^T X reduces over all B T tokens (32768 on config 5) into a small [out, in] tile grid: posed as one GEMM the
+# library runs it at 300-580 TFLOP/s (1024x1024 / 1024x1365 / 2730x1024 outputs: 16-44 tiles for 256 CUs, profiles/
+# r03_dw_gemm.txt); split over the token axis into a batched GEMM with fp32 partial products + one small sum it runs at
+# 830-940 TFLOP/s, and dW comes out in fp32 (the master-weight dtype: no bf16 round trip, no cast kernel).
+_LINEAR_SPLIT_MAX_OUT = 3 * 1024 * 1024        # [out, in] up to this many elements: split (above: enough tiles already)
+_LINEAR_SPLIT_MIN_ROWS = 2048                  # tokens per split slice, at least
+
+
+def _linear_split(rows, n_out, n_in):
+    if n_out * n_in > _LINEAR_SPLIT_MAX_OUT:
+        return 1
+    for s in (8, 4, 2):
+        if rows % s == 0 and rows // s >= _LINEAR_SPLIT_MIN_ROWS:
+            return s
+    return 1
+
+
+def linear_weight_grad(dy2, x2, split=None):
+    """dW [out, in] (fp32) = dy2^T x2 for dy2 [rows, out], x2 [rows, in] of one GEMM dtype: token-split batched GEMM with
+    fp32 partial products (see above); ``split`` None = by shape."""
+    rows, n_out = dy2.shape
+    n_in = x2.shape[1]
+    S = _linear_split(rows, n_out, n_in) if split is None else split
+    f32 = {} if (dy2.dtype == torch.float32 or not dy2.is_cuda) else {"out_dtype": torch.float32}
+    if not dy2.is_cuda and dy2.dtype != torch.float32:
+        dy2, x2 = dy2.float(), x2.float()          # (CPU: no fp32-output bf16 GEMM; same sum, fp32 operands)
+    if S == 1:
+        return torch.mm(dy2.t(), x2, **f32)
+    if n_in % 8:                                   # rows of x2 not 16-byte aligned: the transposed problem is the faster one
+        return torch.bmm(x2.view(S, rows // S, n_in).transpose(1, 2), dy2.view(S, rows // S, n_out), **f32).sum(0).t()
+    return torch.bmm(dy2.view(S, rows // S, n_out).transpose(1, 2), x2.view(S, rows // S, n_in), **f32).sum(0)
+
+
+class _LinearFunction(torch.autograd.Function):
+    """y = x W^T + b in the GEMM dtype (the autocast dtype when autocast is on, like F.linear under autocast); backward:
+    dX on the library GEMM, dW by ``linear_weight_grad``, db as the fp32-accumulated column sum."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        cd = x.dtype
+        if x.is_cuda and torch.is_autocast_enabled("cuda"):
+            cd = torch.get_autocast_dtype("cuda")
+        xc, wc = x.to(cd), w.to(cd)
+        with torch.autocast(x.device.type, enabled=False):
+            y = F.linear(xc, wc, None if b is None else b.to(cd))
+        ctx.save_for_backward(xc, wc)
+        ctx.meta = (x.dtype, w.dtype, None if b is None else b.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc = ctx.saved_tensors
+        xdt, wdt, bdt = ctx.meta
+        n_out, n_in = wc.shape
+        dy2 = dy.to(xc.dtype).reshape(-1, n_out)
+        x2 = xc.reshape(-1, n_in)
+        with torch.autocast(xc.device.type, enabled=False):
+            dx = dw = db = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.mm(dy2, wc).view(xc.shape).to(xdt)
+            if ctx.needs_input_grad[1]:
+                dw = linear_weight_grad(dy2.contiguous(), x2.contiguous()).to(wdt)
+            if bdt is not None and ctx.needs_input_grad[2]:
+                db = dy2.sum(0, dtype=torch.float32).to(bdt)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    """``F.linear(x, weight, bias)`` for the projections of the train path: same forward GEMM (autocast semantics
+    included), weight gradient posed as a token-split batched GEMM in fp32.  Without gradients: F.linear itself."""
+    if not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)) or x.dim() < 2:
+        return F.linear(x, weight, bias)
+    return _LinearFunction.apply(x, weight, bias)
 
 
 class _GateLogSigmoidFunction(torch.autograd.Function):

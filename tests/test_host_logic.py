@@ -177,3 +177,37 @@ def test_isa_audit_flags_an_mfma_under_an_unskipped_exec_mask():
         v_mfma_f32_16x16x32_bf16 v[2:5], v[18:21], v[6:9], v[2:5]
         s_endpgm""".splitlines()
     assert mod.scan(good) == {}
+
+
+@pytest.mark.parametrize("rows,n_out,n_in,split", [(4096, 24, 16, None), (16384, 40, 21, None), (16384, 40, 21, 4),
+                                                   (300, 8, 8, None)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_matches_f_linear_and_splits_the_weight_gradient(rows, n_out, n_in, split, dtype):
+    """ops.linear (the train path's projection): same y, dx, dW, db as F.linear under autograd; the token-split weight
+    gradient (CPU form of the batched GEMM) equals the one-GEMM form."""
+    from lina_speech_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, rows // 2, n_in, generator=g).to(dtype)
+    w = torch.randn(n_out, n_in, generator=g) * 0.2
+    b = torch.randn(n_out, generator=g)
+    dy = torch.randn(2, rows // 2, n_out, generator=g).to(dtype)
+    outs = []
+    for fn in (ops.linear, torch.nn.functional.linear):
+        xx = x.clone().requires_grad_()
+        ww, bb = w.clone().to(dtype).requires_grad_(), b.clone().to(dtype).requires_grad_()
+        y = fn(xx, ww, bb)
+        (y.float() * dy.float()).sum().backward()
+        outs.append((y, xx.grad, ww.grad, bb.grad))
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    for a, r, what in zip(outs[0], outs[1], ("y", "dx", "dW", "db")):
+        assert a.dtype == r.dtype and a.shape == r.shape, what
+        assert (a.float() - r.float()).abs().max() <= tol * max(1.0, r.float().abs().max().item()), what
+    s_auto = ops._linear_split(rows, n_out, n_in)
+    assert s_auto == (1 if rows < 4096 else 8 if rows >= 16384 else 2)
+    d2, x2 = dy.reshape(-1, n_out), x.reshape(-1, n_in)
+    one = ops.linear_weight_grad(d2, x2, split=1)
+    many = ops.linear_weight_grad(d2, x2, split=split)
+    assert one.dtype == many.dtype == torch.float32 and many.shape == (n_out, n_in)
+    assert torch.allclose(one, many, rtol=1e-4, atol=1e-3)
+    # no gradient wanted: the plain library call, no autograd node of ours
+    assert ops.linear(x, w.to(dtype), None).grad_fn is None

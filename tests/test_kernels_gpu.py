@@ -398,3 +398,37 @@ def test_gate_logsigmoid(hip, n, dtype, clamp):
 def test_split_slab(hip, B, T, H, D, dtype, in_place):
     from kernel_cases import check_split_slab
     check_split_slab(DEV, B, T, H, D, dtype, in_place)
+
+
+@pytest.mark.parametrize("n_out,n_in,bias", [(1024, 1365, True), (2730, 1024, True), (1024, 1024, False), (1024, 16, True),
+                                             (4112, 1024, False)])
+def test_linear_train_path_under_autocast(hip, n_out, n_in, bias):
+    """ops.linear under bf16 autocast with fp32 master weights (the train step's setting) against F.linear under the same
+    autocast: same bf16 y; dX equal; dW / db in fp32 and CLOSER to the fp64 product than autograd's bf16-rounded ones
+    (token-split batched GEMM with fp32 partial products)."""
+    rows = 16384
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4, rows // 4, n_in, generator=g).to(DEV)
+    w = (torch.randn(n_out, n_in, generator=g) * 0.05).to(DEV)
+    b = torch.randn(n_out, generator=g).to(DEV) if bias else None
+    dy = torch.randn(4, rows // 4, n_out, generator=g).to(torch.bfloat16).to(DEV)
+    res = []
+    for fn in (ops.linear, torch.nn.functional.linear):
+        xx, ww = x.clone().requires_grad_(), w.clone().requires_grad_()
+        bb = None if b is None else b.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = fn(xx, ww, bb)
+        assert y.dtype == torch.bfloat16
+        (y.float() * dy.float()).sum().backward()
+        assert ww.grad.dtype == torch.float32 and xx.grad.dtype == torch.float32
+        res.append((y, xx.grad, ww.grad, None if bb is None else bb.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.allclose(res[0][1], res[1][1], rtol=2e-2, atol=2e-2)
+    xb, db = x.to(torch.bfloat16).double().view(rows, n_in), dy.double().view(rows, n_out)
+    dw64 = db.t() @ xb
+    e_mine = (res[0][2].double() - dw64).abs().max().item()
+    e_auto = (res[1][2].double() - dw64).abs().max().item()
+    assert e_mine <= max(e_auto, 1e-3 * dw64.abs().max().item()), (e_mine, e_auto)
+    if bias:
+        db64 = db.sum(0)
+        assert (res[0][3].double() - db64).abs().max().item() <= max((res[1][3].double() - db64).abs().max().item(), 1e-3)
