@@ -266,6 +266,18 @@ int lina_swiglu_bwd(const void* ds, const void* u, void* du, int64_t rows, int H
 int lina_gate_logsigmoid(const void* x, const void* dy, void* out, int64_t n, float normalizer, float clamp_min, int dtype,
                          lina_stream_t stream);
 
+/* K12b -- gate projection + gate in one pass (reference model/gla.py:107-109 `gk_proj[1]`, :174-180): with lr [rows, L]
+ * (row stride lr_stride, L <= 16), w fp32 [C, L], b fp32 [C] or NULL (rounded to `dtype` in the kernel, as autocast would):
+ *   dy == NULL:  out [rows, C] = logsigmoid(lr w^T + b) / normalizer, clamped from below unless clamp_min is NaN;
+ *   dy given:    out [rows, C] = d(pre) = dy (1 - sigmoid(pre)) / normalizer (0 where clamped), and
+ *                dwb_partial fp32 [lina_gate_lowrank_partials(rows)][C][L + 1] = per-workgroup sums of d(pre)^T [lr | 1]
+ *                (slot L = bias gradient), summed over dim 0 by the caller.  d(lr) = d(pre) w is the caller's GEMM. */
+#define LINA_GATE_LOWRANK_ROWS 128
+int lina_gate_lowrank_partials(int64_t rows);
+int lina_gate_lowrank(const void* lr, int64_t lr_stride, const float* w, const float* b, const void* dy, void* out,
+                      float* dwb_partial, int64_t rows, int C, int L, float normalizer, float clamp_min, int dtype,
+                      lina_stream_t stream);
+
 /* K10 -- LayerNorm over the last dimension with the residual add that precedes it in a pre-norm block
  * (reference model/base_blocks.py:65-69: `x = tmix(norm1(x)) + x; x = cmix(norm2(x)) + x`), for the TRAINING step:
  *   forward:  x' = x + r (r optional; x' written to xsum when given);  y = (x' - mean) rstd gamma + beta;  mean / rstd

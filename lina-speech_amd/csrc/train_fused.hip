@@ -253,7 +253,155 @@ __global__ __launch_bounds__(256) void gate_logsigmoid_kernel(const T* __restric
     }
 }
 
+// K12b -- the gate projection and the gate in one pass (reference model/gla.py:107-109,174-180): the second factor of the
+// low-rank gate projection has an inner dimension of 16, so pre = lr W^T + b is 16 FMAs per element from a 32-byte row of lr
+// (wave-uniform: scalar loads) and the 4 x 16 weights a thread keeps in registers -- the [R, C] pre-activation never exists
+// in memory, forward or backward.  A thread owns 4 columns and walks the rows of its workgroup's slab (kGateRows rows, 8 at a
+// time with all loads first); backward it also carries dW [4][16] and db [4] of its columns, written once per workgroup as
+// fp32 partials [workgroup][C][L + 1] (slot L = bias) the caller sums -- torch's chain for the same work was a 10-TFLOP/s
+// [C, R] x [R, 16] GEMM, two column sums and the bias add on top of the elementwise kernels.
+// Rounding follows the autocast chain it replaces: weights and bias rounded to T, fp32 accumulate, pre rounded to T.
+constexpr int kGateRows = LINA_GATE_LOWRANK_ROWS;
+constexpr int kGateL = 16;
+constexpr int kGateUnroll = 8;
+
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf2f(f2bf(v)); }
+
+// one row of lr (wave-uniform address): 32-bit words, so that bf16 rows go through the scalar cache as well
+__device__ __forceinline__ void load_lr_row(const float* p, int L, bool full, float (&lv)[kGateL]) {
+#pragma unroll
+    for (int j = 0; j < kGateL; ++j) lv[j] = (full || j < L) ? p[j] : 0.0f;
+}
+__device__ __forceinline__ void load_lr_row(const bf16_t* p, int L, bool full, float (&lv)[kGateL]) {
+    if (full) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+        for (int j = 0; j < kGateL / 2; ++j) {
+            const uint32_t u = q[j];
+            lv[2 * j] = bf2f((bf16_t)(u & 0xffff));
+            lv[2 * j + 1] = bf2f((bf16_t)(u >> 16));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kGateL; ++j) lv[j] = j < L ? bf2f(p[j]) : 0.0f;
+    }
+}
+
+// FULL: L == kGateL and rows of lr 4-byte aligned (the reference's gate_low_rank_dim = 16): no per-element bounds
+template <typename T, bool BWD, bool FULL>
+__global__ __launch_bounds__(256) void gate_lowrank_kernel(const T* __restrict__ lr, int64_t lr_stride, const float* __restrict__ w,
+                                                           const float* __restrict__ b, const T* __restrict__ dy, T* __restrict__ out,
+                                                           float* __restrict__ dwb_partial, int64_t R, int C, int L,
+                                                           float inv_norm, float clamp_min, int has_clamp) {
+    const int c0 = (blockIdx.y * 256 + threadIdx.x) * 4;
+    const bool col_ok = c0 < C;
+    const int cc = col_ok ? c0 : C - 4;
+    float wr[4][kGateL], br[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        br[c] = b ? round_to<T>(b[cc + c]) : 0.0f;
+#pragma unroll
+        for (int j = 0; j < kGateL; ++j) wr[c][j] = (FULL || j < L) ? round_to<T>(w[(int64_t)(cc + c) * L + j]) : 0.0f;
+    }
+    float dwa[BWD ? 4 : 1][BWD ? kGateL : 1], dba[4] = {0.f, 0.f, 0.f, 0.f};
+    if (BWD) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < kGateL; ++j) dwa[c][j] = 0.0f;
+    }
+    const int64_t r_begin = (int64_t)blockIdx.x * kGateRows;
+    const int64_t r_end = r_begin + kGateRows < R ? r_begin + kGateRows : R;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += kGateUnroll) {
+        typename raw4<T>::type dr[kGateUnroll];
+        if (BWD) {
+#pragma unroll
+            for (int u = 0; u < kGateUnroll; ++u) {
+                const int64_t r = r0 + u < R ? r0 + u : R - 1;
+                dr[u] = ld4_raw(dy + r * C + cc);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kGateUnroll; ++u) {
+            const int64_t r = r0 + u;
+            if (r >= r_end) break;                                   // workgroup-uniform
+            float lv[kGateL];
+            load_lr_row(lr + r * lr_stride, L, FULL, lv);
+            float pre[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = 0.0f;
+#pragma unroll
+                for (int j = 0; j < kGateL; ++j) a = fmaf(lv[j], wr[c][j], a);
+                pre[c] = round_to<T>(a + br[c]);
+            }
+            float o[4];
+            if (BWD) {
+                const float4 d4 = cvt4(dr[u]);
+                const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool clamped = has_clamp && logsigmoidf(pre[c]) * inv_norm < clamp_min;
+                    o[c] = round_to<T>(clamped ? 0.0f : dv[c] * inv_norm * sigmoidf(-pre[c]));
+                    dba[c] += o[c];
+#pragma unroll
+                    for (int j = 0; j < kGateL; ++j) dwa[c][j] = fmaf(o[c], lv[j], dwa[c][j]);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    o[c] = logsigmoidf(pre[c]) * inv_norm;
+                    if (has_clamp) o[c] = fmaxf(o[c], clamp_min);
+                }
+            }
+            if (col_ok) st4(out + r * C + c0, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+    if (BWD && col_ok) {
+        float* dst = dwb_partial + ((int64_t)blockIdx.x * C + c0) * (L + 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int j = 0; j < kGateL; ++j)
+                if (FULL || j < L) dst[c * (L + 1) + j] = dwa[c][j];
+            dst[c * (L + 1) + L] = dba[c];
+        }
+    }
+}
+
 }  // namespace lina
+
+extern "C" int lina_gate_lowrank_partials(int64_t rows) {
+    return rows <= 0 ? 0 : (int)((rows + LINA_GATE_LOWRANK_ROWS - 1) / LINA_GATE_LOWRANK_ROWS);
+}
+
+extern "C" int lina_gate_lowrank(const void* lr, int64_t lr_stride, const float* w, const float* b, const void* dy, void* out,
+                                 float* dwb_partial, int64_t rows, int C, int L, float normalizer, float clamp_min, int dtype,
+                                 lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(lr && w && out, "lina_gate_lowrank: null pointer");
+    LINA_REQUIRE(!dy == !dwb_partial, "lina_gate_lowrank: dy and dwb_partial must both be given (backward) or both be NULL");
+    LINA_REQUIRE(rows > 0 && rows <= (int64_t)65535 * LINA_GATE_LOWRANK_ROWS, "lina_gate_lowrank: bad row count %lld", (long long)rows);
+    LINA_REQUIRE(C >= 4 && C % 4 == 0, "lina_gate_lowrank: C=%d must be a positive multiple of 4", C);
+    LINA_REQUIRE(L >= 1 && L <= kGateL, "lina_gate_lowrank: inner dimension L=%d must be in 1..%d", L, kGateL);
+    LINA_REQUIRE(lr_stride >= L, "lina_gate_lowrank: lr_stride=%lld < L", (long long)lr_stride);
+    LINA_REQUIRE(normalizer != 0.0f, "lina_gate_lowrank: normalizer must be non-zero");
+    LINA_REQUIRE(valid_dtype(dtype), "lina_gate_lowrank: bad dtype %d", dtype);
+    const int has_clamp = (clamp_min == clamp_min) ? 1 : 0;          // NaN = no clamp
+    dim3 grid((unsigned)lina_gate_lowrank_partials(rows), (unsigned)((C / 4 + 255) / 256));
+    const bool full = L == kGateL && lr_stride % 2 == 0 && (reinterpret_cast<uintptr_t>(lr) & 3) == 0;
+#define LINA_GLR(TT, BB, FF)                                                                                         \
+    LINA_LAUNCH((gate_lowrank_kernel<TT, BB, FF>), grid, dim3(256), 0, stream, (const TT*)lr, lr_stride, w, b, (const TT*)dy, \
+                (TT*)out, dwb_partial, rows, C, L, 1.0f / normalizer, clamp_min, has_clamp)
+#define LINA_GLR_F(TT, BB) do { if (full) LINA_GLR(TT, BB, true); else LINA_GLR(TT, BB, false); } while (0)
+    if (dtype == LINA_F32) { if (dy) LINA_GLR_F(float, true); else LINA_GLR_F(float, false); }
+    else { if (dy) LINA_GLR_F(bf16_t, true); else LINA_GLR_F(bf16_t, false); }
+#undef LINA_GLR_F
+#undef LINA_GLR
+    return check_launch("lina_gate_lowrank");
+}
 
 extern "C" int lina_gate_logsigmoid(const void* x, const void* dy, void* out, int64_t n, float normalizer, float clamp_min,
                                     int dtype, lina_stream_t stream) {

@@ -59,13 +59,16 @@ class LinaModel(nn.Module):
         if attention_only:
             return att
         logits = self.logits_head(y_hat)
+        target = y[:, 1:]
         if logits_mask is not None:
-            masked_logits = logits[logits_mask[:, 1:], :, :]
-            masked_target = y[:, 1:][logits_mask[:, 1:], :]
+            keep = logits_mask[:, 1:]
+            masked_logits, masked_target = logits[keep, :, :], target[keep, :]      # returned, as the reference does
+            # the loss itself: masked positions carry the ignored class instead of being gathered out -- the same mean
+            # over the same terms (reference modeling_lina.py:97-107), without the scatter of the gather in backward
+            target = torch.where(keep.unsqueeze(-1), target, torch.ones_like(target))
         else:
-            masked_logits, masked_target = logits, y[:, 1:]
-        loss = F.cross_entropy(masked_logits.reshape(-1, masked_logits.shape[-1]), masked_target.reshape(-1),
-                               ignore_index=1)
+            masked_logits, masked_target = logits, target
+        loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), target.reshape(-1), ignore_index=1)
         return logits, loss, att, masked_logits, masked_target
 
     # ------------------------------------------------------------------ batched decode

@@ -75,9 +75,10 @@ class GatedLinearAttention(nn.Module):
     def _gates(self, hidden_states, reset_mask, reset_val, low_rank=None):
         if low_rank is None:
             low_rank = self.gk_proj[0](hidden_states)
-        pre = ops.linear(low_rank, self.gk_proj[1].weight, self.gk_proj[1].bias)
-        # K12: logsigmoid / normalizer (+ clamp) in one pass each way (the head split is a view of the result)
-        gk = self._heads(ops.gate_logsigmoid(pre, self.gate_logit_normalizer, self.clamp_min))
+        # K12b: the 16-wide second projection, logsigmoid / normalizer (+ clamp) in one pass each way (the head split is a
+        # view of the result)
+        gk = self._heads(ops.gate_lowrank(low_rank, self.gk_proj[1].weight, self.gk_proj[1].bias,
+                                          self.gate_logit_normalizer, self.clamp_min))
         if reset_mask is not None:
             gk = gk.masked_fill(reset_mask.unsqueeze(1).unsqueeze(3), reset_val)
         return gk

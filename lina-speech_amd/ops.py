@@ -848,6 +848,64 @@ def gate_logsigmoid(x, normalizer: float = 16.0, clamp_min: Optional[float] = No
     return _GateLogSigmoidFunction.apply(x.contiguous(), float(normalizer), clamp_min).view(x.shape)
 
 
+class _GateLowRankFunction(torch.autograd.Function):
+    """K12b: logsigmoid(lr W^T + b) / normalizer in one pass; backward d(lr), dW, db without the [R, C] pre-activation."""
+
+    @staticmethod
+    def forward(ctx, lr, w, b, normalizer, clamp_min):
+        be = _BACKEND
+        C_, L = w.shape
+        rows = lr.numel() // L
+        lr2 = lr.reshape(rows, L)                              # a view for column slices of a wider row (the slab)
+        if lr2.stride(1) != 1:
+            lr2 = lr2.contiguous()
+        wf = w.detach().float().contiguous()
+        bf = None if b is None else b.detach().float().contiguous()
+        y = torch.empty(*lr.shape[:-1], C_, dtype=lr.dtype, device=lr.device)
+        cm = float("nan") if clamp_min is None else float(clamp_min)
+        _check(be.lib.lina_gate_lowrank(_ptr(lr2), lr2.stride(0), _ptr(wf), _ptr(bf), None, _ptr(y), None, rows, C_, L,
+                                        float(normalizer), cm, _dt(lr2), be.stream(lr)))
+        ctx.save_for_backward(lr2, wf, bf)
+        ctx.args = (float(normalizer), cm, lr.shape, w.dtype, None if b is None else b.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lr2, wf, bf = ctx.saved_tensors
+        normalizer, cm, lr_shape, wdt, bdt = ctx.args
+        be = _BACKEND
+        C_, L = wf.shape
+        rows = lr2.shape[0]
+        dy2 = dy.to(lr2.dtype).reshape(rows, C_).contiguous()
+        dpre = torch.empty_like(dy2)
+        part = torch.empty(int(be.lib.lina_gate_lowrank_partials(rows)), C_, L + 1, dtype=torch.float32, device=dy2.device)
+        _check(be.lib.lina_gate_lowrank(_ptr(lr2), lr2.stride(0), _ptr(wf), _ptr(bf), _ptr(dy2), _ptr(dpre), _ptr(part),
+                                        rows, C_, L, normalizer, cm, _dt(lr2), be.stream(dy2)))
+        red = part.sum(0)
+        dlr = None
+        if ctx.needs_input_grad[0]:
+            with torch.autocast(dy2.device.type, enabled=False):
+                dlr = torch.mm(dpre, wf.to(dpre.dtype)).view(lr_shape)
+        dw = red[:, :L].to(wdt) if ctx.needs_input_grad[1] else None
+        db = red[:, L].to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
+        return dlr, dw, db, None, None
+
+
+def gate_lowrank(lr, weight, bias=None, normalizer: float = 16.0, clamp_min: Optional[float] = None):
+    """``logsigmoid(F.linear(lr, weight, bias)) / normalizer`` (clamped from below when ``clamp_min`` is given): the second
+    factor of the mixer's low-rank gate projection fused with the gate (reference model/gla.py:107-109,174-180), K12b.
+    ``weight`` [C, L <= 16].  Falls back to the unfused ops where the kernel does not apply."""
+    C_, L = weight.shape
+    gemm_dt = lr.dtype
+    if lr.is_cuda and torch.is_autocast_enabled("cuda"):
+        gemm_dt = torch.get_autocast_dtype("cuda")
+    if (not fused_ops_available(lr) or gemm_dt not in (torch.float32, torch.bfloat16) or L > 16 or C_ % 4
+            or lr.numel() == 0 or lr.numel() // L > 65535 * 128):
+        return gate_logsigmoid(linear(lr, weight, bias), normalizer, clamp_min)
+    _BACKEND.require(lr, weight, bias)
+    return _GateLowRankFunction.apply(lr.to(gemm_dt), weight, bias, float(normalizer), clamp_min)
+
+
 # --------------------------------------------------------------------------- codec head (K6)
 def _embed_sum_launch(table, flat, out=None):
     be = _BACKEND

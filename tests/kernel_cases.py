@@ -612,6 +612,43 @@ def check_gate_logsigmoid(dev, n, dtype, clamp):
     assert_close(gd, g64, 8e-3 if lo else 2e-6, "K12 dx")
 
 
+def check_gate_lowrank(dev, B, T, C, L, dtype, clamp, bias=True, strided=False):
+    """K12b: logsigmoid(lr W^T + b) / normalizer (+ clamp) and the gradients of lr, W, b against fp64 autograd of the
+    unfused chain on the operands the kernel sees (weights rounded to the GEMM dtype, as autocast does)."""
+    g = torch.Generator().manual_seed(43)
+    z = torch.randn(B, T, L + 8, generator=g).to(dtype)
+    lr0 = z[..., 4:4 + L] if strided else z[..., :L].contiguous()
+    w = torch.randn(C, L, generator=g) * 1.5
+    b = torch.randn(C, generator=g) if bias else None
+    dy = torch.randn(B, T, C, generator=g).to(dtype)
+    lr64 = lr0.to(F64).requires_grad_()
+    w64 = w.to(dtype).to(F64).requires_grad_()
+    b64 = None if b is None else b.to(dtype).to(F64).requires_grad_()
+    pre64 = F.linear(lr64, w64, b64)
+    pre64 = pre64 + (pre64.to(dtype).to(F64) - pre64).detach()        # the GEMM's output rounding (straight-through)
+    y64 = F.logsigmoid(pre64) / 16.0
+    if clamp is not None:
+        y64 = torch.clamp_min(y64, clamp)
+    (y64 * dy.to(F64)).sum().backward()
+    zd = z.to(dev)
+    lrd = (zd[..., 4:4 + L] if strided else zd[..., :L].contiguous()).requires_grad_()
+    wd = w.to(dev).requires_grad_()
+    bd = None if b is None else b.to(dev).requires_grad_()
+    y = ops.gate_lowrank(lrd, wd, bd, 16.0, clamp)
+    assert y.dtype == dtype and y.shape == (B, T, C)
+    lo = dtype == torch.bfloat16
+    assert_close(y, y64.detach(), 2e-2 if lo else 1e-5, "K12b gate")         # bf16: pre is rounded to bf16 first
+    (y.float() * dy.to(dev).float()).sum().backward()
+    assert wd.grad.dtype == torch.float32 and wd.grad.shape == w.shape
+    if clamp is None:
+        assert_close(lrd.grad, lr64.grad, 3e-2 if lo else 2e-5, "K12b dlr")
+        assert_close(wd.grad, w64.grad, 2e-2 if lo else 2e-5, "K12b dW")
+        if bias:
+            assert_close(bd.grad, b64.grad, 2e-2 if lo else 2e-5, "K12b db")
+    else:                                      # positions at the clamp edge may fall on either side: compare the bulk
+        assert_close(wd.grad, w64.grad, 5e-2, "K12b dW (clamped)")
+
+
 def check_argmax(dev, rows, n, dtype):
     g = torch.Generator().manual_seed(5)
     lg = torch.randn(rows, n, generator=g).to(dtype)

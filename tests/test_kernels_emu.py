@@ -323,3 +323,10 @@ def test_gate_logsigmoid(emu, n, dtype, clamp):
 def test_split_slab(emu, B, T, H, D, dtype, in_place):
     from kernel_cases import check_split_slab
     check_split_slab(DEV, B, T, H, D, dtype, in_place)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,C,L,clamp,bias,strided", [(2, 70, 64, 16, None, True, True), (1, 130, 40, 16, -0.2, True, False), (2, 33, 64, 7, None, False, False)])
+def test_gate_lowrank(emu, B, T, C, L, clamp, bias, strided, dtype):
+    from kernel_cases import check_gate_lowrank
+    check_gate_lowrank(DEV, B, T, C, L, dtype, clamp, bias, strided)

@@ -432,3 +432,10 @@ def test_linear_train_path_under_autocast(hip, n_out, n_in, bias):
     if bias:
         db64 = db.sum(0)
         assert (res[0][3].double() - db64).abs().max().item() <= max((res[1][3].double() - db64).abs().max().item(), 1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,C,L,clamp,bias,strided", [(2, 70, 64, 16, None, True, True), (8, 4096, 1024, 16, None, True, True), (3, 1000, 1024, 16, -0.2, True, False), (2, 333, 2048, 7, None, False, False)])
+def test_gate_lowrank(hip, B, T, C, L, clamp, bias, strided, dtype):
+    from kernel_cases import check_gate_lowrank
+    check_gate_lowrank(DEV, B, T, C, L, dtype, clamp, bias, strided)
