@@ -266,6 +266,14 @@ int lina_swiglu_bwd(const void* ds, const void* u, void* du, int64_t rows, int H
 int lina_gate_logsigmoid(const void* x, const void* dy, void* out, int64_t n, float normalizer, float clamp_min, int dtype,
                          lina_stream_t stream);
 
+/* K11c -- K11b that also leaves the column sums of du (the bias gradient of the up-projection):
+ *   colsum_partial fp32 [lina_swiglu_bwd_partials(rows)][2 Hd], summed over dim 0 by the caller (sums of the values as
+ *   stored in `dtype`).  Hd and the row strides must be multiples of 4. */
+#define LINA_SWIGLU_COLSUM_ROWS 128
+int lina_swiglu_bwd_partials(int64_t rows);
+int lina_swiglu_bwd_colsum(const void* ds, const void* u, void* du, float* colsum_partial, int64_t rows, int Hd,
+                           int64_t ld_u, int64_t ld_ds, int64_t ld_du, int dtype, lina_stream_t stream);
+
 /* K12b -- gate projection + gate in one pass (reference model/gla.py:107-109 `gk_proj[1]`, :174-180): with lr [rows, L]
  * (row stride lr_stride, L <= 16), w fp32 [C, L], b fp32 [C] or NULL (rounded to `dtype` in the kernel, as autocast would):
  *   dy == NULL:  out [rows, C] = logsigmoid(lr w^T + b) / normalizer, clamped from below unless clamp_min is NaN;

@@ -56,6 +56,8 @@ PROTOTYPES = {
                                            _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "lina_swiglu": (C.c_int, [_p, _p, _i64, _i, _i64, _i64, _i, _p]),
     "lina_swiglu_bwd": (C.c_int, [_p, _p, _p, _i64, _i, _i64, _i64, _i64, _i, _p]),
+    "lina_swiglu_bwd_partials": (C.c_int, [_i64]),
+    "lina_swiglu_bwd_colsum": (C.c_int, [_p, _p, _p, _p, _i64, _i, _i64, _i64, _i64, _i, _p]),
     "lina_gate_lowrank_partials": (C.c_int, [_i64]),
     "lina_gate_lowrank": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i, _i, _f, _f, _i, _p]),
     "lina_gate_logsigmoid": (C.c_int, [_p, _p, _p, _i64, _f, _f, _i, _p]),

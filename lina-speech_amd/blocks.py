@@ -23,10 +23,9 @@ class SwiGLU(nn.Module):
 
     def forward(self, x):
         from . import ops
-        # K11 / K11b: the gate in one pass each way (torch fallback off-device); ops.linear: F.linear whose weight
-        # gradient is posed to the GEMM library split over the tokens
-        h = ops.swiglu_gate(ops.linear(x, self.p_in.weight, self.p_in.bias))
-        return ops.linear(h, self.p_out.weight, self.p_out.bias)
+        # train path: one node on padded operands (K11 / K11c gate kernels, token-split weight gradients, the biases
+        # riding in the GEMMs); without gradients / off-device: the three ops
+        return ops.swiglu_mlp(x, self.p_in.weight, self.p_in.bias, self.p_out.weight, self.p_out.bias)
 
 
 class MixingBlock(nn.Module):

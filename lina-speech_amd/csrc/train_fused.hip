@@ -181,6 +181,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TY* __restrict
     }
 }
 
+// the value a store of v to T leaves in memory
+template <typename T> __device__ __forceinline__ float stored_as(float v);
+template <> __device__ __forceinline__ float stored_as<float>(float v) { return v; }
+template <> __device__ __forceinline__ float stored_as<bf16_t>(float v) { return bf2f(f2bf(v)); }
+
 // scalar form for widths / strides that are not multiples of 4 (L169: Hd = 1365): one element per thread
 template <typename T>
 __global__ __launch_bounds__(256) void swiglu_bwd_scalar_kernel(const T* __restrict__ ds, const T* __restrict__ u,
@@ -223,6 +228,74 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ d
     }
 }
 
+// K11c -- K11b plus the column sums of du (the bias gradient of the up-projection) in the same pass: a workgroup takes
+// kColsumRows rows x 256 gate columns, its 4 waves a quarter of the rows each (4 at a time, all loads first), a lane 4
+// columns of each half; the waves' sums meet in LDS and the workgroup writes one fp32 partial row [2 Hd] per row slab
+// (summed over slabs by the caller: 256 x 2 Hd floats at L169 against the 2 x 90 MB of du a separate column sum re-read).
+constexpr int kColsumRows = LINA_SWIGLU_COLSUM_ROWS;
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd_colsum_kernel(const T* __restrict__ ds, const T* __restrict__ u, T* __restrict__ du,
+                                                                float* __restrict__ colsum_partial, int64_t rows, int Hd,
+                                                                int64_t ld_u, int64_t ld_ds, int64_t ld_du) {
+    constexpr int U = 4;
+    __shared__ float s_red[4][8][64];
+    const int lane = threadIdx.x & 63, wv = wave_uniform(threadIdx.x >> 6);
+    const int j = (blockIdx.y * 64 + lane) * 4;
+    const bool ok = j < Hd;
+    const int jc = ok ? j : Hd - 4;
+    float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t r_begin = (int64_t)blockIdx.x * kColsumRows + wv * (kColsumRows / 4);
+    const int64_t r_end = r_begin + kColsumRows / 4 < rows ? r_begin + kColsumRows / 4 : rows;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += U) {
+        typename raw4<T>::type ar[U], br[U], dr[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int64_t r = r0 + q < rows ? r0 + q : rows - 1;
+            ar[q] = ld4_raw(u + r * ld_u + jc);
+            br[q] = ld4_raw(u + r * ld_u + Hd + jc);
+            dr[q] = ld4_raw(ds + r * ld_ds + jc);
+        }
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int64_t r = r0 + q;
+            if (r >= r_end) break;                                   // wave-uniform
+            const float4 a = cvt4(ar[q]), b = cvt4(br[q]), d = cvt4(dr[q]);
+            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, dv[4] = {d.x, d.y, d.z, d.w};
+            float oa[4], ob[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float sg = sigmoidf(av[c]);
+                oa[c] = dv[c] * bv[c] * sg * (1.0f + av[c] * (1.0f - sg));
+                ob[c] = dv[c] * av[c] * sg;
+            }
+            if (ok) {
+                st4(du + r * ld_du + j, make_float4(oa[0], oa[1], oa[2], oa[3]));
+                st4(du + r * ld_du + Hd + j, make_float4(ob[0], ob[1], ob[2], ob[3]));
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                            // sums of the values as stored (rounded to T)
+                sa[c] += stored_as<T>(oa[c]);
+                sb[c] += stored_as<T>(ob[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        s_red[wv][c][lane] = sa[c];
+        s_red[wv][4 + c][lane] = sb[c];
+    }
+    __syncthreads();
+    // 512 sums of this workgroup (256 columns x 2 halves): thread t -> half t / 128 ... two per thread
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const int half = i >> 8, col = i & 255, jj = blockIdx.y * 256 + col;
+        if (jj < Hd) {
+            const int k = half * 4 + (col & 3), l = col >> 2;
+            colsum_partial[(int64_t)blockIdx.x * 2 * Hd + half * Hd + jj] =
+                s_red[0][k][l] + s_red[1][k][l] + s_red[2][k][l] + s_red[3][k][l];
+        }
+    }
+}
+
 // K12 -- the gate of the mixer for a whole sequence (reference model/gla.py:174-180): y = logsigmoid(x) / normalizer
 // (optionally clamped from below), and its gradient dx = dy (1 - sigmoid(x)) / normalizer (0 where the clamp is active).
 // Elementwise over n4 groups of 4 elements; torch's chain (log_sigmoid with its second output, the division, their two
@@ -256,10 +329,12 @@ __global__ __launch_bounds__(256) void gate_logsigmoid_kernel(const T* __restric
 // K12b -- the gate projection and the gate in one pass (reference model/gla.py:107-109,174-180): the second factor of the
 // low-rank gate projection has an inner dimension of 16, so pre = lr W^T + b is 16 FMAs per element from a 32-byte row of lr
 // (wave-uniform: scalar loads) and the 4 x 16 weights a thread keeps in registers -- the [R, C] pre-activation never exists
-// in memory, forward or backward.  A thread owns 4 columns and walks the rows of its workgroup's slab (kGateRows rows, 8 at a
-// time with all loads first); backward it also carries dW [4][16] and db [4] of its columns, written once per workgroup as
-// fp32 partials [workgroup][C][L + 1] (slot L = bias) the caller sums -- torch's chain for the same work was a 10-TFLOP/s
-// [C, R] x [R, 16] GEMM, two column sums and the bias add on top of the elementwise kernels.
+// in memory, forward or backward.  A workgroup takes kGateRows rows x 256 columns: each of its 4 waves a quarter of the rows
+// (8 at a time, all loads first), each lane 4 columns; backward a lane also carries dW [4][16] and db [4] of its columns,
+// the 4 waves add theirs through LDS and the workgroup writes ONE fp32 partial [C-block][L + 1] (slot L = bias) per row slab,
+// which the caller sums -- torch's chain for the same work was a 10-TFLOP/s [C, R] x [R, 16] GEMM, two column sums and the
+// bias add on top of the elementwise kernels.  (First form: 4 waves side by side over 1024 columns, 256 workgroups = one
+// wave per SIMD: 120 / 134 us, latency-bound; this form has 4 per SIMD.)
 // Rounding follows the autocast chain it replaces: weights and bias rounded to T, fp32 accumulate, pre rounded to T.
 constexpr int kGateRows = LINA_GATE_LOWRANK_ROWS;
 constexpr int kGateL = 16;
@@ -295,7 +370,10 @@ __global__ __launch_bounds__(256) void gate_lowrank_kernel(const T* __restrict__
                                                            const float* __restrict__ b, const T* __restrict__ dy, T* __restrict__ out,
                                                            float* __restrict__ dwb_partial, int64_t R, int C, int L,
                                                            float inv_norm, float clamp_min, int has_clamp) {
-    const int c0 = (blockIdx.y * 256 + threadIdx.x) * 4;
+    constexpr int kAcc = 4 * (kGateL + 1), kPad = kAcc + 1;           // per-lane accumulators; odd LDS stride
+    __shared__ float s_red[BWD ? 4 * 64 * kPad : 1];
+    const int lane = threadIdx.x & 63, wv = wave_uniform(threadIdx.x >> 6);
+    const int c0 = (blockIdx.y * 64 + lane) * 4;
     const bool col_ok = c0 < C;
     const int cc = col_ok ? c0 : C - 4;
     float wr[4][kGateL], br[4];
@@ -312,8 +390,8 @@ __global__ __launch_bounds__(256) void gate_lowrank_kernel(const T* __restrict__
 #pragma unroll
             for (int j = 0; j < kGateL; ++j) dwa[c][j] = 0.0f;
     }
-    const int64_t r_begin = (int64_t)blockIdx.x * kGateRows;
-    const int64_t r_end = r_begin + kGateRows < R ? r_begin + kGateRows : R;
+    const int64_t r_begin = (int64_t)blockIdx.x * kGateRows + wv * (kGateRows / 4);
+    const int64_t r_end = r_begin + kGateRows / 4 < R ? r_begin + kGateRows / 4 : R;
     for (int64_t r0 = r_begin; r0 < r_end; r0 += kGateUnroll) {
         typename raw4<T>::type dr[kGateUnroll];
         if (BWD) {
@@ -326,7 +404,7 @@ __global__ __launch_bounds__(256) void gate_lowrank_kernel(const T* __restrict__
 #pragma unroll
         for (int u = 0; u < kGateUnroll; ++u) {
             const int64_t r = r0 + u;
-            if (r >= r_end) break;                                   // workgroup-uniform
+            if (r >= r_end) break;                                   // wave-uniform
             float lv[kGateL];
             load_lr_row(lr + r * lr_stride, L, FULL, lv);
             float pre[4];
@@ -359,19 +437,49 @@ __global__ __launch_bounds__(256) void gate_lowrank_kernel(const T* __restrict__
             if (col_ok) st4(out + r * C + c0, make_float4(o[0], o[1], o[2], o[3]));
         }
     }
-    if (BWD && col_ok) {
-        float* dst = dwb_partial + ((int64_t)blockIdx.x * C + c0) * (L + 1);
+    if (BWD) {
+        // the 4 waves' sums -> LDS [wave][lane][kAcc], added and written as one contiguous run of 64 x kAcc floats
+        float* mine = s_red + (wv * 64 + lane) * kPad;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int j = 0; j < kGateL; ++j)
-                if (FULL || j < L) dst[c * (L + 1) + j] = dwa[c][j];
-            dst[c * (L + 1) + L] = dba[c];
+            for (int j = 0; j < kGateL; ++j) mine[c * (kGateL + 1) + j] = dwa[c][j];
+            mine[c * (kGateL + 1) + kGateL] = dba[c];
+        }
+        __syncthreads();
+        const int ncol = C - blockIdx.y * 256 < 256 ? C - blockIdx.y * 256 : 256;          // columns of this block
+        float* dst = dwb_partial + ((int64_t)blockIdx.x * C + blockIdx.y * 256) * (L + 1);
+        for (int i = threadIdx.x; i < ncol * (L + 1); i += 256) {
+            const int col = i / (L + 1), k = i % (L + 1);               // column within the block, slot (L = bias)
+            const int src = (col >> 2) * kPad + (col & 3) * (kGateL + 1) + (k == L ? kGateL : k);
+            dst[i] = s_red[src] + s_red[64 * kPad + src] + s_red[128 * kPad + src] + s_red[192 * kPad + src];
         }
     }
 }
 
 }  // namespace lina
+
+extern "C" int lina_swiglu_bwd_partials(int64_t rows) {
+    return rows <= 0 ? 0 : (int)((rows + LINA_SWIGLU_COLSUM_ROWS - 1) / LINA_SWIGLU_COLSUM_ROWS);
+}
+
+extern "C" int lina_swiglu_bwd_colsum(const void* ds, const void* u, void* du, float* colsum_partial, int64_t rows, int Hd,
+                                      int64_t ld_u, int64_t ld_ds, int64_t ld_du, int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(ds && u && du && colsum_partial, "lina_swiglu_bwd_colsum: null pointer");
+    LINA_REQUIRE(rows > 0 && rows <= (int64_t)65535 * LINA_SWIGLU_COLSUM_ROWS, "lina_swiglu_bwd_colsum: bad row count");
+    LINA_REQUIRE(Hd >= 4 && Hd % 4 == 0 && ld_u % 4 == 0 && ld_ds % 4 == 0 && ld_du % 4 == 0,
+                 "lina_swiglu_bwd_colsum: Hd and the row strides must be multiples of 4");
+    LINA_REQUIRE(valid_dtype(dtype), "lina_swiglu_bwd_colsum: bad dtype %d", dtype);
+    dim3 grid((unsigned)lina_swiglu_bwd_partials(rows), (unsigned)((Hd + 255) / 256));
+    if (dtype == LINA_F32)
+        LINA_LAUNCH((swiglu_bwd_colsum_kernel<float>), grid, dim3(256), 0, stream, (const float*)ds, (const float*)u, (float*)du,
+                    colsum_partial, rows, Hd, ld_u, ld_ds, ld_du);
+    else
+        LINA_LAUNCH((swiglu_bwd_colsum_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)ds, (const bf16_t*)u,
+                    (bf16_t*)du, colsum_partial, rows, Hd, ld_u, ld_ds, ld_du);
+    return check_launch("lina_swiglu_bwd_colsum");
+}
 
 extern "C" int lina_gate_lowrank_partials(int64_t rows) {
     return rows <= 0 ? 0 : (int)((rows + LINA_GATE_LOWRANK_ROWS - 1) / LINA_GATE_LOWRANK_ROWS);
@@ -390,7 +498,7 @@ extern "C" int lina_gate_lowrank(const void* lr, int64_t lr_stride, const float*
     LINA_REQUIRE(normalizer != 0.0f, "lina_gate_lowrank: normalizer must be non-zero");
     LINA_REQUIRE(valid_dtype(dtype), "lina_gate_lowrank: bad dtype %d", dtype);
     const int has_clamp = (clamp_min == clamp_min) ? 1 : 0;          // NaN = no clamp
-    dim3 grid((unsigned)lina_gate_lowrank_partials(rows), (unsigned)((C / 4 + 255) / 256));
+    dim3 grid((unsigned)lina_gate_lowrank_partials(rows), (unsigned)((C + 255) / 256));
     const bool full = L == kGateL && lr_stride % 2 == 0 && (reinterpret_cast<uintptr_t>(lr) & 3) == 0;
 #define LINA_GLR(TT, BB, FF)                                                                                         \
     LINA_LAUNCH((gate_lowrank_kernel<TT, BB, FF>), grid, dim3(256), 0, stream, (const TT*)lr, lr_stride, w, b, (const TT*)dy, \

@@ -814,6 +814,99 @@ def linear(x, weight, bias=None):
     return _LinearFunction.apply(x, weight, bias)
 
 
+_MLP_PAD = 128          # the hidden dimension of the channel mixer is padded to a multiple of this (+ the bias column)
+
+
+class _SwiGLUMLPFunction(torch.autograd.Function):
+    """The channel mixer ``p_out(silu(a) * b)``, ``(a, b) = p_in(x).chunk(2)`` (reference model/base_blocks.py:42-50) as ONE
+    node for the train path.  L169's hidden size is 1365 = 1024 * 4 // 3: rows of 1365 / 2730 elements are not 16-byte
+    aligned and the GEMM library runs every one of the six GEMMs 15-35 % slower on them (profiles/r03_pad_gemm.txt).  Here
+    the operands live in a PADDED layout: hidden Hp = the next multiple of 128 above H, the halves of the up-projection at
+    rows [0, H) and [Hp, Hp + H) of a zero-padded weight, the pad columns of the gate exactly 0 -- except column H, which
+    the bias pack makes exactly 1 (a = 32, b = 1/32: silu(32) * (1/32) == 1 in fp32 and in bf16), so that the
+    down-projection's bias is column H of its padded weight and its gradient column H of the padded weight gradient: no
+    bias epilogue, no column sum.  The up-projection's bias gradient is summed inside the gate's backward (K11c)."""
+
+    @staticmethod
+    def forward(ctx, x, w_in, b_in, w_out, b_out):
+        be = _BACKEND
+        cd = x.dtype
+        if x.is_cuda and torch.is_autocast_enabled("cuda"):
+            cd = torch.get_autocast_dtype("cuda")
+        H, d_out, d_in = w_out.shape[1], w_out.shape[0], w_in.shape[1]
+        Hp = (H + _MLP_PAD) // _MLP_PAD * _MLP_PAD                    # > H: room for the bias column
+        dev = x.device
+        x2 = x.reshape(-1, d_in).to(cd).contiguous()
+        with torch.autocast(dev.type, enabled=False):
+            Wi = torch.empty(2, Hp, d_in, dtype=cd, device=dev)
+            Wi[:, H:].zero_()
+            Wi[:, :H].copy_(w_in.detach().view(2, H, d_in))
+            bi = torch.zeros(2, Hp, dtype=cd, device=dev)
+            if b_in is not None:
+                bi[:, :H].copy_(b_in.detach().view(2, H))
+            Wo = torch.empty(d_out, Hp, dtype=cd, device=dev)
+            Wo[:, H:].zero_()
+            Wo[:, :H].copy_(w_out.detach())
+            if b_out is not None:
+                bi[:, H] = _mlp_one(cd, dev)
+                Wo[:, H].copy_(b_out.detach())
+            u = torch.addmm(bi.view(-1), x2, Wi.view(2 * Hp, d_in).t())
+            h = torch.empty(x2.shape[0], Hp, dtype=cd, device=dev)
+            _check(be.lib.lina_swiglu(_ptr(u), _ptr(h), x2.shape[0], Hp, u.stride(0), h.stride(0), _dt(u), be.stream(u)))
+            y = torch.mm(h, Wo.t())
+        ctx.save_for_backward(x2, u, h, Wi, Wo)
+        ctx.meta = (x.shape, x.dtype, H, Hp, w_in.dtype, None if b_in is None else b_in.dtype, w_out.dtype,
+                    None if b_out is None else b_out.dtype)
+        return y.view(*x.shape[:-1], d_out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, u, h, Wi, Wo = ctx.saved_tensors
+        x_shape, xdt, H, Hp, widt, bidt, wodt, bodt = ctx.meta
+        be = _BACKEND
+        d_out, d_in = Wo.shape[0], x2.shape[1]
+        M = x2.shape[0]
+        with torch.autocast(x2.device.type, enabled=False):
+            dy2 = dy.reshape(M, d_out).to(x2.dtype).contiguous()
+            dh = torch.mm(dy2, Wo)
+            dWo = linear_weight_grad(dy2, h)                                         # [d_out, Hp] fp32; column H = db_out
+            du = torch.empty_like(u)
+            part = torch.empty(int(be.lib.lina_swiglu_bwd_partials(M)), 2 * Hp, dtype=torch.float32, device=u.device)
+            _check(be.lib.lina_swiglu_bwd_colsum(_ptr(dh), _ptr(u), _ptr(du), _ptr(part), M, Hp, u.stride(0), dh.stride(0),
+                                                 du.stride(0), _dt(u), be.stream(u)))
+            dx = torch.mm(du, Wi.view(2 * Hp, d_in)).view(x_shape).to(xdt) if ctx.needs_input_grad[0] else None
+            dWi = linear_weight_grad(du, x2).view(2, Hp, d_in)
+            dw_in = dWi[:, :H].reshape(2 * H, d_in).to(widt)
+            db_in = None if bidt is None else part.sum(0).view(2, Hp)[:, :H].reshape(2 * H).to(bidt)
+            dw_out = dWo[:, :H].to(wodt)
+            db_out = None if bodt is None else dWo[:, H].to(bodt)
+        return dx, dw_in, db_in, dw_out, db_out
+
+
+_MLP_ONE = {}
+
+
+def _mlp_one(dtype, device):
+    """(32, 1/32): the bias pair that makes the gate's column H exactly 1 (cached per dtype / device)."""
+    key = (dtype, device)
+    if key not in _MLP_ONE:
+        _MLP_ONE[key] = torch.tensor([32.0, 1.0 / 32.0], dtype=dtype, device=device)
+    return _MLP_ONE[key]
+
+
+def swiglu_mlp(x, w_in, b_in, w_out, b_out):
+    """``F.linear(silu(a) * b, w_out, b_out)`` with ``(a, b) = F.linear(x, w_in, b_in).chunk(2, -1)`` -- the channel mixer of
+    a block (reference model/base_blocks.py:42-50).  With gradients on the fused-op devices: one autograd node on padded
+    operands (see ``_SwiGLUMLPFunction``); otherwise the three ops."""
+    ok = (torch.is_grad_enabled() and (x.requires_grad or w_in.requires_grad or w_out.requires_grad)
+          and fused_ops_available(x) and w_in.shape[0] == 2 * w_out.shape[1])
+    cd = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled("cuda")) else x.dtype
+    if not ok or cd not in (torch.float32, torch.bfloat16) or x.numel() == 0:
+        return linear(swiglu_gate(linear(x, w_in, b_in)), w_out, b_out)
+    _BACKEND.require(x, w_in, w_out)
+    return _SwiGLUMLPFunction.apply(x, w_in, b_in, w_out, b_out)
+
+
 class _GateLogSigmoidFunction(torch.autograd.Function):
     """K12: logsigmoid(x) / normalizer (optionally clamped) and its gradient, one pass each."""
 

@@ -649,6 +649,35 @@ def check_gate_lowrank(dev, B, T, C, L, dtype, clamp, bias=True, strided=False):
         assert_close(wd.grad, w64.grad, 5e-2, "K12b dW (clamped)")
 
 
+def check_swiglu_mlp(dev, B, T, d, H, dtype, bias=True):
+    """ops.swiglu_mlp (padded one-node channel mixer: K11, K11c, bias column) against fp64 autograd of the plain chain on
+    the same (dtype-rounded) operands: y and every gradient."""
+    g = torch.Generator().manual_seed(47)
+    x = torch.randn(B, T, d, generator=g).to(dtype)
+    w_in = (torch.randn(2 * H, d, generator=g) / d ** 0.5).to(dtype)
+    b_in = torch.randn(2 * H, generator=g).to(dtype) if bias else None
+    w_out = (torch.randn(d, H, generator=g) / H ** 0.5).to(dtype)
+    b_out = torch.randn(d, generator=g).to(dtype) if bias else None
+    dy = torch.randn(B, T, d, generator=g).to(dtype)
+    ts = [x, w_in, b_in, w_out, b_out]
+    r = [None if t is None else t.to(F64).requires_grad_() for t in ts]
+    a, b = F.linear(r[0], r[1], r[2]).chunk(2, -1)
+    y64 = F.linear(F.silu(a) * b, r[3], r[4])
+    (y64 * dy.to(F64)).sum().backward()
+    m = [None if t is None else t.to(dev).requires_grad_() for t in ts]
+    y = ops.swiglu_mlp(*m)
+    assert y.dtype == dtype and y.shape == x.shape[:-1] + (d,)
+    assert type(y.grad_fn).__name__ == "_SwiGLUMLPFunctionBackward", type(y.grad_fn).__name__
+    lo = dtype == torch.bfloat16
+    tol = 3e-2 if lo else 2e-5
+    assert_close(y, y64.detach(), tol, "MLP y")
+    (y.float() * dy.to(dev).float()).sum().backward()
+    for mine, ref, what in zip(m, r, ("dx", "dW_in", "db_in", "dW_out", "db_out")):
+        if mine is not None:
+            assert mine.grad.shape == ref.grad.shape and mine.grad.dtype == dtype, what
+            assert_close(mine.grad, ref.grad, tol, "MLP " + what)
+
+
 def check_argmax(dev, rows, n, dtype):
     g = torch.Generator().manual_seed(5)
     lg = torch.randn(rows, n, generator=g).to(dtype)

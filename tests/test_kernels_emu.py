@@ -330,3 +330,10 @@ def test_split_slab(emu, B, T, H, D, dtype, in_place):
 def test_gate_lowrank(emu, B, T, C, L, clamp, bias, strided, dtype):
     from kernel_cases import check_gate_lowrank
     check_gate_lowrank(DEV, B, T, C, L, dtype, clamp, bias, strided)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,d,H,bias", [(2, 70, 48, 21, True), (1, 300, 32, 128, False)])
+def test_swiglu_mlp(emu, B, T, d, H, bias, dtype):
+    from kernel_cases import check_swiglu_mlp
+    check_swiglu_mlp(DEV, B, T, d, H, dtype, bias)

@@ -439,3 +439,10 @@ def test_linear_train_path_under_autocast(hip, n_out, n_in, bias):
 def test_gate_lowrank(hip, B, T, C, L, clamp, bias, strided, dtype):
     from kernel_cases import check_gate_lowrank
     check_gate_lowrank(DEV, B, T, C, L, dtype, clamp, bias, strided)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,d,H,bias", [(2, 70, 48, 21, True), (4, 2048, 1024, 1365, True), (1, 300, 256, 128, False)])
+def test_swiglu_mlp(hip, B, T, d, H, bias, dtype):
+    from kernel_cases import check_swiglu_mlp
+    check_swiglu_mlp(DEV, B, T, d, H, dtype, bias)
