@@ -266,6 +266,10 @@ int lina_swiglu_bwd(const void* ds, const void* u, void* du, int64_t rows, int H
 int lina_gate_logsigmoid(const void* x, const void* dy, void* out, int64_t n, float normalizer, float clamp_min, int dtype,
                          lina_stream_t stream);
 
+/* K13 -- second level of the parameter-gradient sums: out[o][n] = sum_p part[o][p][n], part fp32 [outer][P][N] (the
+ * `*_partial` outputs of K3b / K5b / K10b / K11c / K12b), out [outer][N] of out_dtype; N a multiple of 4. */
+int lina_sum_partials(const float* part, void* out, int outer, int P, int64_t N, int out_dtype, lina_stream_t stream);
+
 /* K11c -- K11b that also leaves the column sums of du (the bias gradient of the up-projection):
  *   colsum_partial fp32 [lina_swiglu_bwd_partials(rows)][2 Hd], summed over dim 0 by the caller (sums of the values as
  *   stored in `dtype`).  Hd and the row strides must be multiples of 4. */

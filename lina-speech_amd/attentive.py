@@ -69,12 +69,19 @@ class AttentiveGLA(AttentiveRNN):
     def forward(self, x, ctx, mask=None, pos=None, reset_mask=None, attention_only=None, forced_attention=None,
                 init_state=None, crossatt_pos=None):
         kw = dict(use_cache=init_state is not None, past_key_values=init_state)
+        # the blocks are chained on (stream, pending branch): a block's last residual add rides in the next block's first
+        # norm pass instead of a pass of its own (MixingBlock.forward); the values are those of the plain loop
+        pend = None
         for blk in self.encoder:
-            x = (_maybe_grad_ckpt(blk) if self.training else blk)(x, **kw)
+            x, pend = (_maybe_grad_ckpt(blk) if self.training else blk)(x, _pending=pend, _defer=True, **kw)
+        if pend is not None:
+            x = x + pend
         v, att = self.cross_att(x, ctx, mask=mask, reset_mask=reset_mask, pos=crossatt_pos)
-        x = x + v
+        pend = v                                                # x + v: added by the first decoder block's norm
         for blk in self.decoder:
-            x = (_maybe_grad_ckpt(blk) if self.training else blk)(x, **kw)
+            x, pend = (_maybe_grad_ckpt(blk) if self.training else blk)(x, _pending=pend, _defer=True, **kw)
+        if pend is not None:
+            x = x + pend
         return x, att
 
     def init_state(self, max_seqlen: int = 1000, batch_size: int = 16) -> Cache:

@@ -37,22 +37,43 @@ class MixingBlock(nn.Module):
         self.norm1, self.norm2 = norm(), norm()
         self.drop = nn.Dropout(dropout)
 
-    def forward(self, x, **kwargs):
+    def can_defer(self, x) -> bool:
+        """True when this block can take / hand on a PENDING branch (``forward(..., _pending=, _defer=)``): both norms are
+        LayerNorms on the fused kernel and the block's dropout is the identity."""
+        from . import ops
+        return (isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm) and ops.fused_ops_available(x)
+                and not (self.training and self.drop.p > 0))
+
+    def forward(self, x, _pending=None, _defer: bool = False, **kwargs):
+        """``x += tmix(norm1(x)); x += cmix(norm2(x)); dropout`` (reference base_blocks.py:65-69).
+        A stack of blocks may chain them without materialising the stream in between: ``_pending`` is a branch output the
+        previous block has NOT yet added to ``x`` (it is added inside this block's norm1 pass, K10), and with ``_defer``
+        the block returns ``(x, branch)`` with its own last branch still to be added -- ``x + branch`` is the block's
+        output.  Both default to the plain form."""
         from . import ops
         ln = isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm) and ops.fused_ops_available(x)
         if not ln:
+            if _pending is not None:
+                x = x + _pending
             y = self.tmix(self.norm1(x), **kwargs)
             x = (y[0] if type(y) is tuple else y) + x
-            x = self.cmix(self.norm2(x)) + x
-            return self.drop(x)
-        # K10: the norms run on the HIP kernel (fp32 stream in, GEMM-dtype operand out) and the residual add that
-        # precedes norm2 rides in its pass -- same arithmetic as the lines above (reference base_blocks.py:65-69)
+            x = self.drop(self.cmix(self.norm2(x)) + x)
+            return (x, None) if _defer else x
+        # K10: the norms run on the HIP kernel (fp32 stream in, GEMM-dtype operand out) and the residual adds ride in
+        # their passes -- same arithmetic as the lines above
         n1, n2 = self.norm1, self.norm2
-        y = self.tmix(ops.layer_norm(x, n1.weight, n1.bias, n1.eps), **kwargs)
+        if _pending is not None:
+            h, x = ops.layer_norm(x, n1.weight, n1.bias, n1.eps, residual=_pending)
+        else:
+            h = ops.layer_norm(x, n1.weight, n1.bias, n1.eps)
+        y = self.tmix(h, **kwargs)
         y = y[0] if type(y) is tuple else y
         h, x = ops.layer_norm(x, n2.weight, n2.bias, n2.eps, residual=y)
-        x = self.cmix(h) + x
-        return self.drop(x)
+        c = self.cmix(h)
+        if _defer and self.can_defer(x):
+            return x, c
+        x = self.drop(c + x)
+        return (x, None) if _defer else x
 
 
 class RotaryEmbedding(nn.Module):

@@ -296,6 +296,44 @@ __global__ __launch_bounds__(256) void swiglu_bwd_colsum_kernel(const T* __restr
     }
 }
 
+// K13 -- second level of the two-level parameter-gradient sums: out[o][n] = sum_p part[o][p][n] (fp32 partials written by
+// K3b / K5b / K10b / K11c / K12b, one row per workgroup of those kernels).  A workgroup takes 256 columns: a lane 4 of them,
+// each of the 4 waves every 4th partial row (8 rows requested before the first is used); the waves meet in LDS.  torch's
+// generic reduction took 12-23 us on each of these 2-20 MB inputs, ~100 of them per train step.
+template <typename TO>
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, TO* __restrict__ out, int P, int64_t N) {
+    constexpr int U = 8;
+    __shared__ float4 s_red[3][64];
+    const int lane = threadIdx.x & 63, wv = wave_uniform(threadIdx.x >> 6);
+    const int64_t n = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    const bool ok = n < N;
+    const float* src = part + (int64_t)blockIdx.y * P * N + (ok ? n : N - 4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p0 = wv; p0 < P; p0 += 4 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int p = p0 + 4 * q;
+            v[q] = *reinterpret_cast<const float4*>(src + (int64_t)(p < P ? p : P - 1) * N);
+        }
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            if (p0 + 4 * q >= P) break;                              // wave-uniform
+            acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w;
+        }
+    }
+    if (wv > 0) s_red[wv - 1][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && ok) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float4 c = s_red[o][lane];
+            acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
+        }
+        st4(out + (int64_t)blockIdx.y * N + n, acc);
+    }
+}
+
 // K12 -- the gate of the mixer for a whole sequence (reference model/gla.py:174-180): y = logsigmoid(x) / normalizer
 // (optionally clamped from below), and its gradient dx = dy (1 - sigmoid(x)) / normalizer (0 where the clamp is active).
 // Elementwise over n4 groups of 4 elements; torch's chain (log_sigmoid with its second output, the division, their two
@@ -458,6 +496,20 @@ __global__ __launch_bounds__(256) void gate_lowrank_kernel(const T* __restrict__
 }
 
 }  // namespace lina
+
+extern "C" int lina_sum_partials(const float* part, void* out, int outer, int P, int64_t N, int out_dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(part && out, "lina_sum_partials: null pointer");
+    LINA_REQUIRE(outer >= 1 && outer <= 65535 && P >= 1 && N >= 4 && N % 4 == 0,
+                 "lina_sum_partials: bad shape outer=%d P=%d N=%lld (N must be a multiple of 4)", outer, P, (long long)N);
+    LINA_REQUIRE(valid_dtype(out_dtype), "lina_sum_partials: bad dtype %d", out_dtype);
+    dim3 grid((unsigned)((N / 4 + 63) / 64), (unsigned)outer);
+    if (out_dtype == LINA_F32)
+        LINA_LAUNCH((sum_partials_kernel<float>), grid, dim3(256), 0, stream, part, (float*)out, P, N);
+    else
+        LINA_LAUNCH((sum_partials_kernel<bf16_t>), grid, dim3(256), 0, stream, part, (bf16_t*)out, P, N);
+    return check_launch("lina_sum_partials");
+}
 
 extern "C" int lina_swiglu_bwd_partials(int64_t rows) {
     return rows <= 0 ? 0 : (int)((rows + LINA_SWIGLU_COLSUM_ROWS - 1) / LINA_SWIGLU_COLSUM_ROWS);

@@ -380,6 +380,30 @@ def _short_conv_launch(x, w, bias, mask, cache, act):
     return y
 
 
+def _sum_partials(part, out_dtype=torch.float32):
+    """K13: sum over the partial-row axis of the fp32 ``*_partial`` buffer of a backward kernel -- ``part`` [P, ...] ->
+    [...], or with ``outer`` leading slabs [O, P, ...] -> [O, ...] when ``part.dim() - 1`` trailing dims are given as one."""
+    P = part.shape[0]
+    N = part.numel() // max(P, 1)
+    if N % 4 or N == 0 or out_dtype not in (torch.float32, torch.bfloat16):
+        return part.sum(0).to(out_dtype)
+    be = _BACKEND
+    out = torch.empty(part.shape[1:], dtype=out_dtype, device=part.device)
+    _check(be.lib.lina_sum_partials(_ptr(part), _ptr(out), 1, P, N, _dt(out), be.stream(part)))
+    return out
+
+
+def _sum_partials2(part):
+    """``part`` fp32 [O, P, N] -> [O, N] (K13 with an outer axis: the two parameter gradients of the LayerNorm)."""
+    O, P, N = part.shape
+    if N % 4 or N == 0:
+        return part.sum(1)
+    be = _BACKEND
+    out = torch.empty(O, N, dtype=torch.float32, device=part.device)
+    _check(be.lib.lina_sum_partials(_ptr(part), _ptr(out), O, P, N, _dt(out), be.stream(part)))
+    return out
+
+
 class GradSlab:
     """Backward-time buffer [..., sum(sizes)] for the output gradient of a stacked projection: the consumers of its column
     slices write their input gradients straight into their columns (``part``), so the projection's backward finds dZ
@@ -446,6 +470,11 @@ class _ShortConvFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, mask, act, cache=None, grad_slab=None):
+        # w / bias arrive in the PARAMETER dtype (fp32 master weights under autocast): cast here, once, outside autograd --
+        # the gradients leave in the parameter dtype straight from the fp32 partial sums
+        ctx.w_dtype, ctx.b_dtype = w.dtype, (None if bias is None else bias.dtype)
+        w = w.to(x.dtype).contiguous()
+        bias = None if bias is None else bias.to(x.dtype).contiguous()
         ctx.save_for_backward(x, w, bias, mask)
         ctx.act = act
         ctx.grad_slab = grad_slab
@@ -468,9 +497,9 @@ class _ShortConvFunction(torch.autograd.Function):
         _check(be.lib.lina_short_conv_bwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(mask), _ptr(dy), _ptr(dx), _ptr(part),
                                           B, T, D, W, x.stride(0), x.stride(1), dy.stride(0), dy.stride(1),
                                           dx.stride(0), dx.stride(1), ctx.act, _dt(x), be.stream(x)))
-        red = part.sum(0)
-        dw = red[:, :W].to(w.dtype)
-        db = None if bias is None else red[:, W].to(bias.dtype)
+        red = _sum_partials(part)
+        dw = red[:, :W].to(ctx.w_dtype, copy=True)               # contiguous [D, W] in the parameter's dtype
+        db = None if bias is None else red[:, W].to(ctx.b_dtype, copy=True)
         return dx, dw, db, None, None, None, None
 
 
@@ -485,6 +514,7 @@ def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional
     be = _BACKEND
     be.require(x, w, bias, mask, cache)
     x = _inner_contig(x)
+    w_param, bias_param = w, bias
     w = w.to(x.dtype).contiguous()
     bias = None if bias is None else bias.to(x.dtype).contiguous()
     act = 1 if activation in ("silu", "swish") else 0
@@ -502,7 +532,7 @@ def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional
     if _needs_grad(x, w, bias):
         if cache is not None and T == 1:
             raise NotImplementedError("short_conv: gradients are built for the prefill form (T > 1 or no cache) only")
-        y = _ShortConvFunction.apply(x, w, bias, m, act, cache, grad_slab)
+        y = _ShortConvFunction.apply(x, w_param, bias_param, m, act, cache, grad_slab)
     else:
         if cache is not None and T == 1:
             m = mask
@@ -527,6 +557,8 @@ class _RMSNormGateFunction(torch.autograd.Function):
     def forward(ctx, x, g, w, eps, grad_slab=None):
         be = _BACKEND
         rows, D = x.shape
+        ctx.w_dtype = None if w is None else w.dtype       # the PARAMETER dtype: cast here, gradient returned in it
+        w = None if w is None else w.to(x.dtype).contiguous()
         y = torch.empty_like(x)
         ri, go, gi = _RMSNormGateFunction._gate_strides(g, D)
         _check(be.lib.lina_rmsnorm_gate_fwd(_ptr(x), _ptr(g), _ptr(w), _ptr(y), rows, ri, D, D * ri, D if ri > 1 else 0,
@@ -558,7 +590,7 @@ class _RMSNormGateFunction(torch.autograd.Function):
         part = torch.empty(npart, D, dtype=torch.float32, device=x.device)
         _check(be.lib.lina_rmsnorm_gate_bwd(_ptr(x), _ptr(g), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dg), _ptr(part),
                                             rows, ri, D, go, gi, dgo, dgi, ctx.eps, _dt(x), be.stream(x)))
-        dw = None if w is None else part.sum(0).to(w.dtype)
+        dw = None if w is None else _sum_partials(part, ctx.w_dtype)
         return dx, dg, dw, None, None
 
 
@@ -593,8 +625,7 @@ def rmsnorm_swish_gate(x, g=None, weight=None, eps: float = 1e-5, n_partial: int
             g2 = g.to(odt)
             g3 = _gate_rows_view(g2, D) if g2.shape == x.shape and g2.dim() >= 3 else None
             g2 = g3 if g3 is not None else g2.reshape(-1, D).contiguous()
-        w2 = None if weight is None else weight.to(odt).contiguous()
-        return _RMSNormGateFunction.apply(x2, g2, w2, float(eps), grad_slab).view(x.shape)
+        return _RMSNormGateFunction.apply(x2, g2, weight, float(eps), grad_slab).view(x.shape)
     xs = x.contiguous()
     part_stride = xs.stride(0) if n_partial > 1 else 0
     shape = xs.shape[1:] if n_partial > 1 else xs.shape
@@ -659,7 +690,7 @@ class _LayerNormFunction(torch.autograd.Function):
         _check(be.lib.lina_layernorm_bwd(_ptr(dy), _ptr(xs), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dpass), _ptr(dx),
                                          _ptr(dr), _ptr(part[0]), _ptr(part[1]), N, D, _dt(xs), ctx.rdt, _dt(dy),
                                          be.stream(xs)))
-        sums = part.sum(1)
+        sums = _sum_partials2(part)
         d_r = None
         if ctx.has_r:
             d_r = dr if dr is not None else dx          # same values: the add passes the gradient through unchanged
@@ -877,7 +908,7 @@ class _SwiGLUMLPFunction(torch.autograd.Function):
             dx = torch.mm(du, Wi.view(2 * Hp, d_in)).view(x_shape).to(xdt) if ctx.needs_input_grad[0] else None
             dWi = linear_weight_grad(du, x2).view(2, Hp, d_in)
             dw_in = dWi[:, :H].reshape(2 * H, d_in).to(widt)
-            db_in = None if bidt is None else part.sum(0).view(2, Hp)[:, :H].reshape(2 * H).to(bidt)
+            db_in = None if bidt is None else _sum_partials(part).view(2, Hp)[:, :H].reshape(2 * H).to(bidt)
             dw_out = dWo[:, :H].to(wodt)
             db_out = None if bodt is None else dWo[:, H].to(bodt)
         return dx, dw_in, db_in, dw_out, db_out
@@ -974,7 +1005,7 @@ class _GateLowRankFunction(torch.autograd.Function):
         part = torch.empty(int(be.lib.lina_gate_lowrank_partials(rows)), C_, L + 1, dtype=torch.float32, device=dy2.device)
         _check(be.lib.lina_gate_lowrank(_ptr(lr2), lr2.stride(0), _ptr(wf), _ptr(bf), _ptr(dy2), _ptr(dpre), _ptr(part),
                                         rows, C_, L, normalizer, cm, _dt(lr2), be.stream(dy2)))
-        red = part.sum(0)
+        red = _sum_partials(part)
         dlr = None
         if ctx.needs_input_grad[0]:
             with torch.autocast(dy2.device.type, enabled=False):

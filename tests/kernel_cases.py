@@ -678,6 +678,41 @@ def check_swiglu_mlp(dev, B, T, d, H, dtype, bias=True):
             assert_close(mine.grad, ref.grad, tol, "MLP " + what)
 
 
+def check_block_chain(dev, dtype, B=2, T=70, d=64):
+    """MixingBlock chained on (stream, pending branch) -- the last residual add of a block inside the next block's norm1
+    pass (K10 with a residual), the way AttentiveGLA.forward runs a stack -- against the plain loop over the same blocks:
+    same output, same input / parameter gradients; and the chain really defers (a pending branch comes back)."""
+    import copy
+    import torch.nn as nn
+    from lina_speech_amd.blocks import MixingBlock, SwiGLU
+    torch.manual_seed(5)
+    blocks = nn.ModuleList([MixingBlock(lambda: nn.Linear(d, d), lambda: SwiGLU(d), lambda: nn.LayerNorm(d))
+                            for _ in range(3)]).to(dtype).to(dev)
+    plain = copy.deepcopy(blocks)
+    g = torch.Generator().manual_seed(6)
+    x0 = torch.randn(B, T, d, generator=g).to(dtype)
+    v0 = torch.randn(B, T, d, generator=g).to(dtype)
+    dy = torch.randn(B, T, d, generator=g).to(dtype).to(dev)
+    xa, va = x0.to(dev).requires_grad_(), v0.to(dev).requires_grad_()
+    x, pend = xa, va                                    # a branch handed in from outside (the cross-attention output)
+    for blk in blocks:
+        x, pend = blk(x, _pending=pend, _defer=True)
+        assert pend is not None and blk.can_defer(x)
+    ya = x + pend
+    (ya.float() * dy.float()).sum().backward()
+    xb, vb = x0.to(dev).requires_grad_(), v0.to(dev).requires_grad_()
+    x = xb + vb
+    for blk in plain:
+        x = blk(x)
+    (x.float() * dy.float()).sum().backward()
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert_close(ya, x, tol, "chain y")
+    assert_close(xa.grad, xb.grad, tol, "chain dx")
+    assert_close(va.grad, vb.grad, tol, "chain dpending")
+    for (n, pa), (_, pb) in zip(blocks.named_parameters(), plain.named_parameters()):
+        assert_close(pa.grad, pb.grad, tol, "chain d" + n)
+
+
 def check_argmax(dev, rows, n, dtype):
     g = torch.Generator().manual_seed(5)
     lg = torch.randn(rows, n, generator=g).to(dtype)

@@ -337,3 +337,9 @@ def test_gate_lowrank(emu, B, T, C, L, clamp, bias, strided, dtype):
 def test_swiglu_mlp(emu, B, T, d, H, bias, dtype):
     from kernel_cases import check_swiglu_mlp
     check_swiglu_mlp(DEV, B, T, d, H, dtype, bias)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_block_chain_with_pending_branch(emu, dtype):
+    from kernel_cases import check_block_chain
+    check_block_chain(DEV, dtype)

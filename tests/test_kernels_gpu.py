@@ -446,3 +446,9 @@ def test_gate_lowrank(hip, B, T, C, L, clamp, bias, strided, dtype):
 def test_swiglu_mlp(hip, B, T, d, H, bias, dtype):
     from kernel_cases import check_swiglu_mlp
     check_swiglu_mlp(DEV, B, T, d, H, dtype, bias)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_block_chain_with_pending_branch(hip, dtype):
+    from kernel_cases import check_block_chain
+    check_block_chain(DEV, dtype)
