@@ -297,36 +297,42 @@ __global__ __launch_bounds__(256) void swiglu_bwd_colsum_kernel(const T* __restr
 }
 
 // K13 -- second level of the two-level parameter-gradient sums: out[o][n] = sum_p part[o][p][n] (fp32 partials written by
-// K3b / K5b / K10b / K11c / K12b, one row per workgroup of those kernels).  A workgroup takes 256 columns: a lane 4 of them,
-// each of the 4 waves every 4th partial row (8 rows requested before the first is used); the waves meet in LDS.  torch's
-// generic reduction took 12-23 us on each of these 2-20 MB inputs, ~100 of them per train step.
+// K3b / K5b / K10b / K11c / K12b, one row per workgroup of those kernels).  These inputs are small (2-20 MB) and the sum is
+// LATENCY-bound: what matters is how many dependent load rounds a wave makes.  A workgroup of 16 waves takes 256 columns
+// (a lane 4 of them), wave w the partial rows w, w + 16, ... with 16 rows requested per round: P = 512 is 2 rounds per
+// wave.  (First form: 4 waves, 8 rows per round -- 16 rounds at P = 512, 40-100 us, slower than torch's generic
+// reduction at 12-23 us.)  The waves meet in LDS.
+constexpr int kSumWaves = 16, kSumRows = 16;
 template <typename TO>
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, TO* __restrict__ out, int P, int64_t N) {
-    constexpr int U = 8;
-    __shared__ float4 s_red[3][64];
+__global__ __launch_bounds__(64 * kSumWaves) void sum_partials_kernel(const float* __restrict__ part, TO* __restrict__ out, int P,
+                                                                      int64_t N) {
+    __shared__ float4 s_red[kSumWaves - 1][64];
     const int lane = threadIdx.x & 63, wv = wave_uniform(threadIdx.x >> 6);
     const int64_t n = ((int64_t)blockIdx.x * 64 + lane) * 4;
     const bool ok = n < N;
     const float* src = part + (int64_t)blockIdx.y * P * N + (ok ? n : N - 4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p0 = wv; p0 < P; p0 += 4 * U) {
-        float4 v[U];
+    for (int p0 = wv; p0 < P; p0 += kSumWaves * kSumRows) {
+        float4 v[kSumRows];
 #pragma unroll
-        for (int q = 0; q < U; ++q) {
-            const int p = p0 + 4 * q;
+        for (int q = 0; q < kSumRows; ++q) {
+            const int p = p0 + kSumWaves * q;
             v[q] = *reinterpret_cast<const float4*>(src + (int64_t)(p < P ? p : P - 1) * N);
         }
+        sched_fence();                                               // every load of the round before the first use
 #pragma unroll
-        for (int q = 0; q < U; ++q) {
-            if (p0 + 4 * q >= P) break;                              // wave-uniform
-            acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w;
+        for (int q = 0; q < kSumRows; ++q) {
+            // no branch here: a `break` made the compiler fold each load into its own load / wait / add / branch chain
+            const float m = p0 + kSumWaves * q < P ? 1.0f : 0.0f;
+            acc.x = fmaf(m, v[q].x, acc.x); acc.y = fmaf(m, v[q].y, acc.y);
+            acc.z = fmaf(m, v[q].z, acc.z); acc.w = fmaf(m, v[q].w, acc.w);
         }
     }
     if (wv > 0) s_red[wv - 1][lane] = acc;
     __syncthreads();
     if (wv == 0 && ok) {
 #pragma unroll
-        for (int o = 0; o < 3; ++o) {
+        for (int o = 0; o < kSumWaves - 1; ++o) {
             const float4 c = s_red[o][lane];
             acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
         }
@@ -505,9 +511,9 @@ extern "C" int lina_sum_partials(const float* part, void* out, int outer, int P,
     LINA_REQUIRE(valid_dtype(out_dtype), "lina_sum_partials: bad dtype %d", out_dtype);
     dim3 grid((unsigned)((N / 4 + 63) / 64), (unsigned)outer);
     if (out_dtype == LINA_F32)
-        LINA_LAUNCH((sum_partials_kernel<float>), grid, dim3(256), 0, stream, part, (float*)out, P, N);
+        LINA_LAUNCH((sum_partials_kernel<float>), grid, dim3(64 * kSumWaves), 0, stream, part, (float*)out, P, N);
     else
-        LINA_LAUNCH((sum_partials_kernel<bf16_t>), grid, dim3(256), 0, stream, part, (bf16_t*)out, P, N);
+        LINA_LAUNCH((sum_partials_kernel<bf16_t>), grid, dim3(64 * kSumWaves), 0, stream, part, (bf16_t*)out, P, N);
     return check_launch("lina_sum_partials");
 }
 
