@@ -46,7 +46,10 @@ class LinaModel(nn.Module):
 
     # ------------------------------------------------------------------ teacher-forced
     def forward(self, x, y, encoder_mask, crossatt_mask, logits_mask=None, attention_only=False,
-                forced_attention=None, init_state=None, crossatt_pos=None):
+                forced_attention=None, init_state=None, crossatt_pos=None, return_masked: bool = True):
+        """Reference modeling_lina.py:72-108.  ``return_masked=False`` (ours): skip the two gathered outputs -- their
+        boolean indexing has a data-dependent shape, i.e. a host sync, which a captured (hipGraph) train step cannot
+        contain; the loss does not need them."""
         x_embd = self.txt_embed(x)
         y_embd = self.rvq_embed(y.permute(2, 0, 1)).sum(0)            # 'b n q -> q b n' -> sum over q
         x_enc = self.txt_encoder(x_embd, mask=encoder_mask)
@@ -62,7 +65,9 @@ class LinaModel(nn.Module):
         target = y[:, 1:]
         if logits_mask is not None:
             keep = logits_mask[:, 1:]
-            masked_logits, masked_target = logits[keep, :, :], target[keep, :]      # returned, as the reference does
+            masked_logits = masked_target = None
+            if return_masked:
+                masked_logits, masked_target = logits[keep, :, :], target[keep, :]  # returned, as the reference does
             # the loss itself: masked positions carry the ignored class instead of being gathered out -- the same mean
             # over the same terms (reference modeling_lina.py:97-107), without the scatter of the gather in backward
             target = torch.where(keep.unsqueeze(-1), target, torch.ones_like(target))
