@@ -212,28 +212,39 @@ def measure_chunk_bwd(dev, B=8, H=4, T=4096, Dk=256, Dv=256, reps=100):
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS}
 
 
-def measure_train_step(dev, b=8, T=4096, steps=3):
+def measure_train_step(dev, b=8, T=4096, steps=5):
     """a-11: one L169 training step (teacher-forced forward, CE loss, backward through K2b/K3b/K5b, fused AdamW) in
     bf16 autocast on one GPU; synthetic config-5 batch."""
     from lina_speech_amd.configs import l169
     from lina_speech_amd.train import TrainStep, synthetic_batch
-    torch.manual_seed(0)
-    ts = TrainStep(l169(), device=dev, ddp=False)
-    batch = synthetic_batch(b=b, n=T + 1, t_txt=T_TXT, seed=1).to(dev)
-    for _ in range(2):
-        ts.step(batch)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = ts.step(batch)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    out = {"what": "L169 train step: fwd + CE + bwd + AdamW, bf16 autocast, fp32 master weights", "micro_batch": b,
-           "seq_len": T, "ms_per_step": dt * 1e3, "tokens_per_s": b * T / dt, "loss": float(loss),
-           "max_mem_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
-    del ts, batch
-    torch.cuda.empty_cache()
-    return out
+    def run(graph):
+        torch.manual_seed(0)
+        ts = TrainStep(l169(), device=dev, ddp=False, graph=graph)
+        batch = synthetic_batch(b=b, n=T + 1, t_txt=T_TXT, seed=1).to(dev)
+        for _ in range(2):
+            ts.step(batch)                  # (graph: the first call also captures, after 2 eager warm-up steps of its own)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = ts.step(batch)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res = {"ms_per_step": dt * 1e3, "tokens_per_s": b * T / dt, "loss": float(loss)}
+        del ts, batch
+        torch.cuda.empty_cache()
+        return res
+
+    eager = run(False)
+    try:                                    # the whole step as ONE hipGraph (TrainStep(graph=True)); eager figure beside it
+        captured = run(True)
+    except Exception as e:                  # noqa: BLE001 -- a capture failure must not cost the bench line
+        captured = {"error": f"{type(e).__name__}: {e}"[:300]}
+    best = captured if "ms_per_step" in captured and captured["ms_per_step"] <= eager["ms_per_step"] else eager
+    return {"what": "L169 train step: fwd + CE + bwd + AdamW, bf16 autocast, fp32 master weights", "micro_batch": b,
+            "seq_len": T, "ms_per_step": best["ms_per_step"], "tokens_per_s": best["tokens_per_s"], "loss": best["loss"],
+            "mode": "one hipGraph per step" if best is captured else "eager launches",
+            "eager": eager, "captured": captured, "steps_timed": steps,
+            "max_mem_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
 
 
 def measure_vocoder(dev, B=64, L=750, reps=3):

@@ -515,8 +515,6 @@ def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional
     be.require(x, w, bias, mask, cache)
     x = _inner_contig(x)
     w_param, bias_param = w, bias
-    w = w.to(x.dtype).contiguous()
-    bias = None if bias is None else bias.to(x.dtype).contiguous()
     act = 1 if activation in ("silu", "swish") else 0
     if activation not in ("silu", "swish", None):
         raise ValueError(f"activation {activation!r} not supported")
@@ -536,6 +534,8 @@ def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional
     else:
         if cache is not None and T == 1:
             m = mask
+        w = w.to(x.dtype).contiguous()
+        bias = None if bias is None else bias.to(x.dtype).contiguous()
         y = _short_conv_launch(x, w, bias, m, cache, act)
     if user_cache is not None:
         user_cache.copy_(cache)
