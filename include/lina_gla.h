@@ -266,6 +266,16 @@ int lina_swiglu_bwd(const void* ds, const void* u, void* du, int64_t rows, int H
 int lina_gate_logsigmoid(const void* x, const void* dy, void* out, int64_t n, float normalizer, float clamp_min, int dtype,
                          lina_stream_t stream);
 
+/* K14 -- cross-entropy over the rows of logits [N, V] (row stride ld, any V >= 4 up to 8445) against int64 targets,
+ * fp32 arithmetic (reference modeling_lina.py:106 `F.cross_entropy(flat_logits, flat_target, ignore_index=1)`):
+ *   forward  (loss_row given, dlogits NULL): lse[r] = logsumexp(logits[r]); loss_row[r] = lse[r] - logits[r, target[r]],
+ *            0 for rows whose target is ignore_index (the caller forms sum(loss_row) / count);
+ *   backward (dlogits given, loss_row NULL): dlogits[r] = (softmax(logits[r]) - onehot(target[r])) * scale[0] for rows
+ *            that count, 0 for ignored rows (row stride ld_d); scale is a DEVICE scalar (d loss / count). */
+int lina_cross_entropy(const void* logits, const int64_t* target, float* lse, float* loss_row, const float* scale,
+                       void* dlogits, int64_t N, int V, int64_t ld, int64_t ld_d, int64_t ignore_index, int dtype,
+                       lina_stream_t stream);
+
 /* K13 -- second level of the parameter-gradient sums: out[o][n] = sum_p part[o][p][n], part fp32 [outer][P][N] (the
  * `*_partial` outputs of K3b / K5b / K10b / K11c / K12b), out [outer][N] of out_dtype; N a multiple of 4. */
 int lina_sum_partials(const float* part, void* out, int outer, int P, int64_t N, int out_dtype, lina_stream_t stream);

@@ -340,6 +340,129 @@ __global__ __launch_bounds__(64 * kSumWaves) void sum_partials_kernel(const floa
     }
 }
 
+// K14 -- cross-entropy of the codec head's logits (reference modeling_lina.py:106, F.cross_entropy(..., ignore_index=1)): one
+// wave per row; the row (V = 4099 logits: 8 KB of bf16) is loaded ONCE into registers as NG aligned 4-element groups per lane
+// (rows of an odd width start on any 2-byte boundary: the groups are laid on the 8-byte grid below the row start and the
+// elements outside the row masked), then max, sum of exponentials and the target's logit come from registers.  The backward
+// rebuilds softmax from the row and the saved log-sum-exp: d logits = (softmax - onehot) * scale for rows that count, 0 for
+// ignored rows.  fp32 arithmetic from the stored dtype, as autocast's fp32 log_softmax -- without its fp32 copy of the logits
+// (537 MB at config 5), the two casts and the separate log_softmax / nll kernels and their backwards.
+__device__ __forceinline__ float4 pack4(const float (&e)[4]) { return make_float4(e[0], e[1], e[2], e[3]); }
+__device__ __forceinline__ uint2 pack4(const bf16_t (&e)[4]) {
+    return make_uint2((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16));
+}
+
+template <typename T, int NG> struct CeRow {
+    typename raw4<T>::type raw[NG];
+    int64_t a;          // element index of group 0 (multiple of 4, <= row start)
+    int lo, hi;         // the row's elements are the grid positions [lo, hi) relative to a
+    __device__ __forceinline__ void load(const T* __restrict__ logits, int64_t row, int64_t ld, int V, int lane, int64_t total) {
+        const int64_t b = row * ld;
+        a = b & ~(int64_t)3;
+        lo = (int)(b - a);
+        hi = lo + V;
+        // groups past the row are clamped back to the row's last readable group (their elements are masked in values()); the
+        // one group that may straddle the END OF THE TENSOR (last row only) is assembled from single-element loads
+        const int64_t last_grp = (b + V - 1) & ~(int64_t)3;           // the last group that holds elements of the row
+        const bool tail = last_grp + 4 > total;                       // wave-uniform: it reaches past the tensor
+        const int64_t last_ok = tail ? last_grp - 4 : last_grp;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int64_t e = a + 4 * ((int64_t)g * 64 + lane);
+            raw[g] = ld4_raw(logits + (e <= last_ok ? e : last_ok));
+        }
+        if (tail) {                                                   // scalar branch: the last row of the tensor only
+            const int64_t e0 = last_grp;                              // the straddling group
+            const int64_t q = (e0 - a) / 4;                           // its grid index: lane q % 64 of group q / 64
+            T el[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) el[c] = logits[e0 + c < total ? e0 + c : total - 1];
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                if (g == (int)(q / 64) && lane == (int)(q % 64)) raw[g] = pack4(el);
+        }
+    }
+    __device__ __forceinline__ void values(int g, int lane, float (&v)[4], bool (&in)[4], int64_t total) const {
+        const float4 f = cvt4(raw[g]);
+        const float fv[4] = {f.x, f.y, f.z, f.w};
+        const int p = 4 * (g * 64 + lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            in[c] = p + c >= lo && p + c < hi;                        // (clamped groups lie wholly past hi)
+            v[c] = fv[c];
+        }
+    }
+};
+
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, shfl_xor(v, 1)); v = fmaxf(v, shfl_xor(v, 2)); v = fmaxf(v, shfl_xor(v, 4));
+    v = fmaxf(v, shfl_xor(v, 8)); v = fmaxf(v, shfl_xor(v, 16)); return fmaxf(v, shfl_xor(v, 32));
+}
+template <typename T, int NG, bool BWD>
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
+                                                            float* __restrict__ lse, float* __restrict__ loss_row,
+                                                            const float* __restrict__ scale, T* __restrict__ dlogits, int64_t N,
+                                                            int V, int64_t ld, int64_t ld_d, int64_t ignore_index) {
+    const int lane = threadIdx.x & 63, wv = wave_uniform(threadIdx.x >> 6);
+    const int64_t total = (N - 1) * ld + V;                           // elements of the logits tensor that may be touched
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < N; row += (int64_t)gridDim.x * 4) {
+        CeRow<T, NG> r;
+        r.load(logits, row, ld, V, lane, total);
+        const int64_t tg = target[row];
+        const bool counts = tg != ignore_index && tg >= 0 && tg < V;
+        if (!BWD) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float v[4]; bool in[4];
+                r.values(g, lane, v, in, total);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m = fmaxf(m, in[c] ? v[c] : -INFINITY);
+            }
+            m = wave_max(m);
+            float se = 0.0f, xt = 0.0f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float v[4]; bool in[4];
+                r.values(g, lane, v, in, total);
+                const int p = 4 * (g * 64 + lane) - r.lo;             // column of element 0 of this group
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    se += in[c] ? __expf(v[c] - m) : 0.0f;
+                    xt += (in[c] && p + c == tg) ? v[c] : 0.0f;
+                }
+            }
+            se = wave_sum(se);
+            xt = wave_sum(xt);
+            const float l = m + __logf(se);
+            if (lane == 0) {
+                lse[row] = l;
+                loss_row[row] = counts ? l - xt : 0.0f;
+            }
+        } else {
+            const float l = lse[row];
+            const float sc = counts ? scale[0] : 0.0f;
+            T* drow = dlogits + row * ld_d;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float v[4]; bool in[4];
+                r.values(g, lane, v, in, total);
+                const int p = 4 * (g * 64 + lane) - r.lo;
+                float o[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = (__expf(v[c] - l) - (p + c == tg ? 1.0f : 0.0f)) * sc;
+                if (in[0] && in[3] && ((row * ld_d + p) & 3) == 0) { // whole group inside the row, 8-byte aligned in dlogits
+                    st4(drow + p, make_float4(o[0], o[1], o[2], o[3]));
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (in[c]) st(drow + p + c, o[c]);
+                }
+            }
+        }
+    }
+}
+
 // K12 -- the gate of the mixer for a whole sequence (reference model/gla.py:174-180): y = logsigmoid(x) / normalizer
 // (optionally clamped from below), and its gradient dx = dy (1 - sigmoid(x)) / normalizer (0 where the clamp is active).
 // Elementwise over n4 groups of 4 elements; torch's chain (log_sigmoid with its second output, the division, their two
@@ -515,6 +638,37 @@ extern "C" int lina_sum_partials(const float* part, void* out, int outer, int P,
     else
         LINA_LAUNCH((sum_partials_kernel<bf16_t>), grid, dim3(64 * kSumWaves), 0, stream, part, (bf16_t*)out, P, N);
     return check_launch("lina_sum_partials");
+}
+
+extern "C" int lina_cross_entropy(const void* logits, const int64_t* target, float* lse, float* loss_row, const float* scale,
+                                  void* dlogits, int64_t N, int V, int64_t ld, int64_t ld_d, int64_t ignore_index, int dtype,
+                                  lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(logits && target && lse, "lina_cross_entropy: null pointer");
+    LINA_REQUIRE((loss_row != nullptr) != (dlogits != nullptr), "lina_cross_entropy: give loss_row (forward) or dlogits (backward)");
+    LINA_REQUIRE(!dlogits || scale, "lina_cross_entropy: the backward needs the scale");
+    LINA_REQUIRE(N > 0 && V >= 4 && ld >= V && (!dlogits || ld_d >= V), "lina_cross_entropy: bad shape N=%lld V=%d ld=%lld ld_d=%lld",
+                 (long long)N, V, (long long)ld, (long long)ld_d);
+    LINA_REQUIRE(V + 3 <= 256 * 33, "lina_cross_entropy: V=%d above the register-resident row limit %d", V, 256 * 33 - 3);
+    LINA_REQUIRE(valid_dtype(dtype), "lina_cross_entropy: bad dtype %d", dtype);
+    LINA_REQUIRE((reinterpret_cast<uintptr_t>(logits) & 15) == 0 && (!dlogits || (reinterpret_cast<uintptr_t>(dlogits) & 15) == 0),
+                 "lina_cross_entropy: logits / dlogits must be 16-byte aligned");
+    const int64_t wgs = (N + 3) / 4;
+    dim3 grid((unsigned)(wgs < 4096 ? wgs : 4096));
+    const int ng = (V + 3 + 255) / 256;                               // 4-element groups per lane that cover lo + V
+#define LINA_CE(TT, NGG, BB)                                                                                         \
+    LINA_LAUNCH((cross_entropy_kernel<TT, NGG, BB>), grid, dim3(256), 0, stream, (const TT*)logits, target, lse, loss_row, scale, \
+                (TT*)dlogits, N, V, ld, ld_d, ignore_index)
+#define LINA_CE_N(TT, BB)                                                                                            \
+    do {                                                                                                             \
+        if (ng <= 2) LINA_CE(TT, 2, BB); else if (ng <= 5) LINA_CE(TT, 5, BB); else if (ng <= 9) LINA_CE(TT, 9, BB);   \
+        else if (ng <= 17) LINA_CE(TT, 17, BB); else LINA_CE(TT, 33, BB);                                            \
+    } while (0)
+    if (dtype == LINA_F32) { if (dlogits) LINA_CE_N(float, true); else LINA_CE_N(float, false); }
+    else { if (dlogits) LINA_CE_N(bf16_t, true); else LINA_CE_N(bf16_t, false); }
+#undef LINA_CE_N
+#undef LINA_CE
+    return check_launch("lina_cross_entropy");
 }
 
 extern "C" int lina_swiglu_bwd_partials(int64_t rows) {

@@ -73,7 +73,8 @@ class LinaModel(nn.Module):
             target = torch.where(keep.unsqueeze(-1), target, torch.ones_like(target))
         else:
             masked_logits, masked_target = logits, target
-        loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), target.reshape(-1), ignore_index=1)
+        from . import ops
+        loss = ops.cross_entropy(logits.reshape(-1, logits.shape[-1]), target.reshape(-1), ignore_index=1)   # K14
         return logits, loss, att, masked_logits, masked_target
 
     # ------------------------------------------------------------------ batched decode

@@ -1030,6 +1030,46 @@ def gate_lowrank(lr, weight, bias=None, normalizer: float = 16.0, clamp_min: Opt
     return _GateLowRankFunction.apply(lr.to(gemm_dt), weight, bias, float(normalizer), clamp_min)
 
 
+class _CrossEntropyFunction(torch.autograd.Function):
+    """K14: mean cross-entropy over the rows whose target is not ``ignore_index``; rows [N, V] of the logits' own dtype."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        be = _BACKEND
+        N, V = logits.shape
+        lse = torch.empty(N, dtype=torch.float32, device=logits.device)
+        rows = torch.empty(N, dtype=torch.float32, device=logits.device)
+        _check(be.lib.lina_cross_entropy(_ptr(logits), _ptr(target), _ptr(lse), _ptr(rows), None, None, N, V, logits.stride(0),
+                                         0, int(ignore_index), _dt(logits), be.stream(logits)))
+        count = (target != ignore_index).sum().to(torch.float32)
+        ctx.save_for_backward(logits, target, lse, count)
+        ctx.ignore_index = int(ignore_index)
+        return rows.sum() / count
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, target, lse, count = ctx.saved_tensors
+        be = _BACKEND
+        N, V = logits.shape
+        scale = (dloss.to(torch.float32) / count).reshape(1).contiguous()
+        dlogits = torch.empty(N, V, dtype=logits.dtype, device=logits.device)
+        _check(be.lib.lina_cross_entropy(_ptr(logits), _ptr(target), _ptr(lse), None, _ptr(scale), _ptr(dlogits), N, V,
+                                         logits.stride(0), dlogits.stride(0), ctx.ignore_index, _dt(logits), be.stream(logits)))
+        return dlogits, None, None
+
+
+def cross_entropy(logits, target, ignore_index: int = -100):
+    """``F.cross_entropy(logits, target, ignore_index=ignore_index)`` (mean over the rows that count; reference
+    modeling_lina.py:106) for logits [N, V], target int64 [N]: K14, one pass over the logits each way in fp32 arithmetic
+    from their own dtype.  Falls back to torch where the kernel does not apply."""
+    if (not fused_ops_available(logits) or logits.dim() != 2 or logits.dtype not in (torch.float32, torch.bfloat16)
+            or target.dtype != torch.int64 or logits.shape[0] == 0 or not 4 <= logits.shape[1] <= 8445):
+        return F.cross_entropy(logits, target, ignore_index=ignore_index)
+    _BACKEND.require(logits, target)
+    lg = logits if (logits.stride(1) == 1 and logits.data_ptr() % 16 == 0) else logits.contiguous()
+    return _CrossEntropyFunction.apply(lg, target.contiguous(), ignore_index)
+
+
 # --------------------------------------------------------------------------- codec head (K6)
 def _embed_sum_launch(table, flat, out=None):
     be = _BACKEND

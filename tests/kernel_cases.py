@@ -713,6 +713,34 @@ def check_block_chain(dev, dtype, B=2, T=70, d=64):
         assert_close(pa.grad, pb.grad, tol, "chain d" + n)
 
 
+def check_cross_entropy(dev, N, V, dtype, ld=None):
+    """K14 vs F.cross_entropy in fp64 on the same (dtype-rounded) logits: the mean loss over the rows that count and the
+    gradient of the logits, with ignored rows, an odd row width (rows start on any 2-byte boundary) and a row stride."""
+    g = torch.Generator().manual_seed(53)
+    ld = ld or V
+    buf = (torch.randn(N, ld, generator=g) * 4).to(dtype)
+    tgt = torch.randint(0, V, (N,), generator=g)
+    tgt[::5] = 1                                              # the ignored class
+    tgt[3] = V - 1
+    tgt[4] = 0
+    l64 = buf[:, :V].to(F64).requires_grad_()
+    ref = F.cross_entropy(l64, tgt, ignore_index=1)
+    ref.backward()
+    bd = buf.to(dev)
+    lg = bd[:, :V].requires_grad_() if ld != V else bd.requires_grad_()
+    loss = ops.cross_entropy(lg, tgt.to(dev), ignore_index=1)
+    assert type(loss.grad_fn).__name__ == "_CrossEntropyFunctionBackward", type(loss.grad_fn).__name__
+    lo = dtype == torch.bfloat16
+    assert_close(loss, ref.detach(), 1e-5, "K14 loss")        # fp32 arithmetic on the stored values either way
+    (loss * 3.0).backward()
+    assert lg.grad.dtype == dtype
+    assert_close(lg.grad, l64.grad * 3.0, 1e-2 if lo else 1e-5, "K14 dlogits")
+    assert torch.count_nonzero(lg.grad[::5]) == 0
+    # all rows ignored: nan, like torch
+    none = ops.cross_entropy(bd[:4, :V].contiguous(), torch.ones(4, dtype=torch.int64, device=dev), ignore_index=1)
+    assert torch.isnan(none)
+
+
 def check_argmax(dev, rows, n, dtype):
     g = torch.Generator().manual_seed(5)
     lg = torch.randn(rows, n, generator=g).to(dtype)

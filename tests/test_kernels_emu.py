@@ -343,3 +343,10 @@ def test_swiglu_mlp(emu, B, T, d, H, bias, dtype):
 def test_block_chain_with_pending_branch(emu, dtype):
     from kernel_cases import check_block_chain
     check_block_chain(DEV, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,V,ld", [(37, 131, None), (20, 1027, None), (9, 64, 72)])
+def test_cross_entropy(emu, N, V, ld, dtype):
+    from kernel_cases import check_cross_entropy
+    check_cross_entropy(DEV, N, V, dtype, ld)

@@ -452,3 +452,10 @@ def test_swiglu_mlp(hip, B, T, d, H, bias, dtype):
 def test_block_chain_with_pending_branch(hip, dtype):
     from kernel_cases import check_block_chain
     check_block_chain(DEV, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,V,ld", [(37, 131, None), (4096, 4099, None), (777, 2050, None), (64, 8445, None), (100, 64, 72)])
+def test_cross_entropy(hip, N, V, ld, dtype):
+    from kernel_cases import check_cross_entropy
+    check_cross_entropy(DEV, N, V, dtype, ld)
