@@ -235,10 +235,15 @@ def measure_train_step(dev, b=8, T=4096, steps=5):
         return res
 
     eager = run(False)
-    try:                                    # the whole step as ONE hipGraph (TrainStep(graph=True)); eager figure beside it
-        captured = run(True)
-    except Exception as e:                  # noqa: BLE001 -- a capture failure must not cost the bench line
-        captured = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # the whole step as ONE hipGraph (TrainStep(graph=True)) is opt-in: on ROCm 7.2 replays of this ~2600-node graph were
+    # seen to hang or produce non-finite values at this shape on some runs, and a hung replay cannot be
+    # caught from here
+    captured = {"skipped": "set LINA_BENCH_TRAIN_GRAPH=1 to time the captured step too"}
+    if os.environ.get("LINA_BENCH_TRAIN_GRAPH") == "1":
+        try:
+            captured = run(True)
+        except Exception as e:              # noqa: BLE001 -- a capture failure must not cost the bench line
+            captured = {"error": f"{type(e).__name__}: {e}"[:300]}
     best = captured if "ms_per_step" in captured and captured["ms_per_step"] <= eager["ms_per_step"] else eager
     return {"what": "L169 train step: fwd + CE + bwd + AdamW, bf16 autocast, fp32 master weights", "micro_batch": b,
             "seq_len": T, "ms_per_step": best["ms_per_step"], "tokens_per_s": best["tokens_per_s"], "loss": best["loss"],

@@ -71,7 +71,8 @@ class TrainStep:
         """Optimiser defaults are the reference's (train_lina.py:25-29,104-118): AdamW lr 5e-4, betas (0.9, 0.999),
         weight decay 0.1, cosine schedule with 500 warm-up steps over 300 000 steps, no gradient clipping.
         ``graph``: capture forward + loss + backward + AdamW of one micro-batch shape in ONE hipGraph on first use and
-        replay it per step (single-GPU only: ~2600 launches per step otherwise keep one host core as busy as the GPU)."""
+        replay it per step (single-GPU only: ~2600 launches per step otherwise keep one host core as busy as the GPU).
+        EXPERIMENTAL: on ROCm 7.2 replays were seen to hang or turn non-finite at the config-5 shape on some runs."""
         self.device = device if device is not None else next(model.parameters()).device
         self.model = model.to(self.device).train()
         self.autocast_dtype = autocast_dtype

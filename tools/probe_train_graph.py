@@ -26,6 +26,12 @@ def run(graph, steps=6, b=8, T=4096):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     losses.append(float(loss))
+    per_step = []
+    for _ in range(4):                                       # step by step: loss and time of each
+        t1 = time.perf_counter()
+        l = float(ts.step(batch))
+        per_step.append((round((time.perf_counter() - t1) * 1e3, 1), l))
+    print(json.dumps({"graph": graph, "per_step_ms_loss": per_step}), flush=True)
     out = {"graph": graph, "captured": ts._graph is not None, "ms_per_step": dt * 1e3, "losses": losses,
            "lr": float(ts.opt.param_groups[0]["lr"]), "max_mem_GB": torch.cuda.max_memory_allocated() / 1e9}
     del ts
@@ -34,7 +40,7 @@ def run(graph, steps=6, b=8, T=4096):
 
 
 if __name__ == "__main__":
-    for g in (False, True):
+    for g in ((True,) if os.environ.get("PROBE_GRAPH_ONLY") else (False, True)):
         try:
             print(json.dumps(run(g)), flush=True)
         except Exception:                                   # noqa: BLE001
