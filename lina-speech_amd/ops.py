@@ -515,9 +515,6 @@ def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional
     be.require(x, w, bias, mask, cache)
     x = _inner_contig(x)
     w_param, bias_param = w, bias
-    if os.environ.get("LINA_CONV_CAST_OUTSIDE"):               # (debug switch: the cast as an autograd op of its own)
-        w_param = w.to(x.dtype).contiguous()
-        bias_param = None if bias is None else bias.to(x.dtype).contiguous()
     act = 1 if activation in ("silu", "swish") else 0
     if activation not in ("silu", "swish", None):
         raise ValueError(f"activation {activation!r} not supported")
@@ -1065,8 +1062,7 @@ def cross_entropy(logits, target, ignore_index: int = -100):
     """``F.cross_entropy(logits, target, ignore_index=ignore_index)`` (mean over the rows that count; reference
     modeling_lina.py:106) for logits [N, V], target int64 [N]: K14, one pass over the logits each way in fp32 arithmetic
     from their own dtype.  Falls back to torch where the kernel does not apply."""
-    if (os.environ.get("LINA_DISABLE_K14") or not fused_ops_available(logits) or logits.dim() != 2
-            or logits.dtype not in (torch.float32, torch.bfloat16)
+    if (not fused_ops_available(logits) or logits.dim() != 2 or logits.dtype not in (torch.float32, torch.bfloat16)
             or target.dtype != torch.int64 or logits.shape[0] == 0 or not 4 <= logits.shape[1] <= 8445):
         return F.cross_entropy(logits, target, ignore_index=ignore_index)
     _BACKEND.require(logits, target)
