@@ -17,9 +17,9 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 from torch import Tensor
 
+from . import ops
 from .attentive import AttentiveRNN
 from .codec import CodecHead, MultiEmbedding, topk_sampling, undelay_rvq
 
@@ -73,7 +73,6 @@ class LinaModel(nn.Module):
             target = torch.where(keep.unsqueeze(-1), target, torch.ones_like(target))
         else:
             masked_logits, masked_target = logits, target
-        from . import ops
         loss = ops.cross_entropy(logits.reshape(-1, logits.shape[-1]), target.reshape(-1), ignore_index=1)   # K14
         return logits, loss, att, masked_logits, masked_target
 

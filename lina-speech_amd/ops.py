@@ -14,7 +14,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 import torch.nn.functional as F
