@@ -11,6 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lina_speech_amd import configs  # noqa: E402
 from lina_speech_amd.train import TrainStep, synthetic_batch  # noqa: E402
 
+if os.environ.get("PROBE_BLAS"):                     # e.g. hipblas (= rocBLAS path: no hipBLASLt stream-K kernels / memsets)
+    torch.backends.cuda.preferred_blas_library(os.environ["PROBE_BLAS"])
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 b, T = int(os.environ.get("PROBE_B", "8")), int(os.environ.get("PROBE_T", "4096"))
