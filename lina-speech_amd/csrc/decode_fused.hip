@@ -71,6 +71,37 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ u, T*
     }
 }
 
+// The same gate for a whole sequence of rows (the train path: 32768 rows x 1408 at config 5): a workgroup takes 128 rows x
+// 256 gate columns, its 4 waves a quarter of the rows each (4 at a time, all loads first), a lane 4 columns -- 8-byte loads
+// and stores where the kernel above moves one element per thread (95 us for 277 MB there).  Hd and the strides must be
+// multiples of 4 and ld_y == Hd (no bias column).
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_rows_kernel(const T* __restrict__ u, T* __restrict__ y, int64_t rows, int Hd,
+                                                          int64_t ld_u, int64_t ld_y) {
+    constexpr int U = 4, RW = 32;                                    // rows per round, rows per wave
+    const int lane = threadIdx.x & 63, wv = wave_uniform(threadIdx.x >> 6);
+    const int j = (blockIdx.y * 64 + lane) * 4;
+    const bool ok = j < Hd;
+    const int jc = ok ? j : Hd - 4;
+    const int64_t r_begin = ((int64_t)blockIdx.x * 4 + wv) * RW;
+    const int64_t r_end = r_begin + RW < rows ? r_begin + RW : rows;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += U) {
+        typename raw4<T>::type ar[U], br[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int64_t r = r0 + q < rows ? r0 + q : rows - 1;
+            ar[q] = ld4_raw(u + r * ld_u + jc);
+            br[q] = ld4_raw(u + r * ld_u + Hd + jc);
+        }
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const float4 a = cvt4(ar[q]), b = cvt4(br[q]);
+            const float4 o = make_float4(silu(a.x) * b.x, silu(a.y) * b.y, silu(a.z) * b.z, silu(a.w) * b.w);
+            if (ok && r0 + q < r_end) st4(y + (r0 + q) * ld_y + j, o);
+        }
+    }
+}
+
 }  // namespace lina
 
 extern "C" int lina_gla_decode_prologue(const void* z, int64_t ldz, int off_q, int off_k, int off_v, int off_lr,
@@ -106,6 +137,15 @@ extern "C" int lina_swiglu(const void* u, void* y, int64_t rows, int Hd, int64_t
     LINA_REQUIRE(u && y, "lina_swiglu: null pointer");
     LINA_REQUIRE(rows > 0 && Hd > 0 && ld_u >= 2 * (int64_t)Hd && ld_y >= Hd, "lina_swiglu: bad shape");
     LINA_REQUIRE(valid_dtype(dtype), "lina_swiglu: bad dtype %d", dtype);
+    if (rows >= 1024 && Hd % 4 == 0 && ld_u % 4 == 0 && ld_y == Hd && rows <= (int64_t)65535 * 128) {   // sequence form
+        dim3 grid_r((unsigned)((rows + 127) / 128), (unsigned)((Hd + 255) / 256));
+        if (dtype == LINA_F32)
+            LINA_LAUNCH((swiglu_rows_kernel<float>), grid_r, dim3(256), 0, stream, (const float*)u, (float*)y, rows, Hd, ld_u, ld_y);
+        else
+            LINA_LAUNCH((swiglu_rows_kernel<bf16_t>), grid_r, dim3(256), 0, stream, (const bf16_t*)u, (bf16_t*)y, rows, Hd, ld_u,
+                        ld_y);
+        return check_launch("lina_swiglu");
+    }
     dim3 grid((unsigned)((ld_y + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
     if (dtype == LINA_F32)
         LINA_LAUNCH((swiglu_kernel<float>), grid, dim3(256), 0, stream, (const float*)u, (float*)y, rows, Hd, ld_u, ld_y);

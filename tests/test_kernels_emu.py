@@ -205,6 +205,7 @@ def test_layer_norm(emu, N, D, xd, rd, yd):
 
 
 @pytest.mark.parametrize("N,H,dtype", [(5, 64, torch.float32), (7, 85, torch.float32), (3, 85, torch.bfloat16),
+                                       (1100, 132, torch.bfloat16), (1027, 260, torch.float32),   # sequence form (rows >= 1024)
                                        (9, 128, torch.bfloat16)])
 def test_swiglu_gate(emu, N, H, dtype):
     from kernel_cases import check_swiglu_gate

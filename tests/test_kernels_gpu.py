@@ -340,7 +340,8 @@ def test_layer_norm(hip, N, D, xd, rd, yd):
     check_layer_norm(DEV, N, D, xd, rd, yd)
 
 
-@pytest.mark.parametrize("N,H,dtype", [(32768, 1365, torch.bfloat16), (70000, 64, torch.float32), (513, 1365, torch.float32)])
+@pytest.mark.parametrize("N,H,dtype", [(32768, 1365, torch.bfloat16), (70000, 64, torch.float32), (513, 1365, torch.float32),
+                                       (32768, 1408, torch.bfloat16), (4099, 260, torch.float32)])
 def test_swiglu_gate(hip, N, H, dtype):
     from kernel_cases import check_swiglu_gate
     check_swiglu_gate(DEV, N, H, dtype)
