@@ -248,81 +248,64 @@ __global__ __launch_bounds__(256) void short_conv_bwd_kernel(
         for (int i = 0; i < VEC; ++i) win[j + 1][i] = v[i] * m;
     }
     const int t1 = min(t0 + kConvBwdTT, Tn);
-    const int end = t1 + W - 1;                              // steps u in [t0, end): dz of step u, dx of step u - (W - 1)
-    // Blocks of KB steps, two in flight: the loads of block n + 1 (x and dy rows, clamped past the end of the sequence)
-    // are issued before block n is worked on.  (One block at a time -- load, wait, compute, store, 9 times per thread with 2
-    // waves per SIMD -- was a chain of exposed memory round trips: 60 us for 200 MB.)
-    constexpr int KB = 8;
-    typedef typename RawIO<VEC, T>::type raw_t;
-    raw_t xr0[KB], dr0[KB], xr1[KB], dr1[KB];
-    float mr0[KB], mr1[KB];
-    auto issue = [&](raw_t (&xr)[KB], raw_t (&dr)[KB], float (&mr)[KB], int u0) {
+    constexpr int KB = 8;                                    // steps requested per block (x and dy: 2 KB loads in flight)
+    for (int u0 = t0; u0 < t1 + W - 1; u0 += KB) {
+    typename RawIO<VEC, T>::type xr[KB], dr[KB];
+    float mr[KB];
 #pragma unroll
-        for (int k = 0; k < KB; ++k) {
-            const int uc = min(u0 + k, Tn - 1);
-            xr[k] = RawIO<VEC, T>::load(xb + uc * x_st);
-            dr[k] = RawIO<VEC, T>::load(dyb + uc * dy_st);
-            mr[k] = mb ? mb[uc] : 1.0f;
-        }
-    };
-    auto compute = [&](const raw_t (&xr)[KB], const raw_t (&dr)[KB], const float (&mr)[KB], int u0) {
+    for (int k = 0; k < KB; ++k) {
+        const int uc = min(u0 + k, Tn - 1);
+        xr[k] = RawIO<VEC, T>::load(xb + uc * x_st);
+        dr[k] = RawIO<VEC, T>::load(dyb + uc * dy_st);
+        mr[k] = mb ? mb[uc] : 1.0f;
+    }
 #pragma unroll
-        for (int k = 0; k < KB; ++k) {
-            const int u = u0 + k;
-            if (u < end) {                                   // workgroup-uniform
-                float dz[VEC];
+    for (int k = 0; k < KB; ++k) {
+        const int u = u0 + k;
+        if (u >= t1 + W - 1) break;
+        float dz[VEC];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) dz[i] = 0.0f;
-                if (u < Tn) {
-                    float xv[VEC], dv[VEC];
-                    RawIO<VEC, T>::cvt(xr[k], xv);
-                    RawIO<VEC, T>::cvt(dr[k], dv);
-                    const float m = mr[k];
+        for (int i = 0; i < VEC; ++i) dz[i] = 0.0f;
+        if (u < Tn) {
+            float xv[VEC], dv[VEC];
+            RawIO<VEC, T>::cvt(xr[k], xv);
+            RawIO<VEC, T>::cvt(dr[k], dv);
+            const float m = mr[k];
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) {
+            for (int i = 0; i < VEC; ++i) {
 #pragma unroll
-                        for (int j = 0; j < W - 1; ++j) win[j][i] = win[j + 1][i];
-                        win[W - 1][i] = xv[i] * m;
-                        float z = bv[i];
+                for (int j = 0; j < W - 1; ++j) win[j][i] = win[j + 1][i];
+                win[W - 1][i] = xv[i] * m;
+                float z = bv[i];
 #pragma unroll
-                        for (int j = 0; j < W; ++j) z = fmaf(wv[j][i], win[j][i], z);
-                        float d = dv[i];
-                        if (act) {
-                            const float sg = sigmoidf(z);
-                            d *= sg * (1.0f + z * (1.0f - sg));
-                        }
-                        dz[i] = d;
-                        if (u < t1) {
-#pragma unroll
-                            for (int j = 0; j < W; ++j) dw[j][i] = fmaf(d, win[j][i], dw[j][i]);
-                            db[i] += d;
-                        }
-                    }
+                for (int j = 0; j < W; ++j) z = fmaf(wv[j][i], win[j][i], z);
+                float d = dv[i];
+                if (act) {
+                    const float sg = sigmoidf(z);
+                    d *= sg * (1.0f + z * (1.0f - sg));
                 }
-                const int t = u - (W - 1);
-                float a[VEC];
+                dz[i] = d;
+                if (u < t1) {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-#pragma unroll
-                    for (int j = W - 1; j > 0; --j) dzw[j][i] = dzw[j - 1][i];
-                    dzw[0][i] = dz[i];
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < W; ++j) acc = fmaf(wv[j][i], dzw[j][i], acc);
-                    a[i] = acc * ((mb && t >= 0) ? mb[t] : 1.0f);
+                    for (int j = 0; j < W; ++j) dw[j][i] = fmaf(d, win[j][i], dw[j][i]);
+                    db[i] += d;
                 }
-                if (t >= t0) VecIO<VEC, T>::store(dx + b * dx_sb + t * dx_st + c, a);
             }
         }
-    };
-    issue(xr0, dr0, mr0, t0);
-    for (int u0 = t0; u0 < end; u0 += 2 * KB) {
-        issue(xr1, dr1, mr1, u0 + KB);
-        sched_fence();
-        compute(xr0, dr0, mr0, u0);
-        issue(xr0, dr0, mr0, u0 + 2 * KB);
-        sched_fence();
-        compute(xr1, dr1, mr1, u0 + KB);
+        const int t = u - (W - 1);
+        float a[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+#pragma unroll
+            for (int j = W - 1; j > 0; --j) dzw[j][i] = dzw[j - 1][i];
+            dzw[0][i] = dz[i];
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc = fmaf(wv[j][i], dzw[j][i], acc);
+            a[i] = acc * ((mb && t >= 0) ? mb[t] : 1.0f);
+        }
+        if (t >= t0) VecIO<VEC, T>::store(dx + b * dx_sb + t * dx_st + c, a);
+    }
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
