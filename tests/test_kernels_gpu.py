@@ -460,3 +460,15 @@ def test_block_chain_with_pending_branch(hip, dtype):
 def test_cross_entropy(hip, N, V, ld, dtype):
     from kernel_cases import check_cross_entropy
     check_cross_entropy(DEV, N, V, dtype, ld)
+
+
+def test_sum_partials(hip):
+    from kernel_cases import check_sum_partials
+    check_sum_partials(DEV)
+
+
+@pytest.mark.parametrize("N,V,ld,dtype", [(1, 4, None, torch.float32), (3, 5, 9, torch.bfloat16), (2, 257, 261, torch.bfloat16),
+                                          (5, 1023, None, torch.bfloat16)])
+def test_cross_entropy_edge_shapes(hip, N, V, ld, dtype):
+    from kernel_cases import check_cross_entropy
+    check_cross_entropy(DEV, N, V, dtype, ld)
