@@ -13,6 +13,44 @@ from lina_speech_amd.train import TrainStep, synthetic_batch  # noqa: E402
 
 if os.environ.get("PROBE_BLAS"):                     # e.g. hipblas (= rocBLAS path: no hipBLASLt stream-K kernels / memsets)
     torch.backends.cuda.preferred_blas_library(os.environ["PROBE_BLAS"])
+# PROBE_PLAIN=mlp,linear,slab,gate,ce,ln,chain,conv,norm: replace that fused path by the plain torch ops (monkeypatched here, no
+# product switch) -- to bisect which node a failing replay depends on
+import torch.nn.functional as F  # noqa: E402
+from lina_speech_amd import blocks, ops  # noqa: E402
+plain = set(filter(None, os.environ.get("PROBE_PLAIN", "").split(",")))
+if "mlp" in plain:
+    ops.swiglu_mlp = lambda x, wi, bi, wo, bo: ops.linear(ops.swiglu_gate(ops.linear(x, wi, bi)), wo, bo)
+if "linear" in plain:
+    ops.linear = lambda x, w, b=None: F.linear(x, w, b)
+if "slab" in plain:
+    ops.split_slab = lambda z, sizes: (z.split(list(sizes), dim=-1), None)
+if "gate" in plain:
+    ops.gate_lowrank = lambda lr, w, b=None, normalizer=16.0, clamp_min=None: (
+        F.logsigmoid(F.linear(lr, w, b)) / normalizer if clamp_min is None
+        else torch.clamp_min(F.logsigmoid(F.linear(lr, w, b)) / normalizer, clamp_min))
+if "ce" in plain:
+    ops.cross_entropy = lambda lg, t, ignore_index=-100: F.cross_entropy(lg, t, ignore_index=ignore_index)
+if "ln" in plain:
+    ops.fused_ops_available_orig = ops.fused_ops_available
+    _ln = ops.layer_norm
+
+    def _plain_ln(x, weight, bias, eps=1e-5, residual=None, out_dtype=None):
+        xs = x if residual is None else x + residual
+        y = F.layer_norm(xs, (x.shape[-1],), weight, bias, eps)
+        return y if residual is None else (y, xs)
+    ops.layer_norm = _plain_ln
+if "chain" in plain:
+    blocks.MixingBlock.can_defer = lambda self, x: False
+if "conv" in plain:
+    from oracle import gla_oracle as O  # noqa: E402  (diagnostics only: the CPU restatement's conv is plain torch)
+    ops.short_conv = lambda x, w, bias=None, mask=None, cache=None, activation="silu", grad_slab=None: O.short_conv(
+        x, w, mask, cache, activation, bias).to(x.dtype)
+if "norm" in plain:
+    from oracle import gla_oracle as O2  # noqa: E402
+    ops.rmsnorm_swish_gate = lambda x, g=None, weight=None, eps=1e-5, n_partial=1, out_dtype=None, out=None, grad_slab=None: (
+        O2.rmsnorm_swish_gate(x, g, weight, eps) if g is not None else O2.rmsnorm(x, weight, eps)).to(x.dtype)
+print(json.dumps({"plain": sorted(plain)}), flush=True)
+
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 b, T = int(os.environ.get("PROBE_B", "8")), int(os.environ.get("PROBE_T", "4096"))
