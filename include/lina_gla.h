@@ -276,6 +276,11 @@ int lina_cross_entropy(const void* logits, const int64_t* target, float* lse, fl
                        void* dlogits, int64_t N, int V, int64_t ld, int64_t ld_d, int64_t ignore_index, int dtype,
                        lina_stream_t stream);
 
+/* K13a -- per-slab column sums of x [M, N] (row stride ld; N, ld multiples of 4): partial fp32
+ * [lina_swiglu_bwd_partials(M)][N], summed over dim 0 by lina_sum_partials.  The bias gradient of a projection
+ * (`grad_output.sum(0)` of nn.Linear's autograd) as a deterministic two-level sum without global semaphores. */
+int lina_colsum(const void* x, float* partial, int64_t M, int N, int64_t ld, int dtype, lina_stream_t stream);
+
 /* K13 -- second level of the parameter-gradient sums: out[o][n] = sum_p part[o][p][n], part fp32 [outer][P][N] (the
  * `*_partial` outputs of K3b / K5b / K10b / K11c / K12b), out [outer][N] of out_dtype; N a multiple of 4. */
 int lina_sum_partials(const float* part, void* out, int outer, int P, int64_t N, int out_dtype, lina_stream_t stream);

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "lina_swiglu": (C.c_int, [_p, _p, _i64, _i, _i64, _i64, _i, _p]),
     "lina_swiglu_bwd": (C.c_int, [_p, _p, _p, _i64, _i, _i64, _i64, _i64, _i, _p]),
     "lina_cross_entropy": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i, _i64, _i64, _i64, _i, _p]),
+    "lina_colsum": (C.c_int, [_p, _p, _i64, _i, _i64, _i, _p]),
     "lina_sum_partials": (C.c_int, [_p, _p, _i, _i, _i64, _i, _p]),
     "lina_swiglu_bwd_partials": (C.c_int, [_i64]),
     "lina_swiglu_bwd_colsum": (C.c_int, [_p, _p, _p, _p, _i64, _i, _i64, _i64, _i64, _i, _p]),

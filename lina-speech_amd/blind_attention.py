@@ -13,6 +13,8 @@ import math
 import torch
 import torch.nn as nn
 
+from . import ops
+
 
 def attention_with_weights(q, k, v, mask=None):
     """softmax(q k^T / sqrt(d)) v, also returning the weights (reference crossatt.py:13-19)."""
@@ -61,15 +63,15 @@ class BlindCrossAttention(nn.Module):
 
     def prepare(self, ctx, pos=None):
         """Step-invariant text side: (k, v, pos_emb), each [B|1, 1, Ttxt, d]."""
-        k = self.ln_k(self.k(ctx)).unsqueeze(1)
-        v = self.ln_v(self.v(ctx)).unsqueeze(1)
+        k = self.ln_k(ops.linear(ctx, self.k.weight, self.k.bias)).unsqueeze(1)      # (ops.linear: nn.Linear's forward;
+        v = self.ln_v(ops.linear(ctx, self.v.weight, self.v.bias)).unsqueeze(1)      #  bias gradient as K13a / K13)
         if pos is None:
             pos = torch.arange(ctx.shape[1], device=ctx.device).unsqueeze(0)
         return k, v, self.pos_embed(pos).unsqueeze(1)
 
     def forward(self, q, k, mask=None, time_step=None, pos=None, prepared=None, **kwargs):
         kk, vv, pe = prepared if prepared is not None else self.prepare(k, pos)
-        qq = self.ln_q(self.q(q)).unsqueeze(1)
+        qq = self.ln_q(ops.linear(q, self.q.weight, self.q.bias)).unsqueeze(1)
         if mask is not None:
             mask = mask.unsqueeze(1)
         if self.training:

@@ -120,7 +120,9 @@ class SelfAttention(nn.Module):
 
     def forward(self, x, mask=None, pos=None, time_step: int = 0, **kwargs):
         B, N, D = x.shape
-        q, k, v = self.qkv(x).view(B, N, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
+        from . import ops
+        qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)      # nn.Linear's forward; bias gradient as K13a / K13
+        q, k, v = qkv.view(B, N, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
         if self.rotary is not None:
             if pos is not None:
                 ang = self.rotary(pos).unsqueeze(1)

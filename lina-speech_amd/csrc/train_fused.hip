@@ -296,6 +296,47 @@ __global__ __launch_bounds__(256) void swiglu_bwd_colsum_kernel(const T* __restr
     }
 }
 
+// K13a -- first level for a plain matrix: per-slab column sums of x [M, N] (the bias gradient of a projection: the column
+// sum of its output gradient), fp32 partials [ceil(M / kColsumRows)][N] for K13.  Same mapping as K11c: a workgroup takes
+// kColsumRows rows x 256 columns, its 4 waves a quarter of the rows each (8 at a time, all loads first), a lane 4 columns.
+// (torch's two-stage reduction for this shape keeps semaphores in global memory, and on ROCm 7.2 a hipGraph REPLAY of it
+// returns garbage from the second replay on -- tools/probe_graph_memset.py -- which is what broke the captured train step.)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ partial, int64_t M, int N,
+                                                     int64_t ld) {
+    constexpr int U = 8;
+    __shared__ float4 s_red[3][64];
+    const int lane = threadIdx.x & 63, wv = wave_uniform(threadIdx.x >> 6);
+    const int j = (blockIdx.y * 64 + lane) * 4;
+    const bool ok = j < N;
+    const int jc = ok ? j : N - 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t r_begin = (int64_t)blockIdx.x * kColsumRows + wv * (kColsumRows / 4);
+    const int64_t r_end = r_begin + kColsumRows / 4 < M ? r_begin + kColsumRows / 4 : M;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += U) {
+        typename raw4<T>::type v[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) v[q] = ld4_raw(x + (r0 + q < M ? r0 + q : M - 1) * ld + jc);
+        sched_fence();
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const float m = r0 + q < r_end ? 1.0f : 0.0f;               // branch-free (see K13)
+            const float4 f = cvt4(v[q]);
+            acc.x = fmaf(m, f.x, acc.x); acc.y = fmaf(m, f.y, acc.y); acc.z = fmaf(m, f.z, acc.z); acc.w = fmaf(m, f.w, acc.w);
+        }
+    }
+    if (wv > 0) s_red[wv - 1][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && ok) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float4 c = s_red[o][lane];
+            acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
+        }
+        *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * N + j) = acc;
+    }
+}
+
 // K13 -- second level of the two-level parameter-gradient sums: out[o][n] = sum_p part[o][p][n] (fp32 partials written by
 // K3b / K5b / K10b / K11c / K12b, one row per workgroup of those kernels).  These inputs are small (2-20 MB) and the sum is
 // LATENCY-bound: what matters is how many dependent load rounds a wave makes.  A workgroup of 16 waves takes 256 columns
@@ -625,6 +666,22 @@ __global__ __launch_bounds__(256) void gate_lowrank_kernel(const T* __restrict__
 }
 
 }  // namespace lina
+
+extern "C" int lina_swiglu_bwd_partials(int64_t rows);
+
+extern "C" int lina_colsum(const void* x, float* partial, int64_t M, int N, int64_t ld, int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(x && partial, "lina_colsum: null pointer");
+    LINA_REQUIRE(M > 0 && M <= (int64_t)65535 * LINA_SWIGLU_COLSUM_ROWS && N >= 4 && N % 4 == 0 && ld >= N && ld % 4 == 0,
+                 "lina_colsum: bad shape M=%lld N=%d ld=%lld (N, ld multiples of 4)", (long long)M, N, (long long)ld);
+    LINA_REQUIRE(valid_dtype(dtype), "lina_colsum: bad dtype %d", dtype);
+    dim3 grid((unsigned)lina_swiglu_bwd_partials(M), (unsigned)((N + 255) / 256));
+    if (dtype == LINA_F32)
+        LINA_LAUNCH((colsum_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, partial, M, N, ld);
+    else
+        LINA_LAUNCH((colsum_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)x, partial, M, N, ld);
+    return check_launch("lina_colsum");
+}
 
 extern "C" int lina_sum_partials(const float* part, void* out, int outer, int P, int64_t N, int out_dtype, lina_stream_t stream) {
     using namespace lina;

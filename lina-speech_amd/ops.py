@@ -404,6 +404,19 @@ def _sum_partials2(part):
     return out
 
 
+def column_sum(x2, out_dtype=torch.float32):
+    """``x2.sum(0)`` of a matrix [M, N] with fp32 accumulation (K13a + K13: deterministic, no global semaphores -- torch's
+    two-stage reduction for this shape does not survive a hipGraph replay on ROCm 7.2, tools/probe_graph_memset.py)."""
+    M, N = x2.shape
+    if (not fused_ops_available(x2) or x2.dtype not in (torch.float32, torch.bfloat16) or N % 4 or x2.stride(1) != 1
+            or x2.stride(0) % 4 or M == 0 or M > 65535 * 128):
+        return x2.sum(0, dtype=torch.float32).to(out_dtype)
+    be = _BACKEND
+    part = torch.empty(int(be.lib.lina_swiglu_bwd_partials(M)), N, dtype=torch.float32, device=x2.device)
+    _check(be.lib.lina_colsum(_ptr(x2), _ptr(part), M, N, x2.stride(0), _dt(x2), be.stream(x2)))
+    return _sum_partials(part, out_dtype)
+
+
 class GradSlab:
     """Backward-time buffer [..., sum(sizes)] for the output gradient of a stacked projection: the consumers of its column
     slices write their input gradients straight into their columns (``part``), so the projection's backward finds dZ
@@ -833,7 +846,7 @@ class _LinearFunction(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw = linear_weight_grad(dy2.contiguous(), x2.contiguous()).to(wdt)
             if bdt is not None and ctx.needs_input_grad[2]:
-                db = dy2.sum(0, dtype=torch.float32).to(bdt)
+                db = column_sum(dy2.contiguous()).to(bdt)
         return dx, dw, db
 
 
@@ -1030,6 +1043,16 @@ def gate_lowrank(lr, weight, bias=None, normalizer: float = 16.0, clamp_min: Opt
     return _GateLowRankFunction.apply(lr.to(gemm_dt), weight, bias, float(normalizer), clamp_min)
 
 
+def _sum_vector(v):
+    """Sum of a long fp32 vector as a 0-dim tensor through K13 (rows of 4 as the "partials") and a 4-element tail -- no
+    multi-block torch reduction (see ``column_sum``)."""
+    n = v.numel()
+    if n < 8 or n % 4 or not fused_ops_available(v) or v.dtype != torch.float32:
+        return v.sum()
+    w = 256 if n % 256 == 0 else 4
+    return _sum_partials(v.contiguous().view(n // w, w)).sum()
+
+
 class _CrossEntropyFunction(torch.autograd.Function):
     """K14: mean cross-entropy over the rows whose target is not ``ignore_index``; rows [N, V] of the logits' own dtype."""
 
@@ -1041,10 +1064,11 @@ class _CrossEntropyFunction(torch.autograd.Function):
         rows = torch.empty(N, dtype=torch.float32, device=logits.device)
         _check(be.lib.lina_cross_entropy(_ptr(logits), _ptr(target), _ptr(lse), _ptr(rows), None, None, N, V, logits.stride(0),
                                          0, int(ignore_index), _dt(logits), be.stream(logits)))
-        count = (target != ignore_index).sum().to(torch.float32)
+        valid = (target != ignore_index).to(torch.float32)
+        count, total = _sum_vector(valid), _sum_vector(rows)
         ctx.save_for_backward(logits, target, lse, count)
         ctx.ignore_index = int(ignore_index)
-        return rows.sum() / count
+        return total / count
 
     @staticmethod
     def backward(ctx, dloss):

@@ -764,6 +764,22 @@ def check_sum_partials(dev):
     assert_close(gb, part[0].double().sum(0), 1e-2, "K13 bf16 out")
 
 
+def check_column_sum(dev):
+    """K13a + K13 (ops.column_sum, the bias gradient of ops.linear) against the fp64 column sum: row counts around the
+    128-row slabs, widths that are not multiples of 256, a row stride, both dtypes; and the long-vector sum of K14's rows."""
+    g = torch.Generator().manual_seed(67)
+    for M, N, ld, dtype in ((1, 4, 4, torch.float32), (127, 40, 40, torch.bfloat16), (129, 260, 264, torch.float32),
+                            (1000, 1024, 1024, torch.bfloat16), (300, 16, 4112, torch.bfloat16)):
+        buf = torch.randn(M, ld, generator=g).to(dtype).to(dev)
+        x = buf[:, :N]
+        got = ops.column_sum(x)
+        assert got.dtype == torch.float32 and got.shape == (N,)
+        assert_close(got, x.double().sum(0), 1e-5, f"K13a {M}x{N}")
+    for n in (4096, 1028, 7):
+        v = torch.randn(n, generator=g).to(dev)
+        assert_close(ops._sum_vector(v), v.double().sum(), 1e-5, f"vector sum n={n}")
+
+
 def check_argmax(dev, rows, n, dtype):
     g = torch.Generator().manual_seed(5)
     lg = torch.randn(rows, n, generator=g).to(dtype)

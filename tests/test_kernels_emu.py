@@ -363,3 +363,8 @@ def test_sum_partials(emu):
 def test_cross_entropy_edge_shapes(emu, N, V, ld, dtype):
     from kernel_cases import check_cross_entropy
     check_cross_entropy(DEV, N, V, dtype, ld)
+
+
+def test_column_sum(emu):
+    from kernel_cases import check_column_sum
+    check_column_sum(DEV)

@@ -472,3 +472,8 @@ def test_sum_partials(hip):
 def test_cross_entropy_edge_shapes(hip, N, V, ld, dtype):
     from kernel_cases import check_cross_entropy
     check_cross_entropy(DEV, N, V, dtype, ld)
+
+
+def test_column_sum(hip):
+    from kernel_cases import check_column_sum
+    check_column_sum(DEV)

@@ -63,7 +63,10 @@ for i in range(int(os.environ.get("PROBE_STEPS", "14"))):
     dt = (time.perf_counter() - t0) * 1e3
     bad = [n for n, p in ts.model.named_parameters() if not bool(torch.isfinite(p).all())]
     badg = [n for n, p in ts.model.named_parameters() if p.grad is not None and not bool(torch.isfinite(p.grad).all())]
-    print(json.dumps({"step": i, "ms": round(dt, 1), "loss": loss, "nonfinite_params": bad[:4], "n_bad_params": len(bad),
-                      "nonfinite_grads": badg[:6], "n_bad_grads": len(badg)}), flush=True)
+    n_par = sum(1 for _ in ts.model.parameters())
+    kinds = sorted({n.rsplit(".", 1)[-1] for n in bad}), sorted({str(tuple(p.shape)) for n, p in ts.model.named_parameters() if n in set(bad)})[:8]
+    print(json.dumps({"step": i, "ms": round(dt, 1), "loss": loss, "n_params": n_par, "n_bad_params": len(bad), "n_bad_grads": len(badg),
+                      "bad_param_kinds": kinds[0], "bad_param_shapes": kinds[1], "nonfinite_params": bad[:10],
+                      "nonfinite_grads": badg[:10]}), flush=True)
     if bad or loss != loss:
         break
