@@ -25,6 +25,9 @@
 //      (3) o^T += v^T . mask(A)^T after the barrier (mask(A) has its own buffer), o carried in registers to the next
 //      phase A's end.  1/sqrt(Dk) is applied to o.  History and measurements: DESIGN.md 4.2.
 #include <type_traits>
+#ifndef LINA_DMA_NT
+#define LINA_DMA_NT 1   // the q,k,g,v prefetch is read once: non-temporal DMA (0.582 -> 0.572 ms at B=64,H=4,T=4096, round 4)
+#endif
 #include <lina_dev.h>
 #include "lina_common.h"
 
@@ -35,6 +38,7 @@ __device__ unsigned long long lina_k2_prof[16 * 16 + 3 * 1024];   // + per workg
 #else
 #define K2_PROF(i) do { } while (0)
 #endif
+
 
 namespace lina {
 
@@ -761,6 +765,11 @@ static bool full_ok(int H, int Dk, int Dv, int dtype, const void* q, const void*
     return p16(q) && p16(k) && p16(v) && p16(gk) && p16(o);
 }
 
+// gla_chunk_pipe.hip: the software-pipelined 16-token-chunk form of the plain forward (one head per workgroup)
+int launch_chunk_pipe(const void* q, const void* k, const void* v, const void* gk, void* o, const float* h0, float* ht,
+                      int slots, int H, int T, int nseg, int Tseg, lina_bht_strides sq, lina_bht_strides sk,
+                      lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides so, float scale, lina_stream_t stream);
+
 int launch_chunk_full(const void* q, const void* k, const void* v, const void* gk, void* o, const float* h0,
                       float* ht, int B, int H, int T, int Dk, int Dv, lina_bht_strides sq, lina_bht_strides sk,
                       lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides so, int dtype, int g_dtype,
@@ -770,6 +779,9 @@ int launch_chunk_full(const void* q, const void* k, const void* v, const void* g
              fits32(sv) && fits32(sg) && fits32(so);
     if (!*taken) return LINA_OK;
     const int G = 256 / Dk;
+#ifndef LINA_K2_NOPIPE
+    if (G == 1) return launch_chunk_pipe(q, k, v, gk, o, h0, ht, B * H, H, T, 1, T, sq, sk, sv, sg, so, scale, stream);
+#endif
     dim3 grid((unsigned)(B * H / G));
 #define LINA_FULL(GG)                                                                                                  \
     LINA_LAUNCH((gla_chunk_bf16_h256_kernel<false, GG>), grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k, \

@@ -16,6 +16,7 @@ namespace lina {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((uint32_t)h << 16); }
 // fp32 -> bf16, round-to-nearest-even, via the native __bf16 conversion (v_cvt_pk_bf16_f32 on gfx950;
@@ -47,6 +48,12 @@ __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c)
                                                    __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+//   v_mfma_f32_16x16x16_bf16 : A[i=l&15][k=4*(l>>4)+j]  B[k=4*(l>>4)+j][n=l&15]   (j<4); C/D as above -- the K = 16 form:
+//   same issue time as the K = 32 form, half the operand registers / LDS bytes (for contractions over 16 tokens)
+__device__ __forceinline__ f32x4 mfma_bf16_16x16x16(bf16x4 a, bf16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
 //   v_mfma_f32_32x32x16_bf16 : A[i=l&31][k=8*(l>>5)+j]  B[k=8*(l>>5)+j][n=l&31]  (j<8)
 //   C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5), reg < 16
 __device__ __forceinline__ f32x16 mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -70,7 +77,11 @@ __device__ __forceinline__ void dma16_to_lds(const void* gsrc_lane, void* lds_wa
 __device__ __forceinline__ void dma16_to_lds_async(const void* base_uniform, unsigned lane_byte_off, void* lds_wave_base) {
     const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane(
         (int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+#if defined(LINA_DMA_NT) && LINA_DMA_NT   // non-temporal: the bytes are read once (set per kernel file before this header)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt"
+#else
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+#endif
                  :
                  : "s"(lds), "v"(lane_byte_off), "s"(base_uniform)
                  : "memory", "m0");
@@ -95,6 +106,8 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 u) { return __builtin_bit_cast
 __device__ __forceinline__ bf16x8 as_bf16x8(uint2 lo, uint2 hi) {
     return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 }
+
+__device__ __forceinline__ bf16x4 as_bf16x4(uint2 u) { return __builtin_bit_cast(bf16x4, u); }
 
 // c + a.lo*b.lo + a.hi*b.hi on packed bf16 pairs, fp32 accumulate (v_dot2c_f32_bf16)
 __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {

@@ -15,6 +15,7 @@ struct Fiber {
     bool done = false;
     unsigned wave_parity = 0;
     char* stack = nullptr;
+    std::vector<std::pair<void*, const void*>> pending;   // LINA_EMU_DMA_LATE: issued, not yet landed
 };
 
 struct Wave {
@@ -38,6 +39,16 @@ static const size_t kStack = 256 * 1024;
 
 const dim3& cur_tid() { return cur->tid; }
 int cur_lane() { return cur->linear & 63; }
+
+bool dma_late() {
+    static const bool late = getenv("LINA_EMU_DMA_LATE") && atoi(getenv("LINA_EMU_DMA_LATE")) != 0;
+    return late;
+}
+void dma_defer(void* dst, const void* src) { cur->pending.emplace_back(dst, src); }
+void dma_flush_mine() {
+    for (auto& p : cur->pending) memcpy(p.first, p.second, 16);
+    cur->pending.clear();
+}
 
 static void yield() { swapcontext(&cur->ctx, &sched_ctx); }
 
@@ -71,6 +82,7 @@ void wave_exchange(const uint32_t* mine, int n, uint32_t* out) {
 
 static void trampoline() {
     (*g_body)();
+    dma_flush_mine();
     cur->done = true;
     ++progress;
     swapcontext(&cur->ctx, &sched_ctx);
@@ -107,11 +119,25 @@ void launch_impl(const std::function<void()>& body, dim3 grid, dim3 block, size_
                     f.ctx.uc_link = &sched_ctx;
                     makecontext(&f.ctx, trampoline, 0);
                 }
+                // LINA_EMU_SHUFFLE=seed: the waves are visited in a different pseudo-random order on every scheduler pass (lanes of
+                // a wave stay in order), so that a kernel whose result depends on which wave gets ahead between two barriers
+                // (an LDS race) does not pass on the one fixed interleaving
+                static const unsigned shuffle_seed = getenv("LINA_EMU_SHUFFLE") ? (unsigned)atoi(getenv("LINA_EMU_SHUFFLE")) : 0u;
+                unsigned rng = shuffle_seed * 2654435761u + bx * 40503u + 12345u;
+                const int nwaves = nthr / 64;
+                std::vector<int> worder(nwaves);
+                for (int i = 0; i < nwaves; ++i) worder[i] = i;
                 int live = nthr;
                 while (live > 0) {
                     const unsigned long before = progress;
                     live = 0;
-                    for (int t = 0; t < nthr; ++t) {
+                    if (shuffle_seed)
+                        for (int i = nwaves - 1; i > 0; --i) {
+                            rng = rng * 1664525u + 1013904223u;
+                            std::swap(worder[i], worder[(rng >> 8) % (unsigned)(i + 1)]);
+                        }
+                    for (int tt = 0; tt < nthr; ++tt) {
+                        const int t = worder[tt >> 6] * 64 + (tt & 63);
                         if (fibers[t].done) continue;
                         cur = &fibers[t];
                         swapcontext(&sched_ctx, &fibers[t].ctx);

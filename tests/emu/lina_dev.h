@@ -60,6 +60,9 @@ extern unsigned char* g_dyn_smem;
 const dim3& cur_tid();
 int cur_lane();
 void syncthreads();
+bool dma_late();
+void dma_defer(void* dst, const void* src);
+void dma_flush_mine();
 // wave-collective exchange: every lane of the wave deposits `n` 32-bit words, then reads
 // the 64 x n table `out` (out[lane*n + i]).
 void wave_exchange(const uint32_t* mine, int n, uint32_t* out);
@@ -91,6 +94,11 @@ struct f32x16 {
     float v[16];
     float& operator[](int i) { return v[i]; }
     const float& operator[](int i) const { return v[i]; }
+};
+struct bf16x4 {
+    short v[4];
+    short& operator[](int i) { return v[i]; }
+    const short& operator[](int i) const { return v[i]; }
 };
 struct bf16x8 {
     short v[8];
@@ -189,6 +197,33 @@ static inline f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
     return d;
 }
 
+// v_mfma_f32_16x16x16_bf16: lane l holds A[i=l&15][k=4*(l>>4)+j], B[k=4*(l>>4)+j][n=l&15], j<4.
+static inline f32x4 mfma_bf16_16x16x16(bf16x4 a, bf16x4 b, f32x4 c) {
+    uint32_t mine[4], tab[256];
+    for (int j = 0; j < 2; ++j) {
+        mine[j] = (uint32_t)(uint16_t)a[2 * j] | ((uint32_t)(uint16_t)a[2 * j + 1] << 16);
+        mine[2 + j] = (uint32_t)(uint16_t)b[2 * j] | ((uint32_t)(uint16_t)b[2 * j + 1] << 16);
+    }
+    lina_emu::wave_exchange(mine, 4, tab);
+    const int l = lina_emu::cur_lane(), col = l & 15;
+    auto A = [&](int i, int k) {
+        const uint32_t w = tab[(i + 16 * (k >> 2)) * 4 + ((k & 3) >> 1)];
+        return bf2f((unsigned short)((k & 1) ? (w >> 16) : (w & 0xffff)));
+    };
+    auto Bm = [&](int k, int n) {
+        const uint32_t w = tab[(n + 16 * (k >> 2)) * 4 + 2 + ((k & 3) >> 1)];
+        return bf2f((unsigned short)((k & 1) ? (w >> 16) : (w & 0xffff)));
+    };
+    f32x4 d;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) acc = fmaf(A(row, k), Bm(k, col), acc);
+        d[r] = acc;
+    }
+    return d;
+}
+
 // v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8*(l>>5)+j], B[k=8*(l>>5)+j][n=l&31];
 // D: col=l&31, row=(reg&3)+8*(reg>>2)+4*(l>>5).
 static inline f32x16 mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -221,12 +256,19 @@ static inline void dma16_to_lds(const void* gsrc_lane, void* lds_wave_base) {
     memcpy((unsigned char*)lds_wave_base + 16 * lina_emu::cur_lane(), gsrc_lane, 16);
 }
 
+// LINA_EMU_DMA_LATE=1: the copy is performed when the issuing lane reaches its wait_vmem() -- the LATEST moment the hardware
+// may land it (the default, at issue, is the earliest): a kernel that reads the destination before its wait, or relies on the
+// data not yet having landed, fails under one of the two.
 static inline void dma16_to_lds_async(const void* base_uniform, unsigned lane_byte_off, void* lds_wave_base) {
-    memcpy((unsigned char*)lds_wave_base + 16 * lina_emu::cur_lane(), (const unsigned char*)base_uniform + lane_byte_off, 16);
+    unsigned char* dst = (unsigned char*)lds_wave_base + 16 * lina_emu::cur_lane();
+    const unsigned char* src = (const unsigned char*)base_uniform + lane_byte_off;
+    if (lina_emu::dma_late()) lina_emu::dma_defer(dst, src);
+    else memcpy(dst, src, 16);
 }
 // the wave's DMA pieces have landed: on the emulator every lane copies its own 16 bytes when it runs, so this is a
 // wave-wide meeting point (all lanes of a wave call it together, as on the hardware)
 static inline void wait_vmem() {
+    lina_emu::dma_flush_mine();
     uint32_t mine = 0, tab[64];
     lina_emu::wave_exchange(&mine, 1, tab);
 }
@@ -248,6 +290,7 @@ static inline uint2 lds_read_tr16_b64(const void* piece) {
     }
     return make_uint2((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16));
 }
+static inline bf16x4 as_bf16x4(uint2 u) { bf16x4 r; memcpy(&r, &u, 8); return r; }
 static inline bf16x8 as_bf16x8(uint4 u) { bf16x8 r; memcpy(&r, &u, 16); return r; }
 static inline bf16x8 as_bf16x8(uint2 lo, uint2 hi) { bf16x8 r; memcpy(&r.v[0], &lo, 8); memcpy(&r.v[4], &hi, 8); return r; }
 

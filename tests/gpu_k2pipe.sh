@@ -1,0 +1,17 @@
+#!/bin/bash
+# K2 pipelined forward (gla_chunk_pipe.hip): parity on the device, then ms per launch at B=64,H=4,T=4096 for the product and the
+# experiment builds of tools/k2_tune.sh, then the per-phase clock profile.  Output: gpurun_out/${TAG}_*.txt
+cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+TAG=${1:-r04_k2pipe}
+timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "chunk" --timeout=600 > gpurun_out/${TAG}_pytest.txt 2>&1; echo "pytest=$?"; tail -3 gpurun_out/${TAG}_pytest.txt
+{
+for L in "" ${K2_LIBS:-old ord0 ord1 ord3 ord4 nont old_nont}; do
+  if [ -z "$L" ]; then P=""; N=product; else P=tools/abl/liblina_k2$L.so; N=$L; fi
+  echo -n "$N: "; LINA_GLA_LIB=$P K2_HT=0 K2_REPS=${K2_REPS:-1500} timeout 200 python tools/perf_k2.py 2>&1 | tail -1
+done
+echo -n "product again: "; K2_HT=0 K2_REPS=${K2_REPS:-1500} timeout 200 python tools/perf_k2.py 2>&1 | tail -1
+echo -n "product + final state: "; K2_HT=1 K2_REPS=${K2_REPS:-1500} timeout 200 python tools/perf_k2.py 2>&1 | tail -1
+} > gpurun_out/${TAG}_variants.txt 2>&1
+cat gpurun_out/${TAG}_variants.txt
+LINA_GLA_LIB=tools/abl/liblina_k2prof.so K2_PROF=pipe K2_HT=0 K2_REPS=300 timeout 200 python tools/perf_k2.py > gpurun_out/${TAG}_prof.txt 2>&1
+tail -14 gpurun_out/${TAG}_prof.txt
