@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-B_PER_GPU = 64
+B_PER_GPU = 64               # default of --batch-per-gpu: BASELINE.json configs[1] (the metric's B = 512 is 8 x 64)
 T_TXT = 64
 
 
@@ -217,39 +217,23 @@ def measure_train_step(dev, b=8, T=4096, steps=5):
     bf16 autocast on one GPU; synthetic config-5 batch."""
     from lina_speech_amd.configs import l169
     from lina_speech_amd.train import TrainStep, synthetic_batch
-    def run(graph):
-        torch.manual_seed(0)
-        ts = TrainStep(l169(), device=dev, ddp=False, graph=graph)
-        batch = synthetic_batch(b=b, n=T + 1, t_txt=T_TXT, seed=1).to(dev)
-        for _ in range(2):
-            ts.step(batch)                  # (graph: the first call also captures, after 2 eager warm-up steps of its own)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = ts.step(batch)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        res = {"ms_per_step": dt * 1e3, "tokens_per_s": b * T / dt, "loss": float(loss)}
-        del ts, batch
-        torch.cuda.empty_cache()
-        return res
-
-    eager = run(False)
-    # the whole step as ONE hipGraph (TrainStep(graph=True)) is opt-in: on ROCm 7.2 replays of this ~2600-node graph were
-    # seen to hang or produce non-finite values at this shape on some runs (DESIGN.md 4.5), and a hung replay cannot be
-    # caught from here
-    captured = {"skipped": "set LINA_BENCH_TRAIN_GRAPH=1 to time the captured step too"}
-    if os.environ.get("LINA_BENCH_TRAIN_GRAPH") == "1":
-        try:
-            captured = run(True)
-        except Exception as e:              # noqa: BLE001 -- a capture failure must not cost the bench line
-            captured = {"error": f"{type(e).__name__}: {e}"[:300]}
-    best = captured if "ms_per_step" in captured and captured["ms_per_step"] <= eager["ms_per_step"] else eager
-    return {"what": "L169 train step: fwd + CE + bwd + AdamW, bf16 autocast, fp32 master weights", "micro_batch": b,
-            "seq_len": T, "ms_per_step": best["ms_per_step"], "tokens_per_s": best["tokens_per_s"], "loss": best["loss"],
-            "mode": "one hipGraph per step" if best is captured else "eager launches",
-            "eager": eager, "captured": captured, "steps_timed": steps,
-            "max_mem_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
+    torch.manual_seed(0)
+    ts = TrainStep(l169(), device=dev, ddp=False)
+    batch = synthetic_batch(b=b, n=T + 1, t_txt=T_TXT, seed=1).to(dev)
+    for _ in range(2):
+        ts.step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = ts.step(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    res = {"what": "L169 train step: fwd + CE + bwd + AdamW, bf16 autocast, fp32 master weights", "micro_batch": b,
+           "seq_len": T, "ms_per_step": dt * 1e3, "tokens_per_s": b * T / dt, "loss": float(loss),
+           "mode": "eager launches", "steps_timed": steps, "max_mem_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
+    del ts, batch
+    torch.cuda.empty_cache()
+    return res
 
 
 def measure_vocoder(dev, B=64, L=750, reps=3):
@@ -478,14 +462,14 @@ def check_launch(args):
         dist.all_reduce(t)
         seen = int(t.item())
         from lina_speech_amd.shard import shard_rows
-        lo, hi = shard_rows(B_PER_GPU * world, rank, world)
+        lo, hi = shard_rows(args.batch_per_gpu * world, rank, world)
         rows = torch.tensor([float(hi - lo)], device=dev)
         dist.all_reduce(rows)
-        assert int(rows.item()) == B_PER_GPU * world
+        assert int(rows.item()) == args.batch_per_gpu * world
     if rank == 0:
         print(json.dumps({"check_launch": True, "n_gpus": args.gpus, "world_size": world, "ranks_seen": seen,
                           "backend": (dist.get_backend() if dist is not None else None),
-                          "rows_total": B_PER_GPU * world}), flush=True)
+                          "rows_total": args.batch_per_gpu * world}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -575,6 +559,53 @@ def bench_train(args):
         dist.destroy_process_group()
 
 
+def step_hbm_bytes(eng):
+    """HBM bytes of one decode step of `eng`: recurrent state read every token (+ written every W-th with the windowed
+    update), every decode-time weight read once, text-side K/V rows read once.  Returns (state, weights, text K/V,
+    state bytes of the immediate form = read AND written every token)."""
+    w_bytes = sum(t.numel() * t.element_size() for P_ in eng.packs for t in
+                  (P_.w_in, P_.w_o, P_.w_up, P_.w_down)) + eng.w_head.numel() * eng.w_head.element_size() \
+        + eng.ca_qw.numel() * eng.ca_qw.element_size()
+    s_bytes = int(sum((1.0 + 1.0 / (eng.window if P_.lazy else 1)) * P_.S.numel() * 4 for part in eng.parts
+                      for P_ in part.packs))
+    kv_bytes = sum(part.kk.numel() * part.kk.element_size() + part.vv.numel() * part.vv.element_size()
+                   for part in eng.parts)
+    s_bytes_imm = sum(2 * P_.S.numel() * 4 for part in eng.parts for P_ in part.packs)
+    return s_bytes, w_bytes, kv_bytes, s_bytes_imm
+
+
+def measure_big_batch(model_dev, dev, B=512, steps=120):
+    """The batch the metric is quoted on (B = 512) on ONE GPU: 6.8 GB of recurrent state, the same engine and graph loop.
+    At this size the state traffic (14 GB per token), not the 59 latency-bound projection launches, is most of the step."""
+    from lina_speech_amd.decode import DecodeEngine
+    g = torch.Generator().manual_seed(4321)
+    texts = torch.randint(3, 256, (B, T_TXT), generator=g).to(dev)
+    with torch.inference_mode():
+        eng = DecodeEngine(model_dev, model_dev.txt_encoder(model_dev.txt_embed(texts)), batch_size=B)
+        eng.begin_greedy(steps + 80)
+        eng.greedy_steps(16)                     # captures the multi-token graph
+        eng.greedy_steps(48)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.greedy_steps(steps)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        toks = eng.greedy_tokens()
+        assert int(toks.min()) >= 0 and int(toks.max()) < 4099
+        s_b, w_b, kv_b, s_imm = step_hbm_bytes(eng)
+        mem = torch.cuda.max_memory_allocated(dev) / 1e9
+        del eng
+    torch.cuda.empty_cache()
+    nb = s_b + w_b + kv_b
+    return {"what": f"the same decode loop with B = {B} rows on ONE GPU (the metric's batch; secondary, not `value`)",
+            "batch": B, "steps_timed": steps, "ms_per_step": dt * 1e3, "tokens_per_s": B / dt,
+            "step_roofline": {"state_bytes": s_b, "weight_bytes": w_b, "text_kv_bytes": kv_b, "bytes_per_step": nb,
+                              "bound": "hbm", "achieved": nb / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": nb / dt / 1e9 / HBM_PEAK_GBS,
+                              "immediate_form_frac": (w_b + s_imm + kv_b) / dt / 1e9 / HBM_PEAK_GBS},
+            "max_mem_GB": mem}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -588,6 +619,8 @@ def main():
     ap.add_argument("--train", action="store_true", help="measure config 5 (the DDP training step) instead of decode")
     ap.add_argument("--train-batch", type=int, default=8, help="--train: sequences of 4096 tokens per GPU")
     ap.add_argument("--check-launch", action="store_true", help="only exercise the N-rank launch / rendezvous logic")
+    ap.add_argument("--batch-per-gpu", type=int, default=B_PER_GPU,
+                    help="utterance rows per GPU (default 64 = BASELINE configs[1]; 512 puts the metric's whole batch on one GPU)")
     ap.add_argument("--window", type=int, default=None, help="state window of the decode loop (1 = immediate update K1d; default 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chunk", action="store_true")
@@ -611,7 +644,7 @@ def main():
     ops.get_backend().lib                                            # fail loudly if the HIP library is missing
 
     from lina_speech_amd.shard import shard_rows
-    total_rows = B_PER_GPU * world
+    total_rows = args.batch_per_gpu * world
     lo, hi = shard_rows(total_rows, rank, world)                     # this rank's utterances
     B = hi - lo
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -700,15 +733,8 @@ def main():
             # the step as a whole against HBM: recurrent state read + written once per block, every decode-time weight
             # read once (the bytes the engine's packs actually hold), text-side K/V rows read once
             ms_step = elapsed / k_run * 1e3
-            w_bytes = sum(t.numel() * t.element_size() for P_ in eng.packs for t in
-                          (P_.w_in, P_.w_o, P_.w_up, P_.w_down)) + eng.w_head.numel() * eng.w_head.element_size() \
-                + eng.ca_qw.numel() * eng.ca_qw.element_size()
-            s_bytes = int(sum((1.0 + 1.0 / (eng.window if P_.lazy else 1)) * P_.S.numel() * 4 for part in eng.parts
-                              for P_ in part.packs))
-            kv_bytes = sum(part.kk.numel() * part.kk.element_size() + part.vv.numel() * part.vv.element_size()
-                           for part in eng.parts)
+            s_bytes, w_bytes, kv_bytes, s_bytes_imm = step_hbm_bytes(eng)
             step_bytes = w_bytes + s_bytes + kv_bytes
-            s_bytes_imm = sum(2 * P_.S.numel() * 4 for part in eng.parts for P_ in part.packs)
             step_roof = {"what": "whole decode step vs HBM: state read (+ write every W-th step) + decode-time weights + text K/V, per step per GPU",
                          "immediate_form": {"what": "the same step priced with the state read AND written every token "
                                                     "(SURVEY 8(d) / VERDICT r01 accounting: the bytes K1w avoids still counted)",
@@ -724,7 +750,7 @@ def main():
                 "steps": k_run, "steps_requested": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
-                "config": {"workload": f"L169 greedy codec-token decode, B={B_PER_GPU}/GPU (B_total={total_rows}), "
+                "config": {"workload": f"L169 greedy codec-token decode, B={args.batch_per_gpu}/GPU (B_total={total_rows}), "
                                        f"T_txt={T_TXT}, H=4 Dk=Dv=256, 12+1 GLA blocks, fp32 recurrent state, "
                                        f"{nparam / 1e6:.1f}M params, one hipGraph replay per {eng.GRAPH_STEPS} tokens, state window {eng.window}, "
                                        f"{len(eng.parts)} parallel row ranges per GPU",
@@ -753,6 +779,8 @@ def main():
                 out["sampled_decode"] = {"k": 100, "temp": 1.0, "ms_per_step": (time.perf_counter() - ts0) / 50 * 1e3,
                                          "tokens_per_s": B * 50 / (time.perf_counter() - ts0)}
             if not args.no_chunk and world == 1:
+                if dtype == torch.bfloat16 and args.batch_per_gpu != 512:
+                    out["b512_one_gpu"] = measure_big_batch(model_dev, dev)
                 out["config3_pipeline"] = measure_config3(eng, dev, B)
                 out["chunk_kernel"] = measure_chunk(dev)
                 for hh in (8, 16):                                   # the same width as 8 / 16 heads: 2 / 4 heads per workgroup

@@ -40,6 +40,15 @@ __device__ unsigned long long lina_k2_prof[16 * 16 + 3 * 1024];   // + per workg
 #endif
 
 
+// LINA_K2_EARLY (tools-only experiment, default 0): in the key-gated sweeps (MODE 0) the prefetch of chunk n+1 issued DURING
+// phase A of chunk n -- by the loader waves, at raised priority, as soon as every wave has signalled through an LDS counter that
+// its raw reads are done -- instead of after barrier (2).  MEASURED SLOWER (round 4, profiles/r04_k2early_*): 0.676 vs 0.597 ms at
+// B=64,H=4,T=4096 -- a DMA issued while phase A hammers the LDS costs the loaders ~3000 clocks and everybody waits for them at
+// barrier (2) instead of (3).  The hoisted raw reads / early v^T writes it needs are register-neutral and stay.
+#ifndef LINA_K2_EARLY
+#define LINA_K2_EARLY 0
+#endif
+
 namespace lina {
 
 constexpr int kFullC = 32;
@@ -136,6 +145,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // barrier (2) fetches both (three dependent LDS round trips -- flag, flag, R -- sat in front of every wave's MFMAs)
     __shared__ __attribute__((aligned(8))) unsigned s_flags[4];
     __shared__ int s_cut;
+    __shared__ int s_cons;                                    // EARLY: waves whose raw reads of the current chunk are done, summed over chunks
+    constexpr bool EARLY = LINA_K2_EARLY != 0 && MODE == 0;
     __shared__ __attribute__((aligned(16))) float s_carry[DG ? DK : 4];   // DG: running sum of d per channel (wave-private quads)
 
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -185,7 +196,13 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // them at (3).  So ONLY the last four waves (one per SIMD, the lowest issue priority) issue DMAs, 16 each (row pairs
     // 4(w-12) .. +3); the other twelve go straight to their MFMAs and the four catch up on SIMDs the others have left.
     // Rows past the end of the sequence re-read row T-1 (always mapped); phase A masks them.
-    constexpr int kLoaders = 4;   // loader waves (measured on the final kernel: 8 loaders 0.598 ms, 2 loaders 0.612, 4 loaders 0.592)
+#ifndef LINA_K2_LOADERS
+#define LINA_K2_LOADERS 4
+#endif
+#ifndef LINA_K2_LPRIO
+#define LINA_K2_LPRIO 3
+#endif
+    constexpr int kLoaders = LINA_K2_LOADERS;   // loader waves (measured on the final kernel: 8 loaders 0.598 ms, 2 loaders 0.612, 4 loaders 0.592)
     constexpr int kDmaWave0 = 16 - kLoaders, kPairsPer = 16 / kLoaders;
     // memory row (relative to the segment's first token) of visited row tl <= T-1 of tensor a; REV: the gate (a == 2) of a
     // visited row is the gate of the token after it, clamped to the sequence (the one row past it is zeroed in gate_scan)
@@ -249,7 +266,19 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // MODE 1: slot 0 (X) and slot 1 (Y) are copied raw, slot 3 (Z) is gated like k; X goes to tile row 16 rr + rp (token
     // 2 rp + rr: the column permutation of the products, see the kernel header); Eo = the output factors e^{b+R} of this thread's
     // two tokens x four channels.
-    auto write_tiles = [&](auto full_tag, const float (&bc)[2][4], int nv, int par, float (&Eo)[2][4], uint2 (&Zq)[2]) {
+    // MODE 0: the raw q / k / v rows of this thread (two rows x four channels each), read BEFORE the gate scan: the LDS returns
+    // a wave's reads in order, so once the scan has used the gates (requested last) every raw value of the wave has left the tiles
+    auto read_raw = [&](uint2 (&hq)[2], uint2 (&hk)[2], uint2 (&hv)[2]) {
+        const bf16_t* const rawp = &s_raw[rp * PE + ch0];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            if constexpr (!STATE_ONLY) hq[rr] = *reinterpret_cast<const uint2*>(rawp + rr * DK);
+            hk[rr] = *reinterpret_cast<const uint2*>(rawp + RAWT + rr * DK);
+            hv[rr] = *reinterpret_cast<const uint2*>(rawp + 3 * RAWT + rr * DK);
+        }
+    };
+    auto write_tiles = [&](auto full_tag, const float (&bc)[2][4], int nv, int par, float (&Eo)[2][4], uint2 (&Zq)[2],
+                           const uint2 (&hq)[2], const uint2 (&hk)[2], const uint2 (&hv)[2]) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr float kLog2e = 1.4426950408889634f;
         uint2 kk[2], vv[2];                                   // packed k~ / v of the two rows, for the transposed pieces
@@ -306,21 +335,20 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             } else {
                 if constexpr (!STATE_ONLY) {
                     uint2 pq;
-                    unpack4(*reinterpret_cast<const uint2*>(rawp + rr * DK), f);
+                    unpack4(hq[rr], f);
                     pq.x = pack_bf16x2(f[0] * e[0], f[1] * e[1]);   // rows >= nv: finite values, zeroed as packed words
                     pq.y = pack_bf16x2(f[2] * e[2], f[3] * e[3]);
                     pq.x = valid ? pq.x : 0u;
                     pq.y = valid ? pq.y : 0u;
                     *reinterpret_cast<uint2*>(qkp + rr * SQ) = pq;
                 }
-                unpack4(*reinterpret_cast<const uint2*>(rawp + RAWT + rr * DK), f);
+                unpack4(hk[rr], f);
                 kk[rr].x = pack_bf16x2(f[0] * ri[0], f[1] * ri[1]);
                 kk[rr].y = pack_bf16x2(f[2] * ri[2], f[3] * ri[3]);
                 kk[rr].x = valid ? kk[rr].x : 0u;
                 kk[rr].y = valid ? kk[rr].y : 0u;
                 if constexpr (!STATE_ONLY) *reinterpret_cast<uint2*>(qkp + C * SQ + rr * SQ) = kk[rr];
-                const uint2 rv = *reinterpret_cast<const uint2*>(rawp + 3 * RAWT + rr * DK);
-                vv[rr] = valid ? rv : make_uint2(0u, 0u);
+                (void)hv;                                       // v^T is written by write_vT, before the gate scan
             }
             if (FULL ? (rr == 1 && rp == C / 2 - 1) : (row == nv - 1)) {   // owner of the chunk's last row: R after the chunk
                 bool need = false;
@@ -340,10 +368,25 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             *reinterpret_cast<unsigned*>(tp + 2 * ST) = byte_perm(kk[1].y, kk[0].y, 0x05040100u);
             *reinterpret_cast<unsigned*>(tp + 3 * ST) = byte_perm(kk[1].y, kk[0].y, 0x07060302u);
         }
-        *reinterpret_cast<unsigned*>(tp + DK * ST) = byte_perm(vv[1].x, vv[0].x, 0x05040100u);
-        *reinterpret_cast<unsigned*>(tp + DK * ST + ST) = byte_perm(vv[1].x, vv[0].x, 0x07060302u);
-        *reinterpret_cast<unsigned*>(tp + DK * ST + 2 * ST) = byte_perm(vv[1].y, vv[0].y, 0x05040100u);
-        *reinterpret_cast<unsigned*>(tp + DK * ST + 3 * ST) = byte_perm(vv[1].y, vv[0].y, 0x07060302u);
+        if constexpr (MODE == 1) {
+            *reinterpret_cast<unsigned*>(tp + DK * ST) = byte_perm(vv[1].x, vv[0].x, 0x05040100u);
+            *reinterpret_cast<unsigned*>(tp + DK * ST + ST) = byte_perm(vv[1].x, vv[0].x, 0x07060302u);
+            *reinterpret_cast<unsigned*>(tp + DK * ST + 2 * ST) = byte_perm(vv[1].y, vv[0].y, 0x05040100u);
+            *reinterpret_cast<unsigned*>(tp + DK * ST + 3 * ST) = byte_perm(vv[1].y, vv[0].y, 0x07060302u);
+        }
+    };
+    // MODE 0: v enters the products unscaled, so its transposed pieces need nothing from the gate scan: written first, their
+    // registers are free before the scan starts (the hoisted raw rows are what the early prefetch costs in registers)
+    auto write_vT = [&](auto full_tag, const uint2 (&hv)[2], int nv) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        uint2 vv[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) vv[rr] = (FULL || 2 * rp + rr < nv) ? hv[rr] : make_uint2(0u, 0u);
+        bf16_t* const tp = &s_T[(DK + ch0) * ST + 2 * rp];
+        *reinterpret_cast<unsigned*>(tp) = byte_perm(vv[1].x, vv[0].x, 0x05040100u);
+        *reinterpret_cast<unsigned*>(tp + ST) = byte_perm(vv[1].x, vv[0].x, 0x07060302u);
+        *reinterpret_cast<unsigned*>(tp + 2 * ST) = byte_perm(vv[1].y, vv[0].y, 0x05040100u);
+        *reinterpret_cast<unsigned*>(tp + 3 * ST) = byte_perm(vv[1].y, vv[0].y, 0x07060302u);
     };
     using FullT = std::true_type;
     using PartT = std::false_type;
@@ -353,10 +396,12 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         for (int c = tid; c < DK; c += 1024) s_carry[c] = carry ? carry[(int64_t)slot * DK + c] : 0.0f;
     if (tid < 4) s_flags[tid] = 0;
     if (tid == 2) s_cut = 0;
+    if (tid == 3) s_cons = 0;
     dma_chunk(0, STATE_ONLY ? 1 : 0, 4);
     wait_vmem();
     __syncthreads();   // DMA of chunk 0 landed
     int t0 = 0, par = 0;                                      // par: chunk parity
+    int chunk_no = 0;                                         // EARLY: iterations so far (every wave signals once per iteration)
     int tp = 0, np = 0;                                       // previous chunk: its o is stored at the END of the next phase A
     f32x4 acc[2] = {};       // o^T: this wave's 16 columns (rows 4lg + r) x tokens [16nt, 16nt+16) (column li)
     // o straight from the accumulators.  The products were taken TRANSPOSED (state / v as the A operand), so a lane holds 4
@@ -366,6 +411,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // stores while the others still compute.
     // memory row (relative to the segment's first token) of visited row tl
     auto out_row = [&](int tl) -> unsigned { return (unsigned)(REV ? T - 1 - tl : tl); };
+    uint2 opk[2] = {};                                         // MODE 0: the finished o of the previous chunk, packed (4 registers carried through phase A, not 8)
     uint2 auxr[2], aux2r[2];                                   // DG: aux / aux2 rows of this chunk's tokens (requested early)
     uint2 zq[2];                                               // DG: this thread's raw Z rows of the chunk (kept from phase A)
     const bf16_t* auxb = DG ? aux + b * saux.b + h * saux.h + t_begin * saux.t : nullptr;
@@ -388,12 +434,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int row = 16 * nt + li;
-                uint2 po;
-                po.x = pack_bf16x2(acc[nt][0] * scale, acc[nt][1] * scale);
-                po.y = pack_bf16x2(acc[nt][2] * scale, acc[nt][3] * scale);
                 if (row < np) {
                     const unsigned boff = 2u * (out_row(tp + row) * (unsigned)so.t + 16u * (unsigned)w + 4u * (unsigned)lg);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) + boff) = po;
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) + boff) = opk[nt];
                 }
             }
         }
@@ -464,16 +507,39 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         // (and, in sweep K, the aux rows requested before step (4)) are dead before the tile writes need their registers
         float En[2][4];                                        // MODE 1: this chunk's output factors
         if (DG && np > 0) store_prev();                        // sweep K: before the gate scan (its registers: aux, aux2, q rows)
+        if constexpr (EARLY) {
+            if (w >= kDmaWave0) wave_priority<LINA_K2_LPRIO>();   // the loader waves finish their phase A first ...
+        }
         {
             float bc[2][4];
-            if (nrem >= C) {                                   // workgroup-uniform: the mask-free form
-                if (gate_scan(FullT{}, bc, nrem)) s_flags[2 * par] = 1;
-                if (MODE == 1 && !DG && np > 0) store_prev();
-                write_tiles(FullT{}, bc, C, par, En, zq);
-            } else {
-                if (gate_scan(PartT{}, bc, nrem)) s_flags[2 * par] = 1;
-                if (MODE == 1 && !DG && np > 0) store_prev();
-                write_tiles(PartT{}, bc, n, par, En, zq);
+            uint2 hq[2], hk[2], hv[2];
+            if constexpr (MODE == 0) {
+                read_raw(hq, hk, hv);
+                if (nrem >= C) write_vT(FullT{}, hv, C); else write_vT(PartT{}, hv, n);
+                sched_fence();
+            }
+            bool viol;
+            if (nrem >= C) viol = gate_scan(FullT{}, bc, nrem);   // workgroup-uniform: the mask-free form
+            else viol = gate_scan(PartT{}, bc, nrem);
+            if (viol) s_flags[2 * par] = 1;
+            if constexpr (EARLY) {
+                // this wave's raw reads have left the tiles (the scan used the gates, requested last; the LDS serves a wave's
+                // operations in order, and so the add below comes after them)
+                if (lane == 0) lds_signal_add(&s_cons, 1);
+            }
+            if (MODE == 1 && !DG && np > 0) store_prev();
+            if (nrem >= C) write_tiles(FullT{}, bc, C, par, En, zq, hq, hk, hv);
+            else write_tiles(PartT{}, bc, n, par, En, zq, hq, hk, hv);
+        }
+        if constexpr (EARLY) {
+            // ... and issue the next chunk's prefetch while the other twelve are still in theirs: the raw tiles are free once all
+            // sixteen waves have signalled.  Optimistic chunk length (a cut re-issues below).
+            if (w >= kDmaWave0) {
+                if (t0 + n < T) {
+                    lds_wait_ge(&s_cons, 16 * (chunk_no + 1));
+                    dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);
+                }
+                wave_priority<0>();
             }
         }
         K2_PROF(0);
@@ -486,6 +552,13 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         float rn = tid < DK ? s_Rn[tid] : 0.0f;                 // for the roll of R below, fetched in the same round trip
         if (fl.x) {
             // ---- rare: the decay inside this chunk exceeds e^-60 -> cut the chunk at the first such row ----
+            if constexpr (EARLY) {
+                // the early prefetch is overwriting the raw tiles: fetch THIS chunk again (a wave's loads land in issue order,
+                // so these pieces land after the stale ones); the next chunk is requested again below, from the cut position
+                dma_chunk(t0, STATE_ONLY ? 1 : 0, 4);
+                wait_vmem();
+                __syncthreads();
+            }
             float bc[2][4];
             gate_scan(PartT{}, bc, nrem);
             int nc = C;
@@ -502,8 +575,12 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             __syncthreads();
             n = max(min(n, C - s_cut), 1);
             __syncthreads();   // everyone has read s_cut; the optimistic tiles are dead
-            if (tid == 0) s_cut = 0;
-            write_tiles(PartT{}, bc, n, par, En, zq);
+            if (tid == 0) { int z = 0; opaque(z); s_cut = z; }
+            {
+                uint2 hq[2], hk[2], hv[2];
+                if constexpr (MODE == 0) { read_raw(hq, hk, hv); write_vT(PartT{}, hv, n); }
+                write_tiles(PartT{}, bc, n, par, En, zq, hq, hk, hv);
+            }
             __syncthreads();
             fl.y = s_flags[2 * par + 1];                       // the rewritten tiles may have changed both
             rn = tid < DK ? s_Rn[tid] : 0.0f;
@@ -512,7 +589,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         const bool more = t0 + n < T;
         // (the loader waves interleaving their 16 DMA instructions with their own step-(1) MFMAs instead: 0.644 ms vs 0.592 --
         //  the pieces land later and everybody waits at (3); measured round 2, tests/gpu_k2var.sh)
-        if (more) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);   // next chunk's raw q,k,g,v fly under phase B
+        if (more && (!EARLY || fl.x)) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);   // next chunk's raw q,k,g,v fly under phase B
         if (STATE_ONLY && w == 0) {                                    // s_dec is stable between barriers (2) and (3)
             const float4 d = *reinterpret_cast<const float4*>(&s_dec[4 * lane]);
             decp.x *= d.x; decp.y *= d.y; decp.z *= d.z; decp.w *= d.w;
@@ -694,13 +771,24 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         __syncthreads();   // (3) ... and so has everybody's; operand tiles dead; mask(A) complete (its own buffer)
         K2_PROF(9);
         lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;   // re-derive, do not carry
-        if (tid == 0) { s_flags[2 * par] = 0; s_flags[2 * par + 1] = 0; }   // read by all before (3); set again two chunks later, after (2) of the next
+        if (tid == 0) {                                        // read by all before (3); set again two chunks later, after (2) of the next
+            int z = 0;
+            opaque(z);                                         // materialised here: hoisted out of the loop the constant was SPILLED
+            s_flags[2 * par] = (unsigned)z; s_flags[2 * par + 1] = (unsigned)z;
+        }
         if constexpr (!STATE_ONLY) {
             // (3) o += mask(A) . v -- AFTER the barrier: no barrier of its own for mask(A); s_A is rewritten only after the
             //     next chunk's barrier (2)
             acc[0] = mfma_bf16_16x16x32(vb, frag16(&s_A[hw * 1024 + (0 * 64 + lane) * 8]), acc[0]);   // o^T += v^T . mask(A)^T
             acc[1] = mfma_bf16_16x16x32(vb, frag16(&s_A[hw * 1024 + (1 * 64 + lane) * 8]), acc[1]);
             K2_PROF(7);
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    opk[nt].x = pack_bf16x2(acc[nt][0] * scale, acc[nt][1] * scale);
+                    opk[nt].y = pack_bf16x2(acc[nt][2] * scale, acc[nt][3] * scale);
+                }
+            }
             if constexpr (MODE == 1) {                         // the output factors die here, not in the next phase A
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
@@ -710,6 +798,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         }
         par ^= 1;
         t0 += n;
+        ++chunk_no;
         if constexpr (REV) gate_zero0 = false;
     }
     lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
@@ -779,7 +868,7 @@ int launch_chunk_full(const void* q, const void* k, const void* v, const void* g
              fits32(sv) && fits32(sg) && fits32(so);
     if (!*taken) return LINA_OK;
     const int G = 256 / Dk;
-#ifndef LINA_K2_NOPIPE
+#ifdef LINA_K2_PIPE   // measured slower (0.762 vs 0.599 ms, profiles/r04_k2pipe_*): opt-in experiment build only
     if (G == 1) return launch_chunk_pipe(q, k, v, gk, o, h0, ht, B * H, H, T, 1, T, sq, sk, sv, sg, so, scale, stream);
 #endif
     dim3 grid((unsigned)(B * H / G));

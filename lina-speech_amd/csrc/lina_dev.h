@@ -143,6 +143,15 @@ __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_rea
 // Use it only where no wave touches the DMA destination before the next full __syncthreads().
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// One-way signalling between the waves of a workgroup through an LDS counter, without a barrier.  The LDS serves a wave's
+// operations in issue order, so an add placed after a wave's reads is applied after them; the waiting wave polls.
+__device__ __forceinline__ void lds_signal_add(int* p, int v) {
+    asm volatile("ds_add_u32 %0, %1" ::"v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_wait_ge(const int* p, int target) {
+    while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(p)) < target) __builtin_amdgcn_s_sleep(1);
+}
+
 // value of lane (l - n) of the same 16-lane row, 0 for the first n lanes of a row (v_*_dpp row_shr:n, bound_ctrl): one VALU
 // modifier instead of a ds_bpermute -- the building block of a 16-wide scan
 template <int N>

@@ -67,12 +67,12 @@ class TrainStep:
     def __init__(self, model: LinaModel, lr: float = 5e-4, weight_decay: float = 0.1, betas=(0.9, 0.999),
                  n_warmup_steps: int = 500, n_training_steps: int = 300000,
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16, device: Optional[torch.device] = None,
-                 grad_clip: Optional[float] = None, ddp: Optional[bool] = None, graph: bool = False):
+                 grad_clip: Optional[float] = None, ddp: Optional[bool] = None):
         """Optimiser defaults are the reference's (train_lina.py:25-29,104-118): AdamW lr 5e-4, betas (0.9, 0.999),
         weight decay 0.1, cosine schedule with 500 warm-up steps over 300 000 steps, no gradient clipping.
-        ``graph``: capture forward + loss + backward + AdamW of one micro-batch shape in ONE hipGraph on first use and
-        replay it per step (single-GPU only: ~2600 launches per step otherwise keep one host core as busy as the GPU).
-        EXPERIMENTAL: on ROCm 7.2 replays were seen to hang or turn non-finite at the config-5 shape on some runs."""
+        (Rounds 2-3 carried an opt-in ``graph=True`` -- the whole step as one hipGraph.  It replayed correctly only on some
+        runs -- torch's two-stage reductions read stale partials under replay on ROCm 7.2, profiles/r03_graph_replay_reduction.txt --
+        and gained 0.9 % when it did (56.8 vs 57.3 ms, profiles/r03_train_graph_probe.txt): removed in round 4)"""
         self.device = device if device is not None else next(model.parameters()).device
         self.model = model.to(self.device).train()
         self.autocast_dtype = autocast_dtype
@@ -85,14 +85,7 @@ class TrainStep:
             self.net = DDP(self.model, device_ids=ids, bucket_cap_mb=DDP_BUCKET_MB, gradient_as_bucket_view=True,
                            broadcast_buffers=False)
         fused = self.device.type == "cuda"
-        self.graph_mode = bool(graph) and fused and not use_ddp
-        self._graph = self._static = self._static_loss = None
-        # captured: the step count and the learning rate live on the device (the scheduler fills the lr tensor between
-        # replays), so that a replay applies the CURRENT schedule, not the one baked in at capture time
-        extra = dict(capturable=True) if self.graph_mode else {}
-        lr0 = torch.tensor(lr, dtype=torch.float32, device=self.device) if self.graph_mode else lr
-        self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr0, weight_decay=weight_decay, betas=betas,
-                                     fused=fused, **extra)
+        self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=weight_decay, betas=betas, fused=fused)
 
         def cosine_with_warmup(step: int) -> float:          # transformers.get_cosine_schedule_with_warmup, half a cycle
             if step < n_warmup_steps:
@@ -112,47 +105,8 @@ class TrainStep:
             out = self.net(batch.x, batch.y, batch.encoder_mask, batch.crossatt_mask, **kw)
         return out[1]
 
-    # ------------------------------------------------------------------ captured step
-    @staticmethod
-    def _fields(batch: Batch):
-        return [batch.x, batch.y, batch.encoder_mask, batch.crossatt_mask, batch.logits_mask]
-
-    def _capture(self, batch: Batch, warmup: int = 2) -> None:
-        """Warm up on a side stream (allocator, lazily built constants, autotuned GEMM choices), then record one step."""
-        self._static = Batch(*[None if t is None else t.clone() for t in self._fields(batch)])
-        side = torch.cuda.Stream(self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self.opt.zero_grad(set_to_none=True)
-                self.loss(self._static).backward()
-                self.opt.step()
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        self.opt.zero_grad(set_to_none=True)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            loss = self.loss(self._static)
-            loss.backward()
-            self.opt.step()
-        self._graph, self._static_loss = g, loss
-
-    def _step_captured(self, batch: Batch) -> torch.Tensor:
-        if self._graph is None:
-            self._capture(batch)                           # (its warm-up steps are real optimizer steps on this batch)
-        for dst, src in zip(self._fields(self._static), self._fields(batch)):
-            if dst is not None:
-                if src is None or src.shape != dst.shape:
-                    raise ValueError("TrainStep(graph=True) was captured for another micro-batch shape")
-                dst.copy_(src, non_blocking=True)
-        self._graph.replay()
-        if self.sched is not None:
-            self.sched.step()
-        return self._static_loss.detach().clone()
-
     def step(self, batch: Batch) -> torch.Tensor:
         """One optimizer step; returns the (detached) loss of this rank's micro-batch."""
-        if self.graph_mode and self.grad_clip is None:
-            return self._step_captured(batch)
         self.opt.zero_grad(set_to_none=True)
         loss = self.loss(batch)
         loss.backward()                       # DDP: RCCL all-reduce (mean) of the buckets overlaps with backward

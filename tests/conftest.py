@@ -41,6 +41,13 @@ class EmuBackend:
 def emu_lib():
     from emu import build_emu
     from lina_speech_amd import _lib
+    # LINA_EMU_VARIANT="tag:-DX=1,-DY=2:file.hip,other.hip": run the session on an opt-in build of the kernel sources (e.g. the
+    # C = 32 forward kernel behind -DLINA_K2_NOPIPE=1), built beside the default library
+    var = os.environ.get("LINA_EMU_VARIANT")
+    if var:
+        tag, defs, only = (var.split(":") + ["", ""])[:3]
+        return _lib.bind(build_emu.build(defs=tuple(d for d in defs.split(",") if d), tag=tag,
+                                         only=[f for f in only.split(",") if f] or None), hip_runtime=False)
     return _lib.bind(build_emu.build(), hip_runtime=False)
 
 

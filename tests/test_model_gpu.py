@@ -144,23 +144,25 @@ def test_config1_simple_gla_stack_matches_reference_wrapper(hip):
 
 def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
     """The HEADLINE configuration (BASELINE configs[1]: L169, bf16, B=64, device-side hipGraph loop with the windowed
-    state update) against the fp32 CPU oracle of the reference loop (model/modeling_lina.py:152-179):
+    state update) against the fp32 CPU oracle of the reference loop (model/modeling_lina.py:152-179), on weights whose
+    logits are PEAKED (model_cases.peak_logits: random-init weights give flat logits and a third of the positions were
+    near-ties, where the arg-max claim cannot be checked):
       1. the engine decodes 32 tokens free-running;
       2. the oracle (fp32 arithmetic on the SAME bf16-rounded weights) is teacher-forced with the engine's tokens ->
          reference logits and top-2 margins for the same history at every position;
-      3. the engine's teacher-forced logits (generic step API, immediate state update) must be within 2e-2 of
-         max|oracle logits| (bf16 activations vs fp32);
+      3. the engine's teacher-forced logits (generic step API, immediate state update) and the windowed loop's OWN logits
+         must be within 2e-2 of max|oracle logits| (bf16 activations vs fp32);
       4. every free-running token must be the oracle's arg-max wherever the oracle's margin exceeds TWICE the measured
-         logit error (if |dlogit| <= e everywhere the arg-max cannot differ at a margin > 2e); the number of positions
-         below that margin and the raw token differences are printed (random-init weights give nearly flat logits, so
-         near-ties are common)."""
+         logit error (if |dlogit| <= e everywhere the arg-max cannot differ at a margin > 2e); fewer than 5 % of the
+         B x n positions may fall below that margin, and there must be NO raw token difference outside them."""
     from lina_speech_amd.configs import l169
     from lina_speech_amd.decode import DecodeEngine
     from oracle.lina_decode_oracle import OracleLina
     torch.manual_seed(0)
-    model = l169().eval()
+    from model_cases import peak_logits
+    model = peak_logits(l169().eval())
     B, n, REL = 64, 32, 2e-2
-    MASK_CAP = 0.45          # measured on MI355X: 33-36 % of the positions are near-ties at 2 x the logit error (random-init weights)
+    MASK_CAP = 0.05          # peaked logits: (almost) every position is comparable (round 3, flat logits: 30 % were not)
     x = torch.randint(3, 256, (B, 24), generator=torch.Generator().manual_seed(7))
     mb = model.to(torch.bfloat16)
     sd = {k: v.float() for k, v in mb.state_dict().items()}          # the oracle sees the SAME (bf16-rounded) weights
@@ -204,8 +206,9 @@ def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
     n_masked, n_diff = int((~safe).sum()), int((toks[0] != ref_toks[0]).sum())
     print(f"\nbf16 B=64 engine vs fp32 oracle over {n} free-running steps: max |logit error| of the windowed loop = "
           f"{worst_loop:.4f} = {worst_loop / scale:.2e} of max|logit| (generic step API {worst / scale:.2e}); {n_masked} of "
-          f"{B * n} positions have a top-2 margin <= {2 * worst:.4f} (not comparable); {n_diff} raw token differences, "
-          f"all of them at such positions")
+          f"{B * n} positions have a top-2 margin <= {2 * worst:.4f} (not comparable); {n_diff} raw token differences "
+          f"(all of them must be at such positions); oracle top-2 margin / max|logit|: min {float(margins.min()) / scale:.3f}, "
+          f"median {float(margins.median()) / scale:.3f}; distinct tokens decoded: {int(toks.unique().numel())}")
     record_parity("L169 bf16 B=64 windowed device loop: its own logits vs fp32 oracle (teacher-forced on the loop's tokens)",
                   worst_loop / scale, REL, steps=n, first_step=float(per_step[0] / scale), last_step=float(per_step[-1] / scale))
     record_parity("L169 bf16 B=64: positions with a top-2 margin <= 2 x max logit error (excluded from the token comparison)",
@@ -213,6 +216,43 @@ def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
     assert worst < REL * scale, f"logits rel err {worst / scale:.3e}"
     assert n_masked < MASK_CAP * B * n
     assert torch.equal(toks[0][safe], ref_toks[0][safe]), "bf16 engine token != oracle arg-max at a clear margin"
+
+
+def test_config4_rows_sharded_equal_unsharded(hip):
+    """BASELINE configs[3] (169M decode, B = 512 batch-sharded over 8 GPUs, no collective) on ONE GPU: the eight
+    `shard_rows(512, r, 8)` engines, run one after another on cuda:0 exactly as rank r of the 8-GPU job would run them
+    (its rows of the text batch, its own state), must produce the tokens of the same rows of a single B = 512 engine --
+    rows never interact (reference model/modeling_lina.py:125,152-179: one state and one token stream per row).  bf16, the
+    headline dtype; peaked logits (model_cases.peak_logits) so that the comparison is not decided by near-ties; the B = 512
+    engine also puts config 4's row count through the HIP path (2048 K1w workgroups, 8 row tiles per projection)."""
+    from lina_speech_amd.configs import l169
+    from lina_speech_amd.decode import DecodeEngine
+    from lina_speech_amd.shard import shard_rows
+    from model_cases import peak_logits
+    torch.manual_seed(0)
+    TOTAL, WORLD, n = 512, 8, 24
+    model = peak_logits(l169().eval()).to("cuda", torch.bfloat16)
+    texts = torch.randint(3, 256, (TOTAL, 32), generator=torch.Generator().manual_seed(1234)).cuda()
+    with torch.inference_mode():
+        def decode(rows):
+            eng = DecodeEngine(model, model.txt_encoder(model.txt_embed(rows)), batch_size=rows.shape[0])
+            eng.begin_greedy(n)
+            eng.greedy_steps(n)
+            toks = eng.greedy_tokens().clone()
+            del eng
+            return toks                                                                     # [1, rows, n]
+        full = decode(texts)
+        assert full.shape == (1, TOTAL, n)
+        n_diff = 0
+        for r in range(WORLD):
+            lo, hi = shard_rows(TOTAL, r, WORLD)
+            assert hi - lo == 64
+            part = decode(texts[lo:hi])
+            n_diff += int((part != full[:, lo:hi]).sum())
+    record_parity("config 4: tokens of 8 x 64-row shard engines vs the same rows of one B=512 engine (differences)", n_diff, 0,
+                  rows=TOTAL, steps=n, distinct_tokens=int(full.unique().numel()))
+    assert n_diff == 0, f"{n_diff} of {TOTAL * n} tokens differ between the sharded and the unsharded batch"
+    assert int(full.unique().numel()) > 100          # not a degenerate decode
 
 
 def test_config3_decode_to_waveform_chain_vs_oracle(hip):
@@ -337,39 +377,3 @@ def test_config5_train_step_at_sequence_length_4096(hip):
         assert all(v == v and v < 1e4 for v in l), l
         assert l[-1] < l[0], l
     assert abs(losses[True][0] - losses[False][0]) < 1e-3 * abs(losses[False][0]), losses
-
-
-@pytest.mark.skipif(__import__("os").environ.get("LINA_TEST_TRAIN_GRAPH") != "1",
-                    reason="opt-in (LINA_TEST_TRAIN_GRAPH=1): replays of the captured train step were seen to hang at the "
-                           "config-5 shape on ROCm 7.2 (DESIGN.md 4.5); this small-shape check passed when run")
-def test_train_step_captured_in_one_hipgraph_follows_the_eager_steps(hip):
-    """TrainStep(graph=True): forward + CE + backward (K2b, K3b, K5b, K10-K13) + fused AdamW recorded once as ONE hipGraph
-    and replayed per step, with the scheduler's learning rate and the optimizer's step count on the device.  The losses of
-    the captured run must follow the eager run's step for step (same seeds, same batches -- a different batch per step,
-    copied into the graph's static inputs), and the schedule must advance (the lr tensor changes between replays)."""
-    from lina_speech_amd import configs
-    from lina_speech_amd.train import TrainStep, synthetic_batch
-    dev = torch.device("cuda", 0)
-    batches = [synthetic_batch(b=2, n=513, t_txt=32, seed=10 + i, ragged=(i % 2 == 1)).to(dev) for i in range(6)]
-    runs = {}
-    for graph in (False, True):
-        torch.manual_seed(0)
-        ts = TrainStep(configs.l169(), device=dev, lr=1e-3, ddp=False, n_warmup_steps=4, graph=graph)
-        # the captured run spends 2 eager warm-up steps on its first batch before recording: give the eager run the same two
-        if not graph:
-            for _ in range(2):
-                ts.opt.zero_grad(set_to_none=True)
-                ts.loss(batches[0]).backward()
-                ts.opt.step()
-        losses, lrs = [], []
-        for bt in batches:
-            losses.append(float(ts.step(bt)))
-            lrs.append(float(ts.opt.param_groups[0]["lr"]))
-        runs[graph] = (losses, lrs)
-        assert (ts._graph is not None) == graph
-        del ts
-        torch.cuda.empty_cache()
-    (le, lre), (lg, lrg) = runs[False], runs[True]
-    assert all(v == v and v < 1e4 for v in lg), lg
-    assert lrg == pytest.approx(lre, rel=1e-6) and lrg[0] < lrg[3], (lre, lrg)
-    assert lg == pytest.approx(le, rel=5e-3), (le, lg)

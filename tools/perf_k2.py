@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT)
 import torch
 from lina_speech_amd import ops
 
-B, H, T, Dk, Dv = int(os.environ.get("K2_B", 64)), 4, int(os.environ.get("K2_T", 4096)), 256, 256
+H = int(os.environ.get("K2_H", 4))                        # heads of the 1024-wide model: head dimension 1024 / H
+B, T, Dk, Dv = int(os.environ.get("K2_B", 64)), int(os.environ.get("K2_T", 4096)), 1024 // H, 1024 // H
 reps = int(os.environ.get("K2_REPS", 5))
 dev = "cuda"
 g = torch.Generator().manual_seed(0)
