@@ -10,13 +10,14 @@
 // critical path of every chunk and twelve waves wait 45 % of the time at two barriers.  With C = 16 every tile halves and
 // BOTH the raw tiles and the operand tiles fit twice (138 KB):
 //
-//   iteration v (ONE barrier per 16 tokens):
-//     DMA    raw chunk v+2 -> raw[v&1]           (two pieces per wave; a whole iteration to land, nobody waits for HBM)
-//     fin    o(v-1) += v^T . mask(A)(v-1);  store o(v-1)
-//     B(v)   MFMAs from ops[v&1]:  o^T = S'^T q^^T (8 x K=32),  mask(A)(v) (wave 0, 8 x K=32),  S' += k^^T v (16 x K=16)
-//     A(v+1) gate scan + scaled operands of the NEXT chunk from raw[(v+1)&1] -> ops[(v+1)&1]   (VALU / LDS)
-//   Waves 0..7 run B then A, waves 8..15 A then B: each SIMD hosts two of either, so its matrix pipe and its VALU are
-//   busy at the same time instead of one after the other.
+//   iteration v (ONE barrier per 16 tokens); the sixteen waves split into two sets of eight (two waves of either set on each
+//   SIMD), whose roles alternate every iteration:
+//     A-waves   fin: o(v-1) += v^T mask(A)(v-1), store;  A(v+1): gate scan + scaled operands of the NEXT chunk, raw[(v+1)&1] ->
+//               ops[(v+1)&1], with the C = 32 kernel's thread map (a thread owns 2 rows x 4 channels: the same VALU work per
+//               token as there; the first version, one row per thread on all sixteen waves, was VALU-bound at 0.76 ms);  B(v)
+//     B-waves   DMA: raw chunk v+2 -> raw[v&1], four pieces per wave (a whole iteration to land);  fin;  mask(A)(v) (one wave);  B(v)
+//     B(v)      MFMAs from ops[v&1]:  o^T = S'^T q^^T (8 x K=32),  S' += k^^T v (16 x K=16)
+//   so a SIMD's VALU (phase A) and its matrix pipe (phase B of the other set) are busy at the same time.
 //
 // Same formulation as gla_chunk_full.hip: UN-normalised state S' with S = diag(e^R) S', q^ = q e^{b+R}, k^ = k e^{-(b+R)},
 // o = scale (q^ S' + mask(q^ k^^T) v), S' += k^^T v, R += b_last, rows rescaled when R < -20; a chunk whose in-chunk decay
@@ -35,10 +36,6 @@ __device__ unsigned long long lina_k2p_prof[16 * 16 + 1024];
 #define K2P_PROF(i) do { const unsigned long long now_ = clock64(); pacc[i] += now_ - plast; plast = now_; } while (0)
 #else
 #define K2P_PROF(i) do { } while (0)
-#endif
-// experiment switches of the tools-only builds (tools/k2_tune.sh); the defaults are the product
-#ifndef LINA_PIPE_ORDER
-#define LINA_PIPE_ORDER 2      // which waves run phase A before phase B: 0 none, 1 all, 2 waves 8..15, 3 (w>>2)&1, 4 w&1
 #endif
 
 namespace lina {
@@ -74,9 +71,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_pipe_kernel(
     // the 16 rows x 2 quads of one half-wave ds_read_b64 cover all 64 banks exactly once.
     constexpr int OPT = 2 * DK * C;                 // elements of one {k^^T | v^T} buffer
     // raw tiles: one DMA piece = one row pair (1 KiB) with the two rows INTERLEAVED at 16-byte granularity (lane -> (piece
-    // l>>1 of row l&1)), + 32 B pad per pair: the 16 rows x 2 channel quads of one phase-A half-wave read hit 64 distinct banks.
-    constexpr int PE = 2 * DK + 16;                 // elements per row pair
-    constexpr int RAWT = (C / 2) * PE;              // per tensor
+    // l>>1 of row l&1)); pair p starts at byte 1024 p + 64 (p>>1) + 16 (p&1): the 8 row pairs x 4 channel quads of one phase-A
+    // half-wave read (8 bytes each) hit 64 distinct banks.
+    constexpr int RAWT = (C / 2) * 2 * DK + 128;    // per tensor (elements)
     constexpr int RAWB = 4 * RAWT;                  // per buffer {q, k, g, v}
     __shared__ __attribute__((aligned(16))) bf16_t s_qk[2 * OPQ];
     __shared__ __attribute__((aligned(16))) bf16_t s_T[2 * OPT];
@@ -96,8 +93,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_pipe_kernel(
     const int t_begin = (slot % nseg) * Tseg;
     const int T = min(Tseg, T_total - t_begin);               // tokens of this segment (>= 1 by construction)
     const int NJ = (T + C - 1) / C;                           // raw chunks
-    const bool a_first = LINA_PIPE_ORDER == 0 ? false : LINA_PIPE_ORDER == 1 ? true : LINA_PIPE_ORDER == 2 ? ((w >> 3) & 1) != 0
-                         : LINA_PIPE_ORDER == 3 ? ((w >> 2) & 1) != 0 : (w & 1) != 0;
+    const int wset = (w >> 2) & 1;                            // the two wave sets: {0-3, 8-11} and {4-7, 12-15} (two waves of each per SIMD)
+    const int wa = 4 * (w >> 3) + (w & 3);                    // index of this wave inside its set, 0..7
+    auto pair_base = [](int p) { return p * (2 * DK) + 32 * (p >> 1) + 8 * (p & 1); };   // elements
 
     // ---- state: wave w owns columns [16w, 16w+16); tile p = rows [16p, 16p+16) in C/D layout (col = li, row = 4 lg + reg) ----
     f32x4 S[16];
@@ -117,108 +115,142 @@ __global__ __launch_bounds__(1024) void gla_chunk_pipe_kernel(
     const bf16_t* const gv = v + b * sv.b + h * sv.h + t_begin * sv.t;
     bf16_t* const ob = o + b * so.b + h * so.h + t_begin * so.t;
 
-    // Prefetch of raw chunk j into raw[j&1]: 32 pieces (4 tensors x 8 row pairs), two per wave.  Lane l fetches the 16-byte piece
-    // l>>1 of row 2*pair + (l&1) (the interleaved pair layout above); rows past the end re-read row T-1 (phase A masks them).
-    // Addressed as (uniform 64-bit base) + (32-bit byte offset per lane), issued through inline assembly, waited for by hand.
+    // Prefetch of raw chunk j into raw[j&1]: 32 pieces (4 tensors x 8 row pairs), four per wave of the set whose turn it is NOT to
+    // run phase A (wave wa: tensor wa>>1, pairs 4 (wa&1) .. +3).  Lane l fetches the 16-byte piece l>>1 of row 2*pair + (l&1);
+    // rows past the end re-read row T-1 (phase A masks them).  Addressed as (uniform 64-bit base) + (32-bit byte offset per lane),
+    // issued through inline assembly, waited for by hand.
     const unsigned stq = (unsigned)sq.t, stk = (unsigned)sk.t, stg = (unsigned)sg.t, stv = (unsigned)sv.t;   // < 2^20 (launcher)
-    auto dma_piece = [&](const bf16_t* src, unsigned st, bf16_t* dst_tensor, int j, int pair) {
-        const unsigned t = (unsigned)min(C * j + 2 * pair + (lane & 1), T - 1);
-        const unsigned boff = 2u * (t * st + 8u * (unsigned)(lane >> 1));
-        dma16_to_lds_async(src, boff, &dst_tensor[pair * PE]);   // (non-temporal: every byte is read once, LINA_DMA_NT below)
+    auto dma_pieces = [&](const bf16_t* src, unsigned st, bf16_t* dst_tensor, int j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pair = 4 * (wa & 1) + i;
+            const unsigned t = (unsigned)min(C * j + 2 * pair + (lane & 1), T - 1);
+            const unsigned boff = 2u * (t * st + 8u * (unsigned)(lane >> 1));
+            dma16_to_lds_async(src, boff, &dst_tensor[pair_base(pair)]);
+        }
     };
     auto dma_chunk = [&](int j) {
         bf16_t* const dst = &s_raw[(j & 1) * RAWB];
-        const int pair = w & 7;
-        if (w < 8) {                                           // wave-uniform branch; the tensors are compile-time in each arm
-            dma_piece(gq, stq, dst, j, pair);
-            dma_piece(gkk, stk, dst + RAWT, j, pair);
-        } else {
-            dma_piece(gg, stg, dst + 2 * RAWT, j, pair);
-            dma_piece(gv, stv, dst + 3 * RAWT, j, pair);
-        }
+        const int a = wa >> 1;                                 // wave-uniform; the tensors are compile-time in each arm
+        if (a == 0) dma_pieces(gq, stq, dst, j);
+        else if (a == 1) dma_pieces(gkk, stk, dst + RAWT, j);
+        else if (a == 2) dma_pieces(gg, stg, dst + 2 * RAWT, j);
+        else dma_pieces(gv, stv, dst + 3 * RAWT, j);
     };
 
-    // ---- phase A thread map: wave w <-> channels [16w, 16w+16); lane = (channel quad c4 = lane>>4, row r = lane&15): the gate
-    // scan over the 16 rows of a channel quad is four fused DPP adds per value inside one 16-lane row.
-    // inclusive gate cumsum over rows [lo, r] of raw[rbuf] (rows outside [lo, end) count as 0); true if this row's in-chunk
-    // decay is too large for one chunk (monotone: the last row sees the chunk total)
-    auto gate_scan = [&](float (&bc)[4], int rbuf, int lo, int end) -> bool {
-        const int r = lane & 15, c4 = lane >> 4;
-        const bf16_t* gp = &s_raw[rbuf * RAWB + 2 * RAWT + (r >> 1) * PE + 16 * (2 * w + (c4 >> 1)) + 8 * (r & 1) + 4 * (c4 & 1)];
-        float g[4];
-        unpack4(*reinterpret_cast<const uint2*>(gp), g);
-        const bool in = r >= lo && r < end;
+    // ---- phase A thread map (eight waves): wave wa <-> channels [32 wa, 32 wa + 32); lane = (channel quad cq = lane>>3, row pair
+    // rp = lane&7): a 16-lane DPP row holds two channel quads x 8 row pairs, so the gate scan is the 16-lane scan (four fused DPP
+    // adds per value) + one masked subtraction of the first half's total in the second half; the thread owns two ADJACENT tokens
+    // and writes k^^T / v^T as 4-byte pieces.
+    // inclusive gate cumsum over the rows [lo, .] of raw[rbuf] for this thread's 2 rows x 4 channels (rows outside [lo, end) count
+    // as 0); true if the in-chunk decay at this thread's second row is too large for one chunk (monotone in the row)
+    auto gate_scan = [&](float (&bc)[2][4], int rbuf, int lo, int end) -> bool {
+        const int rp = lane & 7, cq = lane >> 3;
+        const bf16_t* gp = &s_raw[rbuf * RAWB + 2 * RAWT + pair_base(rp) + 16 * (4 * wa + (cq >> 1)) + 4 * (cq & 1)];
+        float g0[4], g1[4];
+        unpack4(*reinterpret_cast<const uint2*>(gp), g0);
+        unpack4(*reinterpret_cast<const uint2*>(gp + 8), g1);
+        const bool in0 = 2 * rp >= lo && 2 * rp < end, in1 = 2 * rp + 1 >= lo && 2 * rp + 1 < end;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) bc[c] = in ? vmax_raw(g[c], -kPipeMaxDecay) : 0.0f;
-        row_scan4(bc[0], bc[1], bc[2], bc[3]);
+        for (int c = 0; c < 4; ++c) {
+            g0[c] = in0 ? vmax_raw(g0[c], -kPipeMaxDecay) : 0.0f;
+            g1[c] = in1 ? vmax_raw(g1[c], -kPipeMaxDecay) : 0.0f;
+            bc[1][c] = g0[c] + g1[c];                         // the row pair's sum
+        }
+        row_scan4(bc[1][0], bc[1][1], bc[1][2], bc[1][3]);
+        row_half_fix4(bc[1][0], bc[1][1], bc[1][2], bc[1][3]);
         bool viol = false;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) viol |= (-bc[c] > kPipeMaxDecay);
+        for (int c = 0; c < 4; ++c) {
+            bc[0][c] = bc[1][c] - g1[c];                      // the pair's first row
+            viol |= (-bc[1][c] > kPipeMaxDecay);
+        }
         return viol;
+    };
+    // first row of this thread's pair whose in-chunk decay is too large (C if none): the rare path's cut position
+    auto first_bad = [&](const float (&bc)[2][4]) -> int {
+        int nc = C;
+#pragma unroll
+        for (int rr = 1; rr >= 0; --rr) {
+            bool bad = false;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bad |= (-bc[rr][c] > kPipeMaxDecay);
+            if (bad) nc = 2 * (lane & 7) + rr;
+        }
+        return nc;
     };
     // operand tiles of a virtual chunk = rows [lo, hi) of raw[rbuf] -> ops[pn]; rows outside are zeroed.  The owner of row
     // hi-1 publishes R after the chunk (s_Rn[pn]) and the renormalisation flag.  q^ carries NO 1/sqrt(Dk) (applied to o).
-    auto write_tiles = [&](const float (&bc)[4], int pn, int rbuf, int lo, int hi, bool zero_r, int rpar, int gen) {
+    auto write_tiles = [&](const float (&bc)[2][4], int pn, int rbuf, int lo, int hi, bool zero_r, int rpar, int gen) {
         constexpr float kLog2e = 1.4426950408889634f;
-        const int r = lane & 15, c4 = lane >> 4, ch0 = 16 * w + 4 * c4;
-        const bool valid = r >= lo && r < hi;
-        const bf16_t* const rawp = &s_raw[rbuf * RAWB + (r >> 1) * PE + 16 * (2 * w + (c4 >> 1)) + 8 * (r & 1) + 4 * (c4 & 1)];
+        const int rp = lane & 7, cq = lane >> 3, ch0 = 32 * wa + 4 * cq;
+        const bf16_t* const rawp = &s_raw[rbuf * RAWB + pair_base(rp) + 16 * (4 * wa + (cq >> 1)) + 4 * (cq & 1)];
         float4 R4 = *reinterpret_cast<const float4*>(&s_Rn[rpar * DK + ch0]);
         if (zero_r) R4 = make_float4(0.f, 0.f, 0.f, 0.f);
         const float Rc[4] = {R4.x, R4.y, R4.z, R4.w};
-        float x[4], e[4], ri[4], f[4];
+        uint2 kk[2], vv[2];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            x[c] = __builtin_fmaf(bc[c], kLog2e, Rc[c]);       // (b + R) log2 e: |b| <= 60 in a legal chunk, |R| <= kPipeRenorm + 60
-            e[c] = fast_exp2(x[c]);
-            ri[c] = fast_rcp(e[c]);
-        }
-        // column of this thread's channel quad in the q^ / k^ tiles: group w/2, piece c4 ^ ((row>>2)&3), half w&1
-        bf16_t* const qkp = &s_qk[pn * OPQ + r * SQ + 32 * (w >> 1) + 8 * (c4 ^ ((r >> 2) & 3)) + 4 * (w & 1)];
-        uint2 pq, kk, vv;
-        unpack4(*reinterpret_cast<const uint2*>(rawp), f);
-        pq.x = pack_bf16x2(f[0] * e[0], f[1] * e[1]);          // rows outside [lo, hi): zeroed as packed words
-        pq.y = pack_bf16x2(f[2] * e[2], f[3] * e[3]);
-        pq.x = valid ? pq.x : 0u; pq.y = valid ? pq.y : 0u;
-        *reinterpret_cast<uint2*>(qkp) = pq;
-        unpack4(*reinterpret_cast<const uint2*>(rawp + RAWT), f);
-        kk.x = pack_bf16x2(f[0] * ri[0], f[1] * ri[1]);
-        kk.y = pack_bf16x2(f[2] * ri[2], f[3] * ri[3]);
-        kk.x = valid ? kk.x : 0u; kk.y = valid ? kk.y : 0u;
-        *reinterpret_cast<uint2*>(qkp + C * SQ) = kk;
-        const uint2 rv = *reinterpret_cast<const uint2*>(rawp + 3 * RAWT);
-        vv.x = valid ? rv.x : 0u; vv.y = valid ? rv.y : 0u;
-        if (r == hi - 1) {                                     // owner of the chunk's last row: R after the chunk
-            bool need = false;
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * rp + rr;
+            const bool valid = row >= lo && row < hi;
+            float x[4], e[4], ri[4], f[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) need |= x[c] < -kPipeRenorm * kLog2e;
-            *reinterpret_cast<float4*>(&s_Rn[pn * DK + ch0]) = make_float4(x[0], x[1], x[2], x[3]);
-            if (need) s_flag[2 * pn + 1] = gen;
+            for (int c = 0; c < 4; ++c) {
+                x[c] = __builtin_fmaf(bc[rr][c], kLog2e, Rc[c]);   // (b + R) log2 e: |b| <= 60 in a legal chunk, |R| <= kPipeRenorm + 60
+                e[c] = fast_exp2(x[c]);
+                ri[c] = fast_rcp(e[c]);
+            }
+            // column of this thread's channel quad in the q^ / k^ tiles: group wa (32 channels), piece (cq&3) ^ ((row>>2)&3), half cq>>2
+            bf16_t* const qkp = &s_qk[pn * OPQ + row * SQ + 32 * wa + 8 * ((cq & 3) ^ ((row >> 2) & 3)) + 4 * (cq >> 2)];
+            uint2 pq;
+            unpack4(*reinterpret_cast<const uint2*>(rawp + 8 * rr), f);
+            pq.x = pack_bf16x2(f[0] * e[0], f[1] * e[1]);      // rows outside [lo, hi): zeroed as packed words
+            pq.y = pack_bf16x2(f[2] * e[2], f[3] * e[3]);
+            pq.x = valid ? pq.x : 0u; pq.y = valid ? pq.y : 0u;
+            *reinterpret_cast<uint2*>(qkp) = pq;
+            unpack4(*reinterpret_cast<const uint2*>(rawp + RAWT + 8 * rr), f);
+            kk[rr].x = pack_bf16x2(f[0] * ri[0], f[1] * ri[1]);
+            kk[rr].y = pack_bf16x2(f[2] * ri[2], f[3] * ri[3]);
+            kk[rr].x = valid ? kk[rr].x : 0u; kk[rr].y = valid ? kk[rr].y : 0u;
+            *reinterpret_cast<uint2*>(qkp + C * SQ) = kk[rr];
+            const uint2 rv = *reinterpret_cast<const uint2*>(rawp + 3 * RAWT + 8 * rr);
+            vv[rr].x = valid ? rv.x : 0u; vv[rr].y = valid ? rv.y : 0u;
+            if (row == hi - 1) {                               // owner of the chunk's last row: R after the chunk
+                bool need = false;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) need |= x[c] < -kPipeRenorm * kLog2e;
+                *reinterpret_cast<float4*>(&s_Rn[pn * DK + ch0]) = make_float4(x[0], x[1], x[2], x[3]);
+                if (need) s_flag[2 * pn + 1] = gen;
+            }
         }
-        // transposed tiles: element (channel ch0+i, token r) at row (ch0+i), position 4*((r>>2) ^ 2*(c4>>1)) + (r&3)
-        // ((ch0+i) & 15 = 4 c4 + i, so (row>>3)&1 = c4>>1)
-        bf16_t* const tp = &s_T[pn * OPT + ch0 * C + 4 * ((r >> 2) ^ (2 * (c4 >> 1))) + (r & 3)];
-        tp[0] = (bf16_t)(kk.x & 0xffff); tp[C] = (bf16_t)(kk.x >> 16);
-        tp[2 * C] = (bf16_t)(kk.y & 0xffff); tp[3 * C] = (bf16_t)(kk.y >> 16);
-        tp[DK * C] = (bf16_t)(vv.x & 0xffff); tp[DK * C + C] = (bf16_t)(vv.x >> 16);
-        tp[DK * C + 2 * C] = (bf16_t)(vv.y & 0xffff); tp[DK * C + 3 * C] = (bf16_t)(vv.y >> 16);
+        // transposed tiles: element (channel ch0+i, tokens 2rp, 2rp+1) = one 4-byte word at row ch0+i, token-quad position
+        // (rp>>1) ^ 2*((row>>3)&1) with (row>>3)&1 = (cq>>1)&1, word (rp&1) of the quad
+        bf16_t* const tp = &s_T[pn * OPT + ch0 * C + 4 * ((rp >> 1) ^ (2 * ((cq >> 1) & 1))) + 2 * (rp & 1)];
+        *reinterpret_cast<unsigned*>(tp) = byte_perm(kk[1].x, kk[0].x, 0x05040100u);
+        *reinterpret_cast<unsigned*>(tp + C) = byte_perm(kk[1].x, kk[0].x, 0x07060302u);
+        *reinterpret_cast<unsigned*>(tp + 2 * C) = byte_perm(kk[1].y, kk[0].y, 0x05040100u);
+        *reinterpret_cast<unsigned*>(tp + 3 * C) = byte_perm(kk[1].y, kk[0].y, 0x07060302u);
+        *reinterpret_cast<unsigned*>(tp + DK * C) = byte_perm(vv[1].x, vv[0].x, 0x05040100u);
+        *reinterpret_cast<unsigned*>(tp + DK * C + C) = byte_perm(vv[1].x, vv[0].x, 0x07060302u);
+        *reinterpret_cast<unsigned*>(tp + DK * C + 2 * C) = byte_perm(vv[1].y, vv[0].y, 0x05040100u);
+        *reinterpret_cast<unsigned*>(tp + DK * C + 3 * C) = byte_perm(vv[1].y, vv[0].y, 0x07060302u);
     };
     // phase A of virtual chunk (raw chunk j, first row lo), optimistic (all rows up to the raw chunk's end): sets the cut
-    // flag (generation gen) when the chunk must be cut
+    // flag (generation gen) when the chunk must be cut.  Run by the eight waves of one set.
     auto phase_a = [&](int pn, int j, int lo, bool zero_r, int rpar, int gen) {
         const int end = min(C, T - C * j);
-        float bc[4];
+        float bc[2][4];
         if (gate_scan(bc, j & 1, lo, end)) s_flag[2 * pn] = gen;
         write_tiles(bc, pn, j & 1, lo, end, zero_r, rpar, gen);
     };
 
     if (threadIdx.x < 4) s_flag[threadIdx.x] = 0;
     if (threadIdx.x == 4) s_cut = 0;
-    dma_chunk(0);
-    if (NJ > 1) dma_chunk(1);
+    if (wset == 0) dma_chunk(0);
+    else if (NJ > 1) dma_chunk(1);
     wait_vmem();
     __syncthreads();                                           // raw chunks 0 (and 1) landed; flags initialised
-    phase_a(0, 0, 0, true, 0, 1);
+    if (wset == 1) phase_a(0, 0, 0, true, 0, 1);               // (iteration v's phase A belongs to set v&1; chunk 0's to set 1)
     __syncthreads();                                           // ops[0] complete
 
     int vj = 0, vlo = 0;                                       // current virtual chunk: raw chunk, first row
@@ -253,32 +285,38 @@ __global__ __launch_bounds__(1024) void gla_chunk_pipe_kernel(
         if (s_flag[2 * par] == vi + 1) {
             // ---- rare: the decay inside this chunk exceeds e^-60 -> cut it at the first such row; the rest of the raw chunk
             //      becomes the next virtual chunk.  Workgroup-uniform branch.
-            float bc[4];
-            const bool bad = gate_scan(bc, vj & 1, vlo, end);
-            if (bad) lds_atomic_max(&s_cut, C - (lane & 15));  // first bad row of the workgroup = C - max
+            // (the rewrite is the work of the set that ran this chunk's optimistic phase A; everybody meets at the barriers)
+            const bool mine = wset == ((vi & 1) ^ 1);
+            float bc[2][4];
+            if (mine) {
+                gate_scan(bc, vj & 1, vlo, end);
+                const int nc = first_bad(bc);
+                if (nc < C) lds_atomic_max(&s_cut, C - nc);    // first bad row of the workgroup = C - max
+            }
             __syncthreads();
             hi = max(min(end, C - s_cut), vlo + 1);            // row vlo itself is never bad (one clamped gate)
             __syncthreads();                                   // everyone has read s_cut; the optimistic tiles are dead
-            if (threadIdx.x == 0) s_cut = 0;
+            if (threadIdx.x == 0) { int z = 0; opaque(z); s_cut = z; }
             const bool zr = vi == 0 || s_flag[2 * (par ^ 1) + 1] == vi;   // R this chunk started from (intact until phase A below)
-            write_tiles(bc, par, vj & 1, vlo, hi, zr, par ^ 1, vi + 1);
+            if (mine) write_tiles(bc, par, vj & 1, vlo, hi, zr, par ^ 1, vi + 1);
             __syncthreads();
         }
         const bool renorm = s_flag[2 * par + 1] == vi + 1;     // workgroup-uniform
         const bool split = hi < end;
         const int nj = split ? vj : vj + 1, nlo = split ? hi : 0;
         const bool more = nj < NJ;
+        const bool a_wave = wset == (vi & 1);                  // this iteration's phase-A set (wave-uniform)
         // raw chunk vj is consumed (phase A of its last virtual chunk ran in the previous iteration): its buffer takes chunk vj+2
-        if (!split && vj + 2 < NJ) dma_chunk(vj + 2);
+        if (!a_wave && !split && vj + 2 < NJ) dma_chunk(vj + 2);
         K2P_PROF(0);
         if (vi > 0) finish_prev(par ^ 1);
         K2P_PROF(1);
 
-        if (a_first && more) phase_a(par ^ 1, nj, nlo, renorm, par, vi + 2);
+        if (a_wave && more) phase_a(par ^ 1, nj, nlo, renorm, par, vi + 2);
         K2P_PROF(2);
 
         // ---------------- phase B of virtual chunk vi ----------------
-        if (w == 0) {
+        if (!a_wave && wa == 0) {
             // mask(A)^T[s][t] = k^_s . q^_t (s <= t), once per workgroup: C/D layout (col t = li, rows s = 4lg + r) IS the B
             // operand layout of the K=16 MFMA of the intra-chunk term -> each lane masks and stores its 4 values as 8 bytes
             wave_priority<2>();
@@ -358,9 +396,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_pipe_kernel(
         for (int r = 0; r < 4; ++r) accp[r] = acc[0][r] + acc[1][r];
         ptok = C * vj; plo = vlo; phi = hi;
         K2P_PROF(5);
-
-        if (!a_first && more) phase_a(par ^ 1, nj, nlo, renorm, par, vi + 2);
-        K2P_PROF(2);
 
         wait_vmem();                                           // this wave's prefetch pieces have landed ...
         K2P_PROF(6);

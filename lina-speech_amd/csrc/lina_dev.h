@@ -176,6 +176,17 @@ __device__ __forceinline__ void row_scan4(float& a, float& b, float& c, float& d
     LINA_DPP_STEP4(4);
     LINA_DPP_STEP4(8);
 }
+// after row_scan4 over a row that holds TWO independent 8-lane groups: lanes 8..15 of every row subtract the value of lane 7
+// (the first group's total), so that each half holds its own inclusive scan.  row_newbcast:7 = lane 7 of the row for every
+// lane; bank_mask 0xc = only banks 2,3 (lanes 8..15) are written.
+__device__ __forceinline__ void row_half_fix4(float& a, float& b, float& c, float& d) {
+    asm("s_nop 1\n\t"
+        "v_subrev_f32_dpp %0, %0, %0 row_newbcast:7 row_mask:0xf bank_mask:0xc\n\t"
+        "v_subrev_f32_dpp %1, %1, %1 row_newbcast:7 row_mask:0xf bank_mask:0xc\n\t"
+        "v_subrev_f32_dpp %2, %2, %2 row_newbcast:7 row_mask:0xf bank_mask:0xc\n\t"
+        "v_subrev_f32_dpp %3, %3, %3 row_newbcast:7 row_mask:0xf bank_mask:0xc"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 #undef LINA_DPP_STEP4
 // max as ONE v_max_f32 (fmaxf first canonicalises an operand the compiler cannot prove quiet: two instructions)
 __device__ __forceinline__ float vmax_raw(float a, float b) {

@@ -327,6 +327,15 @@ static inline void row_scan4(float& a, float& b, float& c, float& d) {
     a += dpp_row_shr<4>(a); b += dpp_row_shr<4>(b); c += dpp_row_shr<4>(c); d += dpp_row_shr<4>(d);
     a += dpp_row_shr<8>(a); b += dpp_row_shr<8>(b); c += dpp_row_shr<8>(c); d += dpp_row_shr<8>(d);
 }
+static inline void row_half_fix4(float& a, float& b, float& c, float& d) {
+    float* v[4] = {&a, &b, &c, &d};
+    for (int i = 0; i < 4; ++i) {
+        uint32_t mine = f2u(*v[i]), tab[64];
+        lina_emu::wave_exchange(&mine, 1, tab);
+        const int l = lina_emu::cur_lane();
+        if ((l & 15) >= 8) *v[i] -= u2f(tab[(l & ~15) + 7]);
+    }
+}
 static inline float vmax_raw(float a, float b) { return a > b ? a : b; }
 static inline unsigned byte_perm(unsigned hi, unsigned lo, unsigned sel) {
     const uint64_t v = ((uint64_t)hi << 32) | lo;
