@@ -40,14 +40,6 @@ __device__ unsigned long long lina_k2_prof[16 * 16 + 3 * 1024];   // + per workg
 #endif
 
 
-// LINA_K2_EARLY (tools-only experiment, default 0): in the key-gated sweeps (MODE 0) the prefetch of chunk n+1 issued DURING
-// phase A of chunk n -- by the loader waves, at raised priority, as soon as every wave has signalled through an LDS counter that
-// its raw reads are done -- instead of after barrier (2).  MEASURED SLOWER (round 4, profiles/r04_k2early_*): 0.676 vs 0.597 ms at
-// B=64,H=4,T=4096 -- a DMA issued while phase A hammers the LDS costs the loaders ~3000 clocks and everybody waits for them at
-// barrier (2) instead of (3).  The hoisted raw reads / early v^T writes it needs are register-neutral and stay.
-#ifndef LINA_K2_EARLY
-#define LINA_K2_EARLY 0
-#endif
 
 namespace lina {
 
@@ -145,8 +137,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // barrier (2) fetches both (three dependent LDS round trips -- flag, flag, R -- sat in front of every wave's MFMAs)
     __shared__ __attribute__((aligned(8))) unsigned s_flags[4];
     __shared__ int s_cut;
-    __shared__ int s_cons;                                    // EARLY: waves whose raw reads of the current chunk are done, summed over chunks
-    constexpr bool EARLY = LINA_K2_EARLY != 0 && MODE == 0;
     __shared__ __attribute__((aligned(16))) float s_carry[DG ? DK : 4];   // DG: running sum of d per channel (wave-private quads)
 
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -196,13 +186,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // them at (3).  So ONLY the last four waves (one per SIMD, the lowest issue priority) issue DMAs, 16 each (row pairs
     // 4(w-12) .. +3); the other twelve go straight to their MFMAs and the four catch up on SIMDs the others have left.
     // Rows past the end of the sequence re-read row T-1 (always mapped); phase A masks them.
-#ifndef LINA_K2_LOADERS
-#define LINA_K2_LOADERS 4
-#endif
-#ifndef LINA_K2_LPRIO
-#define LINA_K2_LPRIO 3
-#endif
-    constexpr int kLoaders = LINA_K2_LOADERS;   // loader waves (measured on the final kernel: 8 loaders 0.598 ms, 2 loaders 0.612, 4 loaders 0.592)
+    constexpr int kLoaders = 4;   // loader waves (measured on the final kernel: 8 loaders 0.598 ms, 2 loaders 0.612, 4 loaders 0.592)
     constexpr int kDmaWave0 = 16 - kLoaders, kPairsPer = 16 / kLoaders;
     // memory row (relative to the segment's first token) of visited row tl <= T-1 of tensor a; REV: the gate (a == 2) of a
     // visited row is the gate of the token after it, clamped to the sequence (the one row past it is zeroed in gate_scan)
@@ -266,8 +250,8 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // MODE 1: slot 0 (X) and slot 1 (Y) are copied raw, slot 3 (Z) is gated like k; X goes to tile row 16 rr + rp (token
     // 2 rp + rr: the column permutation of the products, see the kernel header); Eo = the output factors e^{b+R} of this thread's
     // two tokens x four channels.
-    // MODE 0: the raw q / k / v rows of this thread (two rows x four channels each), read BEFORE the gate scan: the LDS returns
-    // a wave's reads in order, so once the scan has used the gates (requested last) every raw value of the wave has left the tiles
+    // MODE 0: the raw q / k / v rows of this thread (two rows x four channels each), requested in front of the gate scan: they
+    // arrive under the scan instead of being waited for one by one inside the tile writes
     auto read_raw = [&](uint2 (&hq)[2], uint2 (&hk)[2], uint2 (&hv)[2]) {
         const bf16_t* const rawp = &s_raw[rp * PE + ch0];
 #pragma unroll
@@ -396,12 +380,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         for (int c = tid; c < DK; c += 1024) s_carry[c] = carry ? carry[(int64_t)slot * DK + c] : 0.0f;
     if (tid < 4) s_flags[tid] = 0;
     if (tid == 2) s_cut = 0;
-    if (tid == 3) s_cons = 0;
     dma_chunk(0, STATE_ONLY ? 1 : 0, 4);
     wait_vmem();
     __syncthreads();   // DMA of chunk 0 landed
     int t0 = 0, par = 0;                                      // par: chunk parity
-    int chunk_no = 0;                                         // EARLY: iterations so far (every wave signals once per iteration)
     int tp = 0, np = 0;                                       // previous chunk: its o is stored at the END of the next phase A
     f32x4 acc[2] = {};       // o^T: this wave's 16 columns (rows 4lg + r) x tokens [16nt, 16nt+16) (column li)
     // o straight from the accumulators.  The products were taken TRANSPOSED (state / v as the A operand), so a lane holds 4
@@ -507,9 +489,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         // (and, in sweep K, the aux rows requested before step (4)) are dead before the tile writes need their registers
         float En[2][4];                                        // MODE 1: this chunk's output factors
         if (DG && np > 0) store_prev();                        // sweep K: before the gate scan (its registers: aux, aux2, q rows)
-        if constexpr (EARLY) {
-            if (w >= kDmaWave0) wave_priority<LINA_K2_LPRIO>();   // the loader waves finish their phase A first ...
-        }
         {
             float bc[2][4];
             uint2 hq[2], hk[2], hv[2];
@@ -522,25 +501,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             if (nrem >= C) viol = gate_scan(FullT{}, bc, nrem);   // workgroup-uniform: the mask-free form
             else viol = gate_scan(PartT{}, bc, nrem);
             if (viol) s_flags[2 * par] = 1;
-            if constexpr (EARLY) {
-                // this wave's raw reads have left the tiles (the scan used the gates, requested last; the LDS serves a wave's
-                // operations in order, and so the add below comes after them)
-                if (lane == 0) lds_signal_add(&s_cons, 1);
-            }
             if (MODE == 1 && !DG && np > 0) store_prev();
             if (nrem >= C) write_tiles(FullT{}, bc, C, par, En, zq, hq, hk, hv);
             else write_tiles(PartT{}, bc, n, par, En, zq, hq, hk, hv);
-        }
-        if constexpr (EARLY) {
-            // ... and issue the next chunk's prefetch while the other twelve are still in theirs: the raw tiles are free once all
-            // sixteen waves have signalled.  Optimistic chunk length (a cut re-issues below).
-            if (w >= kDmaWave0) {
-                if (t0 + n < T) {
-                    lds_wait_ge(&s_cons, 16 * (chunk_no + 1));
-                    dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);
-                }
-                wave_priority<0>();
-            }
         }
         K2_PROF(0);
         if (MODE == 0 && np > 0) store_prev();
@@ -552,13 +515,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         float rn = tid < DK ? s_Rn[tid] : 0.0f;                 // for the roll of R below, fetched in the same round trip
         if (fl.x) {
             // ---- rare: the decay inside this chunk exceeds e^-60 -> cut the chunk at the first such row ----
-            if constexpr (EARLY) {
-                // the early prefetch is overwriting the raw tiles: fetch THIS chunk again (a wave's loads land in issue order,
-                // so these pieces land after the stale ones); the next chunk is requested again below, from the cut position
-                dma_chunk(t0, STATE_ONLY ? 1 : 0, 4);
-                wait_vmem();
-                __syncthreads();
-            }
             float bc[2][4];
             gate_scan(PartT{}, bc, nrem);
             int nc = C;
@@ -589,7 +545,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         const bool more = t0 + n < T;
         // (the loader waves interleaving their 16 DMA instructions with their own step-(1) MFMAs instead: 0.644 ms vs 0.592 --
         //  the pieces land later and everybody waits at (3); measured round 2, tests/gpu_k2var.sh)
-        if (more && (!EARLY || fl.x)) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);   // next chunk's raw q,k,g,v fly under phase B
+        if (more) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);   // next chunk's raw q,k,g,v fly under phase B
         if (STATE_ONLY && w == 0) {                                    // s_dec is stable between barriers (2) and (3)
             const float4 d = *reinterpret_cast<const float4*>(&s_dec[4 * lane]);
             decp.x *= d.x; decp.y *= d.y; decp.z *= d.z; decp.w *= d.w;
@@ -798,7 +754,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         }
         par ^= 1;
         t0 += n;
-        ++chunk_no;
         if constexpr (REV) gate_zero0 = false;
     }
     lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
@@ -854,11 +809,6 @@ static bool full_ok(int H, int Dk, int Dv, int dtype, const void* q, const void*
     return p16(q) && p16(k) && p16(v) && p16(gk) && p16(o);
 }
 
-// gla_chunk_pipe.hip: the software-pipelined 16-token-chunk form of the plain forward (one head per workgroup)
-int launch_chunk_pipe(const void* q, const void* k, const void* v, const void* gk, void* o, const float* h0, float* ht,
-                      int slots, int H, int T, int nseg, int Tseg, lina_bht_strides sq, lina_bht_strides sk,
-                      lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides so, float scale, lina_stream_t stream);
-
 int launch_chunk_full(const void* q, const void* k, const void* v, const void* gk, void* o, const float* h0,
                       float* ht, int B, int H, int T, int Dk, int Dv, lina_bht_strides sq, lina_bht_strides sk,
                       lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides so, int dtype, int g_dtype,
@@ -868,9 +818,6 @@ int launch_chunk_full(const void* q, const void* k, const void* v, const void* g
              fits32(sv) && fits32(sg) && fits32(so);
     if (!*taken) return LINA_OK;
     const int G = 256 / Dk;
-#ifdef LINA_K2_PIPE   // measured slower (0.762 vs 0.599 ms, profiles/r04_k2pipe_*): opt-in experiment build only
-    if (G == 1) return launch_chunk_pipe(q, k, v, gk, o, h0, ht, B * H, H, T, 1, T, sq, sk, sv, sg, so, scale, stream);
-#endif
     dim3 grid((unsigned)(B * H / G));
 #define LINA_FULL(GG)                                                                                                  \
     LINA_LAUNCH((gla_chunk_bf16_h256_kernel<false, GG>), grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k, \

@@ -16,7 +16,6 @@ namespace lina {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((uint32_t)h << 16); }
 // fp32 -> bf16, round-to-nearest-even, via the native __bf16 conversion (v_cvt_pk_bf16_f32 on gfx950;
@@ -46,12 +45,6 @@ __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c)
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                    __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-
-//   v_mfma_f32_16x16x16_bf16 : A[i=l&15][k=4*(l>>4)+j]  B[k=4*(l>>4)+j][n=l&15]   (j<4); C/D as above -- the K = 16 form:
-//   same issue time as the K = 32 form, half the operand registers / LDS bytes (for contractions over 16 tokens)
-__device__ __forceinline__ f32x4 mfma_bf16_16x16x16(bf16x4 a, bf16x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 
 //   v_mfma_f32_32x32x16_bf16 : A[i=l&31][k=8*(l>>5)+j]  B[k=8*(l>>5)+j][n=l&31]  (j<8)
@@ -107,8 +100,6 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint2 lo, uint2 hi) {
     return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 }
 
-__device__ __forceinline__ bf16x4 as_bf16x4(uint2 u) { return __builtin_bit_cast(bf16x4, u); }
-
 // c + a.lo*b.lo + a.hi*b.hi on packed bf16 pairs, fp32 accumulate (v_dot2c_f32_bf16)
 __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -143,15 +134,6 @@ __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_rea
 // Use it only where no wave touches the DMA destination before the next full __syncthreads().
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// One-way signalling between the waves of a workgroup through an LDS counter, without a barrier.  The LDS serves a wave's
-// operations in issue order, so an add placed after a wave's reads is applied after them; the waiting wave polls.
-__device__ __forceinline__ void lds_signal_add(int* p, int v) {
-    asm volatile("ds_add_u32 %0, %1" ::"v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void lds_wait_ge(const int* p, int target) {
-    while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(p)) < target) __builtin_amdgcn_s_sleep(1);
-}
-
 // value of lane (l - n) of the same 16-lane row, 0 for the first n lanes of a row (v_*_dpp row_shr:n, bound_ctrl): one VALU
 // modifier instead of a ds_bpermute -- the building block of a 16-wide scan
 template <int N>
@@ -175,17 +157,6 @@ __device__ __forceinline__ void row_scan4(float& a, float& b, float& c, float& d
     LINA_DPP_STEP4(2);
     LINA_DPP_STEP4(4);
     LINA_DPP_STEP4(8);
-}
-// after row_scan4 over a row that holds TWO independent 8-lane groups: lanes 8..15 of every row subtract the value of lane 7
-// (the first group's total), so that each half holds its own inclusive scan.  row_newbcast:7 = lane 7 of the row for every
-// lane; bank_mask 0xc = only banks 2,3 (lanes 8..15) are written.
-__device__ __forceinline__ void row_half_fix4(float& a, float& b, float& c, float& d) {
-    asm("s_nop 1\n\t"
-        "v_subrev_f32_dpp %0, %0, %0 row_newbcast:7 row_mask:0xf bank_mask:0xc\n\t"
-        "v_subrev_f32_dpp %1, %1, %1 row_newbcast:7 row_mask:0xf bank_mask:0xc\n\t"
-        "v_subrev_f32_dpp %2, %2, %2 row_newbcast:7 row_mask:0xf bank_mask:0xc\n\t"
-        "v_subrev_f32_dpp %3, %3, %3 row_newbcast:7 row_mask:0xf bank_mask:0xc"
-        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 #undef LINA_DPP_STEP4
 // max as ONE v_max_f32 (fmaxf first canonicalises an operand the compiler cannot prove quiet: two instructions)

@@ -52,8 +52,6 @@ void dma_flush_mine() {
 
 static void yield() { swapcontext(&cur->ctx, &sched_ctx); }
 
-void yield_fiber() { ++progress; yield(); }   // a polling lane: the scheduler pass counts as progress (the poll itself bounds nothing)
-
 void syncthreads() {
     const unsigned g = bar_gen;
     if (++bar_count == (int)fibers.size()) {

@@ -60,7 +60,6 @@ extern unsigned char* g_dyn_smem;
 const dim3& cur_tid();
 int cur_lane();
 void syncthreads();
-void yield_fiber();
 bool dma_late();
 void dma_defer(void* dst, const void* src);
 void dma_flush_mine();
@@ -95,11 +94,6 @@ struct f32x16 {
     float v[16];
     float& operator[](int i) { return v[i]; }
     const float& operator[](int i) const { return v[i]; }
-};
-struct bf16x4 {
-    short v[4];
-    short& operator[](int i) { return v[i]; }
-    const short& operator[](int i) const { return v[i]; }
 };
 struct bf16x8 {
     short v[8];
@@ -198,33 +192,6 @@ static inline f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
     return d;
 }
 
-// v_mfma_f32_16x16x16_bf16: lane l holds A[i=l&15][k=4*(l>>4)+j], B[k=4*(l>>4)+j][n=l&15], j<4.
-static inline f32x4 mfma_bf16_16x16x16(bf16x4 a, bf16x4 b, f32x4 c) {
-    uint32_t mine[4], tab[256];
-    for (int j = 0; j < 2; ++j) {
-        mine[j] = (uint32_t)(uint16_t)a[2 * j] | ((uint32_t)(uint16_t)a[2 * j + 1] << 16);
-        mine[2 + j] = (uint32_t)(uint16_t)b[2 * j] | ((uint32_t)(uint16_t)b[2 * j + 1] << 16);
-    }
-    lina_emu::wave_exchange(mine, 4, tab);
-    const int l = lina_emu::cur_lane(), col = l & 15;
-    auto A = [&](int i, int k) {
-        const uint32_t w = tab[(i + 16 * (k >> 2)) * 4 + ((k & 3) >> 1)];
-        return bf2f((unsigned short)((k & 1) ? (w >> 16) : (w & 0xffff)));
-    };
-    auto Bm = [&](int k, int n) {
-        const uint32_t w = tab[(n + 16 * (k >> 2)) * 4 + 2 + ((k & 3) >> 1)];
-        return bf2f((unsigned short)((k & 1) ? (w >> 16) : (w & 0xffff)));
-    };
-    f32x4 d;
-    for (int r = 0; r < 4; ++r) {
-        const int row = 4 * (l >> 4) + r;
-        float acc = c[r];
-        for (int k = 0; k < 16; ++k) acc = fmaf(A(row, k), Bm(k, col), acc);
-        d[r] = acc;
-    }
-    return d;
-}
-
 // v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8*(l>>5)+j], B[k=8*(l>>5)+j][n=l&31];
 // D: col=l&31, row=(reg&3)+8*(reg>>2)+4*(l>>5).
 static inline f32x16 mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -291,7 +258,6 @@ static inline uint2 lds_read_tr16_b64(const void* piece) {
     }
     return make_uint2((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16));
 }
-static inline bf16x4 as_bf16x4(uint2 u) { bf16x4 r; memcpy(&r, &u, 8); return r; }
 static inline bf16x8 as_bf16x8(uint4 u) { bf16x8 r; memcpy(&r, &u, 16); return r; }
 static inline bf16x8 as_bf16x8(uint2 lo, uint2 hi) { bf16x8 r; memcpy(&r.v[0], &lo, 8); memcpy(&r.v[4], &hi, 8); return r; }
 
@@ -305,11 +271,6 @@ static inline float2 ld_agent8(const float* p) { return make_float2(p[0], p[1]);
 static inline void drain_stores() {}
 static inline int ticket_agent(int* counter) { return (*counter)++; }
 
-// fibers are cooperative: the add is atomic; the waiting lanes hand the processor on until the counter is there
-static inline void lds_signal_add(int* p, int v) { *p += v; }
-static inline void lds_wait_ge(const int* p, int target) {
-    while (*reinterpret_cast<const volatile int*>(p) < target) lina_emu::yield_fiber();
-}
 static inline void lds_barrier() { lina_emu::syncthreads(); }
 static inline int lane_id() { return lina_emu::cur_lane(); }
 static inline int wave_uniform(int v) { return v; }
@@ -326,15 +287,6 @@ static inline void row_scan4(float& a, float& b, float& c, float& d) {
     a += dpp_row_shr<2>(a); b += dpp_row_shr<2>(b); c += dpp_row_shr<2>(c); d += dpp_row_shr<2>(d);
     a += dpp_row_shr<4>(a); b += dpp_row_shr<4>(b); c += dpp_row_shr<4>(c); d += dpp_row_shr<4>(d);
     a += dpp_row_shr<8>(a); b += dpp_row_shr<8>(b); c += dpp_row_shr<8>(c); d += dpp_row_shr<8>(d);
-}
-static inline void row_half_fix4(float& a, float& b, float& c, float& d) {
-    float* v[4] = {&a, &b, &c, &d};
-    for (int i = 0; i < 4; ++i) {
-        uint32_t mine = f2u(*v[i]), tab[64];
-        lina_emu::wave_exchange(&mine, 1, tab);
-        const int l = lina_emu::cur_lane();
-        if ((l & 15) >= 8) *v[i] -= u2f(tab[(l & ~15) + 7]);
-    }
 }
 static inline float vmax_raw(float a, float b) { return a > b ? a : b; }
 static inline unsigned byte_perm(unsigned hi, unsigned lo, unsigned sel) {
