@@ -9,11 +9,12 @@ from .blocks import TextEncoder
 from .lina_model import LinaModel
 
 
-def l169(heads: int = 4, expand_v: float = 1.0, txt_layers: int = 4) -> LinaModel:
+def l169(heads: int = 4, expand_v: float = 1.0, txt_layers: int = 4, n_layer: int = 6) -> LinaModel:
     """"169M d1024 x l12": d_model 1024, 6 encoder + 6 decoder GLA blocks + the pos_net GLA block of the
     blind cross-attention, key_dim = value_dim = 1024, H = 4 (Dk = Dv = 256), conv W = 4, codebook 4096 + 3
-    specials, 1 quantizer, text vocab 256, 4-layer text encoder  ->  166.7 M parameters."""
-    rnn = AttentiveGLA(d_model=1024, n_layer=6, heads=heads, blind=True, use_short_conv=True, expand_k=1.0,
+    specials, 1 quantizer, text vocab 256, 4-layer text encoder  ->  166.7 M parameters.  (``n_layer`` / ``txt_layers`` smaller:
+    a slice of the same width for tests.)"""
+    rnn = AttentiveGLA(d_model=1024, n_layer=n_layer, heads=heads, blind=True, use_short_conv=True, expand_k=1.0,
                        expand_v=expand_v, pos_type="convolutional")
     txt = TextEncoder(1024, 4, n_layers=txt_layers, dropout=0.0, rotary=False)
     return LinaModel(rnn, d_model=1024, n_quant=1, n_codebook=4096, n_special_token_in=3, n_special_token_out=3,

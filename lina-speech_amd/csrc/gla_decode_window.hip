@@ -42,7 +42,7 @@
 
 namespace lina {
 
-constexpr int kWinMax = 8;
+constexpr int kWinMax = 16;
 
 __device__ __forceinline__ float ld_hist(const float* p) {
 #if LINA_K1W_HIST_NT

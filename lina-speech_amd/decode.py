@@ -162,8 +162,16 @@ class _Part:
 class DecodeEngine:
     def __init__(self, model, x_enc: torch.Tensor, batch_size: int, state: Optional[Cache] = None,
                  use_graph: Optional[bool] = None, n_split: Optional[int] = None, fuse_norm: bool = True,
-                 window: Optional[int] = None):
-        """``window`` (1, 2, 4 or 8; default 8): the device-side decode loop keeps the recurrent state of every block
+                 window: Optional[int] = None, stream_weights=("in", "up"), cross: str = "spread",
+                 fused_pick: bool = True, packed: bool = True):
+        """Every variant of the step is a constructor argument (rounds 2-3 read ``LINA_DECODE_*`` environment switches here).
+        ``stream_weights``: which weight matrices of the device loop ("in", "o", "up", "down", "head") are loaded with the
+        non-temporal hint instead of competing for the 256 MB Infinity Cache (measured optimum: in + up).
+        ``cross``: first half of the cross-attention -- "spread" = scores on 256 workgroups + {softmax, att1 . pe} in one launch,
+        "fused" = the round-2 form {scores + softmax in one workgroup per row} + skinny GEMM.  ``fused_pick`` / ``packed``: the
+        one-launch sampled epilogue K6e / the fragment-major operand path of the device loop (False = the unfused forms, kept
+        for A/B measurements and as the parity reference of the fused ones).
+        ``window`` (1, 2, 4, 8 or 16; default 8): the device-side decode loop keeps the recurrent state of every block
         LAZILY WRITTEN -- read every token, rewritten every ``window``-th token (K1w, lina_gla_decode_window); the
         steps in between live in small history buffers.  ``engine.state`` / ``sync_state()`` materialise the exact
         state on demand.  1 = the immediate in-place update K1d on every token.
@@ -172,13 +180,13 @@ class DecodeEngine:
         chains in flight hide each other's launch/drain latency; rows never interact."""
         rnn = model.attentive_rnn
         self.model = model
-        self.fuse_norm = fuse_norm and os.environ.get("LINA_DECODE_FUSE_NORM", "1") != "0"
+        self.fuse_norm = fuse_norm
         self.B = batch_size
         self.dev = x_enc.device
         if window is None:
-            window = int(os.environ.get("LINA_DECODE_WINDOW", "8"))
-        if window not in (1, 2, 4, 8):
-            raise ValueError("window must be 1, 2, 4 or 8")
+            window = 8
+        if window not in (1, 2, 4, 8, 16):
+            raise ValueError("window must be 1, 2, 4, 8 or 16")
         self.window = window if self.fuse_norm else 1
         self._state = state if state is not None else rnn.init_state(batch_size=batch_size)
         self._t_idx = torch.zeros(1, dtype=torch.long, device=self.dev)      # device step counter of the greedy loop
@@ -188,11 +196,14 @@ class DecodeEngine:
         self._loop_packed = False
         # which weight matrices of the device loop are STREAMED (non-temporal loads) instead of competing for the 256 MB
         # Infinity Cache: per token the loop touches 0.87 GB of state (always streamed) + 0.26 GB of weights; streaming
-        # the largest matrices lets the others stay resident between two tokens.  LINA_DECODE_STREAM=in,up,...
-        self._stream = set(os.environ.get("LINA_DECODE_STREAM", "in,up").replace(" ", "").split(",")) - {""}
-        # first half of the cross-attention: scores on 256 workgroups + {softmax, att1 . pe} in one launch (default), or the
-        # round-2 form {scores + softmax in one workgroup per row} + skinny GEMM (LINA_DECODE_CROSS=fused; A/B: DESIGN 4.4)
-        self._cross_spread = os.environ.get("LINA_DECODE_CROSS", "spread") != "fused"
+        # the largest matrices lets the others stay resident between two tokens
+        self._stream = set(stream_weights)
+        if not self._stream <= {"in", "o", "up", "down", "head"}:
+            raise ValueError(f"stream_weights: unknown weight set(s) {sorted(self._stream - {'in', 'o', 'up', 'down', 'head'})}")
+        if cross not in ("spread", "fused"):
+            raise ValueError("cross must be 'spread' or 'fused'")
+        self._cross_spread = cross == "spread"
+        self._fused_pick, self._packed_ok = bool(fused_pick), bool(packed)
         blocks = list(rnn.encoder) + list(rnn.decoder) + [rnn.cross_att.pos_net]
         self.n_enc = len(rnn.encoder)
         ca = rnn.cross_att
@@ -217,7 +228,7 @@ class DecodeEngine:
         if n_split is None:
             # measured on MI355X (B=64): 1 range 1.035 ms/step, 2 ranges 1.013 ms, 4 ranges 1.64 ms -- the forked
             # branches of a hipGraph barely overlap, so one range stays the default
-            n_split = int(os.environ.get("LINA_DECODE_SPLIT", "0")) or 1
+            n_split = 1
         n_split = max(1, min(n_split, batch_size))
         from .shard import shard_rows
         self.parts = []
@@ -491,10 +502,10 @@ class DecodeEngine:
         self._lazy_live = lazy
         n_sampled_ = min(max(first_greedy_quant, 0), self.Q) if k > 1 else 0
         # fragment-major operands: the all-greedy device loop on one row range (the pick kernel K6d keeps x_p current)
-        # (K6d / K6e keep x_p current; the unfused sampled epilogue, LINA_DECODE_FUSED_PICK=0, has no packed output)
-        fused_pick = self.Q <= 16 and (n_sampled_ == 0 or os.environ.get("LINA_DECODE_FUSED_PICK", "1") != "0")
+        # (K6d / K6e keep x_p current; the unfused sampled epilogue, fused_pick=False, has no packed output)
+        fused_pick = self.Q <= 16 and (n_sampled_ == 0 or self._fused_pick)
         packed = (lazy and len(self.parts) == 1 and fused_pick
-                  and all(P.packed for P in self.packs) and os.environ.get("LINA_DECODE_PACKED", "1") != "0")
+                  and all(P.packed for P in self.packs) and self._packed_ok)
         self._loop_packed = packed
         n_sampled = min(max(first_greedy_quant, 0), self.Q) if k > 1 else 0
         is_sampled = (torch.arange(self.Q, device=self.dev) < n_sampled).unsqueeze(0)        # [1,Q]

@@ -1,0 +1,56 @@
+"""Launch POLICY of the operators -- the decisions that are not arithmetic: how many sequence segments the chunk kernels
+run concurrently, which backward implementation serves bf16, when a weight gradient is posed as a token-split batched GEMM,
+how the channel mixer is padded.  One object (``POLICY``) holds the switches a test or a tool may flip; nothing here reads the
+environment."""
+from __future__ import annotations
+
+import torch
+
+
+class Policy:
+    """``k2b_path``: "full" = K2b as three sweeps of the full-head kernel (bf16, Dk = Dv in {64,128,256}, falls back when the
+    layout is not eligible), "sweeps" = always the generic kernel (lina_gla_chunk_bwd)."""
+    k2b_path: str = "full"
+
+
+POLICY = Policy()
+
+
+def _value_blocks(q, v, gk) -> int:
+    """Dv = m * Dk with the L169 key width (``expand_v = 2``: 256 x 512 heads): the recurrence is independent per value
+    column, so the call runs as m calls of the full-head 256 x 256 kernel on column blocks of v / o / the states (same q, k,
+    g); the backward adds the blocks' dq, dk, dg.  Returns m (1 = no split)."""
+    Dk, Dv = q.shape[-1], v.shape[-1]
+    if q.dtype == torch.bfloat16 and gk.dtype == torch.bfloat16 and Dk == 256 and Dv > Dk and Dv % Dk == 0:
+        return Dv // Dk
+    return 1
+
+
+def chunk_segments(n_heads_total: int, T: int) -> int:
+    """Segments for the segment-parallel K2 (lina_gla_chunk_fwd_seg): enough to put ~256 workgroups on the chip
+    when B*H is small, at least 256 tokens per segment; 1 = the plain kernel."""
+    if n_heads_total >= 128 or T < 1024:
+        return 1
+    return max(1, min(256 // n_heads_total, T // 256, 16))
+
+
+# --------------------------------------------------------------------------- projections of the train path
+# The GEMMs stay on the vendor library (hipBLASLt through torch); what is ours is how the WEIGHT GRADIENT is posed to it.
+# dW = dY^T X reduces over all B T tokens (32768 on config 5) into a small [out, in] tile grid: posed as one GEMM the
+# library runs it at 300-580 TFLOP/s (1024x1024 / 1024x1365 / 2730x1024 outputs: 16-44 tiles for 256 CUs, profiles/
+# r03_dw_gemm.txt); split over the token axis into a batched GEMM with fp32 partial products + one small sum it runs at
+# 830-940 TFLOP/s, and dW comes out in fp32 (the master-weight dtype: no bf16 round trip, no cast kernel).
+_LINEAR_SPLIT_MAX_OUT = 3 * 1024 * 1024        # [out, in] up to this many elements: split (above: enough tiles already)
+_LINEAR_SPLIT_MIN_ROWS = 2048                  # tokens per split slice, at least
+
+
+def _linear_split(rows, n_out, n_in):
+    if n_out * n_in > _LINEAR_SPLIT_MAX_OUT:
+        return 1
+    for s in (8, 4, 2):
+        if rows % s == 0 and rows // s >= _LINEAR_SPLIT_MIN_ROWS:
+            return s
+    return 1
+
+
+_MLP_PAD = 128          # the hidden dimension of the channel mixer is padded to a multiple of this (+ the bias column)

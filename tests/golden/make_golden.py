@@ -167,6 +167,35 @@ def golden_lina():
     npz("lina_d64.npz", **out)
 
 
+def golden_config5_slice():
+    """BASELINE configs[4] at its named length: a slice of L169 (d=1024, H=4, n_layer=1 -> 3 GLA blocks, 1 text layer) through
+    the REFERENCE's modules (train() mode, default chunk mode, the CPU oracle behind fla.*), b=1, T=4096: loss + a digest of
+    every parameter gradient.  Weights: tests/model_cases.reseed_parameters (keyed by parameter name), not stored."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from model_cases import reseed_parameters, grad_digest
+    seed = 3
+    torch.manual_seed(0)
+    model = reseed_parameters(build_lina(d=1024, n_layer=1, heads=4, n_codebook=4096, txt_layers=1), seed=seed).train()
+    B, Ttxt, n = 1, 64, 4097
+    g = torch.Generator().manual_seed(17)
+    x = torch.randint(3, 256, (B, Ttxt), generator=g)
+    y = torch.randint(3, 4099, (B, n, 1), generator=g)
+    y[:, 0] = 1
+    em = torch.ones(B, Ttxt, Ttxt, dtype=torch.bool)
+    cm = torch.ones(B, n, Ttxt, dtype=torch.bool)
+    lm = torch.ones(B, n, dtype=torch.bool)
+    model.zero_grad()
+    _, loss, _, _, _ = model(x, y, em, cm, logits_mask=lm)
+    loss.backward()
+    out = dict(x=x, y=y, loss=loss.detach(), seed=torch.tensor(seed))
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        nrm, mx, sam = grad_digest(p.grad)
+        out["gnorm::" + name], out["gmax::" + name], out["gsam::" + name] = torch.tensor(nrm), torch.tensor(mx), sam
+    npz("l169_slice_T4096.npz", **out)
+
+
 def golden_tools():
     """Known answers of model/tools.py helpers."""
     torch.manual_seed(0)
@@ -247,7 +276,7 @@ if __name__ == "__main__":
     import argparse
     only = sys.argv[1:]
     todo = {"vocoder": golden_vocoder, "tools": golden_tools, "mixer": golden_mixer, "lina": golden_lina,
-            "simple_gla": golden_simple_gla}
+            "simple_gla": golden_simple_gla, "config5_slice": golden_config5_slice}
     for name, fn in todo.items():
         if not only or name in only:
             fn()

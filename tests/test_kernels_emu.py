@@ -181,7 +181,8 @@ def test_chunk_simple_gla(emu, Dk, Dv, T, dtype, h0):
 @pytest.mark.parametrize("Dk,Dv,dtype,window,n", [(64, 64, torch.float32, 8, 19), (128, 128, torch.bfloat16, 4, 9),
                                                   (64, 256, torch.float32, 2, 5), (64, 64, torch.float32, 1, 3),
                                                   (256, 256, torch.bfloat16, 8, 10), (256, 128, torch.float32, 8, 9),
-                                                  (64, 512, torch.float32, 4, 6), (128, 512, torch.bfloat16, 8, 9)])
+                                                  (64, 512, torch.float32, 4, 6), (128, 512, torch.bfloat16, 8, 9),
+                                                  (64, 64, torch.float32, 16, 35), (256, 256, torch.bfloat16, 16, 18)])
 def test_decode_window(emu, Dk, Dv, dtype, window, n):
     from kernel_cases import check_decode_window
     check_decode_window(DEV, B=2, H=2, Dk=Dk, Dv=Dv, dtype=dtype, window=window, n_steps=n)
@@ -287,7 +288,7 @@ def test_chunk_bwd_full_head_sweeps_head_groups(emu, D, H, T, nseg):
 
 
 def test_chunk_bwd_generic_kernel_still_reachable_for_bf16(emu, monkeypatch):
-    monkeypatch.setenv("LINA_K2B", "sweeps")
+    monkeypatch.setattr(ops.POLICY, "k2b_path", "sweeps")
     check_chunk_bwd(DEV, B=1, H=1, T=40, Dk=64, Dv=64, dtype=torch.bfloat16)
 
 

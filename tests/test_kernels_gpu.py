@@ -203,7 +203,7 @@ def test_chunk_bwd_segments_agree_with_the_single_pass(hip):
 
 
 def test_chunk_bwd_generic_kernel_for_bf16(hip, monkeypatch):
-    monkeypatch.setenv("LINA_K2B", "sweeps")
+    monkeypatch.setattr(ops.POLICY, "k2b_path", "sweeps")
     check_chunk_bwd(DEV, B=2, H=2, T=150, Dk=256, Dv=256, dtype=torch.bfloat16)
     check_chunk_bwd(DEV, B=2, H=2, T=70, Dk=64, Dv=64, dtype=torch.bfloat16, resets=True)
 
@@ -310,7 +310,8 @@ def test_chunk_segment_parallel_at_the_training_sequence_length(hip, nseg, reset
 # ----------------------------------------------------------------------------- K1w: windowed decode-step update
 @pytest.mark.parametrize("B,H,Dk,Dv,dtype,window,n", [(64, 4, 256, 256, torch.bfloat16, 8, 21), (3, 2, 256, 256, torch.float32, 8, 17),
                                                       (5, 8, 128, 128, torch.bfloat16, 4, 10), (2, 16, 64, 64, torch.float32, 8, 9),
-                                                      (64, 4, 256, 512, torch.bfloat16, 8, 18), (3, 2, 128, 512, torch.float32, 8, 9)])
+                                                      (64, 4, 256, 512, torch.bfloat16, 8, 18), (3, 2, 128, 512, torch.float32, 8, 9),
+                                                      (64, 4, 256, 256, torch.bfloat16, 16, 37), (3, 2, 64, 64, torch.float32, 16, 33)])
 def test_decode_window(hip, B, H, Dk, Dv, dtype, window, n):
     from kernel_cases import check_decode_window
     check_decode_window(DEV, B=B, H=H, Dk=Dk, Dv=Dv, dtype=dtype, window=window, n_steps=n)

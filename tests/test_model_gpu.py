@@ -218,20 +218,35 @@ def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
     assert torch.equal(toks[0][safe], ref_toks[0][safe]), "bf16 engine token != oracle arg-max at a clear margin"
 
 
+def test_config5_slice_at_sequence_length_4096_matches_reference_autograd(hip):
+    """BASELINE configs[4] at its named length, fp32: loss and EVERY parameter gradient of a b=1, T=4096 teacher-forced train
+    step on a one-layer slice of L169 (3 GLA blocks at d=1024, H=4 + text encoder + 4099-way head) against the golden made
+    from the REFERENCE's modules under torch autograd (tests/golden/make_golden.py config5_slice)."""
+    from model_cases import check_config5_slice_golden
+    check_config5_slice_golden("cuda", torch.float32)
+
+
+def test_config5_slice_at_sequence_length_4096_bf16_autocast_tracks_reference_autograd(hip):
+    """The same step the way training runs it (bf16 autocast: K2 / K2b full-head kernels, bf16 MFMA): within the bf16
+    budget of the fp32 reference gradients."""
+    from model_cases import check_config5_slice_golden
+    check_config5_slice_golden("cuda", torch.bfloat16, rel_loss=5e-3, rel_grad=6e-2)
+
+
 def test_config4_rows_sharded_equal_unsharded(hip):
     """BASELINE configs[3] (169M decode, B = 512 batch-sharded over 8 GPUs, no collective) on ONE GPU: the eight
     `shard_rows(512, r, 8)` engines, run one after another on cuda:0 exactly as rank r of the 8-GPU job would run them
     (its rows of the text batch, its own state), must produce the tokens of the same rows of a single B = 512 engine --
     rows never interact (reference model/modeling_lina.py:125,152-179: one state and one token stream per row).  bf16, the
-    headline dtype; peaked logits (model_cases.peak_logits) so that the comparison is not decided by near-ties; the B = 512
-    engine also puts config 4's row count through the HIP path (2048 K1w workgroups, 8 row tiles per projection)."""
+    headline dtype, plain random-init weights (every row decodes its own sequence): a row's arithmetic does not depend on which
+    other rows share its launch, so the tokens must be IDENTICAL, near-ties included.  The B = 512 engine also puts config 4's
+    row count through the HIP path (2048 K1w workgroups, 8 row tiles per projection)."""
     from lina_speech_amd.configs import l169
     from lina_speech_amd.decode import DecodeEngine
     from lina_speech_amd.shard import shard_rows
-    from model_cases import peak_logits
     torch.manual_seed(0)
     TOTAL, WORLD, n = 512, 8, 24
-    model = peak_logits(l169().eval()).to("cuda", torch.bfloat16)
+    model = l169().eval().to("cuda", torch.bfloat16)
     texts = torch.randint(3, 256, (TOTAL, 32), generator=torch.Generator().manual_seed(1234)).cuda()
     with torch.inference_mode():
         def decode(rows):
@@ -252,7 +267,7 @@ def test_config4_rows_sharded_equal_unsharded(hip):
     record_parity("config 4: tokens of 8 x 64-row shard engines vs the same rows of one B=512 engine (differences)", n_diff, 0,
                   rows=TOTAL, steps=n, distinct_tokens=int(full.unique().numel()))
     assert n_diff == 0, f"{n_diff} of {TOTAL * n} tokens differ between the sharded and the unsharded batch"
-    assert int(full.unique().numel()) > 100          # not a degenerate decode
+    assert int(full.unique().numel()) > 500          # not a degenerate decode: the rows decode different sequences
 
 
 def test_config3_decode_to_waveform_chain_vs_oracle(hip):

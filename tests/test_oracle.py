@@ -142,5 +142,6 @@ def test_peaked_logit_weights_give_clear_margins_on_the_oracle():
             assert int(toks.min()) >= 3                        # successors are code tokens, never specials
     finally:
         torch.set_num_threads(n_thr)
-    assert float(fr[True].min()) > 0.05, float(fr[True].min())
-    assert float((fr[False] < 0.016).float().mean()) > 0.05    # what the flat initialisation looks like
+    assert float(fr[True].median()) > 0.2, float(fr[True].median())
+    assert float((fr[True] < 0.016).float().mean()) <= 0.1
+    assert float(fr[False].median()) < 0.1                      # what the flat initialisation looks like

@@ -1,0 +1,20 @@
+#!/usr/bin/env python
+"""Print the headline figures of a bench.py JSON line (one per line, for a session log)."""
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+g = lambda *ks: (lambda v: v)(__import__("functools").reduce(lambda a, k: a.get(k, {}) if isinstance(a, dict) else {}, ks, d))
+print(f"decode: {d['value']:.0f} tok/s  {d['ms_per_step']:.4f} ms/step  step_roofline {g('step_roofline','frac'):.3f}  K1w frac {g('roofline','frac'):.3f} ({g('roofline','us_per_launch'):.2f} us)")
+for k in ("chunk_kernel", "chunk_kernel_h8", "chunk_kernel_h16", "chunk_kernel_dv512", "chunk_kernel_b8", "chunk_bwd_kernel", "chunk_bwd_kernel_b64"):
+    if k in d:
+        print(f"{k}: {d[k]['ms']:.4f} ms  frac {d[k]['frac']:.3f}")
+if "b512_one_gpu" in d:
+    b = d["b512_one_gpu"]
+    print(f"b512_one_gpu: {b['tokens_per_s']:.0f} tok/s  {b['ms_per_step']:.4f} ms/step  step_roofline {b['step_roofline']['frac']:.3f}")
+for k in ("sampled_decode", "train_step", "decode_f32"):
+    if k in d:
+        print(f"{k}: {d[k].get('ms_per_step'):.4f} ms/step  {d[k].get('tokens_per_s'):.0f} tok/s")
+if "other_head_shapes" in d:
+    for k, v in d["other_head_shapes"].items():
+        print(f"{k}: {v['ms_per_step']:.4f} ms/step {v['tokens_per_s']:.0f} tok/s")
+if "cpu_baseline" in d:
+    print(f"cpu_baseline: {d['cpu_baseline']['value']:.1f} tok/s on {d['cpu_baseline']['cores']} threads")

@@ -73,10 +73,10 @@ if MODE == "sampled":                           # the reference's default genera
             return (time.perf_counter() - t0) / n * 1e3
     res["sampled_fused_K6e"] = timed_s(eng, k=100, temp=1.0, seed=1, first_greedy_quant=1)
     toks_f = eng.greedy_tokens().clone()
-    os.environ["LINA_DECODE_FUSED_PICK"] = "0"
+    eng._fused_pick = False                       # (DecodeEngine(fused_pick=False): the unfused sampled epilogue)
     res["sampled_unfused"] = timed_s(eng, k=100, temp=1.0, seed=1, first_greedy_quant=1)
     toks_u = eng.greedy_tokens().clone()
-    os.environ["LINA_DECODE_FUSED_PICK"] = "1"
+    eng._fused_pick = True
     res["greedy_again"] = timed(eng)
     print(" ".join(f"{k_}={v_:.4f}" for k_, v_ in res.items()), "ms/step; fused vs unfused tokens equal:",
           bool(torch.equal(toks_f, toks_u)), " first divergence step:",
