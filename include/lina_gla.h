@@ -472,6 +472,15 @@ int lina_cross_scores_softmax(const void* q_lin, const void* ln_w, const void* l
 int lina_softmax_weighted_rows_add(const void* scores, int64_t scores_sb, float scale, void* att, int64_t att_sb,
                                    const void* vv, void* x, void* x_packed, int B, int T_txt, int d, int dtype,
                                    lina_stream_t stream);
+/* Round 4: the LAST TWO launches of the cross-attention step as one -- the raw scores of the second attention,
+ *     sc[b, t] = < xp[b, :], pe[t, :] >      (reference model/crossatt.py:125-127: q = x_pos, k = the positional table;
+ *                                             fp32 accumulate, rounded to `dtype` as the projection GEMM stored them),
+ * computed by every workgroup for its own row (T_txt x d multiply-adds), then exactly lina_softmax_weighted_rows_add.
+ * xp: [B, d] row-major, or (xp_packed != 0) the fragment-major layout of lina_linear_skinny_ex; pe: [>= T_txt, d] row-major;
+ * d % 256 == 0. */
+int lina_pe_softmax_weighted_rows_add(const void* xp, int xp_packed, const void* pe, float scale, void* att, int64_t att_sb,
+                                      const void* vv, void* x, void* x_packed, int B, int T_txt, int d, int dtype,
+                                      lina_stream_t stream);
 int lina_cross_scores(const void* q_lin, const void* ln_w, const void* ln_b, float ln_eps, const void* kk,
                       float* scores, int B, int T_txt, int d, float scale, int dtype, lina_stream_t stream);
 int lina_softmax_rows(const void* x, int64_t x_sb, int x_dtype, float scale, void* att, int64_t att_sb,

@@ -416,6 +416,101 @@ __global__ __launch_bounds__(256) void softmax_weighted_rows_kernel(const T* __r
     st4(xa, make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w));
 }
 
+// x_pos . pe^T + softmax + weighted row sum + residual in ONE launch (round 4: the last two launches of the cross-attention
+// step as one): as softmax_weighted_rows_kernel, but every workgroup first computes the row's T_txt raw scores
+//   sc[t] = < xp[b, :], pe[t, :] >          (reference model/crossatt.py:125-127: the second sdpa's q . k^T with q = x_pos,
+//                                            k = the positional table; fp32 accumulate, ROUNDED to the model dtype as the
+//                                            projection GEMM this replaces stored them)
+// itself -- T_txt x d multiply-adds per workgroup (65 k at L169: nothing), pe's T_txt rows come from L2 (shared by every
+// workgroup) -- instead of a launch of its own that 256 CUs wait for.  xp is read row-major or fragment-major (xp_packed).
+template <typename T>
+__global__ __launch_bounds__(256) void pe_softmax_weighted_rows_kernel(const T* __restrict__ xp, int xp_packed,
+                                                                       const T* __restrict__ pe, float scale,
+                                                                       T* __restrict__ att, int64_t att_sb,
+                                                                       const T* __restrict__ vv, T* x, int Tn, int d, T* xpk) {
+    LINA_DYN_SMEM(smem);
+    float* s_x = reinterpret_cast<float*>(smem);              // [d]: the row of x_pos in fp32
+    __shared__ float s_a[kCaMaxT];
+    __shared__ float s_red[4];
+    __shared__ __attribute__((aligned(16))) float s_p[3][64][4];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int e = 4 * tid; e < d; e += 1024) {
+        const float4 v4 = ld4(xp_packed ? xp + packed_off<T>(b, e, d) : xp + (int64_t)b * d + e);
+        *reinterpret_cast<float4*>(&s_x[e]) = v4;
+    }
+    __syncthreads();
+    // wave w takes the text positions w, w+4, ...: a lane covers the columns 4 lane + 256 c; four positions in flight
+    const int nc = d / 256;                                   // (launcher: d % 256 == 0)
+    for (int t0 = w; t0 < Tn; t0 += 16) {
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = min(t0 + 4 * u, Tn - 1);
+            const T* row = pe + (int64_t)t * d + 4 * lane;
+            for (int c = 0; c < nc; ++c) {
+                const float4 pv = ld4(row + 256 * c);
+                const float4 xv = *reinterpret_cast<const float4*>(&s_x[4 * lane + 256 * c]);
+                part[u] = fmaf(pv.x, xv.x, part[u]); part[u] = fmaf(pv.y, xv.y, part[u]);
+                part[u] = fmaf(pv.z, xv.z, part[u]); part[u] = fmaf(pv.w, xv.w, part[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float a = part[u];
+            a += shfl_xor(a, 1); a += shfl_xor(a, 2); a += shfl_xor(a, 4);
+            a += shfl_xor(a, 8); a += shfl_xor(a, 16); a += shfl_xor(a, 32);
+            if (lane == 0 && t0 + 4 * u < Tn) {
+                T tmp;                                        // the projection's output dtype
+                st(&tmp, a);
+                s_a[t0 + 4 * u] = ld(&tmp) * scale;
+            }
+        }
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = tid; t < Tn; t += 256) mx = fmaxf(mx, s_a[t]);
+    mx = block_max(mx, s_red);
+    float sum = 0.0f;
+    for (int t = tid; t < Tn; t += 256) sum += expf(s_a[t] - mx);
+    sum = block_sum(sum, s_red);
+    const float inv = 1.0f / sum;
+    for (int t = tid; t < Tn; t += 256) {
+        T tmp;                                               // the weights in the model dtype, as softmax_rows stores them
+        st(&tmp, expf(s_a[t] - mx) * inv);
+        s_a[t] = ld(&tmp);
+        if (blockIdx.x == 0) att[b * att_sb + t] = tmp;
+    }
+    __syncthreads();
+    const int e = blockIdx.x * 256 + lane * 4;
+    const bool live = e < d;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const T* base = vv + (int64_t)b * Tn * d + (live ? e : 0);
+    for (int t0 = w; t0 < Tn; t0 += 32) {
+        float4 p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = ld4(base + (int64_t)min(t0 + 4 * u, Tn - 1) * d);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float a = (t0 + 4 * u < Tn) ? s_a[min(t0 + 4 * u, Tn - 1)] : 0.0f;
+            acc.x = fmaf(a, p[u].x, acc.x); acc.y = fmaf(a, p[u].y, acc.y);
+            acc.z = fmaf(a, p[u].z, acc.z); acc.w = fmaf(a, p[u].w, acc.w);
+        }
+    }
+    if (w > 0) *reinterpret_cast<float4*>(&s_p[w - 1][lane][0]) = acc;
+    __syncthreads();
+    if (w > 0 || !live) return;
+#pragma unroll
+    for (int ww = 0; ww < 3; ++ww) {
+        const float4 o = *reinterpret_cast<const float4*>(&s_p[ww][lane][0]);
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    T tmp4[4];
+    st4(tmp4, acc);
+    T* const xa = xpk ? xpk + packed_off<T>(b, e, d) : x + (int64_t)b * d + e;
+    const float4 o = ld4(tmp4), r = ld4(xa);
+    st4(xa, make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w));
+}
+
 // softmax + att . pe in ONE launch (the first half of the blind cross-attention, reference model/crossatt.py:117-127):
 //   att[b, :Tn] = softmax(scores[b, :Tn])  (scores: fp32, already scaled -- lina_cross_scores' output);
 //   xp[b, :]    = att[b, :] . pe[:Tn, :]    (pe shared by all rows; att rounded to the model dtype first, as the reference's
@@ -717,6 +812,26 @@ extern "C" int lina_softmax_weighted_rows_add(const void* scores, int64_t scores
         LINA_LAUNCH((softmax_weighted_rows_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)scores, scores_sb,
                     scale, (bf16_t*)att, att_sb, (const bf16_t*)vv, (bf16_t*)x, Tn, d, (bf16_t*)x_packed);
     return check_launch("lina_softmax_weighted_rows_add");
+}
+
+extern "C" int lina_pe_softmax_weighted_rows_add(const void* xp, int xp_packed, const void* pe, float scale, void* att,
+                                                 int64_t att_sb, const void* vv, void* x, void* x_packed, int B, int Tn, int d,
+                                                 int dtype, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(xp && pe && att && vv && (x || x_packed), "lina_pe_softmax_weighted_rows_add: null pointer");
+    LINA_REQUIRE(B > 0 && Tn > 0 && Tn <= kCaMaxT, "lina_pe_softmax_weighted_rows_add: 0 < T_txt <= %d", kCaMaxT);
+    LINA_REQUIRE(d > 0 && d % 256 == 0 && d <= 8192, "lina_pe_softmax_weighted_rows_add: d must be a multiple of 256 (<= 8192)");
+    LINA_REQUIRE(valid_dtype(dtype), "lina_pe_softmax_weighted_rows_add: bad dtype %d", dtype);
+    dim3 grid((unsigned)((d + 255) / 256), (unsigned)B);
+    const size_t smem = sizeof(float) * (size_t)d;
+    if (dtype == LINA_F32)
+        LINA_LAUNCH((pe_softmax_weighted_rows_kernel<float>), grid, dim3(256), smem, stream, (const float*)xp, xp_packed,
+                    (const float*)pe, scale, (float*)att, att_sb, (const float*)vv, (float*)x, Tn, d, (float*)x_packed);
+    else
+        LINA_LAUNCH((pe_softmax_weighted_rows_kernel<bf16_t>), grid, dim3(256), smem, stream, (const bf16_t*)xp, xp_packed,
+                    (const bf16_t*)pe, scale, (bf16_t*)att, att_sb, (const bf16_t*)vv, (bf16_t*)x, Tn, d,
+                    (bf16_t*)x_packed);
+    return check_launch("lina_pe_softmax_weighted_rows_add");
 }
 
 #ifdef LINA_SKINNY_PROF

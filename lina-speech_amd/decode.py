@@ -163,14 +163,15 @@ class DecodeEngine:
     def __init__(self, model, x_enc: torch.Tensor, batch_size: int, state: Optional[Cache] = None,
                  use_graph: Optional[bool] = None, n_split: Optional[int] = None, fuse_norm: bool = True,
                  window: Optional[int] = None, stream_weights=("in", "up"), cross: str = "spread",
-                 fused_pick: bool = True, packed: bool = True):
+                 fused_pick: bool = True, packed: bool = True, cross_tail_fused: bool = True):
         """Every variant of the step is a constructor argument (rounds 2-3 read ``LINA_DECODE_*`` environment switches here).
         ``stream_weights``: which weight matrices of the device loop ("in", "o", "up", "down", "head") are loaded with the
         non-temporal hint instead of competing for the 256 MB Infinity Cache (measured optimum: in + up).
         ``cross``: first half of the cross-attention -- "spread" = scores on 256 workgroups + {softmax, att1 . pe} in one launch,
         "fused" = the round-2 form {scores + softmax in one workgroup per row} + skinny GEMM.  ``fused_pick`` / ``packed``: the
         one-launch sampled epilogue K6e / the fragment-major operand path of the device loop (False = the unfused forms, kept
-        for A/B measurements and as the parity reference of the fused ones).
+        for A/B measurements and as the parity reference of the fused ones).  ``cross_tail_fused``: the second attention's
+        scores x_pos . pe^T computed inside the softmax + att2 . V + residual launch (one launch less per token).
         ``window`` (1, 2, 4, 8 or 16; default 8): the device-side decode loop keeps the recurrent state of every block
         LAZILY WRITTEN -- read every token, rewritten every ``window``-th token (K1w, lina_gla_decode_window); the
         steps in between live in small history buffers.  ``engine.state`` / ``sync_state()`` materialise the exact
@@ -204,6 +205,7 @@ class DecodeEngine:
             raise ValueError("cross must be 'spread' or 'fused'")
         self._cross_spread = cross == "spread"
         self._fused_pick, self._packed_ok = bool(fused_pick), bool(packed)
+        self._cross_tail_fused = bool(cross_tail_fused)   # x_pos . pe^T folded into the softmax + att2 . V launch (d % 256 == 0)
         blocks = list(rnn.encoder) + list(rnn.decoder) + [rnn.cross_att.pos_net]
         self.n_enc = len(rnn.encoder)
         ca = rnn.cross_att
@@ -320,18 +322,26 @@ class DecodeEngine:
         else:
             ops.cross_scores_softmax(q_lin, ca.ln_q.weight, ca.ln_q.bias, ca.ln_q.eps, part.kk, att[:, 0, 0], part.attc,
                                      self.att_scale)
+        fuse2 = self._cross_tail_fused and self.d % 256 == 0
         if packed:
             if not self._cross_spread:
                 ops.linear_skinny(part.attc, self.peT, out=part.xp, out_packed=part.xp_p, out_packed_width=self.d)  # xp = att1 . pe
             self._block(part.xp, part.packs[-1], lazy, part.xp_p)
-            ops.linear_skinny_packed(part.xp_p, self.pe_pad_p, B, self.pe_pad.shape[0], self.d, out=part.sc2)
+            if not fuse2:
+                ops.linear_skinny_packed(part.xp_p, self.pe_pad_p, B, self.pe_pad.shape[0], self.d, out=part.sc2)
         else:
             if not self._cross_spread:
                 ops.linear_skinny(part.attc, self.peT, out=part.xp)               # xp = att1 . pe
             self._block(part.xp, part.packs[-1], lazy)
-            ops.linear_skinny(part.xp, self.pe_pad, out=part.sc2)                 # scores2 = xp . pe^T
-        ops.softmax_weighted_rows_add(part.sc2, self.att_scale, att[:, 1, 0], part.vv, x,
-                                      x_packed=part.x_p if packed else None)
+            if not fuse2:
+                ops.linear_skinny(part.xp, self.pe_pad, out=part.sc2)             # scores2 = xp . pe^T
+        if fuse2:
+            # scores2 = xp . pe^T, softmax, att2 . V and the residual add in ONE launch (round 4; was a projection launch + this)
+            ops.pe_softmax_weighted_rows_add(part.xp_p if packed else part.xp, self.pe_pad, self.att_scale, att[:, 1, 0],
+                                             part.vv, x, x_packed=part.x_p if packed else None, xp_is_packed=packed)
+        else:
+            ops.softmax_weighted_rows_add(part.sc2, self.att_scale, att[:, 1, 0], part.vv, x,
+                                          x_packed=part.x_p if packed else None)
 
     def _core_part(self, part, y, lazy=False, packed=False):
         x = part.x

@@ -650,6 +650,22 @@ def softmax_weighted_rows_add(scores, scale, att, vv, x, x_packed=None):
                                                  _ptr(vv), _ptr(x), _ptr(x_packed), B, Tn, d, _dt(vv), be.stream(vv)))
 
 
+def pe_softmax_weighted_rows_add(xp, pe, scale, att, vv, x, x_packed=None, xp_is_packed: bool = False):
+    """The last two launches of the cross-attention step as one (round 4):  sc[b,t] = <xp[b,:], pe[t,:]> rounded to the model
+    dtype, att[b,:Tn] = softmax(sc[b,:Tn] * scale), x[b,:] += att[b,:] . vv[b].  ``xp``: [B,d] row-major, or the
+    fragment-major buffer when ``xp_is_packed``; ``x_packed``: the residual stream in fragment-major form."""
+    be = _backend._BACKEND
+    be.require(xp, pe, att, vv, x, x_packed)
+    B, Tn, d = vv.shape
+    if pe.dtype != vv.dtype or att.dtype != vv.dtype or xp.dtype != vv.dtype:
+        raise TypeError("xp / pe / att / vv must share the model dtype")
+    if pe.shape[0] < Tn or pe.shape[1] != d or pe.stride(1) != 1 or pe.stride(0) != d:
+        raise ValueError("pe must be a contiguous [>= T_txt, d] table")
+    _check(be.lib.lina_pe_softmax_weighted_rows_add(_ptr(xp), 1 if xp_is_packed else 0, _ptr(pe), float(scale), _ptr(att),
+                                                    att.stride(0), _ptr(vv), _ptr(x), _ptr(x_packed), B, Tn, d, _dt(vv),
+                                                    be.stream(vv)))
+
+
 def softmax_pe_rows(scores, att, pe, xp, xp_packed=None):
     """att[b,:Tn] = softmax(scores[b,:Tn]) (fp32 scores, already scaled);  xp[b,:] = att[b,:] . pe[:Tn,:] -- one launch;
     ``xp_packed``: also the fragment-major copy of xp (the A operand of the next projection)."""

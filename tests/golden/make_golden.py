@@ -193,6 +193,24 @@ def golden_config5_slice():
             continue
         nrm, mx, sam = grad_digest(p.grad)
         out["gnorm::" + name], out["gmax::" + name], out["gsam::" + name] = torch.tensor(nrm), torch.tensor(mx), sam
+    # the yardstick of the bf16 test: how far the REFERENCE's own bf16-autocast gradients are from its fp32 gradients
+    from model_cases import grad_errors_by_group
+
+    class _G(dict):
+        files = property(lambda self: list(self.keys()))
+    gg = _G({k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in out.items()})
+    model.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, loss16, _, _, _ = model(x, y, em, cm, logits_mask=lm)
+    loss16.backward()
+    worst, _ = grad_errors_by_group({n_: p.grad for n_, p in model.named_parameters()}, gg, 1e-3)
+    groups = sorted(worst)
+    out["bf16ref_groups"] = np.array(groups)
+    out["bf16ref_max"] = np.array([worst[k]["max"] for k in groups], dtype=np.float32)
+    out["bf16ref_l2"] = np.array([worst[k]["l2"] for k in groups], dtype=np.float32)
+    out["bf16ref_norm"] = np.array([worst[k]["norm"] for k in groups], dtype=np.float32)
+    out["bf16ref_loss"] = loss16.detach().float()
+    print({k: (round(worst[k]["max"], 3), round(worst[k]["norm"], 3)) for k in groups})
     npz("l169_slice_T4096.npz", **out)
 
 

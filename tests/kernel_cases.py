@@ -1234,6 +1234,24 @@ def check_cross_fused(dev, B, Tn, d, dtype):
         x_p = ops.pack_rows(x0)
         ops.softmax_weighted_rows_add(sc2, scale, att_b[:, 1, 0], vv, x0.clone(), x_packed=x_p)
         assert torch.equal(ops.unpack_rows(x_p, B, d), x_b), "packed residual form differs from the row-major one"
+    if d % 256 == 0:
+        # round 4: x_pos . pe^T folded into the same launch == the projection (model-dtype scores) + the launch above
+        pe = mk(Tp, d)
+        xp = mk(B, d)
+        sc3 = (xp.float() @ pe.float().t()).to(dtype) if dev == "cpu" else ops.linear_skinny(xp, pe, out=torch.empty(B, Tp, dtype=dtype, device=dev))
+        x_c, x_d = x0.clone(), x0.clone()
+        att_c, att_d = torch.zeros_like(att_a), torch.zeros_like(att_a)
+        ops.softmax_weighted_rows_add(sc3, scale, att_c[:, 1, 0], vv, x_c)
+        ops.pe_softmax_weighted_rows_add(xp, pe, scale, att_d[:, 1, 0], vv, x_d)
+        # (the scores are rounded to the model dtype on both sides; their fp32 sums are accumulated in different orders)
+        assert_close(att_d[:, 1, 0], att_c[:, 1, 0], tol if dtype == torch.float32 else 3e-2, "pe-scores fused: softmax weights")
+        assert_close(x_d, x_c, tol if dtype == torch.float32 else 3e-2, "pe-scores fused: residual stream")
+        ref_sc = (xp.cpu().to(F64) @ pe.cpu().to(F64).t())[:, :Tn]
+        ref_att = torch.softmax(ref_sc.to(dtype).to(F64) * scale, -1)
+        assert_close(att_d[:, 1, 0], ref_att, 2e-2 if dtype == torch.bfloat16 else 1e-4, "pe-scores fused: weights vs fp64")
+        xp_p, x_p = ops.pack_rows(xp), ops.pack_rows(x0)
+        ops.pe_softmax_weighted_rows_add(xp_p, pe, scale, att_d[:, 1, 0], vv, x0.clone(), x_packed=x_p, xp_is_packed=True)
+        assert torch.equal(ops.unpack_rows(x_p, B, d), x_d), "packed form of the pe-scores fusion differs from the row-major one"
 
 
 def check_softmax_pe_rows(dev, B, Tn, d, dtype):

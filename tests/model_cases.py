@@ -338,6 +338,47 @@ def reseed_parameters(model, seed: int = 0):
     return model
 
 
+def grad_group(name: str) -> str:
+    """Parameter groups of the config-5 slice check, by what differentiates them."""
+    if name.startswith("txt_encoder") or (".cross_att." in name and ".pos_net." not in name):
+        return "softmax attention side (text encoder, cross-attention q/k/v + norms: torch SDPA)"
+    if ".tmix." in name:
+        return "GLA mixers (K2/K2b, K3/K3b, K5/K5b, gate)"
+    if ".cmix." in name:
+        return "channel mixers (K11)"
+    if "embed" in name or "logits_head" in name:
+        return "embeddings + head (K14)"
+    return "block norms (K10)"
+
+
+def grad_errors_by_group(named_grads, g, zero_tol):
+    """Worst per-group errors of gradients against the golden digests ``g``: {group: {max, l2, norm, tensor, n}}, and the number
+    of analytically-zero tensors (golden max < 1e-5 of the largest: both sides must be noise, ``zero_tol`` x largest)."""
+    names = [k[6:] for k in g.files if k.startswith("gsam::")]
+    largest = max(float(g["gmax::" + n]) for n in names)
+    worst, n_zero = {}, 0
+    for name in names:
+        grad = named_grads[name]
+        assert grad is not None, f"no gradient for {name}"
+        nrm, mx, sam = grad_digest(grad)
+        ref_sam, ref_mx, ref_nrm = torch.from_numpy(g["gsam::" + name]), float(g["gmax::" + name]), float(g["gnorm::" + name])
+        if ref_mx < 1e-5 * largest:
+            # analytically zero (e.g. the bias of the keys' LayerNorm: a shift of every key moves all scores of a row
+            # alike and the softmax does not see it): the golden holds rounding noise -- ours must be noise too
+            assert mx < zero_tol * largest, (name, mx, largest)
+            n_zero += 1
+            continue
+        es = float((sam - ref_sam).abs().max()) / ref_mx
+        el = float((sam - ref_sam).norm() / ref_sam.norm())
+        en = abs(nrm - ref_nrm) / ref_nrm
+        w = worst.setdefault(grad_group(name), {"max": 0.0, "l2": 0.0, "norm": 0.0, "tensor": None, "n": 0})
+        w["n"] += 1
+        if es > w["max"]:
+            w["max"], w["tensor"] = es, name
+        w["l2"], w["norm"] = max(w["l2"], el), max(w["norm"], en)
+    return worst, n_zero
+
+
 def grad_digest(t, n: int = 256):
     """What a golden keeps of one gradient tensor: its L2 norm, its max |.| and ``n`` entries at a fixed stride."""
     f = t.detach().float().flatten().cpu()
@@ -350,7 +391,13 @@ def check_config5_slice_golden(dev, dtype=torch.float32, rel_loss=2e-4, rel_grad
     1 + 1 GLA blocks + the pos_net block, one text-encoder layer, 4099-way head), b = 1, T = 4096: teacher-forced forward in
     train() mode, CE loss, backward.  The golden (tests/golden/l169_slice_T4096.npz, made by make_golden.py from the reference's
     model/*.py with the CPU oracle behind the fla names) holds the loss and a digest (norm, max, 256 strided entries) of EVERY
-    parameter gradient; weights come from reseed_parameters on both sides."""
+    parameter gradient in fp32; weights come from reseed_parameters on both sides.  Per tensor: max |sampled - golden| /
+    max|golden|, relative L2 error of the samples, relative norm error; worst case per parameter group (recorded).
+    fp32: every group within ``rel_grad``.
+    bf16 autocast: on this random-init model with random targets the gradients are sums of 4096 cancelling terms, and the
+    REFERENCE's own modules under ``torch.autocast(bfloat16)`` deviate from their fp32 gradients by 19-35 % of max|gradient| on
+    single entries (11 % on norms) -- the golden holds those figures per group (``bf16ref::*``): ours must be as close to the fp32
+    reference as the reference's bf16 run is (x 1.6 + 0.02: two independent draws of the same rounding noise)."""
     from lina_speech_amd.configs import l169
     g = load_golden("l169_slice_T4096.npz")
     torch.manual_seed(0)
@@ -367,29 +414,26 @@ def check_config5_slice_golden(dev, dtype=torch.float32, rel_loss=2e-4, rel_grad
             _, loss, _, _, _ = model(x, y, em, cm, logits_mask=lm)
     loss.backward()
     from kernel_cases import record_parity
+    tag = f"config-5 slice T=4096 ({str(dtype)[6:]})"
     ref_loss = float(g["loss"])
-    e = abs(float(loss) - ref_loss) / abs(ref_loss)
-    record_parity(f"config-5 slice T=4096 ({str(dtype)[6:]}): loss vs reference autograd", e, rel_loss)
+    e = abs(float(loss.detach()) - ref_loss) / abs(ref_loss)
+    record_parity(f"{tag}: loss vs reference autograd", e, rel_loss)
     assert e <= rel_loss, (float(loss), ref_loss)
-    names = [k[6:] for k in g.files if k.startswith("gsam::")]
-    assert len(names) > 40
-    worst, worst_name, worst_norm = 0.0, None, 0.0
-    params = dict(model.named_parameters())
-    for name in names:
-        p = params[name]
-        assert p.grad is not None, f"no gradient for {name}"
-        nrm, mx, sam = grad_digest(p.grad)
-        ref_sam, ref_mx, ref_nrm = torch.from_numpy(g["gsam::" + name]), float(g["gmax::" + name]), float(g["gnorm::" + name])
-        if ref_mx < 1e-12:
-            assert mx < 1e-7, name
-            continue
-        es = float((sam - ref_sam).abs().max()) / ref_mx
-        en = abs(nrm - ref_nrm) / ref_nrm
-        if es > worst:
-            worst, worst_name = es, name
-        worst_norm = max(worst_norm, en)
-    record_parity(f"config-5 slice T=4096 ({str(dtype)[6:]}): worst sampled parameter-gradient error / max|golden gradient| "
-                  f"over {len(names)} tensors", worst, rel_grad, tensor=worst_name)
-    record_parity(f"config-5 slice T=4096 ({str(dtype)[6:]}): worst gradient-norm error over {len(names)} tensors", worst_norm, rel_grad)
-    assert worst <= rel_grad, (worst, worst_name)
-    assert worst_norm <= rel_grad, worst_norm
+    worst, n_zero = grad_errors_by_group({n_: p.grad for n_, p in model.named_parameters()}, g,
+                                         1e-5 if dtype == torch.float32 else 1e-3)
+    assert sum(w["n"] for w in worst.values()) > 40
+    groups = [str(s_) for s_ in g["bf16ref_groups"]]
+    bad = []
+    for grp, w in worst.items():
+        if dtype == torch.float32:
+            tol_max = tol_norm = rel_grad
+        else:
+            i = groups.index(grp)
+            # (single entries: the group's own figure; norms: the largest group figure -- a norm error is one draw per tensor)
+            tol_max, tol_norm = 1.6 * float(g["bf16ref_max"][i]) + 0.02, 1.6 * float(g["bf16ref_norm"].max()) + 0.02
+        record_parity(f"{tag}: {grp}: worst |sampled gradient - golden| / max|golden| over {w['n']} tensors", w["max"], tol_max,
+                      tensor=w["tensor"], worst_relative_l2=w["l2"], worst_norm_error=w["norm"], norm_tolerance=tol_norm)
+        if w["max"] > tol_max or w["norm"] > tol_norm:
+            bad.append((grp, w, tol_max, tol_norm))
+    record_parity(f"{tag}: analytically zero gradient tensors (noise on both sides)", n_zero, None)
+    assert not bad, bad

@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""HBM traffic of one kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs, tests/gpu_evidence.sh),
+corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM) prescribes for gfx950: FETCH_SIZE tallies the 128-byte requests of a
+16-B/lane streaming read at 64 B -> doubled; WRITE_SIZE as reported.  Writes a JSON summary.
+
+    python tools/pmc_traffic.py k1w <fetch_dir> <write_dir> out.json
+    python tools/pmc_traffic.py k2  <fetch_dir> <write_dir> out.json <heads> [kernel_stats.csv]
+"""
+import csv, glob, json, sys
+
+which, fdir, wdir, out = sys.argv[1:5]
+pat = {"k1w": "gla_decode_window_kernel", "k2": "gla_chunk_bf16_h256"}[which]
+res = {}
+for c, d in (("FETCH_SIZE", fdir), ("WRITE_SIZE", wdir)):
+    f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)
+    rows = [r for r in csv.DictReader(open(f[0])) if pat in r.get("Kernel_Name", "") and r.get("Counter_Name") == c]
+    v = sorted(float(r["Counter_Value"]) for r in rows)
+    res[c] = {"dispatches": len(v), "mean_KiB": sum(v) / len(v), "min_KiB": v[0], "max_KiB": v[-1], "median_KiB": v[len(v) // 2]}
+rd, wr = 2 * res["FETCH_SIZE"]["mean_KiB"] * 1024, res["WRITE_SIZE"]["mean_KiB"] * 1024
+o = {"counters": res,
+     "correction": "gfx950 FETCH_SIZE counts the 128-B requests of a 16-B/lane streaming read at 64 B: doubled "
+                   "(MI355X_MICROARCH.md, HBM); WRITE_SIZE taken as is; one counter per rocprofv3 pass, --kernel-trace only",
+     "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr}
+if which == "k1w":
+    B, H, Dk, Dv, W = 64, 4, 256, 256, 8
+    alg = int(B * (4 * H * Dk * Dv * (1 + 1 / W) + 2 * (2 * H * Dk + 2 * H * Dv) + 4 * H * Dk + 4 * H * (2 * Dk + Dv)
+                   + 4 * H * (2 * Dk + Dv) * (W - 1) / 2))
+    o.update(kernel="lina::gla_decode_window_kernel<256, 4, 1, bf16, float> (K1w + K5, window 8)",
+             command="rocprofv3 --kernel-trace --pmc <COUNTER> -- python tools/perf_k1w.py (the 13 layers' real buffers, all 8 "
+                     "window positions in turn; tests/gpu_evidence.sh)",
+             note="mean over all launches of the run = all 8 window positions (7 read-only, 1 write-back)",
+             algorithmic_bytes_per_launch=alg, traffic_over_algorithmic=(rd + wr) / alg)
+else:
+    heads = int(sys.argv[5])
+    D = 1024 // heads
+    alg = 64 * heads * 4096 * 2 * 5 * D
+    o.update(kernel=f"lina::gla_chunk_bf16_h256_kernel<false, G={256 // D}> (K2 forward, training call: no final state)",
+             shape={"B": 64, "H": heads, "T": 4096, "Dk": D, "Dv": D},
+             command=f"K2_H={heads} K2_HT=0 rocprofv3 --kernel-trace --pmc <COUNTER> -- python tools/perf_k2.py (tests/gpu_evidence.sh)",
+             algorithmic_bytes_per_launch=alg, traffic_over_algorithmic=(rd + wr) / alg)
+    if len(sys.argv) > 6:
+        rows = [r for r in csv.DictReader(open(sys.argv[6])) if pat in r.get("name", r.get("Name", ""))]
+        if rows:
+            o["kernel_stats_row"] = rows[0]
+json.dump(o, open(out, "w"), indent=1)
+print(out, "traffic/algorithmic =", round(o["traffic_over_algorithmic"], 4))
