@@ -809,11 +809,6 @@ static bool full_ok(int H, int Dk, int Dv, int dtype, const void* q, const void*
     return p16(q) && p16(k) && p16(v) && p16(gk) && p16(o);
 }
 
-// gla_chunk_reg.hip: the plain forward with the next chunk prefetched into registers and double-buffered operand tiles
-int launch_chunk_reg(const void* q, const void* k, const void* v, const void* gk, void* o, const float* h0, float* ht,
-                     int slots, int H, int T, int nseg, int Tseg, lina_bht_strides sq, lina_bht_strides sk,
-                     lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides so, float scale, lina_stream_t stream);
-
 int launch_chunk_full(const void* q, const void* k, const void* v, const void* gk, void* o, const float* h0,
                       float* ht, int B, int H, int T, int Dk, int Dv, lina_bht_strides sq, lina_bht_strides sk,
                       lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides so, int dtype, int g_dtype,
@@ -823,9 +818,6 @@ int launch_chunk_full(const void* q, const void* k, const void* v, const void* g
              fits32(sv) && fits32(sg) && fits32(so);
     if (!*taken) return LINA_OK;
     const int G = 256 / Dk;
-#ifndef LINA_K2_NOREG
-    if (G == 1) return launch_chunk_reg(q, k, v, gk, o, h0, ht, B * H, H, T, 1, T, sq, sk, sv, sg, so, scale, stream);
-#endif
     dim3 grid((unsigned)(B * H / G));
 #define LINA_FULL(GG)                                                                                                  \
     LINA_LAUNCH((gla_chunk_bf16_h256_kernel<false, GG>), grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k, \

@@ -36,23 +36,7 @@ dt = e0.elapsed_time(e1) * 1e-3 / reps
 nbytes = B * H * T * 2 * (3 * Dk + 2 * Dv)
 print(f"K2[final_state={HT}] B={B} T={T}: {dt*1e3:.3f} ms  {nbytes/dt/1e9:.1f} GB/s ({nbytes/dt/8e12*100:.1f}% of 8 TB/s)  "
       f"{dt/(T/32)*2.4e9:.0f} clk/chunk @2.4GHz")
-if os.environ.get("K2_PROF") == "reg":                     # K2r's profile build (tools/k2_tune.sh: prof)
-    import ctypes, numpy as np
-    from lina_speech_amd import _lib
-    lib = _lib.load()
-    ops.chunk_gla(q, k, v, gk, output_final_state=HT)
-    torch.cuda.synchronize()
-    buf = np.zeros(256 + 1024, dtype=np.uint64)
-    rc = lib.lina_k2r_prof_read(buf.ctypes.data_as(ctypes.c_void_p))
-    a = buf[:256].reshape(16, 16).astype(np.float64) / (T / 32)
-    names = ["flags", "finish prev", "phase A", "maskA (w<4)", "step1 qS", "step4 upd", "raw loads", "barrier"]
-    print("clk per 32-token iteration per phase (shader clock), waves 0, 1, 7, 8, 15 and mean:  rc =", rc)
-    for i, nm in enumerate(names):
-        print(f"  {nm:12s} " + " ".join(f"{a[w, i]:8.0f}" for w in (0, 1, 7, 8, 15)) + f"   mean {a[:, i].mean():8.0f}")
-    print(f"  total        " + " ".join(f"{a[w, :8].sum():8.0f}" for w in (0, 1, 7, 8, 15)))
-    wg = buf[256:256 + B * H].astype(np.float64) / (T / 32)
-    print("per-workgroup clk/iteration (wave 0): min/median/max", np.min(wg), np.median(wg), np.max(wg))
-elif os.environ.get("K2_PROF"):
+if os.environ.get("K2_PROF"):
     import ctypes, numpy as np
     from lina_speech_amd import _lib
     lib = _lib.load()
