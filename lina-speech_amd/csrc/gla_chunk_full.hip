@@ -218,9 +218,11 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     int rp = lane & 15, ch0 = 16 * w + 4 * (lane >> 4);
     bool gate_zero0 = rev_tail;                               // REV, first chunk of the sequence's last segment: row 0 has no gate
     // inclusive gate cumsum of this thread's 2 rows x 4 channels (rows >= nrem count as 0); true if the chunk's total
-    // decay is too large for one chunk.  FULL: all C rows are in the sequence (no masks).
-    auto gate_scan = [&](auto full_tag, float (&bc)[2][4], int nrem) {
-        constexpr bool FULL = decltype(full_tag)::value;
+    // decay is too large for one chunk.  FULL: all C rows are in the sequence (no masks).  CLAMP: a single gate below -60 is
+    // clamped to -60 -- only the cut path needs it: an unclamped gate below -60 makes the optimistic scan report a violation
+    // by itself, and the cut path rescans with the clamp (8 v_max per thread and chunk less in the common path, round 4).
+    auto gate_scan = [&](auto full_tag, auto clamp_tag, float (&bc)[2][4], int nrem) {
+        constexpr bool FULL = decltype(full_tag)::value, CLAMP = decltype(clamp_tag)::value;
         float g0[4], g1[4];
         const bf16_t* gp = &s_rg[rp * PE + ch0];
         unpack4(*reinterpret_cast<const uint2*>(gp), g0);
@@ -228,8 +230,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         const bool in0 = FULL || 2 * rp < nrem, in1 = FULL || 2 * rp + 1 < nrem;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            g0[c] = vmax_raw(g0[c], -kFullMaxDecay);
-            g1[c] = vmax_raw(g1[c], -kFullMaxDecay);
+            if constexpr (CLAMP) {
+                g0[c] = vmax_raw(g0[c], -kFullMaxDecay);
+                g1[c] = vmax_raw(g1[c], -kFullMaxDecay);
+            }
             if constexpr (REV) g0[c] = (gate_zero0 && rp == 0) ? 0.0f : g0[c];
             g1[c] = in1 ? g1[c] : 0.0f;
             bc[1][c] = (in0 ? g0[c] : 0.0f) + g1[c];         // the row pair's sum
@@ -498,8 +502,13 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 sched_fence();
             }
             bool viol;
-            if (nrem >= C) viol = gate_scan(FullT{}, bc, nrem);   // workgroup-uniform: the mask-free form
-            else viol = gate_scan(PartT{}, bc, nrem);
+#ifdef LINA_K2_CLAMP_ALWAYS   // tools-only A/B build: the round-3 form
+            using OptClamp = FullT;
+#else
+            using OptClamp = PartT;
+#endif
+            if (nrem >= C) viol = gate_scan(FullT{}, OptClamp{}, bc, nrem);   // workgroup-uniform: the mask-free form
+            else viol = gate_scan(PartT{}, OptClamp{}, bc, nrem);
             if (viol) s_flags[2 * par] = 1;
             if (MODE == 1 && !DG && np > 0) store_prev();
             if (nrem >= C) write_tiles(FullT{}, bc, C, par, En, zq, hq, hk, hv);
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         if (fl.x) {
             // ---- rare: the decay inside this chunk exceeds e^-60 -> cut the chunk at the first such row ----
             float bc[2][4];
-            gate_scan(PartT{}, bc, nrem);
+            gate_scan(PartT{}, FullT{}, bc, nrem);             // (with the clamp)
             int nc = C;
 #pragma unroll
             for (int rr = 1; rr >= 0; --rr) {
