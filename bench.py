@@ -169,8 +169,9 @@ def measure_chunk(dev, B=64, H=4, T=4096, Dk=256, Dv=256, reps=200):
     nbytes = B * H * T * 2 * (3 * Dk + 2 * Dv)                       # e*(3Dk+2Dv) per (row,head,token)
     flops = B * H * T * (2 * 64 * (Dk + Dv) + 4 * Dk * Dv)            # nominal C=64 count of SURVEY 8(d)
     traffic, traffic_src = None, None
-    for name, note in (("r02_k2_traffic.json", "; includes the 67 MB final state of the prefill call"),
-                       ("r02_k2_b8_traffic.json", "; state-only pass + combine + full pass of the segment-parallel form")):
+    for name, note in (("r02_k2_b8_traffic.json", "; state-only pass + combine + full pass of the segment-parallel form"),
+                       ("r04_k2_h4_traffic.json", "; the training call"), ("r04_k2_h8_traffic.json", "; the training call"),
+                       ("r04_k2_h16_traffic.json", "; the training call")):
         tpath = os.path.join(ROOT, "profiles", name)                 # PMC passes are separate runs; their committed summaries
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -702,7 +703,7 @@ def main():
             k1d_bytes = k1_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4)
             k1_bytes = k1w_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4, eng.window) if lazy else k1d_bytes
             traffic, traffic_src = None, None
-            names = ("r02_k1w_traffic.json",) if lazy else ("r02_k1d_traffic.json", "r01_k1d_traffic.json")
+            names = ("r04_k1w_traffic.json", "r02_k1w_traffic.json") if lazy else ("r02_k1d_traffic.json", "r01_k1d_traffic.json")
             for name in names:                                # PMC passes are separate runs; their committed summary
                 tpath = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tpath) and k1_rows == 64 and dtype == torch.bfloat16:
