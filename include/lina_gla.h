@@ -405,31 +405,6 @@ int lina_gla_decode_window(const void* q, const void* k, const void* v, const vo
 int lina_gla_decode_window_flush(float* state, const float* hist_k, const float* hist_c, const float* hist_v,
                                  int n_pending, int B, int H, int Dk, int Dv, lina_stream_t stream);
 
-/* lina_gla_decode_inproj_packed AND lina_gla_decode_window (K1w + K5) of one mixer in ONE launch: the whole of
- * GatedLinearAttention.forward up to the output projection at T = 1 (reference model/gla.py:158-219).  The K1w workgroups
- * start streaming their fp32 state at launch while the in-projection workgroups run beside them on the same CUs; q | k | v
- * (post conv + SiLU), the output gate and the log-gates are handed over inside the launch (write-through stores, one arrival
- * counter per head, relaxed agent-scope loads on the consuming side).  Results: the K1w half is bit-identical to
- * lina_gla_decode_window on the same q, k, v, gk, gate; the in-projection half equals lina_gla_decode_inproj_packed up to the
- * summation order of the LayerNorm row sums (fp32).
- *   qkv [B, 2 H Dk + H Dv], g_out [B, H Dv] (model dtype), gk fp32 [B, H Dk]: written AND consumed here (row-major, contiguous);
- *   state / hist_* / step / origin / og / og_packed as for lina_gla_decode_window; x_packed, w_in_packed, c1 .. b2, w_stream as
- *   for lina_gla_decode_inproj_packed;
- *   sync: int32 [64] in device memory, ZERO before the first call (the kernel re-arms it); sync[32] != 0 afterwards = a wait
- *   inside a launch timed out (results invalid);
- *   n_pre: state vectors per thread requested before the hand-off (16, 20 or 24 of 32; <= 0 = 24; 28 does not fit the registers);
- *   pace: they are requested in batches of `pace` (2 or 4; < 0 = 4) with at most two batches outstanding per wave, 0 = all at
- *   once (measured slower: the queue then stands in front of the in-projection's loads on the same CU).
- * Built for bf16, Dk = Dv = 256, B <= 64, window <= 8, conv width 4, gate rank 16 and a grid that is resident as a whole
- * (B H <= CUs, B H + tiles <= 2 CUs); LINA_ERR_UNSUPPORTED otherwise -- run the two launches then. */
-int lina_gla_decode_inproj_window(const void* x_packed, const void* w_in_packed, const float* c1, const float* c2,
-                                  const void* wq, const void* wk, const void* wv, void* cq, void* ck, void* cv,
-                                  const void* w2, const void* b2, void* qkv, void* g_out, float* gk, float* state,
-                                  const void* norm_weight, void* og, float* hist_k, float* hist_c, float* hist_v,
-                                  const int64_t* step, const int64_t* origin, int* sync, int window, int B, int K, int H,
-                                  int Dk, int Dv, int W, int R, float ln_eps, float normalizer, float clamp_min, float eps,
-                                  float scale, int og_packed, int w_stream, int n_pre, int pace, int dtype, lina_stream_t stream);
-
 /* Decode-step projection with fused neighbours: out[M,N] = epi(A[M,K] . W[N,K]^T), M ~ batch rows.
  *   ln_dim > 0 : A is layer-normalised over its ln_dim features first, folded algebraically:
  *                out = rstd*(A.W^T - mu*c1) + c2   with W pre-scaled by the LN gamma,

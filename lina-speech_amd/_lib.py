@@ -74,7 +74,6 @@ PROTOTYPES = {
                                               _i, _i, _f, _p]),
     "lina_gla_decode_window_max": (C.c_int, []),
     "lina_gla_decode_window": (C.c_int, [_p] * 15 + [_i] * 5 + [_i64] * 10 + [_f, _i, _i, _i, _f, _p]),
-    "lina_gla_decode_inproj_window": (C.c_int, [_p] * 24 + [_i] * 8 + [_f] * 5 + [_i] * 5 + [_p]),
     "lina_gla_decode_window_flush": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "lina_linear_skinny_ex": (C.c_int, [_p, _i64, _p, _i64, _i, _i, _p, _p, _p, _i64, _p, _i64, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "lina_gla_decode_inproj_packed": (C.c_int, [_p] * 15 + [_i] * 6 + [_f, _f, _f, _i, _i, _p]),

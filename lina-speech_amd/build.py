@@ -22,7 +22,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
 # Kernels that wait for their global->LDS DMA by COUNTING vector-memory operations (wait_vmem_but<N>: "all but the last N
 # loads"): a register spill the compiler adds would put scratch loads into that count, so these files must compile to
 # kernels without scratch -- checked from the compiler's own resource remarks at build time.
-NO_SCRATCH = {"gla_chunk_full.hip", "gla_decode_window.hip", "gla_inproj_window.hip"}   # K1w: a spilled tile register waits for its load mid-issue
+NO_SCRATCH = {"gla_chunk_full.hip", "gla_decode_window.hip"}   # K1w: a spilled tile register waits for its load mid-issue
 
 
 def _check_no_scratch(src: str, out: str) -> str:

@@ -24,7 +24,6 @@ __device__ unsigned long long lina_inproj_prof[1024 * 8];
 #define IP_PROF(i, expr) do { } while (0)
 #define IP_PROF_FLUSH() do { } while (0)
 #endif
-#include "gla_inproj_body.h"
 
 namespace lina {
 
@@ -35,14 +34,279 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
     T* cq, T* ck, T* cv, const T* __restrict__ w2, const T* __restrict__ b2, T* __restrict__ qkv,
     T* __restrict__ g_out, float* __restrict__ gk, int M, int K, int Kd, int Vd, float ln_eps, float inv_norm,
     float clamp_min, int has_clamp) {
-    __shared__ InprojSmem<NT, NW> sm;
-    gla_inproj_body<T, NT, PK, WNT, NW, 0, false>(sm, (int)blockIdx.x, (int)blockIdx.y, A, lda, W, ldw, c1, c2, wq, wk, wv, cq, ck,
-                                                  cv, w2, b2, qkv, g_out, gk, M, K, Kd, Vd, ln_eps, inv_norm, clamp_min,
-                                                  has_clamp, 1, nullptr);
+    using F = Frag<T>;              // WNT: weight fragments with the non-temporal load hint
+#ifdef LINA_SKINNY_PROF
+    unsigned long long pr_[8] = {};
+    IP_PROF(0, wall_clock64());
+    IP_PROF(1, clock64());
+#endif
+    constexpr int R = 16, MT = 4;
+    constexpr int U = NW > 8 ? 2 : (NW > 4 || (NT + MT) * 8 > 48) ? 4 : 8;   // NW: split-K width, see linear_skinny.hip
+    constexpr int RS = NW >= 4 * MT ? 4 : NW >= 2 * MT ? 2 : 1;              // finalising waves per m-tile (row split), see there
+    constexpr int RPW = 4 / RS;
+    __shared__ __attribute__((aligned(16))) float s_acc[NW][NT * MT][64][4];
+    __shared__ float s_st[NW][64][2];
+    __shared__ float s_fin[NW > 4 ? 64 : 1][2];           // NW > 4: the rows' LayerNorm sums, added up once (linear_skinny.hip)
+    __shared__ float s_lr[64][R + 1];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index in an SGPR: everything that depends on it (k-step ownership, remainder rounds, who finalises what) is
+    // then a SCALAR branch.  With w in a VGPR the compiler predicates such code with EXEC -- and an MFMA issued under
+    // EXEC = 0 still executes, on whatever its (unwritten) operand registers hold: non-finite sums on the hardware.
+    const int w = wave_uniform(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int m0 = blockIdx.y * 64;
+    const int n_direct = 2 * Kd + 2 * Vd;               // q | k | v | g columns; low-rank rows follow in W
+    // q | k | v | g workgroups take 16 NT columns; a GATE workgroup takes 16 gate channels (one low-rank tile to multiply, but
+    // the heaviest epilogue -- 16 FMAs + a log-sigmoid per element: with 32 channels the gate workgroups finished ~1.5 us
+    // after everybody else, time stamps of tools/probe_skinny_prof.py; there are idle CUs for the extra workgroups)
+    const int nb_direct = n_direct / (16 * NT);
+    const bool gate_wg = (int)blockIdx.x >= nb_direct;  // block-uniform
+    const int tile0 = gate_wg ? n_direct + ((int)blockIdx.x - nb_direct) * 16 : (int)blockIdx.x * (16 * NT);
+
+    f32x4 acc[NT * MT], st1[MT], st2[MT];
+#pragma unroll
+    for (int i = 0; i < NT * MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { st1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; st2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    F f_ones;
+    f_ones.ones();
+    // PK: A and W fragment-major (skinny_frag.h; rows padded to 64): one contiguous 1 KiB per fragment load
+    const int nks_all = K / F::KSTEP;
+    const int64_t kstr = PK ? 64 * F::KL : F::KSTEP;
+    const T* wp[NT];
+    bool g_on[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        g_on[j] = !gate_wg || j == 0;
+        const int wrow0 = gate_wg ? n_direct : tile0 + 16 * j;
+        wp[j] = PK ? W + ((int64_t)(wrow0 >> 4) * nks_all * 64 + lane) * F::KL
+                   : W + (int64_t)(wrow0 + li) * ldw + F::KL * lg;
+    }
+    const T* ap[MT];
+    bool m_ok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + 16 * mt + li;
+        m_ok[mt] = PK || m < M;
+        ap[mt] = PK ? A + ((int64_t)((m0 >> 4) + mt) * nks_all * 64 + lane) * F::KL
+                    : A + (int64_t)(m < M ? m : 0) * lda + F::KL * lg;
+    }
+    // Epilogue operands that do not depend on the GEMM -- the rolled conv caches of this wave's 4 rows (wave w
+    // finalises m-tile w), the conv taps and the LayerNorm-fold constants -- are requested NOW, so their
+    // (HBM-cold) latency is hidden under the main loop instead of sitting exposed after the reduction.
+    typedef typename raw4<T>::type raw_t;   // RAW bits of the epilogue operands, converted where they are used (lina_common.h)
+    raw_t pre_old[NT][4], pre_wj[NT];
+    T pre_b2[NT];
+    float pre_c1[NT], pre_c2[NT];
+    // Which tensor a TILE needs is decided per tile (Kd, Vd are multiples of 16: a 16-column tile never straddles q|k|v|g):
+    // scalar branches, and inside them every load is unconditional on a clamped address -- a per-lane `ok ? ld(p) : 0`
+    // compiles to one EXEC-masked region + `s_waitcnt vmcnt(0)` per load, i.e. one memory round trip after the other.
+    // Requested BEHIND the first round of fragment loads (loads return in order; the fragments are needed first).
+    auto preload = [&]() {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = gate_wg ? n_direct + li : tile0 + 16 * j + li;
+            pre_c1[j] = c1[n];
+            pre_c2[j] = c2[n];
+            pre_wj[j] = raw_t();
+            pre_b2[j] = T();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pre_old[j][r] = raw_t();
+            if (w >= MT * RS) continue;                         // the other waves only feed the split-K sum
+            const int tn0 = tile0 + 16 * j;                     // first column of this tile: workgroup-uniform
+            if (gate_wg) {
+                // gate tiles: the rank-16 up-projection row of this lane's channel (16 contiguous elements) and its bias are
+                // epilogue operands too -- they travel in the registers the q/k/v tiles use for the conv cache
+                if (j == 0 && tn0 - n_direct < Kd) {            // (Kd % 16 == 0: the whole tile is inside)
+                    const int c = (tn0 - n_direct) + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pre_old[j][r] = ld4_raw(w2 + (int64_t)c * R + 4 * r);
+                    pre_b2[j] = ld_raw(b2 + c);
+                }
+            } else if (tn0 < 2 * Kd + Vd) {
+                const T* wsel; const T* csel; int c, D;
+                if (tn0 < Kd) { c = tn0 + li; D = Kd; wsel = wq; csel = cq; }
+                else if (tn0 < 2 * Kd) { c = tn0 - Kd + li; D = Kd; wsel = wk; csel = ck; }
+                else { c = tn0 - 2 * Kd + li; D = Vd; wsel = wv; csel = cv; }
+                pre_wj[j] = ld4_raw(wsel + (int64_t)c * 4);
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {                  // this wave's rows of m-tile w / RS
+                    const int m = m0 + 16 * (w / RS) + 4 * lg + (w % RS) * RPW + r;
+                    pre_old[j][r] = ld4_raw(csel + ((int64_t)(m < M ? m : 0) * D + c) * 4);
+                }
+            }
+        }
+    };
+    bool pre_done = false;
+
+    const int nsteps = K / F::KSTEP;
+    // wave w takes k-steps {2w, 2w+1} + 8j: its two consecutive 64-byte (bf16) loads of a row are the two halves
+    // of ONE 128-byte line, so every line is pulled into this CU's L1 by a single wave, back to back
+    int ks = 0;                                  // per-wave step counter; global k-step = kstep_of<NW>(w, ks)
+    for (; kstep_of<NW>(w, ks + U - 1) < nsteps; ks += U) {
+        F fb[U][NT], fa[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k0 = kstep_of<NW>(w, ks + u) * kstr;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[u][j].template load_stream<WNT>(wp[j] + k0); else fb[u][j].zero(); }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[u][mt].load(ap[mt] + k0); else fa[u][mt].zero(); }
+        }
+        if (ks == 0) { sched_fence(); preload(); sched_fence(); pre_done = true; }   // behind the first round's fragments
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                st1[mt] = F::mma(fa[u][mt], f_ones, st1[mt]);          // row sums      (LayerNorm mean)
+                st2[mt] = F::mma(fa[u][mt], fa[u][mt], st2[mt]);       // Gram diagonal (LayerNorm variance)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j * MT + mt] = F::mma(fa[u][mt], fb[u][j], acc[j * MT + mt]);
+            }
+#ifdef LINA_SKINNY_PROF
+        if (ks == 0) IP_PROF(2, clock64());
+#endif
+    }
+    IP_PROF(3, clock64());
+    if (!pre_done) preload();                                   // (a K shorter than one round)
+    for (; kstep_of<NW>(w, ks) < nsteps; ++ks) {
+        const int64_t k0 = kstep_of<NW>(w, ks) * kstr;
+        F fb[NT], fa[MT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { if (g_on[j]) fb[j].template load_stream<WNT>(wp[j] + k0); else fb[j].zero(); }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { if (m_ok[mt]) fa[mt].load(ap[mt] + k0); else fa[mt].zero(); }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            st1[mt] = F::mma(fa[mt], f_ones, st1[mt]);
+            st2[mt] = F::mma(fa[mt], fa[mt], st2[mt]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j * MT + mt] = F::mma(fa[mt], fb[j], acc[j * MT + mt]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT * MT; ++i)
+        *reinterpret_cast<float4*>(&s_acc[w][i][lane][0]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (li == 4 * lg + r) { s_st[w][16 * mt + li][0] = st1[mt][r]; s_st[w][16 * mt + li][1] = st2[mt][r]; }
+    __syncthreads();
+    if (NW > 4) {
+        if (tid < 128) {
+            const int row = tid >> 1, c = tid & 1;
+            float a = (s_st[0][row][c] + s_st[1][row][c]) + (s_st[2][row][c] + s_st[3][row][c]);
+#pragma unroll
+            for (int ww = 4; ww < NW; ww += 4)
+                a += (s_st[ww][row][c] + s_st[ww + 1][row][c]) + (s_st[ww + 2][row][c] + s_st[ww + 3][row][c]);
+            s_fin[row][c] = a;
+        }
+        __syncthreads();
+    }
+    IP_PROF(4, clock64());
+    if (w >= MT * RS) {                                     // the extra waves have delivered their partial sums
+        if (gate_wg) __syncthreads();                       // (the gate tiles' low-rank exchange below has one more barrier)
+        return;
+    }
+
+    // wave w finalises rows [rq RPW, rq RPW + RPW) of every lane's four rows of m-tile mtf (rows m0 + 16 mtf + 4 lg + r,
+    // column li of each tile): the same sums in the same order as one wave per m-tile
+    const int mtf = w / RS, rq = w % RS;
+    float val[NT][RPW], mu[RPW], rstd[RPW];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) val[j][r] = s_acc[0][j * MT + mtf][lane][rq * RPW + r];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) val[j][r] += s_acc[ww][j * MT + mtf][lane][rq * RPW + r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = 16 * mtf + 4 * lg + rq * RPW + r;
+        float a, b;
+        if (NW > 4) { a = s_fin[row][0]; b = s_fin[row][1]; }
+        else {
+            a = (s_st[0][row][0] + s_st[1][row][0]) + (s_st[2][row][0] + s_st[3][row][0]);
+            b = (s_st[0][row][1] + s_st[1][row][1]) + (s_st[2][row][1] + s_st[3][row][1]);
+        }
+        const float inv_k = fast_rcp((float)K);
+        mu[r] = a * inv_k;
+        rstd[r] = rsqrtf(fmaxf(b * inv_k - mu[r] * mu[r], 0.f) + ln_eps);
+    }
+
+    if (gate_wg) {
+        const float cc1 = pre_c1[0], cc2 = pre_c2[0];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) s_lr[16 * mtf + 4 * lg + rq * RPW + r][li] = rstd[r] * (val[0][r] - mu[r] * cc1) + cc2;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 1; ++j) {                              // (one 16-channel tile per gate workgroup)
+            const int c = (tile0 - n_direct) + li;                   // gate channel
+            if (c >= Kd) continue;
+            const float4 q0 = cvt4(pre_old[j][0]), q1 = cvt4(pre_old[j][1]), q2 = cvt4(pre_old[j][2]), q3 = cvt4(pre_old[j][3]);
+            const float w2r[R] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            const float bias = cvt1(pre_b2[j]);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = 16 * mtf + 4 * lg + rq * RPW + r, m = m0 + row;
+                float accg = bias;
+#pragma unroll
+                for (int jj = 0; jj < R; ++jj) accg = fmaf(s_lr[row][jj], w2r[jj], accg);
+                float gv = logsigmoidf(accg) * inv_norm;
+                if (has_clamp) gv = fmaxf(gv, clamp_min);
+                if (m < M) gk[(int64_t)m * Kd + c] = gv;
+            }
+        }
+        IP_PROF_FLUSH();
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = tile0 + 16 * j + li;
+        const float cc1 = pre_c1[j], cc2 = pre_c2[j];
+        float z[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) z[r] = rstd[r] * (val[j][r] - mu[r] * cc1) + cc2;   // projected value z[m, n]
+        if (n >= 2 * Kd + Vd) {                              // g columns
+            const int c = n - (2 * Kd + Vd);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int m = m0 + 16 * mtf + 4 * lg + rq * RPW + r;
+                if (m < M) st(g_out + (int64_t)m * Vd + c, z[r]);
+            }
+            continue;
+        }
+        // q / k / v columns: conv step on the rolled cache (W = 4) + SiLU
+        T* csel; int c, D;
+        if (n < Kd) { c = n; D = Kd; csel = cq; }
+        else if (n < 2 * Kd) { c = n - Kd; D = Kd; csel = ck; }
+        else { c = n - 2 * Kd; D = Vd; csel = cv; }
+        const float4 wj = cvt4(pre_wj[j]);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int m = m0 + 16 * mtf + 4 * lg + rq * RPW + r;
+            if (m < M) {
+                T* cb = csel + ((int64_t)m * D + c) * 4;
+                const float4 old = cvt4(pre_old[j][r]);
+                T tmp;                                       // the conv sees the projection in the model dtype
+                st(&tmp, z[r]);
+                const float xn = ld(&tmp);
+                const float4 nw = make_float4(old.y, old.z, old.w, xn);
+                st4(cb, nw);
+                const float y = fmaf(wj.w, nw.w, fmaf(wj.z, nw.z, fmaf(wj.y, nw.y, wj.x * nw.x)));
+                st(qkv + (int64_t)m * (2 * Kd + Vd) + n, silu(y));
+            }
+        }
+    }
+    IP_PROF_FLUSH();
 }
 
 }  // namespace lina
-
 
 static int inproj_impl(const void* x, int64_t ldx, const void* w_in, int64_t ldw, int packed, const float* c1,
                        const float* c2, const void* wq, const void* wk, const void* wv, void* cq, void* ck, void* cv,

@@ -33,7 +33,6 @@ __device__ __forceinline__ int shfl_xor_i(int v, int mask) { return __shfl_xor(v
 __device__ __forceinline__ int shfl_i(int v, int src) { return __shfl(v, src, 64); }
 // value of lane+d / lane-d; a lane whose source is outside the wave gets its own value back
 __device__ __forceinline__ int shfl_down_i(int v, int d) { return __shfl_down(v, d, 64); }
-__device__ __forceinline__ float shfl_down_f(float v, int d) { return __shfl_down(v, d, 64); }
 __device__ __forceinline__ float shfl_up(float v, int d) { return __shfl_up(v, d, 64); }
 // LDS atomics on a workgroup-shared int
 __device__ __forceinline__ void lds_atomic_add(int* p, int v) { atomicAdd(p, v); }
@@ -76,15 +75,6 @@ __device__ __forceinline__ void dma16_to_lds_async(const void* base_uniform, uns
 #else
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
 #endif
-                 :
-                 : "s"(lds), "v"(lane_byte_off), "s"(base_uniform)
-                 : "memory", "m0");
-}
-// 4 bytes per lane (global_load_lds_dword): a wave copies 256 contiguous bytes to lds_wave_base + 4 lane
-__device__ __forceinline__ void dma4_to_lds_async(const void* base_uniform, unsigned lane_byte_off, void* lds_wave_base) {
-    const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane(
-        (int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
                  :
                  : "s"(lds), "v"(lane_byte_off), "s"(base_uniform)
                  : "memory", "m0");
@@ -133,28 +123,6 @@ __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0
 __device__ __forceinline__ int ticket_agent(int* counter) {
     return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-// The same protocol with a waiting consumer (a flag / counter the consumer polls): payload stores as above (2-, 4- or 8-byte
-// relaxed agent-scope atomics = write-through), polled word and payload loads relaxed agent-scope (sc1: served by L2, never by a
-// stale L1 line).  Poll from ONE lane, sleeping between polls (guide: polling-cost).
-__device__ __forceinline__ void st_agent_u64(void* p, uint32_t lo, uint32_t hi) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)lo | ((unsigned long long)hi << 32),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint2 ld_agent_u64(const void* p) {
-    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-    return make_uint2((unsigned)(v & 0xffffffffu), (unsigned)(v >> 32));
-}
-__device__ __forceinline__ unsigned short ld_agent_u16(const unsigned short* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_agent_f32(const float* p) {
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ int ld_agent_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent_i32(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void poll_sleep() { __builtin_amdgcn_s_sleep(2); }
 
 // lane index from the hardware (v_mbcnt: no register has to stay live for it) and a wave-uniform value moved to an
 // SGPR: together they let a kernel re-derive threadIdx.x anywhere instead of carrying it in (or spilling it from) a VGPR

@@ -135,14 +135,6 @@ class _BlockPack:
         if self.packed:
             self.og_p = torch.zeros(ops.packed_numel(B, self.Vd), dtype=dt, device=dev)
             self.s_p = torch.zeros(ops.packed_numel(B, self.hid_pad), dtype=dt, device=dev)
-        # in-projection + K1w + K5 as ONE launch (lina_gla_decode_inproj_window): what that kernel is built for, and a grid
-        # that is resident as a whole (its K1w workgroups wait for the in-projection's inside the launch)
-        cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
-        n_tiles = (2 * self.Kd + 2 * self.Vd) // 32 + self.Kd // 16
-        self.one_launch_ok = (self.packed and dt == torch.bfloat16 and self.Dk == 256 and self.Dv == 256 and B <= 64
-                              and self.H <= 16 and self.window <= 8 and self.d % 64 == 0 and B * self.H <= cus
-                              and B * self.H + n_tiles <= 2 * cus)
-        self.sync = torch.zeros(64, dtype=torch.int32, device=dev)        # its hand-off words (zero between launches)
         if self.lazy:      # K1w: k_s, cumulative log-gate c_s and v_s of the steps of the current window
             self.hk = torch.zeros(self.window, B * self.H, self.Dk, dtype=torch.float32, device=dev)
             self.hc = torch.zeros(self.window, B * self.H, self.Dk, dtype=torch.float32, device=dev)
@@ -171,8 +163,7 @@ class DecodeEngine:
     def __init__(self, model, x_enc: torch.Tensor, batch_size: int, state: Optional[Cache] = None,
                  use_graph: Optional[bool] = None, n_split: Optional[int] = None, fuse_norm: bool = True,
                  window: Optional[int] = None, stream_weights=("in", "up"), cross: str = "spread",
-                 fused_pick: bool = True, packed: bool = True, cross_tail_fused: bool = True,
-                 one_launch_mixer: Optional[bool] = None, n_pre: int = 24, pace: int = 4):
+                 fused_pick: bool = True, packed: bool = True, cross_tail_fused: bool = True):
         """Every variant of the step is a constructor argument (rounds 2-3 read ``LINA_DECODE_*`` environment switches here).
         ``stream_weights``: which weight matrices of the device loop ("in", "o", "up", "down", "head") are loaded with the
         non-temporal hint instead of competing for the 256 MB Infinity Cache (measured optimum: in + up).
@@ -181,10 +172,6 @@ class DecodeEngine:
         one-launch sampled epilogue K6e / the fragment-major operand path of the device loop (False = the unfused forms, kept
         for A/B measurements and as the parity reference of the fused ones).  ``cross_tail_fused``: the second attention's
         scores x_pos . pe^T computed inside the softmax + att2 . V + residual launch (one launch less per token).
-        ``one_launch_mixer`` (default: on where the kernel is built for the shape -- bf16, Dk = Dv = 256, window <= 8, rows x
-        heads <= CUs): the in-projection and K1w + K5 of a block run as ONE launch whose K1w workgroups stream the state
-        while the in-projection runs beside them (lina_gla_decode_inproj_window); ``n_pre``: state vectors per thread it
-        requests before the hand-off (16 / 20 / 24 of 32).
         ``window`` (1, 2, 4, 8 or 16; default 8): the device-side decode loop keeps the recurrent state of every block
         LAZILY WRITTEN -- read every token, rewritten every ``window``-th token (K1w, lina_gla_decode_window); the
         steps in between live in small history buffers.  ``engine.state`` / ``sync_state()`` materialise the exact
@@ -218,10 +205,6 @@ class DecodeEngine:
             raise ValueError("cross must be 'spread' or 'fused'")
         self._cross_spread = cross == "spread"
         self._fused_pick, self._packed_ok = bool(fused_pick), bool(packed)
-        self._one_launch = one_launch_mixer
-        self._n_pre = int(n_pre)
-        self._pace = int(pace)
-        self._skip_inproj = False
         self._cross_tail_fused = bool(cross_tail_fused)   # x_pos . pe^T folded into the softmax + att2 . V launch (d % 256 == 0)
         blocks = list(rnn.encoder) + list(rnn.decoder) + [rnn.cross_att.pos_net]
         self.n_enc = len(rnn.encoder)
@@ -272,19 +255,7 @@ class DecodeEngine:
         ``x_p``: the fragment-major copy of x -- the projections then run on packed operands and keep it current."""
         B = x.shape[0]
         packed = x_p is not None
-        one_launch = (packed and lazy and P.lazy and P.one_launch_ok and self._one_launch is not False
-                      and not self._skip_update)
-        if self._one_launch and lazy and not (packed and P.lazy and P.one_launch_ok):
-            raise RuntimeError("one_launch_mixer=True: the one-launch mixer kernel is not built for this block / batch shape")
-        if one_launch:
-            ops.gla_decode_inproj_window(x_p, P.w_in_p, B, P.d, P.c1_in, P.c2_in, P.wq, P.wk, P.wv, P.cq, P.ck, P.cv, P.w2, P.b2,
-                                         P.qkv, P.g, P.gk, P.S, P.gnw, P.og_p, P.hk, P.hc, P.hv, self._t_idx, self._origin,
-                                         P.sync, P.window, P.n1_eps, P.normalizer, P.clamp_min, P.eps_gate,
-                                         og_packed=True, w_stream="in" in self._stream, n_pre=self._n_pre, pace=self._pace)
-            gate = P.g.view(B, P.H, P.Dv)
-        elif packed and self._skip_inproj:
-            gate = P.g.view(B, P.H, P.Dv)         # measurement only (time_update_kernel): the step without the mixer's input side
-        elif packed:
+        if packed:
             ops.gla_decode_inproj_packed(x_p, P.w_in_p, B, P.d, P.c1_in, P.c2_in, P.wq, P.wk, P.wv, P.cq, P.ck, P.cv,
                                          P.w2, P.b2, P.qkv, P.g, P.gk, P.n1_eps, P.normalizer, P.clamp_min,
                                          w_stream="in" in self._stream)
@@ -301,8 +272,8 @@ class DecodeEngine:
         q = P.qkv[:, :P.Kd].view(B, P.H, P.Dk)
         k = P.qkv[:, P.Kd:2 * P.Kd].view(B, P.H, P.Dk)
         v = P.qkv[:, 2 * P.Kd:].view(B, P.H, P.Dv)
-        if self._skip_update or one_launch:
-            pass                                  # one launch: done above; _skip_update: measurement only (time_update_kernel)
+        if self._skip_update:
+            pass                                  # measurement only (time_update_kernel): the step without K1w / K1d
         elif lazy and P.lazy:
             ops.gla_decode_window(q, k, v, P.gk.view(B, P.H, P.Dk), P.S, gate, P.gnw, P.og_p if packed else P.og,
                                   P.hk, P.hc, P.hv, self._t_idx, self._origin, P.window, P.eps_gate, og_packed=packed,

@@ -586,47 +586,6 @@ def gla_decode_window(q, k, v, gk, state, gate, norm_weight, og, hist_k, hist_c,
     return og
 
 
-def gla_decode_inproj_window(x_packed, w_in_packed, B, K, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_out, gk, state,
-                             norm_weight, og, hist_k, hist_c, hist_v, step, origin, sync, window: int, ln_eps: float = 1e-5,
-                             normalizer: float = 16.0, clamp_min: Optional[float] = None, eps: float = 1e-5, scale=None,
-                             og_packed: bool = True, w_stream: bool = False, n_pre: int = 0, pace: int = -1):
-    """gla_decode_inproj_packed + gla_decode_window in ONE launch (lina_gla_decode_inproj_window, see lina_gla.h): the K1w
-    workgroups stream the state while the in-projection runs beside them and hands q | k | v | g | gk over inside the launch.
-    ``qkv`` [B, 2 H Dk + H Dv], ``g_out`` [B, H Dv], ``gk`` fp32 [B, H Dk] are written and consumed; ``sync``: int32 [64],
-    zero before the first call.  Raises LinaError(LINA_ERR_UNSUPPORTED) for shapes the one-launch form is not built for."""
-    be = _backend._BACKEND
-    be.require(x_packed, w_in_packed, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, g_out, gk, state, norm_weight, og,
-               hist_k, hist_c, hist_v, step, origin, sync)
-    Bs, H, Dk, Dv = state.shape
-    Kd, W = wq.shape[0], wq.shape[-1]
-    Vd, R = wv.shape[0], w2.shape[1]
-    if Bs != B or Kd != H * Dk or Vd != H * Dv:
-        raise ValueError("state [B,H,Dk,Dv] does not match the projection widths")
-    if state.dtype != torch.float32 or not state.is_contiguous():
-        raise ValueError("state must be contiguous fp32 [B,H,Dk,Dv]")
-    for t, shp in ((hist_k, (window, B * H, Dk)), (hist_c, (window, B * H, Dk)), (hist_v, (window, B * H, Dv))):
-        if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shp:
-            raise ValueError(f"history buffers must be contiguous fp32 {shp}")
-    if step.dtype != torch.int64 or origin.dtype != torch.int64:
-        raise ValueError("step / origin must be int64 device tensors")
-    if sync.dtype != torch.int32 or sync.numel() < 64 or not sync.is_contiguous():
-        raise ValueError("sync must be a contiguous int32 tensor with 64 entries (zero before the first call)")
-    if tuple(qkv.shape) != (B, 2 * Kd + Vd) or tuple(g_out.shape) != (B, Vd) or tuple(gk.shape) != (B, Kd) \
-            or not (qkv.is_contiguous() and g_out.is_contiguous() and gk.is_contiguous()) or gk.dtype != torch.float32:
-        raise ValueError("qkv [B,2Kd+Vd], g_out [B,Vd] (model dtype) and gk [B,Kd] (fp32) must be contiguous")
-    if x_packed.numel() < packed_numel(B, K) or w_in_packed.numel() < packed_numel(2 * Kd + 2 * Vd + R, K):
-        raise ValueError("packed operand too small")
-    if og_packed and og.numel() < packed_numel(B, H * Dv):
-        raise ValueError("packed og buffer is too small")
-    _check(be.lib.lina_gla_decode_inproj_window(
-        _ptr(x_packed), _ptr(w_in_packed), _ptr(c1), _ptr(c2), _ptr(wq), _ptr(wk), _ptr(wv), _ptr(cq), _ptr(ck), _ptr(cv),
-        _ptr(w2), _ptr(b2), _ptr(qkv), _ptr(g_out), _ptr(gk), _ptr(state), _ptr(norm_weight), _ptr(og), _ptr(hist_k),
-        _ptr(hist_c), _ptr(hist_v), _ptr(step), _ptr(origin), _ptr(sync), int(window), B, K, H, Dk, Dv, W, R, float(ln_eps),
-        float(normalizer), float("nan") if clamp_min is None else float(clamp_min), float(eps),
-        float(Dk ** -0.5 if scale is None else scale), 1 if og_packed else 0, 1 if w_stream else 0, int(n_pre), int(pace),
-        _dt(x_packed), be.stream(x_packed)))
-
-
 def gla_decode_window_flush(state, hist_k, hist_c, hist_v, n_pending: int):
     """Apply the first ``n_pending`` steps of the current window to ``state`` (in place)."""
     be = _backend._BACKEND

@@ -26,7 +26,7 @@ from .kernels import (
     column_sum, _sum_vector, _embed_sum_launch, argmax_rows, greedy_pick_embed, sample_pick_embed, topk_sample_rows,
     gla_decode_prologue, swiglu, gla_decode_update, _kstep, packed_numel, pack_rows, unpack_rows,
     linear_skinny_packed, linear_skinny, gla_decode_inproj, gla_decode_inproj_packed, gla_decode_update_norm,
-    gla_decode_window, gla_decode_window_flush, gla_decode_inproj_window, cross_att_step1, cross_att_step2, cross_scores,
+    gla_decode_window, gla_decode_window_flush, cross_att_step1, cross_att_step2, cross_scores,
     cross_scores_softmax, softmax_weighted_rows_add, pe_softmax_weighted_rows_add, softmax_pe_rows, softmax_rows, weighted_rows_add, dwconv7_ln,
     istft_ola)
 from .autograd import (

@@ -61,7 +61,7 @@ const dim3& cur_tid();
 int cur_lane();
 void syncthreads();
 bool dma_late();
-void dma_defer(void* dst, const void* src, int bytes = 16);
+void dma_defer(void* dst, const void* src);
 void dma_flush_mine();
 // wave-collective exchange: every lane of the wave deposits `n` 32-bit words, then reads
 // the 64 x n table `out` (out[lane*n + i]).
@@ -134,12 +134,6 @@ static inline int shfl_down_i(int v, int d) {
     lina_emu::wave_exchange(&mine, 1, tab);
     const int src = lina_emu::cur_lane() + d;
     return src < 64 ? (int)tab[src] : v;
-}
-static inline float shfl_down_f(float v, int d) {
-    uint32_t mine = f2u(v), tab[64];
-    lina_emu::wave_exchange(&mine, 1, tab);
-    const int src = lina_emu::cur_lane() + d;
-    return src < 64 ? u2f(tab[src]) : v;
 }
 static inline float shfl_up(float v, int d) {
     uint32_t mine = f2u(v), tab[64];
@@ -239,12 +233,6 @@ static inline void dma16_to_lds_async(const void* base_uniform, unsigned lane_by
     if (lina_emu::dma_late()) lina_emu::dma_defer(dst, src);
     else memcpy(dst, src, 16);
 }
-static inline void dma4_to_lds_async(const void* base_uniform, unsigned lane_byte_off, void* lds_wave_base) {
-    unsigned char* dst = (unsigned char*)lds_wave_base + 4 * lina_emu::cur_lane();
-    const unsigned char* src = (const unsigned char*)base_uniform + lane_byte_off;
-    if (lina_emu::dma_late()) lina_emu::dma_defer(dst, src, 4);
-    else memcpy(dst, src, 4);
-}
 // the wave's DMA pieces have landed: on the emulator every lane copies its own 16 bytes when it runs, so this is a
 // wave-wide meeting point (all lanes of a wave call it together, as on the hardware)
 static inline void wait_vmem() {
@@ -281,14 +269,6 @@ static inline float dot2_bf16(uint32_t a, uint32_t b, float c) {
 static inline void st_agent8(float* p, float a, float b) { p[0] = a; p[1] = b; }
 static inline float2 ld_agent8(const float* p) { return make_float2(p[0], p[1]); }
 static inline void drain_stores() {}
-static inline void st_agent_u64(void* p, uint32_t lo, uint32_t hi) { uint32_t* q = (uint32_t*)p; q[0] = lo; q[1] = hi; }
-static inline uint2 ld_agent_u64(const void* p) { const uint32_t* q = (const uint32_t*)p; return make_uint2(q[0], q[1]); }
-static inline unsigned short ld_agent_u16(const unsigned short* p) { return *p; }
-static inline float ld_agent_f32(const float* p) { return *p; }
-static inline int ld_agent_i32(const int* p) { return *p; }
-static inline void st_agent_i32(int* p, int v) { *p = v; }
-static inline void poll_sleep() {}
-static inline long long wall_clock64() { static long long t = 0; return ++t; }
 static inline int ticket_agent(int* counter) { return (*counter)++; }
 
 static inline void lds_barrier() { lina_emu::syncthreads(); }

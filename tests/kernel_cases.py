@@ -1144,69 +1144,6 @@ def check_decode_window(dev, B, H, Dk, Dv, dtype, window=8, n_steps=19, resets=T
         assert_close(S_w, S_i, 1e-5, "K1w flushed state vs K1d state")
 
 
-def check_inproj_window(dev, B, H, K, window=8, n_steps=11, n_pre=0, og_packed=False, w_stream=False, origin0=3, pace=-1):
-    """lina_gla_decode_inproj_window (in-projection + K1w + K5 in one launch, hand-off inside the launch) over ``n_steps`` decode
-    steps -- a full window, its write-back and a partial one:
-      * its K1w half is BIT-identical to lina_gla_decode_window run on the q | k | v | g | gk the fused launch produced, from the
-        same state and history (outputs, written-back state, history entries);
-      * its in-projection half equals lina_gla_decode_inproj_packed (outputs and rolled conv caches) up to the summation order of
-        the LayerNorm row sums;
-      * the hand-off words are back at zero after every launch and the timeout flag stays clear."""
-    dtype = torch.bfloat16
-    Dk = Dv = 256
-    Kd, Vd, R, W = H * Dk, H * Dv, 16, 4
-    g = torch.Generator().manual_seed(31)
-    w_in = (torch.randn(2 * Kd + 2 * Vd + R, K, generator=g) / K ** 0.5).to(dtype).to(dev)
-    c1 = w_in.float().sum(1).contiguous()
-    c2 = (0.3 * torch.randn(w_in.shape[0], generator=g)).to(dev)
-    mk = lambda *sh: (torch.randn(*sh, generator=g) * 0.5).to(dtype).to(dev)
-    wq, wk, wv, w2, b2 = mk(Kd, W), mk(Kd, W), mk(Vd, W), mk(Kd, R) * 4, mk(Kd)
-    w_in_p = ops.pack_rows(w_in)
-    nw = (1 + 0.1 * torch.randn(Dv, generator=g)).to(dtype).to(dev)
-    caches_a = [mk(B, Kd, W), mk(B, Kd, W), mk(B, Vd, W)]
-    caches_b = [c.clone() for c in caches_a]
-    S_b = (torch.randn(B, H, Dk, Dv, generator=g) * 0.5).to(dev)
-    hist_b = [torch.full((window, B * H, D), float("nan"), device=dev) for D in (Dk, Dk, Dv)]       # k, c, v
-    step = torch.full((1,), origin0, dtype=torch.int64, device=dev)
-    origin = torch.full((1,), origin0, dtype=torch.int64, device=dev)
-    sync = torch.zeros(64, dtype=torch.int32, device=dev)
-    n_og = ops.packed_numel(B, H * Dv) if og_packed else B * H * Dv
-    for t in range(n_steps):
-        x = (torch.randn(B, K, generator=g) * 1.2 + 0.3).to(dtype).to(dev)
-        x_p = ops.pack_rows(x)
-        # reference in-projection (its own launch)
-        qkv_a = torch.empty(B, 2 * Kd + Vd, dtype=dtype, device=dev)
-        g_a = torch.empty(B, Vd, dtype=dtype, device=dev)
-        gk_a = torch.empty(B, Kd, dtype=torch.float32, device=dev)
-        ops.gla_decode_inproj_packed(x_p, w_in_p, B, K, c1, c2, wq, wk, wv, *caches_a, w2, b2, qkv_a, g_a, gk_a, w_stream=w_stream)
-        # the one-launch form
-        S_c, hist_c = S_b.clone(), [h.clone() for h in hist_b]
-        qkv_b = torch.full_like(qkv_a, float("nan"))
-        g_b = torch.full_like(g_a, float("nan"))
-        gk_b = torch.full_like(gk_a, float("nan"))
-        og_b = torch.full((n_og,), float("nan"), dtype=dtype, device=dev)
-        ops.gla_decode_inproj_window(x_p, w_in_p, B, K, c1, c2, wq, wk, wv, *caches_b, w2, b2, qkv_b, g_b, gk_b, S_b, nw, og_b,
-                                     hist_b[0], hist_b[1], hist_b[2], step, origin, sync, window, og_packed=og_packed,
-                                     w_stream=w_stream, n_pre=n_pre, pace=pace)
-        assert int(sync.abs().sum()) == 0, f"hand-off words after step {t}: {sync.tolist()}"
-        for name, a, b in (("qkv", qkv_a, qkv_b), ("g", g_a, g_b), ("gk", gk_a, gk_b)):
-            assert_close(b, a.double().cpu(), 1.6e-2, f"one-launch in-projection {name} (step {t})")
-        for nm, a, b in zip("qkv", caches_a, caches_b):
-            assert_close(b, a.double().cpu(), 1.6e-2, f"one-launch in-projection conv cache {nm} (step {t})")
-            a.copy_(b)                       # (keep the two in-projections on the same history: the caches hold rounded values)
-        # K1w on the fused launch's own q | k | v | g | gk, from the same state and history: bit-identical
-        og_c = torch.full((n_og,), float("nan"), dtype=dtype, device=dev)
-        ops.gla_decode_window(qkv_b[:, :Kd].view(B, H, Dk), qkv_b[:, Kd:2 * Kd].view(B, H, Dk), qkv_b[:, 2 * Kd:].view(B, H, Dv),
-                              gk_b.view(B, H, Dk), S_c, g_b.view(B, H, Dv), nw, og_c, hist_c[0], hist_c[1], hist_c[2], step,
-                              origin, window, 1e-5, og_packed=og_packed)
-        assert torch.equal(og_b.view(torch.int16), og_c.view(torch.int16)), f"one-launch K1w output differs (step {t})"
-        assert torch.equal(S_b, S_c), f"one-launch K1w state differs (step {t})"
-        j = (int(step.item()) - origin0) % window
-        for nm, hb, hc_ in zip(("k", "c", "v"), hist_b, hist_c):
-            assert torch.equal(hb[:j + 1], hc_[:j + 1]), f"one-launch K1w history {nm} differs (step {t})"
-        step += 1
-
-
 def check_cross_att(dev, B, Tn, d, dtype):
     """lina_cross_att_step1/2 vs the eager attention of reference crossatt.py:13-19,114,143,149 in fp64."""
     g = torch.Generator().manual_seed(14)

@@ -188,14 +188,6 @@ def test_decode_window(emu, Dk, Dv, dtype, window, n):
     check_decode_window(DEV, B=2, H=2, Dk=Dk, Dv=Dv, dtype=dtype, window=window, n_steps=n)
 
 
-@pytest.mark.parametrize("B,H,K,window,n,n_pre,packed", [(2, 2, 128, 8, 10, 24, False), (3, 1, 64, 4, 6, 16, True),
-                                                        (2, 2, 128, 8, 9, 20, True)])
-def test_inproj_window_one_launch(emu, B, H, K, window, n, n_pre, packed):
-    """In-projection + K1w + K5 in one launch (the emulator runs the producing workgroups first)."""
-    from kernel_cases import check_inproj_window
-    check_inproj_window(DEV, B=B, H=H, K=K, window=window, n_steps=n, n_pre=n_pre, og_packed=packed)
-
-
 @pytest.mark.parametrize("Q,L,d,dtype", [(1, 300, 64, torch.float32), (3, 70, 32, torch.bfloat16)])
 def test_greedy_pick_embed(emu, Q, L, d, dtype):
     from kernel_cases import check_greedy_pick_embed

@@ -317,16 +317,6 @@ def test_decode_window(hip, B, H, Dk, Dv, dtype, window, n):
     check_decode_window(DEV, B=B, H=H, Dk=Dk, Dv=Dv, dtype=dtype, window=window, n_steps=n)
 
 
-@pytest.mark.parametrize("B,H,K,window,n,n_pre,packed,stream", [(64, 4, 1024, 8, 19, 24, True, True), (64, 4, 1024, 8, 10, 16, False, False),
-                                                               (5, 2, 256, 4, 9, 20, True, False), (64, 4, 1024, 2, 5, 24, True, True)])
-def test_inproj_window_one_launch(hip, B, H, K, window, n, n_pre, packed, stream):
-    """In-projection + K1w + K5 in ONE launch with the hand-off inside it (B H K1w workgroups wait for the tiles of the
-    in-projection workgroups running beside them): K1w half bit-identical to lina_gla_decode_window on the same operands,
-    in-projection half equal to lina_gla_decode_inproj_packed, hand-off words re-armed after every launch."""
-    from kernel_cases import check_inproj_window
-    check_inproj_window(DEV, B=B, H=H, K=K, window=window, n_steps=n, n_pre=n_pre, og_packed=packed, w_stream=stream)
-
-
 @pytest.mark.parametrize("B,Q,L,d,dtype", [(64, 1, 4099, 1024, torch.bfloat16), (7, 4, 1027, 256, torch.float32)])
 def test_greedy_pick_embed(hip, B, Q, L, d, dtype):
     from kernel_cases import check_greedy_pick_embed
