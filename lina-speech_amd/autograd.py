@@ -9,6 +9,7 @@ from typing import Optional
 
 import torch
 import torch.nn.functional as F
+from torch.utils.weak import WeakIdKeyDictionary
 
 from . import _lib
 from . import backend as _backend
@@ -291,7 +292,8 @@ def _gate_rows_view(g, D):
         v = g.view(-1, H, D)
     except RuntimeError:
         return None
-    return v if v.stride(0) % 4 == 0 else None
+    # the kernels read / write the gate (and its gradient) with 4-element vector accesses: strides AND the base must allow it
+    return v if (v.stride(0) % 4 == 0 and v.data_ptr() % (4 * v.element_size()) == 0) else None
 
 
 def rmsnorm_swish_gate(x, g=None, weight=None, eps: float = 1e-5, n_partial: int = 1, out_dtype=None, out=None,
@@ -325,7 +327,7 @@ def rmsnorm_swish_gate(x, g=None, weight=None, eps: float = 1e-5, n_partial: int
     if g is not None:
         gs = g if g.dtype == odt else g.to(odt)
         if (gs.dim() == 3 and gs.stride(-1) == 1 and tuple(gs.shape) == tuple(shape[-3:]) and rows == gs.shape[0] * gs.shape[1]
-                and gs.stride(0) % 4 == 0 and gs.stride(1) % 4 == 0):
+                and gs.stride(0) % 4 == 0 and gs.stride(1) % 4 == 0 and gs.data_ptr() % (4 * gs.element_size()) == 0):
             rows_inner, g_outer, g_inner = gs.shape[1], gs.stride(0), gs.stride(1)
         else:
             gs = gs.contiguous()
@@ -451,15 +453,34 @@ def swiglu_gate(u):
     return _SwiGLUFunction.apply(u2, hidden).view(*u.shape[:-1], hidden)
 
 
+_MM_OUT_DTYPE = None
+
+
+def _mm_has_out_dtype(dev) -> bool:
+    """torch.mm / torch.bmm with ``out_dtype=`` (bf16 operands, fp32 result) exist only in recent torch: probed once, on the
+    device that asks, instead of failing with a TypeError in the middle of a backward pass."""
+    global _MM_OUT_DTYPE
+    if _MM_OUT_DTYPE is None:
+        try:
+            a = torch.zeros(8, 8, dtype=torch.bfloat16, device=dev)
+            _MM_OUT_DTYPE = torch.mm(a, a, out_dtype=torch.float32).dtype == torch.float32
+        except (TypeError, RuntimeError):
+            _MM_OUT_DTYPE = False
+    return _MM_OUT_DTYPE
+
+
 def linear_weight_grad(dy2, x2, split=None):
     """dW [out, in] (fp32) = dy2^T x2 for dy2 [rows, out], x2 [rows, in] of one GEMM dtype: token-split batched GEMM with
     fp32 partial products (see above); ``split`` None = by shape."""
     rows, n_out = dy2.shape
     n_in = x2.shape[1]
     S = _linear_split(rows, n_out, n_in) if split is None else split
-    f32 = {} if (dy2.dtype == torch.float32 or not dy2.is_cuda) else {"out_dtype": torch.float32}
-    if not dy2.is_cuda and dy2.dtype != torch.float32:
-        dy2, x2 = dy2.float(), x2.float()          # (CPU: no fp32-output bf16 GEMM; same sum, fp32 operands)
+    f32 = {}
+    if dy2.dtype != torch.float32:
+        if dy2.is_cuda and _mm_has_out_dtype(dy2.device):
+            f32 = {"out_dtype": torch.float32}
+        else:
+            dy2, x2 = dy2.float(), x2.float()      # (CPU / older torch: no fp32-output bf16 GEMM; same sum, fp32 operands)
     if S == 1:
         return torch.mm(dy2.t(), x2, **f32)
     if n_in % 8:                                   # rows of x2 not 16-byte aligned: the transposed problem is the faster one
@@ -530,18 +551,7 @@ class _SwiGLUMLPFunction(torch.autograd.Function):
         dev = x.device
         x2 = x.reshape(-1, d_in).to(cd).contiguous()
         with torch.autocast(dev.type, enabled=False):
-            Wi = torch.empty(2, Hp, d_in, dtype=cd, device=dev)
-            Wi[:, H:].zero_()
-            Wi[:, :H].copy_(w_in.detach().view(2, H, d_in))
-            bi = torch.zeros(2, Hp, dtype=cd, device=dev)
-            if b_in is not None:
-                bi[:, :H].copy_(b_in.detach().view(2, H))
-            Wo = torch.empty(d_out, Hp, dtype=cd, device=dev)
-            Wo[:, H:].zero_()
-            Wo[:, :H].copy_(w_out.detach())
-            if b_out is not None:
-                bi[:, H] = _mlp_one(cd, dev)
-                Wo[:, H].copy_(b_out.detach())
+            Wi, bi, Wo = _mlp_padded_weights(w_in, b_in, w_out, b_out, cd, H, Hp)
             u = torch.addmm(bi.view(-1), x2, Wi.view(2 * Hp, d_in).t())
             h = torch.empty(x2.shape[0], Hp, dtype=cd, device=dev)
             _check(be.lib.lina_swiglu(_ptr(u), _ptr(h), x2.shape[0], Hp, u.stride(0), h.stride(0), _dt(u), be.stream(u)))
@@ -573,6 +583,36 @@ class _SwiGLUMLPFunction(torch.autograd.Function):
             dw_out = dWo[:, :H].to(wodt)
             db_out = None if bodt is None else dWo[:, H].to(bodt)
         return dx, dw_in, db_in, dw_out, db_out
+
+
+_MLP_PACK = WeakIdKeyDictionary()            # up-projection weight (the parameter OBJECT) -> (key, Wi, bi, Wo)
+
+
+def _mlp_padded_weights(w_in, b_in, w_out, b_out, cd, H, Hp):
+    """The zero-padded operands of ``_SwiGLUMLPFunction`` (the cast of the master weights that happens every step anyway, into
+    the padded layout).  Kept per parameter VERSION: the weights change only at the optimizer step, so a second forward on the
+    same weights -- the recompute of a checkpointed block, gradient accumulation -- reuses the pack instead of rebuilding three
+    weight-sized tensors."""
+    ver = lambda t: None if t is None else (t.data_ptr(), t._version)
+    key = (cd, H, Hp, ver(w_in), ver(b_in), ver(w_out), ver(b_out))
+    hit = _MLP_PACK.get(w_in)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2], hit[3]
+    dev, d_in, d_out = w_in.device, w_in.shape[1], w_out.shape[0]
+    Wi = torch.empty(2, Hp, d_in, dtype=cd, device=dev)
+    Wi[:, H:].zero_()
+    Wi[:, :H].copy_(w_in.detach().view(2, H, d_in))
+    bi = torch.zeros(2, Hp, dtype=cd, device=dev)
+    if b_in is not None:
+        bi[:, :H].copy_(b_in.detach().view(2, H))
+    Wo = torch.empty(d_out, Hp, dtype=cd, device=dev)
+    Wo[:, H:].zero_()
+    Wo[:, :H].copy_(w_out.detach())
+    if b_out is not None:
+        bi[:, H] = _mlp_one(cd, dev)
+        Wo[:, H].copy_(b_out.detach())
+    _MLP_PACK[w_in] = (key, Wi, bi, Wo)
+    return Wi, bi, Wo
 
 
 _MLP_ONE = {}

@@ -587,6 +587,21 @@ def check_swiglu_gate(dev, N, H, dtype):
     assert_close(ud.grad, u64.grad, 1.5e-2 if lo else 2e-6, "K11b du")
 
 
+def check_swiglu_unit_column(dev, dtype):
+    """The padded channel mixer (`_SwiGLUMLPFunction`) carries the down-projection's bias in column H of its weight and relies on
+    the gate producing EXACTLY 1 there from the bias pair (32, 1/32): silu(32) * (1/32) == 1 in the gate kernel's arithmetic.  Any
+    change to the device silu (a faster exp / reciprocal) that breaks this would silently bias the output and its gradient."""
+    from lina_speech_amd.autograd import _mlp_one
+    one = _mlp_one(dtype, dev)
+    for width in (8, 7):                                     # vector and scalar kernels
+        u = torch.zeros(5, 2 * width, dtype=dtype, device=dev)
+        u[:, 3] = one[0]
+        u[:, width + 3] = one[1]
+        h = ops.swiglu_gate(u)
+        assert torch.equal(h[:, 3].float().cpu(), torch.ones(5)), (dtype, width, h[:, 3].tolist())
+        assert float(h.float().abs().sum()) == 5.0           # silu(0) * 0 == 0 everywhere else
+
+
 def check_gate_logsigmoid(dev, n, dtype, clamp):
     """K12: logsigmoid(x) / normalizer (+ clamp) and its gradient against fp64 autograd, over the range the fast
     log1p / exp forms switch in."""
@@ -676,6 +691,19 @@ def check_swiglu_mlp(dev, B, T, d, H, dtype, bias=True):
         if mine is not None:
             assert mine.grad.shape == ref.grad.shape and mine.grad.dtype == dtype, what
             assert_close(mine.grad, ref.grad, tol, "MLP " + what)
+    # the padded weights are kept per parameter version: a second forward on the same weights reuses them (same result), an
+    # in-place update of ANY of the four parameters invalidates them
+    from lina_speech_amd.autograd import _MLP_PACK
+    pack0 = _MLP_PACK[m[1]][1]
+    y2 = ops.swiglu_mlp(*m)
+    assert _MLP_PACK[m[1]][1] is pack0 and torch.equal(y2, y)
+    with torch.no_grad():
+        m[3].mul_(2.0)
+        if bias:
+            m[4].mul_(2.0)
+    y3 = ops.swiglu_mlp(*m)
+    assert _MLP_PACK[m[1]][1] is not pack0
+    assert_close(y3, 2.0 * y64.detach(), tol, "MLP y after an in-place weight update")
 
 
 def check_block_chain(dev, dtype, B=2, T=70, d=64):

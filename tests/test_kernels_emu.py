@@ -213,6 +213,12 @@ def test_swiglu_gate(emu, N, H, dtype):
     check_swiglu_gate(DEV, N, H, dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_swiglu_gate_unit_column_is_exactly_one(emu, dtype):
+    from kernel_cases import check_swiglu_unit_column
+    check_swiglu_unit_column(DEV, dtype)
+
+
 @pytest.mark.parametrize("nw", [8, 16])
 def test_projections_wider_split_k(emu, monkeypatch, nw):
     """The packed projection kernels with 8 / 16 waves per workgroup (K = 1024: 32 k-steps): same products, another

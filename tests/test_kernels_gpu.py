@@ -348,6 +348,12 @@ def test_swiglu_gate(hip, N, H, dtype):
     check_swiglu_gate(DEV, N, H, dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_swiglu_gate_unit_column_is_exactly_one(hip, dtype):
+    from kernel_cases import check_swiglu_unit_column
+    check_swiglu_unit_column(DEV, dtype)
+
+
 # ----------------------------------------------------------------------------- fragment-major (packed) projections
 @pytest.mark.parametrize("M,N,K,dtype,ln,bias,resid,sw", [(64, 1024, 1024, torch.bfloat16, False, False, True, 0),
                                                           (64, 1376, 1024, torch.bfloat16, True, True, False, 1365),
