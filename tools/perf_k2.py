@@ -18,6 +18,10 @@ gk = gk.view(B, T, H, Dk).transpose(1, 2)
 HT = os.environ.get("K2_HT", "1") != "0"                   # also return the final state (67 MB more at B = 64)
 NSEG = os.environ.get("K2_NSEG") or None
 run = lambda: ops.chunk_gla(q, k, v, gk, output_final_state=HT, nseg=None if NSEG is None else int(NSEG))
+BWD = os.environ.get("K2_BWD", "0") != "0"                 # K2b instead: the three sweeps of lina_gla_chunk_bwd_full (no segments at B*H >= 256)
+if BWD:
+    do = mk(Dv)
+    run = lambda: ops.gla_chunk_bwd(q, k, v, gk, do, Dk ** -0.5)
 run()
 torch.cuda.synchronize()
 if reps >= 100:                                            # settle the clocks first
@@ -33,8 +37,8 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 dt = e0.elapsed_time(e1) * 1e-3 / reps
-nbytes = B * H * T * 2 * (3 * Dk + 2 * Dv)
-print(f"K2[final_state={HT}] B={B} T={T}: {dt*1e3:.3f} ms  {nbytes/dt/1e9:.1f} GB/s ({nbytes/dt/8e12*100:.1f}% of 8 TB/s)  "
+nbytes = B * H * T * 2 * ((5 * Dk + 4 * Dv) if BWD else (3 * Dk + 2 * Dv))
+print(f"{'K2b' if BWD else 'K2'}[final_state={HT}] B={B} T={T}: {dt*1e3:.3f} ms  {nbytes/dt/1e9:.1f} GB/s ({nbytes/dt/8e12*100:.1f}% of 8 TB/s)  "
       f"{dt/(T/32)*2.4e9:.0f} clk/chunk @2.4GHz")
 if os.environ.get("K2_PROF"):
     import ctypes, numpy as np
