@@ -36,6 +36,35 @@ def test_chunk_equals_recurrent_equals_fp64(resets):
     assert (o32.double() - o64).abs().max() / o64.abs().max() < 1e-5
 
 
+def test_recurrence_equals_the_published_parallel_form_and_a_closed_form():
+    """Two checks of the oracle's GLA recurrence that share NO code with it (the arithmetic itself lives in the absent `fla`
+    package, so this is what can be pinned here beyond the reference's call sites):
+    (a) the parallel ("attention") form of the published definition -- Yang et al., Gated Linear Attention Transformers with
+        Hardware-Efficient Training: o_t = sum_{s<=t} (q_t (.) prod_{s<r<=t} a_r) . k_s  v_s  + q_t (.) prod_{r<=t} a_r . S_0,
+        a_r = exp(g_r) -- written out with explicit O(T^2) numpy float64 loops;
+    (b) a closed form: all-ones q, k, v, constant log-gate g, S_0 = 0  ->  S_t[i, j] = (1 - e^{g (t + 1)}) / (1 - e^g)."""
+    q, k, v, gk, h0 = (x.double() for x in _inputs(B=1, H=2, T=13, Dk=8, Dv=5, resets=True, seed=3))
+    o, sT = O.naive_recurrent_gla(q, k, v, gk, h0, True, compute_dtype=torch.float64)      # (o comes back in q's dtype)
+    qn, kn, vn, gn, hn = (x.double().numpy() for x in (q, k, v, gk, h0))
+    scale = 8 ** -0.5
+    for h in range(2):
+        for t in range(13):
+            acc = np.zeros(5)
+            for s_ in range(t + 1):
+                decay = np.exp(gn[0, h, s_ + 1:t + 1].sum(0))            # prod over s < r <= t, per key channel
+                acc += (qn[0, h, t] * decay * kn[0, h, s_]).sum() * vn[0, h, s_]
+            acc += (qn[0, h, t] * np.exp(gn[0, h, :t + 1].sum(0))) @ hn[0, h]
+            assert np.abs(scale * acc - o[0, h, t].numpy()).max() < 1e-12 * max(1.0, np.abs(acc).max())
+    T, g0 = 40, -0.07
+    one = lambda *sh: torch.ones(*sh, dtype=torch.float64)
+    o, sT = O.naive_recurrent_gla(one(1, 1, T, 4), one(1, 1, T, 4), one(1, 1, T, 3), g0 * one(1, 1, T, 4), None, True,
+                                  scale=1.0, compute_dtype=torch.float64)
+    geo = lambda t: (1 - np.exp(g0 * (t + 1))) / (1 - np.exp(g0))
+    assert abs(float(sT[0, 0, 2, 1]) - geo(T - 1)) < 1e-12 and float((sT - sT[0, 0, 0, 0]).abs().max()) == 0.0
+    for t in (0, 7, T - 1):
+        assert abs(float(o[0, 0, t, 0]) - 4 * geo(t)) < 1e-11
+
+
 def test_prefill_then_step_equals_longer_prefill():
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 11, 24, generator=g)
