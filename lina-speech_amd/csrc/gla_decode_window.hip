@@ -22,8 +22,6 @@
 #include <lina_dev.h>
 #include "lina_common.h"
 #include "skinny_frag.h"
-#include <stdlib.h>
-#include <type_traits>
 
 #ifndef LINA_K1W_HIST_NT
 #define LINA_K1W_HIST_NT 0     // experiment: window-history loads / stores with the non-temporal hint
@@ -304,200 +302,12 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
     }
 }
 
-
-// ---- the same step at Dk = Dv = 256 with EIGHT waves (512 threads, one workgroup per head as above).  A thread owns 32 state
-// vectors; NPRE of them are requested at entry (all 32 fit: eight waves may use 256 registers each), the rest into the registers
-// of the first ones consumed.  The window's history comes by 4-byte global->LDS copies (no registers), wave 0
-// requests the output gate and the norm weights at entry.  Wave w accumulates the two row-group partials (2w, 2w + 1) of the
-// sixteen-wave kernel in the same order, the partials meet in the same s_red layout and wave 0 finishes the head with the same
-// arithmetic: outputs, written-back state and history are BIT-identical to gla_decode_window_kernel<256, 4, 1>.
-constexpr int kW8 = 8;            // window positions this form is built for
-
-template <int NPRE, typename TIO>
-__global__ __launch_bounds__(512) void gla_decode_window8w_kernel(
-    const TIO* __restrict__ q, const TIO* __restrict__ k, const TIO* __restrict__ v, const float* __restrict__ gk, float* S,
-    float* hist_k, float* hist_c, float* hist_v, const int64_t* step, const int64_t* origin, int window, int H, int64_t q_sb,
-    int64_t q_sh, int64_t k_sb, int64_t k_sh, int64_t v_sb, int64_t v_sh, int64_t g_sb, int64_t g_sh, float scale,
-    const TIO* __restrict__ gate, int64_t gate_sb, int64_t gate_sh, const TIO* __restrict__ nw, float eps,
-    TIO* __restrict__ og, int og_packed) {
-    constexpr int DK = 256, DV = 256, NTOT = 32, NLATE = NTOT - NPRE;
-    static_assert(NPRE >= 16 && NPRE <= 32 && NPRE % 2 == 0 && NLATE <= NPRE, "NPRE");
-    __shared__ float s_q[DK], s_e[DK], s_a[kW8][4];
-    __shared__ float s_w[kW8][DK];                                       // e^{c_j - c_s} k_s per row
-    __shared__ __attribute__((aligned(16))) float s_v[kW8][DV];
-    __shared__ float s_h1[kW8][DK], s_h2[kW8][DK];                       // the window's c_s, k_s as stored
-    __shared__ __attribute__((aligned(16))) float s_red[16 * DV];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = wave_uniform(tid >> 6);
-    const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const int64_t BH = gridDim.x;
-    const int j = (int)(step[0] - origin[0]) & (window - 1);             // window position: workgroup-uniform
-    const bool write_back = j == window - 1;
-    const bool row_thr = w < 4;                    // waves 0..3: lane = row (c_s, k_s); waves 4..7: lane = v column
-    const int rc = tid & 255;                      // this thread's row / column
-    const int64_t hoff = (int64_t)bh * DK + rc;
-
-    // ---- small operands first (loads return in order), then the history copies, then the state
-    float gj = 0.f, kj = 0.f, qj = 0.f, vj = 0.f;
-    typedef typename raw4<TIO>::type raw_t;
-    raw_t gate_raw = raw_t(), nw_raw = raw_t();
-    if (row_thr) {
-        gj = gk[b * g_sb + h * g_sh + rc];
-        kj = ld(k + b * k_sb + h * k_sh + rc);
-        qj = ld(q + b * q_sb + h * q_sh + rc) * scale;
-    } else {
-        vj = ld(v + b * v_sb + h * v_sh + rc);
-    }
-    if (w == 0) {
-        gate_raw = ld4_raw(gate + b * gate_sb + h * gate_sh + 4 * lane);
-        nw_raw = ld4_raw(nw + 4 * lane);
-    }
-    {
-        const unsigned lane_b = 4u * (unsigned)lane;
-        if (row_thr) {
-#pragma unroll
-            for (int s = 0; s < kW8; ++s)
-                if (s < j) {                                             // workgroup-uniform
-                    dma4_to_lds_async(hist_c + ((int64_t)s * BH + bh) * DK + 64 * w, lane_b, &s_h1[s][64 * w]);
-                    dma4_to_lds_async(hist_k + ((int64_t)s * BH + bh) * DK + 64 * w, lane_b, &s_h2[s][64 * w]);
-                }
-        } else {
-#pragma unroll
-            for (int s = 0; s < kW8; ++s)
-                if (s < j) dma4_to_lds_async(hist_v + ((int64_t)s * BH + bh) * DV + 64 * (w - 4), lane_b, &s_v[s][64 * (w - 4)]);
-        }
-    }
-    // state: wave w owns the row groups (rb = w / 2, rg in {2 (w % 2), 2 (w % 2) + 1}) of the sixteen-wave kernel, i.e. rows
-    // rb 64 + rg + 4 i; vector n = 2 i + (rg & 1); lane = 4 columns.  Addresses = wave-uniform base + compile-time row offset + one
-    // 32-bit lane offset (no per-load address registers).
-    const int row0 = (w >> 1) * 64 + 2 * (w & 1);
-    float* const tile_w = S + ((int64_t)bh * DK + row0) * DV;
-    const unsigned lane4 = 4u * (unsigned)lane;
-    auto rel_of = [](int n) { return (n & 1) + 4 * (n >> 1); };
-    auto row_of = [&](int n) { return row0 + rel_of(n); };
-    float4 St[NPRE];
-#pragma unroll
-    for (int n = 0; n < NPRE; ++n) St[n] = LINA_K1W_STATE_LOAD((tile_w + rel_of(n) * DV) + lane4);
-
-    // ---- per-row gate bookkeeping and the window's v rows (the operands and the history have landed; the state is in flight)
-    wait_vmem_but<NPRE>();
-    if (row_thr) {
-        float cprev = 0.0f;
-#pragma unroll
-        for (int s = 0; s < kW8; ++s) cprev = (s == j - 1) ? s_h1[s][rc] : cprev;
-        const float cj = cprev + gj;
-        st_hist(&hist_c[(int64_t)j * BH * DK + hoff], cj);
-        st_hist(&hist_k[(int64_t)j * BH * DK + hoff], kj);
-        s_q[rc] = qj;
-        s_e[rc] = __expf(cj);
-#pragma unroll
-        for (int s = 0; s < kW8; ++s) {
-            if (s <= j) {                                                // workgroup-uniform
-                const float ws = s == j ? kj : __expf(cj - s_h1[s][rc]) * s_h2[s][rc];
-                s_w[s][rc] = ws;
-                float a = qj * ws;                                       // <q (.) e^{c_j - c_s}, k_s> over this wave's 64 rows
-                a += shfl_xor(a, 1); a += shfl_xor(a, 2); a += shfl_xor(a, 4);
-                a += shfl_xor(a, 8); a += shfl_xor(a, 16); a += shfl_xor(a, 32);
-                if (lane == 0) s_a[s][w] = a;
-            }
-        }
-    } else {
-        s_v[j][rc] = vj;
-        st_hist(&hist_v[((int64_t)j * BH + bh) * DV + rc], vj);
-    }
-    lds_barrier();                                 // (leaves the state loads in flight)
-
-    // ---- the state pass: vectors n = 0 .. 31 in order (the order of the sixteen-wave kernel's i loop per partial)
-    float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    auto consume = [&](float4& s4, int n) {        // one state vector: (write-back: update + store,) accumulate
-        const int r = row_of(n);
-        float4& ac = acc[n & 1];
-        if (write_back) {
-            const float d = s_e[r];
-            s4.x *= d; s4.y *= d; s4.z *= d; s4.w *= d;
-#pragma unroll 1
-            for (int s = 0; s <= j; ++s) {        // (not unrolled: eight v vectors at once do not fit beside the state)
-                const float4 vv = *reinterpret_cast<const float4*>(&s_v[s][4 * lane]);
-                const float ws = s_w[s][r];
-                s4.x = fmaf(ws, vv.x, s4.x); s4.y = fmaf(ws, vv.y, s4.y); s4.z = fmaf(ws, vv.z, s4.z); s4.w = fmaf(ws, vv.w, s4.w);
-            }
-            int l4 = (int)lane4;
-            opaque(l4);                           // (address formed here, not hoisted into -- and spilled from -- 64 registers)
-            st_nt4((tile_w + rel_of(n) * DV) + (unsigned)l4, s4);
-            const float qq = s_q[r];
-            ac.x = fmaf(qq, s4.x, ac.x); ac.y = fmaf(qq, s4.y, ac.y); ac.z = fmaf(qq, s4.z, ac.z); ac.w = fmaf(qq, s4.w, ac.w);
-        } else {
-            const float qe = s_q[r] * s_e[r];
-            ac.x = fmaf(qe, s4.x, ac.x); ac.y = fmaf(qe, s4.y, ac.y); ac.z = fmaf(qe, s4.z, ac.z); ac.w = fmaf(qe, s4.w, ac.w);
-        }
-    };
-#pragma unroll
-    for (int n = 0; n < NLATE; ++n) consume(St[n], n);
-#pragma unroll
-    for (int n = 0; n < NLATE; ++n) {              // the rest, into the freed registers
-        int l4 = (int)lane4;
-        opaque(l4);
-        St[n] = LINA_K1W_STATE_LOAD((tile_w + rel_of(NPRE + n) * DV) + (unsigned)l4);
-    }
-#pragma unroll
-    for (int n = NLATE; n < NPRE; ++n) consume(St[n], n);
-#pragma unroll
-    for (int n = 0; n < NLATE; ++n) consume(St[n], NPRE + n);
-    *reinterpret_cast<float4*>(&s_red[(2 * w) * DV + 4 * lane]) = acc[0];
-    *reinterpret_cast<float4*>(&s_red[(2 * w + 1) * DV + 4 * lane]) = acc[1];
-    __syncthreads();
-    if (tid < 64) {
-        // ---- wave 0 finishes the head: sum of the 16 row-group partials (+ the pending window terms), then K5
-        float4 r = *reinterpret_cast<const float4*>(&s_red[4 * tid]);
-#pragma unroll
-        for (int jj = 1; jj < 16; ++jj) {
-            const float4 t = *reinterpret_cast<const float4*>(&s_red[jj * DV + 4 * tid]);
-            r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
-        }
-        if (!write_back)
-            for (int s = 0; s <= j; ++s) {
-                float a = s_a[s][0];
-#pragma unroll
-                for (int g2 = 1; g2 < 4; ++g2) a += s_a[s][g2];
-                const float4 vv = *reinterpret_cast<const float4*>(&s_v[s][4 * tid]);
-                r.x = fmaf(a, vv.x, r.x); r.y = fmaf(a, vv.y, r.y); r.z = fmaf(a, vv.z, r.z); r.w = fmaf(a, vv.w, r.w);
-            }
-        float ss = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
-        ss += shfl_xor(ss, 1); ss += shfl_xor(ss, 2); ss += shfl_xor(ss, 4);
-        ss += shfl_xor(ss, 8); ss += shfl_xor(ss, 16); ss += shfl_xor(ss, 32);
-        const float rs = rsqrtf(ss / (float)DV + eps);
-        r.x *= rs; r.y *= rs; r.z *= rs; r.w *= rs;
-        const float4 ww = cvt4(nw_raw), gg = cvt4(gate_raw);
-        r.x *= ww.x; r.y *= ww.y; r.z *= ww.z; r.w *= ww.w;
-        r.x *= gg.x * sigmoidf(gg.x); r.y *= gg.y * sigmoidf(gg.y);
-        r.z *= gg.z * sigmoidf(gg.z); r.w *= gg.w * sigmoidf(gg.w);
-        if (og_packed) st4(og + packed_off<TIO>(b, h * DV + 4 * tid, H * DV), r);
-        else st4(og + (int64_t)bh * DV + 4 * tid, r);
-    }
-}
-
 template <typename TIO, typename TG>
 static int launch_window(const void* q, const void* k, const void* v, const void* gk, float* S, float* hk, float* hc,
                          float* hv, const int64_t* step, const int64_t* origin, int window, int flush_n, int B, int H,
                          int Dk, int Dv, const int64_t* st, float scale, lina_stream_t stream, const void* gate,
                          int64_t gate_sb, int64_t gate_sh, const void* nw, float eps, void* og, int og_packed = 0,
                          float* o_x = nullptr, int* counters = nullptr) {
-    if constexpr (std::is_same<TG, float>::value) {
-        const char* w8 = getenv("LINA_K1W_WAVES");           // A/B knob (read per call): "8" = the eight-wave form where it exists
-        if (flush_n < 0 && Dk == 256 && Dv == 256 && window <= kW8 && w8 && atoi(w8) == 8) {
-            const char* np = getenv("LINA_K1W_NPRE");
-            const int n_pre = np ? atoi(np) : 32;
-#define LINA_WIN8(NPREE)                                                                                              \
-    LINA_LAUNCH((gla_decode_window8w_kernel<NPREE, TIO>), dim3((unsigned)(B * H)), dim3(512), 0, stream, (const TIO*)q, \
-                (const TIO*)k, (const TIO*)v, (const float*)gk, S, hk, hc, hv, step, origin, window, H, st[0], st[1],  \
-                st[2], st[3], st[4], st[5], st[6], st[7], scale, (const TIO*)gate, gate_sb, gate_sh, (const TIO*)nw,   \
-                eps, (TIO*)og, og_packed)
-            if (n_pre == 16) LINA_WIN8(16); else if (n_pre == 24) LINA_WIN8(24); else LINA_WIN8(32);
-#undef LINA_WIN8
-            return check_launch("lina_gla_decode_window (eight waves)");
-        }
-    }
     const int cs = Dv == 512 ? 2 : 1;                        // column splits: one workgroup streams <= 256 columns
     dim3 grid((unsigned)(B * H), (unsigned)cs);
 #define LINA_WIN_ONE(DVV, NRBB, CSS)                                                                                   \

@@ -79,15 +79,6 @@ __device__ __forceinline__ void dma16_to_lds_async(const void* base_uniform, uns
                  : "s"(lds), "v"(lane_byte_off), "s"(base_uniform)
                  : "memory", "m0");
 }
-// 4 bytes per lane (global_load_lds_dword): a wave copies 256 contiguous bytes to lds_wave_base + 4 lane
-__device__ __forceinline__ void dma4_to_lds_async(const void* base_uniform, unsigned lane_byte_off, void* lds_wave_base) {
-    const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane(
-        (int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
-                 :
-                 : "s"(lds), "v"(lane_byte_off), "s"(base_uniform)
-                 : "memory", "m0");
-}
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // ds_read_b64_tr_b16: transposing LDS read of 16-bit elements.  Every lane passes the address of an 8-byte piece; inside
 // each group of 16 lanes  result[lane i][j] = piece[lane 4 j + i / 4][element i % 4]  (probed: tools/micro/tr_read.hip,

@@ -15,8 +15,7 @@ struct Fiber {
     bool done = false;
     unsigned wave_parity = 0;
     char* stack = nullptr;
-    struct Dma { void* dst; const void* src; int bytes; };
-    std::vector<Dma> pending;   // LINA_EMU_DMA_LATE: issued, not yet landed
+    std::vector<std::pair<void*, const void*>> pending;   // LINA_EMU_DMA_LATE: issued, not yet landed
 };
 
 struct Wave {
@@ -45,9 +44,9 @@ bool dma_late() {
     static const bool late = getenv("LINA_EMU_DMA_LATE") && atoi(getenv("LINA_EMU_DMA_LATE")) != 0;
     return late;
 }
-void dma_defer(void* dst, const void* src, int bytes) { cur->pending.push_back({dst, src, bytes}); }
+void dma_defer(void* dst, const void* src) { cur->pending.emplace_back(dst, src); }
 void dma_flush_mine() {
-    for (auto& p : cur->pending) memcpy(p.dst, p.src, p.bytes);
+    for (auto& p : cur->pending) memcpy(p.first, p.second, 16);
     cur->pending.clear();
 }
 

@@ -61,7 +61,7 @@ const dim3& cur_tid();
 int cur_lane();
 void syncthreads();
 bool dma_late();
-void dma_defer(void* dst, const void* src, int bytes = 16);
+void dma_defer(void* dst, const void* src);
 void dma_flush_mine();
 // wave-collective exchange: every lane of the wave deposits `n` 32-bit words, then reads
 // the 64 x n table `out` (out[lane*n + i]).
@@ -232,12 +232,6 @@ static inline void dma16_to_lds_async(const void* base_uniform, unsigned lane_by
     const unsigned char* src = (const unsigned char*)base_uniform + lane_byte_off;
     if (lina_emu::dma_late()) lina_emu::dma_defer(dst, src);
     else memcpy(dst, src, 16);
-}
-static inline void dma4_to_lds_async(const void* base_uniform, unsigned lane_byte_off, void* lds_wave_base) {
-    unsigned char* dst = (unsigned char*)lds_wave_base + 4 * lina_emu::cur_lane();
-    const unsigned char* src = (const unsigned char*)base_uniform + lane_byte_off;
-    if (lina_emu::dma_late()) lina_emu::dma_defer(dst, src, 4);
-    else memcpy(dst, src, 4);
 }
 // the wave's DMA pieces have landed: on the emulator every lane copies its own 16 bytes when it runs, so this is a
 // wave-wide meeting point (all lanes of a wave call it together, as on the hardware)

@@ -1172,52 +1172,6 @@ def check_decode_window(dev, B, H, Dk, Dv, dtype, window=8, n_steps=19, resets=T
         assert_close(S_w, S_i, 1e-5, "K1w flushed state vs K1d state")
 
 
-def check_decode_window_eight_waves(dev, B, H, dtype, window=8, n_steps=11, n_pre=32, og_packed=False, origin0=3):
-    """The eight-wave form of K1w + K5 at Dk = Dv = 256 (LINA_K1W_WAVES=8) against the sixteen-wave kernel on the same operands,
-    step by step over a window, its write-back and the steps after it: outputs, written-back state and history BIT-identical."""
-    import os
-    Dk = Dv = 256
-    g = torch.Generator().manual_seed(41)
-    nw = (1 + 0.1 * torch.randn(Dv, generator=g)).to(dtype).to(dev)
-    S = [(torch.randn(B, H, Dk, Dv, generator=g) * 0.5).to(dev)]
-    S.append(S[0].clone())
-    hist = [[torch.full((window, B * H, D), float("nan"), device=dev) for D in (Dk, Dk, Dv)] for _ in range(2)]
-    step = torch.full((1,), origin0, dtype=torch.int64, device=dev)
-    origin = torch.full((1,), origin0, dtype=torch.int64, device=dev)
-    n_og = ops.packed_numel(B, H * Dv) if og_packed else B * H * Dv
-    keep = {k_: os.environ.get(k_) for k_ in ("LINA_K1W_WAVES", "LINA_K1W_NPRE")}
-    try:
-        for t in range(n_steps):
-            q = torch.randn(B, H, Dk, generator=g).to(dtype).to(dev)
-            k = torch.randn(B, H, Dk, generator=g).to(dtype).to(dev)
-            v = torch.randn(B, H, Dv, generator=g).to(dtype).to(dev)
-            gk = (F.logsigmoid(torch.randn(B, H, Dk, generator=g) * 2.0) / 4.0)
-            if t in (2, 7):
-                gk[:, :, ::2] = -20.0
-            gk = gk.to(dev)
-            gate = torch.randn(B, H, Dv, generator=g).to(dtype).to(dev)
-            og = []
-            for i, waves in enumerate(("16", "8")):
-                os.environ["LINA_K1W_WAVES"], os.environ["LINA_K1W_NPRE"] = waves, str(n_pre)
-                o = torch.full((n_og,), float("nan"), dtype=dtype, device=dev)
-                ops.gla_decode_window(q, k, v, gk, S[i], gate, nw, o, hist[i][0], hist[i][1], hist[i][2], step, origin, window, 1e-5,
-                                      og_packed=og_packed)
-                og.append(o)
-            bits = torch.int16 if dtype == torch.bfloat16 else torch.int32
-            assert torch.equal(og[0].view(bits), og[1].view(bits)), f"eight-wave K1w output differs (step {t})"
-            assert torch.equal(S[0], S[1]), f"eight-wave K1w state differs (step {t})"
-            j = (int(step.item()) - origin0) % window
-            for nm, a, b in zip(("k", "c", "v"), hist[0], hist[1]):
-                assert torch.equal(a[:j + 1], b[:j + 1]), f"eight-wave K1w history {nm} differs (step {t})"
-            step += 1
-    finally:
-        for k_, v_ in keep.items():
-            if v_ is None:
-                os.environ.pop(k_, None)
-            else:
-                os.environ[k_] = v_
-
-
 def check_cross_att(dev, B, Tn, d, dtype):
     """lina_cross_att_step1/2 vs the eager attention of reference crossatt.py:13-19,114,143,149 in fp64."""
     g = torch.Generator().manual_seed(14)

@@ -188,13 +188,6 @@ def test_decode_window(emu, Dk, Dv, dtype, window, n):
     check_decode_window(DEV, B=2, H=2, Dk=Dk, Dv=Dv, dtype=dtype, window=window, n_steps=n)
 
 
-@pytest.mark.parametrize("dtype,window,n,n_pre,packed", [(torch.bfloat16, 8, 10, 32, False), (torch.float32, 4, 6, 24, False),
-                                                        (torch.bfloat16, 8, 9, 16, True)])
-def test_decode_window_eight_waves_equals_sixteen(emu, dtype, window, n, n_pre, packed):
-    from kernel_cases import check_decode_window_eight_waves
-    check_decode_window_eight_waves(DEV, B=2, H=2, dtype=dtype, window=window, n_steps=n, n_pre=n_pre, og_packed=packed)
-
-
 @pytest.mark.parametrize("Q,L,d,dtype", [(1, 300, 64, torch.float32), (3, 70, 32, torch.bfloat16)])
 def test_greedy_pick_embed(emu, Q, L, d, dtype):
     from kernel_cases import check_greedy_pick_embed

@@ -317,14 +317,6 @@ def test_decode_window(hip, B, H, Dk, Dv, dtype, window, n):
     check_decode_window(DEV, B=B, H=H, Dk=Dk, Dv=Dv, dtype=dtype, window=window, n_steps=n)
 
 
-@pytest.mark.parametrize("B,H,dtype,window,n,n_pre,packed", [(64, 4, torch.bfloat16, 8, 19, 32, True), (64, 4, torch.bfloat16, 8, 10, 24, False),
-                                                            (5, 2, torch.float32, 4, 9, 16, False), (64, 4, torch.bfloat16, 2, 5, 32, True)])
-def test_decode_window_eight_waves_equals_sixteen(hip, B, H, dtype, window, n, n_pre, packed):
-    """The eight-wave K1w + K5 (Dk = Dv = 256) is bit-identical to the sixteen-wave kernel: outputs, state, history."""
-    from kernel_cases import check_decode_window_eight_waves
-    check_decode_window_eight_waves(DEV, B=B, H=H, dtype=dtype, window=window, n_steps=n, n_pre=n_pre, og_packed=packed)
-
-
 @pytest.mark.parametrize("B,Q,L,d,dtype", [(64, 1, 4099, 1024, torch.bfloat16), (7, 4, 1027, 256, torch.float32)])
 def test_greedy_pick_embed(hip, B, Q, L, d, dtype):
     from kernel_cases import check_greedy_pick_embed
