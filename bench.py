@@ -204,10 +204,19 @@ def measure_chunk_bwd(dev, B=8, H=4, T=4096, Dk=256, Dv=256, reps=100):
     dt, burst = sustained(lambda: ops.gla_chunk_bwd(q, k, v, gk, do, scale, nseg=nseg, seg_states=seg_ws), warm_s=1.0,
                           reps=reps)
     nbytes = B * H * T * 2 * (5 * Dk + 4 * Dv)
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r04_k2b_traffic.json")     # PMC passes are separate runs; their committed summary
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("shape") == {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv}:
+            traffic = tj["traffic_bytes_per_launch"]
+            traffic_src = ("profiles/r04_k2b_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected; per backward "
+                           "call = the three sweeps: 18 tensor passes for the 9 algorithmic ones)")
     return {"kernel": "lina::gla_chunk_bf16_h256_kernel<MODE, REV, DG>: reverse sweep (dv, dS) + value-gated sweeps (dq | dk, dg)"
                       + (f", {nseg} sequence segments from boundary states (forward's S, one state-only reverse pass for dS)"
                          if nseg > 1 else ""),
             "shape": {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv},
+            "bytes_per_launch": nbytes, "traffic": traffic, "traffic_source": traffic_src,
             "dtype": "bf16 I/O, bf16 MFMA, fp32 accumulate", "ms": dt * 1e3, "ms_burst_of_3": burst * 1e3, "bound": "hbm",
             "achieved": nbytes / dt / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS}
