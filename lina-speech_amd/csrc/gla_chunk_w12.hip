@@ -67,6 +67,7 @@ __global__ __launch_bounds__(768) void gla_chunk_bf16_h256_w12_kernel(
     float* const s_Rn = s_Rs + DK;        // R after this chunk
     __shared__ __attribute__((aligned(8))) unsigned s_flags[4];         // {cut needed, renormalise} per chunk parity
     __shared__ int s_cut;
+    __shared__ unsigned s_acnt;                                          // mask(A) tiles written (monotone: 4 per chunk)
     __shared__ unsigned s_rawcnt;                                        // waves that have finished reading the raw tiles (monotone: 12 per chunk)
 
     int tid = threadIdx.x, lane = tid & 63;
@@ -88,14 +89,231 @@ __global__ __launch_bounds__(768) void gla_chunk_bf16_h256_w12_kernel(
     if (tid < 4) s_flags[tid] = 0;
     if (tid == 4) s_cut = 0;
     if (tid == 5) s_rawcnt = 0;
+    if (tid == 6) s_acnt = 0;
 
-    if (util) {
+    if (!util) {
+
+    // =========================================================================================================
+    // state waves: columns [32 w, 32 w + 32) as two tiles of 16; tile (c2, p) = rows [16p, 16p + 16) in C/D layout
+    // (col = lane & 15, row = 4 (lane >> 4) + reg)
+    // =========================================================================================================
+    lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;
+    f32x4 S[2][16];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int p = 0; p < 16; ++p) S[c2][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (h0) {
+        const float* hp = h0 + ((int64_t)slot * DK + 4 * lg) * DV + 32 * w + li;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[c2][p][r] = hp[(16 * p + r) * DV + 16 * c2] * h0_scale;
+    }
+    __syncthreads();   // DMA of chunk 0 landed
+    int t0 = 0, par = 0;
+    // v^T of this wave's 32 columns (channel blocks 2w, 2w + 1; lane = (channel quad, row pair) as in phase A): v enters the
+    // products unscaled, so the state waves -- idle during phase A -- transpose it; rows >= nv are zeroed
+    auto write_vT = [&](int nv) {
+        const int rp_ = lane & 15;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int ch0 = 16 * (2 * w + blk) + 4 * (lane >> 4);
+            const bf16_t* const rawp = &s_raw[3 * RAWT + rp_ * PE + ch0];
+            uint2 vv[2];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                vv[rr] = *reinterpret_cast<const uint2*>(rawp + rr * DK);
+                vv[rr] = (2 * rp_ + rr < nv) ? vv[rr] : make_uint2(0u, 0u);
+            }
+            bf16_t* const tp = &s_T[(DK + ch0) * ST + 2 * rp_];
+            *reinterpret_cast<unsigned*>(tp) = byte_perm(vv[1].x, vv[0].x, 0x05040100u);
+            *reinterpret_cast<unsigned*>(tp + ST) = byte_perm(vv[1].x, vv[0].x, 0x07060302u);
+            *reinterpret_cast<unsigned*>(tp + 2 * ST) = byte_perm(vv[1].y, vv[0].y, 0x05040100u);
+            *reinterpret_cast<unsigned*>(tp + 3 * ST) = byte_perm(vv[1].y, vv[0].y, 0x07060302u);
+        }
+    };
+    // the prefetch of the rows from t_first on: state wave w issues row pairs 2w, 2w + 1 of q, k, g, v (8 pieces).  An LDS-DMA
+    // instruction blocks its wave until the memory system has accepted it -- here, in the phase-A window, the state waves
+    // have nothing else to do
+    auto dma_pairs = [&](int t_first) {                         // (g and v; q and k come from the utility waves after barrier (2))
+#pragma unroll
+        for (int a = 2; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int pair = 2 * w + j;
+                const unsigned t = (unsigned)min(t_first + 2 * pair + (lane >> 5), T - 1);
+                const unsigned boff = 2u * (t * gst[a] + 8u * (unsigned)(lane & 31));
+                dma16_to_lds_async(gsrc[a], boff, &s_raw[a * RAWT + pair * PE]);
+            }
+    };
+    // o of the chunk [tp, tp + np), packed after step (3): stored in the next window (a state wave has nothing else to do then)
+    uint2 opk[2][2] = {};
+    auto store_prev = [&](int tp, int np) {
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int row = 16 * nt + li;
+                if (row < np) {
+                    const unsigned boff = 2u * ((unsigned)(tp + row) * (unsigned)so.t + 32u * (unsigned)w + 16u * (unsigned)c2 +
+                                                4u * (unsigned)lg);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) + boff) = opk[c2][nt];
+                }
+            }
+    };
+    W12_PROF_INIT;
+    int tp = 0, np = 0;                                        // the previous chunk, finished at the top of the next window
+    unsigned chunk_no = 0;
+    while (t0 < T) {
+        const int nrem = T - t0;
+        int n = min(C, nrem);
+        lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
+        // ---------------- the phase-A window of the state waves ----------------
+        if (np > 0) store_prev(tp, np);
+        write_vT(n);                                           // reads this chunk's raw v rows
+        lds_wait();
+        if (lane == 0) lds_atomic_add(reinterpret_cast<int*>(&s_rawcnt), 1);
+        W12_PROF(0);       // step (3) + stores of the previous chunk, v^T
+        if (t0 + C < T) {
+            // every wave has read what it needs of the raw tiles (12 arrivals per chunk): the next chunk's rows may overwrite them
+            const unsigned target = 12u * (chunk_no + 1u);
+            unsigned seen;
+            do { seen = (unsigned)shfl_i((int)*reinterpret_cast<volatile unsigned*>(&s_rawcnt), 0); } while (seen < target);
+            dma_pairs(t0 + C);
+        }
+        W12_PROF(4);       // wait for the raw tiles + DMA issue
+        __syncthreads();   // (2)
+        W12_PROF(1);       // wait at (2)
+        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;
+        uint2 fl = *reinterpret_cast<const uint2*>(&s_flags[2 * par]);   // workgroup-uniform
+        float rn = tid < DK ? s_Rn[tid] : 0.0f;
+        if (fl.x) {
+            wait_vmem();                                       // this wave's (now useless) prefetch pieces have landed ...
+            __syncthreads();   // (c0) ... everybody's have: the utility waves fetch this chunk's rows again
+            __syncthreads();   // (c1)
+            __syncthreads();   // (c2)
+            n = max(min(n, C - s_cut), 1);
+            __syncthreads();   // (c3)
+            if (tid == 0) { int z = 0; opaque(z); s_cut = z; }
+            write_vT(n);                                       // the cut chunk's rows >= n are zero
+            __syncthreads();   // (c4)
+            fl.y = s_flags[2 * par + 1];                       // the rewritten tiles may have changed both
+            rn = tid < DK ? s_Rn[tid] : 0.0f;
+        }
+        const bool renorm = fl.y != 0;
+        // next chunk's R: s_R is read by phase A only (before (2) / after (3)), s_Rn is stable between (2) and (3)
+        if (tid < DK) s_R[tid] = renorm ? 0.0f : rn;
+
+        // ---------------- phase B ----------------
+        const bf16_t* ktp = &s_kT[li * ST + 8 * lg];
+        const bf16_t* qp = &s_q[li * SQ + 8 * (lg ^ ((li >> 2) & 3))];
+        // (1) o^T = S'^T q~^T: one K = 32 MFMA per pair of 16-row state tiles (converted to bf16 in registers), then (3)
+        //     o^T += v^T mask(A)^T and the packed o -- one column tile after the other, so that only one tile's accumulators are
+        //     live.  mask(A) of THIS chunk is complete when its four tiles have been counted in (the utility waves write them
+        //     first thing after barrier (2)); the k-slots of both operands of (3) are tokens s = 8 lg .. 8 lg + 7
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            // (the q~ fragment of token tile 1 of pair pp is requested behind the MFMA of token tile 0 and so on: a ring of ONE pair --
+            //  this wave has 168 registers and 128 of them are the state)
+            bf16x8 q0 = frag16(qp), q1 = frag16(qp + 16 * SQ);
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) {
+                bf16x8 bb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bb[r] = (short)f2bf(S[c2][2 * pp][r]);
+                    bb[4 + r] = (short)f2bf(S[c2][2 * pp + 1][r]);
+                }
+                acc0 = mfma_bf16_16x16x32(bb, q0, acc0);
+                if (pp + 1 < 8) q0 = frag16(qp + 32 * (pp + 1));
+                sched_fence();
+                acc1 = mfma_bf16_16x16x32(bb, q1, acc1);
+                if (pp + 1 < 8) q1 = frag16(qp + 16 * SQ + 32 * (pp + 1));
+                sched_fence();
+            }
+            if (c2 == 0) {
+                const unsigned target = 4u * (chunk_no + 1u);
+                unsigned seen;
+                do { seen = (unsigned)shfl_i((int)*reinterpret_cast<volatile unsigned*>(&s_acnt), 0); } while (seen < target);
+            }
+            const bf16x8 vbc = frag16(&s_vT[(32 * w + 16 * c2 + li) * ST + 8 * lg]);
+            acc0 = mfma_bf16_16x16x32(vbc, frag16(&s_A[li * SA + 8 * lg]), acc0);
+            acc1 = mfma_bf16_16x16x32(vbc, frag16(&s_A[(16 + li) * SA + 8 * lg]), acc1);
+            opk[c2][0].x = pack_bf16x2(acc0[0] * scale, acc0[1] * scale);
+            opk[c2][0].y = pack_bf16x2(acc0[2] * scale, acc0[3] * scale);
+            opk[c2][1].x = pack_bf16x2(acc1[0] * scale, acc1[1] * scale);
+            opk[c2][1].y = pack_bf16x2(acc1[2] * scale, acc1[3] * scale);
+        }
+        W12_PROF(2);       // steps (1) + (3)
+        // (4) S' += k~^T v: the k~^T fragments are shared by the two column tiles
+        {
+            bf16x8 vb[2];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) vb[c2] = frag16(&s_vT[(32 * w + 16 * c2 + li) * ST + 8 * lg]);
+            bf16x8 tf[2];
+            tf[0] = frag16(ktp);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                if (p + 1 < 16) tf[(p + 1) & 1] = frag16(ktp + 16 * (p + 1) * ST);
+                sched_fence();
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) S[c2][p] = mfma_bf16_16x16x32(tf[p & 1], vb[c2], S[c2][p]);
+                sched_fence();
+            }
+        }
+        if (renorm) {                                          // rare: S' <- e^{R} S' (R = s_Rn, the value after this chunk)
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const float4 r4 = *reinterpret_cast<const float4*>(&s_Rn[16 * p + 4 * lg]);
+                const float f0 = fast_exp2(r4.x), f1 = fast_exp2(r4.y), f2 = fast_exp2(r4.z), f3 = fast_exp2(r4.w);
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) { S[c2][p][0] *= f0; S[c2][p][1] *= f1; S[c2][p][2] *= f2; S[c2][p][3] *= f3; }
+            }
+        }
+        W12_PROF(3);       // step (4)
+        wait_vmem();       // this wave's prefetch pieces (issued in the window above) have long landed
+        __syncthreads();   // (3) operand tiles dead; mask(A) complete; next raw tiles landed
+        W12_PROF(5);       // wait at (3)
+        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;
+        if (tid == 0) {                                        // read by all before (3); set again two chunks later
+            int z = 0;
+            opaque(z);
+            s_flags[2 * par] = (unsigned)z; s_flags[2 * par + 1] = (unsigned)z;
+        }
+        tp = t0; np = n;
+        par ^= 1;
+        t0 += n;
+        ++chunk_no;
+    }
+    lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
+    store_prev(tp, np);                                        // the last chunk (T >= 1)
+    W12_PROF_FLUSH;
+    if (ht) {
+        __syncthreads();                                       // s_R of the last chunk is visible
+        lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
+        float* hp = ht + ((int64_t)slot * DK + 4 * lg) * DV + 32 * w + li;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {                          // S = diag(e^{R}) S'
+            const float4 r4 = *reinterpret_cast<const float4*>(&s_R[16 * p + 4 * lg]);
+            const float f[4] = {fast_exp2(r4.x), fast_exp2(r4.y), fast_exp2(r4.z), fast_exp2(r4.w)};
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hp[(16 * p + r) * DV + 16 * c2] = S[c2][p][r] * f[r];
+        }
+    }
+    } else {
         // =====================================================================================================
         // utility waves
         // =====================================================================================================
-        auto dma_chunk = [&](int t_first) {                   // row pairs 4u .. 4u + 3 of q, k, g, v; rows past the end re-read row T-1
+        lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4; rp = lane & 15;   // (nothing per-lane is shared with the state waves' code: a common subexpression hoisted above the role split lives in a register through BOTH loops)
+        auto dma_chunk = [&](int t_first, int a_lo, int a_hi) {   // row pairs 4u .. 4u + 3 of tensors [a_lo, a_hi) of q, k, g, v; rows past the end re-read row T-1
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = a_lo; a < a_hi; ++a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int pair = 4 * u + j;
@@ -191,7 +409,7 @@ __global__ __launch_bounds__(768) void gla_chunk_bf16_h256_w12_kernel(
         using FullT = std::true_type;
         using PartT = std::false_type;
 
-        dma_chunk(0);
+        dma_chunk(0, 0, 4);
         wait_vmem();
         __syncthreads();   // DMA of chunk 0 landed
         int t0 = 0, par = 0;
@@ -254,7 +472,7 @@ __global__ __launch_bounds__(768) void gla_chunk_bf16_h256_w12_kernel(
                 // have already prefetched rows t0 + C .. into the raw tiles: once that has landed (barrier 0) this chunk's rows are
                 // fetched again, the chunk is redone with n rows, and the prefetch of rows t0 + n .. is this wave's (below).
                 __syncthreads();   // (c0) the state waves' prefetch has landed
-                dma_chunk(t0);
+                dma_chunk(t0, 0, 4);
                 wait_vmem();
                 __syncthreads();   // (c1) this chunk's raw rows are back
                 int nc = C;
@@ -285,7 +503,7 @@ __global__ __launch_bounds__(768) void gla_chunk_bf16_h256_w12_kernel(
                 }
                 __syncthreads();   // (c4)
                 own_prefetch = t0 + n < T;
-                if (own_prefetch) dma_chunk(t0 + n);            // (beside the state waves' phase B, waited for before (3))
+                if (own_prefetch) dma_chunk(t0 + n, 0, 4);      // (beside the state waves' phase B, waited for before (3))
             }
             W12_PROF(2);       // DMA issue
             {
@@ -311,8 +529,14 @@ __global__ __launch_bounds__(768) void gla_chunk_bf16_h256_w12_kernel(
                 pa.x = pack_bf16x2(sb <= t ? at[0] : 0.0f, sb + 1 <= t ? at[1] : 0.0f);
                 pa.y = pack_bf16x2(sb + 2 <= t ? at[2] : 0.0f, sb + 3 <= t ? at[3] : 0.0f);
                 *reinterpret_cast<uint2*>(&s_A[(16 * nt + li) * SA + sb]) = pa;
+                lds_wait();
+                if (lane == 0) lds_atomic_add(reinterpret_cast<int*>(&s_acnt), 1);   // the state waves take step (3) before barrier (3)
             }
             W12_PROF(3);       // mask(A)
+            if (!cut_needed && t0 + C < T) {
+                dma_chunk(t0 + C, 0, 2);                        // q, k of the next chunk (g, v: the state waves, in their window)
+                own_prefetch = true;
+            }
             if (own_prefetch) wait_vmem();
             W12_PROF(4);       // wait_vmem
             __syncthreads();   // (3) the next raw tiles have landed (the state waves waited for theirs); operand tiles dead; mask(A) complete
@@ -322,219 +546,6 @@ __global__ __launch_bounds__(768) void gla_chunk_bf16_h256_w12_kernel(
         }
         W12_PROF_FLUSH;
         if (ht) __syncthreads();                                // (pairs with the state waves' barrier in front of the final state)
-        return;
-    }
-
-    // =========================================================================================================
-    // state waves: columns [32 w, 32 w + 32) as two tiles of 16; tile (c2, p) = rows [16p, 16p + 16) in C/D layout
-    // (col = lane & 15, row = 4 (lane >> 4) + reg)
-    // =========================================================================================================
-    f32x4 S[2][16];
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-        for (int p = 0; p < 16; ++p) S[c2][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (h0) {
-        const float* hp = h0 + ((int64_t)slot * DK + 4 * lg) * DV + 32 * w + li;
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-            for (int p = 0; p < 16; ++p)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[c2][p][r] = hp[(16 * p + r) * DV + 16 * c2] * h0_scale;
-    }
-    __syncthreads();   // DMA of chunk 0 landed
-    int t0 = 0, par = 0;
-    f32x4 acc[2][2];
-    bf16x8 vb[2];                                               // v^T fragments of the two column tiles: steps (4) and (3)
-    // v^T of this wave's 32 columns (channel blocks 2w, 2w + 1; lane = (channel quad, row pair) as in phase A): v enters the
-    // products unscaled, so the state waves -- idle during phase A -- transpose it; rows >= nv are zeroed
-    auto write_vT = [&](int nv) {
-        const int rp_ = lane & 15;
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const int ch0 = 16 * (2 * w + blk) + 4 * (lane >> 4);
-            const bf16_t* const rawp = &s_raw[3 * RAWT + rp_ * PE + ch0];
-            uint2 vv[2];
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                vv[rr] = *reinterpret_cast<const uint2*>(rawp + rr * DK);
-                vv[rr] = (2 * rp_ + rr < nv) ? vv[rr] : make_uint2(0u, 0u);
-            }
-            bf16_t* const tp = &s_T[(DK + ch0) * ST + 2 * rp_];
-            *reinterpret_cast<unsigned*>(tp) = byte_perm(vv[1].x, vv[0].x, 0x05040100u);
-            *reinterpret_cast<unsigned*>(tp + ST) = byte_perm(vv[1].x, vv[0].x, 0x07060302u);
-            *reinterpret_cast<unsigned*>(tp + 2 * ST) = byte_perm(vv[1].y, vv[0].y, 0x05040100u);
-            *reinterpret_cast<unsigned*>(tp + 3 * ST) = byte_perm(vv[1].y, vv[0].y, 0x07060302u);
-        }
-    };
-    // the prefetch of the rows from t_first on: state wave w issues row pairs 2w, 2w + 1 of q, k, g, v (8 pieces).  An LDS-DMA
-    // instruction blocks its wave until the memory system has accepted it -- here, in the phase-A window, the state waves
-    // have nothing else to do
-    auto dma_pairs = [&](int t_first) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int pair = 2 * w + j;
-                const unsigned t = (unsigned)min(t_first + 2 * pair + (lane >> 5), T - 1);
-                const unsigned boff = 2u * (t * gst[a] + 8u * (unsigned)(lane & 31));
-                dma16_to_lds_async(gsrc[a], boff, &s_raw[a * RAWT + pair * PE]);
-            }
-    };
-    // (3) o^T += v^T mask(A)^T for the chunk [tp, tp + np) -- mask(A) has its own buffer, rewritten only after the next barrier
-    //     (2); the k-slots of both operands are tokens s = 8 lg .. 8 lg + 7 -- and o straight out
-    auto finish_prev = [&](int tp, int np) {
-        const bf16x8 a0 = frag16(&s_A[li * SA + 8 * lg]), a1 = frag16(&s_A[(16 + li) * SA + 8 * lg]);
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-            acc[c2][0] = mfma_bf16_16x16x32(vb[c2], a0, acc[c2][0]);
-            acc[c2][1] = mfma_bf16_16x16x32(vb[c2], a1, acc[c2][1]);
-        }
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                uint2 po;
-                po.x = pack_bf16x2(acc[c2][nt][0] * scale, acc[c2][nt][1] * scale);
-                po.y = pack_bf16x2(acc[c2][nt][2] * scale, acc[c2][nt][3] * scale);
-                const int row = 16 * nt + li;
-                if (row < np) {
-                    const unsigned boff = 2u * ((unsigned)(tp + row) * (unsigned)so.t + 32u * (unsigned)w + 16u * (unsigned)c2 +
-                                                4u * (unsigned)lg);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ob) + boff) = po;
-                }
-            }
-    };
-    W12_PROF_INIT;
-    int tp = 0, np = 0;                                        // the previous chunk, finished at the top of the next window
-    unsigned chunk_no = 0;
-    while (t0 < T) {
-        const int nrem = T - t0;
-        int n = min(C, nrem);
-        lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
-        // ---------------- the phase-A window of the state waves ----------------
-        write_vT(n);                                           // reads this chunk's raw v rows
-        lds_wait();
-        if (lane == 0) lds_atomic_add(reinterpret_cast<int*>(&s_rawcnt), 1);
-        if (np > 0) finish_prev(tp, np);
-        W12_PROF(0);       // v^T, step (3) + stores of the previous chunk
-        if (t0 + C < T) {
-            // every wave has read what it needs of the raw tiles (12 arrivals per chunk): the next chunk's rows may overwrite them
-            const unsigned target = 12u * (chunk_no + 1u);
-            unsigned seen;
-            do { seen = (unsigned)shfl_i((int)*reinterpret_cast<volatile unsigned*>(&s_rawcnt), 0); } while (seen < target);
-            dma_pairs(t0 + C);
-        }
-        W12_PROF(4);       // wait for the raw tiles + DMA issue
-        __syncthreads();   // (2)
-        W12_PROF(1);       // wait at (2)
-        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;
-        uint2 fl = *reinterpret_cast<const uint2*>(&s_flags[2 * par]);   // workgroup-uniform
-        float rn = tid < DK ? s_Rn[tid] : 0.0f;
-        if (fl.x) {
-            wait_vmem();                                       // this wave's (now useless) prefetch pieces have landed ...
-            __syncthreads();   // (c0) ... everybody's have: the utility waves fetch this chunk's rows again
-            __syncthreads();   // (c1)
-            __syncthreads();   // (c2)
-            n = max(min(n, C - s_cut), 1);
-            __syncthreads();   // (c3)
-            if (tid == 0) { int z = 0; opaque(z); s_cut = z; }
-            write_vT(n);                                       // the cut chunk's rows >= n are zero
-            __syncthreads();   // (c4)
-            fl.y = s_flags[2 * par + 1];                       // the rewritten tiles may have changed both
-            rn = tid < DK ? s_Rn[tid] : 0.0f;
-        }
-        const bool renorm = fl.y != 0;
-        // next chunk's R: s_R is read by phase A only (before (2) / after (3)), s_Rn is stable between (2) and (3)
-        if (tid < DK) s_R[tid] = renorm ? 0.0f : rn;
-
-        // ---------------- phase B ----------------
-        const bf16_t* ktp = &s_kT[li * ST + 8 * lg];
-        const bf16_t* qp = &s_q[li * SQ + 8 * (lg ^ ((li >> 2) & 3))];
-        // (1) o^T = S'^T q~^T: one K = 32 MFMA per pair of 16-row state tiles (converted to bf16 in registers); one column tile
-        //     after the other (registers)
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-            acc[c2][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc[c2][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            bf16x8 qf[2][2];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) qf[0][nt] = frag16(qp + 16 * nt * SQ);
-#pragma unroll
-            for (int pp = 0; pp < 8; ++pp) {
-                if (pp + 1 < 8) {
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) qf[(pp + 1) & 1][nt] = frag16(qp + 16 * nt * SQ + 32 * (pp + 1));
-                }
-                sched_fence();
-                bf16x8 bb;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    bb[r] = (short)f2bf(S[c2][2 * pp][r]);
-                    bb[4 + r] = (short)f2bf(S[c2][2 * pp + 1][r]);
-                }
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[c2][nt] = mfma_bf16_16x16x32(bb, qf[pp & 1][nt], acc[c2][nt]);
-                sched_fence();
-            }
-        }
-        W12_PROF(2);       // step (1)
-        // (4) S' += k~^T v: the k~^T fragments are shared by the two column tiles
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) vb[c2] = frag16(&s_vT[(32 * w + 16 * c2 + li) * ST + 8 * lg]);
-        {
-            bf16x8 tf[2];
-            tf[0] = frag16(ktp);
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                if (p + 1 < 16) tf[(p + 1) & 1] = frag16(ktp + 16 * (p + 1) * ST);
-                sched_fence();
-#pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) S[c2][p] = mfma_bf16_16x16x32(tf[p & 1], vb[c2], S[c2][p]);
-                sched_fence();
-            }
-        }
-        if (renorm) {                                          // rare: S' <- e^{R} S' (R = s_Rn, the value after this chunk)
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const float4 r4 = *reinterpret_cast<const float4*>(&s_Rn[16 * p + 4 * lg]);
-                const float f0 = fast_exp2(r4.x), f1 = fast_exp2(r4.y), f2 = fast_exp2(r4.z), f3 = fast_exp2(r4.w);
-#pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) { S[c2][p][0] *= f0; S[c2][p][1] *= f1; S[c2][p][2] *= f2; S[c2][p][3] *= f3; }
-            }
-        }
-        W12_PROF(3);       // step (4)
-        wait_vmem();       // this wave's prefetch pieces (issued in the window above) have long landed
-        __syncthreads();   // (3) operand tiles dead; mask(A) complete; next raw tiles landed
-        W12_PROF(5);       // wait at (3)
-        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;
-        if (tid == 0) {                                        // read by all before (3); set again two chunks later
-            int z = 0;
-            opaque(z);
-            s_flags[2 * par] = (unsigned)z; s_flags[2 * par + 1] = (unsigned)z;
-        }
-        tp = t0; np = n;
-        par ^= 1;
-        t0 += n;
-        ++chunk_no;
-    }
-    lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
-    finish_prev(tp, np);                                       // the last chunk (T >= 1)
-    W12_PROF_FLUSH;
-    if (ht) {
-        __syncthreads();                                       // s_R of the last chunk is visible
-        lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
-        float* hp = ht + ((int64_t)slot * DK + 4 * lg) * DV + 32 * w + li;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {                          // S = diag(e^{R}) S'
-            const float4 r4 = *reinterpret_cast<const float4*>(&s_R[16 * p + 4 * lg]);
-            const float f[4] = {fast_exp2(r4.x), fast_exp2(r4.y), fast_exp2(r4.z), fast_exp2(r4.w)};
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hp[(16 * p + r) * DV + 16 * c2] = S[c2][p][r] * f[r];
-        }
     }
 }
 

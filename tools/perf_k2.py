@@ -71,9 +71,9 @@ if os.environ.get("K2_W12_PROF"):                          # tools/w12_prof.sh b
     rc = lib.lina_w12_prof_read(buf.ctypes.data_as(ctypes.c_void_p))
     a = buf.reshape(12, 8).astype(np.float64) / (T / 32)
     print("twelve-wave K2, shader clocks per chunk of workgroup 0:  rc =", rc)
-    print("  state waves 0..7:   prev step (3) + stores + v^T | wait (2) | step (1) | step (4) | - | wait (3)")
+    print("  state waves 0..7:   stores of the previous chunk + v^T | raw wait + DMA issue | wait (2) | steps (1)+(3) | step (4) | wait (3)")
     for w_ in range(8):
-        print(f"    wave {w_:2d}: " + " ".join(f"{a[w_, i]:7.0f}" for i in (0, 1, 2, 3, 5)) + f"   total {a[w_, :6].sum():7.0f}")
+        print(f"    wave {w_:2d}: " + " ".join(f"{a[w_, i]:7.0f}" for i in (0, 4, 1, 2, 3, 5)) + f"   total {a[w_, :6].sum():7.0f}")
     print("  utility waves 8..11: phase A | wait (2) | DMA issue | mask(A) | wait_vmem | wait (3)")
     for w_ in range(8, 12):
         print(f"    wave {w_:2d}: " + " ".join(f"{a[w_, i]:7.0f}" for i in range(6)) + f"   total {a[w_, :6].sum():7.0f}")
