@@ -25,8 +25,6 @@
 //      (3) o^T += v^T . mask(A)^T after the barrier (mask(A) has its own buffer), o carried in registers to the next
 //      phase A's end.  1/sqrt(Dk) is applied to o.  History and measurements: DESIGN.md 4.2.
 #include <type_traits>
-#include <stdlib.h>
-#include <stdio.h>
 #ifndef LINA_DMA_NT
 #define LINA_DMA_NT 1   // the q,k,g,v prefetch is read once: non-temporal DMA (0.582 -> 0.572 ms at B=64,H=4,T=4096, round 4)
 #endif
@@ -820,19 +818,6 @@ static bool full_ok(int H, int Dk, int Dv, int dtype, const void* q, const void*
     return p16(q) && p16(k) && p16(v) && p16(gk) && p16(o);
 }
 
-// gla_chunk_w12.hip: the forward, key-gated form at G = 1 on twelve specialised waves
-int launch_chunk_w12(const void* q, const void* k, const void* v, const void* gk, void* o, const float* h0, float* ht,
-                     int64_t slots, int H, int T, int nseg, int Tseg, lina_bht_strides sq, lina_bht_strides sk,
-                     lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides so, float scale, float h0_scale,
-                     lina_stream_t stream);
-// test / measurement hook (read per call): LINA_K2_WAVES=16 keeps the sixteen-wave kernel for the forward at G = 1
-static bool use_w12() {
-    const char* e = getenv("LINA_K2_WAVES");
-    const bool on = !(e && atoi(e) == 16);
-    if (getenv("LINA_K2_TRACE")) fprintf(stderr, "[lina] K2 forward at G = 1: %s waves\n", on ? "12" : "16");
-    return on;
-}
-
 int launch_chunk_full(const void* q, const void* k, const void* v, const void* gk, void* o, const float* h0,
                       float* ht, int B, int H, int T, int Dk, int Dv, lina_bht_strides sq, lina_bht_strides sk,
                       lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides so, int dtype, int g_dtype,
@@ -842,10 +827,6 @@ int launch_chunk_full(const void* q, const void* k, const void* v, const void* g
              fits32(sv) && fits32(sg) && fits32(so);
     if (!*taken) return LINA_OK;
     const int G = 256 / Dk;
-    if (G == 1 && use_w12()) {
-        launch_chunk_w12(q, k, v, gk, o, h0, ht, (int64_t)B * H, H, T, 1, T, sq, sk, sv, sg, so, scale, 1.0f, stream);
-        return check_launch("lina_gla_chunk_fwd(w12)");
-    }
     dim3 grid((unsigned)(B * H / G));
 #define LINA_FULL(GG)                                                                                                  \
     LINA_LAUNCH((gla_chunk_bf16_h256_kernel<false, GG>), grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k, \
@@ -954,8 +935,7 @@ extern "C" int lina_gla_chunk_fwd_seg(const void* q, const void* k, const void* 
     LINA_LAUNCH(gla_seg_combine_kernel<false>, dim3((unsigned)(B * H / G), (unsigned)(Dk / 4)), dim3(256), 0, stream,
                 (const float*)L, (const float*)P, h0, 1.0f, Sstart, ht, ns, Dk, (const float*)nullptr,
                 (const bf16_t*)nullptr, sg, (const float*)nullptr, (float*)nullptr, H, Tseg, scale);
-    if (G == 1 && use_w12()) launch_chunk_w12(q, k, v, gk, o, Sstart, nullptr, slots, H, T, ns, Tseg, sq, sk, sv, sg, so, scale, 1.0f, stream);
-    else if (G == 1) LINA_SEG(false, 1, o, Sstart, nullptr, nullptr); else if (G == 2) LINA_SEG(false, 2, o, Sstart, nullptr, nullptr);
+    if (G == 1) LINA_SEG(false, 1, o, Sstart, nullptr, nullptr); else if (G == 2) LINA_SEG(false, 2, o, Sstart, nullptr, nullptr);
     else LINA_SEG(false, 4, o, Sstart, nullptr, nullptr);
 #undef LINA_SEG
     return check_launch("lina_gla_chunk_fwd_seg");

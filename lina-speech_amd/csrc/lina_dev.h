@@ -132,10 +132,6 @@ __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_rea
 // Workgroup barrier that orders LDS traffic only (ds_* via lgkmcnt) and leaves global / LDS-DMA operations in flight:
 // __syncthreads() also drains vmcnt, i.e. it would wait for an asynchronous global->LDS prefetch that nobody reads yet.
 // Use it only where no wave touches the DMA destination before the next full __syncthreads().
-// this wave's LDS operations have completed (its reads have returned their data) -- without a barrier
-__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// the four values are needed HERE (an opaque use: loads that produce them are issued, and waited for, before this point)
-__device__ __forceinline__ void consume4(unsigned a, unsigned b, unsigned c, unsigned d_) { asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d_)); }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // value of lane (l - n) of the same 16-lane row, 0 for the first n lanes of a row (v_*_dpp row_shr:n, bound_ctrl): one VALU

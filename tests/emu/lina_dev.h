@@ -271,8 +271,6 @@ static inline float2 ld_agent8(const float* p) { return make_float2(p[0], p[1]);
 static inline void drain_stores() {}
 static inline int ticket_agent(int* counter) { return (*counter)++; }
 
-static inline void lds_wait() {}
-static inline void consume4(unsigned, unsigned, unsigned, unsigned) {}
 static inline void lds_barrier() { lina_emu::syncthreads(); }
 static inline int lane_id() { return lina_emu::cur_lane(); }
 static inline int wave_uniform(int v) { return v; }

@@ -60,20 +60,3 @@ if os.environ.get("K2_PROF"):
           " wait_vmem median/max", np.median(wg[:, 1]), np.max(wg[:, 1]), " bar(3) median/max", np.median(wg[:, 2]), np.max(wg[:, 2]))
     order = np.argsort(wg[:, 0])
     print("slowest workgroups:", order[-8:], wg[order[-8:], 0].round(), " fastest:", order[:8], wg[order[:8], 0].round())
-
-if os.environ.get("K2_W12_PROF"):                          # tools/w12_prof.sh build, LINA_GLA_LIB=tools/abl/liblina_w12prof.so
-    import ctypes, numpy as np
-    from lina_speech_amd import _lib
-    lib = _lib.load()
-    ops.chunk_gla(q, k, v, gk, output_final_state=False)
-    torch.cuda.synchronize()
-    buf = np.zeros(12 * 8, dtype=np.uint64)
-    rc = lib.lina_w12_prof_read(buf.ctypes.data_as(ctypes.c_void_p))
-    a = buf.reshape(12, 8).astype(np.float64) / (T / 32)
-    print("twelve-wave K2, shader clocks per chunk of workgroup 0:  rc =", rc)
-    print("  state waves 0..7:   stores of the previous chunk + v^T | raw wait + DMA issue | wait (2) | steps (1)+(3) | step (4) | wait (3)")
-    for w_ in range(8):
-        print(f"    wave {w_:2d}: " + " ".join(f"{a[w_, i]:7.0f}" for i in (0, 4, 1, 2, 3, 5)) + f"   total {a[w_, :6].sum():7.0f}")
-    print("  utility waves 8..11: phase A | wait (2) | DMA issue | mask(A) | wait_vmem | wait (3)")
-    for w_ in range(8, 12):
-        print(f"    wave {w_:2d}: " + " ".join(f"{a[w_, i]:7.0f}" for i in range(6)) + f"   total {a[w_, :6].sum():7.0f}")
