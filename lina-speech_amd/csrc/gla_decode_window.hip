@@ -31,9 +31,6 @@
 #ifndef LINA_K1W_STATE_PLAIN
 #define LINA_K1W_STATE_PLAIN 0  // state loads WITHOUT the non-temporal hint (is a cache-resident state any faster?)
 #endif
-#ifndef LINA_K1W_NPRE
-#define LINA_K1W_NPRE 0          // experiment: see the state loads
-#endif
 #ifndef LINA_K1W_NO_TAIL_LOADS
 #define LINA_K1W_NO_TAIL_LOADS 0  // WRONG RESULTS: the K5 tail without its norm-weight / gate loads (what does their latency cost?)
 #endif
@@ -128,16 +125,9 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
         if (!flush_only) vj = ld(v + b * v_sb + h * v_sh + col0 + vc);
     }
 
-#if LINA_K1W_NPRE   // experiment (tools build): only NPRE of a thread's NP state vectors are requested up front, the rest once the
-                    // first NP - NPRE have been consumed (into their registers)
-    constexpr int NPRE = (LINA_K1W_NPRE < NP && 2 * LINA_K1W_NPRE >= NP) ? LINA_K1W_NPRE : NP;
-#else
-    constexpr int NPRE = NP;
-#endif
-    constexpr int NLATE = NP - NPRE;
-    float4 St[NPRE];
+    float4 St[NP];
 #pragma unroll
-    for (int i = 0; i < NPRE; ++i) St[i] = LINA_K1W_STATE_LOAD(tile + (int64_t)(rg + RPI * i) * DVT);
+    for (int i = 0; i < NP; ++i) St[i] = LINA_K1W_STATE_LOAD(tile + (int64_t)(rg + RPI * i) * DVT);
 
     // ---- per-row gate bookkeeping and the window's v rows
     if (row_wave) {
@@ -192,39 +182,6 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
     __syncthreads();
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (NLATE > 0) {
-        // (experiment) one vector at a time, in the order of the loops below: the same values bit for bit
-        auto consume = [&](float4& s4, int i) {
-            const int rr = r0 + rg + RPI * i;
-            if (write_back) {
-                const float d = s_e[rr];
-                s4.x *= d; s4.y *= d; s4.z *= d; s4.w *= d;
-#pragma unroll 1
-                for (int s = 0; s <= j; ++s) {
-                    const float4 vv = *reinterpret_cast<const float4*>(&s_v[s][4 * cg]);
-                    const float ws = s_w[s][rr];
-                    s4.x = fmaf(ws, vv.x, s4.x); s4.y = fmaf(ws, vv.y, s4.y); s4.z = fmaf(ws, vv.z, s4.z); s4.w = fmaf(ws, vv.w, s4.w);
-                }
-                st_nt4(tile + (int64_t)(rg + RPI * i) * DVT, s4);
-                if (!flush_only) {
-                    const float qq = s_q[rr];
-                    acc.x = fmaf(qq, s4.x, acc.x); acc.y = fmaf(qq, s4.y, acc.y); acc.z = fmaf(qq, s4.z, acc.z); acc.w = fmaf(qq, s4.w, acc.w);
-                }
-            } else {
-                const float qe = s_q[rr] * s_e[rr];
-                acc.x = fmaf(qe, s4.x, acc.x); acc.y = fmaf(qe, s4.y, acc.y); acc.z = fmaf(qe, s4.z, acc.z); acc.w = fmaf(qe, s4.w, acc.w);
-            }
-        };
-#pragma unroll
-        for (int i = 0; i < NLATE; ++i) consume(St[i], i);
-#pragma unroll
-        for (int i = 0; i < NLATE; ++i) St[i] = LINA_K1W_STATE_LOAD(tile + (int64_t)(rg + RPI * (NPRE + i)) * DVT);
-#pragma unroll
-        for (int i = NLATE; i < NPRE; ++i) consume(St[i], i);
-#pragma unroll
-        for (int i = 0; i < NLATE; ++i) consume(St[i], NPRE + i);
-        if (flush_only) return;
-    } else
     if (write_back) {
         // S <- e^{c_j} S + sum_s w_s (x) v_s  (the window's rank-(j+1) update), o from the UPDATED rows
 #pragma unroll
