@@ -200,19 +200,27 @@ int lina_embed_sum(const int64_t* idx, const void* table, void* out,
  * when step[0] >= max_steps), x_out[b,:] = sum_q table[q, pick_q, :] (K6a), and step[0] += 1 by the last workgroup to
  * finish.  logits: [B, Q*L] with a row stride; counter: one int32, zero before the first call (left zero).
  * x_out_packed (optional): the same rows in the fragment-major layout of the packed projections (see below).
- * Replaces reference model/modeling_lina.py:159-179 (k = 1 picks, token list append, next-input embedding). */
+ * loop_ctl (optional, int32 [LINA_LOOP_CTL_ROWS + B], zero with word [1] = -1 before the loop): the reference's stop
+ * bookkeeping (model/modeling_lina.py:126,168-173) kept on the device --
+ *     word [0] = rows that have emitted the stop token (id 2 on every quantizer) at some step so far,
+ *     word [1] = the first step at which ALL rows had (the step the reference breaks at), -1 until then,
+ *     words [2],[3] = a per-call seed word (lo, hi) XORed into `seed` of lina_sample_pick_embed (a captured launch is
+ *                     re-seeded by writing it),   words [4 + b] = row b has stopped.
+ * The host reads word [1] whenever it likes (every 16 steps in LinaModel.generate_batch) instead of syncing per step.
+ * Replaces reference model/modeling_lina.py:159-179 (k = 1 picks, token list append, stop flags, next-input embedding). */
+#define LINA_LOOP_CTL_ROWS 4
 int lina_greedy_pick_embed(const void* logits, int64_t row_stride, const void* table, void* x_out,
-                           void* x_out_packed, int64_t* tok_log, int64_t* step, int* counter, int B, int Q, int L,
-                           int n_emb, int d, int max_steps, int dtype, lina_stream_t stream);
+                           void* x_out_packed, int64_t* tok_log, int64_t* step, int* counter, int* loop_ctl, int B, int Q,
+                           int L, int n_emb, int d, int max_steps, int dtype, lina_stream_t stream);
 
 /* K6e -- K6d for the reference's DEFAULT generation mode (model/modeling_lina.py:119-121,159-164, tools.py:38-44):
  * quantizers q < n_sampled are SAMPLED (top-k / temperature, K6c) and the others take the arg-max (K6b); everything else
  * as lina_greedy_pick_embed.  The uniform number of (row b, quantizer q) is the one lina_topk_sample_rows hashes for row
  * b*Q + q of a [B*Q]-row call at the same (seed, step[0]): the tokens equal those of the separate launches. */
 int lina_sample_pick_embed(const void* logits, int64_t row_stride, const void* table, void* x_out,
-                           void* x_out_packed, int64_t* tok_log, int64_t* step, int* counter, int B, int Q, int L,
-                           int n_emb, int d, int max_steps, int n_sampled, int k, float temp, uint64_t seed, int dtype,
-                           lina_stream_t stream);
+                           void* x_out_packed, int64_t* tok_log, int64_t* step, int* counter, int* loop_ctl, int B, int Q,
+                           int L, int n_emb, int d, int max_steps, int n_sampled, int k, float temp, uint64_t seed,
+                           int dtype, lina_stream_t stream);
 
 /* K6b -- greedy pick: out[r] = argmax_j logits[r,j], lowest index on exact ties.
  * Replaces topk_sampling(k=1) (reference model/tools.py:38-44, modeling_lina.py:159-164);
@@ -454,8 +462,13 @@ int lina_cross_att_step2(const void* xp, const void* pe, const void* vv, void* a
  *   lina_weighted_rows_add: x[b,:] += sum_t attc[b,t] * vv[b,t,:]                                              */
 /* Blind cross-attention step, first half after the scores (reference model/crossatt.py:117-127) in one launch:
  *   att[b,:Tn] = softmax(scores[b,:Tn])  (scores fp32, already scaled: lina_cross_scores);  xp[b,:] = att[b,:] . pe[:Tn,:]
- *   (pe [Tn,d] shared by all rows) -> xp [B,d] row-major and, when xp_packed is given, its fragment-major copy. */
-int lina_softmax_pe_rows(const float* scores, int64_t scores_sb, void* att, int64_t att_sb, const void* pe, void* xp,
+ *   (pe [Tn,d] shared by all rows) -> xp [B,d] row-major and, when xp_packed is given, its fragment-major copy.
+ * The att LOG of the device-side decode loop (reference model/modeling_lina.py:157,180: `atts.append(att)` / torch.cat over
+ * steps): with att_step != NULL row b is stored at  att + b*att_sb + att_step[0]*att_step_stride  (a device step counter,
+ * so one captured launch is valid at every step) and dropped when att_step[0] is outside [0, att_steps); att_step == NULL:
+ * att + b*att_sb as before.  Same three arguments on lina_pe_softmax_weighted_rows_add. */
+int lina_softmax_pe_rows(const float* scores, int64_t scores_sb, void* att, int64_t att_sb,
+                         const int64_t* att_step, int64_t att_step_stride, int64_t att_steps, const void* pe, void* xp,
                          void* xp_packed, int B, int Tn, int d, int dtype, lina_stream_t stream);
 
 /* Round-2 fusions of the same step (fewer launches on the serial chain):
@@ -479,7 +492,7 @@ int lina_softmax_weighted_rows_add(const void* scores, int64_t scores_sb, float 
  * xp: [B, d] row-major, or (xp_packed != 0) the fragment-major layout of lina_linear_skinny_ex; pe: [>= T_txt, d] row-major;
  * d % 256 == 0. */
 int lina_pe_softmax_weighted_rows_add(const void* xp, int xp_packed, const void* pe, float scale, void* att, int64_t att_sb,
-                                      const void* vv, void* x, void* x_packed, int B, int T_txt, int d, int dtype,
+                                      const int64_t* att_step, int64_t att_step_stride, int64_t att_steps, const void* vv, void* x, void* x_packed, int B, int T_txt, int d, int dtype,
                                       lina_stream_t stream);
 int lina_cross_scores(const void* q_lin, const void* ln_w, const void* ln_b, float ln_eps, const void* kk,
                       float* scores, int B, int T_txt, int d, float scale, int dtype, lina_stream_t stream);

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("LINA_GLA_LIB") or os.path.join(_HERE, "csrc", "liblin
 
 LINA_F32, LINA_BF16 = 0, 1
 CONV_BWD_TT = 64          # LINA_CONV_BWD_TT in include/lina_gla.h
+LOOP_CTL_ROWS = 4         # LINA_LOOP_CTL_ROWS: int32 words in front of the per-row stop flags of a loop-control block
 
 
 class BHT(C.Structure):
@@ -45,8 +46,8 @@ PROTOTYPES = {
     "lina_rmsnorm_gate_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i64,
                                         _f, _i, _i, _p]),
     "lina_embed_sum": (C.c_int, [_p, _p, _p, _i, _i64, _i, _i, _i, _p]),
-    "lina_greedy_pick_embed": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "lina_sample_pick_embed": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, C.c_uint64,
+    "lina_greedy_pick_embed": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "lina_sample_pick_embed": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, C.c_uint64,
                                          _i, _p]),
     "lina_argmax_rows": (C.c_int, [_p, _p, _i64, _i, _i64, _i, _p]),
     "lina_topk_sample_rows": (C.c_int, [_p, _p, _i64, _i, _i64, _i, _f, _p, C.c_uint64, _p, _i, _p]),
@@ -82,8 +83,8 @@ PROTOTYPES = {
     "lina_cross_att_step2": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i, _i, _i, _f, _i, _p]),
     "lina_cross_scores_softmax": (C.c_int, [_p, _p, _p, _f, _p, _p, _i64, _p, _i, _i, _i, _i, _f, _i, _p]),
     "lina_softmax_weighted_rows_add": (C.c_int, [_p, _i64, _f, _p, _i64, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "lina_pe_softmax_weighted_rows_add": (C.c_int, [_p, _i, _p, _f, _p, _i64, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "lina_softmax_pe_rows": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "lina_pe_softmax_weighted_rows_add": (C.c_int, [_p, _i, _p, _f, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "lina_softmax_pe_rows": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i, _i, _i, _i, _p]),
     "lina_cross_scores": (C.c_int, [_p, _p, _p, _f, _p, _p, _i, _i, _i, _f, _i, _p]),
     "lina_softmax_rows": (C.c_int, [_p, _i64, _i, _f, _p, _i64, _p, _i, _i, _i, _i, _p]),
     "lina_weighted_rows_add": (C.c_int, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),

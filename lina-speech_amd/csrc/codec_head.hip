@@ -50,6 +50,20 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const T* __restrict__ 
     }
 }
 
+// Loop-control block of the device-side decode loop (include/lina_gla.h LINA_LOOP_CTL_*): int32 words
+//   [0] rows that have emitted the stop token so far   [1] first step at which ALL rows had (or -1)
+//   [2],[3] per-call seed word (lo, hi)                [4 + b] row b has stopped
+// -- the reference's `is_stop_token = (q_sampled == stop_token).prod(0)`, `all_stop_token |= ...`, `if all_stop_token.prod(): break`
+// (model/modeling_lina.py:168-173) kept on the device: the host reads word [1] every few steps instead of syncing every step.
+constexpr int kCtlCount = 0, kCtlStopAt = 1, kCtlSeedLo = 2, kCtlSeedHi = 3, kCtlRows = 4, kStopToken = 2;
+__device__ __forceinline__ void note_stop(int* ctl, const int* toks, int Q, int b, int B, int64_t t) {
+    bool stop = true;
+    for (int qi = 0; qi < Q; ++qi) stop = stop && toks[qi] == kStopToken;
+    if (!stop || ctl[kCtlRows + b]) return;
+    ctl[kCtlRows + b] = 1;
+    if (ticket_agent(ctl + kCtlCount) == B - 1) ctl[kCtlStopAt] = (int)t;   // this row was the last one still running
+}
+
 // K6d -- the whole token epilogue of a greedy decode step in ONE launch (one workgroup per batch row): arg-max of every
 // quantizer's logits (K6b), the pick appended to the device-side token log at position step[0], the next step's input
 // embedding sum_q table[q, pick_q] (K6a) written into the residual-stream buffer, and -- by the LAST workgroup to finish,
@@ -60,7 +74,7 @@ __global__ __launch_bounds__(256) void greedy_pick_embed_kernel(const T* __restr
                                                                 const T* __restrict__ table, T* __restrict__ x_out,
                                                                 int64_t* __restrict__ tok_log, int64_t* step, int* counter,
                                                                 int Q, int L, int n_emb, int d, int max_steps,
-                                                                T* __restrict__ x_pk) {
+                                                                T* __restrict__ x_pk, int* ctl) {
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
     __shared__ int s_tok[16];
@@ -108,6 +122,7 @@ __global__ __launch_bounds__(256) void greedy_pick_embed_kernel(const T* __restr
         }
     }
     if (tid == 0) {
+        if (ctl) note_stop(ctl, s_tok, Q, b, B, s_step);
         const int tk = ticket_agent(counter);       // taken AFTER this workgroup has read step[0]
         if (tk == B - 1) {
             *counter = 0;                            // re-armed for the next launch
@@ -127,7 +142,7 @@ __global__ __launch_bounds__(256) void sample_pick_embed_kernel(const T* __restr
                                                                 int64_t* __restrict__ tok_log, int64_t* step, int* counter,
                                                                 int Q, int L, int n_emb, int d, int max_steps,
                                                                 T* __restrict__ x_pk, int n_sampled, int k, float inv_temp,
-                                                                uint64_t seed) {
+                                                                uint64_t seed, int* ctl) {
     LINA_DYN_SMEM(smem_raw);
     float* s_x = reinterpret_cast<float*>(smem_raw);            // [L] the row being sampled
     __shared__ SampleScratch sc;
@@ -139,6 +154,8 @@ __global__ __launch_bounds__(256) void sample_pick_embed_kernel(const T* __restr
     if (tid == 0) s_step = step[0];
     __syncthreads();
     const int64_t t = s_step;
+    // the loop-control block carries a per-call seed word (XORed in) so that a captured launch can be re-seeded
+    if (ctl) seed ^= ((uint64_t)(uint32_t)ctl[kCtlSeedLo]) | ((uint64_t)(uint32_t)ctl[kCtlSeedHi] << 32);
     for (int qi = 0; qi < Q; ++qi) {
         const T* row = logits + (int64_t)b * row_stride + (int64_t)qi * L;
         int pick;
@@ -171,6 +188,7 @@ __global__ __launch_bounds__(256) void sample_pick_embed_kernel(const T* __restr
         }
     }
     if (tid == 0) {
+        if (ctl) note_stop(ctl, s_tok, Q, b, B, t);
         const int tk = ticket_agent(counter);       // taken AFTER this workgroup has read step[0]
         if (tk == B - 1) {
             *counter = 0;                            // re-armed for the next launch
@@ -182,8 +200,8 @@ __global__ __launch_bounds__(256) void sample_pick_embed_kernel(const T* __restr
 }  // namespace lina
 
 extern "C" int lina_greedy_pick_embed(const void* logits, int64_t row_stride, const void* table, void* x_out,
-                                      void* x_out_packed, int64_t* tok_log, int64_t* step, int* counter, int B, int Q,
-                                      int L, int n_emb, int d, int max_steps, int dtype, lina_stream_t stream) {
+                                      void* x_out_packed, int64_t* tok_log, int64_t* step, int* counter, int* loop_ctl, int B,
+                                      int Q, int L, int n_emb, int d, int max_steps, int dtype, lina_stream_t stream) {
     using namespace lina;
     LINA_REQUIRE(logits && table && x_out && tok_log && step && counter, "lina_greedy_pick_embed: null pointer");
     LINA_REQUIRE(B > 0 && Q > 0 && Q <= 16 && L > 0 && n_emb > 0 && max_steps > 0,
@@ -195,17 +213,17 @@ extern "C" int lina_greedy_pick_embed(const void* logits, int64_t row_stride, co
     if (dtype == LINA_F32)
         LINA_LAUNCH((greedy_pick_embed_kernel<float>), grid, dim3(256), 0, stream, (const float*)logits, row_stride,
                     (const float*)table, (float*)x_out, tok_log, step, counter, Q, L, n_emb, d, max_steps,
-                    (float*)x_out_packed);
+                    (float*)x_out_packed, loop_ctl);
     else
         LINA_LAUNCH((greedy_pick_embed_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)logits, row_stride,
                     (const bf16_t*)table, (bf16_t*)x_out, tok_log, step, counter, Q, L, n_emb, d, max_steps,
-                    (bf16_t*)x_out_packed);
+                    (bf16_t*)x_out_packed, loop_ctl);
     return check_launch("lina_greedy_pick_embed");
 }
 
 extern "C" int lina_sample_pick_embed(const void* logits, int64_t row_stride, const void* table, void* x_out,
-                                      void* x_out_packed, int64_t* tok_log, int64_t* step, int* counter, int B, int Q,
-                                      int L, int n_emb, int d, int max_steps, int n_sampled, int k, float temp,
+                                      void* x_out_packed, int64_t* tok_log, int64_t* step, int* counter, int* loop_ctl, int B,
+                                      int Q, int L, int n_emb, int d, int max_steps, int n_sampled, int k, float temp,
                                       uint64_t seed, int dtype, lina_stream_t stream) {
     using namespace lina;
     LINA_REQUIRE(logits && table && x_out && tok_log && step && counter, "lina_sample_pick_embed: null pointer");
@@ -222,11 +240,11 @@ extern "C" int lina_sample_pick_embed(const void* logits, int64_t row_stride, co
     if (dtype == LINA_F32)
         LINA_LAUNCH((sample_pick_embed_kernel<float>), grid, dim3(256), smem, stream, (const float*)logits, row_stride,
                     (const float*)table, (float*)x_out, tok_log, step, counter, Q, L, n_emb, d, max_steps,
-                    (float*)x_out_packed, n_sampled, k, 1.0f / temp, seed);
+                    (float*)x_out_packed, n_sampled, k, 1.0f / temp, seed, loop_ctl);
     else
         LINA_LAUNCH((sample_pick_embed_kernel<bf16_t>), grid, dim3(256), smem, stream, (const bf16_t*)logits, row_stride,
                     (const bf16_t*)table, (bf16_t*)x_out, tok_log, step, counter, Q, L, n_emb, d, max_steps,
-                    (bf16_t*)x_out_packed, n_sampled, k, 1.0f / temp, seed);
+                    (bf16_t*)x_out_packed, n_sampled, k, 1.0f / temp, seed, loop_ctl);
     return check_launch("lina_sample_pick_embed");
 }
 

@@ -427,7 +427,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void pe_softmax_weighted_rows_kernel(const T* __restrict__ xp, int xp_packed,
                                                                        const T* __restrict__ pe, float scale,
                                                                        T* __restrict__ att, int64_t att_sb,
-                                                                       const T* __restrict__ vv, T* x, int Tn, int d, T* xpk) {
+                                                                       const T* __restrict__ vv, T* x, int Tn, int d, T* xpk,
+                                                                       const int64_t* __restrict__ att_step, int64_t att_ss,
+                                                                       int64_t att_ns) {
     LINA_DYN_SMEM(smem);
     float* s_x = reinterpret_cast<float*>(smem);              // [d]: the row of x_pos in fp32
     __shared__ float s_a[kCaMaxT];
@@ -474,11 +476,14 @@ __global__ __launch_bounds__(256) void pe_softmax_weighted_rows_kernel(const T* 
     for (int t = tid; t < Tn; t += 256) sum += expf(s_a[t] - mx);
     sum = block_sum(sum, s_red);
     const float inv = 1.0f / sum;
+    // att log of the device-side decode loop: the row goes to att + step[0] * att_ss (dropped outside [0, att_ns))
+    const int64_t a_t = att_step ? att_step[0] : 0;
+    const bool a_ok = blockIdx.x == 0 && (!att_step || (a_t >= 0 && a_t < att_ns));
     for (int t = tid; t < Tn; t += 256) {
         T tmp;                                               // the weights in the model dtype, as softmax_rows stores them
         st(&tmp, expf(s_a[t] - mx) * inv);
         s_a[t] = ld(&tmp);
-        if (blockIdx.x == 0) att[b * att_sb + t] = tmp;
+        if (a_ok) att[b * att_sb + a_t * att_ss + t] = tmp;
     }
     __syncthreads();
     const int e = blockIdx.x * 256 + lane * 4;
@@ -521,7 +526,9 @@ __global__ __launch_bounds__(256) void pe_softmax_weighted_rows_kernel(const T* 
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_pe_rows_kernel(const float* __restrict__ scores, int64_t sc_sb,
                                                               T* __restrict__ att, int64_t att_sb, const T* __restrict__ pe,
-                                                              T* __restrict__ xp, T* __restrict__ xpk, int Tn, int d) {
+                                                              T* __restrict__ xp, T* __restrict__ xpk, int Tn, int d,
+                                                              const int64_t* __restrict__ att_step, int64_t att_ss,
+                                                              int64_t att_ns) {
     __shared__ float s_a[kCaMaxT];
     __shared__ float s_red[4];
     __shared__ __attribute__((aligned(16))) float s_p[3][64][4];
@@ -541,11 +548,14 @@ __global__ __launch_bounds__(256) void softmax_pe_rows_kernel(const float* __res
     for (int t = tid; t < Tn; t += 256) sum += expf(s_a[t] - mx);
     sum = block_sum(sum, s_red);
     const float inv = 1.0f / sum;
+    // att log of the device-side decode loop: the row goes to att + step[0] * att_ss (dropped outside [0, att_ns))
+    const int64_t a_t = att_step ? att_step[0] : 0;
+    const bool a_ok = blockIdx.x == 0 && (!att_step || (a_t >= 0 && a_t < att_ns));
     for (int t = tid; t < Tn; t += 256) {
         T tmp;                                               // the weights in the model dtype, as softmax_rows stores them
         st(&tmp, expf(s_a[t] - mx) * inv);
         s_a[t] = ld(&tmp);
-        if (blockIdx.x == 0) att[b * att_sb + t] = tmp;
+        if (a_ok) att[b * att_sb + a_t * att_ss + t] = tmp;
     }
     __syncthreads();
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -777,7 +787,8 @@ extern "C" int lina_cross_scores_softmax(const void* q_lin, const void* ln_w, co
     return check_launch("lina_cross_scores_softmax");
 }
 
-extern "C" int lina_softmax_pe_rows(const float* scores, int64_t scores_sb, void* att, int64_t att_sb, const void* pe, void* xp,
+extern "C" int lina_softmax_pe_rows(const float* scores, int64_t scores_sb, void* att, int64_t att_sb,
+                                    const int64_t* att_step, int64_t att_step_stride, int64_t att_steps, const void* pe, void* xp,
                                    void* xp_packed, int B, int Tn, int d, int dtype, lina_stream_t stream) {
     using namespace lina;
     LINA_REQUIRE(scores && att && pe && xp, "lina_softmax_pe_rows: null pointer");
@@ -788,10 +799,10 @@ extern "C" int lina_softmax_pe_rows(const float* scores, int64_t scores_sb, void
     dim3 grid((unsigned)((d + 255) / 256), (unsigned)B);
     if (dtype == LINA_F32)
         LINA_LAUNCH((softmax_pe_rows_kernel<float>), grid, dim3(256), 0, stream, scores, scores_sb, (float*)att, att_sb,
-                    (const float*)pe, (float*)xp, (float*)xp_packed, Tn, d);
+                    (const float*)pe, (float*)xp, (float*)xp_packed, Tn, d, att_step, att_step_stride, att_steps);
     else
         LINA_LAUNCH((softmax_pe_rows_kernel<bf16_t>), grid, dim3(256), 0, stream, scores, scores_sb, (bf16_t*)att, att_sb,
-                    (const bf16_t*)pe, (bf16_t*)xp, (bf16_t*)xp_packed, Tn, d);
+                    (const bf16_t*)pe, (bf16_t*)xp, (bf16_t*)xp_packed, Tn, d, att_step, att_step_stride, att_steps);
     return check_launch("lina_softmax_pe_rows");
 }
 
@@ -815,7 +826,8 @@ extern "C" int lina_softmax_weighted_rows_add(const void* scores, int64_t scores
 }
 
 extern "C" int lina_pe_softmax_weighted_rows_add(const void* xp, int xp_packed, const void* pe, float scale, void* att,
-                                                 int64_t att_sb, const void* vv, void* x, void* x_packed, int B, int Tn, int d,
+                                                 int64_t att_sb, const int64_t* att_step, int64_t att_step_stride,
+                                                 int64_t att_steps, const void* vv, void* x, void* x_packed, int B, int Tn, int d,
                                                  int dtype, lina_stream_t stream) {
     using namespace lina;
     LINA_REQUIRE(xp && pe && att && vv && (x || x_packed), "lina_pe_softmax_weighted_rows_add: null pointer");
@@ -826,11 +838,12 @@ extern "C" int lina_pe_softmax_weighted_rows_add(const void* xp, int xp_packed, 
     const size_t smem = sizeof(float) * (size_t)d;
     if (dtype == LINA_F32)
         LINA_LAUNCH((pe_softmax_weighted_rows_kernel<float>), grid, dim3(256), smem, stream, (const float*)xp, xp_packed,
-                    (const float*)pe, scale, (float*)att, att_sb, (const float*)vv, (float*)x, Tn, d, (float*)x_packed);
+                    (const float*)pe, scale, (float*)att, att_sb, (const float*)vv, (float*)x, Tn, d, (float*)x_packed,
+                    att_step, att_step_stride, att_steps);
     else
         LINA_LAUNCH((pe_softmax_weighted_rows_kernel<bf16_t>), grid, dim3(256), smem, stream, (const bf16_t*)xp, xp_packed,
                     (const bf16_t*)pe, scale, (bf16_t*)att, att_sb, (const bf16_t*)vv, (bf16_t*)x, Tn, d,
-                    (bf16_t*)x_packed);
+                    (bf16_t*)x_packed, att_step, att_step_stride, att_steps);
     return check_launch("lina_pe_softmax_weighted_rows_add");
 }
 

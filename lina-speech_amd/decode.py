@@ -159,6 +159,15 @@ class _Part:
         self.attc = torch.zeros(hi - lo, Tp, dtype=dtype, device=dev)  # softmax rows, zero-padded to whole k-steps
 
 
+class _Loop:
+    """One captured configuration of the device-side decode loop: its logs, control block and hipGraphs."""
+    __slots__ = ("cap", "tok_log", "att_log", "att_direct", "ctl", "body", "graph1", "graphN", "att")
+
+    def __init__(self):
+        self.cap, self.tok_log, self.att_log, self.att_direct, self.ctl = 0, None, None, False, None
+        self.body = self.graph1 = self.graphN = self.att = None
+
+
 class DecodeEngine:
     def __init__(self, model, x_enc: torch.Tensor, batch_size: int, state: Optional[Cache] = None,
                  use_graph: Optional[bool] = None, n_split: Optional[int] = None, fuse_norm: bool = True,
@@ -195,6 +204,9 @@ class DecodeEngine:
         self._origin_host, self._n_done, self._lazy_live = 0, 0, False
         self._skip_update = False
         self._loop_packed = False
+        self._loops, self._loop, self._att_direct, self._t0 = {}, None, None, 0
+        self._pin = self._pin_ev = None
+        self._pick_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
         # which weight matrices of the device loop are STREAMED (non-temporal loads) instead of competing for the 256 MB
         # Infinity Cache: per token the loop touches 0.87 GB of state (always streamed) + 0.26 GB of weights; streaming
         # the largest matrices lets the others stay resident between two tokens
@@ -212,6 +224,9 @@ class DecodeEngine:
         self.ca = ca
         kk, vv, pe = ca.prepare(x_enc)                                   # [B,1,Ttxt,d] x2, [1,1,Ttxt,d]
         kk, vv = kk.squeeze(1).contiguous(), vv.squeeze(1).contiguous()
+        if kk.shape[0] != batch_size:                                    # one text for every row
+            kk, vv = kk.expand(batch_size, -1, -1).contiguous(), vv.expand(batch_size, -1, -1).contiguous()
+        self._kk, self._vv = kk, vv                                      # static: reset(x_enc) rewrites them in place
         self.pe = pe.squeeze(1).squeeze(0).contiguous()                  # [Ttxt, d]
         self.Tn = self.pe.shape[0]
         Tp = (self.Tn + 31) // 32 * 32
@@ -311,6 +326,12 @@ class DecodeEngine:
         ca = self.ca
         att = self._att[part.lo:part.hi]
         B = x.shape[0]
+        log = self._att_direct                 # the loop's att log [B,2,cap,Ttxt]: rows filed at the device step index
+        if log is not None:
+            att = log.att_log[part.lo:part.hi]
+            log_kw = dict(att_step=self._t_idx, att_step_stride=log.att_log.stride(2), att_steps=log.cap)
+        else:
+            log_kw = {}
         if packed:
             q_lin = ops.linear_skinny_packed(part.x_p, self.ca_qw_p, B, self.d, self.d, c2=self.ca_qb, out=part.q_lin)
         else:
@@ -318,7 +339,7 @@ class DecodeEngine:
         if self._cross_spread:
             # scores on 256 workgroups (4 per row), then softmax + att1 . pe in one launch (K = T_txt: no MFMA needed)
             ops.cross_scores(q_lin, ca.ln_q.weight, ca.ln_q.bias, ca.ln_q.eps, part.kk, part.scores, self.att_scale)
-            ops.softmax_pe_rows(part.scores, att[:, 0, 0], self.pe, part.xp, part.xp_p if packed else None)
+            ops.softmax_pe_rows(part.scores, att[:, 0, 0], self.pe, part.xp, part.xp_p if packed else None, **log_kw)
         else:
             ops.cross_scores_softmax(q_lin, ca.ln_q.weight, ca.ln_q.bias, ca.ln_q.eps, part.kk, att[:, 0, 0], part.attc,
                                      self.att_scale)
@@ -338,7 +359,8 @@ class DecodeEngine:
         if fuse2:
             # scores2 = xp . pe^T, softmax, att2 . V and the residual add in ONE launch (round 4; was a projection launch + this)
             ops.pe_softmax_weighted_rows_add(part.xp_p if packed else part.xp, self.pe_pad, self.att_scale, att[:, 1, 0],
-                                             part.vv, x, x_packed=part.x_p if packed else None, xp_is_packed=packed)
+                                             part.vv, x, x_packed=part.x_p if packed else None, xp_is_packed=packed,
+                                             **log_kw)
         else:
             ops.softmax_weighted_rows_add(part.sc2, self.att_scale, att[:, 1, 0], part.vv, x,
                                           x_packed=part.x_p if packed else None)
@@ -490,56 +512,92 @@ class DecodeEngine:
 
     step = __call__
 
-    # ------------------------------------------------------------------ fully device-side greedy loop
+    # ------------------------------------------------------------------ fully device-side decode loop
     def begin_greedy(self, max_steps: int, y0: Optional[torch.Tensor] = None, k: int = 1, temp: float = 1.0,
-                     seed: int = 0, first_greedy_quant: int = 0):
-        """Arm the device-side decode loop: token picks, the next-token embedding (K6a) and the token log are
-        part of the captured step, so one token == one graph replay and nothing is read back until
-        ``greedy_tokens()``.  Quantizers ``i < first_greedy_quant`` are SAMPLED (top-``k``, temperature
-        ``temp``, K6c with uniforms hashed from (seed, device step counter, row)) like the reference's default
-        generation mode (modeling_lina.py:159-164); the others -- all of them by default -- take the arg-max
-        (K6b)."""
+                     seed: int = 0, first_greedy_quant: int = 0, log_att: bool = False, t0: int = 0):
+        """Arm the device-side decode loop: token picks, the stop bookkeeping, the next-token embedding (K6a), the token
+        log and -- with ``log_att`` -- the attention log are part of the captured step, so one token == one graph replay
+        and nothing is read back until ``greedy_tokens()``.  Quantizers ``i < first_greedy_quant`` are SAMPLED (top-``k``,
+        temperature ``temp``, K6c with uniforms hashed from (seed, device step counter, row)) like the reference's
+        default generation mode (modeling_lina.py:159-164); the others -- all of them by default -- take the arg-max
+        (K6b).  ``t0``: the step index the loop starts at (a prompt prefill has produced steps 0 .. t0-1; ``preload``
+        puts their tokens / attention rows into the logs).  The recurrent state is NOT reset (``reset()`` does that).
+
+        A configuration (sampling mode, att log, operand layout) is captured ONCE per engine and kept (``self._loops``):
+        arming it again only rewrites the control block (stop flags, per-call seed word), the step counters and the
+        first input -- no new graph capture."""
         emb = self.model.rvq_embed
         self.sync_state()                     # pending window steps of an earlier loop
         if y0 is None:
             y0 = emb.embed_sum(torch.ones(self.Q, self.B, 1, dtype=torch.long, device=self.dev))
         self._y_in.copy_(y0.reshape(self.B, self.d))
-        self._tok_log = torch.zeros(max_steps, self.Q, self.B, dtype=torch.long, device=self.dev)
-        self._t_idx.zero_()
-        self._origin.zero_()
-        self._n_done, self._origin_host = 0, 0
         lazy = self.window > 1
-        self._lazy_live = lazy
-        n_sampled_ = min(max(first_greedy_quant, 0), self.Q) if k > 1 else 0
-        # fragment-major operands: the all-greedy device loop on one row range (the pick kernel K6d keeps x_p current)
-        # (K6d / K6e keep x_p current; the unfused sampled epilogue, fused_pick=False, has no packed output)
-        fused_pick = self.Q <= 16 and (n_sampled_ == 0 or self._fused_pick)
+        n_sampled = min(max(first_greedy_quant, 0), self.Q) if k > 1 else 0
+        # fragment-major operands: the device loop on one row range with the one-launch token epilogue (K6d / K6e keep
+        # x_p current; the unfused sampled epilogue, fused_pick=False, has no packed output)
+        fused_pick = self.Q <= 16 and (n_sampled == 0 or self._fused_pick)
         packed = (lazy and len(self.parts) == 1 and fused_pick
                   and all(P.packed for P in self.packs) and self._packed_ok)
+        if n_sampled == 0:
+            k, temp = 1, 1.0
+        key = (n_sampled, int(k), float(temp), bool(log_att), packed, fused_pick, 0 if fused_pick else int(seed))
+        loop = self._loops.get(key)
+        if loop is None or loop.cap < max_steps:
+            loop = self._build_loop(key, max_steps, lazy)
+            self._loops[key] = loop
+        self._loop = loop
         self._loop_packed = packed
-        n_sampled = min(max(first_greedy_quant, 0), self.Q) if k > 1 else 0
-        is_sampled = (torch.arange(self.Q, device=self.dev) < n_sampled).unsqueeze(0)        # [1,Q]
-
-        # one row range: the residual-stream buffer itself is the step's input (no y -> x copy, no embed -> y copy)
-        y_buf = self.parts[0].x if len(self.parts) == 1 else self._y_in
+        self._lazy_live = lazy
+        # ---- arm: control block, counters, first input
+        loop.tok_log.zero_()
+        loop.ctl.copy_(ops.new_loop_ctl(self.B, "cpu", int(seed) if fused_pick else 0))
+        self._pick_counter.zero_()
+        self._t_idx.fill_(t0)
+        self._origin.fill_(t0)
+        self._n_done, self._origin_host, self._t0 = t0, t0, t0
+        y_buf = self._loop_input()
         y_buf.copy_(self._y_in)
         if packed:
             ops.pack_rows(y_buf, out=self.parts[0].x_p)
 
-        self._pick_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
+    def _loop_input(self):
+        """One row range: the residual-stream buffer itself is the step's input (no y -> x copy, no embed -> y copy)."""
+        return self.parts[0].x if len(self.parts) == 1 else self._y_in
+
+    def _build_loop(self, key, max_steps: int, lazy: bool):
+        n_sampled, k, temp, log_att, packed, fused_pick, seed = key
+        emb = self.model.rvq_embed
+        L = _Loop()
+        L.cap = (max(int(max_steps), 1) + 63) // 64 * 64
+        L.tok_log = torch.zeros(L.cap, self.Q, self.B, dtype=torch.long, device=self.dev)
+        L.ctl = ops.new_loop_ctl(self.B, self.dev)
+        hw_dt = self._att.dtype
+        L.att_log = torch.zeros(self.B, 2, L.cap, self.Tn, dtype=hw_dt, device=self.dev) if log_att else None
+        # the two cross-attention launches of the default step write their rows straight into the log at the device step
+        # index; the other forms of the step write the engine's static [B,2,1,Ttxt] buffer and one index_copy_ files it
+        L.att_direct = bool(log_att and self._cross_spread and self._cross_tail_fused and self.d % 256 == 0)
+        is_sampled = (torch.arange(self.Q, device=self.dev) < n_sampled).unsqueeze(0)        # [1,Q]
+        y_buf = self._loop_input()
+        R = ops.LOOP_CTL_ROWS
 
         def body():
-            logits, att = self._core(y_buf, lazy, packed)
+            self._att_direct = L if L.att_direct else None
+            try:
+                logits, att = self._core(y_buf, lazy, packed)
+            finally:
+                self._att_direct = None
+            if L.att_log is not None and not L.att_direct:
+                L.att_log.index_copy_(2, self._t_idx, att)
             lg = logits.view(self.B, self.Q, self.L)
             if n_sampled == 0 and self.Q <= 16:
-                # K6d: picks, token log, next-token embedding and the step counter in ONE launch
-                ops.greedy_pick_embed(lg, emb.weight, y_buf, self._tok_log, self._t_idx, self._pick_counter,
-                                      x_packed=self.parts[0].x_p if packed else None)
+                # K6d: picks, token log, stop flags, next-token embedding and the step counter in ONE launch
+                ops.greedy_pick_embed(lg, emb.weight, y_buf, L.tok_log, self._t_idx, self._pick_counter,
+                                      x_packed=self.parts[0].x_p if packed else None, loop_ctl=L.ctl)
                 return att
             if fused_pick:
                 # K6e: the same epilogue with the first n_sampled quantizers drawn by top-k / temperature sampling
-                ops.sample_pick_embed(lg, emb.weight, y_buf, self._tok_log, self._t_idx, self._pick_counter, n_sampled, k,
-                                      temp, seed=seed, x_packed=self.parts[0].x_p if packed else None)
+                ops.sample_pick_embed(lg, emb.weight, y_buf, L.tok_log, self._t_idx, self._pick_counter, n_sampled, k,
+                                      temp, seed=0, x_packed=self.parts[0].x_p if packed else None, loop_ctl=L.ctl)
                 return att
             if n_sampled == 0:
                 pick = ops.argmax_rows(lg)
@@ -549,17 +607,24 @@ class DecodeEngine:
                 pick = torch.where(is_sampled, ops.topk_sample_rows(lg, k, temp, seed=seed, step=self._t_idx),
                                    ops.argmax_rows(lg))
             pick = pick.t().contiguous()                                                      # [Q,B]
-            self._tok_log.index_copy_(0, self._t_idx, pick.unsqueeze(0))
+            L.tok_log.index_copy_(0, self._t_idx, pick.unsqueeze(0))
+            # the stop bookkeeping of K6d / K6e as torch ops on the same control block (reference modeling_lina.py:168-173)
+            rows = L.ctl[R:R + self.B]
+            rows.copy_(torch.maximum(rows, (pick == 2).all(dim=0).to(torch.int32)))
+            L.ctl[0:1].copy_(rows.sum().to(torch.int32).view(1))
+            first = (L.ctl[0:1] >= self.B) & (L.ctl[1:2] < 0)
+            L.ctl[1:2].copy_(torch.where(first, self._t_idx.to(torch.int32), L.ctl[1:2]))
             self._t_idx.add_(1)
             ops.embed_sum(emb.weight, pick, out=y_buf)              # next step's input, written in place
             return att
 
-        self._greedy_body = body
-        self._greedy_graph = None
-        self._greedy_graph_n = None
+        L.body = body
         if self.use_graph:
             snap, y_keep = self._snapshot(), y_buf.clone()
             xp_keep = self.parts[0].x_p.clone() if packed else None
+            t_keep, o_keep = self._t_idx.clone(), self._origin.clone()
+            self._t_idx.zero_()
+            self._origin.zero_()
             side = torch.cuda.Stream(device=self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
@@ -570,21 +635,63 @@ class DecodeEngine:
             y_buf.copy_(y_keep)
             if packed:
                 self.parts[0].x_p.copy_(xp_keep)
-            self._tok_log.zero_()
-            self._t_idx.zero_()
+            self._t_idx.copy_(t_keep)
+            self._origin.copy_(o_keep)
+            self._pick_counter.zero_()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
-                self._greedy_att = body()
-            self._greedy_graph = g
+                L.att = body()
+            L.graph1 = g
+        return L
+
+    # names older callers / tests look at
+    @property
+    def _greedy_graph(self):
+        return None if self._loop is None else self._loop.graph1
+
+    @property
+    def _greedy_graph_n(self):
+        return None if self._loop is None else self._loop.graphN
+
+    @property
+    def _tok_log(self):
+        return self._loop.tok_log
+
+    def preload(self, tokens: torch.Tensor, atts: Optional[torch.Tensor] = None):
+        """File the steps a prefill produced in front of the loop: ``tokens [Q,B,t0]`` (and ``atts [B,2,t0,Ttxt]``) go
+        into the logs at 0 .. t0-1 and the control block learns which rows have already emitted the stop token --
+        everything ``begin_greedy(t0=...)`` needs to continue as if it had run those steps itself."""
+        L = self._loop
+        t0 = tokens.shape[2]
+        if t0 != self._t0:
+            raise ValueError("preload: the number of steps must equal begin_greedy's t0")
+        L.tok_log[:t0].copy_(tokens.permute(2, 0, 1))
+        if L.att_log is not None and atts is not None:
+            L.att_log[:, :, :t0].copy_(atts)
+        is_stop = (tokens == 2).all(dim=0)                                     # [B,t0]
+        seen = is_stop.cummax(dim=1).values                                     # row has stopped at or before step t
+        all_seen = seen.all(dim=0)                                              # [t0]
+        R = ops.LOOP_CTL_ROWS
+        L.ctl[R:R + self.B].copy_(seen[:, -1].to(torch.int32))
+        L.ctl[0:1].copy_(seen[:, -1].sum().to(torch.int32).view(1))
+        first = torch.where(all_seen.any(), all_seen.to(torch.int32).argmax().to(torch.int32),
+                            torch.full((), -1, dtype=torch.int32, device=tokens.device))
+        L.ctl[1:2].copy_(first.view(1))
+
+    def stop_step(self) -> int:
+        """First step at which every row had emitted the stop token (the step the reference's loop breaks at), -1 if
+        that has not happened.  Reads 4 bytes back (host sync)."""
+        return int(self._loop.ctl[1])
 
     def greedy_step(self):
         """Enqueue one token for every row (no host sync). Returns the step's attention weights
-        (a static buffer: clone to keep)."""
+        (a static buffer: clone to keep; stale when the loop files them into its att log itself)."""
         self._n_done += 1
-        if self._greedy_graph is not None:
-            self._greedy_graph.replay()
-            return self._greedy_att
-        return self._greedy_body()
+        L = self._loop
+        if L.graph1 is not None:
+            L.graph1.replay()
+            return L.att
+        return L.body()
 
     GRAPH_STEPS = 8          # tokens per replay of the multi-step graph (greedy_steps)
 
@@ -594,15 +701,16 @@ class DecodeEngine:
         graph pays per token); the remainder token by token.  The window position of K1w and the token log index come
         from the device step counter, so the same captured graph is valid at any position."""
         N = self.GRAPH_STEPS
-        if self._greedy_graph is not None and n >= N:
-            if self._greedy_graph_n is None:                 # captured on first use (stream capture executes nothing)
+        L = self._loop
+        if L.graph1 is not None and n >= N:
+            if L.graphN is None:                             # captured on first use (stream capture executes nothing)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
                     for _ in range(N):
-                        self._greedy_body()
-                self._greedy_graph_n = g
+                        L.body()
+                L.graphN = g
             while n >= N:
-                self._greedy_graph_n.replay()
+                L.graphN.replay()
                 self._n_done += N
                 n -= N
         for _ in range(n):
@@ -610,18 +718,101 @@ class DecodeEngine:
 
     def greedy_tokens(self):
         """Tokens produced so far: [Q,B,n]."""
-        return self._tok_log[:self._n_done].permute(1, 2, 0).contiguous()
+        return self._loop.tok_log[:self._n_done].permute(1, 2, 0).contiguous()
+
+    def logged_atts(self, n: Optional[int] = None):
+        """The attention log of a loop armed with ``log_att``: [B,2,n,Ttxt]."""
+        n = self._n_done if n is None else n
+        return self._loop.att_log[:, :, :n].contiguous()
+
+    # ------------------------------------------------------------------ engine reuse
+    def reset(self, x_enc: Optional[torch.Tensor] = None, state: Optional[Cache] = None):
+        """Back to the start of an utterance batch: recurrent states and conv caches zeroed (or copied from ``state``, a
+        Cache of the reference layout), and -- with ``x_enc`` -- the text side of the cross-attention recomputed into the
+        engine's static buffers.  The captured graphs stay valid: they only know buffer addresses."""
+        if x_enc is not None:
+            if x_enc.shape[1] != self.Tn:
+                raise ValueError("reset: the text length is part of the captured step (build another engine)")
+            kk, vv, _ = self.ca.prepare(x_enc)
+            self._kk.copy_(kk.squeeze(1))
+            self._vv.copy_(vv.squeeze(1))
+        self._lazy_live = False                       # pending window steps of the previous utterances are dropped
+        for li, st in enumerate(self._state.states):
+            for j, dst in enumerate(st):
+                if state is None:
+                    dst.zero_()
+                else:
+                    dst.copy_(state.states[li][j])
+        for P in self._all_packs():
+            P.counters.zero_()
+        self._n_done = self._origin_host = 0
+        self._t_idx.zero_()
+        self._origin.zero_()
+
+    @torch.inference_mode()
+    def generate(self, max_seqlen: int, y0: Optional[torch.Tensor] = None, k: int = 1, temp: float = 1.0,
+                 first_greedy_quant: int = 0, seed: int = 0, force_max_seqlen: bool = False,
+                 stop_check_every: int = 16, log_att: bool = True, preload=None):
+        """The loop of the reference's ``generate_batch`` (model/modeling_lina.py:152-179) on the device: up to
+        ``max_seqlen`` steps in replays of GRAPH_STEPS tokens; every ``stop_check_every`` steps 8 bytes of the control
+        block are copied to pinned host memory BEHIND the queued work, and the copy issued one check earlier is looked at
+        -- the GPU always has the next group of steps queued, the host never waits for the step it has just enqueued.
+        When the block says that every row has stopped, the loop ends; up to two groups of steps may have run past that
+        point, and the logs are trimmed to the exact length the reference's per-step check produces.
+        ``preload`` = (tokens [Q,B,t0], atts [B,2,t0,Ttxt]) of a prompt prefill.  Returns (qs [Q,B,n], atts [B,2,n,Ttxt]
+        or None, n)."""
+        t0 = 0 if preload is None else int(preload[0].shape[2])
+        self.begin_greedy(max_seqlen, y0, k=k, temp=temp, seed=seed, first_greedy_quant=first_greedy_quant,
+                          log_att=log_att, t0=t0)
+        if preload is not None:
+            self.preload(*preload)
+        L = self._loop
+        total = max(max_seqlen - t0, 0)
+        if force_max_seqlen:
+            self.greedy_steps(total)
+            n = t0 + total
+        else:
+            N = self.GRAPH_STEPS
+            every = max(int(stop_check_every), 1)
+            every = (every + N - 1) // N * N if L.graph1 is not None else every
+            stop_at, done, prev = -1, 0, None
+            if preload is not None:
+                stop_at = self.stop_step()                  # the prefill may already have seen every row stop
+            cuda = self.dev.type == "cuda"
+            if cuda and self._pin is None:
+                self._pin = [torch.empty(2, dtype=torch.int32).pin_memory() for _ in range(2)]
+                self._pin_ev = [torch.cuda.Event() for _ in range(2)]
+            while stop_at < 0 and done < total:
+                n_now = min(every, total - done)
+                self.greedy_steps(n_now)
+                done += n_now
+                if not cuda:
+                    stop_at = self.stop_step()
+                    continue
+                if prev is not None:                        # the check issued BEFORE the group just enqueued
+                    self._pin_ev[prev].synchronize()
+                    stop_at = int(self._pin[prev][1])
+                    if stop_at >= 0:
+                        break
+                if done < total:
+                    slot = 1 if prev == 0 else 0
+                    self._pin[slot].copy_(L.ctl[:2], non_blocking=True)
+                    self._pin_ev[slot].record()
+                    prev = slot
+            if stop_at < 0:
+                stop_at = self.stop_step()
+            n = min(stop_at + 1, t0 + done) if stop_at >= 0 else t0 + done
+        qs = L.tok_log[:n].permute(1, 2, 0).contiguous()
+        atts = L.att_log[:, :, :n].contiguous() if L.att_log is not None else None
+        return qs, atts, n
 
     @torch.inference_mode()
     def run_greedy(self, n_steps: int, y0: Optional[torch.Tensor] = None, record_att: bool = False, **sampling):
         """Decode ``n_steps`` tokens on the device (greedy unless ``k``/``temp``/``seed``/``first_greedy_quant``
         say otherwise, see begin_greedy). Returns tokens [Q,B,n_steps] (and atts [B,2,n,Ttxt])."""
-        self.begin_greedy(n_steps, y0, **sampling)
-        atts = []
+        self.begin_greedy(n_steps, y0, log_att=record_att, **sampling)
         for _ in range(n_steps):
-            att = self.greedy_step()
-            if record_att:
-                atts.append(att.clone())
+            self.greedy_step()
         toks = self.greedy_tokens()
         self.sync_state()
-        return (toks, torch.cat(atts, dim=2)) if record_att else toks
+        return (toks, self.logged_atts(n_steps)) if record_att else toks

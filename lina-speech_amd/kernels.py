@@ -10,6 +10,7 @@ import torch
 from . import backend as _backend
 from .backend import _bht, _check, _dt, _inner_contig, _no_grad, _ptr, _workspace, fused_ops_available
 from .policy import POLICY, _value_blocks, chunk_segments
+from ._lib import LOOP_CTL_ROWS
 
 
 # --------------------------------------------------------------------------- GLA (K1 / K2 / K2b)
@@ -261,7 +262,26 @@ def argmax_rows(logits, out=None):
     return out.view(logits.shape[:-1])
 
 
-def greedy_pick_embed(logits, table, x_out, tok_log, step, counter, x_packed=None):
+def _loop_ctl_ptr(be, loop_ctl, B):
+    if loop_ctl is None:
+        return None
+    be.require(loop_ctl)
+    if loop_ctl.dtype != torch.int32 or not loop_ctl.is_contiguous() or loop_ctl.numel() < LOOP_CTL_ROWS + B:
+        raise ValueError("loop_ctl must be a contiguous int32 tensor of LOOP_CTL_ROWS + B words (new_loop_ctl)")
+    return _ptr(loop_ctl)
+
+
+def new_loop_ctl(B: int, device, seed_word: int = 0) -> torch.Tensor:
+    """A fresh loop-control block (include/lina_gla.h): no row stopped, stop step -1, the per-call seed word."""
+    host = torch.zeros(LOOP_CTL_ROWS + B, dtype=torch.int32)
+    host[1] = -1
+    lo, hi = seed_word & 0xFFFFFFFF, (seed_word >> 32) & 0xFFFFFFFF
+    host[2] = lo - (1 << 32) if lo >= (1 << 31) else lo
+    host[3] = hi - (1 << 32) if hi >= (1 << 31) else hi
+    return host.to(device)
+
+
+def greedy_pick_embed(logits, table, x_out, tok_log, step, counter, x_packed=None, loop_ctl=None):
     """K6d (lina_greedy_pick_embed): arg-max per quantizer of ``logits [B, Q, L]``, the picks logged at
     ``tok_log[step[0]]`` ([max_steps, Q, B] int64), the next input ``x_out [B, d] = sum_q table[q, pick_q]`` and
     ``step[0] += 1`` -- one launch.  ``counter``: int32 [1], zero."""
@@ -282,12 +302,13 @@ def greedy_pick_embed(logits, table, x_out, tok_log, step, counter, x_packed=Non
         raise ValueError("packed x buffer is too small")
     _check(be.lib.lina_greedy_pick_embed(_ptr(logits), logits.stride(0), _ptr(table.contiguous()), _ptr(x_out), _ptr(x_packed),
                                          _ptr(tok_log),
-                                         _ptr(step), _ptr(counter), B, Q, L, n_emb, d, tok_log.shape[0], _dt(table),
+                                         _ptr(step), _ptr(counter), _loop_ctl_ptr(be, loop_ctl, B), B, Q, L, n_emb, d,
+                                         tok_log.shape[0], _dt(table),
                                          be.stream(table)))
 
 
 def sample_pick_embed(logits, table, x_out, tok_log, step, counter, n_sampled: int, k: int, temp: float = 1.0,
-                      seed: int = 0, x_packed=None):
+                      seed: int = 0, x_packed=None, loop_ctl=None):
     """K6e (lina_sample_pick_embed): greedy_pick_embed for the reference's default generation mode -- quantizers
     ``q < n_sampled`` are sampled (top-``k``, temperature, the draw of row ``b*Q + q`` of topk_sample_rows at the same
     (seed, step)), the others take the arg-max; token log, next-input embedding and ``step[0] += 1`` in the same launch."""
@@ -306,7 +327,8 @@ def sample_pick_embed(logits, table, x_out, tok_log, step, counter, n_sampled: i
     if x_packed is not None and x_packed.numel() < packed_numel(B, d):
         raise ValueError("packed x buffer is too small")
     _check(be.lib.lina_sample_pick_embed(_ptr(logits), logits.stride(0), _ptr(table.contiguous()), _ptr(x_out),
-                                         _ptr(x_packed), _ptr(tok_log), _ptr(step), _ptr(counter), B, Q, L, n_emb, d,
+                                         _ptr(x_packed), _ptr(tok_log), _ptr(step), _ptr(counter),
+                                         _loop_ctl_ptr(be, loop_ctl, B), B, Q, L, n_emb, d,
                                          tok_log.shape[0], int(n_sampled), int(k), float(temp),
                                          int(seed) & 0xFFFFFFFFFFFFFFFF, _dt(table), be.stream(table)))
 
@@ -650,7 +672,17 @@ def softmax_weighted_rows_add(scores, scale, att, vv, x, x_packed=None):
                                                  _ptr(vv), _ptr(x), _ptr(x_packed), B, Tn, d, _dt(vv), be.stream(vv)))
 
 
-def pe_softmax_weighted_rows_add(xp, pe, scale, att, vv, x, x_packed=None, xp_is_packed: bool = False):
+def _att_log_args(att, att_step, att_step_stride, att_steps):
+    """(step pointer, stride, number of steps) of the att-log form of the cross-attention launches (lina_gla.h)."""
+    if att_step is None:
+        return None, 0, 0
+    if att_step.dtype != torch.int64 or att_step.numel() < 1:
+        raise TypeError("att_step must be a device int64 step counter")
+    return _ptr(att_step), int(att_step_stride), int(att_steps)
+
+
+def pe_softmax_weighted_rows_add(xp, pe, scale, att, vv, x, x_packed=None, xp_is_packed: bool = False,
+                                 att_step=None, att_step_stride: int = 0, att_steps: int = 0):
     """The last two launches of the cross-attention step as one (round 4):  sc[b,t] = <xp[b,:], pe[t,:]> rounded to the model
     dtype, att[b,:Tn] = softmax(sc[b,:Tn] * scale), x[b,:] += att[b,:] . vv[b].  ``xp``: [B,d] row-major, or the
     fragment-major buffer when ``xp_is_packed``; ``x_packed``: the residual stream in fragment-major form."""
@@ -661,12 +693,14 @@ def pe_softmax_weighted_rows_add(xp, pe, scale, att, vv, x, x_packed=None, xp_is
         raise TypeError("xp / pe / att / vv must share the model dtype")
     if pe.shape[0] < Tn or pe.shape[1] != d or pe.stride(1) != 1 or pe.stride(0) != d:
         raise ValueError("pe must be a contiguous [>= T_txt, d] table")
+    be.require(att_step)
     _check(be.lib.lina_pe_softmax_weighted_rows_add(_ptr(xp), 1 if xp_is_packed else 0, _ptr(pe), float(scale), _ptr(att),
-                                                    att.stride(0), _ptr(vv), _ptr(x), _ptr(x_packed), B, Tn, d, _dt(vv),
+                                                    att.stride(0), *_att_log_args(att, att_step, att_step_stride, att_steps),
+                                                    _ptr(vv), _ptr(x), _ptr(x_packed), B, Tn, d, _dt(vv),
                                                     be.stream(vv)))
 
 
-def softmax_pe_rows(scores, att, pe, xp, xp_packed=None):
+def softmax_pe_rows(scores, att, pe, xp, xp_packed=None, att_step=None, att_step_stride: int = 0, att_steps: int = 0):
     """att[b,:Tn] = softmax(scores[b,:Tn]) (fp32 scores, already scaled);  xp[b,:] = att[b,:] . pe[:Tn,:] -- one launch;
     ``xp_packed``: also the fragment-major copy of xp (the A operand of the next projection)."""
     be = _backend._BACKEND
@@ -679,7 +713,9 @@ def softmax_pe_rows(scores, att, pe, xp, xp_packed=None):
         raise TypeError("att / pe / xp must share the model dtype; pe [>= Tn, d] and xp [B, d] contiguous")
     if xp_packed is not None and xp_packed.numel() < packed_numel(B, d):
         raise ValueError("packed xp buffer is too small")
-    _check(be.lib.lina_softmax_pe_rows(_ptr(scores), scores.stride(0), _ptr(att), att.stride(0), _ptr(pe), _ptr(xp),
+    be.require(att_step)
+    _check(be.lib.lina_softmax_pe_rows(_ptr(scores), scores.stride(0), _ptr(att), att.stride(0),
+                                       *_att_log_args(att, att_step, att_step_stride, att_steps), _ptr(pe), _ptr(xp),
                                        _ptr(xp_packed), B, Tn, d, _dt(pe), be.stream(pe)))
 
 

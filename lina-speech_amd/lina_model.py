@@ -77,11 +77,48 @@ class LinaModel(nn.Module):
         return logits, loss, att, masked_logits, masked_target
 
     # ------------------------------------------------------------------ batched decode
+    _ENGINE_CACHE_SIZE = 2
+
+    def clear_decode_cache(self):
+        """Drop the cached decode engines (packed weights, static buffers, captured hipGraphs).  The cache is keyed on
+        every parameter's (storage, version), so optimizer steps and ``load_state_dict`` invalidate it by themselves;
+        writes through ``param.data`` do not bump the version -- call this after them."""
+        self.__dict__.pop("_decode_engines", None)
+
+    def _decode_engine(self, x_enc: Tensor, B: int, init_state):
+        """The DecodeEngine of (batch size, text length, dtype, device, current weights), built once and re-armed for
+        every later ``generate_batch`` call of the same shape: construction packs 0.3 GB of weights and captures two
+        hipGraphs (~0.6 k kernel nodes), far more than a call at B = 64 should pay."""
+        from .decode import DecodeEngine
+        w = self.logits_head.weight
+        key = (B, int(x_enc.shape[1]), w.dtype, str(w.device),
+               tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        cache = self.__dict__.setdefault("_decode_engines", {})
+        eng = cache.pop(key, None)
+        if eng is None:
+            eng = DecodeEngine(self, x_enc, batch_size=B)            # NotImplementedError: architecture not covered
+            if init_state is not None:
+                eng.reset(state=init_state)
+        else:
+            eng.reset(x_enc, state=init_state)
+        cache[key] = eng                                             # most recently used last
+        while len(cache) > self._ENGINE_CACHE_SIZE:
+            cache.pop(next(iter(cache)))
+        return eng
+
     @torch.inference_mode()
     def generate_batch(self, x: Tensor, batch_size: int = 3, prompt: Optional[Tensor] = None, device: str = "cpu",
                        max_seqlen: int = 1000, k: int = 100, first_greedy_quant: int = 1, temp: float = 1.0,
                        init_state=None, force_max_seqlen: bool = False, stop_check_every: int = 16,
-                       engine: Optional[str] = None):
+                       engine: Optional[str] = None, seed: Optional[int] = None):
+        """Reference model/modeling_lina.py:111-192 (same arguments, same four returns).  ``engine``:
+          None / "auto" -- the device-side loop (decode.DecodeEngine.generate: one hipGraph replay per 8 tokens, picks /
+                           stop flags / attention log / next-token embedding inside the graph) when the architecture is
+                           one it covers, else the module path;
+          "loop"        -- the device-side loop or an error;   "fused" -- the fused step, one graph replay per token, picks
+                           on the host side;   "module" -- ``AttentiveGLA.step`` + logits head per token (unfused).
+        ``seed`` feeds the device-side sampler of the loop (default: drawn from torch's generator, so
+        ``torch.manual_seed`` makes a call reproducible, like the reference's multinomial)."""
         B, Q = batch_size, self.n_quant
         x = (x.unsqueeze(0).expand(B, -1) if x.dim() == 1 else x).to(device)   # 1-D: one text for every row
         x_enc = self.txt_encoder(self.txt_embed(x))
@@ -96,7 +133,20 @@ class LinaModel(nn.Module):
             if self.spk_encoder is not None:
                 prompt[:, 0] = self.spk_encoder(prompt)
 
-        if engine == "fused":
+        mode = engine or "auto"
+        if mode not in ("auto", "loop", "fused", "module"):
+            raise ValueError("engine must be None, 'auto', 'loop', 'fused' or 'module'")
+        eng = None
+        if mode in ("auto", "loop"):
+            try:
+                eng = self._decode_engine(x_enc, B, init_state)
+            except NotImplementedError:
+                if mode == "loop":
+                    raise
+                mode = "module"
+        if eng is not None:
+            state, prepared, step_fn = eng.state, None, None
+        elif mode == "fused":
             from .decode import DecodeEngine
             step_fn = DecodeEngine(self, x_enc, batch_size=B, state=init_state)
             state = step_fn.state
@@ -122,6 +172,26 @@ class LinaModel(nn.Module):
             h, pre_att, _ = self.attentive_rnn.step(y_seq, x_enc, 0, state, prepared=prepared)
             pre_logits = self.logits_head(h)                        # [B,n_pre,Q,L]
 
+        def pick_tokens(logits):                                    # [B,1,Q,L] -> [Q,B,1]
+            per_q = logits.squeeze(1).transpose(0, 1)               # [Q,B,L]
+            return torch.stack([topk_sampling(per_q[i], k=k, temp=temp) if i < first_greedy_quant
+                                else topk_sampling(per_q[i], k=1) for i in range(Q)])
+
+        if eng is not None:
+            # ---- the device-side loop: the prefill's positions are picked here and filed in front of it
+            preload = None
+            y0 = y_embd
+            if n_pre > 0:
+                pre_q = torch.cat([pick_tokens(pre_logits[:, t:t + 1]) for t in range(n_pre)], dim=2)   # [Q,B,n_pre]
+                preload = (pre_q, pre_att)
+                y0 = prompt[:, [n_pre - 1]] if n_pre - 1 < p_len else self.rvq_embed.embed_sum(pre_q[:, :, -1:])
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)))
+            qs, atts, n = eng.generate(max_seqlen, y0, k=k, temp=temp, first_greedy_quant=first_greedy_quant, seed=seed,
+                                       force_max_seqlen=force_max_seqlen, stop_check_every=stop_check_every,
+                                       log_att=True, preload=preload)
+            return self._finish_generate(qs, atts, (qs == 2).all(dim=0), B, device)
+
         all_stop = torch.zeros(B, 1, dtype=torch.bool, device=device)
         qs, atts, stop_tokens = [], [], []
         stop_at = None                      # first step index at which every row had stopped
@@ -131,10 +201,7 @@ class LinaModel(nn.Module):
             else:
                 logits, att = step_fn(y_embd, t)                # [B,1,Q,L], [B,2,1,Ttxt]
             atts.append(att)
-            per_q = logits.squeeze(1).transpose(0, 1)           # [Q,B,L]
-            picks = [topk_sampling(per_q[i], k=k, temp=temp) if i < first_greedy_quant
-                     else topk_sampling(per_q[i], k=1) for i in range(Q)]
-            q_sampled = torch.stack(picks)                      # [Q,B,1]
+            q_sampled = pick_tokens(logits)                     # [Q,B,1]
             qs.append(q_sampled)
             is_stop = (q_sampled == 2).all(dim=0)               # every quantizer emitted the stop token
             stop_tokens.append(is_stop)
@@ -150,13 +217,22 @@ class LinaModel(nn.Module):
             qs, atts, stop_tokens = qs[:stop_at + 1], atts[:stop_at + 1], stop_tokens[:stop_at + 1]
         atts = torch.cat(atts, dim=2) if atts[0] is not None else None
         qs = torch.stack(qs, dim=2).squeeze(-1)                                  # [Q,B,n]
-        stop_tokens = torch.stack([s.float() for s in stop_tokens] + [torch.ones(B, 1, device=device)],
-                                  dim=1).squeeze(-1)
+        return self._finish_generate(qs, atts, torch.cat(stop_tokens, dim=1), B, device)
+
+    def _finish_generate(self, qs, atts, is_stop, B, device):
+        """Post-processing of the reference (modeling_lina.py:180-192) from the [B,n] stop flags: the stop-flag matrix
+        with the closing column of ones, the un-delayed codes and the per-row cuts.  The reference takes
+        ``torch.unique(stop_idx[i])[1]`` row by row (a sort and a host read per row); the set it sorts is {0} plus the
+        positions of the row's stop flags, so element [1] is the first position >= 1 that carries a flag -- computed here
+        for all rows at once and read back once."""
+        stop_tokens = torch.cat([is_stop.float(), torch.ones(B, 1, device=device)], dim=1)    # [B,n+1]
         n = stop_tokens.shape[1]
         rvq = (undelay_rvq(qs) - self.n_special_token_in).clamp_min(0)
-        stop_idx = (stop_tokens * torch.arange(n, device=device)[None, :]).long()
-        cuts = []
-        for i in range(B):
-            idx = torch.unique(stop_idx[i])[1]
-            cuts.append((rvq[:, [i], :idx - self.n_quant], None if atts is None else atts[i, :, :idx]))
+        pos = torch.arange(n, device=device)[None, :].expand(B, -1)
+        flagged = (stop_tokens != 0) & (pos >= 1)
+        if n < 2:
+            raise IndexError("generate_batch: no step was decoded (max_seqlen == 0)")   # the reference's unique()[1] raises too
+        first = torch.where(flagged, pos, torch.full_like(pos, n)).min(dim=1).values.tolist()
+        cuts = [(rvq[:, i:i + 1, :idx - self.n_quant], None if atts is None else atts[i, :, :idx])
+                for i, idx in enumerate(first)]
         return qs, atts, stop_tokens, cuts

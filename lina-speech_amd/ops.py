@@ -23,7 +23,7 @@ from .policy import (
     _MLP_PAD)
 from .kernels import (
     _gla_prepare, _head_first_empty, _gla_launch, gla_chunk_bwd, _short_conv_launch, _sum_partials, _sum_partials2,
-    column_sum, _sum_vector, _embed_sum_launch, argmax_rows, greedy_pick_embed, sample_pick_embed, topk_sample_rows,
+    column_sum, _sum_vector, _embed_sum_launch, argmax_rows, new_loop_ctl, LOOP_CTL_ROWS, greedy_pick_embed, sample_pick_embed, topk_sample_rows,
     gla_decode_prologue, swiglu, gla_decode_update, _kstep, packed_numel, pack_rows, unpack_rows,
     linear_skinny_packed, linear_skinny, gla_decode_inproj, gla_decode_inproj_packed, gla_decode_update_norm,
     gla_decode_window, gla_decode_window_flush, cross_att_step1, cross_att_step2, cross_scores,

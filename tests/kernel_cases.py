@@ -495,6 +495,53 @@ def check_greedy_pick_embed(dev, B, Q, L, d, dtype, steps=3):
         assert_close(x, rx, 1e-2 if dtype == torch.bfloat16 else 1e-6, "K6d next-input embedding")
 
 
+def check_pick_loop_ctl(dev, B, Q, L, d, dtype, sampled=False):
+    """The loop-control block of K6d / K6e (include/lina_gla.h): rows that picked the stop token (id 2) on EVERY quantizer are
+    counted once, word [1] = the first step at which all rows have -- the reference's is_stop_token / all_stop_token / break
+    of model/modeling_lina.py:168-173 replayed on the host from the same logits; and (K6e) the per-call seed word: a block
+    carrying word w with seed s draws what a block-less call draws with seed s ^ w."""
+    g = torch.Generator().manual_seed(53)
+    n_emb = L + 3
+    table = torch.randn(Q, n_emb, d, generator=g).to(dtype).to(dev)
+    steps = 6
+    tok_log = torch.zeros(steps, Q, B, dtype=torch.int64, device=dev)
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    word = 0x9E3779B97F4A7C15
+    ctl = ops.new_loop_ctl(B, dev, word if sampled else 0)
+    R = ops.LOOP_CTL_ROWS
+    assert ctl.tolist()[:2] == [0, -1]
+    stop_plan = {0: [0], 1: [], 2: [0, 1], 3: list(range(1, B - 1)), 4: [B - 1], 5: [0]}     # rows forced to stop per step
+    seen = torch.zeros(B, dtype=torch.bool)
+    first_all = -1
+    for t in range(steps):
+        logits = torch.randn(B, Q, L, generator=g).to(dtype)
+        logits[:, :, 2] = -40.0                                   # nobody picks the stop token by chance ...
+        for b in stop_plan[t]:
+            logits[b, :, 2] = 40.0                                # ... these rows pick it on every quantizer
+        if B > 1 and Q > 1:
+            logits[B - 1, 0, 2] = 40.0 if t == 1 else logits[B - 1, 0, 2]     # one quantizer only: NOT a stop
+        logits = logits.to(dev)
+        x = torch.empty(B, d, dtype=dtype, device=dev)
+        if sampled:
+            ref = ops.topk_sample_rows(logits, 3, 0.7, seed=5 ^ word, step=step.clone()).t().contiguous()      # [Q,B]
+            ops.sample_pick_embed(logits, table, x, tok_log, step, counter, Q, 3, 0.7, seed=5, loop_ctl=ctl)
+            assert torch.equal(tok_log[t], ref), "seed word: the draws differ from those of seed ^ word"
+        else:
+            ops.greedy_pick_embed(logits, table, x, tok_log, step, counter, loop_ctl=ctl)
+        picks = tok_log[t].cpu()                                                   # [Q,B]
+        is_stop = (picks == 2).all(dim=0)
+        for b in stop_plan[t]:
+            assert bool(is_stop[b])
+        seen |= is_stop
+        if first_all < 0 and bool(seen.all()):
+            first_all = t
+        got = ctl.cpu().tolist()
+        assert got[0] == int(seen.sum()) and got[1] == first_all, (t, got[:2], int(seen.sum()), first_all)
+        assert got[R:R + B] == seen.int().tolist()
+    assert first_all == 4
+
+
 def check_sample_pick_embed(dev, B, Q, L, d, dtype, n_sampled, k=7, temp=0.8, seed=11, steps=4):
     """K6e: the one-launch token epilogue with the first ``n_sampled`` quantizers sampled.  Picks must EQUAL the separate
     launches it replaces at the same (seed, device step): K6c over the [B*Q] rows for the sampled quantizers (itself checked
@@ -1280,6 +1327,21 @@ def check_cross_fused(dev, B, Tn, d, dtype):
         xp_p, x_p = ops.pack_rows(xp), ops.pack_rows(x0)
         ops.pe_softmax_weighted_rows_add(xp_p, pe, scale, att_d[:, 1, 0], vv, x0.clone(), x_packed=x_p, xp_is_packed=True)
         assert torch.equal(ops.unpack_rows(x_p, B, d), x_d), "packed form of the pe-scores fusion differs from the row-major one"
+        # att-log form (round 5): second attention's row filed at log[b, 1, step[0], :]
+        cap = 4
+        log = torch.full((B, 2, cap, Tn), 7.0, dtype=dtype, device=dev)
+        step = torch.zeros(1, dtype=torch.int64, device=dev)
+        for t in (2, cap):
+            step.fill_(t)
+            before = log.clone()
+            x_e = x0.clone()
+            ops.pe_softmax_weighted_rows_add(xp, pe, scale, log[:, 1, 0], vv, x_e, att_step=step,
+                                             att_step_stride=log.stride(2), att_steps=cap)
+            assert torch.equal(x_e, x_d)
+            if t < cap:
+                assert torch.equal(log[:, 1, t], att_d[:, 1, 0])
+                before[:, 1, t] = att_d[:, 1, 0]
+            assert torch.equal(log, before), "att log: something else was written"
 
 
 def check_softmax_pe_rows(dev, B, Tn, d, dtype):
@@ -1301,6 +1363,20 @@ def check_softmax_pe_rows(dev, B, Tn, d, dtype):
     assert_close(xp, a_model @ pe[:Tn].cpu().to(F64), tol, "softmax_pe_rows xp")
     if xp_p is not None:
         assert torch.equal(ops.unpack_rows(xp_p, B, d), xp), "packed copy of xp differs"
+    # att-log form (round 5): the same row filed at log[b, 0, step[0], :]; a step outside the log is dropped
+    cap = 5
+    log = torch.full((B, 2, cap, Tn), 7.0, dtype=dtype, device=dev)
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    for t in (3, 0, cap, -1):
+        step.fill_(t)
+        before = log.clone()
+        xp2 = torch.empty_like(xp)
+        ops.softmax_pe_rows(scores, log[:, 0, 0], pe, xp2, None, att_step=step, att_step_stride=log.stride(2), att_steps=cap)
+        assert torch.equal(xp2, xp)
+        if 0 <= t < cap:
+            assert torch.equal(log[:, 0, t], att[:, 0, 0]), f"att log row at step {t}"
+            before[:, 0, t] = att[:, 0, 0]
+        assert torch.equal(log, before), "att log: something else was written"
 
 
 def check_dwconv7_ln(dev, B, L, C, dtype, ada=False):

@@ -197,6 +197,99 @@ def check_engine_sampling(dev, n_steps=10, k=20, temp=0.9, seed=77):
     assert compared >= 2 * n_steps
 
 
+def check_generate_batch_loop(dev, rel=REL, full=True):
+    """a-10: ``LinaModel.generate_batch`` with NO engine argument runs the device-side loop (decode.DecodeEngine.generate:
+    picks, stop flags, attention log and next-token embedding inside the step, stop test read back every few steps) and
+    returns what the per-token module path returns with the reference's per-step stop test (model/modeling_lina.py:152-192):
+    token ids, stop flags and cut lengths exactly, attention rows within ``rel`` -- on a model whose stop-token head row is
+    scaled up so that rows stop early and at DIFFERENT steps, with and without a codec prompt; the engine (packed weights,
+    captured graphs) is built once per (batch, text length) and re-armed for other texts, and rebuilt when a weight changes."""
+    g = load_golden("lina_d64.npz")
+    model = build_lina()
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    with torch.no_grad():
+        model.logits_head.weight[0, 2] *= 6.0
+    model = model.to(dev).eval()
+    B = 4
+    seen_n, engines = set(), []
+    cases = ((1, 0, 4), (4, 0, 4), (2, 3, 8), (3, 0, 16), (1, 0, 1)) if full else ((4, 0, 4), (2, 3, 8), (3, 0, 16))
+    for ci, (seed, prompt_len, every) in enumerate(cases):
+        gen = torch.Generator().manual_seed(seed)
+        x = torch.randint(3, 256, (B, 9), generator=gen).to(dev)
+        prompt = torch.randint(0, 250, (1, 1, prompt_len), generator=gen).to(dev) if prompt_len else None
+        kw = dict(batch_size=B, prompt=prompt, max_seqlen=48 if full else 20, k=1, first_greedy_quant=0, device=dev)
+        ref = model.generate_batch(x, engine="module", stop_check_every=1, **kw)
+        got = model.generate_batch(x, stop_check_every=every, **kw)
+        engines.append(next(reversed(model._decode_engines.values())))
+        assert torch.equal(got[0], ref[0]), f"token ids differ (seed {seed})"
+        assert torch.equal(got[2], ref[2]), "stop flags differ"
+        close(got[1], ref[1], "generate_batch loop atts", rel)
+        assert [c[0].shape for c in got[3]] == [c[0].shape for c in ref[3]]
+        for cg, cr in zip(got[3], ref[3]):
+            assert torch.equal(cg[0], cr[0]) and cg[1].shape == cr[1].shape
+        seen_n.add(int(got[0].shape[-1]))
+        assert got[0].shape[-1] < 20, "this model must stop early"
+        if ci and not full:
+            continue
+        forced = model.generate_batch(x, force_max_seqlen=True, **{**kw, "max_seqlen": 11})
+        assert forced[0].shape[-1] == 11 and torch.equal(forced[0][:, :, :min(11, got[0].shape[-1])],
+                                                        got[0][:, :, :11])
+    assert len(seen_n) >= (3 if full else 2), seen_n
+    assert all(e is engines[0] for e in engines), "same (batch, text length, weights): one engine, re-armed"
+    with torch.no_grad():
+        model.logits_head.weight[0, 5].mul_(1.5)                 # a weight changed: the cached engine is stale
+    x = torch.randint(3, 256, (B, 9), generator=torch.Generator().manual_seed(1)).to(dev)
+    kw = dict(batch_size=B, max_seqlen=10, k=1, first_greedy_quant=0, device=dev)
+    got = model.generate_batch(x, **kw)
+    assert next(reversed(model._decode_engines.values())) is not engines[0]
+    assert torch.equal(got[0], model.generate_batch(x, engine="module", stop_check_every=1, **kw)[0])
+    # the reference's default mode (k = 100, first quantizer sampled): reproducible under torch.manual_seed, another seed differs
+    torch.manual_seed(5)
+    a = model.generate_batch(x, batch_size=B, max_seqlen=6, device=dev, force_max_seqlen=True)
+    torch.manual_seed(5)
+    b = model.generate_batch(x, batch_size=B, max_seqlen=6, device=dev, force_max_seqlen=True)
+    c = model.generate_batch(x, batch_size=B, max_seqlen=6, device=dev, force_max_seqlen=True)
+    assert torch.equal(a[0], b[0]) and not torch.equal(a[0], c[0])
+
+
+def check_generate_batch_early_stop(dev, dtype=torch.float32, d=256, B=8, max_seqlen=160, need_late_stop=True):
+    """a-10, the early-stop path of the device loop over MANY stop checks (reference model/modeling_lina.py:168-173): a small
+    vocabulary (13 codes + 3 specials) in the reference's default SAMPLED mode makes every row emit the stop token (id 2) at a
+    random step.  For a seed, the run with ``force_max_seqlen=True`` is the ground truth (same seed, same kernels -> the same
+    token stream): the early-stopping run must return exactly its first n steps, n = the first step at which every row has
+    emitted the stop token at some step so far, + 1 -- tokens and attention rows bit-exact, stop flags and cuts as the
+    reference's post-processing derives them -- for several ``stop_check_every`` (the loop runs past the stop by up to two
+    groups of steps and trims)."""
+    from lina_speech_amd.configs import tiny
+    torch.manual_seed(2)
+    model = tiny(d=d, heads=2, n_layer=2, n_codebook=13).eval().to(dev).to(dtype)
+    x = torch.randint(3, 256, (B, 12), generator=torch.Generator().manual_seed(3)).to(dev)
+    kw = dict(batch_size=B, max_seqlen=max_seqlen, k=16, temp=1.0, first_greedy_quant=1, device=dev)
+    late, checked = 0, 0
+    for seed in range(6):
+        full = model.generate_batch(x, force_max_seqlen=True, seed=seed, **kw)
+        assert full[0].shape == (1, B, max_seqlen) and full[1].shape[2] == max_seqlen
+        all_seen = (full[0] == 2).all(dim=0).cummax(dim=1).values.all(dim=0)        # [n]
+        if not bool(all_seen.any()):
+            continue
+        n = int(all_seen.int().argmax()) + 1
+        late += n >= 40
+        for every in (8, 16, 40):
+            got = model.generate_batch(x, seed=seed, stop_check_every=every, **kw)
+            assert got[0].shape[-1] == n, (seed, every, got[0].shape, n)
+            assert torch.equal(got[0], full[0][:, :, :n]) and torch.equal(got[1], full[1][:, :, :n])
+            st = torch.cat([(full[0][:, :, :n] == 2).all(dim=0).float(), torch.ones(B, 1, device=full[0].device)], dim=1)
+            assert torch.equal(got[2], st)
+            idx = (st * torch.arange(n + 1, device=st.device)[None]).long()
+            for i in range(B):
+                cut = int(torch.unique(idx[i])[1])                                  # the reference's formula, row by row
+                assert got[3][i][0].shape[-1] == len(range(max(n - 2, 0))[:cut - 1]) and got[3][i][1].shape[-1] == min(cut, n)
+            checked += 1
+    assert checked >= 6, "too few seeds stopped early: the check did not bite"
+    if need_late_stop:
+        assert late >= 1, "no seed stopped after step 40: the stop check never ran more than a few times"
+
+
 def check_init_state_tuning_golden(dev, rel=5e-4):
     """f-4: loss and the gradients of the rank-1 start-state parameters (dh0 out of K2b, through
     get_state_from_params) equal the reference's (golden from the reference modules, mode 'fused_recurrent',

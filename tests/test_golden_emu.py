@@ -37,6 +37,11 @@ def test_fused_decode_engine_matches_reference_tokens(emu):
     check_lina_golden("cpu", engine="fused")
 
 
+def test_generate_batch_default_is_the_device_loop(emu):
+    from model_cases import check_generate_batch_loop
+    check_generate_batch_loop("cpu", full=False)
+
+
 def test_engine_device_side_greedy_loop(emu):
     import torch
     from model_cases import build_lina, golden_state_dict, load_golden

@@ -232,6 +232,13 @@ def test_projections_wider_split_k(emu, monkeypatch, nw):
     check_inproj_packed(DEV, 5, 1024, 16, 48, torch.bfloat16)
 
 
+@pytest.mark.parametrize("Q,L,d,dtype,sampled", [(1, 70, 32, torch.float32, False), (3, 70, 32, torch.bfloat16, False),
+                                                 (2, 70, 32, torch.float32, True)])
+def test_pick_loop_control_block(emu, Q, L, d, dtype, sampled):
+    from kernel_cases import check_pick_loop_ctl
+    check_pick_loop_ctl(DEV, B=5, Q=Q, L=L, d=d, dtype=dtype, sampled=sampled)
+
+
 @pytest.mark.parametrize("Q,L,d,dtype,ns", [(1, 300, 64, torch.float32, 1), (3, 70, 32, torch.bfloat16, 1),
                                             (3, 70, 32, torch.bfloat16, 3), (2, 50, 20, torch.float32, 0)])
 def test_sample_pick_embed(emu, Q, L, d, dtype, ns):

@@ -323,6 +323,13 @@ def test_greedy_pick_embed(hip, B, Q, L, d, dtype):
     check_greedy_pick_embed(DEV, B=B, Q=Q, L=L, d=d, dtype=dtype, steps=4)
 
 
+@pytest.mark.parametrize("B,Q,L,d,dtype,sampled", [(64, 1, 4099, 1024, torch.bfloat16, False), (7, 4, 1027, 256, torch.float32, False),
+                                                   (64, 1, 4099, 1024, torch.bfloat16, True), (9, 3, 513, 64, torch.float32, True)])
+def test_pick_loop_control_block(hip, B, Q, L, d, dtype, sampled):
+    from kernel_cases import check_pick_loop_ctl
+    check_pick_loop_ctl(DEV, B=B, Q=Q, L=L, d=d, dtype=dtype, sampled=sampled)
+
+
 @pytest.mark.parametrize("B,Q,L,d,dtype,ns,k", [(64, 1, 4099, 1024, torch.bfloat16, 1, 100),
                                                 (7, 4, 1027, 256, torch.float32, 2, 5),
                                                 (9, 3, 513, 64, torch.bfloat16, 0, 3)])

@@ -21,6 +21,22 @@ def test_fused_engine_with_hipgraph_matches_reference_tokens(hip):
     check_lina_golden("cuda", engine="fused")
 
 
+def test_generate_batch_default_is_the_device_loop(hip):
+    """generate_batch with no engine argument == the per-token module path with the reference's per-step stop test (tokens,
+    stop flags, cuts exact; attention rows 2e-4), early stops at different steps, prompt, engine reuse / invalidation."""
+    from model_cases import check_generate_batch_loop
+    check_generate_batch_loop("cuda")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_generate_batch_early_stop_over_many_checks(hip, dtype):
+    """The hipGraph loop (8 tokens per replay, attention rows filed by the cross-attention kernels at the device step index,
+    stop flags in the token epilogue, control block polled through pinned memory behind the queued work) stops where the
+    reference's per-step test stops."""
+    from model_cases import check_generate_batch_early_stop
+    check_generate_batch_early_stop("cuda", dtype)
+
+
 def test_l169_greedy_tokens_match_cpu_oracle(hip):
     """Full 166.7M model, fp32: device-side greedy loop (graph replay) vs oracle/lina_decode_oracle.py.
     Token ids must be identical wherever the oracle's top-2 logit margin exceeds 1e-3 (SURVEY A.8:
@@ -182,13 +198,24 @@ def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
         toks = eng.greedy_tokens().cpu()                                                    # [1,B,n]
         eng.sync_state()
         loop_logits = torch.cat(loop_logits, dim=1)                                         # [B,n,Q,L]
+        # the reference's ENTRY POINT with no engine argument runs this very loop (8 tokens per replay, its own engine):
+        # same tokens bit for bit, so everything established below about `toks` holds for what generate_batch returns
+        gb_qs, gb_atts, gb_stops, gb_cuts = m.generate_batch(x.cuda(), batch_size=B, max_seqlen=n, k=1, first_greedy_quant=0,
+                                                             force_max_seqlen=True, device="cuda")
+        assert torch.equal(gb_qs.cpu(), toks), "generate_batch does not run the loop whose logits are checked here"
+        assert next(reversed(m._decode_engines.values()))._loop.att_direct, "att rows must be filed by the cross-attention launches"
+        gb_atts = gb_atts.float().cpu()
     orc = OracleLina(sd, n_layer=6, heads=4, txt_heads=4)
     n_thr = torch.get_num_threads()
     torch.set_num_threads(min(n_thr, 32))        # small-op decode on a 256-thread host: more threads only add sync cost
     try:
-        ref_toks, ref_logits, _, margins = orc.generate_greedy(x, n, teacher=toks)         # teacher-forced on OUR tokens
+        ref_toks, ref_logits, ref_atts, margins = orc.generate_greedy(x, n, teacher=toks)  # teacher-forced on OUR tokens
     finally:
         torch.set_num_threads(n_thr)
+    att_err = float((gb_atts - ref_atts).abs().max() / ref_atts.abs().max())
+    record_parity("L169 bf16 B=64 generate_batch: attention log [B,2,n,Ttxt] vs fp32 oracle", att_err, REL)
+    assert gb_atts.shape == ref_atts.shape and att_err < REL, f"attention log rel err {att_err:.3e}"
+    assert gb_stops.shape == (B, n + 1) and len(gb_cuts) == B
     scale = float(ref_logits.abs().max())
     with torch.inference_mode():
         eng2 = DecodeEngine(m, x_enc, batch_size=B)
