@@ -616,6 +616,59 @@ def measure_big_batch(model_dev, dev, B=512, steps=120):
             "max_mem_GB": mem}
 
 
+def measure_generate_batch(model_dev, texts, dev, loop_ms, max_seqlen=750):
+    """The reference's decode ENTRY POINT end to end (model/modeling_lina.py:111-192): ``LinaModel.generate_batch(texts,
+    max_seqlen=750, force_max_seqlen=True)`` with no engine argument -- text embedding + text encoder, the text side of the
+    cross-attention, state reset, the device loop (what `value` times), token / attention-log read-out, stop-flag matrix,
+    un-delay and the per-row cuts -- wall time of the whole call on a warm engine cache (the first call of a (batch, text
+    length) builds the engine: packs the weights, captures two hipGraphs; reported as `first_call_s`).  Greedy and the
+    reference's default sampled mode (k = 100, first quantizer sampled); plus one EARLY-STOPPING call on a copy of the model
+    whose stop-token head row is scaled up so that every row emits token 2 within ~100 steps (random-init weights never do)."""
+    import copy
+    B = texts.shape[0]
+    res = {"what": f"LinaModel.generate_batch(x, batch_size={B}, max_seqlen={max_seqlen}, force_max_seqlen=True, device=...) "
+                   "end to end, engine argument left at its default", "batch": B, "max_seqlen": max_seqlen}
+    with torch.inference_mode():
+        kw = dict(batch_size=B, max_seqlen=max_seqlen, device=dev, force_max_seqlen=True)
+        t0 = time.perf_counter()
+        model_dev.generate_batch(texts, k=1, first_greedy_quant=0, **{**kw, "max_seqlen": 64})
+        torch.cuda.synchronize()
+        res["first_call_s"] = time.perf_counter() - t0
+        for name, mode in (("greedy", dict(k=1, first_greedy_quant=0)), ("sampled_k100", dict(k=100, first_greedy_quant=1))):
+            model_dev.generate_batch(texts, **mode, **{**kw, "max_seqlen": 64})          # this mode's graphs (untimed)
+            torch.cuda.synchronize()
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                qs, atts, stops, cuts = model_dev.generate_batch(texts, **mode, **kw)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            assert qs.shape == (1, B, max_seqlen) and atts.shape[:3] == (B, 2, max_seqlen) and stops.shape == (B, max_seqlen + 1)
+            res[name] = {"seconds": best, "tokens_per_s": B * max_seqlen / best, "ms_per_step_end_to_end": best / max_seqlen * 1e3,
+                         "loop_ms_per_step": loop_ms, "vs_loop": (best / max_seqlen * 1e3) / loop_ms if loop_ms else None}
+        # early stop: scale the stop token's head row (logit_2 = s * <h, w_2>: positive and dominant at random steps)
+        m2 = copy.deepcopy(model_dev)
+        m2.logits_head.weight[0, 2] *= 3.0
+        m2.generate_batch(texts, batch_size=B, max_seqlen=64, k=1, first_greedy_quant=0, device=dev, force_max_seqlen=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        qs, atts, stops, cuts = m2.generate_batch(texts, batch_size=B, max_seqlen=max_seqlen, k=1, first_greedy_quant=0, device=dev)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        eng = next(reversed(m2._decode_engines.values()))
+        n = qs.shape[-1]
+        res["early_stop"] = {"what": "stop-token head row x 3; force_max_seqlen=False, stop_check_every=16 (default)",
+                             "steps_returned": n, "steps_executed": eng._n_done, "seconds": dt,
+                             "ms_per_returned_step": dt / n * 1e3, "stopped_early": n < max_seqlen,
+                             "cut_lengths_min_max": [min(c[0].shape[-1] for c in cuts), max(c[0].shape[-1] for c in cuts)]}
+        m2.clear_decode_cache()
+        del m2
+    model_dev.clear_decode_cache()
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

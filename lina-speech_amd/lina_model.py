@@ -79,10 +79,17 @@ class LinaModel(nn.Module):
     # ------------------------------------------------------------------ batched decode
     _ENGINE_CACHE_SIZE = 2
 
+    def __getstate__(self):
+        """copy.deepcopy / pickling: the cached decode engines (hipGraphs, static buffers) stay with the original."""
+        st = self.__dict__.copy()
+        st.pop("_decode_engines", None)
+        return st
+
     def clear_decode_cache(self):
         """Drop the cached decode engines (packed weights, static buffers, captured hipGraphs).  The cache is keyed on
         every parameter's (storage, version), so optimizer steps and ``load_state_dict`` invalidate it by themselves;
-        writes through ``param.data`` do not bump the version -- call this after them."""
+        writes through ``param.data`` (and in-place writes to parameters created under ``torch.inference_mode``, which
+        have no version counter) do not show up in the key -- call this after them."""
         self.__dict__.pop("_decode_engines", None)
 
     def _decode_engine(self, x_enc: Tensor, B: int, init_state):
@@ -92,7 +99,7 @@ class LinaModel(nn.Module):
         from .decode import DecodeEngine
         w = self.logits_head.weight
         key = (B, int(x_enc.shape[1]), w.dtype, str(w.device),
-               tuple((p.data_ptr(), p._version) for p in self.parameters()))
+               tuple((p.data_ptr(), -1 if p.is_inference() else p._version) for p in self.parameters()))
         cache = self.__dict__.setdefault("_decode_engines", {})
         eng = cache.pop(key, None)
         if eng is None:

@@ -223,7 +223,7 @@ def check_generate_batch_loop(dev, rel=REL, full=True):
         engines.append(next(reversed(model._decode_engines.values())))
         assert torch.equal(got[0], ref[0]), f"token ids differ (seed {seed})"
         assert torch.equal(got[2], ref[2]), "stop flags differ"
-        close(got[1], ref[1], "generate_batch loop atts", rel)
+        close(got[1], ref[1].cpu(), "generate_batch loop atts", rel)
         assert [c[0].shape for c in got[3]] == [c[0].shape for c in ref[3]]
         for cg, cr in zip(got[3], ref[3]):
             assert torch.equal(cg[0], cr[0]) and cg[1].shape == cr[1].shape
@@ -283,7 +283,7 @@ def check_generate_batch_early_stop(dev, dtype=torch.float32, d=256, B=8, max_se
             idx = (st * torch.arange(n + 1, device=st.device)[None]).long()
             for i in range(B):
                 cut = int(torch.unique(idx[i])[1])                                  # the reference's formula, row by row
-                assert got[3][i][0].shape[-1] == len(range(max(n - 2, 0))[:cut - 1]) and got[3][i][1].shape[-1] == min(cut, n)
+                assert got[3][i][0].shape[-1] == len(range(max(n - 2, 0))[:cut - 1]) and got[3][i][1].shape[1] == min(cut, n)
             checked += 1
     assert checked >= 6, "too few seeds stopped early: the check did not bite"
     if need_late_stop:
