@@ -588,6 +588,14 @@ class _SwiGLUMLPFunction(torch.autograd.Function):
 _MLP_PACK = WeakIdKeyDictionary()            # up-projection weight (the parameter OBJECT) -> (key, Wi, bi, Wo)
 
 
+def clear_mlp_pack() -> None:
+    """Forget the cached padded SwiGLU weights.  The cache key is every parameter's (storage, version): in-place ops on the
+    Parameter and ``load_state_dict`` bump the version, writes through ``param.data`` (EMA swaps, weight clipping, some
+    third-party optimizers) do NOT -- after such a write call this (``TrainStep.step`` does after every optimizer step,
+    ``ops.clear_workspaces`` does too)."""
+    _MLP_PACK.clear()
+
+
 def _mlp_padded_weights(w_in, b_in, w_out, b_out, cd, H, Hp):
     """The zero-padded operands of ``_SwiGLUMLPFunction`` (the cast of the master weights that happens every step anyway, into
     the padded layout).  Kept per parameter VERSION: the weights change only at the optimizer step, so a second forward on the

@@ -101,6 +101,8 @@ def clear_workspaces() -> None:
     """Release the cached kernel scratch (segment / boundary states of the segment-parallel K2 / K2b): at small B*H with
     many segments it is the size of several activations and would otherwise stay pinned for the life of the process."""
     _WORKSPACES.clear()
+    from .autograd import clear_mlp_pack          # (the padded SwiGLU weight cache: see its note on ``param.data`` writes)
+    clear_mlp_pack()
 
 
 def fused_ops_available(x: torch.Tensor) -> bool:

@@ -34,5 +34,5 @@ from .autograd import (
     chunk_simple_gla, GradSlab, _slab_part, _SplitSlabFunction, split_slab, _ShortConvFunction, short_conv,
     _RMSNormGateFunction, _gate_rows_view, rmsnorm_swish_gate, rmsnorm, _LayerNormFunction, _LN_TRIPLES, layer_norm,
     _SwiGLUFunction, swiglu_gate, linear_weight_grad, _LinearFunction, linear, _SwiGLUMLPFunction, _MLP_ONE,
-    _mlp_one, swiglu_mlp, _GateLogSigmoidFunction, gate_logsigmoid, _GateLowRankFunction, gate_lowrank,
+    _mlp_one, swiglu_mlp, clear_mlp_pack, _GateLogSigmoidFunction, gate_logsigmoid, _GateLowRankFunction, gate_lowrank,
     _CrossEntropyFunction, cross_entropy, _EmbedSumFunction, embed_sum)

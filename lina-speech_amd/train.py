@@ -23,6 +23,7 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
+from . import ops
 from .lina_model import LinaModel
 
 DDP_BUCKET_MB = 128        # ~0.67 GB of fp32 gradients at L169 -> 6 buckets
@@ -113,6 +114,7 @@ class TrainStep:
         if self.grad_clip is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
         self.opt.step()
+        ops.clear_mlp_pack()                  # padded SwiGLU weights of this step (also covers optimizers that write .data)
         if self.sched is not None:
             self.sched.step()
         return loss.detach()

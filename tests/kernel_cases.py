@@ -751,6 +751,14 @@ def check_swiglu_mlp(dev, B, T, d, H, dtype, bias=True):
     y3 = ops.swiglu_mlp(*m)
     assert _MLP_PACK[m[1]][1] is not pack0
     assert_close(y3, 2.0 * y64.detach(), tol, "MLP y after an in-place weight update")
+    # a write through ``.data`` does NOT bump the version (EMA swaps, weight clipping): the documented way out is
+    # ops.clear_mlp_pack() (also part of ops.clear_workspaces and of TrainStep.step)
+    pack3 = _MLP_PACK[m[1]][1]
+    m[3].data.mul_(0.5)
+    assert ops.swiglu_mlp(*m) is not None and _MLP_PACK[m[1]][1] is pack3, "expected: the stale pack is still served"
+    ops.clear_mlp_pack()
+    y4 = ops.swiglu_mlp(*m)
+    assert_close(y4, y64.detach(), tol, "MLP y after a .data write + clear_mlp_pack()")
 
 
 def check_block_chain(dev, dtype, B=2, T=70, d=64):
