@@ -11,6 +11,7 @@
 #include <lina_dev.h>
 #include "lina_common.h"
 #include "skinny_frag.h"
+#include "linear_tall.h"
 #include <stdlib.h>
 
 #ifdef LINA_SKINNY_PROF
@@ -306,6 +307,136 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
     IP_PROF_FLUSH();
 }
 
+// ---- B >= 128: the same launch on the tall tiling (linear_tall.h: 128 rows x 64 weight rows per workgroup, the weights of a
+// k-step staged through LDS once for the four waves, every wave's accumulators final).  grid.x = (2 Kd + 2 Vd) / 64 workgroups
+// on q | k | v | g columns (Kd, Vd multiples of 64: a workgroup's columns lie in ONE region) + Kd / 64 GATE workgroups, each
+// projecting its 128 rows on the 16 low-rank weight rows (one weight fragment per k-step) and applying the rank-16
+// up-projection + bias + log-sigmoid for 64 gate channels; grid.y = ceil(B / 128).  Epilogues as gla_inproj_kernel's.
+template <typename T, int V>
+__global__ __launch_bounds__(64 * TallShape<V>::NWV) void gla_inproj_tall_kernel(
+    const T* __restrict__ A, const T* __restrict__ W, const float* __restrict__ c1, const float* __restrict__ c2,
+    const T* __restrict__ wq, const T* __restrict__ wk, const T* __restrict__ wv, T* cq, T* ck, T* cv,
+    const T* __restrict__ w2, const T* __restrict__ b2, T* __restrict__ qkv, T* __restrict__ g_out, float* __restrict__ gk,
+    int M, int K, int Kd, int Vd, float ln_eps, float inv_norm, float clamp_min, int has_clamp) {
+    using F = Frag<T>;
+    constexpr int R = 16, NT = 4, MTW = TallShape<V>::MTW;
+    typedef typename raw4<T>::type raw_t;
+    __shared__ __attribute__((aligned(16))) unsigned char s_w[TallShape<V>::LDS];   // the ONLY LDS object (see linear_tall.h)
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    const int w = wave_uniform(threadIdx.x >> 6);
+    const int n_direct = 2 * Kd + 2 * Vd;
+    const int nb_direct = n_direct / (16 * NT);
+    int cblk, rblk;
+    if (!tall_tile_of((int)blockIdx.x, nb_direct + Kd / 64, (M + TallShape<V>::ROWS - 1) / TallShape<V>::ROWS, cblk, rblk)) return;
+    const int m0 = rblk * TallShape<V>::ROWS + 16 * MTW * w;       // this wave's first row
+    const bool gate_wg = cblk >= nb_direct;                       // block-uniform
+    const int nks = K / F::KSTEP;
+    const bool wave_on = m0 < (M + 63) / 64 * 64;
+    const float inv_k = fast_rcp((float)K);
+    float s1[MTW], s2[MTW];
+
+    if (gate_wg) {
+        const int c0 = (cblk - nb_direct) * 64;                   // first gate channel of this workgroup
+        const int nb[1] = {n_direct >> 4};
+        const float cc1 = c1[n_direct + li], cc2 = c2[n_direct + li];
+        f32x4 acc[1][MTW];
+        tall_core_v<V, T, 1, true, MTW>(A, W, nb, nks, m0 >> 4, wave_on, s_w, acc, s1, s2);
+        // the 16 low-rank activations of a row sit in 16 lanes: exchanged through this wave's slice of the (now idle) stage
+        float (*s_lr)[R + 1] = reinterpret_cast<float (*)[R + 1]>(s_w) + 16 * MTW * w;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            float mu[4], rstd[4];
+            tall_row_stats(s1[mt], s2[mt], lg, inv_k, ln_eps, mu, rstd);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_lr[16 * mt + 4 * lg + r][li] = rstd[r] * (acc[0][mt][r] - mu[r] * cc1) + cc2;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int jj = 0; jj < 4; ++jj) {
+            const int c = c0 + 16 * jj + li;                       // (Kd % 64 == 0: always a real channel)
+            const float4 q0 = cvt4(ld4_raw(w2 + (int64_t)c * R)), q1 = cvt4(ld4_raw(w2 + (int64_t)c * R + 4)),
+                         q2 = cvt4(ld4_raw(w2 + (int64_t)c * R + 8)), q3 = cvt4(ld4_raw(w2 + (int64_t)c * R + 12));
+            const float w2r[R] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            const float bias = ld(b2 + c);
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * mt + 4 * lg + r, m = m0 + row;
+                    float accg = bias;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) accg = fmaf(s_lr[row][k], w2r[k], accg);
+                    float gv = logsigmoidf(accg) * inv_norm;
+                    if (has_clamp) gv = fmaxf(gv, clamp_min);
+                    if (m < M) gk[(int64_t)m * Kd + c] = gv;
+                }
+        }
+        return;
+    }
+
+    const int n0 = cblk * (16 * NT);
+    int nb[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) nb[j] = (n0 >> 4) + j;
+    float pre_c1[NT], pre_c2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { pre_c1[j] = c1[n0 + 16 * j + li]; pre_c2[j] = c2[n0 + 16 * j + li]; }
+    f32x4 acc[NT][MTW];
+    tall_core_v<V, T, NT, true, MTW>(A, W, nb, nks, m0 >> 4, wave_on, s_w, acc, s1, s2);
+
+    // the workgroup's 64 columns lie in one region (block-uniform): q | k | v -> conv step + SiLU, g -> stored as is
+    const bool is_g = n0 >= 2 * Kd + Vd;
+    const T* wsel; T* csel; int cb0, D;
+    if (n0 < Kd) { cb0 = n0; D = Kd; wsel = wq; csel = cq; }
+    else if (n0 < 2 * Kd) { cb0 = n0 - Kd; D = Kd; wsel = wk; csel = ck; }
+    else if (!is_g) { cb0 = n0 - 2 * Kd; D = Vd; wsel = wv; csel = cv; }
+    else { cb0 = n0 - (2 * Kd + Vd); D = Vd; wsel = wv; csel = cv; }
+    raw_t pre_wj[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) pre_wj[j] = is_g ? raw_t() : ld4_raw(wsel + (int64_t)(cb0 + 16 * j + li) * 4);
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        float mu[4], rstd[4];
+        tall_row_stats(s1[mt], s2[mt], lg, inv_k, ln_eps, mu, rstd);
+        if (is_g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * mt + 4 * lg + r;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    if (m < M) st(g_out + (int64_t)m * Vd + cb0 + 16 * j + li, rstd[r] * (acc[j][mt][r] - mu[r] * pre_c1[j]) + pre_c2[j]);
+            }
+            continue;
+        }
+        // the rolled conv caches of this m-tile's 4 x NT (row, channel) pairs: all requested before any is used / rewritten
+        raw_t old[4][NT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * mt + 4 * lg + r;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) old[r][j] = ld4_raw(csel + ((int64_t)(m < M ? m : 0) * D + cb0 + 16 * j + li) * 4);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * mt + 4 * lg + r;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int c = cb0 + 16 * j + li;
+                const float z = rstd[r] * (acc[j][mt][r] - mu[r] * pre_c1[j]) + pre_c2[j];
+                const float4 o4 = cvt4(old[r][j]), wj = cvt4(pre_wj[j]);
+                T tmp;                                       // the conv sees the projection in the model dtype
+                st(&tmp, z);
+                const float xn = ld(&tmp);
+                const float4 nw = make_float4(o4.y, o4.z, o4.w, xn);
+                st4(csel + ((int64_t)m * D + c) * 4, nw);
+                const float y = fmaf(wj.w, nw.w, fmaf(wj.z, nw.z, fmaf(wj.y, nw.y, wj.x * nw.x)));
+                st(qkv + (int64_t)m * (2 * Kd + Vd) + n0 + 16 * j + li, silu(y));
+            }
+        }
+    }
+}
+
 }  // namespace lina
 
 static int inproj_impl(const void* x, int64_t ldx, const void* w_in, int64_t ldw, int packed, const float* c1,
@@ -325,6 +456,29 @@ static int inproj_impl(const void* x, int64_t ldx, const void* w_in, int64_t ldw
     const int has_clamp = (clamp_min == clamp_min) ? 1 : 0;
     // 64 rows x 32 columns per workgroup when the q|k|v|g regions allow it (fewer, fatter workgroups: one per CU at
     // L169 -- the busiest CU's byte count sets the time, see linear_skinny.hip); else 64 x 16
+    {   // B >= 384 on packed operands: the tall tiling (see gla_inproj_tall_kernel; 31.6 -> 24.2 us per launch at B = 512,
+        // 17.2 -> 19.1 at B = 256: profiles/r05_tall_perf.txt).  LINA_TALL=0 / 1: never / whenever the operands allow it
+        // (test hook, read per call)
+        const char* tall_env = getenv("LINA_TALL");
+        const int tall_mode = tall_env ? atoi(tall_env) : -1;
+        const bool can = (packed & 1) && Kd % 64 == 0 && Vd % 64 == 0;
+        if (can && (tall_mode == 1 || (tall_mode != 0 && B >= kTallMinRows))) {
+            const char* v_env = getenv("LINA_TALL_V");       // variant (linear_tall.h): 0 = LDS ring, 1 = register ring
+            const int tv = v_env ? atoi(v_env) : LINA_TALL_DEFAULT_V;
+            const int rows = tv ? TallShape<1>::ROWS : TallShape<0>::ROWS;
+            dim3 tgrid(tall_grid((2 * Kd + 2 * Vd) / 64 + Kd / 64, (B + rows - 1) / rows));
+#define LINA_INPROJ_TALL(TT, VV)                                                                                      \
+    LINA_LAUNCH((gla_inproj_tall_kernel<TT, VV>), tgrid, dim3(64 * TallShape<VV>::NWV), 0, stream, (const TT*)x,        \
+                (const TT*)w_in, c1, c2, (const TT*)wq, (const TT*)wk, (const TT*)wv, (TT*)cq, (TT*)ck, (TT*)cv,       \
+                (const TT*)w2, (const TT*)b2, (TT*)qkv, (TT*)g_out, gk, B, K, Kd, Vd, ln_eps, 1.0f / normalizer,        \
+                clamp_min, has_clamp)
+#define LINA_INPROJ_TALL_T(TT) do { if (tv) LINA_INPROJ_TALL(TT, 1); else LINA_INPROJ_TALL(TT, 0); } while (0)
+            if (dtype == LINA_F32) LINA_INPROJ_TALL_T(float); else LINA_INPROJ_TALL_T(bf16_t);
+#undef LINA_INPROJ_TALL_T
+#undef LINA_INPROJ_TALL
+            return check_launch("lina_gla_decode_inproj (tall)");
+        }
+    }
     static const bool narrow = getenv("LINA_INPROJ_NARROW") != nullptr;      // tuning knob (tools/probe_decode.py)
     const bool wide = Kd % 32 == 0 && Vd % 32 == 0 && !narrow;
     const int cols = wide ? 32 : 16;

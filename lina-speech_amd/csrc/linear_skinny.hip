@@ -18,6 +18,7 @@
 #include <lina_dev.h>
 #include "lina_common.h"
 #include "skinny_frag.h"
+#include "linear_tall.h"
 #include <stdlib.h>
 
 #ifdef LINA_SKINNY_PROF
@@ -334,6 +335,74 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
 #endif
 }
 
+// ---- M >= 128: the tall tiling (linear_tall.h) with the same epilogues.  Packed operands only; grid (ceil(N / 16 NT), ceil(M / 128)).
+template <typename T, bool SWIGLU, bool LN, int NT, int V>
+__global__ __launch_bounds__(64 * TallShape<V>::NWV) void linear_tall_kernel(
+    const T* __restrict__ A, const T* __restrict__ W, const float* __restrict__ c1, const float* __restrict__ c2,
+    const T* resid, int64_t ldr, T* out, int64_t ldo, int M, int N, int K, int Hd, int ln_dim, float ln_eps, T* outp, int Kp,
+    int Hp) {
+    using F = Frag<T>;
+    constexpr int NB = SWIGLU ? 2 : 1, G = NB * NT, MTW = TallShape<V>::MTW;
+    __shared__ __attribute__((aligned(16))) unsigned char s_w[TallShape<V>::LDS];
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    const int w = wave_uniform(threadIdx.x >> 6);
+    int cblk, rblk;
+    if (!tall_tile_of((int)blockIdx.x, (N + 16 * NT - 1) / (16 * NT), (M + TallShape<V>::ROWS - 1) / TallShape<V>::ROWS, cblk, rblk))
+        return;
+    const int n0 = cblk * (16 * NT), m0 = rblk * TallShape<V>::ROWS + 16 * MTW * w;
+    const int n_rows = SWIGLU ? Hd : N;                    // weight rows per half
+    int nb[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) nb[g] = ((g / NT) * Hp + n0 + 16 * (g % NT)) >> 4;
+    // fold constants of this lane's columns (clamped address; columns past the end are never stored)
+    float pre_c1[G], pre_c2[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int n = n0 + 16 * (g % NT) + li;
+        const int idx = (g / NT) * Hd + (n < n_rows ? n : n_rows - 1);
+        pre_c1[g] = LN ? c1[idx] : 0.0f;
+        pre_c2[g] = c2 ? c2[idx] : 0.0f;
+    }
+    f32x4 acc[G][MTW];
+    float s1[MTW], s2[MTW];
+    tall_core_v<V, T, G, LN, MTW>(A, W, nb, K / F::KSTEP, m0 >> 4, m0 < (M + 63) / 64 * 64, s_w, acc, s1, s2);
+
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        float mu[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {1.f, 1.f, 1.f, 1.f};
+        if (LN) tall_row_stats(s1[mt], s2[mt], lg, fast_rcp((float)ln_dim), ln_eps, mu, rstd);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * mt + 4 * lg + r;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + 16 * j + li;
+                const bool n_ok = n < n_rows;
+                float res;
+                if (SWIGLU) {
+                    float ga = acc[j][mt][r], gb = acc[NT + j][mt][r];
+                    if (n_ok) {
+                        if (LN) { ga = rstd[r] * (ga - mu[r] * pre_c1[j]); gb = rstd[r] * (gb - mu[r] * pre_c1[NT + j]); }
+                        if (c2) { ga += pre_c2[j]; gb += pre_c2[NT + j]; }
+                    }
+                    res = n_ok ? silu(ga) * gb : ((n == Hd) ? 1.0f : 0.0f);   // bias column of the K-padded row
+                } else {
+                    res = acc[j][mt][r];
+                    if (n_ok) {
+                        if (LN) res = rstd[r] * (res - mu[r] * pre_c1[j]);
+                        if (c2) res += pre_c2[j];
+                    }
+                }
+                if (m < M && n < N) {
+                    if (resid) res += ld(resid == outp ? resid + packed_off<T>(m, n, Kp) : resid + (int64_t)m * ldr + n);
+                    if (out) st(out + (int64_t)m * ldo + n, res);
+                    if (outp) st(outp + packed_off<T>(m, n, Kp), res);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace lina
 
 // packed kernels: one launch helper per tiling that picks the split-K width.  16 waves only where a wave's accumulators and
@@ -380,6 +449,39 @@ static int linear_skinny_impl(const void* A, int64_t lda, const void* W, int64_t
     // with rounds = ceil(workgroups / 256 CUs).
     const bool sw = swiglu_hidden > 0, ln = ln_dim > 0;
     const int nb = sw ? 2 : 1;
+    {   // M >= 384 on packed operands, wide outputs: the tall tiling (linear_tall.h).  Measured per launch at L169 (tools/perf_tall.py,
+        // profiles/r05_tall_perf.txt; 64-row kernel -> tall): M = 512 up-projection 22.1 -> 17.3 us, head 22.5 -> 14.4;
+        // M = 256 11.3 -> 17.4 and 12.9 -> 15.3 (half as many workgroups as CUs: slower), hence the row threshold.
+        // LINA_TALL=0 / 1: never / whenever the operands allow it (test hook, like LINA_SKINNY_WAVES: read per call)
+        const char* tall_env = getenv("LINA_TALL");
+        const int tall_mode = tall_env ? atoi(tall_env) : -1;
+        const bool can = (packed & 1) && Hp % 64 == 0;
+        const bool want = tall_mode == 1 || (tall_mode != 0 && M >= kTallMinRows && (sw || N >= 2048));
+        if (can && want) {
+            const int nt = sw ? 2 : 4;                       // 32 gate + 32 value weight rows / 64 plain weight rows per workgroup
+            LINA_REQUIRE(Hp >= (N + 16 * nt - 1) / (16 * nt) * (16 * nt),
+                         "lina_linear_skinny: packed weights must be zero-padded to whole %d-row blocks covering N", 16 * nt);
+            const char* v_env = getenv("LINA_TALL_V");       // variant (linear_tall.h): 0 = LDS ring, 1 = register ring
+            const int tv = v_env ? atoi(v_env) : ((sw || ln) ? 0 : 1);   // measured: the plain projection prefers the register ring
+            const int rows = tv ? TallShape<1>::ROWS : TallShape<0>::ROWS;
+            dim3 tgrid(tall_grid((N + 16 * nt - 1) / (16 * nt), (M + rows - 1) / rows));
+#define LINA_LT(TT, SW, LNN, NTT, VV)                                                                                \
+    LINA_LAUNCH((linear_tall_kernel<TT, SW, LNN, NTT, VV>), tgrid, dim3(64 * TallShape<VV>::NWV), 0, stream,          \
+                (const TT*)A, (const TT*)W, c1, c2, (const TT*)resid, ldr, (TT*)out, ldo, M, N, K, swiglu_hidden,       \
+                ln_dim, ln_eps, (TT*)outp, Kp, Hp)
+#define LINA_LT_V(TT, VV)                                                                                            \
+    do {                                                                                                             \
+        if (sw && ln) LINA_LT(TT, true, true, 2, VV); else if (sw) LINA_LT(TT, true, false, 2, VV);                  \
+        else if (ln) LINA_LT(TT, false, true, 4, VV); else LINA_LT(TT, false, false, 4, VV);                         \
+    } while (0)
+#define LINA_LT_T(TT) do { if (tv) LINA_LT_V(TT, 1); else LINA_LT_V(TT, 0); } while (0)
+            if (dtype == LINA_BF16) LINA_LT_T(bf16_t); else LINA_LT_T(float);
+#undef LINA_LT_T
+#undef LINA_LT_V
+#undef LINA_LT
+            return check_launch("lina_linear_skinny (tall)");
+        }
+    }
     int best_mt = 4, best_nt = 1;
     long best_cost = -1;
     const int cand[5][2] = {{1, 1}, {2, 1}, {4, 1}, {2, 2}, {4, 2}};

@@ -1,0 +1,233 @@
+// linear_tall.h -- the decode-step projections at a LARGE utterance batch (M >= 128 rows): main loop shared by the plain /
+// LayerNorm-folded / SwiGLU projection (linear_skinny.hip) and by the fused input side of a GLA mixer (gla_inproj.hip).
+//
+// The "skinny" kernels of those files are built for M <= 64: a workgroup owns 64 rows x 16-32 columns and splits K over its
+// waves, every operand byte goes straight from L2 into MFMA fragments once per workgroup.  At M = 512 (the batch the headline
+// metric is quoted on) that tiling re-reads the activations once per 32 columns and the weights once per 64 rows: the
+// in-projection pulled 1.15 MB through every CU's vector-memory path and ran 38 us for 4.3 GFLOP (rocprofv3,
+// profiles/r05_step_b512_before_timeline.txt) -- 19 % of the step, the up-projection another 13 %.
+//
+// Tall tiling: a workgroup of NWV = 4 waves owns 128 rows x (16 G) weight rows; wave w owns rows [32 w, 32 w + 32) for the
+// WHOLE contraction (no split-K, no reduction through LDS: the accumulators are final), so
+//   * its A fragments (fragment-major: 1 KiB contiguous per load instruction, skinny_frag.h) are nobody else's;
+//   * the weight fragments of a k-step are needed by all four waves: fetched once per workgroup;
+//   * both go global -> LDS by DMA (global_load_lds_dwordx4, lane-linear = exactly the fragment-major image, so the consumer's
+//     ds_read_b128 is conflict-free) through a three-stage ring with counted waits (tall_core below), one barrier per stage.
+// Bytes through a CU per 128 x 64 output tile: (128 + 64) x K x e instead of 4 x (64 + 32) x 2 x K x e -- 2.7 x fewer for the
+// same flops, and the k-loop overlaps loads with MFMAs instead of "everything in flight, then compute, then reduce".
+// LayerNorm statistics: per-lane sums over the lane's own fragment elements (2 registers per m-tile), reduced over the four
+// lane groups of a row at the end and fetched by the lanes that hold that row's outputs with one shuffle per row.
+#pragma once
+#include <lina_dev.h>
+#include "lina_common.h"
+#include "skinny_frag.h"
+
+namespace lina {
+
+constexpr int kTallMTW = 2;       // 16-row m-tiles per wave
+constexpr int kTallNWV = 4;       // waves per workgroup (rows per workgroup = 16 * MTW * NWV = 128)
+#ifndef LINA_TALL_KB
+#define LINA_TALL_KB 2            // (tools/tall_variants.sh builds other ring shapes for A/B)
+#endif
+#ifndef LINA_TALL_NS
+#define LINA_TALL_NS 3
+#endif
+constexpr int kTallKB = LINA_TALL_KB;   // k-steps per LDS stage
+constexpr int kTallNS = LINA_TALL_NS;   // stages in the LDS ring (NS - 1 of them in flight while one is consumed)
+constexpr int kTallRows = 16 * kTallMTW * kTallNWV;
+constexpr int kTallMinRows = 384; // the launchers' own rule: below this the 64-row kernels have more workgroups than the tall ones and win
+constexpr int kTallSlots = kTallMTW * kTallNWV + kTallNWV;    // fragments per k-step: 8 of A (two per wave) + 4 of W
+
+// LDS of the ring: NS stages x KB k-steps x 12 fragments of 1 KiB (72 KiB: two workgroups per CU)
+constexpr int tall_lds_bytes() { return kTallNS * kTallKB * kTallSlots * 1024; }
+
+// one fragment (1 KiB) out of the staged image: lane-linear, 16 bytes per lane
+template <typename T>
+__device__ __forceinline__ void frag_from_lds(Frag<T>& f, const unsigned char* stage, int lane) {
+    f.load(reinterpret_cast<const T*>(stage + 16 * lane));
+}
+
+// acc[g][mt] += A[rows of this wave's m-tile mt, :] . W[16-row block nb[g], :]^T over all nks k-steps.
+//   A, W: fragment-major (packed) operands; mtile0: this wave's first 16-row block of A; wave_on: the block exists (a wave
+//   beyond the padded batch streams block 0 instead -- the launch's operation counts stay uniform -- and its results are never
+//   stored); s_w: tall_lds_bytes() of LDS, 16-byte aligned, the workgroup's ONLY LDS use while the loop runs.  G = 4 or 1
+//   weight fragments per k-step (G = 1: the four waves all fetch that one fragment -- again uniform counts).  Every wave of
+//   the workgroup must call this (barriers inside).
+//
+// BOTH operands travel global -> LDS by DMA (inline asm: the compiler neither waits for it nor counts it), in a ring of NS
+// stages of KB k-steps: the first version of this loop kept A in a compiler-managed register double buffer beside a
+// two-stage DMA of W, and every stage ended in `vmcnt(0)` -- one full memory round trip per 128 columns of K, 8 per workgroup
+// at K = 1024: 24 us for the 4.3 GFLOP in-projection (profiles/r05_tall_v1_timeline.txt).  Here a wave issues 3 DMA pieces
+// per k-step (its own two A fragments, one W fragment), waits with a COUNTED vmcnt for the stage it is about to consume
+// (NS - 2 younger stages stay in flight), meets the others at a raw barrier (LDS counter only), refills the stage consumed
+// last, and multiplies.  The last NS - 2 stages wait with vmcnt(0) (their successors may be short or absent).
+template <typename T, int G, bool LN>
+__device__ __forceinline__ void tall_core(const T* __restrict__ A, const T* __restrict__ W, const int (&nb)[G], int nks,
+                                          int mtile0, bool wave_on, unsigned char* s_w, f32x4 (&acc)[G][kTallMTW],
+                                          float (&s1)[kTallMTW], float (&s2)[kTallMTW]) {
+    using F = Frag<T>;
+    constexpr int MTW = kTallMTW, NWV = kTallNWV, KB = kTallKB, NS = kTallNS, SL = kTallSlots;
+    constexpr int OPS = KB * (MTW + 1);                     // DMA pieces per wave and (full) stage
+    static_assert(G == 4 || G == 1, "one weight fragment per wave and k-step (G = 4), or the same one for all (G = 1)");
+    const int lane = threadIdx.x & 63;
+    const int w = wave_uniform(threadIdx.x >> 6);
+    const int64_t fstr = 64 * F::KL;                        // elements per fragment
+    const int mt_src = wave_on ? mtile0 : 0;
+    const int wb = nb[G == 4 ? w : 0];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[g][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) { s1[mt] = 0.f; s2[mt] = 0.f; }
+    const int nst = (nks + KB - 1) / KB;
+
+    auto issue = [&](int st) {                              // this wave's pieces of stage st -> ring slot st % NS
+        unsigned char* base = s_w + (st % NS) * (KB * SL * 1024);
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const int ks = st * KB + u;                     // wave-uniform
+            if (ks >= nks) break;
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+                dma16_to_lds_async(A + ((int64_t)(mt_src + mt) * nks + ks) * fstr, 16u * (unsigned)lane,
+                                   base + (u * SL + MTW * w + mt) * 1024);
+            dma16_to_lds_async(W + ((int64_t)wb * nks + ks) * fstr, 16u * (unsigned)lane,
+                               base + (u * SL + MTW * NWV + w) * 1024);
+        }
+    };
+    auto compute = [&](int st) {
+        const unsigned char* base = s_w + (st % NS) * (KB * SL * 1024);
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            if (st * KB + u >= nks) break;                  // wave-uniform (a last, partial stage)
+            F fa[MTW], fb[G];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) frag_from_lds<T>(fa[mt], base + (u * SL + MTW * w + mt) * 1024, lane);
+#pragma unroll
+            for (int g = 0; g < G; ++g) frag_from_lds<T>(fb[g], base + (u * SL + MTW * NWV + g) * 1024, lane);
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                if (LN) fa[mt].stats(s1[mt], s2[mt]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g][mt] = F::mma(fa[mt], fb[g], acc[g][mt]);
+            }
+        }
+    };
+
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nst) issue(p);
+    for (int st = 0; st < nst; ++st) {
+        if (st + NS - 2 <= nst - 2) wait_vmem_but<(NS - 2) * OPS>();   // stage st has landed; NS - 2 full stages stay in flight
+        else wait_vmem();
+        lds_barrier();                                      // ... everybody's pieces; and stage st - 1 has been consumed by all
+        if (st + NS - 1 < nst) issue(st + NS - 1);          // -> into the slot of stage st - 1
+        compute(st);
+    }
+    __syncthreads();                                        // the ring is free: callers reuse it for their epilogue exchange
+}
+
+// ---- variant 1: no LDS at all.  ONE wave per workgroup owns a 64 x (16 G) tile for the whole contraction and streams BOTH
+// operands straight from L2 into VGPRs through a register ring D k-steps deep (plain loads: asynchronous until the compiler's
+// counted wait in front of the MFMAs that consume them; an LDS-DMA piece blocks the issuing wave until the memory system has
+// taken it, ~34 clocks per KiB, which is what kept the ring of variant 0 from overlapping its own refill with its MFMAs).
+// 4 + G fragments per k-step feed 4 G MFMAs (variant 0: 3 DMA pieces + 6 LDS reads for 2 G); nothing is shared inside a
+// workgroup, tiles that share an operand meet in L2 (the launchers map them to one XCD).
+#ifndef LINA_TALL_DEFAULT_V
+#define LINA_TALL_DEFAULT_V 0     // which variant the launchers pick (LINA_TALL_V overrides per call: test / A-B hook)
+#endif
+constexpr int kTallRegMT = 4;     // m-tiles of a variant-1 wave (64 rows)
+#ifndef LINA_TALL_D
+#define LINA_TALL_D 4
+#endif
+constexpr int kTallRegD = LINA_TALL_D;
+
+template <typename T, int G, bool LN>
+__device__ __forceinline__ void tall_core_reg(const T* __restrict__ A, const T* __restrict__ W, const int (&nb)[G], int nks,
+                                              int mtile0, bool wave_on, f32x4 (&acc)[G][kTallRegMT], float (&s1)[kTallRegMT],
+                                              float (&s2)[kTallRegMT]) {
+    using F = Frag<T>;
+    constexpr int MT = kTallRegMT, D = kTallRegD;
+    const int lane = threadIdx.x & 63;
+    const int64_t fstr = 64 * F::KL;
+    const int mt_src = wave_on ? mtile0 : 0;
+    const T* ap[MT];
+    const T* wp[G];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) ap[mt] = A + ((int64_t)(mt_src + mt) * nks * 64 + lane) * F::KL;
+#pragma unroll
+    for (int g = 0; g < G; ++g) wp[g] = W + ((int64_t)nb[g] * nks * 64 + lane) * F::KL;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[g][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { s1[mt] = 0.f; s2[mt] = 0.f; }
+    F fa[D][MT], fb[D][G];
+    auto load = [&](int slot, int ks) {                     // (slot: a compile-time constant after unrolling)
+        const int kc = ks < nks ? ks : nks - 1;             // past the end: a harmless re-read, never multiplied
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fa[slot][mt].load(ap[mt] + (int64_t)kc * fstr);
+#pragma unroll
+        for (int g = 0; g < G; ++g) fb[slot][g].load(wp[g] + (int64_t)kc * fstr);
+    };
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) load(d, d);
+    for (int k0 = 0; k0 < nks; k0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            load((d + D - 1) % D, k0 + d + D - 1);           // refill the slot consumed one step ago
+            if (k0 + d < nks) {                              // wave-uniform
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (LN) fa[d][mt].stats(s1[mt], s2[mt]);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acc[g][mt] = F::mma(fa[d][mt], fb[d][g], acc[g][mt]);
+                }
+            }
+        }
+    }
+}
+
+// shape of a tall workgroup by variant: 0 = LDS ring (4 waves x 32 rows), 1 = register ring (1 wave x 64 rows)
+template <int V> struct TallShape {
+    static constexpr int MTW = V ? kTallRegMT : kTallMTW, NWV = V ? 1 : kTallNWV, ROWS = 16 * MTW * NWV;
+    static constexpr int LDS = V ? 64 * 17 * 4 : tall_lds_bytes();     // V = 1: only the gate tiles' 64 x 16 exchange
+};
+// XCD-aware tile order: consecutive workgroup ids go round the 8 XCDs (each with its own L2), so the row blocks that share a
+// weight tile must have ids that are EQUAL mod 8 to meet in one L2 -- with the natural (column, row) order of a 43- or
+// 65-column grid every weight tile was fetched from the fabric by four XCDs (PMC: FETCH_SIZE 4.4 x the unique bytes, L2 hit
+// rate 0.6; profiles/r05_tall_pmc.txt).  1-D grid of 8 * ceil(ncol / 8) * nrow ids: id -> (column block, row block) with the
+// column fixed by (id mod 8, id / (8 nrow)) and the row blocks of a column on consecutive slots of that XCD.  Returns false
+// for the padding ids (column >= ncol): the workgroup exits before any barrier.
+__device__ __forceinline__ bool tall_tile_of(int id, int ncol, int nrow, int& col, int& row) {
+    const int xcd = id & 7, j = id >> 3;
+    col = (j / nrow) * 8 + xcd;
+    row = j % nrow;
+    return col < ncol;
+}
+static inline unsigned tall_grid(int ncol, int nrow) { return 8u * (unsigned)((ncol + 7) / 8) * (unsigned)nrow; }
+
+template <int V, typename T, int G, bool LN, int MTW>
+__device__ __forceinline__ void tall_core_v(const T* A, const T* W, const int (&nb)[G], int nks, int mtile0, bool wave_on,
+                                            unsigned char* s_w, f32x4 (&acc)[G][MTW], float (&s1)[MTW], float (&s2)[MTW]) {
+    if constexpr (V == 0) tall_core<T, G, LN>(A, W, nb, nks, mtile0, wave_on, s_w, acc, s1, s2);
+    else tall_core_reg<T, G, LN>(A, W, nb, nks, mtile0, wave_on, acc, s1, s2);
+}
+
+// LayerNorm statistics of the rows a lane holds OUTPUTS for (D layout: rows 4 lg + r of the m-tile) from the per-lane
+// partial sums of the row it holds INPUTS for (A layout: row li): reduce over the four lane groups, then one shuffle per row.
+__device__ __forceinline__ void tall_row_stats(float s1, float s2, int lg, float inv_d, float eps, float (&mu)[4],
+                                               float (&rstd)[4]) {
+    s1 += shfl_xor(s1, 16); s2 += shfl_xor(s2, 16);
+    s1 += shfl_xor(s1, 32); s2 += shfl_xor(s2, 32);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float a = shfl(s1, 4 * lg + r), b = shfl(s2, 4 * lg + r);
+        mu[r] = a * inv_d;
+        rstd[r] = rsqrtf(fmaxf(b * inv_d - mu[r] * mu[r], 0.f) + eps);
+    }
+}
+
+}  // namespace lina

@@ -1059,6 +1059,126 @@ def check_linear_skinny_packed(dev, M, N, K, dtype, ln=False, bias=False, resid=
     same(ops.unpack_rows(out_p2, M, Np)[:, :N], out, "row-major inputs + packed output copy")
 
 
+def check_linear_tall(dev, M, N, K, dtype, ln=False, bias=False, resid=False, swiglu=0, force=True, variant=None):
+    """The tall tiling of the packed projection (linear_tall.h: 128 rows x 64 weight rows per workgroup, weights staged through
+    LDS by DMA, no split-K) against fp64 of the same bf16 / fp32 operands -- LayerNorm fold, bias, residual (row-major and
+    in-place packed), SwiGLU with the constant-1 bias column, row-major and packed outputs, ragged M / N / K-stage counts --
+    and against the skinny kernel (another summation order: fp32 rounding of the partial sums).  ``force``: LINA_TALL=1 (the
+    launcher's own rule picks the tall kernel only for M >= 128 and wide outputs)."""
+    import os
+    g = torch.Generator().manual_seed(23)
+    kq = 32 if dtype == torch.bfloat16 else 16
+    a = (torch.randn(M, K, generator=g) * 1.5 + (0.7 if ln else 0.0)).to(dtype).to(dev)
+    n_w = 2 * swiglu if swiglu else N
+    w = (torch.randn(n_w, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+    c1 = (torch.randn(n_w, generator=g)).to(dev) if ln else None
+    c2 = torch.randn(n_w, generator=g).to(dev) if (bias or ln) else None
+    r = torch.randn(M, N, generator=g).to(dtype).to(dev) if resid else None
+    a_p = ops.pack_rows(a)
+    if swiglu:
+        half = (N + 63) // 64 * 64
+        pad = lambda h: torch.cat([h, torch.zeros(half - h.shape[0], K, dtype=dtype, device=dev)])
+        w_p = torch.cat([ops.pack_rows(pad(w[:swiglu])), ops.pack_rows(pad(w[swiglu:]))])
+    else:
+        half = None
+        w_p = ops.pack_rows(w)
+    Np = (N + kq - 1) // kq * kq
+    kw = dict(swiglu_hidden=swiglu, ln_dim=K if ln else 0, w_half_rows=half)
+    prev, prev_v = os.environ.get("LINA_TALL"), os.environ.get("LINA_TALL_V")
+    try:
+        if variant is not None:                     # 0 = LDS ring, 1 = register ring (linear_tall.h); None = the launcher's default
+            os.environ["LINA_TALL_V"] = str(variant)
+        os.environ["LINA_TALL"] = "0"
+        ref_sk = torch.empty(M, N, dtype=dtype, device=dev)
+        ops.linear_skinny_packed(a_p, w_p, M, N, K, c1, c2, resid=r, out=ref_sk, **kw)
+        if force:
+            os.environ["LINA_TALL"] = "1"
+        else:
+            os.environ.pop("LINA_TALL")
+        out = torch.full((M, N), float("nan"), dtype=dtype, device=dev)
+        out_p = torch.zeros(ops.packed_numel(M, Np), dtype=dtype, device=dev)
+        ops.linear_skinny_packed(a_p, w_p, M, N, K, c1, c2, resid=r, out=out, out_packed=out_p, out_packed_width=Np, **kw)
+        if resid:
+            rp = torch.zeros(M, Np, dtype=dtype, device=dev)
+            rp[:, :N] = r
+            x_p = ops.pack_rows(rp)
+            ops.linear_skinny_packed(a_p, w_p, M, N, K, c1, c2, resid=x_p, out_packed=x_p, out_packed_width=Np, **kw)
+            assert torch.equal(ops.unpack_rows(x_p, M, Np)[:, :N], out), "tall: in-place packed residual update differs"
+    finally:
+        for name, old in (("LINA_TALL", prev), ("LINA_TALL_V", prev_v)):
+            if old is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = old
+    # fp64 of the same operands
+    a64, w64 = a.cpu().to(F64), w.cpu().to(F64)
+    if ln:
+        mu = a64.mean(-1, keepdim=True)
+        var = (a64 * a64).mean(-1, keepdim=True) - mu * mu
+        z = (a64 @ w64.t() - mu * c1.cpu().to(F64)[None]) * torch.rsqrt(var.clamp_min(0) + 1e-5) + c2.cpu().to(F64)[None]
+    else:
+        z = a64 @ w64.t() + (c2.cpu().to(F64)[None] if c2 is not None else 0.0)
+    if swiglu:
+        y = torch.zeros(M, N, dtype=F64)
+        y[:, :swiglu] = torch.nn.functional.silu(z[:, :swiglu]) * z[:, swiglu:]
+        if N > swiglu:
+            y[:, swiglu] = 1.0
+    else:
+        y = z
+    if resid:
+        y = y + r.cpu().to(F64)
+    tol = 1.6e-2 if dtype == torch.bfloat16 else 2e-5
+    assert_close(out, y, tol, "tall projection vs fp64")
+    assert_close(out, ref_sk.double().cpu(), tol, "tall projection vs the skinny kernel")
+    assert torch.equal(ops.unpack_rows(out_p, M, Np)[:, :N], out), "tall: packed output copy differs"
+
+
+def check_inproj_tall(dev, B, K, Kd, Vd, dtype, force=True, variant=None):
+    """The tall tiling of the fused input side of a mixer (gla_inproj_tall_kernel: B >= 128) against the 64-row kernel on the
+    same operands: q | k | v (conv step + SiLU), g, the gate (rank-16 up-projection + log-sigmoid) and the rolled conv caches
+    -- another summation order of the same products (no split-K), so equal to fp32 rounding of the partial sums.  The 64-row
+    kernel itself is checked against fp64 in check_inproj."""
+    import os
+    g = torch.Generator().manual_seed(31)
+    R, W = 16, 4
+    x = (torch.randn(B, K, generator=g) + 0.3).to(dtype).to(dev)
+    w_in = (torch.randn(2 * Kd + 2 * Vd + R, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+    c1 = w_in.float().sum(1).contiguous()
+    c2 = torch.randn(w_in.shape[0], generator=g).to(dev)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dtype).to(dev)
+    wq, wk, wv, w2, b2 = mk(Kd, W), mk(Kd, W), mk(Vd, W), mk(Kd, R), mk(Kd)
+    caches = [mk(B, Kd, W), mk(B, Kd, W), mk(B, Vd, W)]
+    x_p, w_p = ops.pack_rows(x), ops.pack_rows(w_in)
+    outs = []
+    prev, prev_v = os.environ.get("LINA_TALL"), os.environ.get("LINA_TALL_V")
+    try:
+        if variant is not None:
+            os.environ["LINA_TALL_V"] = str(variant)
+        for tall in (False, True):
+            if tall and not force:
+                os.environ.pop("LINA_TALL", None)
+            else:
+                os.environ["LINA_TALL"] = "1" if tall else "0"
+            cq, ck, cv = (c.clone() for c in caches)
+            qkv = torch.full((B, 2 * Kd + Vd), float("nan"), dtype=dtype, device=dev)
+            go = torch.full((B, Vd), float("nan"), dtype=dtype, device=dev)
+            gk = torch.full((B, Kd), float("nan"), dtype=torch.float32, device=dev)
+            ops.gla_decode_inproj_packed(x_p, w_p, B, K, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, go, gk,
+                                         clamp_min=-0.03 if Kd == 128 else None)
+            outs.append((qkv, go, gk, cq, ck, cv))
+    finally:
+        for name, old in (("LINA_TALL", prev), ("LINA_TALL_V", prev_v)):
+            if old is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = old
+    for name, a, b in zip(("qkv", "g", "gk", "cq", "ck", "cv"), *outs):
+        assert_close(b, a.double().cpu(), 1.6e-2 if a.dtype == torch.bfloat16 else 5e-5, f"tall in-projection: {name}")
+    # the cache roll itself is exact: three old taps move up unchanged
+    for a, c0 in zip(outs[1][3:], caches):
+        assert torch.equal(a[..., :3], c0[..., 1:]), "tall in-projection: the rolled cache taps changed"
+
+
 def _skinny_waves(K, kq):
     """Split-K width the packed projection kernels pick for this K (mirrors linear_skinny_impl / inproj_impl)."""
     import os

@@ -323,6 +323,29 @@ def test_greedy_pick_embed(hip, B, Q, L, d, dtype):
     check_greedy_pick_embed(DEV, B=B, Q=Q, L=L, d=d, dtype=dtype, steps=4)
 
 
+@pytest.mark.parametrize("M,N,K,dtype,ln,bias,resid,sw,force", [
+    (512, 4099, 1024, torch.bfloat16, False, False, False, 0, False),        # the codec head at the metric's batch
+    (512, 1376, 1024, torch.bfloat16, True, True, False, 1365, False),       # LN-2 + up-projection + SwiGLU (+ bias column)
+    (400, 1376, 1024, torch.bfloat16, True, True, False, 1365, False),
+    (130, 1024, 1376, torch.bfloat16, False, False, True, 0, True),          # down-projection shape, ragged rows, 43 k-steps
+    (200, 4099, 1024, torch.float32, False, True, False, 0, True),
+    (129, 56, 288, torch.float32, True, True, True, 40, True)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_linear_tall(hip, M, N, K, dtype, ln, bias, resid, sw, force, variant):
+    from kernel_cases import check_linear_tall
+    check_linear_tall(DEV, M, N, K, dtype, ln=ln, bias=bias, resid=resid, swiglu=sw, force=force, variant=variant)
+
+
+@pytest.mark.parametrize("B,K,Kd,Vd,dtype,force", [(512, 1024, 1024, 1024, torch.bfloat16, False),
+                                                   (130, 1024, 1024, 2048, torch.bfloat16, True),
+                                                   (70, 160, 128, 64, torch.bfloat16, True),
+                                                   (200, 256, 256, 256, torch.float32, True)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_inproj_tall(hip, B, K, Kd, Vd, dtype, force, variant):
+    from kernel_cases import check_inproj_tall
+    check_inproj_tall(DEV, B, K, Kd, Vd, dtype, force=force, variant=variant)
+
+
 @pytest.mark.parametrize("B,Q,L,d,dtype,sampled", [(64, 1, 4099, 1024, torch.bfloat16, False), (7, 4, 1027, 256, torch.float32, False),
                                                    (64, 1, 4099, 1024, torch.bfloat16, True), (9, 3, 513, 64, torch.float32, True)])
 def test_pick_loop_control_block(hip, B, Q, L, d, dtype, sampled):
