@@ -6,11 +6,15 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one decode token for every row of the batch: the whole hot path (13 GLA blocks with
-the fused HIP step kernels, blind cross-attention, 4099-way head, device-side argmax + next-token
-embedding) as one hipGraph replay.  B = 64 rows per GPU (BASELINE.json configs[1]); with N GPUs the
-utterance batch is sharded 64/GPU with NO data-path collective (weak scaling; B = 512 at N = 8).
-Inputs and state are resident in HBM when the timed region starts.  Synthetic data, seeded
-random-init weights from the reference initialisers.
+the fused HIP step kernels, blind cross-attention, 4099-way head, device-side pick + stop flags +
+attention log + next-token embedding) -- the loop `LinaModel.generate_batch` runs, 8 tokens per
+hipGraph replay.  The utterance batch is the one BASELINE.json's metric is quoted on, B_total = 512
+(`--total-batch`), sharded over the N GPUs with NO data-path collective: 512 rows on one GPU at
+N = 1, 64 per GPU at N = 8 ("scaling": "strong").  `--batch-per-gpu R` keeps R rows per GPU instead
+(weak scaling; R = 64 is BASELINE configs[1]); at N = 1 the per-GPU batches 64 / 128 / 256 are
+measured beside the headline (`per_gpu_batch`), and the reference's decode ENTRY POINT end to end
+(`generate_batch`).  Inputs and state are resident in HBM when the timed region starts.  Synthetic
+data, seeded random-init weights from the reference initialisers.
 
 Prints ONE JSON line (rank 0) with the driver contract plus
   roofline      the dominant kernel of the step -- K1w + K5 (lina::gla_decode_window_kernel), the windowed recurrent-state
@@ -38,7 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-B_PER_GPU = 64               # default of --batch-per-gpu: BASELINE.json configs[1] (the metric's B = 512 is 8 x 64)
+TOTAL_BATCH = 512            # default of --total-batch: the batch BASELINE.json's metric is quoted on (8 x configs[1]'s 64)
 T_TXT = 64
 
 
@@ -467,19 +471,20 @@ def check_launch(args):
     group, contributes its rank to an all-reduce and rank 0 prints what it saw."""
     rank, local, world, dev, dist = init_world(args.gpus)
     seen = world
+    total = args.total_batch if args.batch_per_gpu is None else args.batch_per_gpu * world
     if dist is not None:
         t = torch.ones(1, device=dev)
         dist.all_reduce(t)
         seen = int(t.item())
         from lina_speech_amd.shard import shard_rows
-        lo, hi = shard_rows(args.batch_per_gpu * world, rank, world)
+        lo, hi = shard_rows(total, rank, world)
         rows = torch.tensor([float(hi - lo)], device=dev)
         dist.all_reduce(rows)
-        assert int(rows.item()) == args.batch_per_gpu * world
+        assert int(rows.item()) == total
     if rank == 0:
         print(json.dumps({"check_launch": True, "n_gpus": args.gpus, "world_size": world, "ranks_seen": seen,
                           "backend": (dist.get_backend() if dist is not None else None),
-                          "rows_total": args.batch_per_gpu * world}), flush=True)
+                          "rows_total": total, "scaling": "strong" if args.batch_per_gpu is None else "weak"}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -584,15 +589,15 @@ def step_hbm_bytes(eng):
     return s_bytes, w_bytes, kv_bytes, s_bytes_imm
 
 
-def measure_big_batch(model_dev, dev, B=512, steps=120):
-    """The batch the metric is quoted on (B = 512) on ONE GPU: 6.8 GB of recurrent state, the same engine and graph loop.
-    At this size the state traffic (14 GB per token), not the 59 latency-bound projection launches, is most of the step."""
+def measure_batch(model_dev, dev, B=512, steps=120):
+    """The same engine and device loop at another per-GPU batch (secondary blocks beside the headline): ms per token, tok/s and
+    the step against its HBM bytes."""
     from lina_speech_amd.decode import DecodeEngine
     g = torch.Generator().manual_seed(4321)
     texts = torch.randint(3, 256, (B, T_TXT), generator=g).to(dev)
     with torch.inference_mode():
         eng = DecodeEngine(model_dev, model_dev.txt_encoder(model_dev.txt_embed(texts)), batch_size=B)
-        eng.begin_greedy(steps + 80)
+        eng.begin_greedy(steps + 80, log_att=True)
         eng.greedy_steps(16)                     # captures the multi-token graph
         eng.greedy_steps(48)
         torch.cuda.synchronize()
@@ -607,7 +612,7 @@ def measure_big_batch(model_dev, dev, B=512, steps=120):
         del eng
     torch.cuda.empty_cache()
     nb = s_b + w_b + kv_b
-    return {"what": f"the same decode loop with B = {B} rows on ONE GPU (the metric's batch; secondary, not `value`)",
+    return {"what": f"the same decode loop with B = {B} rows on ONE GPU (secondary, not `value`)",
             "batch": B, "steps_timed": steps, "ms_per_step": dt * 1e3, "tokens_per_s": B / dt,
             "step_roofline": {"state_bytes": s_b, "weight_bytes": w_b, "text_kv_bytes": kv_b, "bytes_per_step": nb,
                               "bound": "hbm", "achieved": nb / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -623,7 +628,7 @@ def measure_generate_batch(model_dev, texts, dev, loop_ms, max_seqlen=750):
     un-delay and the per-row cuts -- wall time of the whole call on a warm engine cache (the first call of a (batch, text
     length) builds the engine: packs the weights, captures two hipGraphs; reported as `first_call_s`).  Greedy and the
     reference's default sampled mode (k = 100, first quantizer sampled); plus one EARLY-STOPPING call on a copy of the model
-    whose stop-token head row is scaled up so that every row emits token 2 within ~100 steps (random-init weights never do)."""
+    whose stop-token head row is scaled up (x 6) so that every row emits token 2 within ~100 steps (random-init weights never do)."""
     import copy
     B = texts.shape[0]
     res = {"what": f"LinaModel.generate_batch(x, batch_size={B}, max_seqlen={max_seqlen}, force_max_seqlen=True, device=...) "
@@ -649,7 +654,7 @@ def measure_generate_batch(model_dev, texts, dev, loop_ms, max_seqlen=750):
                          "loop_ms_per_step": loop_ms, "vs_loop": (best / max_seqlen * 1e3) / loop_ms if loop_ms else None}
         # early stop: scale the stop token's head row (logit_2 = s * <h, w_2>: positive and dominant at random steps)
         m2 = copy.deepcopy(model_dev)
-        m2.logits_head.weight[0, 2] *= 3.0
+        m2.logits_head.weight[0, 2] *= 6.0
         m2.generate_batch(texts, batch_size=B, max_seqlen=64, k=1, first_greedy_quant=0, device=dev, force_max_seqlen=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -658,7 +663,7 @@ def measure_generate_batch(model_dev, texts, dev, loop_ms, max_seqlen=750):
         dt = time.perf_counter() - t0
         eng = next(reversed(m2._decode_engines.values()))
         n = qs.shape[-1]
-        res["early_stop"] = {"what": "stop-token head row x 3; force_max_seqlen=False, stop_check_every=16 (default)",
+        res["early_stop"] = {"what": "stop-token head row x 6; force_max_seqlen=False, stop_check_every=16 (default)",
                              "steps_returned": n, "steps_executed": eng._n_done, "seconds": dt,
                              "ms_per_returned_step": dt / n * 1e3, "stopped_early": n < max_seqlen,
                              "cut_lengths_min_max": [min(c[0].shape[-1] for c in cuts), max(c[0].shape[-1] for c in cuts)]}
@@ -682,8 +687,11 @@ def main():
     ap.add_argument("--train", action="store_true", help="measure config 5 (the DDP training step) instead of decode")
     ap.add_argument("--train-batch", type=int, default=8, help="--train: sequences of 4096 tokens per GPU")
     ap.add_argument("--check-launch", action="store_true", help="only exercise the N-rank launch / rendezvous logic")
-    ap.add_argument("--batch-per-gpu", type=int, default=B_PER_GPU,
-                    help="utterance rows per GPU (default 64 = BASELINE configs[1]; 512 puts the metric's whole batch on one GPU)")
+    ap.add_argument("--total-batch", type=int, default=TOTAL_BATCH,
+                    help="utterance rows of the whole job, sharded over the GPUs (default 512 = the batch BASELINE's metric is "
+                         "quoted on: strong scaling, 512 / N rows per GPU)")
+    ap.add_argument("--batch-per-gpu", type=int, default=None,
+                    help="instead of --total-batch: this many rows on EVERY GPU (weak scaling; 64 = BASELINE configs[1])")
     ap.add_argument("--window", type=int, default=None, help="state window of the decode loop (1 = immediate update K1d; default 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chunk", action="store_true")
@@ -707,7 +715,10 @@ def main():
     ops.get_backend().lib                                            # fail loudly if the HIP library is missing
 
     from lina_speech_amd.shard import shard_rows
-    total_rows = args.batch_per_gpu * world
+    weak = args.batch_per_gpu is not None
+    total_rows = args.batch_per_gpu * world if weak else args.total_batch
+    if total_rows < world:
+        raise SystemExit(f"bench.py: {total_rows} utterance rows cannot be sharded over {world} GPUs")
     lo, hi = shard_rows(total_rows, rank, world)                     # this rank's utterances
     B = hi - lo
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -727,7 +738,7 @@ def main():
         t_pre = time.perf_counter()
         n_pre = 0
         while time.perf_counter() - t_pre < args.preheat_s or n_pre == 0:
-            eng.begin_greedy(150)
+            eng.begin_greedy(150, log_att=True)
             for _ in range(100):
                 eng.greedy_step()
             torch.cuda.synchronize()
@@ -743,7 +754,8 @@ def main():
             kk = torch.tensor([k_run, k_sus], device=dev, dtype=torch.int64)   # every rank sizes its token log for the same counts
             dist.all_reduce(kk, op=dist.ReduceOp.MAX)
             k_run, k_sus = int(kk[0].item()), int(kk[1].item())
-        eng.begin_greedy(k_run + k_sus + args.warmup + 8)
+        # the loop generate_batch runs: picks, stop flags, the attention log and the next-token embedding inside the step
+        eng.begin_greedy(k_run + k_sus + args.warmup + 8, log_att=True)
         eng.greedy_steps(8)                                           # captures the multi-token graph (untimed)
         for _ in range(args.warmup):
             eng.greedy_step()
@@ -765,11 +777,14 @@ def main():
             k1d_bytes = k1_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4)
             k1_bytes = k1w_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4, eng.window) if lazy else k1d_bytes
             traffic, traffic_src = None, None
-            names = ("r04_k1w_traffic.json", "r02_k1w_traffic.json") if lazy else ("r02_k1d_traffic.json", "r01_k1d_traffic.json")
+            names = ("r05_k1w_traffic_b%d.json" % k1_rows, "r04_k1w_traffic.json", "r02_k1w_traffic.json") if lazy \
+                else ("r02_k1d_traffic.json", "r01_k1d_traffic.json")
             for name in names:                                # PMC passes are separate runs; their committed summary
                 tpath = os.path.join(ROOT, "profiles", name)
-                if os.path.exists(tpath) and k1_rows == 64 and dtype == torch.bfloat16:
+                if os.path.exists(tpath) and dtype == torch.bfloat16:
                     tj = json.load(open(tpath))
+                    if tj.get("rows_per_launch", 64) != k1_rows:
+                        continue
                     traffic = tj["traffic_bytes_per_launch"]
                     traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
                     break
@@ -811,13 +826,16 @@ def main():
                 "metric": "codec tokens/sec (whole node), 169M d1024xl12 batched greedy decode",
                 "value": total_rows * k_run / elapsed, "unit": "codec tokens/s", "n_gpus": world,
                 "steps": k_run, "steps_requested": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
                 "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
-                "config": {"workload": f"L169 greedy codec-token decode, B={args.batch_per_gpu}/GPU (B_total={total_rows}), "
+                "config": {"workload": f"L169 greedy codec-token decode, B_total={total_rows} ({B} rows on this GPU" + (", fixed per GPU" if weak else f" = B_total / {world}") + "), "
                                        f"T_txt={T_TXT}, H=4 Dk=Dv=256, 12+1 GLA blocks, fp32 recurrent state, "
                                        f"{nparam / 1e6:.1f}M params, one hipGraph replay per {eng.GRAPH_STEPS} tokens, state window {eng.window}, "
                                        f"{len(eng.parts)} parallel row ranges per GPU",
-                           "global_batch": total_rows, "parallelism": f"batch-shard x{world} (no collective)",
+                           "global_batch": total_rows, "rows_per_gpu": B,
+                           "loop": "the device loop LinaModel.generate_batch runs (picks, stop flags, attention log, next-token "
+                                   "embedding inside the captured step)",
+                           "parallelism": f"batch-shard x{world} (no collective)",
                            "timed_region": f"exactly {k_run} steps" + (f" (--min-timed-s {args.min_timed_s})" if args.min_timed_s > 0 else "")},
                 "min_timed_s": args.min_timed_s,
                 "sustained": {"what": f"the same loop over >= {SUSTAINED_S} s right after the timed region (secondary; not `value`)",
@@ -841,10 +859,28 @@ def main():
                 torch.cuda.synchronize()
                 out["sampled_decode"] = {"k": 100, "temp": 1.0, "ms_per_step": (time.perf_counter() - ts0) / 50 * 1e3,
                                          "tokens_per_s": B * 50 / (time.perf_counter() - ts0)}
+            if world == 1 and dtype == torch.bfloat16:
+                # the reference's entry point end to end, on the headline batch and on configs[1]'s 64 rows
+                gb = {}
+                for bb in sorted({B, 64}):
+                    try:
+                        gb[f"B={bb}"] = measure_generate_batch(model_dev, texts[:bb] if bb <= B else texts, dev,
+                                                                ms_step if bb == B else None)
+                    except Exception as e:                       # (a secondary block must not cost the headline line)
+                        gb[f"B={bb}"] = {"error": repr(e)}
+                out["generate_batch"] = gb
             if not args.no_chunk and world == 1:
-                if dtype == torch.bfloat16 and args.batch_per_gpu != 512:
-                    out["b512_one_gpu"] = measure_big_batch(model_dev, dev)
-                out["config3_pipeline"] = measure_config3(eng, dev, B)
+                if dtype == torch.bfloat16:
+                    per = {}
+                    for bb in (64, 128, 256, 512):
+                        if bb == B:
+                            continue
+                        try:
+                            per[f"B={bb}"] = measure_batch(model_dev, dev, B=bb)
+                        except Exception as e:
+                            per[f"B={bb}"] = {"error": repr(e)}
+                    out["per_gpu_batch"] = per
+                out["config3_pipeline"] = measure_config3(eng, dev, min(B, 64))
                 out["chunk_kernel"] = measure_chunk(dev)
                 for hh in (8, 16):                                   # the same width as 8 / 16 heads: 2 / 4 heads per workgroup
                     ck = measure_chunk(dev, B=64, H=hh, Dk=1024 // hh, Dv=1024 // hh, reps=100)

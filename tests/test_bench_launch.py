@@ -22,7 +22,11 @@ def test_bench_gpus_2_relaunches_itself_with_two_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
-    assert j["world_size"] == 2 and j["ranks_seen"] == 2 and j["n_gpus"] == 2 and j["rows_total"] == 128
+    assert j["world_size"] == 2 and j["ranks_seen"] == 2 and j["n_gpus"] == 2
+    assert j["rows_total"] == 512 and j["scaling"] == "strong"        # B_total = 512 (the metric's batch) split over the ranks
+    r = _run(["bench.py", "--gpus", "2", "--check-launch", "--batch-per-gpu", "64"])
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["rows_total"] == 128 and j["scaling"] == "weak"
 
 
 def test_bench_under_the_drivers_launcher_sees_world_2():
@@ -49,7 +53,7 @@ def test_decode_bench_under_a_live_rccl_process_group_on_one_gpu():
         pytest.skip("no ROCm device")
     r = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
               "--master-port", "29741", "bench.py", "--gpus", "1", "--steps", "24", "--warmup", "4", "--preheat-s", "0.2",
-              "--no-chunk", "--no-train", "--no-cpu-baseline"],
+              "--batch-per-gpu", "64", "--no-chunk", "--no-train", "--no-cpu-baseline"],
              {"LINA_BENCH_FORCE_PG": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])

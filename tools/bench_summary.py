@@ -7,9 +7,18 @@ print(f"decode: {d['value']:.0f} tok/s  {d['ms_per_step']:.4f} ms/step  step_roo
 for k in ("chunk_kernel", "chunk_kernel_h8", "chunk_kernel_h16", "chunk_kernel_dv512", "chunk_kernel_b8", "chunk_bwd_kernel", "chunk_bwd_kernel_b64"):
     if k in d:
         print(f"{k}: {d[k]['ms']:.4f} ms  frac {d[k]['frac']:.3f}")
-if "b512_one_gpu" in d:
-    b = d["b512_one_gpu"]
-    print(f"b512_one_gpu: {b['tokens_per_s']:.0f} tok/s  {b['ms_per_step']:.4f} ms/step  step_roofline {b['step_roofline']['frac']:.3f}")
+for k, b in d.get("per_gpu_batch", {}).items():
+    if "error" in b:
+        print(f"per_gpu_batch {k}: {b['error']}")
+    else:
+        print(f"per_gpu_batch {k}: {b['tokens_per_s']:.0f} tok/s  {b['ms_per_step']:.4f} ms/step  step_roofline {b['step_roofline']['frac']:.3f}")
+for k, b in d.get("generate_batch", {}).items():
+    if "error" in b:
+        print(f"generate_batch {k}: {b['error']}")
+    else:
+        print(f"generate_batch {k}: greedy {b['greedy']['tokens_per_s']:.0f} tok/s ({b['greedy']['vs_loop']} x loop), sampled "
+              f"{b['sampled_k100']['tokens_per_s']:.0f}, first call {b['first_call_s']:.2f} s, early stop returned "
+              f"{b['early_stop']['steps_returned']} of {b['early_stop']['steps_executed']} executed steps")
 for k in ("sampled_decode", "train_step", "decode_f32"):
     if k in d:
         print(f"{k}: {d[k].get('ms_per_step'):.4f} ms/step  {d[k].get('tokens_per_s'):.0f} tok/s")

@@ -12,7 +12,7 @@ from lina_speech_amd.decode import DecodeEngine
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = l169().eval().to(dev, torch.bfloat16)
-B = 64
+B = int(os.environ.get("K1_B", 64))
 texts = torch.randint(3, 256, (B, 64), generator=torch.Generator().manual_seed(1234)).to(dev)
 with torch.inference_mode():
     eng = DecodeEngine(model, model.txt_encoder(model.txt_embed(texts)), batch_size=B, use_graph=False)

@@ -3,7 +3,7 @@
 corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM) prescribes for gfx950: FETCH_SIZE tallies the 128-byte requests of a
 16-B/lane streaming read at 64 B -> doubled; WRITE_SIZE as reported.  Writes a JSON summary.
 
-    python tools/pmc_traffic.py k1w <fetch_dir> <write_dir> out.json
+    python tools/pmc_traffic.py k1w <fetch_dir> <write_dir> out.json [rows per launch, default 64]
     python tools/pmc_traffic.py k2  <fetch_dir> <write_dir> out.json <heads> [kernel_stats.csv]
     python tools/pmc_traffic.py k2b <fetch_dir> <write_dir> out.json <heads>      (sum over the sweeps of one backward call)
 """
@@ -41,13 +41,13 @@ if which == "k2b":
              note="algorithmic = q, k, v, g, do in + dq, dk, dv, dg out (9 tensor passes); the three sweeps make 18",
              algorithmic_bytes_per_launch=alg, traffic_over_algorithmic=(rd + wr) / alg)
 elif which == "k1w":
-    B, H, Dk, Dv, W = 64, 4, 256, 256, 8
+    B, H, Dk, Dv, W = (int(sys.argv[5]) if len(sys.argv) > 5 else 64), 4, 256, 256, 8
     alg = int(B * (4 * H * Dk * Dv * (1 + 1 / W) + 2 * (2 * H * Dk + 2 * H * Dv) + 4 * H * Dk + 4 * H * (2 * Dk + Dv)
                    + 4 * H * (2 * Dk + Dv) * (W - 1) / 2))
     o.update(kernel="lina::gla_decode_window_kernel<256, 4, 1, bf16, float> (K1w + K5, window 8)",
              command="rocprofv3 --kernel-trace --pmc <COUNTER> -- python tools/perf_k1w.py (the 13 layers' real buffers, all 8 "
                      "window positions in turn; tests/gpu_evidence.sh)",
-             note="mean over all launches of the run = all 8 window positions (7 read-only, 1 write-back)",
+             note="mean over all launches of the run = all 8 window positions (7 read-only, 1 write-back)", rows_per_launch=B,
              algorithmic_bytes_per_launch=alg, traffic_over_algorithmic=(rd + wr) / alg)
 else:
     heads = int(sys.argv[5])
