@@ -174,6 +174,7 @@ def measure_chunk(dev, B=64, H=4, T=4096, Dk=256, Dv=256, reps=200):
     flops = B * H * T * (2 * 64 * (Dk + Dv) + 4 * Dk * Dv)            # nominal C=64 count of SURVEY 8(d)
     traffic, traffic_src = None, None
     for name, note in (("r02_k2_b8_traffic.json", "; state-only pass + combine + full pass of the segment-parallel form"),
+                       ("r05_k2_b8_traffic.json", "; state-only pass + combine + full pass of the segment-parallel form"),
                        ("r04_k2_h4_traffic.json", "; the training call"), ("r04_k2_h8_traffic.json", "; the training call"),
                        ("r04_k2_h16_traffic.json", "; the training call")):
         tpath = os.path.join(ROOT, "profiles", name)                 # PMC passes are separate runs; their committed summaries
@@ -182,8 +183,16 @@ def measure_chunk(dev, B=64, H=4, T=4096, Dk=256, Dv=256, reps=200):
             if tj.get("shape") == {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv}:
                 traffic = tj["traffic_bytes_per_launch"]
                 traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected{note})"
+    sq = None                                                        # SQ counter passes (separate rocprofv3 runs): committed summary
+    spath = os.path.join(ROOT, "profiles", "r05_k2_sq.json")
+    if os.path.exists(spath) and (B, H, T, Dk, Dv) == (64, 4, 4096, 256, 256):
+        der = next(iter(json.load(open(spath))["kernels"].values()))["derived"]
+        sq = {"source": "profiles/r05_k2_sq.json (rocprofv3 --pmc, SQ counters; tools/pmc_sq.py)",
+              **{k_: der[k_] for k_ in ("mfma_util", "wait_share", "issue_stall", "active_share", "valu_share", "lds_conflict")
+                 if k_ in der}}
     return {"kernel": "lina::gla_chunk_bf16_h256_kernel", "shape": {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv},
             "bytes_per_launch": nbytes, "traffic": traffic, "traffic_source": traffic_src,
+            "mfma_util": None if sq is None else sq["mfma_util"], "sq_counters": sq,
             "dtype": "bf16", "ms": dt * 1e3, "ms_burst_of_3": burst * 1e3, "bound": "hbm", "achieved": nbytes / dt / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS, "tflops": flops / dt / 1e12,
             "call": "output_final_state=False (the training call)",
@@ -209,13 +218,15 @@ def measure_chunk_bwd(dev, B=8, H=4, T=4096, Dk=256, Dv=256, reps=100):
                           reps=reps)
     nbytes = B * H * T * 2 * (5 * Dk + 4 * Dv)
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r04_k2b_traffic.json")     # PMC passes are separate runs; their committed summary
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("shape") == {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv}:
-            traffic = tj["traffic_bytes_per_launch"]
-            traffic_src = ("profiles/r04_k2b_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected; per backward "
-                           "call = the three sweeps: 18 tensor passes for the 9 algorithmic ones)")
+    for tname in ("r04_k2b_traffic.json", "r05_k2b_b8_traffic.json"):   # PMC passes are separate runs; their committed summaries
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("shape") == {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv}:
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_src = (f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected; per backward "
+                               "call = the three sweeps: 18 tensor passes for the 9 algorithmic ones"
+                               + (" + the boundary states of the segment-parallel form" if B * H < 256 else "") + ")")
     return {"kernel": "lina::gla_chunk_bf16_h256_kernel<MODE, REV, DG>: reverse sweep (dv, dS) + value-gated sweeps (dq | dk, dg)"
                       + (f", {nseg} sequence segments from boundary states (forward's S, one state-only reverse pass for dS)"
                          if nseg > 1 else ""),
@@ -880,7 +891,7 @@ def main():
                         except Exception as e:
                             per[f"B={bb}"] = {"error": repr(e)}
                     out["per_gpu_batch"] = per
-                out["config3_pipeline"] = measure_config3(eng, dev, min(B, 64))
+                out["config3_pipeline"] = measure_config3(eng, dev, B)
                 out["chunk_kernel"] = measure_chunk(dev)
                 for hh in (8, 16):                                   # the same width as 8 / 16 heads: 2 / 4 heads per workgroup
                     ck = measure_chunk(dev, B=64, H=hh, Dk=1024 // hh, Dv=1024 // hh, reps=100)
