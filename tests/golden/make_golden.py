@@ -214,6 +214,59 @@ def golden_config5_slice():
     npz("l169_slice_T4096.npz", **out)
 
 
+def golden_config5_structured():
+    """The config-5 slice again (d=1024, H=4, 3 GLA blocks, T=4096, b=1) on a WELL-CONDITIONED problem: the targets follow a
+    seeded successor chain (y[t+1] = succ[y[t]] for 90 % of the positions, random otherwise) -- a bigram structure every
+    block's gradient sees coherently, instead of 4096 random targets whose contributions cancel (on those the reference's own
+    bf16-autocast gradients are 19-35 % off its fp32 ones on single entries, so a bf16 check against them cannot bite).
+    Stored: loss, and per parameter gradient its norm, max and 4096 strided entries (fp32 reference autograd); plus, as the
+    yardstick, the cosine / norm error of the REFERENCE's own bf16-autocast gradients against them."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from model_cases import reseed_parameters, grad_digest, structured_targets
+    seed = 5
+    torch.manual_seed(0)
+    model = reseed_parameters(build_lina(d=1024, n_layer=1, heads=4, n_codebook=4096, txt_layers=1), seed=seed).train()
+    B, Ttxt, n = 1, 64, 4097
+    g = torch.Generator().manual_seed(23)
+    x = torch.randint(3, 256, (B, Ttxt), generator=g)
+    y = structured_targets(B, n, 4099, seed=29)
+    em = torch.ones(B, Ttxt, Ttxt, dtype=torch.bool)
+    cm = torch.ones(B, n, Ttxt, dtype=torch.bool)
+    lm = torch.ones(B, n, dtype=torch.bool)
+    model.zero_grad()
+    _, loss, _, _, _ = model(x, y, em, cm, logits_mask=lm)
+    loss.backward()
+    out = dict(x=x, y=y, loss=loss.detach(), seed=torch.tensor(seed))
+    ref = {}
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        nrm, mx, sam = grad_digest(p.grad, n=4096)
+        out["gnorm::" + name], out["gmax::" + name], out["gsam::" + name] = torch.tensor(nrm), torch.tensor(mx), sam
+        ref[name] = p.grad.detach().clone()
+    model.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, loss16, _, _, _ = model(x, y, em, cm, logits_mask=lm)
+    loss16.backward()
+    names, cos, nerr = [], [], []
+    for name, p in model.named_parameters():
+        if name not in ref:
+            continue
+        a, b = p.grad.detach().float().flatten(), ref[name].float().flatten()
+        names.append(name)
+        cos.append(float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-30)))
+        nerr.append(float((a.norm() - b.norm()).abs() / b.norm().clamp_min(1e-30)))
+    out["bf16ref_names"] = np.array(names)
+    out["bf16ref_cos"] = np.array(cos, dtype=np.float32)
+    out["bf16ref_norm_err"] = np.array(nerr, dtype=np.float32)
+    out["bf16ref_loss"] = loss16.detach().float()
+    order = np.argsort(cos)
+    print("loss", float(loss), "bf16", float(loss16))
+    print("lowest cosines:", [(names[i], round(cos[i], 4), round(nerr[i], 4)) for i in order[:12]])
+    print("median cosine", float(np.median(cos)), "max norm err", max(nerr))
+    npz("l169_slice_T4096_structured.npz", **out)
+
+
 def golden_tools():
     """Known answers of model/tools.py helpers."""
     torch.manual_seed(0)
@@ -294,7 +347,8 @@ if __name__ == "__main__":
     import argparse
     only = sys.argv[1:]
     todo = {"vocoder": golden_vocoder, "tools": golden_tools, "mixer": golden_mixer, "lina": golden_lina,
-            "simple_gla": golden_simple_gla, "config5_slice": golden_config5_slice}
+            "simple_gla": golden_simple_gla, "config5_slice": golden_config5_slice,
+            "config5_structured": golden_config5_structured}
     for name, fn in todo.items():
         if not only or name in only:
             fn()

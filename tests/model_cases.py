@@ -290,6 +290,77 @@ def check_generate_batch_early_stop(dev, dtype=torch.float32, d=256, B=8, max_se
         assert late >= 1, "no seed stopped after step 40: the stop check never ran more than a few times"
 
 
+def check_config5_structured_golden(dev, dtype=torch.float32, rel_loss=2e-4, rel_grad=5e-3, min_cos=0.97, max_norm_err=5e-2):
+    """The config-5 slice (L169 width, 3 GLA blocks, b = 1, T = 4096) on a WELL-CONDITIONED problem -- targets that follow a
+    bigram chain (structured_targets), so that every block's gradient is a sum of coherent terms instead of 4096 cancelling
+    ones -- against the REFERENCE's fp32 autograd (tests/golden/l169_slice_T4096_structured.npz: loss, and per parameter the
+    gradient's norm, max and 4096 strided entries).
+      fp32: every sampled entry within ``rel_grad`` of max|golden| (as check_config5_slice_golden);
+      bf16 autocast (the way training runs: K2 / K2b full-head kernels, bf16 MFMA): per tensor COSINE of the sampled entries
+      with the fp32 reference >= ``min_cos`` and norm error <= ``max_norm_err``.  On this problem the reference's own modules
+      under torch.autocast(bfloat16) reach cosine 0.975-0.99 (median 0.984) and norm errors <= 1.5 % against their fp32
+      gradients (stored in the golden): a kernel that loses 25 % of a gradient component lands below 0.97.  This replaces the
+      round-4 rule "1.6 x the reference's bf16 deviation + 0.02" (0.3-0.6 relative on single entries of the random-target run)."""
+    from lina_speech_amd.configs import l169
+    from kernel_cases import record_parity
+    g = load_golden("l169_slice_T4096_structured.npz")
+    torch.manual_seed(0)
+    model = reseed_parameters(l169(n_layer=1, txt_layers=1), seed=int(g["seed"])).to(dev).train()
+    x, y = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["y"]).to(dev)
+    assert torch.equal(y.cpu(), structured_targets(1, y.shape[1], 4099, seed=29)), "the golden's targets are the documented chain"
+    em = torch.ones(x.shape[0], x.shape[1], x.shape[1], dtype=torch.bool, device=dev)
+    cm = torch.ones(x.shape[0], y.shape[1], x.shape[1], dtype=torch.bool, device=dev)
+    lm = torch.ones(x.shape[0], y.shape[1], dtype=torch.bool, device=dev)
+    model.zero_grad()
+    if dtype == torch.float32:
+        _, loss, _, _, _ = model(x, y, em, cm, logits_mask=lm)
+    else:
+        with torch.autocast("cuda", dtype=dtype):
+            _, loss, _, _, _ = model(x, y, em, cm, logits_mask=lm)
+    loss.backward()
+    tag = f"config-5 slice T=4096, bigram targets ({str(dtype)[6:]})"
+    e = abs(float(loss.detach()) - float(g["loss"])) / abs(float(g["loss"]))
+    record_parity(f"{tag}: loss vs reference autograd", e, rel_loss)
+    assert e <= rel_loss, (float(loss), float(g["loss"]))
+    names = [k[6:] for k in g.files if k.startswith("gsam::")]
+    largest = max(float(g["gmax::" + n]) for n in names)
+    ref_cos = dict(zip([str(n) for n in g["bf16ref_names"]], g["bf16ref_cos"].tolist()))
+    grads = dict(model.named_parameters())
+    worst = {"cos": (2.0, None), "norm": (0.0, None), "max": (0.0, None)}
+    n_checked = 0
+    for name in names:
+        grad = grads[name].grad
+        assert grad is not None, name
+        nrm, mx, sam = grad_digest(grad, n=4096)
+        ref_sam, ref_mx, ref_nrm = torch.from_numpy(g["gsam::" + name]), float(g["gmax::" + name]), float(g["gnorm::" + name])
+        if ref_mx < 1e-5 * largest:                         # analytically zero: noise on both sides
+            assert mx < 1e-3 * largest, (name, mx)
+            continue
+        n_checked += 1
+        cos = float((sam @ ref_sam) / (sam.norm() * ref_sam.norm()).clamp_min(1e-30))
+        en = abs(nrm - ref_nrm) / ref_nrm
+        es = float((sam - ref_sam).abs().max()) / ref_mx
+        if cos < worst["cos"][0]:
+            worst["cos"] = (cos, name)
+        if en > worst["norm"][0]:
+            worst["norm"] = (en, name)
+        if es > worst["max"][0]:
+            worst["max"] = (es, name)
+    assert n_checked > 80
+    if dtype == torch.float32:
+        record_parity(f"{tag}: worst |sampled gradient - golden| / max|golden| over {n_checked} tensors", worst["max"][0], rel_grad,
+                      tensor=worst["max"][1], lowest_cosine=worst["cos"][0])
+        assert worst["max"][0] <= rel_grad, worst
+    else:
+        record_parity(f"{tag}: 1 - lowest per-tensor cosine with the fp32 reference gradients over {n_checked} tensors",
+                      1.0 - worst["cos"][0], 1.0 - min_cos, tensor=worst["cos"][1],
+                      reference_bf16_autocast_cosine_of_that_tensor=ref_cos.get(worst["cos"][1]),
+                      reference_bf16_autocast_lowest_cosine=min(v for k, v in ref_cos.items() if abs(v) > 0.5))
+        record_parity(f"{tag}: worst per-tensor gradient-norm error vs the fp32 reference", worst["norm"][0], max_norm_err,
+                      tensor=worst["norm"][1])
+        assert worst["cos"][0] >= min_cos and worst["norm"][0] <= max_norm_err, worst
+
+
 def check_init_state_tuning_golden(dev, rel=5e-4):
     """f-4: loss and the gradients of the rank-1 start-state parameters (dh0 out of K2b, through
     get_state_from_params) equal the reference's (golden from the reference modules, mode 'fused_recurrent',
@@ -470,6 +541,21 @@ def grad_errors_by_group(named_grads, g, zero_tol):
             w["max"], w["tensor"] = es, name
         w["l2"], w["norm"] = max(w["l2"], el), max(w["norm"], en)
     return worst, n_zero
+
+
+def structured_targets(B, n, vocab, seed=29, follow=0.9):
+    """Codec-token targets with a bigram structure: y[0] = BOS (1), then y[t+1] = succ[y[t]] with probability ``follow``
+    (succ = a seeded permutation of the code tokens 3..vocab-1), a random code token otherwise.  [B, n, 1] int64."""
+    g = torch.Generator().manual_seed(seed)
+    succ = torch.randperm(vocab - 3, generator=g) + 3
+    succ = torch.cat([succ[:3], succ])
+    y = torch.empty(B, n, dtype=torch.long)
+    y[:, 0] = 1
+    rnd = torch.randint(3, vocab, (B, n), generator=g)
+    keep = torch.rand(B, n, generator=g) < follow
+    for t in range(1, n):
+        y[:, t] = torch.where(keep[:, t], succ[y[:, t - 1]], rnd[:, t])
+    return y.unsqueeze(-1)
 
 
 def grad_digest(t, n: int = 256):
