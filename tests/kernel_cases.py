@@ -754,7 +754,9 @@ def check_swiglu_mlp(dev, B, T, d, H, dtype, bias=True):
     # a write through ``.data`` does NOT bump the version (EMA swaps, weight clipping): the documented way out is
     # ops.clear_mlp_pack() (also part of ops.clear_workspaces and of TrainStep.step)
     pack3 = _MLP_PACK[m[1]][1]
-    m[3].data.mul_(0.5)
+    m[3].data.mul_(0.5)                                      # back to the original weights, behind the version counter's back
+    if bias:
+        m[4].data.mul_(0.5)
     assert ops.swiglu_mlp(*m) is not None and _MLP_PACK[m[1]][1] is pack3, "expected: the stale pack is still served"
     ops.clear_mlp_pack()
     y4 = ops.swiglu_mlp(*m)

@@ -263,7 +263,7 @@ def test_config5_slice_at_sequence_length_4096_bf16_autocast_tracks_reference_au
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_config5_slice_bigram_targets_cosine_with_reference_gradients(hip, dtype):
     """A bf16 train check that bites: the T = 4096 slice on coherent (bigram) targets -- fp32 entries within
-    5e-3, bf16-autocast per-tensor cosine >= 0.97 and norm error <= 5 % against the reference's fp32 autograd."""
+    5e-3, bf16-autocast per-tensor cosine >= 0.97 and norm error <= 10 % against the reference's fp32 autograd."""
     from model_cases import check_config5_structured_golden
     check_config5_structured_golden("cuda", dtype)
 
