@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64 * TallShape<V>::NWV) void gla_inproj_tall_kernel
     const int nks = K / F::KSTEP;
     const bool wave_on = m0 < (M + 63) / 64 * 64;
     const float inv_k = fast_rcp((float)K);
-    float s1[MTW], s2[MTW];
+    float s1[MTW][4], s2[MTW][4];
 
     if (gate_wg) {
         const int c0 = (cblk - nb_direct) * 64;                   // first gate channel of this workgroup
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * TallShape<V>::NWV) void gla_inproj_tall_kernel
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
             float mu[4], rstd[4];
-            tall_row_stats(s1[mt], s2[mt], lg, inv_k, ln_eps, mu, rstd);
+            tall_row_stats(s1[mt], s2[mt], inv_k, ln_eps, mu, rstd);
 #pragma unroll
             for (int r = 0; r < 4; ++r) s_lr[16 * mt + 4 * lg + r][li] = rstd[r] * (acc[0][mt][r] - mu[r] * cc1) + cc2;
         }
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * TallShape<V>::NWV) void gla_inproj_tall_kernel
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
         float mu[4], rstd[4];
-        tall_row_stats(s1[mt], s2[mt], lg, inv_k, ln_eps, mu, rstd);
+        tall_row_stats(s1[mt], s2[mt], inv_k, ln_eps, mu, rstd);
         if (is_g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -456,23 +456,23 @@ static int inproj_impl(const void* x, int64_t ldx, const void* w_in, int64_t ldw
     const int has_clamp = (clamp_min == clamp_min) ? 1 : 0;
     // 64 rows x 32 columns per workgroup when the q|k|v|g regions allow it (fewer, fatter workgroups: one per CU at
     // L169 -- the busiest CU's byte count sets the time, see linear_skinny.hip); else 64 x 16
-    {   // B >= 384 on packed operands: the tall tiling (see gla_inproj_tall_kernel; 31.6 -> 24.2 us per launch at B = 512,
-        // 17.2 -> 19.1 at B = 256: profiles/r05_tall_perf.txt).  LINA_TALL=0 / 1: never / whenever the operands allow it
+    {   // B >= 384 on packed operands: the tall tiling (see gla_inproj_tall_kernel; 31.6 -> 21.3 us per launch at B = 512,
+        // 17.4 -> 16.8 at B = 256, 26.3 -> ~21 at B = 384: profiles/r05_tall_perf.txt).  LINA_TALL=0 / 1: never / whenever the operands allow it
         // (test hook, read per call)
         const char* tall_env = getenv("LINA_TALL");
         const int tall_mode = tall_env ? atoi(tall_env) : -1;
         const bool can = (packed & 1) && Kd % 64 == 0 && Vd % 64 == 0;
         if (can && (tall_mode == 1 || (tall_mode != 0 && B >= kTallMinRows))) {
-            const char* v_env = getenv("LINA_TALL_V");       // variant (linear_tall.h): 0 = LDS ring, 1 = register ring
+            const char* v_env = getenv("LINA_TALL_V");       // variant (linear_tall.h): 0 = LDS ring (default: 21.3 us at B = 512; 24.3 / 28.2 as 1 / 2)
             const int tv = v_env ? atoi(v_env) : LINA_TALL_DEFAULT_V;
-            const int rows = tv ? TallShape<1>::ROWS : TallShape<0>::ROWS;
+            const int rows = tv == 1 ? TallShape<1>::ROWS : TallShape<0>::ROWS;
             dim3 tgrid(tall_grid((2 * Kd + 2 * Vd) / 64 + Kd / 64, (B + rows - 1) / rows));
 #define LINA_INPROJ_TALL(TT, VV)                                                                                      \
     LINA_LAUNCH((gla_inproj_tall_kernel<TT, VV>), tgrid, dim3(64 * TallShape<VV>::NWV), 0, stream, (const TT*)x,        \
                 (const TT*)w_in, c1, c2, (const TT*)wq, (const TT*)wk, (const TT*)wv, (TT*)cq, (TT*)ck, (TT*)cv,       \
                 (const TT*)w2, (const TT*)b2, (TT*)qkv, (TT*)g_out, gk, B, K, Kd, Vd, ln_eps, 1.0f / normalizer,        \
                 clamp_min, has_clamp)
-#define LINA_INPROJ_TALL_T(TT) do { if (tv) LINA_INPROJ_TALL(TT, 1); else LINA_INPROJ_TALL(TT, 0); } while (0)
+#define LINA_INPROJ_TALL_T(TT) do { if (tv == 2) LINA_INPROJ_TALL(TT, 2); else if (tv) LINA_INPROJ_TALL(TT, 1); else LINA_INPROJ_TALL(TT, 0); } while (0)
             if (dtype == LINA_F32) LINA_INPROJ_TALL_T(float); else LINA_INPROJ_TALL_T(bf16_t);
 #undef LINA_INPROJ_TALL_T
 #undef LINA_INPROJ_TALL

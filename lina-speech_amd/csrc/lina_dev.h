@@ -79,6 +79,24 @@ __device__ __forceinline__ void dma16_to_lds_async(const void* base_uniform, uns
                  : "s"(lds), "v"(lane_byte_off), "s"(base_uniform)
                  : "memory", "m0");
 }
+// The same, addressed by an LDS BYTE ADDRESS held as an integer: a kernel that walks a ring of LDS stages converts its base pointer
+// once (lds_addr_of) and adds plain integers -- every generic -> LDS pointer conversion in a loop is a null check + select on the
+// scalar pipe (s_cmp_lg_u64 / s_cselect per DMA piece in the first version of linear_tall.h).
+typedef unsigned lds_addr_t;
+__device__ __forceinline__ lds_addr_t lds_addr_of(void* lds_ptr) {
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_ptr);
+}
+__device__ __forceinline__ lds_addr_t lds_addr_add(lds_addr_t a, unsigned bytes) { return a + bytes; }
+__device__ __forceinline__ void dma16_to_lds_at(const void* base_uniform, unsigned lane_byte_off, lds_addr_t lds_wave_base) {
+#if defined(LINA_DMA_NT) && LINA_DMA_NT
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt"
+#else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+#endif
+                 :
+                 : "s"(lds_wave_base), "v"(lane_byte_off), "s"(base_uniform)
+                 : "memory", "m0");
+}
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // ds_read_b64_tr_b16: transposing LDS read of 16-bit elements.  Every lane passes the address of an 8-byte piece; inside
 // each group of 16 lanes  result[lane i][j] = piece[lane 4 j + i / 4][element i % 4]  (probed: tools/micro/tr_read.hip,

@@ -364,13 +364,13 @@ __global__ __launch_bounds__(64 * TallShape<V>::NWV) void linear_tall_kernel(
         pre_c2[g] = c2 ? c2[idx] : 0.0f;
     }
     f32x4 acc[G][MTW];
-    float s1[MTW], s2[MTW];
+    float s1[MTW][4], s2[MTW][4];
     tall_core_v<V, T, G, LN, MTW>(A, W, nb, K / F::KSTEP, m0 >> 4, m0 < (M + 63) / 64 * 64, s_w, acc, s1, s2);
 
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
         float mu[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {1.f, 1.f, 1.f, 1.f};
-        if (LN) tall_row_stats(s1[mt], s2[mt], lg, fast_rcp((float)ln_dim), ln_eps, mu, rstd);
+        if (LN) tall_row_stats(s1[mt], s2[mt], fast_rcp((float)ln_dim), ln_eps, mu, rstd);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + 16 * mt + 4 * lg + r;
@@ -450,8 +450,9 @@ static int linear_skinny_impl(const void* A, int64_t lda, const void* W, int64_t
     const bool sw = swiglu_hidden > 0, ln = ln_dim > 0;
     const int nb = sw ? 2 : 1;
     {   // M >= 384 on packed operands, wide outputs: the tall tiling (linear_tall.h).  Measured per launch at L169 (tools/perf_tall.py,
-        // profiles/r05_tall_perf.txt; 64-row kernel -> tall): M = 512 up-projection 22.1 -> 17.3 us, head 22.5 -> 14.4;
-        // M = 256 11.3 -> 17.4 and 12.9 -> 15.3 (half as many workgroups as CUs: slower), hence the row threshold.
+        // profiles/r05_tall_perf.txt; 64-row kernel -> tall): M = 512 up-projection 22.1 -> 14.7 us, head 22.5 -> 12.9;
+        // M = 256 11.3 -> 14.2 and 12.9 -> 11.5 (a tall workgroup takes ~13 us whatever M: fewer of them do not help),
+        // M = 384 20.4 -> 14.6 and 17.9 -> 14.6: hence the row threshold.
         // LINA_TALL=0 / 1: never / whenever the operands allow it (test hook, like LINA_SKINNY_WAVES: read per call)
         const char* tall_env = getenv("LINA_TALL");
         const int tall_mode = tall_env ? atoi(tall_env) : -1;
@@ -461,9 +462,9 @@ static int linear_skinny_impl(const void* A, int64_t lda, const void* W, int64_t
             const int nt = sw ? 2 : 4;                       // 32 gate + 32 value weight rows / 64 plain weight rows per workgroup
             LINA_REQUIRE(Hp >= (N + 16 * nt - 1) / (16 * nt) * (16 * nt),
                          "lina_linear_skinny: packed weights must be zero-padded to whole %d-row blocks covering N", 16 * nt);
-            const char* v_env = getenv("LINA_TALL_V");       // variant (linear_tall.h): 0 = LDS ring, 1 = register ring
-            const int tv = v_env ? atoi(v_env) : ((sw || ln) ? 0 : 1);   // measured: the plain projection prefers the register ring
-            const int rows = tv ? TallShape<1>::ROWS : TallShape<0>::ROWS;
+            const char* v_env = getenv("LINA_TALL_V");       // variant (linear_tall.h): 0 = LDS ring, 1 = register ring, 2 = W in LDS + A in registers
+            const int tv = v_env ? atoi(v_env) : ((sw || ln) ? 0 : 2);   // measured (profiles/r05_tall_perf.txt): head 15.3 / 14.8 / 12.9 us as variant 0 / 1 / 2
+            const int rows = tv == 1 ? TallShape<1>::ROWS : TallShape<0>::ROWS;
             dim3 tgrid(tall_grid((N + 16 * nt - 1) / (16 * nt), (M + rows - 1) / rows));
 #define LINA_LT(TT, SW, LNN, NTT, VV)                                                                                \
     LINA_LAUNCH((linear_tall_kernel<TT, SW, LNN, NTT, VV>), tgrid, dim3(64 * TallShape<VV>::NWV), 0, stream,          \
@@ -474,7 +475,7 @@ static int linear_skinny_impl(const void* A, int64_t lda, const void* W, int64_t
         if (sw && ln) LINA_LT(TT, true, true, 2, VV); else if (sw) LINA_LT(TT, true, false, 2, VV);                  \
         else if (ln) LINA_LT(TT, false, true, 4, VV); else LINA_LT(TT, false, false, 4, VV);                         \
     } while (0)
-#define LINA_LT_T(TT) do { if (tv) LINA_LT_V(TT, 1); else LINA_LT_V(TT, 0); } while (0)
+#define LINA_LT_T(TT) do { if (tv == 2) LINA_LT_V(TT, 2); else if (tv) LINA_LT_V(TT, 1); else LINA_LT_V(TT, 0); } while (0)
             if (dtype == LINA_BF16) LINA_LT_T(bf16_t); else LINA_LT_T(float);
 #undef LINA_LT_T
 #undef LINA_LT_V

@@ -19,6 +19,7 @@
 // lane groups of a row at the end and fetched by the lanes that hold that row's outputs with one shuffle per row.
 #pragma once
 #include <lina_dev.h>
+#include <type_traits>
 #include "lina_common.h"
 #include "skinny_frag.h"
 
@@ -64,7 +65,11 @@ __device__ __forceinline__ void frag_from_lds(Frag<T>& f, const unsigned char* s
 template <typename T, int G, bool LN>
 __device__ __forceinline__ void tall_core(const T* __restrict__ A, const T* __restrict__ W, const int (&nb)[G], int nks,
                                           int mtile0, bool wave_on, unsigned char* s_w, f32x4 (&acc)[G][kTallMTW],
-                                          float (&s1)[kTallMTW], float (&s2)[kTallMTW]) {
+                                          float (&rs1)[kTallMTW][4], float (&rs2)[kTallMTW][4]) {
+    // rs1 / rs2 (LN): sum_k a and sum_k a^2 of the rows this lane holds OUTPUTS for (rows 4 lg + r of m-tile mt).  They come
+    // off the matrix pipe -- A . 1 and the diagonal of A . A^T, two more MFMAs per m-tile and k-step, as in the 64-row kernels
+    // -- not off the VALU: the SQ counters of the first version showed ten VALU instructions per MFMA and the matrix pipe
+    // 7 % busy (profiles/r05_tall_sq.json); the per-lane dot products of the statistics were a fifth of them.
     using F = Frag<T>;
     constexpr int MTW = kTallMTW, NWV = kTallNWV, KB = kTallKB, NS = kTallNS, SL = kTallSlots;
     constexpr int OPS = KB * (MTW + 1);                     // DMA pieces per wave and (full) stage
@@ -78,54 +83,86 @@ __device__ __forceinline__ void tall_core(const T* __restrict__ A, const T* __re
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) acc[g][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 st1[MTW], st2[MTW];
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) { s1[mt] = 0.f; s2[mt] = 0.f; }
-    const int nst = (nks + KB - 1) / KB;
+    for (int mt = 0; mt < MTW; ++mt) { st1[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; st2[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    F f_ones;
+    f_ones.ones();
+    // Full stages run in a loop whose body has NO data-dependent exit (the first version broke out of the unrolled k-step loop
+    // of a partial stage: the compiler then kept the accumulators in AGPRs and copied them at every loop edge -- 91 of the 98
+    // VALU instructions of a stage were v_accvgpr moves); a last partial stage (K not a multiple of KB k-steps) is handled after.
+    const int nfull = nks / KB, rem = nks - nfull * KB;    // rem < KB k-steps in a last, partial stage
+    const lds_addr_t lds0 = lds_addr_of(s_w);
+    const unsigned my_a = (unsigned)(MTW * w) * 1024u, my_w = (unsigned)(MTW * NWV + w) * 1024u;
+    const T* a_src = A + (int64_t)mt_src * nks * fstr;
+    const T* w_src = W + (int64_t)wb * nks * fstr;
 
-    auto issue = [&](int st) {                              // this wave's pieces of stage st -> ring slot st % NS
-        unsigned char* base = s_w + (st % NS) * (KB * SL * 1024);
+    auto issue_steps = [&](int st, int nu) {               // this wave's pieces of k-steps [st KB, st KB + nu) -> ring slot st % NS
+        const lds_addr_t base = lds_addr_add(lds0, (unsigned)(st % NS) * (unsigned)(KB * SL * 1024));
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
-            const int ks = st * KB + u;                     // wave-uniform
-            if (ks >= nks) break;
+            if (u < nu) {                                   // (nu == KB in the loop: folded)
+                const int64_t ks = (int64_t)st * KB + u;
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
-                dma16_to_lds_async(A + ((int64_t)(mt_src + mt) * nks + ks) * fstr, 16u * (unsigned)lane,
-                                   base + (u * SL + MTW * w + mt) * 1024);
-            dma16_to_lds_async(W + ((int64_t)wb * nks + ks) * fstr, 16u * (unsigned)lane,
-                               base + (u * SL + MTW * NWV + w) * 1024);
+                for (int mt = 0; mt < MTW; ++mt)
+                    dma16_to_lds_at(a_src + ((int64_t)mt * nks + ks) * fstr, 16u * (unsigned)lane,
+                                    lds_addr_add(base, (unsigned)(u * SL + mt) * 1024u + my_a));
+                dma16_to_lds_at(w_src + ks * fstr, 16u * (unsigned)lane, lds_addr_add(base, (unsigned)(u * SL) * 1024u + my_w));
+            }
         }
     };
-    auto compute = [&](int st) {
+    auto issue = [&](int st) {
+        if (st < nfull) issue_steps(st, KB);
+        else if (st == nfull && rem) issue_steps(st, rem);
+    };
+    auto compute_steps = [&](int st, int nu) {
         const unsigned char* base = s_w + (st % NS) * (KB * SL * 1024);
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
-            if (st * KB + u >= nks) break;                  // wave-uniform (a last, partial stage)
-            F fa[MTW], fb[G];
+            if (u < nu) {
+                F fa[MTW], fb[G];
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) frag_from_lds<T>(fa[mt], base + (u * SL + MTW * w + mt) * 1024, lane);
+                for (int mt = 0; mt < MTW; ++mt) frag_from_lds<T>(fa[mt], base + (u * SL + MTW * w + mt) * 1024, lane);
 #pragma unroll
-            for (int g = 0; g < G; ++g) frag_from_lds<T>(fb[g], base + (u * SL + MTW * NWV + g) * 1024, lane);
+                for (int g = 0; g < G; ++g) frag_from_lds<T>(fb[g], base + (u * SL + MTW * NWV + g) * 1024, lane);
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) {
-                if (LN) fa[mt].stats(s1[mt], s2[mt]);
+                for (int mt = 0; mt < MTW; ++mt) {
+                    if (LN) {
+                        st1[mt] = F::mma(fa[mt], f_ones, st1[mt]);       // row sums (every column)
+                        st2[mt] = F::mma(fa[mt], fa[mt], st2[mt]);       // Gram matrix: the diagonal holds sum a^2
+                    }
 #pragma unroll
-                for (int g = 0; g < G; ++g) acc[g][mt] = F::mma(fa[mt], fb[g], acc[g][mt]);
+                    for (int g = 0; g < G; ++g) acc[g][mt] = F::mma(fa[mt], fb[g], acc[g][mt]);
+                }
             }
         }
     };
 
 #pragma unroll
-    for (int p = 0; p < NS - 1; ++p)
-        if (p < nst) issue(p);
-    for (int st = 0; st < nst; ++st) {
-        if (st + NS - 2 <= nst - 2) wait_vmem_but<(NS - 2) * OPS>();   // stage st has landed; NS - 2 full stages stay in flight
+    for (int p = 0; p < NS - 1; ++p) issue(p);
+    for (int st = 0; st < nfull; ++st) {
+        if (st + NS - 2 <= nfull - 1) wait_vmem_but<(NS - 2) * OPS>();   // stage st has landed; NS - 2 FULL stages stay in flight
         else wait_vmem();
         lds_barrier();                                      // ... everybody's pieces; and stage st - 1 has been consumed by all
-        if (st + NS - 1 < nst) issue(st + NS - 1);          // -> into the slot of stage st - 1
-        compute(st);
+        issue(st + NS - 1);                                 // -> into the slot of stage st - 1
+        compute_steps(st, KB);
+    }
+    if (rem) {
+        wait_vmem();
+        lds_barrier();
+        compute_steps(nfull, rem);
     }
     __syncthreads();                                        // the ring is free: callers reuse it for their epilogue exchange
+    // D layout: lane (li, lg) holds column li, rows 4 lg + r.  A . 1 has the row sum in every column; the diagonal element
+    // of row 4 lg + r sits in the lane with li = 4 lg + r, register r: one shuffle per row
+    const int lg = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rs1[mt][r] = LN ? st1[mt][r] : 0.f;
+            rs2[mt][r] = LN ? shfl(st2[mt][r], 16 * lg + 4 * lg + r) : 0.f;
+        }
 }
 
 // ---- variant 1: no LDS at all.  ONE wave per workgroup owns a 64 x (16 G) tile for the whole contraction and streams BOTH
@@ -145,10 +182,11 @@ constexpr int kTallRegD = LINA_TALL_D;
 
 template <typename T, int G, bool LN>
 __device__ __forceinline__ void tall_core_reg(const T* __restrict__ A, const T* __restrict__ W, const int (&nb)[G], int nks,
-                                              int mtile0, bool wave_on, f32x4 (&acc)[G][kTallRegMT], float (&s1)[kTallRegMT],
-                                              float (&s2)[kTallRegMT]) {
+                                              int mtile0, bool wave_on, f32x4 (&acc)[G][kTallRegMT], float (&rs1)[kTallRegMT][4],
+                                              float (&rs2)[kTallRegMT][4]) {
     using F = Frag<T>;
     constexpr int MT = kTallRegMT, D = kTallRegD;
+    float s1[MT], s2[MT];              // (this variant has no registers for two more accumulator tiles per m-tile: per-lane sums)
     const int lane = threadIdx.x & 63;
     const int64_t fstr = 64 * F::KL;
     const int mt_src = wave_on ? mtile0 : 0;
@@ -188,12 +226,135 @@ __device__ __forceinline__ void tall_core_reg(const T* __restrict__ A, const T* 
             }
         }
     }
+    // per-lane partial sums of the row the lane holds INPUTS for (A layout: row li) -> reduce over the four lane groups,
+    // then one shuffle per OUTPUT row (D layout: rows 4 lg + r)
+    const int lg = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float a = s1[mt], b = s2[mt];
+        a += shfl_xor(a, 16); b += shfl_xor(b, 16);
+        a += shfl_xor(a, 32); b += shfl_xor(b, 32);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { rs1[mt][r] = shfl(a, 4 * lg + r); rs2[mt][r] = shfl(b, 4 * lg + r); }
+    }
+}
+
+// ---- variant 2: the LDS ring carries only what the four waves SHARE (the weight fragments, by DMA); every wave's own A
+// fragments go straight to its registers with plain loads, through a register ring of the same depth.  An LDS-DMA piece
+// occupies the issuing wave until the memory system has taken it (K2's loader waves measured ~34 clocks per KiB, twice that
+// beside LDS reads), and variant 0 pushes 24 KiB per stage and CU through that path: its stages take ~1800 clocks for 24
+// MFMAs per wave whatever the ring depth (profiles/r05_tall_perf.txt).  Here the DMA path carries 8 KiB per stage; the A loads
+// are asynchronous until they are used.  Same stage bookkeeping as variant 0: per wave and stage KB x (MTW loads + 1 DMA
+// piece) vector-memory operations, so the counted wait is the same expression; the compiler adds its own (earlier) wait for
+// the A registers -- it does not see the DMA pieces between its loads, so that wait also covers part of the next stage.
+template <typename T, int G, bool LN>
+__device__ __forceinline__ void tall_core_hyb(const T* __restrict__ A, const T* __restrict__ W, const int (&nb)[G], int nks,
+                                              int mtile0, bool wave_on, unsigned char* s_w, f32x4 (&acc)[G][kTallMTW],
+                                              float (&rs1)[kTallMTW][4], float (&rs2)[kTallMTW][4]) {
+    using F = Frag<T>;
+    constexpr int MTW = kTallMTW, NWV = kTallNWV, KB = kTallKB, NS = kTallNS;
+    constexpr int OPS = KB * (MTW + 1);
+    static_assert(G == 4 || G == 1, "one weight fragment per wave and k-step (G = 4), or the same one for all (G = 1)");
+    static_assert(NS == 3, "the stage loop is unrolled by hand over a ring of three");
+    const int lane = threadIdx.x & 63;
+    const int w = wave_uniform(threadIdx.x >> 6);
+    const int64_t fstr = 64 * F::KL;
+    const int mt_src = wave_on ? mtile0 : 0;
+    const int wb = nb[G == 4 ? w : 0];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[g][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 st1[MTW], st2[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) { st1[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; st2[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    F f_ones;
+    f_ones.ones();
+    const int nfull = nks / KB, rem = nks - nfull * KB;
+    const lds_addr_t lds0 = lds_addr_of(s_w);
+    const T* a_src = A + ((int64_t)mt_src * nks * 64 + lane) * F::KL;
+    const T* w_src = W + (int64_t)wb * nks * fstr;
+    F fa[NS][KB][MTW];
+
+    // stage st -> ring slot S (a compile-time constant: the register ring is indexed with it)
+    auto issue = [&](auto slot, int st) {
+        constexpr int S = decltype(slot)::value;
+        const int nu = st < nfull ? KB : (st == nfull ? rem : 0);           // wave-uniform
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            if (u < nu) {
+                const int64_t ks = (int64_t)st * KB + u;
+                dma16_to_lds_at(w_src + ks * fstr, 16u * (unsigned)lane,
+                                lds_addr_add(lds0, (unsigned)((S * KB + u) * NWV + w) * 1024u));
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) fa[S][u][mt].load(a_src + ((int64_t)mt * nks + ks) * fstr);
+            }
+        }
+    };
+    auto compute = [&](auto slot, int nu) {
+        constexpr int S = decltype(slot)::value;
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            if (u < nu) {
+                F fb[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) frag_from_lds<T>(fb[g], s_w + ((S * KB + u) * NWV + g) * 1024, lane);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    if (LN) {
+                        st1[mt] = F::mma(fa[S][u][mt], f_ones, st1[mt]);
+                        st2[mt] = F::mma(fa[S][u][mt], fa[S][u][mt], st2[mt]);
+                    }
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acc[g][mt] = F::mma(fa[S][u][mt], fb[g], acc[g][mt]);
+                }
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    auto body = [&](auto slot, auto refill, int st) {       // one FULL stage: wait, meet, refill the slot consumed last, multiply
+        if (st + NS - 2 <= nfull - 1) wait_vmem_but<(NS - 2) * OPS>();
+        else wait_vmem();
+        lds_barrier();
+        issue(refill, st + NS - 1);
+        compute(slot, KB);
+    };
+    issue(I0{}, 0);
+    issue(I1{}, 1);
+    int st = 0;
+    for (; st + NS <= nfull; st += NS) {
+        body(I0{}, I2{}, st);
+        body(I1{}, I0{}, st + 1);
+        body(I2{}, I1{}, st + 2);
+    }
+    const int left = nfull - st;                            // 0, 1 or 2 full stages, then the partial one in slot `left`
+    if (left >= 1) body(I0{}, I2{}, st);
+    if (left >= 2) body(I1{}, I0{}, st + 1);
+    if (rem) {
+        wait_vmem();
+        lds_barrier();
+        if (left == 0) compute(I0{}, rem);
+        else if (left == 1) compute(I1{}, rem);
+        else compute(I2{}, rem);
+    }
+    __syncthreads();
+    const int lg = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rs1[mt][r] = LN ? st1[mt][r] : 0.f;
+            rs2[mt][r] = LN ? shfl(st2[mt][r], 16 * lg + 4 * lg + r) : 0.f;
+        }
 }
 
 // shape of a tall workgroup by variant: 0 = LDS ring (4 waves x 32 rows), 1 = register ring (1 wave x 64 rows)
 template <int V> struct TallShape {
-    static constexpr int MTW = V ? kTallRegMT : kTallMTW, NWV = V ? 1 : kTallNWV, ROWS = 16 * MTW * NWV;
-    static constexpr int LDS = V ? 64 * 17 * 4 : tall_lds_bytes();     // V = 1: only the gate tiles' 64 x 16 exchange
+    static constexpr int MTW = V == 1 ? kTallRegMT : kTallMTW, NWV = V == 1 ? 1 : kTallNWV, ROWS = 16 * MTW * NWV;
+    // V = 1: only the gate tiles' 64 x 16 exchange; V = 2: the weight ring (and, after it, the gate tiles' 128 x 16 exchange)
+    static constexpr int LDS = V == 1 ? 64 * 17 * 4 : V == 2 ? kTallNS * kTallKB * kTallNWV * 1024 : tall_lds_bytes();
 };
 // XCD-aware tile order: consecutive workgroup ids go round the 8 XCDs (each with its own L2), so the row blocks that share a
 // weight tile must have ids that are EQUAL mod 8 to meet in one L2 -- with the natural (column, row) order of a 43- or
@@ -211,22 +372,19 @@ static inline unsigned tall_grid(int ncol, int nrow) { return 8u * (unsigned)((n
 
 template <int V, typename T, int G, bool LN, int MTW>
 __device__ __forceinline__ void tall_core_v(const T* A, const T* W, const int (&nb)[G], int nks, int mtile0, bool wave_on,
-                                            unsigned char* s_w, f32x4 (&acc)[G][MTW], float (&s1)[MTW], float (&s2)[MTW]) {
-    if constexpr (V == 0) tall_core<T, G, LN>(A, W, nb, nks, mtile0, wave_on, s_w, acc, s1, s2);
-    else tall_core_reg<T, G, LN>(A, W, nb, nks, mtile0, wave_on, acc, s1, s2);
+                                            unsigned char* s_w, f32x4 (&acc)[G][MTW], float (&rs1)[MTW][4], float (&rs2)[MTW][4]) {
+    if constexpr (V == 0) tall_core<T, G, LN>(A, W, nb, nks, mtile0, wave_on, s_w, acc, rs1, rs2);
+    else if constexpr (V == 2) tall_core_hyb<T, G, LN>(A, W, nb, nks, mtile0, wave_on, s_w, acc, rs1, rs2);
+    else tall_core_reg<T, G, LN>(A, W, nb, nks, mtile0, wave_on, acc, rs1, rs2);
 }
 
-// LayerNorm statistics of the rows a lane holds OUTPUTS for (D layout: rows 4 lg + r of the m-tile) from the per-lane
-// partial sums of the row it holds INPUTS for (A layout: row li): reduce over the four lane groups, then one shuffle per row.
-__device__ __forceinline__ void tall_row_stats(float s1, float s2, int lg, float inv_d, float eps, float (&mu)[4],
-                                               float (&rstd)[4]) {
-    s1 += shfl_xor(s1, 16); s2 += shfl_xor(s2, 16);
-    s1 += shfl_xor(s1, 32); s2 += shfl_xor(s2, 32);
+// mean / reciprocal standard deviation of the lane's four output rows from their sums (rs1, rs2 of the cores above)
+__device__ __forceinline__ void tall_row_stats(const float (&rs1)[4], const float (&rs2)[4], float inv_d, float eps,
+                                               float (&mu)[4], float (&rstd)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float a = shfl(s1, 4 * lg + r), b = shfl(s2, 4 * lg + r);
-        mu[r] = a * inv_d;
-        rstd[r] = rsqrtf(fmaxf(b * inv_d - mu[r] * mu[r], 0.f) + eps);
+        mu[r] = rs1[r] * inv_d;
+        rstd[r] = rsqrtf(fmaxf(rs2[r] * inv_d - mu[r] * mu[r], 0.f) + eps);
     }
 }
 

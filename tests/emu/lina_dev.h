@@ -233,6 +233,13 @@ static inline void dma16_to_lds_async(const void* base_uniform, unsigned lane_by
     if (lina_emu::dma_late()) lina_emu::dma_defer(dst, src);
     else memcpy(dst, src, 16);
 }
+// LDS byte address as a value (lina_dev.h of the product: an unsigned; here the host pointer itself)
+typedef unsigned char* lds_addr_t;
+static inline lds_addr_t lds_addr_of(void* lds_ptr) { return (unsigned char*)lds_ptr; }
+static inline lds_addr_t lds_addr_add(lds_addr_t a, unsigned bytes) { return a + bytes; }
+static inline void dma16_to_lds_at(const void* base_uniform, unsigned lane_byte_off, lds_addr_t lds_wave_base) {
+    dma16_to_lds_async(base_uniform, lane_byte_off, lds_wave_base);
+}
 // the wave's DMA pieces have landed: on the emulator every lane copies its own 16 bytes when it runs, so this is a
 // wave-wide meeting point (all lanes of a wave call it together, as on the hardware)
 static inline void wait_vmem() {

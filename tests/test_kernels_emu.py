@@ -238,7 +238,7 @@ def test_projections_wider_split_k(emu, monkeypatch, nw):
                                                           (33, 64, 128, torch.bfloat16, False, False, False, 64),
                                                           (140, 48, 80, torch.float32, True, True, True, 0),
                                                           (20, 40, 48, torch.float32, True, False, False, 21)])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_linear_tall(emu, M, N, K, dtype, ln, bias, resid, sw, variant):
     from kernel_cases import check_linear_tall
     check_linear_tall(DEV, M, N, K, dtype, ln=ln, bias=bias, resid=resid, swiglu=sw, variant=variant)
@@ -246,7 +246,7 @@ def test_linear_tall(emu, M, N, K, dtype, ln, bias, resid, sw, variant):
 
 @pytest.mark.parametrize("B,K,Kd,Vd,dtype", [(130, 96, 64, 128, torch.bfloat16), (70, 160, 128, 64, torch.bfloat16),
                                              (129, 48, 64, 64, torch.float32)])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_inproj_tall(emu, B, K, Kd, Vd, dtype, variant):
     from kernel_cases import check_inproj_tall
     check_inproj_tall(DEV, B, K, Kd, Vd, dtype, variant=variant)

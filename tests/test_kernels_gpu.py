@@ -330,7 +330,7 @@ def test_greedy_pick_embed(hip, B, Q, L, d, dtype):
     (130, 1024, 1376, torch.bfloat16, False, False, True, 0, True),          # down-projection shape, ragged rows, 43 k-steps
     (200, 4099, 1024, torch.float32, False, True, False, 0, True),
     (129, 56, 288, torch.float32, True, True, True, 40, True)])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_linear_tall(hip, M, N, K, dtype, ln, bias, resid, sw, force, variant):
     from kernel_cases import check_linear_tall
     check_linear_tall(DEV, M, N, K, dtype, ln=ln, bias=bias, resid=resid, swiglu=sw, force=force, variant=variant)
@@ -340,7 +340,7 @@ def test_linear_tall(hip, M, N, K, dtype, ln, bias, resid, sw, force, variant):
                                                    (130, 1024, 1024, 2048, torch.bfloat16, True),
                                                    (70, 160, 128, 64, torch.bfloat16, True),
                                                    (200, 256, 256, 256, torch.float32, True)])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_inproj_tall(hip, B, K, Kd, Vd, dtype, force, variant):
     from kernel_cases import check_inproj_tall
     check_inproj_tall(DEV, B, K, Kd, Vd, dtype, force=force, variant=variant)
