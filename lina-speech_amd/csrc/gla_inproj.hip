@@ -456,9 +456,9 @@ static int inproj_impl(const void* x, int64_t ldx, const void* w_in, int64_t ldw
     const int has_clamp = (clamp_min == clamp_min) ? 1 : 0;
     // 64 rows x 32 columns per workgroup when the q|k|v|g regions allow it (fewer, fatter workgroups: one per CU at
     // L169 -- the busiest CU's byte count sets the time, see linear_skinny.hip); else 64 x 16
-    {   // B >= 384 on packed operands: the tall tiling (see gla_inproj_tall_kernel; 31.6 -> 21.3 us per launch at B = 512,
-        // 17.4 -> 16.8 at B = 256, 26.3 -> ~21 at B = 384: profiles/r05_tall_perf.txt).  LINA_TALL=0 / 1: never / whenever the operands allow it
-        // (test hook, read per call)
+    {   // B >= 160 on packed operands: the tall tiling (see gla_inproj_tall_kernel).  Per launch at L169 (profiles/r05_tall_perf.txt;
+        // 64-row split-K kernel -> tall): B = 512 31.5 -> 19.0 us, 384: 25.9 -> 16.0, 256: 17.1 -> 14.3, 192: 16.1 -> 11.9,
+        // 128: 12.0 -> 12.0.  LINA_TALL=0 / 1: never / whenever the operands allow it (test hook, read per call)
         const char* tall_env = getenv("LINA_TALL");
         const int tall_mode = tall_env ? atoi(tall_env) : -1;
         const bool can = (packed & 1) && Kd % 64 == 0 && Vd % 64 == 0;

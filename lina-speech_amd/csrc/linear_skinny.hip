@@ -449,10 +449,10 @@ static int linear_skinny_impl(const void* A, int64_t lda, const void* W, int64_t
     // with rounds = ceil(workgroups / 256 CUs).
     const bool sw = swiglu_hidden > 0, ln = ln_dim > 0;
     const int nb = sw ? 2 : 1;
-    {   // M >= 384 on packed operands, wide outputs: the tall tiling (linear_tall.h).  Measured per launch at L169 (tools/perf_tall.py,
-        // profiles/r05_tall_perf.txt; 64-row kernel -> tall): M = 512 up-projection 22.1 -> 14.7 us, head 22.5 -> 12.9;
-        // M = 256 11.3 -> 14.2 and 12.9 -> 11.5 (a tall workgroup takes ~13 us whatever M: fewer of them do not help),
-        // M = 384 20.4 -> 14.6 and 17.9 -> 14.6: hence the row threshold.
+    {   // M >= 160 on packed operands, wide outputs: the tall tiling (linear_tall.h).  Measured per launch at L169
+        // (tools/perf_tall.py, profiles/r05_tall_perf.txt; 64-row split-K kernel -> tall), up-projection / head:
+        // M = 512 21.9 -> 12.0 / 22.4 -> 12.6 us, 384: 20.4 -> 11.5 / 18.0 -> 11.8, 256: 11.3 -> 9.8 / 13.1 -> 10.4,
+        // 192: 10.9 -> 9.7 / 9.6 -> 9.8, 128: 8.8 -> 9.6 / 9.1 -> 9.5 (hence the row threshold).
         // LINA_TALL=0 / 1: never / whenever the operands allow it (test hook, like LINA_SKINNY_WAVES: read per call)
         const char* tall_env = getenv("LINA_TALL");
         const int tall_mode = tall_env ? atoi(tall_env) : -1;
@@ -463,7 +463,7 @@ static int linear_skinny_impl(const void* A, int64_t lda, const void* W, int64_t
             LINA_REQUIRE(Hp >= (N + 16 * nt - 1) / (16 * nt) * (16 * nt),
                          "lina_linear_skinny: packed weights must be zero-padded to whole %d-row blocks covering N", 16 * nt);
             const char* v_env = getenv("LINA_TALL_V");       // variant (linear_tall.h): 0 = LDS ring, 1 = register ring, 2 = W in LDS + A in registers
-            const int tv = v_env ? atoi(v_env) : ((sw || ln) ? 0 : 2);   // measured (profiles/r05_tall_perf.txt): head 15.3 / 14.8 / 12.9 us as variant 0 / 1 / 2
+            const int tv = v_env ? atoi(v_env) : 0;   // measured (profiles/r05_tall_perf.txt): head 12.5 / 14.8 / 13.1 us as variant 0 / 1 / 2
             const int rows = tv == 1 ? TallShape<1>::ROWS : TallShape<0>::ROWS;
             dim3 tgrid(tall_grid((N + 16 * nt - 1) / (16 * nt), (M + rows - 1) / rows));
 #define LINA_LT(TT, SW, LNN, NTT, VV)                                                                                \

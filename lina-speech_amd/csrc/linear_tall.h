@@ -25,7 +25,10 @@
 
 namespace lina {
 
-constexpr int kTallMTW = 2;       // 16-row m-tiles per wave
+#ifndef LINA_TALL_MTW
+#define LINA_TALL_MTW 1            // 1: 64-row workgroups (twice as many, two to three per CU): in-projection 21.4 -> 18.5 us, up 14.7 -> 11.8,
+#endif                            // head 15.2 -> 12.5 at M = 512 against 2 (128 rows); profiles/r05_tall_perf.txt
+constexpr int kTallMTW = LINA_TALL_MTW;   // 16-row m-tiles per wave
 constexpr int kTallNWV = 4;       // waves per workgroup (rows per workgroup = 16 * MTW * NWV = 128)
 #ifndef LINA_TALL_KB
 #define LINA_TALL_KB 2            // (tools/tall_variants.sh builds other ring shapes for A/B)
@@ -36,7 +39,7 @@ constexpr int kTallNWV = 4;       // waves per workgroup (rows per workgroup = 1
 constexpr int kTallKB = LINA_TALL_KB;   // k-steps per LDS stage
 constexpr int kTallNS = LINA_TALL_NS;   // stages in the LDS ring (NS - 1 of them in flight while one is consumed)
 constexpr int kTallRows = 16 * kTallMTW * kTallNWV;
-constexpr int kTallMinRows = 384; // the launchers' own rule: below this the 64-row kernels have more workgroups than the tall ones and win
+constexpr int kTallMinRows = 160; // the launchers' own rule: from M = 192 up the tall kernels win (M = 128: equal or slightly slower)
 constexpr int kTallSlots = kTallMTW * kTallNWV + kTallNWV;    // fragments per k-step: 8 of A (two per wave) + 4 of W
 
 // LDS of the ring: NS stages x KB k-steps x 12 fragments of 1 KiB (72 KiB: two workgroups per CU)
