@@ -486,34 +486,42 @@ __global__ __launch_bounds__(256) void pe_softmax_weighted_rows_kernel(const T* 
         if (a_ok) att[b * att_sb + a_t * att_ss + t] = tmp;
     }
     __syncthreads();
-    const int e = blockIdx.x * 256 + lane * 4;
-    const bool live = e < d;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const T* base = vv + (int64_t)b * Tn * d + (live ? e : 0);
-    for (int t0 = w; t0 < Tn; t0 += 32) {
-        float4 p[8];
+    // the row's 256-column slabs: one per workgroup (grid.x = d / 256: small batches, more workgroups) or all of them in turn
+    // (grid.x = 1: at B >= 256 the T_txt x d scores above -- pe's 128 KB from L2 and 65 k multiply-adds per workgroup -- were
+    // recomputed by four workgroups per row and were most of the launch's 37 us at B = 512; profiles/r05_step_timeline.txt)
+    const int nslab = (d + 255) / 256;
+    for (int sb = blockIdx.x; sb < nslab; sb += gridDim.x) {
+        const int e = sb * 256 + lane * 4;
+        const bool live = e < d;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const T* base = vv + (int64_t)b * Tn * d + (live ? e : 0);
+        for (int t0 = w; t0 < Tn; t0 += 32) {
+            float4 p[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = ld4(base + (int64_t)min(t0 + 4 * u, Tn - 1) * d);
+            for (int u = 0; u < 8; ++u) p[u] = ld4(base + (int64_t)min(t0 + 4 * u, Tn - 1) * d);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float a = (t0 + 4 * u < Tn) ? s_a[min(t0 + 4 * u, Tn - 1)] : 0.0f;
-            acc.x = fmaf(a, p[u].x, acc.x); acc.y = fmaf(a, p[u].y, acc.y);
-            acc.z = fmaf(a, p[u].z, acc.z); acc.w = fmaf(a, p[u].w, acc.w);
+            for (int u = 0; u < 8; ++u) {
+                const float a = (t0 + 4 * u < Tn) ? s_a[min(t0 + 4 * u, Tn - 1)] : 0.0f;
+                acc.x = fmaf(a, p[u].x, acc.x); acc.y = fmaf(a, p[u].y, acc.y);
+                acc.z = fmaf(a, p[u].z, acc.z); acc.w = fmaf(a, p[u].w, acc.w);
+            }
         }
-    }
-    if (w > 0) *reinterpret_cast<float4*>(&s_p[w - 1][lane][0]) = acc;
-    __syncthreads();
-    if (w > 0 || !live) return;
+        if (w > 0) *reinterpret_cast<float4*>(&s_p[w - 1][lane][0]) = acc;
+        __syncthreads();
+        if (w == 0 && live) {
 #pragma unroll
-    for (int ww = 0; ww < 3; ++ww) {
-        const float4 o = *reinterpret_cast<const float4*>(&s_p[ww][lane][0]);
-        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+            for (int ww = 0; ww < 3; ++ww) {
+                const float4 o = *reinterpret_cast<const float4*>(&s_p[ww][lane][0]);
+                acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+            }
+            T tmp4[4];
+            st4(tmp4, acc);
+            T* const xa = xpk ? xpk + packed_off<T>(b, e, d) : x + (int64_t)b * d + e;
+            const float4 o = ld4(tmp4), r = ld4(xa);
+            st4(xa, make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w));
+        }
+        __syncthreads();                                      // the partial sums have been read: the next slab may write them
     }
-    T tmp4[4];
-    st4(tmp4, acc);
-    T* const xa = xpk ? xpk + packed_off<T>(b, e, d) : x + (int64_t)b * d + e;
-    const float4 o = ld4(tmp4), r = ld4(xa);
-    st4(xa, make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w));
 }
 
 // softmax + att . pe in ONE launch (the first half of the blind cross-attention, reference model/crossatt.py:117-127):
@@ -834,7 +842,7 @@ extern "C" int lina_pe_softmax_weighted_rows_add(const void* xp, int xp_packed, 
     LINA_REQUIRE(B > 0 && Tn > 0 && Tn <= kCaMaxT, "lina_pe_softmax_weighted_rows_add: 0 < T_txt <= %d", kCaMaxT);
     LINA_REQUIRE(d > 0 && d % 256 == 0 && d <= 8192, "lina_pe_softmax_weighted_rows_add: d must be a multiple of 256 (<= 8192)");
     LINA_REQUIRE(valid_dtype(dtype), "lina_pe_softmax_weighted_rows_add: bad dtype %d", dtype);
-    dim3 grid((unsigned)((d + 255) / 256), (unsigned)B);
+    dim3 grid((unsigned)(B >= 256 ? 1 : (d + 255) / 256), (unsigned)B);   // B >= 256: one workgroup per row takes every slab
     const size_t smem = sizeof(float) * (size_t)d;
     if (dtype == LINA_F32)
         LINA_LAUNCH((pe_softmax_weighted_rows_kernel<float>), grid, dim3(256), smem, stream, (const float*)xp, xp_packed,

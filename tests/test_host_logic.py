@@ -177,6 +177,21 @@ def test_isa_audit_flags_an_mfma_under_an_unskipped_exec_mask():
         v_mfma_f32_16x16x32_bf16 v[2:5], v[18:21], v[6:9], v[2:5]
         s_endpgm""".splitlines()
     assert mod.scan(good) == {}
+    # control flow: behind an unconditional branch the fall-through is dead (the masked block above jumped back to its loop
+    # header, which restores EXEC): the block at the next label is entered by jumps only and starts clean; an MFMA that
+    # follows the saveexec in the SAME block is still flagged, and scanning goes on behind an s_endpgm in mid-kernel
+    flow = """_Z4flowv:
+        s_and_saveexec_b64 s[10:11], s[8:9]
+        v_mfma_f32_16x16x32_bf16 v[2:5], v[18:21], v[6:9], v[2:5]
+        s_branch .LBB0_9
+    .LBB0_5:
+        v_mfma_f32_16x16x32_bf16 v[2:5], v[18:21], v[6:9], v[2:5]
+        s_endpgm
+    .LBB0_9:
+        s_and_saveexec_b64 s[10:11], s[8:9]
+        v_mfma_f32_16x16x32_bf16 v[2:5], v[18:21], v[6:9], v[2:5]
+        s_endpgm""".splitlines()
+    assert mod.scan(flow) == {"_Z4flowv": 2}
 
 
 @pytest.mark.parametrize("rows,n_out,n_in,split", [(4096, 24, 16, None), (16384, 40, 21, None), (16384, 40, 21, 4),

@@ -295,7 +295,8 @@ def test_chunk_segment_parallel_head_groups(emu, H, D, T, nseg):
 
 
 @pytest.mark.parametrize("B,Tn,d,dtype", [(3, 11, 64, torch.float32), (2, 40, 128, torch.bfloat16),
-                                          (2, 13, 256, torch.float32), (3, 33, 256, torch.bfloat16)])
+                                          (2, 13, 256, torch.float32), (3, 33, 256, torch.bfloat16),
+                                          (257, 9, 512, torch.bfloat16)])      # B >= 256: one workgroup per row loops the slabs
 def test_cross_attention_fusions(emu, B, Tn, d, dtype):
     from kernel_cases import check_cross_fused, check_softmax_pe_rows
     check_cross_fused(DEV, B, Tn, d, dtype)

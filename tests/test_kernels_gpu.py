@@ -415,7 +415,8 @@ def test_chunk_segment_parallel_head_groups(hip, H, D, T, nseg):
     check_chunk_segmented(DEV, B=1, H=H, T=T, nseg=nseg, resets=True, D=D)
 
 
-@pytest.mark.parametrize("B,Tn,d,dtype", [(64, 64, 1024, torch.bfloat16), (5, 100, 256, torch.float32), (64, 20, 1024, torch.float32)])
+@pytest.mark.parametrize("B,Tn,d,dtype", [(64, 64, 1024, torch.bfloat16), (5, 100, 256, torch.float32), (64, 20, 1024, torch.float32),
+                                          (512, 64, 1024, torch.bfloat16), (300, 33, 512, torch.float32)])
 def test_cross_attention_fusions(hip, B, Tn, d, dtype):
     from kernel_cases import check_cross_fused, check_softmax_pe_rows
     check_cross_fused(DEV, B, Tn, d, dtype)
