@@ -1,18 +1,22 @@
-"""DecodeEngine: the single-token step of ``AttentiveGLA.step`` + logits head
-(reference model/gla.py:358-365 driven by model/modeling_lina.py:152-179) restructured for
-MI355X: per GLA block SIX launches instead of ~30 --
-  1 LayerNorm-1 (folded) + fused projection q|k|v|g|gate-low-rank + 3 conv steps + gate
-                                                                            (lina_gla_decode_inproj)
-  3 in-place recurrent-state update, row-split, fp32 partial o             (lina_gla_decode_update, K1d)
-  4 partial-sum + RMSNorm (x) swish gate, gate read from the projection row (lina_rmsnorm_gate_fwd, K5)
-  5 o_proj + residual                                                       (lina_linear_skinny)
-  6 up-projection with LayerNorm-2 folded in + bias + SwiGLU                (lina_linear_skinny)
-  7 down-projection (bias as a constant-1 column) + residual                (lina_linear_skinny)
--- and the whole step captured in a hipGraph (no per-step host work, no host sync).
+"""DecodeEngine: the decode loop of ``LinaModel.generate_batch`` (reference model/modeling_lina.py:111-192) and its
+single-token step (``AttentiveGLA.step`` + logits head, model/gla.py:358-365) restructured for MI355X.
 
-The text side of the cross-attention is projected once (BlindCrossAttention.prepare).
-State lives in the caller-visible ``Cache`` tensors (reference layout, updated in place).
-The blind cross-attention is 3 more launches (query projection + lina_cross_att_step1/2) around its pos_net block.
+Per GLA block FIVE launches instead of ~30 --
+  1 LayerNorm-1 (folded) + fused projection q|k|v|g|gate-low-rank + 3 conv steps + gate   (lina_gla_decode_inproj[_packed])
+  2 recurrent-state update + RMSNorm (x) swish gate: K1w, the windowed (lazily written) state inside the device loop
+    (lina_gla_decode_window), or the immediate row-split update K1d + K5 for a single step  (lina_gla_decode_update_norm)
+  3 o_proj + residual                                                                     (lina_linear_skinny[_ex])
+  4 up-projection with LayerNorm-2 folded in + bias + SwiGLU                              (lina_linear_skinny[_ex])
+  5 down-projection (bias as a constant-1 column) + residual                              (lina_linear_skinny[_ex])
+-- the blind cross-attention is 4 more launches around its pos_net block, the head one, the token epilogue one (K6d / K6e:
+picks, token log, stop bookkeeping, next-token embedding, step counter): 71 launches per token, captured in hipGraphs of 1 and 8
+tokens.  From 160 utterance rows up the projections of 1 / 4 / head run on the tall tiling (csrc/linear_tall.h).
+
+``generate()`` is what ``LinaModel.generate_batch`` runs by default: tokens, attention log and stop flags stay on the device, 8
+bytes of the loop-control block are read back every ``stop_check_every`` steps through pinned memory behind the queued work.
+The text side of the cross-attention is projected once (BlindCrossAttention.prepare); state lives in the caller-visible
+``Cache`` tensors (reference layout; ``state`` / ``sync_state()`` materialise the pending window steps on demand);
+``reset()`` re-arms a built engine for the next utterance batch.
 """
 from __future__ import annotations
 

@@ -5,11 +5,11 @@ state-dict keys ``txt_embed / rvq_embed / logits_head / attentive_rnn / txt_enco
 
 MI355X-first differences that do not change results:
   * the text side of the cross-attention is projected once per utterance (prepare());
-  * greedy picks, stop bookkeeping and the next-token embedding stay on the device, and the
-    "all rows stopped" test is read back every ``stop_check_every`` steps instead of every step
-    (the loop may run up to that many extra steps; the returned tensors are trimmed to the exact
-    length the reference would have produced);
-  * ``engine='fused'`` routes the loop through decode.DecodeEngine (fused HIP step + hipGraph).
+  * ``generate_batch`` runs the device-side loop by default (decode.DecodeEngine.generate: fused HIP step, 8 tokens per
+    hipGraph replay): picks, stop bookkeeping, the attention log and the next-token embedding stay on the device, and the
+    "all rows stopped" test is read back every ``stop_check_every`` steps instead of every step (the loop may run up to two
+    such groups of extra steps; the returned tensors are trimmed to the exact length the reference would have produced);
+  * the engine is cached per (batch, text length, weights) and re-armed for later calls (``clear_decode_cache``).
 """
 from __future__ import annotations
 
