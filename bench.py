@@ -685,6 +685,43 @@ def measure_generate_batch(model_dev, texts, dev, loop_ms, max_seqlen=750):
     return res
 
 
+def measure_two_engines(model_dev, texts, dev, steps=240, max_seqlen=750):
+    """The same utterance batch on TWO engines (half the rows each, shared packed weights) driven on two HIP streams
+    (decode.DecodeEngineGroup; ``generate_batch(..., n_engines=2)``): one half's projections run under the other half's
+    HBM-bound state update.  Secondary figure (opt-in: the default entry point uses one engine)."""
+    from lina_speech_amd.decode import DecodeEngineGroup
+    B = texts.shape[0]
+    with torch.inference_mode():
+        grp = DecodeEngineGroup(model_dev, model_dev.txt_encoder(model_dev.txt_embed(texts)), batch_size=B, n_engines=2)
+        grp.begin_greedy(steps + 80, log_att=True)
+        grp.greedy_steps(64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        grp.greedy_steps(steps)
+        toks = grp.greedy_tokens()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        assert toks.shape == (1, B, steps + 64) and int(toks.min()) >= 0 and int(toks.max()) < 4099
+        del grp
+        torch.cuda.empty_cache()
+        kw = dict(batch_size=B, max_seqlen=max_seqlen, device=dev, force_max_seqlen=True, k=1, first_greedy_quant=0, n_engines=2)
+        model_dev.generate_batch(texts, **{**kw, "max_seqlen": 64})
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            qs, atts, stops, cuts = model_dev.generate_batch(texts, **kw)
+            torch.cuda.synchronize()
+            g = time.perf_counter() - t0
+            best = g if best is None else min(best, g)
+        assert qs.shape == (1, B, max_seqlen) and atts.shape[:3] == (B, 2, max_seqlen)
+    model_dev.clear_decode_cache()
+    torch.cuda.empty_cache()
+    return {"what": f"{B} rows on 2 engines x {B // 2} rows, one HIP stream each (DecodeEngineGroup); secondary, not `value`",
+            "loop_ms_per_step": dt * 1e3, "loop_tokens_per_s": B / dt,
+            "generate_batch_tokens_per_s": B * max_seqlen / best, "generate_batch_seconds": best}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -890,6 +927,11 @@ def main():
                     except Exception as e:
                         gb[f"B={bb}"] = {"error": repr(e)}
                 out["generate_batch"] = gb
+                if B >= 256:
+                    try:
+                        out["two_engines"] = measure_two_engines(model_dev, texts, dev)
+                    except Exception as e:
+                        out["two_engines"] = {"error": repr(e)}
             if not args.no_chunk and world == 1:
                 out["config3_pipeline"] = measure_config3(eng, dev, B)
                 out["chunk_kernel"] = measure_chunk(dev)

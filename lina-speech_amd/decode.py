@@ -176,8 +176,11 @@ class DecodeEngine:
     def __init__(self, model, x_enc: torch.Tensor, batch_size: int, state: Optional[Cache] = None,
                  use_graph: Optional[bool] = None, n_split: Optional[int] = None, fuse_norm: bool = True,
                  window: Optional[int] = None, stream_weights=("in", "up"), cross: str = "spread",
-                 fused_pick: bool = True, packed: bool = True, cross_tail_fused: bool = True):
-        """Every variant of the step is a constructor argument (rounds 2-3 read ``LINA_DECODE_*`` environment switches here).
+                 fused_pick: bool = True, packed: bool = True, cross_tail_fused: bool = True,
+                 share_weights_with: Optional["DecodeEngine"] = None):
+        """``share_weights_with``: another engine of the same model whose packed decode-time weights this one reuses
+        (DecodeEngineGroup: several engines on row ranges of one batch).
+        Every variant of the step is a constructor argument (rounds 2-3 read ``LINA_DECODE_*`` environment switches here).
         ``stream_weights``: which weight matrices of the device loop ("in", "o", "up", "down", "head") are loaded with the
         non-temporal hint instead of competing for the 256 MB Infinity Cache (measured optimum: in + up).
         ``cross``: first half of the cross-attention -- "spread" = scores on 256 workgroups + {softmax, att1 . pe} in one launch,
@@ -253,7 +256,7 @@ class DecodeEngine:
         n_split = max(1, min(n_split, batch_size))
         from .shard import shard_rows
         self.parts = []
-        first = None
+        first = None if share_weights_with is None else share_weights_with.packs
         for i in range(n_split):
             lo, hi = shard_rows(batch_size, i, n_split)
             packs = [_BlockPack(b, self._state[j], lo, hi, shared=None if first is None else first[j],
@@ -810,6 +813,19 @@ class DecodeEngine:
         atts = L.att_log[:, :, :n].contiguous() if L.att_log is not None else None
         return qs, atts, n
 
+    def poll_stop(self, slot: int):
+        """Queue a copy of the control block's first two words to pinned slot ``slot`` behind the work enqueued so far."""
+        if self._pin is None:
+            self._pin = [torch.empty(2, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._pin_ev = [torch.cuda.Event() for _ in range(2)]
+        self._pin[slot].copy_(self._loop.ctl[:2], non_blocking=True)
+        self._pin_ev[slot].record()
+
+    def polled_stop(self, slot: int) -> int:
+        """Wait for the copy queued by ``poll_stop(slot)`` and return the stop step it carried (-1: not every row has stopped)."""
+        self._pin_ev[slot].synchronize()
+        return int(self._pin[slot][1])
+
     @torch.inference_mode()
     def run_greedy(self, n_steps: int, y0: Optional[torch.Tensor] = None, record_att: bool = False, **sampling):
         """Decode ``n_steps`` tokens on the device (greedy unless ``k``/``temp``/``seed``/``first_greedy_quant``
@@ -820,3 +836,126 @@ class DecodeEngine:
         toks = self.greedy_tokens()
         self.sync_state()
         return (toks, self.logged_atts(n_steps)) if record_att else toks
+
+
+class DecodeEngineGroup:
+    """Several DecodeEngines on contiguous row ranges of ONE utterance batch, each driven on its own HIP stream.
+
+    The rows of a batch never interact (reference model/modeling_lina.py:125,152-179: one state and one token stream per row), and
+    at a large batch the step of one engine is two thirds K1w -- HBM-bound -- and one third projections that leave HBM idle: two
+    half-batch engines whose graph replays sit in different hardware queues run one half's projections under the other half's
+    state update.  Measured at L169, 512 rows (tools/probe_two_engines.py, profiles/r05_two_engines.txt): one engine 2.34 ms per
+    token, 2 x 256 rows on two streams 2.22 ms (sequentially 2.80), 4 x 128 rows 2.43.  The packed weights are shared; every
+    engine has its own state, logs, control block and captured graphs.  ``generate`` is DecodeEngine.generate over the group: the
+    loop ends when EVERY engine's control block says all of its rows have stopped, and the logs are trimmed at the last of those
+    steps -- the step the reference's single loop breaks at.  No codec-prompt preload (the caller uses one engine for that)."""
+
+    def __init__(self, model, x_enc: torch.Tensor, batch_size: int, n_engines: int = 2, **engine_args):
+        from .shard import shard_rows
+        if n_engines < 2 or n_engines > batch_size:
+            raise ValueError("DecodeEngineGroup needs 2 <= n_engines <= batch_size")
+        self.B, self.dev = batch_size, x_enc.device
+        self.ranges = [shard_rows(batch_size, i, n_engines) for i in range(n_engines)]
+        self.engines = []
+        for lo, hi in self.ranges:
+            xe = x_enc[lo:hi] if x_enc.shape[0] == batch_size else x_enc
+            self.engines.append(DecodeEngine(model, xe, batch_size=hi - lo,
+                                             share_weights_with=self.engines[0] if self.engines else None, **engine_args))
+        self.Q, self.Tn = self.engines[0].Q, self.engines[0].Tn
+        self.streams = ([torch.cuda.Stream(device=self.dev) for _ in self.engines] if self.dev.type == "cuda" else None)
+        self._n_done = 0
+
+    def _each(self, fn):
+        """fn(engine, lo, hi) for every engine, each on its own stream (forked from / before the caller's current stream)."""
+        if self.streams is None:
+            return [fn(e, lo, hi) for e, (lo, hi) in zip(self.engines, self.ranges)]
+        main = torch.cuda.current_stream(self.dev)
+        out = []
+        for e, (lo, hi), st in zip(self.engines, self.ranges, self.streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                out.append(fn(e, lo, hi))
+        return out
+
+    def _join(self):
+        if self.streams is not None:
+            main = torch.cuda.current_stream(self.dev)
+            for st in self.streams:
+                main.wait_stream(st)
+
+    def reset(self, x_enc: Optional[torch.Tensor] = None):
+        self._each(lambda e, lo, hi: e.reset(None if x_enc is None else (x_enc[lo:hi] if x_enc.shape[0] == self.B else x_enc)))
+        self._join()
+
+    def begin_greedy(self, max_steps: int, y0: Optional[torch.Tensor] = None, seed: int = 0, **kw):
+        # (another seed word per engine: the sampler hashes (seed, step, LOCAL row))
+        self._each(lambda e, lo, hi: e.begin_greedy(max_steps, None if y0 is None else y0[lo:hi],
+                                                    seed=(seed + 0x9E3779B97F4A7C15 * self.engines.index(e)) & (2 ** 63 - 1), **kw))
+        self._n_done = 0
+
+    def greedy_steps(self, n: int):
+        """``n`` tokens on every engine, enqueued ALTERNATELY in groups of GRAPH_STEPS: a hipGraph launch costs the host a
+        fraction of a millisecond, so enqueueing one engine's whole run first would start the other one that much later (the
+        first form of generate_batch(n_engines=2) ran 750 steps 15 % slower than the bare loop for that reason)."""
+        N = DecodeEngine.GRAPH_STEPS
+        if self.streams is None:
+            for e in self.engines:
+                e.greedy_steps(n)
+        else:
+            main = torch.cuda.current_stream(self.dev)
+            for st in self.streams:
+                st.wait_stream(main)
+            k = 0
+            while k < n:
+                m = min(N, n - k)
+                for e, st in zip(self.engines, self.streams):
+                    with torch.cuda.stream(st):
+                        e.greedy_steps(m)
+                k += m
+        self._n_done += n
+
+    def greedy_tokens(self):
+        self._join()
+        return torch.cat([e._loop.tok_log[:self._n_done].permute(1, 2, 0) for e in self.engines], dim=1).contiguous()
+
+    @torch.inference_mode()
+    def generate(self, max_seqlen: int, y0: Optional[torch.Tensor] = None, k: int = 1, temp: float = 1.0,
+                 first_greedy_quant: int = 0, seed: int = 0, force_max_seqlen: bool = False, stop_check_every: int = 16,
+                 log_att: bool = True):
+        """As DecodeEngine.generate (no preload).  Returns (qs [Q,B,n], atts [B,2,n,Ttxt] or None, n)."""
+        self.begin_greedy(max_seqlen, y0, seed=seed, k=k, temp=temp, first_greedy_quant=first_greedy_quant, log_att=log_att)
+        total, done = max(int(max_seqlen), 0), 0
+        stops = [-1] * len(self.engines)
+        if force_max_seqlen:
+            self.greedy_steps(total)
+            done = total
+        else:
+            N = DecodeEngine.GRAPH_STEPS
+            every = max(int(stop_check_every), 1)
+            every = (every + N - 1) // N * N if self.engines[0]._loop.graph1 is not None else every
+            prev = None
+            while min(stops) < 0 and done < total:
+                n_now = min(every, total - done)
+                self.greedy_steps(n_now)
+                done += n_now
+                if self.streams is None:
+                    stops = [e.stop_step() for e in self.engines]
+                    continue
+                if prev is not None:                        # the checks issued BEFORE the group of steps just enqueued
+                    stops = [e.polled_stop(prev) for e in self.engines]
+                    if min(stops) >= 0:
+                        break
+                if done < total:
+                    slot = 1 if prev == 0 else 0
+                    self._each(lambda e, lo, hi: e.poll_stop(slot))
+                    prev = slot
+        self._join()
+        if not force_max_seqlen:
+            stops = [e.stop_step() for e in self.engines]
+        n = done
+        if not force_max_seqlen and min(stops) >= 0:
+            n = min(max(stops) + 1, done)                   # every engine's rows have stopped: the last of those steps
+        qs = torch.cat([e._loop.tok_log[:n].permute(1, 2, 0) for e in self.engines], dim=1).contiguous()
+        atts = (torch.cat([e._loop.att_log[:, :, :n] for e in self.engines], dim=0).contiguous()
+                if self.engines[0]._loop.att_log is not None else None)
+        return qs, atts, n

@@ -252,6 +252,40 @@ def check_generate_batch_loop(dev, rel=REL, full=True):
     assert torch.equal(a[0], b[0]) and not torch.equal(a[0], c[0])
 
 
+def check_generate_batch_group(dev, rel=REL):
+    """``generate_batch(..., n_engines=2)``: the batch cut into two row ranges, one DecodeEngine (and one HIP stream) each
+    (decode.DecodeEngineGroup) == the per-token module path with the reference's per-step stop test -- rows never interact, and
+    the loop must end at the step where the LAST of the two engines has seen all of its rows stop."""
+    from lina_speech_amd.decode import DecodeEngineGroup
+    g = load_golden("lina_d64.npz")
+    model = build_lina()
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    with torch.no_grad():
+        model.logits_head.weight[0, 2] *= 6.0
+    model = model.to(dev).eval()
+    B = 5                                                   # 3 + 2 rows
+    for seed, every in (((4, 4), (1, 16)) if dev != "cpu" else ((4, 4),)):      # (the emulator is slow: one case there)
+        x = torch.randint(3, 256, (B, 9), generator=torch.Generator().manual_seed(seed)).to(dev)
+        kw = dict(batch_size=B, max_seqlen=20, k=1, first_greedy_quant=0, device=dev)
+        ref = model.generate_batch(x, engine="module", stop_check_every=1, **kw)
+        got = model.generate_batch(x, stop_check_every=every, n_engines=2, **kw)
+        eng = next(reversed(model._decode_engines.values()))
+        assert isinstance(eng, DecodeEngineGroup) and [hi - lo for lo, hi in eng.ranges] == [3, 2]
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]), f"tokens / stop flags differ (seed {seed})"
+        close(got[1], ref[1].cpu(), "generate_batch with two engines: atts", rel)
+        assert [c[0].shape for c in got[3]] == [c[0].shape for c in ref[3]]
+        assert got[0].shape[-1] < 20
+    forced = model.generate_batch(x, force_max_seqlen=True, n_engines=2, **{**kw, "max_seqlen": 9})
+    assert forced[0].shape[-1] == 9 and torch.equal(forced[0][:, :, :got[0].shape[-1]], got[0][:, :, :9])
+    if dev == "cpu":
+        return
+    torch.manual_seed(7)
+    a = model.generate_batch(x, batch_size=B, max_seqlen=5, device=dev, force_max_seqlen=True, n_engines=2)
+    torch.manual_seed(7)
+    b = model.generate_batch(x, batch_size=B, max_seqlen=5, device=dev, force_max_seqlen=True, n_engines=2)
+    assert torch.equal(a[0], b[0])
+
+
 def check_generate_batch_early_stop(dev, dtype=torch.float32, d=256, B=8, max_seqlen=160, need_late_stop=True):
     """a-10, the early-stop path of the device loop over MANY stop checks (reference model/modeling_lina.py:168-173): a small
     vocabulary (13 codes + 3 specials) in the reference's default SAMPLED mode makes every row emit the stop token (id 2) at a

@@ -42,6 +42,11 @@ def test_generate_batch_default_is_the_device_loop(emu):
     check_generate_batch_loop("cpu", full=False)
 
 
+def test_generate_batch_with_two_engines(emu):
+    from model_cases import check_generate_batch_group
+    check_generate_batch_group("cpu")
+
+
 def test_engine_device_side_greedy_loop(emu):
     import torch
     from model_cases import build_lina, golden_state_dict, load_golden

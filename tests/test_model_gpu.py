@@ -28,6 +28,13 @@ def test_generate_batch_default_is_the_device_loop(hip):
     check_generate_batch_loop("cuda")
 
 
+def test_generate_batch_with_two_engines_on_two_streams(hip):
+    """decode.DecodeEngineGroup: two engines on two HIP streams behind generate_batch(n_engines=2) == the per-token module path
+    (early stops at different steps in the two halves, forced length, reproducible sampling)."""
+    from model_cases import check_generate_batch_group
+    check_generate_batch_group("cuda")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_generate_batch_early_stop_over_many_checks(hip, dtype):
     """The hipGraph loop (8 tokens per replay, attention rows filed by the cross-attention kernels at the device step index,

@@ -27,3 +27,6 @@ if "other_head_shapes" in d:
         print(f"{k}: {v['ms_per_step']:.4f} ms/step {v['tokens_per_s']:.0f} tok/s")
 if "cpu_baseline" in d:
     print(f"cpu_baseline: {d['cpu_baseline']['value']:.1f} tok/s on {d['cpu_baseline']['cores']} threads")
+if "two_engines" in d:
+    t = d["two_engines"]
+    print("two_engines:", t.get("error") or f"{t['loop_tokens_per_s']:.0f} tok/s ({t['loop_ms_per_step']:.4f} ms/step), generate_batch {t['generate_batch_tokens_per_s']:.0f} tok/s")
