@@ -621,6 +621,8 @@ def measure_batch(model_dev, dev, B=512, steps=120):
         s_b, w_b, kv_b, s_imm = step_hbm_bytes(eng)
         mem = torch.cuda.max_memory_allocated(dev) / 1e9
         del eng
+    import gc
+    gc.collect()                                 # (an engine is a reference cycle: free its graphs and buffers now)
     torch.cuda.empty_cache()
     nb = s_b + w_b + kv_b
     return {"what": f"the same decode loop with B = {B} rows on ONE GPU (secondary, not `value`)",
@@ -703,6 +705,8 @@ def measure_two_engines(model_dev, texts, dev, steps=240, max_seqlen=750):
         dt = (time.perf_counter() - t0) / steps
         assert toks.shape == (1, B, steps + 64) and int(toks.min()) >= 0 and int(toks.max()) < 4099
         del grp
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
         kw = dict(batch_size=B, max_seqlen=max_seqlen, device=dev, force_max_seqlen=True, k=1, first_greedy_quant=0, n_engines=2)
         model_dev.generate_batch(texts, **{**kw, "max_seqlen": 64})

@@ -49,6 +49,28 @@ def _fold_layernorm(weight, ln, bias=None):
 _CAPTURE_MODE = "thread_local"
 
 
+class _capture_guard:
+    """No garbage collection while a stream is capturing.  An engine is a reference cycle (its loop bodies close over it), so a
+    dropped engine -- and the hipGraphs it owns -- is destroyed whenever Python's cyclic collector happens to run; if that moment
+    falls inside another engine's stream capture, ``hipGraphDestroy`` fails with "operation not permitted when stream is
+    capturing" inside a C++ destructor and the process aborts (seen in round 5: bench.py building its fifth engine).  Collect
+    first, outside the capture, then keep the collector off until the capture has ended."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
+
 class _BlockPack:
     """Decode-time weights of one MixingBlock(GatedLinearAttention, SwiGLU, LayerNorm)."""
 
@@ -451,7 +473,7 @@ class DecodeEngine:
                 self._core(y, lazy, self._loop_packed)
             torch.cuda.current_stream(self.dev).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+            with _capture_guard(), torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
                 self._core(y, lazy, self._loop_packed)
                 self._t_idx.add_(1)                       # walks through the window positions
             for _ in range(16):
@@ -500,7 +522,7 @@ class DecodeEngine:
         torch.cuda.current_stream(self.dev).wait_stream(side)
         self._restore(snap)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+        with _capture_guard(), torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
             self._core(self._y_in)
         self._graph = g
 
@@ -646,7 +668,7 @@ class DecodeEngine:
             self._origin.copy_(o_keep)
             self._pick_counter.zero_()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+            with _capture_guard(), torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
                 L.att = body()
             L.graph1 = g
         return L
@@ -712,7 +734,7 @@ class DecodeEngine:
         if L.graph1 is not None and n >= N:
             if L.graphN is None:                             # captured on first use (stream capture executes nothing)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+                with _capture_guard(), torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
                     for _ in range(N):
                         L.body()
                 L.graphN = g

@@ -91,6 +91,8 @@ class LinaModel(nn.Module):
         writes through ``param.data`` (and in-place writes to parameters created under ``torch.inference_mode``, which
         have no version counter) do not show up in the key -- call this after them."""
         self.__dict__.pop("_decode_engines", None)
+        import gc
+        gc.collect()                      # engines are reference cycles: destroy their graphs / buffers now, not at some later point
 
     def _decode_engine(self, x_enc: Tensor, B: int, init_state, n_engines: int = 1):
         """The DecodeEngine of (batch size, text length, dtype, device, current weights), built once and re-armed for
