@@ -42,6 +42,7 @@ def assert_close(got, ref, rel, what):
 
 
 def make_gla_inputs(B, H, T, Dk, Dv, dtype, dev, seed=0, resets=False):
+    """``resets``: False | True (reset gates, a cut-forcing run of them, one gate beyond the clamp) | "saturated" (see below)."""
     g = torch.Generator().manual_seed(seed)
     # projections arrive as [B,T,H*D]; the ops see the head-first VIEW (reference gla.py:173)
     def heads(x):
@@ -55,6 +56,13 @@ def make_gla_inputs(B, H, T, Dk, Dv, dtype, dev, seed=0, resets=False):
         gk[:, 17, ::3] = -20.0
         gk[:, 23, 1::2] = -70.0     # single gate beyond the clamp
         gk[:, 30:33, :7] = -25.0
+    if resets == "saturated":       # ONE gate below the -60 clamp with every other gate of its chunk at 0, in a full chunk
+        gk[:, 32:64] = 0.0          # (tokens 32..63) and in the last, partial one -- the optimistic scan flags it and rescans
+        gk[:, 40, 3::5] = -70.0
+        if T % 32 and T > 64:
+            t0 = T - T % 32
+            gk[:, t0:] = 0.0
+            gk[:, t0 + 1, 1::4] = -75.0
     gk = gk.to(dtype)
     h0 = torch.randn(B, H, Dk, Dv, generator=g) * 0.5
     return [heads(x.to(dev)) for x in (q, k, v, gk)] + [h0.to(dev)]

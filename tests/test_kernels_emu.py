@@ -38,6 +38,15 @@ def test_chunk_bwd(emu, Dk, Dv, T, dtype):
     check_chunk_bwd(DEV, B=1, H=2, T=T, Dk=Dk, Dv=Dv, dtype=dtype)
 
 
+@pytest.mark.parametrize("T", [70, 101])
+def test_chunk_single_saturated_gate_full_and_partial_chunk(emu, T):
+    """one gate below -60 among zeros, in a full and in the last partial chunk: forward (MODE 0) on the full-head
+    kernel and the three backward sweeps (MODE 1) vs the fp64 oracle / fp64 autograd."""
+    from kernel_cases import check_chunk_bwd_full
+    check_chunk(DEV, B=1, H=1, T=T, Dk=256, Dv=256, dtype=torch.bfloat16, resets="saturated")
+    check_chunk_bwd_full(DEV, B=1, H=1, T=T, D=256, nseg=1, resets="saturated")
+
+
 def test_chunk_bwd_reset_gates_no_state(emu):
     check_chunk_bwd(DEV, B=1, H=1, T=40, Dk=64, Dv=64, dtype=torch.float32, resets=True, with_h0=False, with_dht=False)
 

@@ -174,7 +174,7 @@ def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
       2. the oracle (fp32 arithmetic on the SAME bf16-rounded weights) is teacher-forced with the engine's tokens ->
          reference logits and top-2 margins for the same history at every position;
       3. the engine's teacher-forced logits (generic step API, immediate state update) and the windowed loop's OWN logits
-         must be within 2e-2 of max|oracle logits| (bf16 activations vs fp32);
+         must be within 1e-2 of max|oracle logits| (bf16 activations vs fp32; achieved 3.3e-3);
       4. every free-running token must be the oracle's arg-max wherever the oracle's margin exceeds TWICE the measured
          logit error (if |dlogit| <= e everywhere the arg-max cannot differ at a margin > 2e); fewer than 5 % of the
          B x n positions may fall below that margin, and there must be NO raw token difference outside them."""
@@ -184,7 +184,8 @@ def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
     torch.manual_seed(0)
     from model_cases import peak_logits
     model = peak_logits(l169().eval())
-    B, n, REL = 64, 32, 2e-2
+    B, n, REL, REL_ATT = 64, 32, 1e-2, 2e-2     # logits: 1e-2 of max|oracle logit| (achieved 3.3e-3; ADVICE r04: the peaked head
+                                                # makes max|logit| several times larger, so the round-4 bound of 2e-2 was loose)
     MASK_CAP = 0.05          # peaked logits: (almost) every position is comparable (round 3, flat logits: 30 % were not)
     x = torch.randint(3, 256, (B, 24), generator=torch.Generator().manual_seed(7))
     mb = model.to(torch.bfloat16)
@@ -220,8 +221,8 @@ def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
     finally:
         torch.set_num_threads(n_thr)
     att_err = float((gb_atts - ref_atts).abs().max() / ref_atts.abs().max())
-    record_parity("L169 bf16 B=64 generate_batch: attention log [B,2,n,Ttxt] vs fp32 oracle", att_err, REL)
-    assert gb_atts.shape == ref_atts.shape and att_err < REL, f"attention log rel err {att_err:.3e}"
+    record_parity("L169 bf16 B=64 generate_batch: attention log [B,2,n,Ttxt] vs fp32 oracle", att_err, REL_ATT)
+    assert gb_atts.shape == ref_atts.shape and att_err < REL_ATT, f"attention log rel err {att_err:.3e}"
     assert gb_stops.shape == (B, n + 1) and len(gb_cuts) == B
     scale = float(ref_logits.abs().max())
     with torch.inference_mode():
