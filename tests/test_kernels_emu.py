@@ -241,21 +241,22 @@ def test_projections_wider_split_k(emu, monkeypatch, nw):
     check_inproj_packed(DEV, 5, 1024, 16, 48, torch.bfloat16)
 
 
-@pytest.mark.parametrize("M,N,K,dtype,ln,bias,resid,sw", [(130, 70, 160, torch.bfloat16, False, True, True, 0),
-                                                          (70, 100, 96, torch.bfloat16, True, True, False, 0),
-                                                          (129, 56, 288, torch.bfloat16, True, True, False, 40),
-                                                          (33, 64, 128, torch.bfloat16, False, False, False, 64),
-                                                          (140, 48, 80, torch.float32, True, True, True, 0),
-                                                          (20, 40, 48, torch.float32, True, False, False, 21)])
-@pytest.mark.parametrize("variant", [0, 1, 2])
-def test_linear_tall(emu, M, N, K, dtype, ln, bias, resid, sw, variant):
+_TALL_CASES = [(130, 70, 160, torch.bfloat16, False, True, True, 0), (70, 100, 96, torch.bfloat16, True, True, False, 0),
+               (129, 56, 288, torch.bfloat16, True, True, False, 40), (33, 64, 128, torch.bfloat16, False, False, False, 64),
+               (140, 48, 80, torch.float32, True, True, True, 0), (20, 40, 48, torch.float32, True, False, False, 21)]
+
+
+# variant 0 (the launchers' default) on every case; variants 1 and 2 (A/B builds of the operand path) on two cases each
+@pytest.mark.parametrize("variant,case", [(0, c) for c in _TALL_CASES] + [(v, _TALL_CASES[i]) for v in (1, 2) for i in (2, 4)])
+def test_linear_tall(emu, variant, case):
     from kernel_cases import check_linear_tall
+    M, N, K, dtype, ln, bias, resid, sw = case
     check_linear_tall(DEV, M, N, K, dtype, ln=ln, bias=bias, resid=resid, swiglu=sw, variant=variant)
 
 
-@pytest.mark.parametrize("B,K,Kd,Vd,dtype", [(130, 96, 64, 128, torch.bfloat16), (70, 160, 128, 64, torch.bfloat16),
-                                             (129, 48, 64, 64, torch.float32)])
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("B,K,Kd,Vd,dtype,variant", [(130, 96, 64, 128, torch.bfloat16, 0), (70, 160, 128, 64, torch.bfloat16, 0),
+                                                     (129, 48, 64, 64, torch.float32, 0), (70, 160, 128, 64, torch.bfloat16, 1),
+                                                     (129, 48, 64, 64, torch.float32, 2)])
 def test_inproj_tall(emu, B, K, Kd, Vd, dtype, variant):
     from kernel_cases import check_inproj_tall
     check_inproj_tall(DEV, B, K, Kd, Vd, dtype, variant=variant)
