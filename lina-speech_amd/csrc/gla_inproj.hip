@@ -307,11 +307,11 @@ __global__ __launch_bounds__(64 * NW) void gla_inproj_kernel(
     IP_PROF_FLUSH();
 }
 
-// ---- B >= 128: the same launch on the tall tiling (linear_tall.h: 128 rows x 64 weight rows per workgroup, the weights of a
+// ---- B >= 160 (kTallMinRows): the same launch on the tall tiling (linear_tall.h: 64 rows x 64 weight rows per workgroup, the weights of a
 // k-step staged through LDS once for the four waves, every wave's accumulators final).  grid.x = (2 Kd + 2 Vd) / 64 workgroups
 // on q | k | v | g columns (Kd, Vd multiples of 64: a workgroup's columns lie in ONE region) + Kd / 64 GATE workgroups, each
-// projecting its 128 rows on the 16 low-rank weight rows (one weight fragment per k-step) and applying the rank-16
-// up-projection + bias + log-sigmoid for 64 gate channels; grid.y = ceil(B / 128).  Epilogues as gla_inproj_kernel's.
+// projecting its 64 rows on the 16 low-rank weight rows (one weight fragment per k-step) and applying the rank-16
+// up-projection + bias + log-sigmoid for 64 gate channels; ceil(B / 64) row blocks (XCD-aware 1-D grid).  Epilogues as gla_inproj_kernel's.
 template <typename T, int V>
 __global__ __launch_bounds__(64 * TallShape<V>::NWV) void gla_inproj_tall_kernel(
     const T* __restrict__ A, const T* __restrict__ W, const float* __restrict__ c1, const float* __restrict__ c2,
@@ -319,6 +319,11 @@ __global__ __launch_bounds__(64 * TallShape<V>::NWV) void gla_inproj_tall_kernel
     const T* __restrict__ w2, const T* __restrict__ b2, T* __restrict__ qkv, T* __restrict__ g_out, float* __restrict__ gk,
     int M, int K, int Kd, int Vd, float ln_eps, float inv_norm, float clamp_min, int has_clamp) {
     using F = Frag<T>;
+#ifdef LINA_SKINNY_PROF
+    unsigned long long pr_[8] = {};
+    IP_PROF(0, wall_clock64());
+    IP_PROF(1, clock64());
+#endif
     constexpr int R = 16, NT = 4, MTW = TallShape<V>::MTW;
     typedef typename raw4<T>::type raw_t;
     __shared__ __attribute__((aligned(16))) unsigned char s_w[TallShape<V>::LDS];   // the ONLY LDS object (see linear_tall.h)
@@ -371,6 +376,7 @@ __global__ __launch_bounds__(64 * TallShape<V>::NWV) void gla_inproj_tall_kernel
                     if (m < M) gk[(int64_t)m * Kd + c] = gv;
                 }
         }
+        IP_PROF_FLUSH();
         return;
     }
 
@@ -383,6 +389,7 @@ __global__ __launch_bounds__(64 * TallShape<V>::NWV) void gla_inproj_tall_kernel
     for (int j = 0; j < NT; ++j) { pre_c1[j] = c1[n0 + 16 * j + li]; pre_c2[j] = c2[n0 + 16 * j + li]; }
     f32x4 acc[NT][MTW];
     tall_core_v<V, T, NT, true, MTW>(A, W, nb, nks, m0 >> 4, wave_on, s_w, acc, s1, s2);
+    IP_PROF(2, clock64());
 
     // the workgroup's 64 columns lie in one region (block-uniform): q | k | v -> conv step + SiLU, g -> stored as is
     const bool is_g = n0 >= 2 * Kd + Vd;
@@ -435,6 +442,192 @@ __global__ __launch_bounds__(64 * TallShape<V>::NWV) void gla_inproj_tall_kernel
             }
         }
     }
+    IP_PROF_FLUSH();
+}
+
+// ---- B > 256 (round 6): 128 rows x 64 columns per workgroup on EXACTLY (2 Kd + 2 Vd) / 64 x ceil(B / 128) workgroups -- 256 at
+// L169 / B = 512, one per CU -- with the register-ring main loop (linear_tall.h, variant 3) and two changes to the launch itself:
+//   * no gate workgroups.  The kernel above spends Kd / 64 of its column blocks (128 of 640 workgroups at B = 512) on the 16
+//     low-rank gate rows: each streams its rows of A over the WHOLE contraction -- the bytes and the time of a regular workgroup --
+//     for 1/64 of the flops, sixteen times over per row block.  Here the low-rank rows ride along as a FIFTH weight fragment in
+//     every workgroup (+ 8 % bytes per workgroup), and a workgroup applies the rank-16 up-projection + bias + log-sigmoid to ITS
+//     share of the gate channels (Kd / 64 ... : 16 of them at L169: 16 fmas + one log-sigmoid for 8 elements per thread);
+//   * the rolled conv caches are requested BEFORE the main loop in the epilogue's own lane mapping (a tile row is 64 channels x
+//     4 taps = one contiguous 512-byte run of the cache: 16 bytes per lane), the tile goes through LDS once, and the cache is
+//     rewritten / q|k|v stored with 16- / 4-byte accesses instead of 8- / 2-byte ones.
+// Bytes a CU pulls: (128 + 80) rows x K x e = 416 KB against 640 KB (2.5 workgroups of 256 KB per CU) -- the loop time of these
+// kernels is that figure / ~30 B per clock (linear_tall.h).  Contract (checked by the launcher): K a multiple of kTallRwD k-steps,
+// Kd, Vd multiples of 64.  Results: the same sums in the same order as gla_inproj_tall_kernel (bit-identical outputs).
+template <typename T, bool WNT, int MT>
+__global__ __launch_bounds__(256) void gla_inproj_tall3_kernel(
+    const T* A, const T* W, const float* __restrict__ c1, const float* __restrict__ c2,
+    const T* __restrict__ wq, const T* __restrict__ wk, const T* __restrict__ wv, T* cq, T* ck, T* cv,
+    const T* __restrict__ w2, const T* __restrict__ b2, T* __restrict__ qkv, T* __restrict__ g_out, float* __restrict__ gk,
+    int M, int K, int Kd, int Vd, float ln_eps, float inv_norm, float clamp_min, int has_clamp) {
+    using F = Frag<T>;
+#ifdef LINA_SKINNY_PROF
+    unsigned long long pr_[8] = {};
+    IP_PROF(0, wall_clock64());
+    IP_PROF(1, clock64());
+#endif
+    constexpr int R = 16, NT = 4, D = kTallRwD, G = NT + 1, ROWS = 64 * MT;
+    constexpr int ZS = 68;                                   // staging row stride in floats (272 B: rows 4 apart sit 16 banks apart)
+    constexpr int WR = 16 * MT;                              // rows per wave
+    constexpr int CPL = 16 / (int)sizeof(T);                 // columns per 16-byte piece of an output row
+    typedef typename raw4<T>::type raw_t;
+    __shared__ __attribute__((aligned(16))) unsigned char s_w[tall_rw_lds_bytes(G)];
+    __shared__ __attribute__((aligned(16))) float s_z[4][16 * MT][ZS];
+    __shared__ float s_lr[ROWS][R + 1];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int w = wave_uniform(tid >> 6);
+    const int n_direct = 2 * Kd + 2 * Vd;
+    const int nb_direct = n_direct / (16 * NT);
+    int cblk, rblk;
+    if (!tall_tile_of((int)blockIdx.x, nb_direct, (M + ROWS - 1) / ROWS, cblk, rblk)) return;
+    const int mw = rblk * ROWS + WR * w;                     // this wave's first row
+    const int n0 = cblk * (16 * NT);
+    const int nks = K / F::KSTEP;
+    const bool wave_on = mw < (M + 63) / 64 * 64;            // (the packed operand is padded to whole 64-row blocks)
+    const float inv_k = fast_rcp((float)K);
+
+    // the workgroup's 64 columns lie in one region (block-uniform): q | k | v -> conv step + SiLU, g -> stored as is
+    const bool is_g = n0 >= 2 * Kd + Vd;
+    const T* wsel; T* csel; int cb0, Dch;
+    if (n0 < Kd) { cb0 = n0; Dch = Kd; wsel = wq; csel = cq; }
+    else if (n0 < 2 * Kd) { cb0 = n0 - Kd; Dch = Kd; wsel = wk; csel = ck; }
+    else if (!is_g) { cb0 = n0 - 2 * Kd; Dch = Vd; wsel = wv; csel = cv; }
+    else { cb0 = n0 - (2 * Kd + Vd); Dch = Vd; wsel = wv; csel = cv; }
+
+    int nb[G];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) nb[j] = (n0 >> 4) + j;
+    nb[NT] = n_direct >> 4;
+    float pre_c1[G], pre_c2[G];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { pre_c1[j] = c1[n0 + 16 * j + li]; pre_c2[j] = c2[n0 + 16 * j + li]; }
+    pre_c1[NT] = c1[n_direct + li];
+    pre_c2[NT] = c2[n_direct + li];
+
+    // conv epilogue mapping of a wave's WR x 64 tile: item i of a lane = (row 2 i + lane / 32, channel pair lane % 32); the pair's
+    // 2 x 4 cached taps are 16 contiguous bytes (bf16), a row of the tile one contiguous run of the cache
+    constexpr int NI = WR / 2;
+    const int cp = lane & 31, rsub = lane >> 5;
+    raw_t old[NI][2], wj[2];
+    // this workgroup's share of the gate channels, GC of them from c_lo on.  256 % GC == 0 (GC = 16 at Kd == Vd): a thread's
+    // channel is the same for all of its elements, and its rank-16 weight row + bias are requested here, in front of the main
+    // loop -- in the epilogue each element's row was a memory round trip of its own (8 in a row: 3.4 us, profiles/r06_tall_prof.txt)
+    const int GC = (Kd + nb_direct - 1) / nb_direct;
+    const int c_lo = cblk * GC;
+    const bool gate_fixed = 256 % GC == 0;
+    raw_t w2q[4];
+    T b2q;
+    auto prefetch = [&]() {                                  // called by the main loop behind its first D k-steps of loads
+        const int c = c_lo + tid % GC;
+        const int cc = c < Kd ? c : Kd - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w2q[q] = ld4_raw(w2 + (int64_t)cc * R + 4 * q);
+        b2q = ld_raw(b2 + cc);
+        if (!is_g) {
+            wj[0] = ld4_raw(wsel + (int64_t)(cb0 + 2 * cp) * 4);
+            wj[1] = ld4_raw(wsel + (int64_t)(cb0 + 2 * cp + 1) * 4);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int m = mw + 2 * i + rsub;
+                const T* src = csel + ((int64_t)(m < M ? m : 0) * Dch + cb0 + 2 * cp) * 4;
+                old[i][0] = ld4_raw(src);
+                old[i][1] = ld4_raw(src + 4);
+            }
+        }
+    };
+
+    f32x4 acc[G][MT];
+    float s1[MT][4], s2[MT][4];
+    IP_PROF(7, clock64());
+    tall_core_rw<T, G, true, WNT, MT, D>(A, W, nb, nks, mw >> 4, wave_on, s_w, acc, s1, s2, prefetch);
+    IP_PROF(2, clock64());
+#pragma unroll
+    for (int q = 0; q < 4; ++q) opaque_raw(w2q[q]);          // the prefetched bits are first USED behind this point (lina_dev.h)
+    if (!is_g) {
+        opaque_raw(wj[0]);
+        opaque_raw(wj[1]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { opaque_raw(old[i][0]); opaque_raw(old[i][1]); }
+    }
+
+    // LayerNorm fold; the tile (rounded to the model dtype: the conv / the stored g see the projection in that dtype) and the
+    // low-rank activations go through LDS
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float mu[4], rstd[4];
+        tall_row_stats(s1[mt], s2[mt], inv_k, ln_eps, mu, rstd);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + 4 * lg + r;
+            s_lr[WR * w + row][li] = rstd[r] * (acc[NT][mt][r] - mu[r] * pre_c1[NT]) + pre_c2[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                T tmp;
+                st(&tmp, rstd[r] * (acc[j][mt][r] - mu[r] * pre_c1[j]) + pre_c2[j]);
+                s_z[w][row][16 * j + li] = ld(&tmp);
+            }
+        }
+    }
+    __syncthreads();
+    IP_PROF(3, clock64());
+
+    if (is_g) {
+        // rows of 64 columns as 16-byte pieces: item -> (row, piece)
+        constexpr int PPR = 64 / CPL, NP = WR * PPR / 64;    // pieces per row, pieces per lane
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = lane + 64 * i, row = idx / PPR, pc = idx % PPR;
+            const int m = mw + row;
+            if (m >= M) continue;
+            T* dst = g_out + (int64_t)m * Vd + cb0 + CPL * pc;
+            const float* zr = &s_z[w][row][CPL * pc];
+#pragma unroll
+            for (int q = 0; q < CPL / 4; ++q) st4(dst + 4 * q, make_float4(zr[4 * q], zr[4 * q + 1], zr[4 * q + 2], zr[4 * q + 3]));
+        }
+    } else {
+        const float4 wa = cvt4(wj[0]), wb = cvt4(wj[1]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = 2 * i + rsub, m = mw + row;
+            if (m >= M) continue;
+            const float z0 = s_z[w][row][2 * cp], z1 = s_z[w][row][2 * cp + 1];
+            const float4 o0 = cvt4(old[i][0]), o1 = cvt4(old[i][1]);
+            const float4 n0v = make_float4(o0.y, o0.z, o0.w, z0), n1v = make_float4(o1.y, o1.z, o1.w, z1);
+            T* cb = csel + ((int64_t)m * Dch + cb0 + 2 * cp) * 4;
+            st4(cb, n0v);
+            st4(cb + 4, n1v);
+            const float y0 = fmaf(wa.w, n0v.w, fmaf(wa.z, n0v.z, fmaf(wa.y, n0v.y, wa.x * n0v.x)));
+            const float y1 = fmaf(wb.w, n1v.w, fmaf(wb.z, n1v.z, fmaf(wb.y, n1v.y, wb.x * n1v.x)));
+            T* qd = qkv + (int64_t)m * (2 * Kd + Vd) + n0 + 2 * cp;
+            st_pair(qd, silu(y0), silu(y1));
+        }
+    }
+
+    IP_PROF(4, clock64());
+    // this workgroup's share of the gate channels: rank-16 up-projection + bias + log-sigmoid / normaliser (+ clamp)
+    for (int idx = tid; idx < ROWS * GC; idx += 256) {
+        const int row = idx / GC, c = c_lo + idx % GC;
+        const int m = rblk * ROWS + row;
+        if (c >= Kd || m >= M) continue;
+        if (!gate_fixed) {                                   // (a thread's channel changes from element to element)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w2q[q] = ld4_raw(w2 + (int64_t)c * R + 4 * q);
+            b2q = ld_raw(b2 + c);
+        }
+        const float4 q0 = cvt4(w2q[0]), q1 = cvt4(w2q[1]), q2 = cvt4(w2q[2]), q3 = cvt4(w2q[3]);
+        const float w2r[R] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        float accg = cvt1(b2q);
+#pragma unroll
+        for (int k = 0; k < R; ++k) accg = fmaf(s_lr[row][k], w2r[k], accg);
+        float gv = logsigmoidf(accg) * inv_norm;
+        if (has_clamp) gv = fmaxf(gv, clamp_min);
+        gk[(int64_t)m * Kd + c] = gv;
+    }
+    IP_PROF_FLUSH();
 }
 
 }  // namespace lina
@@ -463,8 +656,27 @@ static int inproj_impl(const void* x, int64_t ldx, const void* w_in, int64_t ldw
         const int tall_mode = tall_env ? atoi(tall_env) : -1;
         const bool can = (packed & 1) && Kd % 64 == 0 && Vd % 64 == 0;
         if (can && (tall_mode == 1 || (tall_mode != 0 && B >= kTallMinRows))) {
-            const char* v_env = getenv("LINA_TALL_V");       // variant (linear_tall.h): 0 = LDS ring (default: 21.3 us at B = 512; 24.3 / 28.2 as 1 / 2)
-            const int tv = v_env ? atoi(v_env) : LINA_TALL_DEFAULT_V;
+            // variant (linear_tall.h): 0 = LDS-DMA ring, 64-row workgroups + gate workgroups (21.3 us at B = 512 in situ; 24.3 / 28.2
+            // as 1 / 2); 3 = register ring, 128-row workgroups, gate folded in (gla_inproj_tall3_kernel) -- the default from 257
+            // rows up when K is a whole number of its 8-k-step groups.  LINA_TALL_V forces one (test / A-B hook, read per call).
+            const char* v_env = getenv("LINA_TALL_V");
+            const bool v3_ok = (K / kstep) % kTallRwD == 0;
+            int tv = v_env ? atoi(v_env) : LINA_TALL_DEFAULT_V;
+            if ((tv == 3 || tv == 4) && !v3_ok) tv = LINA_TALL_DEFAULT_V;
+            if (tv == 3 || tv == 4) {                        // 4: the same kernel on 64-row workgroups (twice as many: A/B)
+                const int mt = tv == 3 ? kTallRwMT : 1;
+                dim3 tgrid(tall_grid((2 * Kd + 2 * Vd) / 64, (B + 64 * mt - 1) / (64 * mt)));
+#define LINA_INPROJ_T3(TT, WNTT, MTT)                                                                                 \
+    LINA_LAUNCH((gla_inproj_tall3_kernel<TT, WNTT, MTT>), tgrid, dim3(256), 0, stream, (const TT*)x, (const TT*)w_in, c1, c2, \
+                (const TT*)wq, (const TT*)wk, (const TT*)wv, (TT*)cq, (TT*)ck, (TT*)cv, (const TT*)w2, (const TT*)b2,   \
+                (TT*)qkv, (TT*)g_out, gk, B, K, Kd, Vd, ln_eps, 1.0f / normalizer, clamp_min, has_clamp)
+#define LINA_INPROJ_T3M(TT, WNTT) do { if (mt == 1) LINA_INPROJ_T3(TT, WNTT, 1); else LINA_INPROJ_T3(TT, WNTT, kTallRwMT); } while (0)
+                if (dtype == LINA_F32) { if (packed == 3) LINA_INPROJ_T3M(float, true); else LINA_INPROJ_T3M(float, false); }
+                else { if (packed == 3) LINA_INPROJ_T3M(bf16_t, true); else LINA_INPROJ_T3M(bf16_t, false); }
+#undef LINA_INPROJ_T3M
+#undef LINA_INPROJ_T3
+                return check_launch("lina_gla_decode_inproj (tall, register ring)");
+            }
             const int rows = tv == 1 ? TallShape<1>::ROWS : TallShape<0>::ROWS;
             dim3 tgrid(tall_grid((2 * Kd + 2 * Vd) / 64 + Kd / 64, (B + rows - 1) / rows));
 #define LINA_INPROJ_TALL(TT, VV)                                                                                      \

@@ -53,6 +53,10 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     *reinterpret_cast<uint2*>(p) = u;
 }
 
+// 2 consecutive elements (pointer 8-B aligned for float, 4-B for bf16)
+__device__ __forceinline__ void st_pair(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+__device__ __forceinline__ void st_pair(bf16_t* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(a, b); }
+
 // RAW forms of the 4-element load: a load whose value is only needed much later must not be converted where it is issued --
 // the bf16 -> fp32 conversion is a USE of the loaded register, i.e. an `s_waitcnt` for this load and for every load issued
 // before it.  Keep the raw bits, convert at the point of use.

@@ -206,6 +206,13 @@ __device__ __forceinline__ void cfence() { asm volatile("" ::: "memory"); }
 // (and being spilled from) VGPRs across the whole loop
 __device__ __forceinline__ void opaque(int& x) { asm volatile("" : "+v"(x)); }
 
+// the same for the raw bits of a prefetched operand (uint2 / float4 / uint4): placed AFTER a main loop it pins the bf16 -> fp32
+// conversion (a USE of the loaded registers, i.e. a wait for the prefetch) behind the loop -- the compiler otherwise hoists the
+// conversion to right behind the loads and the kernel waits for its epilogue operands before it starts
+__device__ __forceinline__ void opaque_raw(uint2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+__device__ __forceinline__ void opaque_raw(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void opaque_raw(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
 // streaming (read-once / write-once) 16-byte accesses: keep the state tile out of the caches
 __device__ __forceinline__ float4 ld_nt4(const float* p) {
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));

@@ -463,7 +463,8 @@ static int linear_skinny_impl(const void* A, int64_t lda, const void* W, int64_t
             LINA_REQUIRE(Hp >= (N + 16 * nt - 1) / (16 * nt) * (16 * nt),
                          "lina_linear_skinny: packed weights must be zero-padded to whole %d-row blocks covering N", 16 * nt);
             const char* v_env = getenv("LINA_TALL_V");       // variant (linear_tall.h): 0 = LDS ring, 1 = register ring, 2 = W in LDS + A in registers
-            const int tv = v_env ? atoi(v_env) : 0;   // measured (profiles/r05_tall_perf.txt): head 12.5 / 14.8 / 13.1 us as variant 0 / 1 / 2
+            int tv = v_env ? atoi(v_env) : 0;         // measured (profiles/r05_tall_perf.txt): head 12.5 / 14.8 / 13.1 us as variant 0 / 1 / 2
+            if (tv < 0 || tv > 2) tv = 0;             // (3 / 4 name variants of the fused in-projection only: gla_inproj.hip)
             const int rows = tv == 1 ? TallShape<1>::ROWS : TallShape<0>::ROWS;
             dim3 tgrid(tall_grid((N + 16 * nt - 1) / (16 * nt), (M + rows - 1) / rows));
 #define LINA_LT(TT, SW, LNN, NTT, VV)                                                                                \

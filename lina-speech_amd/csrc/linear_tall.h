@@ -353,6 +353,112 @@ __device__ __forceinline__ void tall_core_hyb(const T* __restrict__ A, const T* 
         }
 }
 
+// ---- variant 3 ("rw"): NO LDS-DMA.  Every wave's own A fragments go straight into a register ring D k-steps deep (plain 16-byte
+// loads: asynchronous until the compiler's counted wait in front of the MFMAs that use them); the weight fragments the four waves
+// share go global -> registers (the same ring) -> ds_write_b128 -> a two-slot LDS buffer of ONE k-step each, one barrier per
+// k-step.  Round 6 measured every main loop of this file on its own (tools/micro/tall_gemm.hip, profiles/r06_tall_gemm.txt): a
+// workgroup ingests ~30 bytes per clock whatever the transport (LDS-DMA ring, register ring, 4 or 8 waves per CU, ring depth 4-16,
+// with or without the LayerNorm MFMAs) -- the CU's vector-memory path, not the matrix pipe or the LDS, sets the loop time, so the
+// loop time is (bytes a CU pulls) / 30 B/clk and the tile shape that minimises it at M = 512 is 128 rows x 64 columns on exactly
+// 256 workgroups.  At 128 rows (two m-tiles per wave) this loop takes 14.4 k clocks against 19.8 k for the LDS-DMA ring, whose
+// issuing waves block 60-185 clocks per piece.  G = 5: a fifth weight fragment (the 16 low-rank gate rows of the fused
+// in-projection) rides along, fetched in quarters (4 bytes per lane and wave) so that the four waves stay uniform.
+// The loop is the ONLY code (no tail with its own register assignment: the accumulators then stay put instead of being
+// permuted through v_accvgpr moves at the loop edge): nks % D == 0 and nks >= D are the CALLER's contract; the prefetch past the
+// end re-reads the last k-step (clamped address, never multiplied) and the last LDS write fills a slot nobody reads.
+// (element-wise: an aggregate copy out of the register ring makes the compiler keep the whole ring in scratch)
+__device__ __forceinline__ void st16_lds(unsigned char* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void st16_lds(unsigned char* p, const float4& v) { *reinterpret_cast<float4*>(p) = make_float4(v.x, v.y, v.z, v.w); }
+constexpr int kTallRwMT = 2;      // m-tiles per wave (32 rows; 128 rows per workgroup)
+constexpr int kTallRwD = 8;       // k-steps in flight per wave
+constexpr int tall_rw_lds_bytes(int G) { return 2 * G * 1024; }
+
+// (A / W deliberately NOT __restrict__, here and in the calling kernels: loads from a noalias read-only pointer may be moved
+// across the compiler fences below, and the compiler then sinks the prologue's A loads behind the first barrier -- two serial
+// memory round trips before the first MFMA instead of one)
+// ``prefetch()`` is called once, BEHIND the ring's first D k-steps of loads and in front of the loop: the place for the caller's
+// epilogue operands (loads return in order: requested first they would hold up k-step 0, requested here they land while the
+// first D k-steps are being multiplied).
+template <typename T, int G, bool LN, bool WNT, int MT, int D, class Prefetch>
+__device__ __forceinline__ void tall_core_rw(const T* A, const T* W, const int (&nb)[G], int nks,
+                                             int mtile0, bool wave_on, unsigned char* s_w, f32x4 (&acc)[G][MT],
+                                             float (&rs1)[MT][4], float (&rs2)[MT][4], Prefetch&& prefetch) {
+    using F = Frag<T>;
+    static_assert(G == 4 || G == 5, "four shared weight fragments per k-step (one per wave), optionally a fifth fetched in quarters");
+    const int lane = threadIdx.x & 63;
+    const int w = wave_uniform(threadIdx.x >> 6);
+    const int64_t fstr = 64 * F::KL;                        // elements per fragment (1 KiB)
+    const int mt_src = wave_on ? mtile0 : 0;
+    const T* ap[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) ap[mt] = A + ((int64_t)(mt_src + mt) * nks * 64 + lane) * F::KL;
+    const int wb = w == 0 ? nb[0] : w == 1 ? nb[1] : w == 2 ? nb[2] : nb[3];
+    const T* wp = W + ((int64_t)wb * nks * 64 + lane) * F::KL;
+    // quarter w of the fifth fragment: 4 bytes per lane
+    const float* xp = reinterpret_cast<const float*>(W + (int64_t)nb[G - 1] * nks * fstr) + 64 * w + lane;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[g][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 st1[MT], st2[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { st1[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; st2[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    F f_ones;
+    f_ones.ones();
+    F fa[D][MT], fw[D];
+    float fx[D];
+    auto load = [&](int slot, int ks) {                     // (slot: a compile-time constant after unrolling)
+        const int kc = ks < nks ? ks : nks - 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fa[slot][mt].load(ap[mt] + (int64_t)kc * fstr);
+        fw[slot].template load_stream<WNT>(wp + (int64_t)kc * fstr);
+        if (G == 5) fx[slot] = WNT ? ld_nt1(xp + (int64_t)kc * 256) : xp[(int64_t)kc * 256];
+    };
+    auto put = [&](int slot, int lds_slot) {                // this wave's share of a k-step's weight fragments -> LDS
+        st16_lds(s_w + (lds_slot * G + w) * 1024 + 16 * lane, fw[slot].v);
+        if (G == 5) *reinterpret_cast<float*>(s_w + (lds_slot * G + 4) * 1024 + 256 * w + 4 * lane) = fx[slot];
+    };
+    auto step = [&](int d, int ks) {                        // one k-step; ring slot d == ks % D
+        put((d + 1) % D, (ks + 1) & 1);
+        F fb[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) frag_from_lds<T>(fb[g], s_w + ((ks & 1) * G + g) * 1024, lane);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (LN) {
+                st1[mt] = F::mma(fa[d][mt], f_ones, st1[mt]);       // row sums (every column)
+                st2[mt] = F::mma(fa[d][mt], fa[d][mt], st2[mt]);    // Gram matrix: the diagonal holds sum a^2
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g][mt] = F::mma(fa[d][mt], fb[g], acc[g][mt]);
+        }
+        load(d, ks + D);                                    // refill the slot just consumed
+        lds_barrier();                                      // slot (ks + 1) & 1 is complete; slot ks & 1 has been read by all
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        load(d, d);
+        cfence();                                           // in k order: the first LDS write waits for k-step 0 only, not for the whole ring
+    }
+    prefetch();
+    cfence();
+    put(0, 0);
+    lds_barrier();
+    for (int k0 = 0; k0 < nks; k0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) step(d, k0 + d);
+    }
+    __syncthreads();                                        // (also drains the prefetch past the end)
+    const int lg = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rs1[mt][r] = LN ? st1[mt][r] : 0.f;
+            rs2[mt][r] = LN ? shfl(st2[mt][r], 16 * lg + 4 * lg + r) : 0.f;
+        }
+}
+
 // shape of a tall workgroup by variant: 0 = LDS ring (4 waves x 32 rows), 1 = register ring (1 wave x 64 rows)
 template <int V> struct TallShape {
     static constexpr int MTW = V == 1 ? kTallRegMT : kTallMTW, NWV = V == 1 ? 1 : kTallNWV, ROWS = 16 * MTW * NWV;

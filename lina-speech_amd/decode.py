@@ -570,10 +570,16 @@ class DecodeEngine:
         if n_sampled == 0:
             k, temp = 1, 1.0
         key = (n_sampled, int(k), float(temp), bool(log_att), packed, fused_pick, 0 if fused_pick else int(seed))
-        loop = self._loops.get(key)
+        loop = self._loops.pop(key, None)
         if loop is None or loop.cap < max_steps:
+            # a configuration owns its logs (att log: B x 2 x cap x T_txt, ~134 MB at B = 512) and two hipGraphs; callers that
+            # sweep k / temp (captured kernel arguments) or, on the unfused pick path, the seed would otherwise grow the set
+            # without bound: keep the MAX_LOOPS most recently used (dropped here, outside any stream capture)
+            loop = None
+            while len(self._loops) >= self.MAX_LOOPS:
+                self._loops.pop(next(iter(self._loops)))
             loop = self._build_loop(key, max_steps, lazy)
-            self._loops[key] = loop
+        self._loops[key] = loop                              # most recently used last
         self._loop = loop
         self._loop_packed = packed
         self._lazy_live = lazy
@@ -673,6 +679,22 @@ class DecodeEngine:
             L.graph1 = g
         return L
 
+    MAX_LOOPS = 4            # captured loop configurations kept per engine (least recently used dropped first)
+
+    def close(self):
+        """Release the engine's device memory and hipGraphs now.  An engine is a reference cycle (its loop bodies close over
+        it), so dropping the last reference frees nothing until a later pass of Python's cyclic collector -- at B = 512 that
+        is ~7 GB of state and logs lingering after a cache eviction.  The engine is unusable afterwards."""
+        for L in self._loops.values():
+            L.body = L.graph1 = L.graphN = L.att = L.tok_log = L.att_log = L.ctl = None
+        self._loops.clear()
+        self._loop = self._graph = self._att_direct = None
+        for part in self.parts:
+            part.packs = []
+        self.parts, self.packs, self._state = [], [], None
+        self._kk = self._vv = self._logits = self._att = self._y_in = None
+        self.model = None
+
     # names older callers / tests look at
     @property
     def _greedy_graph(self):
@@ -747,12 +769,12 @@ class DecodeEngine:
 
     def greedy_tokens(self):
         """Tokens produced so far: [Q,B,n]."""
-        return self._loop.tok_log[:self._n_done].permute(1, 2, 0).contiguous()
+        return self._loop.tok_log[:self._n_done].permute(1, 2, 0).clone(memory_format=torch.contiguous_format)
 
     def logged_atts(self, n: Optional[int] = None):
         """The attention log of a loop armed with ``log_att``: [B,2,n,Ttxt]."""
         n = self._n_done if n is None else n
-        return self._loop.att_log[:, :, :n].contiguous()
+        return self._loop.att_log[:, :, :n].clone(memory_format=torch.contiguous_format)   # never the static log itself (n == cap)
 
     # ------------------------------------------------------------------ engine reuse
     def reset(self, x_enc: Optional[torch.Tensor] = None, state: Optional[Cache] = None):
@@ -831,8 +853,10 @@ class DecodeEngine:
             if stop_at < 0:
                 stop_at = self.stop_step()
             n = min(stop_at + 1, t0 + done) if stop_at >= 0 else t0 + done
-        qs = L.tok_log[:n].permute(1, 2, 0).contiguous()
-        atts = L.att_log[:, :, :n].contiguous() if L.att_log is not None else None
+        # fresh tensors, like the reference's: `.contiguous()` is a no-op -- i.e. a view of the engine's static log that the next
+        # call on the cached engine overwrites -- whenever n == cap (max_seqlen a multiple of 64 and no early stop)
+        qs = L.tok_log[:n].permute(1, 2, 0).clone(memory_format=torch.contiguous_format)
+        atts = L.att_log[:, :, :n].clone(memory_format=torch.contiguous_format) if L.att_log is not None else None
         return qs, atts, n
 
     def poll_stop(self, slot: int):
@@ -886,6 +910,11 @@ class DecodeEngineGroup:
         self.Q, self.Tn = self.engines[0].Q, self.engines[0].Tn
         self.streams = ([torch.cuda.Stream(device=self.dev) for _ in self.engines] if self.dev.type == "cuda" else None)
         self._n_done = 0
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+        self.engines = []
 
     def _each(self, fn):
         """fn(engine, lo, hi) for every engine, each on its own stream (forked from / before the caller's current stream)."""

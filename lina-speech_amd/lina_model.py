@@ -86,22 +86,32 @@ class LinaModel(nn.Module):
         return st
 
     def clear_decode_cache(self):
-        """Drop the cached decode engines (packed weights, static buffers, captured hipGraphs).  The cache is keyed on
-        every parameter's (storage, version), so optimizer steps and ``load_state_dict`` invalidate it by themselves;
-        writes through ``param.data`` (and in-place writes to parameters created under ``torch.inference_mode``, which
-        have no version counter) do not show up in the key -- call this after them."""
-        self.__dict__.pop("_decode_engines", None)
-        import gc
-        gc.collect()                      # engines are reference cycles: destroy their graphs / buffers now, not at some later point
+        """Drop the cached decode engines (packed weights, static buffers, captured hipGraphs) NOW.  Not needed for
+        correctness: the cache key carries a content fingerprint of every parameter (``_weights_fingerprint``), so any
+        change of the weights -- optimizer steps, ``load_state_dict``, writes through ``param.data``, in-place writes to
+        inference-mode parameters -- builds a new engine by itself."""
+        for eng in self.__dict__.pop("_decode_engines", {}).values():
+            eng.close()
+
+    def _weights_fingerprint(self):
+        """Per-parameter L2 norms (one multi-tensor kernel + one 4-byte-per-parameter read-back, ~0.3 ms for L169): a
+        (storage, version) key alone does not see ``param.data`` writes (EMA swaps) or in-place writes to parameters made
+        under ``torch.inference_mode`` (no version counter), and a stale engine would silently decode with the old
+        packed weights."""
+        ps = [p.detach() for p in self.parameters()]
+        if not ps:
+            return ()
+        return tuple(torch.stack(torch._foreach_norm(ps)).float().cpu().tolist())
 
     def _decode_engine(self, x_enc: Tensor, B: int, init_state, n_engines: int = 1):
         """The DecodeEngine of (batch size, text length, dtype, device, current weights), built once and re-armed for
         every later ``generate_batch`` call of the same shape: construction packs 0.3 GB of weights and captures two
-        hipGraphs (~0.6 k kernel nodes), far more than a call at B = 64 should pay."""
+        hipGraphs (~0.6 k kernel nodes), far more than a call at B = 64 should pay.  "Current weights" = every
+        parameter's storage address AND a content fingerprint (see ``_weights_fingerprint``)."""
         from .decode import DecodeEngine, DecodeEngineGroup
         w = self.logits_head.weight
         key = (B, int(n_engines), int(x_enc.shape[1]), w.dtype, str(w.device),
-               tuple((p.data_ptr(), -1 if p.is_inference() else p._version) for p in self.parameters()))
+               tuple(p.data_ptr() for p in self.parameters()), self._weights_fingerprint())
         cache = self.__dict__.setdefault("_decode_engines", {})
         eng = cache.pop(key, None)
         if eng is None:
@@ -117,7 +127,7 @@ class LinaModel(nn.Module):
             eng.reset(x_enc, state=init_state)
         cache[key] = eng                                             # most recently used last
         while len(cache) > self._ENGINE_CACHE_SIZE:
-            cache.pop(next(iter(cache)))
+            cache.pop(next(iter(cache))).close()                     # an engine is a reference cycle: free its device memory now
         return eng
 
     @torch.inference_mode()

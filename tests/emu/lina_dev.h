@@ -312,6 +312,9 @@ static inline void opaque(int& x) { asm volatile("" : "+r"(x)); }
 
 static inline float4 ld_nt4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static inline void st_nt4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+static inline void opaque_raw(uint2&) {}
+static inline void opaque_raw(uint4&) {}
+static inline void opaque_raw(float4&) {}
 static inline uint4 ld_nt16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 static inline float ld_nt1(const float* p) { return *p; }
 static inline void st_nt1(float* p, float v) { *p = v; }

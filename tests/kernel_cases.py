@@ -1143,7 +1143,7 @@ def check_linear_tall(dev, M, N, K, dtype, ln=False, bias=False, resid=False, sw
     assert torch.equal(ops.unpack_rows(out_p, M, Np)[:, :N], out), "tall: packed output copy differs"
 
 
-def check_inproj_tall(dev, B, K, Kd, Vd, dtype, force=True, variant=None):
+def check_inproj_tall(dev, B, K, Kd, Vd, dtype, force=True, variant=None, same_as_variant=None):
     """The tall tiling of the fused input side of a mixer (gla_inproj_tall_kernel: B >= 128) against the 64-row kernel on the
     same operands: q | k | v (conv step + SiLU), g, the gate (rank-16 up-projection + log-sigmoid) and the rolled conv caches
     -- another summation order of the same products (no split-K), so equal to fp32 rounding of the partial sums.  The 64-row
@@ -1187,6 +1187,24 @@ def check_inproj_tall(dev, B, K, Kd, Vd, dtype, force=True, variant=None):
     # the cache roll itself is exact: three old taps move up unchanged
     for a, c0 in zip(outs[1][3:], caches):
         assert torch.equal(a[..., :3], c0[..., 1:]), "tall in-projection: the rolled cache taps changed"
+    if same_as_variant is not None:
+        # two variants of the tall launch that add the same products in the same order (e.g. the 128-row kernel with the gate
+        # folded in, variant 3, against the 64-row kernel with gate workgroups, variant 0): bit-identical outputs
+        try:
+            os.environ["LINA_TALL_V"], os.environ["LINA_TALL"] = str(same_as_variant), "1"
+            cq, ck, cv = (c.clone() for c in caches)
+            qkv, go = torch.empty(B, 2 * Kd + Vd, dtype=dtype, device=dev), torch.empty(B, Vd, dtype=dtype, device=dev)
+            gk = torch.empty(B, Kd, dtype=torch.float32, device=dev)
+            ops.gla_decode_inproj_packed(x_p, w_p, B, K, c1, c2, wq, wk, wv, cq, ck, cv, w2, b2, qkv, go, gk,
+                                         clamp_min=-0.03 if Kd == 128 else None)
+        finally:
+            for name, old in (("LINA_TALL", prev), ("LINA_TALL_V", prev_v)):
+                if old is None:
+                    os.environ.pop(name, None)
+                else:
+                    os.environ[name] = old
+        for name, a, b in zip(("qkv", "g", "gk", "cq", "ck", "cv"), outs[1], (qkv, go, gk, cq, ck, cv)):
+            assert torch.equal(a, b), f"tall in-projection: {name} of variant {variant} != variant {same_as_variant}"
 
 
 def _skinny_waves(K, kq):

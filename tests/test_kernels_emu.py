@@ -256,10 +256,15 @@ def test_linear_tall(emu, variant, case):
 
 @pytest.mark.parametrize("B,K,Kd,Vd,dtype,variant", [(130, 96, 64, 128, torch.bfloat16, 0), (70, 160, 128, 64, torch.bfloat16, 0),
                                                      (129, 48, 64, 64, torch.float32, 0), (70, 160, 128, 64, torch.bfloat16, 1),
-                                                     (129, 48, 64, 64, torch.float32, 2)])
+                                                     (129, 48, 64, 64, torch.float32, 2),
+                                                     # variant 3 (128-row workgroups, gate folded in; K = whole groups of 8 k-steps):
+                                                     # ragged gate-channel shares (64 channels over 6 column blocks), a row block
+                                                     # with idle waves, two groups of k-steps
+                                                     (130, 256, 64, 128, torch.bfloat16, 3), (70, 512, 128, 64, torch.bfloat16, 3),
+                                                     (200, 128, 64, 64, torch.float32, 3)])
 def test_inproj_tall(emu, B, K, Kd, Vd, dtype, variant):
     from kernel_cases import check_inproj_tall
-    check_inproj_tall(DEV, B, K, Kd, Vd, dtype, variant=variant)
+    check_inproj_tall(DEV, B, K, Kd, Vd, dtype, variant=variant, same_as_variant=0 if variant == 3 else None)
 
 
 @pytest.mark.parametrize("Q,L,d,dtype,sampled", [(1, 70, 32, torch.float32, False), (3, 70, 32, torch.bfloat16, False),
