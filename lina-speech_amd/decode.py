@@ -187,10 +187,10 @@ class _Part:
 
 class _Loop:
     """One captured configuration of the device-side decode loop: its logs, control block and hipGraphs."""
-    __slots__ = ("cap", "tok_log", "att_log", "att_direct", "ctl", "body", "graph1", "graphN", "att")
+    __slots__ = ("cap", "tok_log", "att_log", "att_direct", "ctl", "body", "graph1", "graphN", "att", "hid_log")
 
     def __init__(self):
-        self.cap, self.tok_log, self.att_log, self.att_direct, self.ctl = 0, None, None, False, None
+        self.cap, self.tok_log, self.att_log, self.att_direct, self.ctl, self.hid_log = 0, None, None, False, None, None
         self.body = self.graph1 = self.graphN = self.att = None
 
 
@@ -543,13 +543,17 @@ class DecodeEngine:
 
     # ------------------------------------------------------------------ fully device-side decode loop
     def begin_greedy(self, max_steps: int, y0: Optional[torch.Tensor] = None, k: int = 1, temp: float = 1.0,
-                     seed: int = 0, first_greedy_quant: int = 0, log_att: bool = False, t0: int = 0):
+                     seed: int = 0, first_greedy_quant: int = 0, log_att: bool = False, t0: int = 0,
+                     log_hidden: bool = False):
         """Arm the device-side decode loop: token picks, the stop bookkeeping, the next-token embedding (K6a), the token
         log and -- with ``log_att`` -- the attention log are part of the captured step, so one token == one graph replay
         and nothing is read back until ``greedy_tokens()``.  Quantizers ``i < first_greedy_quant`` are SAMPLED (top-``k``,
         temperature ``temp``, K6c with uniforms hashed from (seed, device step counter, row)) like the reference's
         default generation mode (modeling_lina.py:159-164); the others -- all of them by default -- take the arg-max
-        (K6b).  ``t0``: the step index the loop starts at (a prompt prefill has produced steps 0 .. t0-1; ``preload``
+        (K6b).  ``log_hidden`` (parity tests): the residual stream the codec head reads -- the pre-head hidden state [B,d] of
+        every step -- is filed in a log as well (one more copy per token; ``logged_hidden()``): a check on it is sensitive to
+        recurrent-state error where the logits of a peaked head are dominated by the embedding -> head shortcut.
+        ``t0``: the step index the loop starts at (a prompt prefill has produced steps 0 .. t0-1; ``preload``
         puts their tokens / attention rows into the logs).  The recurrent state is NOT reset (``reset()`` does that).
 
         A configuration (sampling mode, att log, operand layout) is captured ONCE per engine and kept (``self._loops``):
@@ -569,7 +573,8 @@ class DecodeEngine:
                   and all(P.packed for P in self.packs) and self._packed_ok)
         if n_sampled == 0:
             k, temp = 1, 1.0
-        key = (n_sampled, int(k), float(temp), bool(log_att), packed, fused_pick, 0 if fused_pick else int(seed))
+        key = (n_sampled, int(k), float(temp), bool(log_att), packed, fused_pick, 0 if fused_pick else int(seed),
+               bool(log_hidden))
         loop = self._loops.pop(key, None)
         if loop is None or loop.cap < max_steps:
             # a configuration owns its logs (att log: B x 2 x cap x T_txt, ~134 MB at B = 512) and two hipGraphs; callers that
@@ -600,7 +605,7 @@ class DecodeEngine:
         return self.parts[0].x if len(self.parts) == 1 else self._y_in
 
     def _build_loop(self, key, max_steps: int, lazy: bool):
-        n_sampled, k, temp, log_att, packed, fused_pick, seed = key
+        n_sampled, k, temp, log_att, packed, fused_pick, seed, log_hidden = key
         emb = self.model.rvq_embed
         L = _Loop()
         L.cap = (max(int(max_steps), 1) + 63) // 64 * 64
@@ -611,6 +616,11 @@ class DecodeEngine:
         # the two cross-attention launches of the default step write their rows straight into the log at the device step
         # index; the other forms of the step write the engine's static [B,2,1,Ttxt] buffer and one index_copy_ files it
         L.att_direct = bool(log_att and self._cross_spread and self._cross_tail_fused and self.d % 256 == 0)
+        if log_hidden:
+            if len(self.parts) != 1:
+                raise ValueError("log_hidden needs the engine on one row range")
+            hid_src = self.parts[0].x_p if packed else self.parts[0].x      # the operand of the head projection
+            L.hid_log = torch.zeros(L.cap, hid_src.numel(), dtype=hid_src.dtype, device=self.dev)
         is_sampled = (torch.arange(self.Q, device=self.dev) < n_sampled).unsqueeze(0)        # [1,Q]
         y_buf = self._loop_input()
         R = ops.LOOP_CTL_ROWS
@@ -623,6 +633,8 @@ class DecodeEngine:
                 self._att_direct = None
             if L.att_log is not None and not L.att_direct:
                 L.att_log.index_copy_(2, self._t_idx, att)
+            if L.hid_log is not None:          # before the token epilogue overwrites the stream with the next token's embedding
+                L.hid_log.index_copy_(0, self._t_idx, (self.parts[0].x_p if packed else self.parts[0].x).reshape(1, -1))
             lg = logits.view(self.B, self.Q, self.L)
             if n_sampled == 0 and self.Q <= 16:
                 # K6d: picks, token log, stop flags, next-token embedding and the step counter in ONE launch
@@ -686,7 +698,7 @@ class DecodeEngine:
         it), so dropping the last reference frees nothing until a later pass of Python's cyclic collector -- at B = 512 that
         is ~7 GB of state and logs lingering after a cache eviction.  The engine is unusable afterwards."""
         for L in self._loops.values():
-            L.body = L.graph1 = L.graphN = L.att = L.tok_log = L.att_log = L.ctl = None
+            L.body = L.graph1 = L.graphN = L.att = L.tok_log = L.att_log = L.ctl = L.hid_log = None
         self._loops.clear()
         self._loop = self._graph = self._att_direct = None
         for part in self.parts:
@@ -775,6 +787,14 @@ class DecodeEngine:
         """The attention log of a loop armed with ``log_att``: [B,2,n,Ttxt]."""
         n = self._n_done if n is None else n
         return self._loop.att_log[:, :, :n].clone(memory_format=torch.contiguous_format)   # never the static log itself (n == cap)
+
+    def logged_hidden(self, n: Optional[int] = None):
+        """The pre-head hidden states of a loop armed with ``log_hidden``: [n, B, d] (row-major, whatever the loop's layout)."""
+        n = self._n_done if n is None else n
+        L = self._loop
+        if self._loop_packed:
+            return torch.stack([ops.unpack_rows(L.hid_log[t], self.B, self.d) for t in range(n)])
+        return L.hid_log[:n].view(n, self.B, self.d).clone()
 
     # ------------------------------------------------------------------ engine reuse
     def reset(self, x_enc: Optional[torch.Tensor] = None, state: Optional[Cache] = None):

@@ -94,14 +94,15 @@ class LinaModel(nn.Module):
             eng.close()
 
     def _weights_fingerprint(self):
-        """Per-parameter L2 norms (one multi-tensor kernel + one 4-byte-per-parameter read-back, ~0.3 ms for L169): a
-        (storage, version) key alone does not see ``param.data`` writes (EMA swaps) or in-place writes to parameters made
-        under ``torch.inference_mode`` (no version counter), and a stale engine would silently decode with the old
-        packed weights."""
+        """Two numbers per parameter -- the L2 norm of the tensor and of its positive part (the second one tells a sign flip
+        apart) -- from three multi-tensor kernels and one 8-byte-per-parameter read-back (~0.5 ms for L169): a (storage,
+        version) key alone does not see ``param.data`` writes (EMA swaps) or in-place writes to parameters made under
+        ``torch.inference_mode`` (no version counter), and a stale engine would silently decode with the old packed weights."""
         ps = [p.detach() for p in self.parameters()]
         if not ps:
             return ()
-        return tuple(torch.stack(torch._foreach_norm(ps)).float().cpu().tolist())
+        stats = torch._foreach_norm(ps) + torch._foreach_norm(torch._foreach_clamp_min(ps, 0))
+        return tuple(torch.stack(stats).float().cpu().tolist())
 
     def _decode_engine(self, x_enc: Tensor, B: int, init_state, n_engines: int = 1):
         """The DecodeEngine of (batch size, text length, dtype, device, current weights), built once and re-armed for

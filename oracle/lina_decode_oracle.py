@@ -132,6 +132,7 @@ class OracleLina:
         for i in range(n, 2 * n):
             y = self.block(y, self._block_prefix(i), state[i])
         W = self.sd["logits_head.weight"]                           # [q,l,d]
+        self.last_hidden = y                                        # what the head reads (tests compare it as well as the logits)
         return torch.einsum("bnd,qld->bnql", y, W), att
 
     def embed(self, tok):                                           # tok [q,B,n] -> [B,n,d]
@@ -147,8 +148,10 @@ class OracleLina:
         state = self.init_state(B)
         y = self.embed(torch.ones(self.n_quant, B, 1, dtype=torch.long))
         toks, logits_all, atts, margins = [], [], [], []
+        self.hiddens = []                                           # pre-head hidden state of every step, [B,1,d] each
         for t in range(n_steps):
             logits, att = self.step(y, x_enc, state)
+            self.hiddens.append(self.last_hidden)
             pick = O.argmax_lowest(logits[:, 0].transpose(0, 1)).unsqueeze(-1)        # [q,B,1]
             top2 = logits[:, 0, 0].float().topk(2, dim=-1).values
             margins.append(top2[:, 0] - top2[:, 1])

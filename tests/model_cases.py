@@ -288,6 +288,84 @@ def check_generate_batch_group(dev, rel=REL):
     assert torch.equal(a[0], b[0])
 
 
+def check_generate_batch_outputs_are_fresh(dev):
+    """(1) the tensors a ``generate_batch`` call returns are the caller's -- not views of the cached engine's static
+    logs, which the next call of the same shape overwrites (the case that bit: max_seqlen a multiple of 64 and no early stop, where
+    the trimmed log IS the whole log); (2) a write through ``param.data`` (an EMA swap) is seen by the engine cache key (content
+    fingerprint), so the next call decodes with the new weights; (3) the per-engine set of captured loop configurations stays
+    bounded when a caller sweeps the temperature."""
+    from lina_speech_amd.decode import DecodeEngine
+    g = load_golden("lina_d64.npz")
+    model = build_lina()
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    model = model.to(dev).eval()
+    B, n = 2, 64
+    kw = dict(batch_size=B, max_seqlen=n, k=1, first_greedy_quant=0, device=dev, force_max_seqlen=True)
+    xa = torch.randint(3, 256, (B, 9), generator=torch.Generator().manual_seed(11)).to(dev)
+    xb = torch.randint(3, 256, (B, 9), generator=torch.Generator().manual_seed(12)).to(dev)
+    a = model.generate_batch(xa, **kw)
+    eng = next(reversed(model._decode_engines.values()))
+    assert isinstance(eng, DecodeEngine) and eng._loop.cap == n
+    assert a[1].data_ptr() != eng._loop.att_log.data_ptr(), "generate_batch returned the engine's static attention log"
+    keep = [t.clone() for t in (a[0], a[1], a[2])] + [c[1].clone() for c in a[3]]
+    # same shape: the cached engine is re-armed and overwrites its logs (the emulator is slow: 8 steps there -- the first 8 log
+    # entries are rewritten all the same)
+    kw2 = kw if dev != "cpu" else {**kw, "max_seqlen": 8}
+    b = model.generate_batch(xb, **kw2)
+    assert next(reversed(model._decode_engines.values())) is eng
+    assert not torch.equal(b[1][:, :, :8], keep[1][:, :, :8])
+    for was, now in zip(keep, [a[0], a[1], a[2]] + [c[1] for c in a[3]]):
+        assert torch.equal(was, now), "a later generate_batch call changed the tensors an earlier one returned"
+    # (2) EMA-style swap through param.data: neither the storage nor the version counter changes
+    with torch.no_grad():
+        model.logits_head.weight.data.mul_(-1.0)
+    c = model.generate_batch(xb, **{**kw, "max_seqlen": 8})
+    assert next(reversed(model._decode_engines.values())) is not eng, "stale packed weights: the cache key missed a param.data write"
+    ref = model.generate_batch(xb, engine="module", **{**kw, "max_seqlen": 8})
+    assert torch.equal(c[0], ref[0])
+    with torch.no_grad():
+        model.logits_head.weight.data.mul_(-1.0)
+    # (3) bounded loop cache
+    with torch.inference_mode():
+        eng2 = DecodeEngine(model, model.txt_encoder(model.txt_embed(xa)), batch_size=B)
+        for t in range(DecodeEngine.MAX_LOOPS + 3):
+            eng2.begin_greedy(8, k=4, temp=1.0 + 0.1 * t, first_greedy_quant=1)
+            assert len(eng2._loops) <= DecodeEngine.MAX_LOOPS
+        eng2.close()
+    model.clear_decode_cache()
+    assert not model.__dict__.get("_decode_engines")
+
+
+def check_engine_hidden_log(dev, n=5):
+    """``begin_greedy(log_hidden=True)``: the pre-head hidden state filed by the device loop (fragment-major inside the loop)
+    == the residual stream the generic step API leaves behind when it is teacher-forced with the loop's tokens -- and the tokens
+    are the ones the loop decodes without the log.  (The GPU parity tests compare this log with the oracle's hidden states.)"""
+    from lina_speech_amd.decode import DecodeEngine
+    g = load_golden("lina_d64.npz")
+    model = build_lina()
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    model = model.to(dev).eval()
+    B = 3
+    x = torch.randint(3, 256, (B, 9), generator=torch.Generator().manual_seed(5)).to(dev)
+    with torch.inference_mode():
+        x_enc = model.txt_encoder(model.txt_embed(x))
+        eng = DecodeEngine(model, x_enc, batch_size=B)
+        plain = eng.run_greedy(n)
+        eng.reset()
+        eng.begin_greedy(n, log_hidden=True)
+        eng.greedy_steps(n)
+        toks, hid = eng.greedy_tokens(), eng.logged_hidden(n)
+        assert torch.equal(toks, plain) and hid.shape == (n, B, eng.d)
+        eng2 = DecodeEngine(model, x_enc, batch_size=B)
+        y = model.rvq_embed.embed_sum(torch.ones(eng.Q, B, 1, dtype=torch.long, device=dev))
+        for t in range(n):
+            logits, _ = eng2(y, t)
+            close(hid[t], eng2.parts[0].x.cpu(), f"hidden-state log, step {t}", 2e-5)
+            close(torch.einsum("bd,qld->bql", hid[t].float(), model.logits_head.weight.float()), logits[:, 0].float().cpu(),
+                  f"logits implied by the hidden-state log, step {t}", 2e-5)
+            y = model.rvq_embed.embed_sum(toks[:, :, t:t + 1])
+
+
 def check_generate_batch_early_stop(dev, dtype=torch.float32, d=256, B=8, max_seqlen=160, need_late_stop=True):
     """a-10, the early-stop path of the device loop over MANY stop checks (reference model/modeling_lina.py:168-173): a small
     vocabulary (13 codes + 3 specials) in the reference's default SAMPLED mode makes every row emit the stop token (id 2) at a

@@ -42,6 +42,16 @@ def test_generate_batch_default_is_the_device_loop(emu):
     check_generate_batch_loop("cpu", full=False)
 
 
+def test_generate_batch_outputs_are_fresh(emu):
+    from model_cases import check_generate_batch_outputs_are_fresh
+    check_generate_batch_outputs_are_fresh("cpu")
+
+
+def test_engine_hidden_state_log(emu):
+    from model_cases import check_engine_hidden_log
+    check_engine_hidden_log("cpu")
+
+
 def test_generate_batch_with_two_engines(emu):
     from model_cases import check_generate_batch_group
     check_generate_batch_group("cpu")
