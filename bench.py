@@ -758,6 +758,8 @@ def main():
                          "quoted on: strong scaling, 512 / N rows per GPU)")
     ap.add_argument("--batch-per-gpu", type=int, default=None,
                     help="instead of --total-batch: this many rows on EVERY GPU (weak scaling; 64 = BASELINE configs[1])")
+    ap.add_argument("--engines", type=int, default=0,
+                    help="engines (row ranges, one HIP stream each) per GPU; 0 = what generate_batch picks for the batch (2 from 512 rows up)")
     ap.add_argument("--window", type=int, default=None, help="state window of the decode loop (1 = immediate update K1d; default 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chunk", action="store_true")
@@ -798,22 +800,28 @@ def main():
 
     with torch.inference_mode():
         x_enc = model_dev.txt_encoder(model_dev.txt_embed(texts))
-        eng = DecodeEngine(model_dev, x_enc, batch_size=B, window=args.window)
+        # the loop LinaModel.generate_batch runs for this many rows: from LinaModel.AUTO_TWO_ENGINES_ROWS (512) rows up the batch is
+        # cut into two row ranges, one engine and one HIP stream each (decode.DecodeEngineGroup; --engines overrides)
+        n_eng = args.engines if args.engines else (2 if B >= model_dev.AUTO_TWO_ENGINES_ROWS else 1)
+        if n_eng > 1:
+            from lina_speech_amd.decode import DecodeEngineGroup
+            eng = DecodeEngineGroup(model_dev, x_enc, batch_size=B, n_engines=n_eng, window=args.window)
+            eng1 = eng.engines[0]                 # (attribute reads, and the engine the update kernel is timed in)
+        else:
+            eng = eng1 = DecodeEngine(model_dev, x_enc, batch_size=B, window=args.window)
         # settle the engine clock first (untimed, outside the W warm-up steps): the chip ramps up from idle over the first
         # fraction of a second of load
         t_pre = time.perf_counter()
         n_pre = 0
         while time.perf_counter() - t_pre < args.preheat_s or n_pre == 0:
             eng.begin_greedy(150, log_att=True)
-            for _ in range(100):
-                eng.greedy_step()
+            eng.greedy_steps(96)
             torch.cuda.synchronize()
-            n_pre += 100
+            n_pre += 96
         t_est = time.perf_counter()                                  # step time estimate on the captured graph
-        for _ in range(50):
-            eng.greedy_step()
+        eng.greedy_steps(48)
         torch.cuda.synchronize()
-        est = (time.perf_counter() - t_est) / 50
+        est = (time.perf_counter() - t_est) / 48
         k_run = max(args.steps, int(args.min_timed_s / est) + 1) if args.min_timed_s > 0 else args.steps
         k_sus = max(args.steps, int(SUSTAINED_S / est) + 1)
         if dist is not None:
@@ -823,8 +831,7 @@ def main():
         # the loop generate_batch runs: picks, stop flags, the attention log and the next-token embedding inside the step
         eng.begin_greedy(k_run + k_sus + args.warmup + 8, log_att=True)
         eng.greedy_steps(8)                                           # captures the multi-token graph (untimed)
-        for _ in range(args.warmup):
-            eng.greedy_step()
+        eng.greedy_steps(args.warmup)
         elapsed, k_run = timed_steps(lambda n: eng.greedy_steps(n), k_run, dist, dev, batched=True)
         ranks_ms = per_rank_ms(timed_steps.local_elapsed, k_run, dist, dev)
         el_sus, k_sus = timed_steps(lambda n: eng.greedy_steps(n), k_sus, dist, dev, batched=True)   # secondary figure
@@ -834,14 +841,14 @@ def main():
 
         out = None
         if rank == 0:
-            P = eng.packs[0]
-            k1_b2b, k1_entry = measure_k1(eng)                     # back to back with itself (conservative)
-            k1_dt, k1_n, ms_with, ms_without = eng.time_update_kernel()
+            P = eng1.packs[0]
+            k1_b2b, k1_entry = measure_k1(eng1)                    # back to back with itself (conservative)
+            k1_dt, k1_n, ms_with, ms_without = eng1.time_update_kernel()   # (two engines: in ONE engine's step graph, the other idle)
             e_io = 2 if dtype == torch.bfloat16 else 4
             k1_rows = P.S.shape[0]
             lazy = k1_entry == "lina_gla_decode_window"
             k1d_bytes = k1_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4)
-            k1_bytes = k1w_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4, eng.window) if lazy else k1d_bytes
+            k1_bytes = k1w_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4, eng1.window) if lazy else k1d_bytes
             traffic, traffic_src = None, None
             names = ("r05_k1w_traffic_b%d.json" % k1_rows, "r04_k1w_traffic.json", "r02_k1w_traffic.json") if lazy \
                 else ("r02_k1d_traffic.json", "r01_k1d_traffic.json")
@@ -861,13 +868,13 @@ def main():
                     "achieved": k1_bytes / k1_dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": k1_bytes / k1_dt / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": k1_bytes, "us_per_launch": k1_dt * 1e6, "rows_per_launch": k1_rows,
-                    "launches_per_step": len(eng.packs) * len(eng.parts),
+                    "launches_per_step": len(eng1.packs) * len(eng1.parts) * n_eng,
                     "timing": f"in situ: (step graph {ms_with:.4f} ms - the same graph without its {k1_n} update launches "
                               f"{ms_without:.4f} ms) / {k1_n}, HIP events around 160 replays each",
                     "us_per_launch_back_to_back": k1_b2b * 1e6,
                     "frac_back_to_back": k1_bytes / k1_b2b / 1e9 / HBM_PEAK_GBS}
             if lazy:
-                roof["window"] = eng.window
+                roof["window"] = eng1.window
                 roof["bytes_definition"] = ("state read every step + written every W-th (4 H Dk Dv (1 + 1/W)) + q,k,v,gk,o "
                                             "+ window history; averaged over the W window positions (DESIGN 4.1)")
                 roof["immediate_form"] = {"what": "SURVEY 8(d) bytes of the immediate update K1 (state read AND written "
@@ -877,7 +884,10 @@ def main():
             # the step as a whole against HBM: recurrent state read + written once per block, every decode-time weight
             # read once (the bytes the engine's packs actually hold), text-side K/V rows read once
             ms_step = elapsed / k_run * 1e3
-            s_bytes, w_bytes, kv_bytes, s_bytes_imm = step_hbm_bytes(eng)
+            engs = eng.engines if n_eng > 1 else [eng]
+            parts_b = [step_hbm_bytes(e_) for e_ in engs]
+            s_bytes, kv_bytes, s_bytes_imm = (sum(p_[i] for p_ in parts_b) for i in (0, 2, 3))
+            w_bytes = parts_b[0][1] * (n_eng if B < 256 else 1)      # (packed weights are shared; at a large batch the second engine's reads hit the Infinity Cache or not: priced ONCE)
             step_bytes = w_bytes + s_bytes + kv_bytes
             step_roof = {"what": "whole decode step vs HBM: state read (+ write every W-th step) + decode-time weights + text K/V, per step per GPU",
                          "immediate_form": {"what": "the same step priced with the state read AND written every token "
@@ -896,9 +906,10 @@ def main():
                 "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
                 "config": {"workload": f"L169 greedy codec-token decode, B_total={total_rows} ({B} rows on this GPU" + (", fixed per GPU" if weak else f" = B_total / {world}") + "), "
                                        f"T_txt={T_TXT}, H=4 Dk=Dv=256, 12+1 GLA blocks, fp32 recurrent state, "
-                                       f"{nparam / 1e6:.1f}M params, one hipGraph replay per {eng.GRAPH_STEPS} tokens, state window {eng.window}, "
-                                       f"{len(eng.parts)} parallel row ranges per GPU",
-                           "global_batch": total_rows, "rows_per_gpu": B,
+                                       f"{nparam / 1e6:.1f}M params, one hipGraph replay per {eng1.GRAPH_STEPS} tokens, state window {eng1.window}, "
+                                       + (f"{n_eng} engines of {B // n_eng} rows on {n_eng} HIP streams (shared packed weights)" if n_eng > 1
+                                          else "one engine"),
+                           "global_batch": total_rows, "rows_per_gpu": B, "engines_per_gpu": n_eng,
                            "loop": "the device loop LinaModel.generate_batch runs (picks, stop flags, attention log, next-token "
                                    "embedding inside the captured step)",
                            "parallelism": f"batch-shard x{world} (no collective)",
@@ -915,20 +926,18 @@ def main():
             # secondary, untimed-region measurements (rank 0 only): the default sampling mode of the reference
             # (top-k 100, temperature) through the same graph, K2 / K2b at the training shape
             if world == 1:
-                eng.begin_greedy(60, k=100, temp=1.0, seed=1, first_greedy_quant=1)
-                for _ in range(10):
-                    eng.greedy_step()
+                eng.begin_greedy(80, k=100, temp=1.0, seed=1, first_greedy_quant=1)
+                eng.greedy_steps(16)
                 torch.cuda.synchronize()
                 ts0 = time.perf_counter()
-                for _ in range(50):
-                    eng.greedy_step()
+                eng.greedy_steps(48)
                 torch.cuda.synchronize()
-                out["sampled_decode"] = {"k": 100, "temp": 1.0, "ms_per_step": (time.perf_counter() - ts0) / 50 * 1e3,
-                                         "tokens_per_s": B * 50 / (time.perf_counter() - ts0)}
+                out["sampled_decode"] = {"k": 100, "temp": 1.0, "ms_per_step": (time.perf_counter() - ts0) / 48 * 1e3,
+                                         "tokens_per_s": B * 48 / (time.perf_counter() - ts0)}
             per = {}
             if not args.no_chunk and world == 1 and dtype == torch.bfloat16:
                 for bb in (64, 128, 256, 512):                   # the same loop at the other per-GPU batches
-                    if bb == B:
+                    if bb == B and n_eng == 1:           # (two engines: the one-engine loop of the same rows stays beside the headline)
                         continue
                     try:
                         per[f"B={bb}"] = measure_batch(model_dev, dev, B=bb)
@@ -945,7 +954,7 @@ def main():
                     except Exception as e:
                         gb[f"B={bb}"] = {"error": repr(e)}
                 out["generate_batch"] = gb
-                if B >= 256:
+                if B >= 256 and n_eng == 1:
                     try:
                         out["two_engines"] = measure_two_engines(model_dev, texts, dev)
                     except Exception as e:
@@ -969,7 +978,8 @@ def main():
     if rank == 0:
         if world == 1 and dtype == torch.bfloat16 and not args.no_chunk:
             # other head shapes of the same width (the 169M hyper-parameters are inferred)
-            del eng
+            eng.close()
+            del eng, eng1
             torch.cuda.empty_cache()
             shapes = {}
             for heads, ev in ((8, 1.0), (16, 1.0), (4, 2.0)):

@@ -78,6 +78,10 @@ class LinaModel(nn.Module):
 
     # ------------------------------------------------------------------ batched decode
     _ENGINE_CACHE_SIZE = 2
+    # generate_batch(n_engines=None): from this many rows up the batch is decoded by TWO engines on two HIP streams (rows never
+    # interact -- reference modeling_lina.py:125,152-179; measured at L169: 512 rows 2.20 ms per token against 2.34 on one engine,
+    # 4 x 128 rows and every split of 64 rows slower: profiles/r05_two_engines.txt, r06_b64_engines.txt)
+    AUTO_TWO_ENGINES_ROWS = 512
 
     def __getstate__(self):
         """copy.deepcopy / pickling: the cached decode engines (hipGraphs, static buffers) stay with the original."""
@@ -135,7 +139,7 @@ class LinaModel(nn.Module):
     def generate_batch(self, x: Tensor, batch_size: int = 3, prompt: Optional[Tensor] = None, device: str = "cpu",
                        max_seqlen: int = 1000, k: int = 100, first_greedy_quant: int = 1, temp: float = 1.0,
                        init_state=None, force_max_seqlen: bool = False, stop_check_every: int = 16,
-                       engine: Optional[str] = None, seed: Optional[int] = None, n_engines: int = 1):
+                       engine: Optional[str] = None, seed: Optional[int] = None, n_engines: Optional[int] = None):
         """Reference model/modeling_lina.py:111-192 (same arguments, same four returns).  ``engine``:
           None / "auto" -- the device-side loop (decode.DecodeEngine.generate: one hipGraph replay per 8 tokens, picks /
                            stop flags / attention log / next-token embedding inside the graph) when the architecture is
@@ -143,7 +147,10 @@ class LinaModel(nn.Module):
           "loop"        -- the device-side loop or an error;   "fused" -- the fused step, one graph replay per token, picks
                            on the host side;   "module" -- ``AttentiveGLA.step`` + logits head per token (unfused).
         ``n_engines`` > 1 (device loop, no codec prompt, no init_state): the batch is cut into that many row ranges, one
-        engine and one HIP stream each (decode.DecodeEngineGroup: at B = 512 two engines decode 5 % faster than one).
+        engine and one HIP stream each (decode.DecodeEngineGroup: at B = 512 two engines decode 6-8 % faster than one: one
+        half's projections run under the other half's HBM-bound state update).  None (default): 2 from
+        ``AUTO_TWO_ENGINES_ROWS`` rows up, else 1.  Greedy tokens do not depend on it (rows never interact, every kernel's
+        per-row sums are independent of the row count); the sampled quantizers draw from a per-engine seed word.
         ``seed`` feeds the device-side sampler of the loop (default: drawn from torch's generator, so
         ``torch.manual_seed`` makes a call reproducible, like the reference's multinomial)."""
         B, Q = batch_size, self.n_quant
@@ -165,6 +172,8 @@ class LinaModel(nn.Module):
             raise ValueError("engine must be None, 'auto', 'loop', 'fused' or 'module'")
         eng = None
         if mode in ("auto", "loop"):
+            if n_engines is None:
+                n_engines = 2 if B >= self.AUTO_TWO_ENGINES_ROWS else 1
             n_eng = n_engines if (n_engines > 1 and prompt is None and init_state is None and B >= 2 * n_engines) else 1
             try:
                 eng = self._decode_engine(x_enc, B, init_state, n_eng)

@@ -265,6 +265,32 @@ def test_l169_bf16_engine_b64_free_running_vs_fp32_oracle(hip):
     assert torch.equal(toks[0][safe], ref_toks[0][safe]), "bf16 engine token != oracle arg-max at a clear margin"
 
 
+def test_generate_batch_picks_two_engines_at_512_rows_same_tokens(hip):
+    """The entry point's default at the metric's batch: from ``LinaModel.AUTO_TWO_ENGINES_ROWS`` rows up ``generate_batch`` runs
+    decode.DecodeEngineGroup (two engines of 256 rows on two HIP streams).  Rows never interact (reference
+    model/modeling_lina.py:125,152-179) and no kernel's per-row sums depend on the row count, so the greedy tokens, stop flags
+    and attention rows must be BIT-IDENTICAL to the one-engine loop of the same 512 rows (L169, bf16, peaked logits)."""
+    from lina_speech_amd.configs import l169
+    from lina_speech_amd.decode import DecodeEngine, DecodeEngineGroup
+    from model_cases import peak_logits
+    torch.manual_seed(0)
+    m = peak_logits(l169().eval()).to("cuda", torch.bfloat16)
+    B, n = m.AUTO_TWO_ENGINES_ROWS, 24
+    x = torch.randint(3, 256, (B, 24), generator=torch.Generator().manual_seed(21)).cuda()
+    kw = dict(batch_size=B, max_seqlen=n, k=1, first_greedy_quant=0, force_max_seqlen=True, device="cuda")
+    two = m.generate_batch(x, **kw)
+    grp = next(reversed(m._decode_engines.values()))
+    assert isinstance(grp, DecodeEngineGroup) and [hi - lo for lo, hi in grp.ranges] == [B // 2, B // 2]
+    one = m.generate_batch(x, n_engines=1, **kw)
+    assert isinstance(next(reversed(m._decode_engines.values())), DecodeEngine)
+    assert torch.equal(two[0], one[0]) and torch.equal(two[2], one[2]), "two engines decode other tokens than one"
+    assert torch.equal(two[1], one[1]), "attention rows differ between one and two engines"
+    assert int(one[0].unique().numel()) > 100                       # (rows decode different sequences)
+    m.generate_batch(x[:64], **{**kw, "batch_size": 64})
+    assert isinstance(next(reversed(m._decode_engines.values())), DecodeEngine)      # below the threshold: one engine
+    m.clear_decode_cache()
+
+
 def _oracle_threads():
     n = torch.get_num_threads()
     torch.set_num_threads(min(n, 32))            # small-op decode on a 256-thread host: more threads only add sync cost
