@@ -606,11 +606,11 @@ def step_hbm_bytes(eng):
     w_bytes = sum(t.numel() * t.element_size() for P_ in eng.packs for t in
                   (P_.w_in, P_.w_o, P_.w_up, P_.w_down)) + eng.w_head.numel() * eng.w_head.element_size() \
         + eng.ca_qw.numel() * eng.ca_qw.element_size()
-    s_bytes = int(sum((1.0 + 1.0 / (eng.window if P_.lazy else 1)) * P_.S.numel() * 4 for part in eng.parts
+    s_bytes = int(sum((1.0 + 1.0 / (eng.window if P_.lazy else 1)) * P_.S.numel() * P_.S.element_size() for part in eng.parts
                       for P_ in part.packs))
     kv_bytes = sum(part.kk.numel() * part.kk.element_size() + part.vv.numel() * part.vv.element_size()
                    for part in eng.parts)
-    s_bytes_imm = sum(2 * P_.S.numel() * 4 for part in eng.parts for P_ in part.packs)
+    s_bytes_imm = sum(2 * P_.S.numel() * P_.S.element_size() for part in eng.parts for P_ in part.packs)
     return s_bytes, w_bytes, kv_bytes, s_bytes_imm
 
 
@@ -646,6 +646,43 @@ def measure_batch(model_dev, dev, B=512, steps=120):
                               "frac": nb / dt / 1e9 / HBM_PEAK_GBS,
                               "immediate_form_frac": (w_b + s_imm + kv_b) / dt / 1e9 / HBM_PEAK_GBS},
             "max_mem_GB": mem}
+
+
+def measure_bf16_state(model_dev, texts, dev, steps=160):
+    """SECONDARY line (never `value`): the opt-in reference-dtype recurrent state, ``DecodeEngine(state_dtype=torch.bfloat16)``.
+    The reference keeps the state of a bf16 model in bf16 between decode steps (model/gla.py:229-240 + Cache.update: rounded
+    after every step); the product's default -- and the headline -- is an fp32 state.  window 1 = the reference's arithmetic
+    (state read AND written every token, 2 + 2 bytes per element); window 8 = bf16 storage rounded every 8th token (2 (1 + 1/8)
+    bytes per element per token: half of the fp32 K1w's).  One engine of all the rows."""
+    from lina_speech_amd.decode import DecodeEngine
+    B = texts.shape[0]
+    res = {"what": "opt-in bf16 recurrent state (the reference's state dtype for a bf16 model); secondary, the headline keeps fp32 state",
+           "batch": B}
+    with torch.inference_mode():
+        x_enc = model_dev.txt_encoder(model_dev.txt_embed(texts))
+        for window in (1, 8):
+            eng = DecodeEngine(model_dev, x_enc, batch_size=B, state_dtype=torch.bfloat16, window=window)
+            eng.begin_greedy(steps + 80, log_att=True)
+            eng.greedy_steps(64)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.greedy_steps(steps)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            toks = eng.greedy_tokens()
+            assert int(toks.min()) >= 0 and int(toks.max()) < 4099
+            s_b, w_b, kv_b, s_imm = step_hbm_bytes(eng)
+            nb = s_b + w_b + kv_b
+            res[f"window_{window}"] = {
+                "what": ("state rounded to bf16 after every token: the reference's own arithmetic for a bf16 model" if window == 1
+                         else "state stored in bf16, rounded every 8th token (K1w window)"),
+                "ms_per_step": dt * 1e3, "tokens_per_s": B / dt,
+                "step_roofline": {"state_bytes": s_b, "weight_bytes": w_b, "text_kv_bytes": kv_b, "bytes_per_step": nb, "bound": "hbm",
+                                  "achieved": nb / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nb / dt / 1e9 / HBM_PEAK_GBS}}
+            eng.close()
+            del eng
+            torch.cuda.empty_cache()
+    return res
 
 
 def measure_generate_batch(model_dev, texts, dev, loop_ms, max_seqlen=750):
@@ -959,6 +996,10 @@ def main():
                         out["two_engines"] = measure_two_engines(model_dev, texts, dev)
                     except Exception as e:
                         out["two_engines"] = {"error": repr(e)}
+                try:
+                    out["decode_bf16_state"] = measure_bf16_state(model_dev, texts, dev)
+                except Exception as e:
+                    out["decode_bf16_state"] = {"error": repr(e)}
             if not args.no_chunk and world == 1:
                 out["config3_pipeline"] = measure_config3(eng, dev, B)
                 out["chunk_kernel"] = measure_chunk(dev)

@@ -412,6 +412,23 @@ int lina_gla_decode_window(const void* q, const void* k, const void* v, const vo
                            int dtype, int g_dtype, float scale, lina_stream_t stream);
 int lina_gla_decode_window_flush(float* state, const float* hist_k, const float* hist_c, const float* hist_v,
                                  int n_pending, int B, int H, int Dk, int Dv, lina_stream_t stream);
+/* The same two entry points with the dtype of `state` as an argument (round 6, opt-in): LINA_F32 = the entries above;
+ * LINA_BF16 = a bf16 state [B,H,Dk,Dv] -- what the reference keeps between the decode steps of a bf16 model
+ * (model/gla.py:229-240: init_state allocates with param.new_zeros, Cache.update copy_-s the fp32 final state into it): read,
+ * updated in fp32 registers, rounded (nearest-even) when written back -- every step at window 1 (the reference's arithmetic),
+ * every window-th step otherwise.  bf16 state needs dtype == LINA_BF16; the window history stays fp32. */
+int lina_gla_decode_window_s(const void* q, const void* k, const void* v, const void* gk,
+                             void* state, int state_dtype, const void* gate, const void* norm_weight,
+                             void* og, float* o_exchange, int* counters,
+                             float* hist_k, float* hist_c, float* hist_v,
+                             const int64_t* step, const int64_t* origin, int window,
+                             int B, int H, int Dk, int Dv,
+                             int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
+                             int64_t v_sb, int64_t v_sh, int64_t g_sb, int64_t g_sh,
+                             int64_t gate_sb, int64_t gate_sh, float eps, int og_packed,
+                             int dtype, int g_dtype, float scale, lina_stream_t stream);
+int lina_gla_decode_window_flush_s(void* state, int state_dtype, const float* hist_k, const float* hist_c,
+                                   const float* hist_v, int n_pending, int B, int H, int Dk, int Dv, lina_stream_t stream);
 
 /* Decode-step projection with fused neighbours: out[M,N] = epi(A[M,K] . W[N,K]^T), M ~ batch rows.
  *   ln_dim > 0 : A is layer-normalised over its ln_dim features first, folded algebraically:

@@ -76,6 +76,8 @@ PROTOTYPES = {
     "lina_gla_decode_window_max": (C.c_int, []),
     "lina_gla_decode_window": (C.c_int, [_p] * 15 + [_i] * 5 + [_i64] * 10 + [_f, _i, _i, _i, _f, _p]),
     "lina_gla_decode_window_flush": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "lina_gla_decode_window_s": (C.c_int, [_p] * 5 + [_i] + [_p] * 10 + [_i] * 5 + [_i64] * 10 + [_f, _i, _i, _i, _f, _p]),
+    "lina_gla_decode_window_flush_s": (C.c_int, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "lina_linear_skinny_ex": (C.c_int, [_p, _i64, _p, _i64, _i, _i, _p, _p, _p, _i64, _p, _i64, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "lina_gla_decode_inproj_packed": (C.c_int, [_p] * 15 + [_i] * 6 + [_f, _f, _f, _i, _i, _p]),
     "lina_weighted_rows_add_packed": (C.c_int, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),

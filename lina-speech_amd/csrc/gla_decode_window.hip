@@ -59,9 +59,19 @@ __device__ __forceinline__ void st_hist(float* p, float v) {
 #endif
 }
 
-template <int DV, int NRB, int CS, typename TIO, typename TG>
+// Four consecutive state elements of a row: fp32 (the product's default) or bf16 -- the OPT-IN state dtype of round 6: the
+// reference keeps the recurrent state of a bf16 model in bf16 between decode steps (model/gla.py:229-240 `param.new_zeros` +
+// Cache.update's copy_): every step upcasts it, updates in fp32 and rounds the result back.  With a bf16 state the arithmetic
+// below is unchanged (fp32 registers); only what is read / written back differs -- at window 1 exactly the reference's
+// per-step rounding, at window W a rounding every W-th step.
+__device__ __forceinline__ float4 ld_state4(const float* p) { return LINA_K1W_STATE_LOAD(p); }
+__device__ __forceinline__ float4 ld_state4(const bf16_t* p) { return cvt4(ld_nt8(p)); }
+__device__ __forceinline__ void st_state4(float* p, float4 v) { st_nt4(p, v); }
+__device__ __forceinline__ void st_state4(bf16_t* p, float4 v) { st_nt8(p, make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w))); }
+
+template <int DV, int NRB, int CS, typename TIO, typename TG, typename TS = float>
 __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
-    const TIO* __restrict__ q, const TIO* __restrict__ k, const TIO* __restrict__ v, const TG* __restrict__ gk, float* S,
+    const TIO* __restrict__ q, const TIO* __restrict__ k, const TIO* __restrict__ v, const TG* __restrict__ gk, TS* S,
     float* hist_k, float* hist_c, float* hist_v, const int64_t* step, const int64_t* origin, int window, int flush_n,
     int H, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh, int64_t v_sb, int64_t v_sh, int64_t g_sb,
     int64_t g_sh, float scale, const TIO* __restrict__ gate, int64_t gate_sb, int64_t gate_sh,
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
     const int r0 = rb * RB;
     const int64_t BH = gridDim.x;
     const int col0 = CS > 1 ? (int)blockIdx.y * DV : 0;
-    float* tile = S + ((int64_t)bh * DK + r0) * DVT + col0 + 4 * cg;
+    TS* tile = S + ((int64_t)bh * DK + r0) * DVT + col0 + 4 * cg;
 
     // window position: workgroup-uniform.  flush_n >= 0: apply the first flush_n history entries to the state, no output
     const bool flush_only = flush_n >= 0;
@@ -127,7 +137,7 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
 
     float4 St[NP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) St[i] = LINA_K1W_STATE_LOAD(tile + (int64_t)(rg + RPI * i) * DVT);
+    for (int i = 0; i < NP; ++i) St[i] = ld_state4(tile + (int64_t)(rg + RPI * i) * DVT);
 
     // ---- per-row gate bookkeeping and the window's v rows
     if (row_wave) {
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
             }
         }
 #pragma unroll
-        for (int i = 0; i < NP; ++i) st_nt4(tile + (int64_t)(rg + RPI * i) * DVT, St[i]);
+        for (int i = 0; i < NP; ++i) st_state4(tile + (int64_t)(rg + RPI * i) * DVT, St[i]);
         if (flush_only) return;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -302,8 +312,8 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
     }
 }
 
-template <typename TIO, typename TG>
-static int launch_window(const void* q, const void* k, const void* v, const void* gk, float* S, float* hk, float* hc,
+template <typename TIO, typename TG, typename TS = float>
+static int launch_window(const void* q, const void* k, const void* v, const void* gk, TS* S, float* hk, float* hc,
                          float* hv, const int64_t* step, const int64_t* origin, int window, int flush_n, int B, int H,
                          int Dk, int Dv, const int64_t* st, float scale, lina_stream_t stream, const void* gate,
                          int64_t gate_sb, int64_t gate_sh, const void* nw, float eps, void* og, int og_packed = 0,
@@ -311,7 +321,7 @@ static int launch_window(const void* q, const void* k, const void* v, const void
     const int cs = Dv == 512 ? 2 : 1;                        // column splits: one workgroup streams <= 256 columns
     dim3 grid((unsigned)(B * H), (unsigned)cs);
 #define LINA_WIN_ONE(DVV, NRBB, CSS)                                                                                   \
-    LINA_LAUNCH((gla_decode_window_kernel<DVV, NRBB, CSS, TIO, TG>), grid, dim3(256 * NRBB), 0, stream, (const TIO*)q, \
+    LINA_LAUNCH((gla_decode_window_kernel<DVV, NRBB, CSS, TIO, TG, TS>), grid, dim3(256 * NRBB), 0, stream, (const TIO*)q, \
                 (const TIO*)k, (const TIO*)v, (const TG*)gk, S, hk, hc, hv, step, origin, window, flush_n, H, st[0],   \
                 st[1], st[2], st[3], st[4], st[5], st[6], st[7], scale, (const TIO*)gate, gate_sb, gate_sh,            \
                 (const TIO*)nw, eps, (TIO*)og, og_packed, o_x, counters)
@@ -381,4 +391,55 @@ extern "C" int lina_gla_decode_window_flush(float* state, const float* hist_k, c
     return launch_window<float, float>(nullptr, nullptr, nullptr, nullptr, state, (float*)hist_k, (float*)hist_c,
                                        (float*)hist_v, nullptr, nullptr, kWinMax, n_pending, B, H, Dk, Dv, st, 1.0f, stream,
                                        nullptr, 0, 0, nullptr, 0.f, nullptr);
+}
+
+// ---- opt-in state dtype (round 6): the same two entry points with the dtype of `state` as an argument (LINA_F32: identical to
+// the entries above; LINA_BF16: the reference's own arithmetic for a bf16 model at window 1, see ld_state4).  bf16 state is
+// built for bf16 activations (dtype == LINA_BF16), gates in either dtype.
+extern "C" int lina_gla_decode_window_s(const void* q, const void* k, const void* v, const void* gk, void* state, int state_dtype,
+                                        const void* gate, const void* norm_weight, void* og, float* o_exchange, int* counters,
+                                        float* hist_k, float* hist_c, float* hist_v, const int64_t* step, const int64_t* origin,
+                                        int window, int B, int H, int Dk, int Dv, int64_t q_sb, int64_t q_sh, int64_t k_sb,
+                                        int64_t k_sh, int64_t v_sb, int64_t v_sh, int64_t g_sb, int64_t g_sh, int64_t gate_sb,
+                                        int64_t gate_sh, float eps, int og_packed, int dtype, int g_dtype, float scale,
+                                        lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(valid_dtype(state_dtype), "lina_gla_decode_window_s: bad state dtype %d", state_dtype);
+    if (state_dtype == LINA_F32)
+        return lina_gla_decode_window(q, k, v, gk, (float*)state, gate, norm_weight, og, o_exchange, counters, hist_k, hist_c, hist_v,
+                                      step, origin, window, B, H, Dk, Dv, q_sb, q_sh, k_sb, k_sh, v_sb, v_sh, g_sb, g_sh, gate_sb,
+                                      gate_sh, eps, og_packed, dtype, g_dtype, scale, stream);
+    LINA_REQUIRE(q && k && v && gk && state && gate && norm_weight && og && hist_k && hist_c && hist_v && step && origin,
+                 "lina_gla_decode_window_s: null pointer");
+    LINA_REQUIRE(B > 0 && H > 0, "lina_gla_decode_window_s: B,H must be positive");
+    LINA_REQUIRE(window >= 1 && window <= kWinMax && (window & (window - 1)) == 0,
+                 "lina_gla_decode_window_s: window must be a power of two in [1, %d]", kWinMax);
+    LINA_REQUIRE(valid_dtype(dtype) && valid_dtype(g_dtype), "lina_gla_decode_window_s: bad dtype enum");
+    LINA_REQUIRE(gate_sb % 4 == 0 && gate_sh % 4 == 0, "lina_gla_decode_window_s: gate strides must be multiples of 4");
+    if (dtype != LINA_BF16) return fail(LINA_ERR_UNSUPPORTED, "lina_gla_decode_window_s: a bf16 state is built for bf16 activations");
+    const int64_t st[8] = {q_sb, q_sh, k_sb, k_sh, v_sb, v_sh, g_sb, g_sh};
+    if (g_dtype == LINA_F32)
+        return launch_window<bf16_t, float, bf16_t>(q, k, v, gk, (bf16_t*)state, hist_k, hist_c, hist_v, step, origin, window, -1,
+                                                    B, H, Dk, Dv, st, scale, stream, gate, gate_sb, gate_sh, norm_weight, eps, og,
+                                                    og_packed, o_exchange, counters);
+    return launch_window<bf16_t, bf16_t, bf16_t>(q, k, v, gk, (bf16_t*)state, hist_k, hist_c, hist_v, step, origin, window, -1, B,
+                                                 H, Dk, Dv, st, scale, stream, gate, gate_sb, gate_sh, norm_weight, eps, og,
+                                                 og_packed, o_exchange, counters);
+}
+
+extern "C" int lina_gla_decode_window_flush_s(void* state, int state_dtype, const float* hist_k, const float* hist_c,
+                                              const float* hist_v, int n_pending, int B, int H, int Dk, int Dv,
+                                              lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(valid_dtype(state_dtype), "lina_gla_decode_window_flush_s: bad state dtype %d", state_dtype);
+    if (state_dtype == LINA_F32)
+        return lina_gla_decode_window_flush((float*)state, hist_k, hist_c, hist_v, n_pending, B, H, Dk, Dv, stream);
+    LINA_REQUIRE(state && hist_k && hist_c && hist_v, "lina_gla_decode_window_flush_s: null pointer");
+    LINA_REQUIRE(B > 0 && H > 0, "lina_gla_decode_window_flush_s: B,H must be positive");
+    LINA_REQUIRE(n_pending >= 0 && n_pending <= kWinMax, "lina_gla_decode_window_flush_s: n_pending must be in [0, %d]", kWinMax);
+    if (n_pending == 0) return LINA_OK;
+    const int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return launch_window<bf16_t, float, bf16_t>(nullptr, nullptr, nullptr, nullptr, (bf16_t*)state, (float*)hist_k, (float*)hist_c,
+                                                (float*)hist_v, nullptr, nullptr, kWinMax, n_pending, B, H, Dk, Dv, st, 1.0f,
+                                                stream, nullptr, 0, 0, nullptr, 0.f, nullptr);
 }

@@ -224,6 +224,17 @@ __device__ __forceinline__ uint4 ld_nt16(const void* p) {
     const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
     return make_uint4(t[0], t[1], t[2], t[3]);
 }
+// ... and on one 8-byte piece (four bf16 state elements)
+__device__ __forceinline__ uint2 ld_nt8(const void* p) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
+    return make_uint2(t[0], t[1]);
+}
+__device__ __forceinline__ void st_nt8(void* p, uint2 v) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x2_t*>(p));
+}
 __device__ __forceinline__ float ld_nt1(const float* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void st_nt1(float* p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void st_nt4(float* p, float4 v) {

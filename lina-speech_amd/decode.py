@@ -140,8 +140,8 @@ class _BlockPack:
         self._buffers(state, lo, hi, dt, dev)
 
     def _buffers(self, state, lo, hi, dt, dev):
-        if state[3].dtype != torch.float32 or not state[3].is_contiguous():
-            raise ValueError("recurrent state must be a contiguous fp32 tensor (see GatedLinearAttention.init_state)")
+        if state[3].dtype not in (torch.float32, torch.bfloat16) or not state[3].is_contiguous():
+            raise ValueError("recurrent state must be a contiguous fp32 (opt-in: bf16) tensor (see GatedLinearAttention.init_state)")
         hi = state[3].shape[0] if hi is None else hi
         self.cq, self.ck, self.cv, self.S = (t[lo:hi] for t in state)    # row slices stay contiguous
         B = hi - lo
@@ -155,7 +155,11 @@ class _BlockPack:
         self.og = torch.empty(B, self.H, self.Dv, dtype=dt, device=dev)
         self.counters = torch.zeros(B * self.H, dtype=torch.int32, device=dev)
         self.s = torch.empty(B, self.hid_pad, dtype=dt, device=dev)
-        self.lazy = self.window > 1 and self.Dk in (64, 128, 256) and self.Dv in (64, 128, 256, 512)
+        # (a bf16 state always takes K1w, at window 1 too: the immediate kernels K1d / K1 are built for an fp32 state)
+        self.lazy = ((self.window > 1 or state[3].dtype == torch.bfloat16) and self.Dk in (64, 128, 256)
+                     and self.Dv in (64, 128, 256, 512))
+        if state[3].dtype == torch.bfloat16 and not self.lazy:
+            raise NotImplementedError("bf16 recurrent state: head shapes of K1w only")
         self.o_x = torch.zeros(B * self.H * self.Dv, dtype=torch.float32, device=dev) if self.Dv > 256 else None
         self.packed = self.lazy and self.fused_in
         if self.packed:
@@ -199,7 +203,7 @@ class DecodeEngine:
                  use_graph: Optional[bool] = None, n_split: Optional[int] = None, fuse_norm: bool = True,
                  window: Optional[int] = None, stream_weights=("in", "up"), cross: str = "spread",
                  fused_pick: bool = True, packed: bool = True, cross_tail_fused: bool = True,
-                 share_weights_with: Optional["DecodeEngine"] = None):
+                 share_weights_with: Optional["DecodeEngine"] = None, state_dtype: Optional[torch.dtype] = None):
         """``share_weights_with``: another engine of the same model whose packed decode-time weights this one reuses
         (DecodeEngineGroup: several engines on row ranges of one batch).
         Every variant of the step is a constructor argument (rounds 2-3 read ``LINA_DECODE_*`` environment switches here).
@@ -214,6 +218,12 @@ class DecodeEngine:
         LAZILY WRITTEN -- read every token, rewritten every ``window``-th token (K1w, lina_gla_decode_window); the
         steps in between live in small history buffers.  ``engine.state`` / ``sync_state()`` materialise the exact
         state on demand.  1 = the immediate in-place update K1d on every token.
+        ``state_dtype`` (opt-in; default fp32): ``torch.bfloat16`` keeps the recurrent state of every block in bf16, as the
+        REFERENCE does for a bf16 model (model/gla.py:229-240: ``init_state`` allocates with ``param.new_zeros`` and
+        ``Cache.update`` copies the fp32 final state of every step into it): read, updated in fp32 registers, rounded when
+        written back -- on every token with ``window=1`` (the reference's arithmetic; the default window for this dtype), on
+        every ``window``-th token otherwise (less rounding than the reference, half of K1w's bytes).  bf16 models only; the
+        fp32 state stays the product's default and the headline's.
         ``n_split`` > 1 cuts the batch into independent row ranges that run on parallel HIP streams inside
         the same graph: the step is a chain of ~100 short dependent launches, so two (or four) independent
         chains in flight hide each other's launch/drain latency; rows never interact."""
@@ -222,12 +232,23 @@ class DecodeEngine:
         self.fuse_norm = fuse_norm
         self.B = batch_size
         self.dev = x_enc.device
+        if state_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("state_dtype must be torch.float32 or torch.bfloat16")
+        self.state_dtype = state_dtype or torch.float32
+        bf16_state = self.state_dtype == torch.bfloat16
+        if bf16_state and (model.logits_head.weight.dtype != torch.bfloat16 or not fuse_norm):
+            raise ValueError("a bf16 recurrent state is the reference's arithmetic for a bf16 model: bf16 weights only")
         if window is None:
-            window = 8
+            window = 1 if bf16_state else 8
         if window not in (1, 2, 4, 8, 16):
             raise ValueError("window must be 1, 2, 4, 8 or 16")
         self.window = window if self.fuse_norm else 1
         self._state = state if state is not None else rnn.init_state(batch_size=batch_size)
+        if bf16_state:                                 # the Cache the caller sees then holds bf16 states, like the reference's
+            conv = Cache()
+            for li, st in enumerate(self._state.states):
+                conv.update(tuple(st[:-1]) + (st[-1].to(torch.bfloat16).contiguous(),), li, offset=0)
+            self._state = conv
         self._t_idx = torch.zeros(1, dtype=torch.long, device=self.dev)      # device step counter of the greedy loop
         self._origin = torch.zeros(1, dtype=torch.long, device=self.dev)     # step at which the current window began
         self._origin_host, self._n_done, self._lazy_live = 0, 0, False
@@ -318,10 +339,11 @@ class DecodeEngine:
         v = P.qkv[:, 2 * P.Kd:].view(B, P.H, P.Dv)
         if self._skip_update:
             pass                                  # measurement only (time_update_kernel): the step without K1w / K1d
-        elif lazy and P.lazy:
+        elif (lazy and P.lazy) or P.S.dtype == torch.bfloat16:
+            # (a bf16 state outside the device loop: the same kernel as an immediate update, window 1)
             ops.gla_decode_window(q, k, v, P.gk.view(B, P.H, P.Dk), P.S, gate, P.gnw, P.og_p if packed else P.og,
-                                  P.hk, P.hc, P.hv, self._t_idx, self._origin, P.window, P.eps_gate, og_packed=packed,
-                                  o_exchange=P.o_x, counters=P.counters)
+                                  P.hk, P.hc, P.hv, self._t_idx, self._origin, P.window if lazy else 1, P.eps_gate,
+                                  og_packed=packed, o_exchange=P.o_x, counters=P.counters)
         elif P.row_split and self.fuse_norm:
             ops.gla_decode_update_norm(q, k, v, P.gk.view(B, P.H, P.Dk), P.o_part, P.S, gate, P.gnw, P.og,
                                        P.counters, P.eps_gate)
@@ -457,7 +479,7 @@ class DecodeEngine:
         if not self.use_graph:
             raise RuntimeError("time_update_kernel needs the hipGraph path (a ROCm device)")
         self.sync_state()
-        lazy = self.window > 1
+        lazy = self.window > 1 or self.state_dtype == torch.bfloat16
         snap = self._snapshot()
         x_keep = [part.x.clone() for part in self.parts]
         t_keep, o_keep, live = self._t_idx.clone(), self._origin.clone(), self._lazy_live
@@ -564,7 +586,7 @@ class DecodeEngine:
         if y0 is None:
             y0 = emb.embed_sum(torch.ones(self.Q, self.B, 1, dtype=torch.long, device=self.dev))
         self._y_in.copy_(y0.reshape(self.B, self.d))
-        lazy = self.window > 1
+        lazy = self.window > 1 or self.state_dtype == torch.bfloat16     # (K1w: also the bf16 state's immediate update, window 1)
         n_sampled = min(max(first_greedy_quant, 0), self.Q) if k > 1 else 0
         # fragment-major operands: the device loop on one row range with the one-launch token epilogue (K6d / K6e keep
         # x_p current; the unfused sampled epilogue, fused_pick=False, has no packed output)

@@ -574,13 +574,16 @@ def gla_decode_window(q, k, v, gk, state, gate, norm_weight, og, hist_k, hist_c,
     """K1w + K5 (lina_gla_decode_window): decode-step update with a lazily written state -- ``state`` is read every
     step and rewritten every ``window``-th one, the steps in between live in hist_k / hist_c [window,B*H,Dk] and
     hist_v [window,B*H,Dv] (fp32).  ``step`` / ``origin``: int64 device tensors (window position = (step-origin) %
-    window).  Call gla_decode_window_flush before anybody else reads ``state``."""
+    window).  Call gla_decode_window_flush before anybody else reads ``state``.  ``state``: fp32, or (opt-in, bf16 activations
+    only) bf16 -- the reference's state dtype for a bf16 model, rounded at every write-back (lina_gla_decode_window_s)."""
     be = _backend._BACKEND
     be.require(q, k, v, gk, state, gate, norm_weight, og, hist_k, hist_c, hist_v, step, origin)
     B, H, Dk = q.shape
     Dv = v.shape[-1]
-    if state.dtype != torch.float32 or not state.is_contiguous() or tuple(state.shape) != (B, H, Dk, Dv):
-        raise ValueError("state must be contiguous fp32 [B,H,Dk,Dv]")
+    if state.dtype not in (torch.float32, torch.bfloat16) or not state.is_contiguous() or tuple(state.shape) != (B, H, Dk, Dv):
+        raise ValueError("state must be contiguous fp32 (or, opt-in, bf16) [B,H,Dk,Dv]")
+    if state.dtype == torch.bfloat16 and q.dtype != torch.bfloat16:
+        raise ValueError("a bf16 state needs bf16 activations")
     for t, shp in ((hist_k, (window, B * H, Dk)), (hist_c, (window, B * H, Dk)), (hist_v, (window, B * H, Dv))):
         if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shp:
             raise ValueError(f"history buffers must be contiguous fp32 {shp}")
@@ -597,7 +600,7 @@ def gla_decode_window(q, k, v, gk, state, gate, norm_weight, og, hist_k, hist_c,
     if Dv > 256 and (o_exchange is None or counters is None or o_exchange.dtype != torch.float32
                      or o_exchange.numel() < B * H * Dv or counters.dtype != torch.int32 or counters.numel() < B * H):
         raise ValueError("Dv > 256 needs o_exchange (fp32 [B*H*Dv]) and counters (int32 [B*H], zero)")
-    _check(be.lib.lina_gla_decode_window(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(state), _ptr(gate),
+    _check(be.lib.lina_gla_decode_window_s(_ptr(q), _ptr(k), _ptr(v), _ptr(gk), _ptr(state), _dt(state), _ptr(gate),
                                          _ptr(norm_weight), _ptr(og), _ptr(o_exchange), _ptr(counters), _ptr(hist_k),
                                          _ptr(hist_c),
                                          _ptr(hist_v), _ptr(step), _ptr(origin), int(window), B, H, Dk, Dv,
@@ -613,8 +616,8 @@ def gla_decode_window_flush(state, hist_k, hist_c, hist_v, n_pending: int):
     be = _backend._BACKEND
     be.require(state, hist_k, hist_c, hist_v)
     B, H, Dk, Dv = state.shape
-    _check(be.lib.lina_gla_decode_window_flush(_ptr(state), _ptr(hist_k), _ptr(hist_c), _ptr(hist_v), int(n_pending),
-                                               B, H, Dk, Dv, be.stream(state)))
+    _check(be.lib.lina_gla_decode_window_flush_s(_ptr(state), _dt(state), _ptr(hist_k), _ptr(hist_c), _ptr(hist_v),
+                                                 int(n_pending), B, H, Dk, Dv, be.stream(state)))
     return state
 
 

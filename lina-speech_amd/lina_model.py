@@ -108,22 +108,22 @@ class LinaModel(nn.Module):
         stats = torch._foreach_norm(ps) + torch._foreach_norm(torch._foreach_clamp_min(ps, 0))
         return tuple(torch.stack(stats).float().cpu().tolist())
 
-    def _decode_engine(self, x_enc: Tensor, B: int, init_state, n_engines: int = 1):
+    def _decode_engine(self, x_enc: Tensor, B: int, init_state, n_engines: int = 1, state_dtype=None):
         """The DecodeEngine of (batch size, text length, dtype, device, current weights), built once and re-armed for
         every later ``generate_batch`` call of the same shape: construction packs 0.3 GB of weights and captures two
         hipGraphs (~0.6 k kernel nodes), far more than a call at B = 64 should pay.  "Current weights" = every
         parameter's storage address AND a content fingerprint (see ``_weights_fingerprint``)."""
         from .decode import DecodeEngine, DecodeEngineGroup
         w = self.logits_head.weight
-        key = (B, int(n_engines), int(x_enc.shape[1]), w.dtype, str(w.device),
+        key = (B, int(n_engines), int(x_enc.shape[1]), w.dtype, str(w.device), str(state_dtype),
                tuple(p.data_ptr() for p in self.parameters()), self._weights_fingerprint())
         cache = self.__dict__.setdefault("_decode_engines", {})
         eng = cache.pop(key, None)
         if eng is None:
             if n_engines > 1:                                        # (no init_state / prompt in this form: the caller checked)
-                eng = DecodeEngineGroup(self, x_enc, batch_size=B, n_engines=n_engines)
+                eng = DecodeEngineGroup(self, x_enc, batch_size=B, n_engines=n_engines, state_dtype=state_dtype)
             else:
-                eng = DecodeEngine(self, x_enc, batch_size=B)        # NotImplementedError: architecture not covered
+                eng = DecodeEngine(self, x_enc, batch_size=B, state_dtype=state_dtype)   # NotImplementedError: architecture not covered
                 if init_state is not None:
                     eng.reset(state=init_state)
         elif n_engines > 1:
@@ -139,7 +139,8 @@ class LinaModel(nn.Module):
     def generate_batch(self, x: Tensor, batch_size: int = 3, prompt: Optional[Tensor] = None, device: str = "cpu",
                        max_seqlen: int = 1000, k: int = 100, first_greedy_quant: int = 1, temp: float = 1.0,
                        init_state=None, force_max_seqlen: bool = False, stop_check_every: int = 16,
-                       engine: Optional[str] = None, seed: Optional[int] = None, n_engines: Optional[int] = None):
+                       engine: Optional[str] = None, seed: Optional[int] = None, n_engines: Optional[int] = None,
+                       state_dtype: Optional[torch.dtype] = None):
         """Reference model/modeling_lina.py:111-192 (same arguments, same four returns).  ``engine``:
           None / "auto" -- the device-side loop (decode.DecodeEngine.generate: one hipGraph replay per 8 tokens, picks /
                            stop flags / attention log / next-token embedding inside the graph) when the architecture is
@@ -151,6 +152,8 @@ class LinaModel(nn.Module):
         half's projections run under the other half's HBM-bound state update).  None (default): 2 from
         ``AUTO_TWO_ENGINES_ROWS`` rows up, else 1.  Greedy tokens do not depend on it (rows never interact, every kernel's
         per-row sums are independent of the row count); the sampled quantizers draw from a per-engine seed word.
+        ``state_dtype`` (device loop, bf16 models; opt-in): ``torch.bfloat16`` keeps the recurrent state in bf16 and rounds it
+        after every step, as the reference itself does for a bf16 model (model/gla.py:229-240 + Cache.update); default fp32.
         ``seed`` feeds the device-side sampler of the loop (default: drawn from torch's generator, so
         ``torch.manual_seed`` makes a call reproducible, like the reference's multinomial)."""
         B, Q = batch_size, self.n_quant
@@ -176,7 +179,7 @@ class LinaModel(nn.Module):
                 n_engines = 2 if B >= self.AUTO_TWO_ENGINES_ROWS else 1
             n_eng = n_engines if (n_engines > 1 and prompt is None and init_state is None and B >= 2 * n_engines) else 1
             try:
-                eng = self._decode_engine(x_enc, B, init_state, n_eng)
+                eng = self._decode_engine(x_enc, B, init_state, n_eng, state_dtype)
             except NotImplementedError:
                 if mode == "loop":
                     raise

@@ -26,12 +26,16 @@ from . import gla_oracle as O
 
 class OracleLina:
     def __init__(self, sd: dict, n_layer: int, heads: int, txt_heads: int = None, n_quant: int = 1,
-                 normalizer: float = 16.0, eps: float = 1e-5, dtype=torch.float32):
+                 normalizer: float = 16.0, eps: float = 1e-5, dtype=torch.float32, state_dtype=None):
         self.sd = {k: v.detach().to("cpu", dtype if v.is_floating_point() else v.dtype) for k, v in sd.items()}
         self.n_layer, self.H, self.n_quant = n_layer, heads, n_quant
         self.txt_heads = txt_heads or heads
         self.normalizer, self.eps = normalizer, eps
         self.dtype = dtype
+        # the dtype the recurrent state is STORED in between decode steps.  The reference allocates it with param.new_zeros
+        # (model/gla.py:229-240) and Cache.update copy_-s every step's fp32 final state into it: a bf16 model rounds its state
+        # to bf16 after EVERY step.  None = keep it in the arithmetic dtype (what the product's fp32 state does).
+        self.state_dtype = state_dtype
 
     # ---- small pieces -----------------------------------------------------------------
     def _lin(self, x, name, bias=True):
@@ -60,7 +64,7 @@ class OracleLina:
         o, S = O.naive_recurrent_gla(hf(q), hf(k), hf(v), gk, initial_state=None if state is None else state[3],
                                      output_final_state=state is not None)
         if state is not None:
-            state[3].copy_(S)
+            state[3].copy_(S if self.state_dtype is None else S.to(self.state_dtype))
         g = self._lin(x, p + ".g_proj", bias=False).view(B, T, H, -1)
         o = O.rmsnorm_swish_gate(o.transpose(1, 2), g, self.sd[p + ".g_norm_swish_gate.weight"], self.eps)
         return self._lin(o.reshape(B, T, -1), p + ".o_proj", bias=False)

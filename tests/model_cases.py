@@ -366,6 +366,50 @@ def check_engine_hidden_log(dev, n=5):
             y = model.rvq_embed.embed_sum(toks[:, :, t:t + 1])
 
 
+def check_engine_bf16_state(dev, n=6):
+    """Opt-in ``DecodeEngine(state_dtype=torch.bfloat16)`` (the reference's state dtype for a bf16 model, model/gla.py:229-240 +
+    Cache.update): the device loop at window 1 (rounded after every step) and at window 4, and the generic step API on a bf16
+    state, against the oracle that rounds its state to bf16 after every step (fp32 arithmetic on the same bf16-rounded weights),
+    teacher-forced on the loop's tokens."""
+    from lina_speech_amd.decode import DecodeEngine
+    from oracle.lina_decode_oracle import OracleLina
+    g = load_golden("lina_d64.npz")
+    model = build_lina()
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    model = model.to(torch.bfloat16).to(dev).eval()
+    sd = {k: v.float().cpu() for k, v in model.state_dict().items()}
+    B = 3
+    x = torch.randint(3, 256, (B, 9), generator=torch.Generator().manual_seed(5))
+    orc = OracleLina(sd, n_layer=1, heads=1, state_dtype=torch.bfloat16)
+    with torch.inference_mode():
+        x_enc = model.txt_encoder(model.txt_embed(x.to(dev)))
+        for window in (1, 4):
+            eng = DecodeEngine(model, x_enc, batch_size=B, state_dtype=torch.bfloat16, window=window)
+            assert all(P.S.dtype == torch.bfloat16 and P.lazy for P in eng.packs)
+            eng.begin_greedy(n, log_hidden=True)
+            eng.greedy_steps(n)
+            toks, hid = eng.greedy_tokens().cpu(), eng.logged_hidden(n).float().cpu()
+            assert eng.state.states[0][3].dtype == torch.bfloat16
+            ref_toks, ref_logits, _, margins = orc.generate_greedy(x, n, teacher=toks)
+            lg = torch.einsum("nbd,ld->bnl", hid, sd["logits_head.weight"][0])
+            close(lg, ref_logits[:, :, 0], f"bf16-state engine (window {window}): logits vs the bf16-state oracle", 4e-2)
+            close(eng.state.states[0][3], orc.final_state[0][3], f"bf16-state engine (window {window}): first block's state", 4e-2)
+            eng.close()
+        # generic step API (immediate update of the bf16 state through K1w at window 1)
+        eng = DecodeEngine(model, x_enc, batch_size=B, state_dtype=torch.bfloat16)
+        y = model.rvq_embed.embed_sum(torch.ones(eng.Q, B, 1, dtype=torch.long, device=dev))
+        for t in range(n):
+            logits, _ = eng(y, t)
+            close(logits[:, 0, 0], ref_logits[:, t, 0], f"bf16-state engine, generic step {t}", 4e-2)
+            y = model.rvq_embed.embed_sum(toks[:, :, t:t + 1].to(dev))
+        # fp32 models refuse the option
+        try:
+            DecodeEngine(model.float(), x_enc.float(), batch_size=B, state_dtype=torch.bfloat16)
+            raise AssertionError("a bf16 state on an fp32 model must be refused")
+        except ValueError:
+            pass
+
+
 def check_generate_batch_early_stop(dev, dtype=torch.float32, d=256, B=8, max_seqlen=160, need_late_stop=True):
     """a-10, the early-stop path of the device loop over MANY stop checks (reference model/modeling_lina.py:168-173): a small
     vocabulary (13 codes + 3 specials) in the reference's default SAMPLED mode makes every row emit the stop token (id 2) at a

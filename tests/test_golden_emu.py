@@ -52,6 +52,11 @@ def test_engine_hidden_state_log(emu):
     check_engine_hidden_log("cpu")
 
 
+def test_engine_bf16_state(emu):
+    from model_cases import check_engine_bf16_state
+    check_engine_bf16_state("cpu")
+
+
 def test_generate_batch_with_two_engines(emu):
     from model_cases import check_generate_batch_group
     check_generate_batch_group("cpu")

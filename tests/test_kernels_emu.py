@@ -197,6 +197,14 @@ def test_decode_window(emu, Dk, Dv, dtype, window, n):
     check_decode_window(DEV, B=2, H=2, Dk=Dk, Dv=Dv, dtype=dtype, window=window, n_steps=n)
 
 
+# the opt-in bf16 recurrent state (the reference's state dtype for a bf16 model): rounded at every write-back -- every step at
+# window 1 (the reference's arithmetic), every window-th step otherwise
+@pytest.mark.parametrize("Dk,Dv,window,n", [(256, 256, 1, 6), (128, 128, 8, 11), (64, 512, 4, 6)])
+def test_decode_window_bf16_state(emu, Dk, Dv, window, n):
+    from kernel_cases import check_decode_window
+    check_decode_window(DEV, B=2, H=2, Dk=Dk, Dv=Dv, dtype=torch.bfloat16, window=window, n_steps=n, state_dtype=torch.bfloat16)
+
+
 @pytest.mark.parametrize("Q,L,d,dtype", [(1, 300, 64, torch.float32), (3, 70, 32, torch.bfloat16)])
 def test_greedy_pick_embed(emu, Q, L, d, dtype):
     from kernel_cases import check_greedy_pick_embed

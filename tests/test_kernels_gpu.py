@@ -317,6 +317,15 @@ def test_decode_window(hip, B, H, Dk, Dv, dtype, window, n):
     check_decode_window(DEV, B=B, H=H, Dk=Dk, Dv=Dv, dtype=dtype, window=window, n_steps=n)
 
 
+@pytest.mark.parametrize("B,H,Dk,Dv,window,n", [(64, 4, 256, 256, 1, 9), (64, 4, 256, 256, 8, 21), (5, 8, 128, 128, 4, 10),
+                                                (3, 4, 256, 512, 8, 10)])
+def test_decode_window_bf16_state(hip, B, H, Dk, Dv, window, n):
+    """Opt-in bf16 recurrent state (reference model/gla.py:229-240 + Cache.update for a bf16 model): window 1 = rounded after
+    every step, as the reference does; window W = every W-th step."""
+    from kernel_cases import check_decode_window
+    check_decode_window(DEV, B=B, H=H, Dk=Dk, Dv=Dv, dtype=torch.bfloat16, window=window, n_steps=n, state_dtype=torch.bfloat16)
+
+
 @pytest.mark.parametrize("B,Q,L,d,dtype", [(64, 1, 4099, 1024, torch.bfloat16), (7, 4, 1027, 256, torch.float32)])
 def test_greedy_pick_embed(hip, B, Q, L, d, dtype):
     from kernel_cases import check_greedy_pick_embed

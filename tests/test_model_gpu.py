@@ -291,6 +291,61 @@ def test_generate_batch_picks_two_engines_at_512_rows_same_tokens(hip):
     m.clear_decode_cache()
 
 
+@pytest.mark.parametrize("window", [1, 8])
+def test_l169_bf16_state_engine_vs_oracle_with_bf16_rounded_state(hip, window):
+    """VERDICT r05 item 9, the opt-in reference-dtype state: ``DecodeEngine(state_dtype=torch.bfloat16)`` against an oracle that
+    keeps the recurrent state in bf16 between steps -- rounds it after EVERY step, as the reference does for a bf16 model
+    (model/gla.py:229-240 `param.new_zeros` + Cache.update's copy_).  window = 1 is that arithmetic (the kernel rounds at every
+    write-back = every step); window = 8 stores the state in bf16 but rounds it every 8th step only.  L169, bf16, B = 8, peaked
+    logits, 24 free-running steps of the device loop; the oracle is teacher-forced on the loop's tokens: pre-head hidden state
+    and logits within the bf16 bounds of the fp32-state test, tokens equal at margins beyond twice the logit error."""
+    from lina_speech_amd.configs import l169
+    from lina_speech_amd.decode import DecodeEngine
+    from oracle.lina_decode_oracle import OracleLina
+    from model_cases import peak_logits
+    torch.manual_seed(0)
+    mb = peak_logits(l169().eval()).to(torch.bfloat16)
+    B, n = 8, 24
+    x = torch.randint(3, 256, (B, 24), generator=torch.Generator().manual_seed(17))
+    sd = {k: v.float() for k, v in mb.state_dict().items()}
+    with torch.inference_mode():
+        m = mb.to("cuda")
+        eng = DecodeEngine(m, m.txt_encoder(m.txt_embed(x.cuda())), batch_size=B, state_dtype=torch.bfloat16, window=window)
+        assert eng.packs[0].S.dtype == torch.bfloat16 and eng.packs[0].lazy and eng.window == window
+        eng.begin_greedy(n, log_hidden=True)
+        assert eng._loop_packed
+        eng.greedy_steps(n)
+        toks = eng.greedy_tokens().cpu()
+        hid = eng.logged_hidden(n).float().cpu()
+        S_eng = eng.state.states[0][3].float().cpu()          # (sync_state: pending window steps applied, rounded)
+        gb = m.generate_batch(x.cuda(), batch_size=B, max_seqlen=n, k=1, first_greedy_quant=0, force_max_seqlen=True,
+                              device="cuda", state_dtype=torch.bfloat16) if window == 1 else None
+        eng.close()
+    if gb is not None:                                        # the entry point's opt-in runs this very loop (window 1)
+        assert torch.equal(gb[0].cpu(), toks)
+    orc = OracleLina(sd, n_layer=6, heads=4, txt_heads=4, state_dtype=torch.bfloat16)
+    n_thr = _oracle_threads()
+    try:
+        ref_toks, ref_logits, ref_atts, margins = orc.generate_greedy(x, n, teacher=toks)
+    finally:
+        torch.set_num_threads(n_thr)
+    ref_hid = torch.cat(orc.hiddens, dim=1).transpose(0, 1)
+    hid_err = float((hid - ref_hid).abs().max() / ref_hid.abs().max())
+    W = sd["logits_head.weight"][0].double()
+    lg = (hid.double() @ W.t()).transpose(0, 1)
+    lg_err = float((lg - ref_logits[:, :, 0].double()).abs().max())
+    scale = float(ref_logits.abs().max())
+    st_err = float((S_eng - orc.final_state[0][3]).abs().max() / orc.final_state[0][3].abs().max())
+    safe = margins > 2.0 * lg_err
+    tag = f"L169 bf16 activations + bf16 recurrent state (window {window}) B=8 x 24 steps vs the oracle with a bf16-rounded state"
+    record_parity(tag + ": pre-head hidden state", hid_err, 2e-2)
+    record_parity(tag + ": logits implied by the hidden states", lg_err / scale, 1e-2)
+    record_parity(tag + ": first block's state after the run", st_err, 3e-2, masked_positions=int((~safe).sum()), positions=B * n)
+    assert hid_err < 2e-2 and lg_err < 1e-2 * scale and st_err < 3e-2
+    assert int((~safe).sum()) < 0.1 * B * n
+    assert torch.equal(toks[0][safe], ref_toks[0][safe])
+
+
 def _oracle_threads():
     n = torch.get_num_threads()
     torch.set_num_threads(min(n, 32))            # small-op decode on a 256-thread host: more threads only add sync cost

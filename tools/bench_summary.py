@@ -27,6 +27,16 @@ if "other_head_shapes" in d:
         print(f"{k}: {v['ms_per_step']:.4f} ms/step {v['tokens_per_s']:.0f} tok/s")
 if "cpu_baseline" in d:
     print(f"cpu_baseline: {d['cpu_baseline']['value']:.1f} tok/s on {d['cpu_baseline']['cores']} threads")
+if "decode_bf16_state" in d:
+    t = d["decode_bf16_state"]
+    print("decode_bf16_state:", t.get("error") or "  ".join(
+        f"window {w}: {t[f'window_{w}']['tokens_per_s']:.0f} tok/s ({t[f'window_{w}']['ms_per_step']:.4f} ms, step {t[f'window_{w}']['step_roofline']['frac']:.3f} of HBM)"
+        for w in (1, 8)))
+if "per_gpu_batch" in d:
+    print("per_gpu_batch:", "  ".join(f"{k} {v.get('ms_per_step', float('nan')):.4f} ms ({v.get('tokens_per_s', 0):.0f} tok/s)" for k, v in d["per_gpu_batch"].items()))
+cb = d.get("cpu_baseline")
+if cb:
+    print(f"cpu_baseline: {cb['value']:.1f} tok/s at {cb['cores']} threads (min {cb.get('min', 0):.1f}, max {cb.get('max', 0):.1f})")
 if "two_engines" in d:
     t = d["two_engines"]
     print("two_engines:", t.get("error") or f"{t['loop_tokens_per_s']:.0f} tok/s ({t['loop_ms_per_step']:.4f} ms/step), generate_batch {t['generate_batch_tokens_per_s']:.0f} tok/s")
