@@ -176,7 +176,12 @@ def measure_chunk(dev, B=64, H=4, T=4096, Dk=256, Dv=256, reps=200):
     for name, note in (("r02_k2_b8_traffic.json", "; state-only pass + combine + full pass of the segment-parallel form"),
                        ("r05_k2_b8_traffic.json", "; state-only pass + combine + full pass of the segment-parallel form"),
                        ("r04_k2_h4_traffic.json", "; the training call"), ("r04_k2_h8_traffic.json", "; the training call"),
-                       ("r04_k2_h16_traffic.json", "; the training call")):
+                       ("r04_k2_h16_traffic.json", "; the training call"),
+                       # round 6: every figure re-measured in one session on the final tree (tests/gpu_r06_evidence.sh); the LAST match wins
+                       ("r06_k2_b8_traffic.json", "; state-only pass + combine + full pass of the segment-parallel form"),
+                       ("r06_k2_h4_traffic.json", "; the training call"), ("r06_k2_h8_traffic.json", "; the training call"),
+                       ("r06_k2_h16_traffic.json", "; the training call"),
+                       ("r06_k2_dv512_traffic.json", "; the training call, two 256-column launches per call: q, k, g read by both")):
         tpath = os.path.join(ROOT, "profiles", name)                 # PMC passes are separate runs; their committed summaries
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -184,10 +189,11 @@ def measure_chunk(dev, B=64, H=4, T=4096, Dk=256, Dv=256, reps=200):
                 traffic = tj["traffic_bytes_per_launch"]
                 traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected{note})"
     sq = None                                                        # SQ counter passes (separate rocprofv3 runs): committed summary
-    spath = os.path.join(ROOT, "profiles", "r05_k2_sq.json")
+    sname = "r06_k2_sq.json" if os.path.exists(os.path.join(ROOT, "profiles", "r06_k2_sq.json")) else "r05_k2_sq.json"
+    spath = os.path.join(ROOT, "profiles", sname)
     if os.path.exists(spath) and (B, H, T, Dk, Dv) == (64, 4, 4096, 256, 256):
         der = next(iter(json.load(open(spath))["kernels"].values()))["derived"]
-        sq = {"source": "profiles/r05_k2_sq.json (rocprofv3 --pmc, SQ counters; tools/pmc_sq.py)",
+        sq = {"source": f"profiles/{sname} (rocprofv3 --pmc, SQ counters; tools/pmc_sq.py)",
               **{k_: der[k_] for k_ in ("mfma_util", "wait_share", "issue_stall", "active_share", "valu_share", "lds_conflict")
                  if k_ in der}}
     return {"kernel": "lina::gla_chunk_bf16_h256_kernel", "shape": {"B": B, "H": H, "T": T, "Dk": Dk, "Dv": Dv},
@@ -218,7 +224,7 @@ def measure_chunk_bwd(dev, B=8, H=4, T=4096, Dk=256, Dv=256, reps=100):
                           reps=reps)
     nbytes = B * H * T * 2 * (5 * Dk + 4 * Dv)
     traffic, traffic_src = None, None
-    for tname in ("r04_k2b_traffic.json", "r05_k2b_b8_traffic.json"):   # PMC passes are separate runs; their committed summaries
+    for tname in ("r04_k2b_traffic.json", "r05_k2b_b8_traffic.json", "r06_k2b_traffic.json", "r06_k2b_b8_traffic.json"):   # PMC passes are separate runs; their committed summaries (the last match wins)
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -337,16 +343,17 @@ def physical_cores_per_socket() -> int:
 def cpu_baseline(model, B=8, steps=200, repeats=3):
     """The reference's pure-PyTorch recurrent path (mode='naive') restated in oracle/, timed on the host cores on a bounded
     sample of the same workload: same 166.7M weights (fp32), B = 8 rows, T_txt = 64, greedy, a FIXED number of steps, run
-    ``repeats`` times from a fresh state; `value` is the MEDIAN run (min and max beside it).  Threads = the physical cores of one
-    socket (round 6; rounds 1-5 also probed os.cpu_count() = 256 threads, where one step of these small ops takes 50 s, and
-    took the faster of two settings -- a third of the bench's wall time for a figure with a 4 x spread between sessions).
+    ``repeats`` times from a fresh state; `value` is the MEDIAN run (min and max beside it).  Threads: FIXED at min(32, physical
+    cores of one socket) -- the setting that is fastest for these small per-token ops on the GPU box's host (measured there: 32
+    threads 156-178 tok/s, 64 threads = one socket's cores 58 tok/s, os.cpu_count() = 256 threads 50 s for ONE step); rounds 1-5
+    probed two settings per run and took the faster -- a third of the bench's wall time for a figure with a 4 x spread.
     Also times BASELINE config 1 (d256 x l2 simple-GLA forward, B=4, T=256, pure-PyTorch recurrent) on the same cores."""
     from oracle.lina_decode_oracle import OracleLina
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     orc = OracleLina(sd, n_layer=6, heads=4, txt_heads=4)
     g = torch.Generator().manual_seed(0)
     x = torch.randint(3, 256, (B, T_TXT), generator=g)
-    threads = min(physical_cores_per_socket(), os.cpu_count() or 1)
+    threads = min(32, physical_cores_per_socket(), os.cpu_count() or 1)
     torch.set_num_threads(threads)
     runs = []
     with torch.no_grad():
@@ -370,8 +377,8 @@ def cpu_baseline(model, B=8, steps=200, repeats=3):
     return {"value": med, "unit": "codec tokens/s", "cores": threads, "kind": "port", "min": rates[0], "max": rates[-1],
             "spread": rates[-1] / max(rates[0], 1e-9), "host": host_cpu(), "runs": runs,
             "sample": f"oracle/lina_decode_oracle.py (pure-PyTorch recurrent, fp32), 166.7M model, B={B}, T_txt={T_TXT}, "
-                      f"{runs[0]['steps']} greedy steps x {repeats} runs at {threads} threads (= the physical cores of one socket; "
-                      f"os.cpu_count() = {os.cpu_count()}); value = the median run",
+                      f"{runs[0]['steps']} greedy steps x {repeats} runs at {threads} threads (fixed: min(32, the {physical_cores_per_socket()} physical "
+                      f"cores of one socket); os.cpu_count() = {os.cpu_count()}); value = the median run",
             "config1_cpu": cfg1}
 
 
@@ -887,7 +894,7 @@ def main():
             k1d_bytes = k1_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4)
             k1_bytes = k1w_algorithmic_bytes(k1_rows, P.H, P.Dk, P.Dv, e_io, 4, eng1.window) if lazy else k1d_bytes
             traffic, traffic_src = None, None
-            names = ("r05_k1w_traffic_b%d.json" % k1_rows, "r04_k1w_traffic.json", "r02_k1w_traffic.json") if lazy \
+            names = ("r06_k1w_traffic_b%d.json" % k1_rows, "r05_k1w_traffic_b%d.json" % k1_rows, "r04_k1w_traffic.json", "r02_k1w_traffic.json") if lazy \
                 else ("r02_k1d_traffic.json", "r01_k1d_traffic.json")
             for name in names:                                # PMC passes are separate runs; their committed summary
                 tpath = os.path.join(ROOT, "profiles", name)

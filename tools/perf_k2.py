@@ -7,7 +7,8 @@ import torch
 from lina_speech_amd import ops
 
 H = int(os.environ.get("K2_H", 4))                        # heads of the 1024-wide model: head dimension 1024 / H
-B, T, Dk, Dv = int(os.environ.get("K2_B", 64)), int(os.environ.get("K2_T", 4096)), 1024 // H, 1024 // H
+B, T, Dk = int(os.environ.get("K2_B", 64)), int(os.environ.get("K2_T", 4096)), 1024 // H
+Dv = int(os.environ.get("K2_DV", Dk))                     # K2_DV=512: expand_v = 2 (two 256-column launches per call)
 reps = int(os.environ.get("K2_REPS", 5))
 dev = "cuda"
 g = torch.Generator().manual_seed(0)

@@ -12,7 +12,8 @@ import csv, glob, json, os, sys
 BK = int(os.environ.get("PMC_B", 64))        # batch rows of the K2 / K2b shape the passes ran (tools/perf_k2.py K2_B)
 
 which, fdir, wdir, out = sys.argv[1:5]
-pat = {"k1w": "gla_decode_window_kernel", "k2": "gla_chunk_bf16_h256", "k2b": "gla_chunk_bf16_h256", "k2seg": "gla_"}[which]
+pat = {"k1w": "gla_decode_window_kernel", "k2": "gla_chunk_bf16_h256", "k2b": "gla_chunk_bf16_h256", "k2seg": "gla_",
+       "k2dv512": "gla_chunk_bf16_h256"}[which]
 res = {}
 for c, d in (("FETCH_SIZE", fdir), ("WRITE_SIZE", wdir)):
     f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)
@@ -31,7 +32,17 @@ o = {"counters": res,
      "correction": "gfx950 FETCH_SIZE counts the 128-B requests of a 16-B/lane streaming read at 64 B: doubled "
                    "(MI355X_MICROARCH.md, HBM); WRITE_SIZE taken as is; one counter per rocprofv3 pass, --kernel-trace only",
      "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr}
-if which == "k2seg":       # segment-parallel forward: state-only pass + combine + full pass, summed per call
+if which == "k2dv512":     # expand_v = 2: one call = two launches of the 256-column kernel (q, k, g read by both)
+    rd, wr = 2 * rd, 2 * wr
+    heads = int(sys.argv[5])
+    D = 1024 // heads
+    alg = BK * heads * 4096 * 2 * (3 * D + 2 * 2 * D)
+    o.update(hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, traffic_bytes_per_launch=rd + wr,
+             kernel="lina::gla_chunk_bf16_h256_kernel<false, 1> x 2 (one launch per 256-column block of v / o), per CALL",
+             shape={"B": BK, "H": heads, "T": 4096, "Dk": D, "Dv": 2 * D},
+             command=f"K2_B={BK} K2_H={heads} K2_DV={2 * D} K2_HT=0 rocprofv3 --kernel-trace --pmc <COUNTER> -- python tools/perf_k2.py (tests/gpu_r06_evidence.sh)",
+             algorithmic_bytes_per_launch=alg, traffic_over_algorithmic=(rd + wr) / alg)
+elif which == "k2seg":       # segment-parallel forward: state-only pass + combine + full pass, summed per call
     rd, wr = 2 * res["FETCH_SIZE"]["per_call_KiB"] * 1024, res["WRITE_SIZE"]["per_call_KiB"] * 1024
     heads = int(sys.argv[5])
     D = 1024 // heads
