@@ -844,7 +844,7 @@ def main():
 
     with torch.inference_mode():
         x_enc = model_dev.txt_encoder(model_dev.txt_embed(texts))
-        # the loop LinaModel.generate_batch runs for this many rows: from LinaModel.AUTO_TWO_ENGINES_ROWS (512) rows up the batch is
+        # the loop LinaModel.generate_batch runs for this many rows: from LinaModel.AUTO_TWO_ENGINES_ROWS (384) rows up the batch is
         # cut into two row ranges, one engine and one HIP stream each (decode.DecodeEngineGroup; --engines overrides)
         n_eng = args.engines if args.engines else (2 if B >= model_dev.AUTO_TWO_ENGINES_ROWS else 1)
         if n_eng > 1:

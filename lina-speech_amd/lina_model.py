@@ -79,9 +79,10 @@ class LinaModel(nn.Module):
     # ------------------------------------------------------------------ batched decode
     _ENGINE_CACHE_SIZE = 2
     # generate_batch(n_engines=None): from this many rows up the batch is decoded by TWO engines on two HIP streams (rows never
-    # interact -- reference modeling_lina.py:125,152-179; measured at L169: 512 rows 2.20 ms per token against 2.34 on one engine,
-    # 4 x 128 rows and every split of 64 rows slower: profiles/r05_two_engines.txt, r06_b64_engines.txt)
-    AUTO_TWO_ENGINES_ROWS = 512
+    # interact -- reference modeling_lina.py:125,152-179; measured at L169, ms per token as one / two engines: 512 rows 2.31 /
+    # 2.16, 384 rows 1.82 / 1.74, 256 rows 1.38 / 1.36, 128 rows 0.875 / 0.852; 4 x 128 rows and every split of 64 rows are slower
+    # than one engine: profiles/r06_two_engines.txt, r06_b64_engines.txt)
+    AUTO_TWO_ENGINES_ROWS = 384
 
     def __getstate__(self):
         """copy.deepcopy / pickling: the cached decode engines (hipGraphs, static buffers) stay with the original."""

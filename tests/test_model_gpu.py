@@ -275,7 +275,8 @@ def test_generate_batch_picks_two_engines_at_512_rows_same_tokens(hip):
     from model_cases import peak_logits
     torch.manual_seed(0)
     m = peak_logits(l169().eval()).to("cuda", torch.bfloat16)
-    B, n = m.AUTO_TWO_ENGINES_ROWS, 24
+    B, n = 512, 24
+    assert B >= m.AUTO_TWO_ENGINES_ROWS
     x = torch.randint(3, 256, (B, 24), generator=torch.Generator().manual_seed(21)).cuda()
     kw = dict(batch_size=B, max_seqlen=n, k=1, first_greedy_quant=0, force_max_seqlen=True, device="cuda")
     two = m.generate_batch(x, **kw)
