@@ -26,8 +26,10 @@
 //      phase A's end.  1/sqrt(Dk) is applied to o.  History and measurements: DESIGN.md 4.2.
 #include <type_traits>
 #ifndef LINA_DMA_NT
-#define LINA_DMA_NT 1   // the q,k,g,v prefetch is read once: non-temporal DMA (0.582 -> 0.572 ms at B=64,H=4,T=4096, round 4)
-#endif
+#define LINA_DMA_NT 1   // the q,k,g,v prefetch is read once: non-temporal DMA (0.582 -> 0.572 ms at B=64,H=4,T=4096, round 4).  Per
+#endif                  // instantiation since round 6 (template argument NTD, default = this): the segment-parallel FORWARD reads k, g, v
+                        // twice within microseconds (state-only pass, then the full pass) and runs 0.150 instead of 0.162 ms at b = 8 with
+                        // the plain policy; the backward's sweeps and the one-workgroup-per-head form keep nt (profiles/r06_k2_dma_nt_ab.txt)
 #include <lina_dev.h>
 #include "lina_common.h"
 
@@ -81,7 +83,7 @@ __device__ __forceinline__ bf16x8 frag8x2(const bf16_t* p_lo, const bf16_t* p_hi
 //           z = q (this sweep's own Z rows: in MODE 1 a phase-A thread reads exactly the (token, channel) values whose output
 //           it will hold), aux2 = dq (sweep Q's output) and aux = k that is dg = reverse-cumsum(q dq - k dk), formed while dk
 //           is still fp32 in registers.
-template <bool STATE_ONLY, int G, int MODE = 0, bool REV = false, bool DG = false>
+template <bool STATE_ONLY, int G, int MODE = 0, bool REV = false, bool DG = false, bool NTD = (LINA_DMA_NT != 0)>
 __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ gk, bf16_t* __restrict__ o, const float* h0, float* ht, float* dec_out, int H,
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 // uniform base + 32-bit BYTE offset per lane (< 2^32: launcher guard): selects the SGPR-base addressing form,
                 // no 64-bit per-lane address arithmetic (whose zero high word the compiler kept in -- and spilled from -- a VGPR)
                 const unsigned boff = 2u * (t * gst[a] + 8u * (unsigned)(lane & 31));
-                dma16_to_lds_async(gsrc[a], boff, &dst[pair * PE]);
+                dma16_to_lds_async_p<NTD>(gsrc[a], boff, &dst[pair * PE]);
             }
         }
     };
@@ -926,8 +928,9 @@ extern "C" int lina_gla_chunk_fwd_seg(const void* q, const void* k, const void* 
     float* Sstart = workspace;
     float* P = Sstart + slots * 256 * Dk;
     dim3 grid((unsigned)slots);
+    // (plain cache policy for both passes: the second one finds k, g, v where the first one left them)
 #define LINA_SEG(SO, GG, OO, H0, HT, PP)                                                                               \
-    LINA_LAUNCH((gla_chunk_bf16_h256_kernel<SO, GG>), grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k,  \
+    LINA_LAUNCH((gla_chunk_bf16_h256_kernel<SO, GG, 0, false, false, false>), grid, dim3(1024), 0, stream, (const bf16_t*)q, (const bf16_t*)k,  \
                 (const bf16_t*)v, (const bf16_t*)gk, (bf16_t*)(OO), (const float*)(H0), (float*)(HT), (float*)(PP), H, T, \
                 ns, Tseg, sq, sk, sv, sg, so, scale, LINA_FWD_ONLY)
     if (G == 1) LINA_SEG(true, 1, nullptr, nullptr, L, P); else if (G == 2) LINA_SEG(true, 2, nullptr, nullptr, L, P);

@@ -79,6 +79,18 @@ __device__ __forceinline__ void dma16_to_lds_async(const void* base_uniform, uns
                  : "s"(lds), "v"(lane_byte_off), "s"(base_uniform)
                  : "memory", "m0");
 }
+// The same with the cache policy as a template argument (a kernel whose instantiations want different policies: K2's plain passes
+// read every byte once -- non-temporal -- while the segment-parallel passes of a small batch read k, g, v twice within
+// microseconds and are 7.5 % faster when the first pass leaves them in the caches; profiles/r06_k2_dma_nt_ab.txt)
+template <bool NT>
+__device__ __forceinline__ void dma16_to_lds_async_p(const void* base_uniform, unsigned lane_byte_off, void* lds_wave_base) {
+    const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    if constexpr (NT)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" : : "s"(lds), "v"(lane_byte_off), "s"(base_uniform) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds), "v"(lane_byte_off), "s"(base_uniform) : "memory", "m0");
+}
 // The same, addressed by an LDS BYTE ADDRESS held as an integer: a kernel that walks a ring of LDS stages converts its base pointer
 // once (lds_addr_of) and adds plain integers -- every generic -> LDS pointer conversion in a loop is a null check + select on the
 // scalar pipe (s_cmp_lg_u64 / s_cselect per DMA piece in the first version of linear_tall.h).

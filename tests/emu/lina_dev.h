@@ -233,6 +233,10 @@ static inline void dma16_to_lds_async(const void* base_uniform, unsigned lane_by
     if (lina_emu::dma_late()) lina_emu::dma_defer(dst, src);
     else memcpy(dst, src, 16);
 }
+template <bool NT>
+static inline void dma16_to_lds_async_p(const void* base_uniform, unsigned lane_byte_off, void* lds_wave_base) {
+    dma16_to_lds_async(base_uniform, lane_byte_off, lds_wave_base);      // (the cache policy has no meaning here)
+}
 // LDS byte address as a value (lina_dev.h of the product: an unsigned; here the host pointer itself)
 typedef unsigned char* lds_addr_t;
 static inline lds_addr_t lds_addr_of(void* lds_ptr) { return (unsigned char*)lds_ptr; }
