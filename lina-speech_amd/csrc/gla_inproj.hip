@@ -445,7 +445,8 @@ __global__ __launch_bounds__(64 * TallShape<V>::NWV) void gla_inproj_tall_kernel
     IP_PROF_FLUSH();
 }
 
-// ---- B > 256 (round 6): 128 rows x 64 columns per workgroup on EXACTLY (2 Kd + 2 Vd) / 64 x ceil(B / 128) workgroups -- 256 at
+// ---- opt-in variants 3 / 4 of the tall launch (LINA_TALL_V; round 6, measured: no faster than variant 0 -- kept as A/B builds,
+// see DESIGN.md 4.3): 128 (variant 4: 64) rows x 64 columns per workgroup on EXACTLY (2 Kd + 2 Vd) / 64 x ceil(B / 128) workgroups -- 256 at
 // L169 / B = 512, one per CU -- with the register-ring main loop (linear_tall.h, variant 3) and two changes to the launch itself:
 //   * no gate workgroups.  The kernel above spends Kd / 64 of its column blocks (128 of 640 workgroups at B = 512) on the 16
 //     low-rank gate rows: each streams its rows of A over the WHOLE contraction -- the bytes and the time of a regular workgroup --

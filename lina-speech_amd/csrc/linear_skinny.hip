@@ -335,7 +335,8 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(
 #endif
 }
 
-// ---- M >= 128: the tall tiling (linear_tall.h) with the same epilogues.  Packed operands only; grid (ceil(N / 16 NT), ceil(M / 128)).
+// ---- M >= kTallMinRows (160): the tall tiling (linear_tall.h) with the same epilogues.  Packed operands only; XCD-aware 1-D grid over
+// ceil(N / 16 NT) column blocks x ceil(M / 64) row blocks (tall_tile_of).
 template <typename T, bool SWIGLU, bool LN, int NT, int V>
 __global__ __launch_bounds__(64 * TallShape<V>::NWV) void linear_tall_kernel(
     const T* __restrict__ A, const T* __restrict__ W, const float* __restrict__ c1, const float* __restrict__ c2,

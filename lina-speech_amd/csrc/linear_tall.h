@@ -1,4 +1,4 @@
-// linear_tall.h -- the decode-step projections at a LARGE utterance batch (M >= 128 rows): main loop shared by the plain /
+// linear_tall.h -- the decode-step projections at a LARGE utterance batch (M >= kTallMinRows = 160 rows): main loop shared by the plain /
 // LayerNorm-folded / SwiGLU projection (linear_skinny.hip) and by the fused input side of a GLA mixer (gla_inproj.hip).
 //
 // The "skinny" kernels of those files are built for M <= 64: a workgroup owns 64 rows x 16-32 columns and splits K over its
@@ -7,7 +7,8 @@
 // in-projection pulled 1.15 MB through every CU's vector-memory path and ran 38 us for 4.3 GFLOP (rocprofv3,
 // profiles/r05_step_b512_before_timeline.txt) -- 19 % of the step, the up-projection another 13 %.
 //
-// Tall tiling: a workgroup of NWV = 4 waves owns 128 rows x (16 G) weight rows; wave w owns rows [32 w, 32 w + 32) for the
+// Tall tiling: a workgroup of NWV = 4 waves owns 16 MTW NWV rows x (16 G) weight rows -- 64 rows since LINA_TALL_MTW = 1 became the
+// default (128 in the first versions, which the byte count below is written for); wave w owns rows [16 MTW w, 16 MTW (w + 1)) for the
 // WHOLE contraction (no split-K, no reduction through LDS: the accumulators are final), so
 //   * its A fragments (fragment-major: 1 KiB contiguous per load instruction, skinny_frag.h) are nobody else's;
 //   * the weight fragments of a k-step are needed by all four waves: fetched once per workgroup;
@@ -29,7 +30,7 @@ namespace lina {
 #define LINA_TALL_MTW 1            // 1: 64-row workgroups (twice as many, two to three per CU): in-projection 21.4 -> 18.5 us, up 14.7 -> 11.8,
 #endif                            // head 15.2 -> 12.5 at M = 512 against 2 (128 rows); profiles/r05_tall_perf.txt
 constexpr int kTallMTW = LINA_TALL_MTW;   // 16-row m-tiles per wave
-constexpr int kTallNWV = 4;       // waves per workgroup (rows per workgroup = 16 * MTW * NWV = 128)
+constexpr int kTallNWV = 4;       // waves per workgroup (rows per workgroup = 16 * MTW * NWV = 64 at MTW = 1)
 #ifndef LINA_TALL_KB
 #define LINA_TALL_KB 2            // (tools/tall_variants.sh builds other ring shapes for A/B)
 #endif
