@@ -33,17 +33,6 @@
 #include <lina_dev.h>
 #include "lina_common.h"
 
-// Round 6 (the key-gated forward, one head per workgroup): the four LOADER waves take no part in phase A.  Their 64 channels are done
-// by the waves four below them (one per SIMD: those run phase A twice, at raised priority), and the loaders spend the phase-A window
-// issuing the NEXT chunk's prefetch -- as soon as the twelve working waves have signalled (LDS counter) that their raw reads of the
-// current chunk are in registers.  The prefetch's issue time (~2100 clocks during which the issuing wave is blocked) then lies under
-// phase A instead of in front of the loaders' own MFMA steps, which were the chunk's critical path behind barrier (2): every wave
-// starts phase B together.  (Round 4's "early prefetch" had the loaders do their phase A AND the issue: 4700 clocks, everybody
-// waited at barrier (2) instead.)  A cut chunk (rare) fetches its own rows again and falls back to the prefetch behind barrier (2).
-#ifndef LINA_K2_SKIPA
-#define LINA_K2_SKIPA 1
-#endif
-
 #ifdef LINA_K2_PROF
 // tools-only build (tools/k2_prof.sh): per-phase shader-clock totals of workgroup 0, [wave][slot]; NOT part of the product library
 __device__ unsigned long long lina_k2_prof[16 * 16 + 3 * 1024];   // + per workgroup: total, wait_vmem, bar(3) of wave 0
@@ -150,8 +139,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // barrier (2) fetches both (three dependent LDS round trips -- flag, flag, R -- sat in front of every wave's MFMAs)
     __shared__ __attribute__((aligned(8))) unsigned s_flags[4];
     __shared__ int s_cut;
-    __shared__ int s_cons;                                    // SKIPA: working waves whose raw reads of the current chunk are done, summed over chunks
-    constexpr bool SKIPA = LINA_K2_SKIPA != 0 && MODE == 0 && !STATE_ONLY && G == 1 && !REV;
     __shared__ __attribute__((aligned(16))) float s_carry[DG ? DK : 4];   // DG: running sum of d per channel (wave-private quads)
 
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -231,22 +218,17 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     // no cross-wave totals, no barrier, no serial prefix loop; the thread owns two ADJACENT tokens, so it writes
     // k~^T / v^T directly (4-byte pieces).
     int rp = lane & 15, ch0 = 16 * w + 4 * (lane >> 4);
-    int wa = w;                                               // the wave index phase A works FOR (SKIPA: a second pass for wave w + 4)
     bool gate_zero0 = rev_tail;                               // REV, first chunk of the sequence's last segment: row 0 has no gate
     // inclusive gate cumsum of this thread's 2 rows x 4 channels (rows >= nrem count as 0); true if the chunk's total
     // decay is too large for one chunk.  FULL: all C rows are in the sequence (no masks).  CLAMP: a single gate below -60 is
     // clamped to -60 -- only the cut path needs it: an unclamped gate below -60 makes the optimistic scan report a violation
     // by itself, and the cut path rescans with the clamp (8 v_max per thread and chunk less in the common path, round 4).
-    auto read_g = [&](uint2 (&gr)[2]) {                      // the raw gate rows of this thread (requested with the other raw rows)
-        const bf16_t* gp = &s_rg[rp * PE + ch0];
-        gr[0] = *reinterpret_cast<const uint2*>(gp);
-        gr[1] = *reinterpret_cast<const uint2*>(gp + DK);
-    };
-    auto gate_scan_of = [&](auto full_tag, auto clamp_tag, const uint2 (&gr)[2], float (&bc)[2][4], int nrem) {
+    auto gate_scan = [&](auto full_tag, auto clamp_tag, float (&bc)[2][4], int nrem) {
         constexpr bool FULL = decltype(full_tag)::value, CLAMP = decltype(clamp_tag)::value;
         float g0[4], g1[4];
-        unpack4(gr[0], g0);
-        unpack4(gr[1], g1);
+        const bf16_t* gp = &s_rg[rp * PE + ch0];
+        unpack4(*reinterpret_cast<const uint2*>(gp), g0);
+        unpack4(*reinterpret_cast<const uint2*>(gp + DK), g1);
         const bool in0 = FULL || 2 * rp < nrem, in1 = FULL || 2 * rp + 1 < nrem;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -268,11 +250,6 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             viol |= (-bc[1][c] > kFullMaxDecay);              // b is monotone: the last row pair sees the chunk total
         }
         return viol;
-    };
-    auto gate_scan = [&](auto full_tag, auto clamp_tag, float (&bc)[2][4], int nrem) {
-        uint2 gr[2];
-        read_g(gr);
-        return gate_scan_of(full_tag, clamp_tag, gr, bc, nrem);
     };
     // rows >= nv are zeroed; the thread that owns row nv-1 publishes R after the chunk.  FULL: nv == C.
     // q~ carries NO 1/sqrt(Dk): the scale is applied to o (linear), one multiply per output instead of one per q element.
@@ -297,9 +274,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         uint2 kk[2], vv[2];                                   // packed k~ / v of the two rows, for the transposed pieces
         // column (element index) of this thread's channel quad in the q~ / k~ tiles: group w/2, piece c4 ^ ((row>>2)&3) =
         // c4 ^ ((rp>>1)&3) for both rows 2rp, 2rp+1, half w&1
-        bf16_t* const qkp = &s_qk[2 * rp * SQ + 32 * (wa >> 1) + 8 * ((lane >> 4) ^ ((rp >> 1) & 3)) + 4 * (wa & 1)];
+        bf16_t* const qkp = &s_qk[2 * rp * SQ + 32 * (w >> 1) + 8 * ((lane >> 4) ^ ((rp >> 1) & 3)) + 4 * (w & 1)];
         // MODE 1, X tile: rows rp and 16 + rp, piece c4 ^ ((row>>2)&3) = c4 ^ ((rp>>2)&3)
-        bf16_t* const xp = &s_qk[rp * SQ + 32 * (wa >> 1) + 8 * ((lane >> 4) ^ ((rp >> 2) & 3)) + 4 * (wa & 1)];
+        bf16_t* const xp = &s_qk[rp * SQ + 32 * (w >> 1) + 8 * ((lane >> 4) ^ ((rp >> 2) & 3)) + 4 * (w & 1)];
         const bf16_t* const rawp = &s_raw[rp * PE + ch0];
         bf16_t* const tp = &s_T[ch0 * ST + 2 * rp];          // transposed pieces: (channel ch0+i, tokens 2rp, 2rp+1) = one word
         if constexpr (MODE == 1) {
@@ -409,12 +386,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         for (int c = tid; c < DK; c += 1024) s_carry[c] = carry ? carry[(int64_t)slot * DK + c] : 0.0f;
     if (tid < 4) s_flags[tid] = 0;
     if (tid == 2) s_cut = 0;
-    if (tid == 3) s_cons = 0;
     dma_chunk(0, STATE_ONLY ? 1 : 0, 4);
     wait_vmem();
     __syncthreads();   // DMA of chunk 0 landed
     int t0 = 0, par = 0;                                      // par: chunk parity
-    int chunk_no = 0;                                         // SKIPA: iterations so far (every working wave signals once per iteration)
     int tp = 0, np = 0;                                       // previous chunk: its o is stored at the END of the next phase A
     f32x4 acc[2] = {};       // o^T: this wave's 16 columns (rows 4lg + r) x tokens [16nt, 16nt+16) (column li)
     // o straight from the accumulators.  The products were taken TRANSPOSED (state / v as the A operand), so a lane holds 4
@@ -510,9 +485,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     while (t0 < T) {
         // nothing per-lane is carried across iterations: the wave index sits in an SGPR, the lane index comes from v_mbcnt
         // (a spilled index would be reloaded through vmcnt, the counter the in-flight DMA also uses, and stall on it)
-        lane = lane_id_here();
+        lane = lane_id();
+        opaque(lane);
         w = w_s; tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; rp = lane & 15; ch0 = 16 * w + 4 * (lane >> 4);
-        wa = w;
         const int nrem = T - t0;
         int n = min(C, nrem);
         // ---------------- phase A: gate scan, scaled operands, transposed operands ----------------
@@ -520,48 +495,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         // (and, in sweep K, the aux rows requested before step (4)) are dead before the tile writes need their registers
         float En[2][4];                                        // MODE 1: this chunk's output factors
         if (DG && np > 0) store_prev();                        // sweep K: before the gate scan (its registers: aux, aux2, q rows)
-        int wr = w_s;                                          // (re-derived per iteration: hoisted, the two flags were spilled)
-        if constexpr (SKIPA) opaque_s(wr);
-        const bool loader = SKIPA && wr >= kDmaWave0, doubler = SKIPA && !loader && wr >= kDmaWave0 - kLoaders;
-        const bool early = SKIPA && t0 + n < T;                // workgroup-uniform: the next chunk's prefetch is issued in THIS phase A
-        // phase-A pass for wave index `wv` (its 16 channels): ch0 / wa are what the lambdas above address with
-        auto set_pass = [&](int wv) { wa = wv; ch0 = 16 * wv + 4 * (lane >> 4); };
-        if constexpr (SKIPA) {
-            if (!loader) {
-                if (doubler) wave_priority<1>();               // two passes on this wave: it goes first on its SIMD
-                // a pass requests ALL its raw rows first; behind the LAST pass's reads the tiles are dead for this wave and it says
-                // so (holding the second pass's rows in registers through the first one would let the twelve signal at once, but
-                // costs 16 registers the kernel does not have: 212 bytes per lane of scratch)
-                bool viol = false;
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    if (ps == 1 && !doubler) break;             // wave-uniform
-                    sched_fence();                              // (the second pass's reads stay behind the first pass: registers)
-                    set_pass(w + ps * kLoaders);
-                    float bc[2][4];
-                    uint2 hq[2], hk[2], hv[2], gr[2];
-                    read_raw(hq, hk, hv);
-                    if (nrem >= C) write_vT(FullT{}, hv, C); else write_vT(PartT{}, hv, n);
-                    sched_fence();
-                    read_g(gr);                                 // the gates last (as the scan of the sixteen-wave form does): registers
-                    if (ps == (doubler ? 1 : 0)) {
-                        cfence();
-                        if (lane == 0) lds_signal_add(&s_cons, 1);  // (the LDS serves a wave's operations in order: applied after the reads)
-                    }
-                    if (nrem >= C) viol |= gate_scan_of(FullT{}, PartT{}, gr, bc, nrem);
-                    else viol |= gate_scan_of(PartT{}, PartT{}, gr, bc, nrem);
-                    if (nrem >= C) write_tiles(FullT{}, bc, C, par, En, zq, hq, hk, hv);
-                    else write_tiles(PartT{}, bc, n, par, En, zq, hq, hk, hv);
-                }
-                if (viol) s_flags[2 * par] = 1;
-                set_pass(w);
-                if (doubler) wave_priority<0>();
-            } else if (early) {
-                // the raw tiles are free once the twelve working waves have signalled.  Optimistic chunk length (a cut fetches again)
-                lds_wait_ge(&s_cons, (kDmaWave0) * (chunk_no + 1));
-                dma_chunk(t0 + n, 0, 4);
-            }
-        } else {
+        {
             float bc[2][4];
             uint2 hq[2], hk[2], hv[2];
             if constexpr (MODE == 0) {
@@ -587,78 +521,32 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         K2_PROF(10);
         __syncthreads();   // (2) operand tiles ready; raw q,k,g,v consumed
         K2_PROF(1);
-        lane = lane_id_here(); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; rp = lane & 15; ch0 = 16 * w + 4 * (lane >> 4);
+        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4; rp = lane & 15; ch0 = 16 * w + 4 * (lane >> 4);
         uint2 fl = *reinterpret_cast<const uint2*>(&s_flags[2 * par]);   // workgroup-uniform
         float rn = tid < DK ? s_Rn[tid] : 0.0f;                 // for the roll of R below, fetched in the same round trip
         if (fl.x) {
             // ---- rare: the decay inside this chunk exceeds e^-60 -> cut the chunk at the first such row ----
-            if (early) {
-                // the early prefetch is overwriting the raw tiles with the NEXT chunk: let it land, then fetch THIS chunk again
-                // (the next chunk is requested again below, from the cut position)
-                wait_vmem();
-                __syncthreads();
-                dma_chunk(t0, 0, 4);
-                wait_vmem();
-                __syncthreads();
+            float bc[2][4];
+            gate_scan(PartT{}, FullT{}, bc, nrem);             // (with the clamp)
+            int nc = C;
+#pragma unroll
+            for (int rr = 1; rr >= 0; --rr) {
+                bool bad = false;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bad |= (-bc[rr][c] > kFullMaxDecay);
+                if (bad) nc = 2 * rp + rr;
             }
-            if constexpr (SKIPA) {
-                int nc = C;
-                const int npass = (SKIPA && loader) ? 0 : (doubler ? 2 : 1);
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    if (ps >= npass) break;                        // wave-uniform
-                    set_pass(w + ps * kLoaders);
-                    float bc[2][4];
-                    gate_scan(PartT{}, FullT{}, bc, nrem);         // (with the clamp)
-#pragma unroll
-                    for (int rr = 1; rr >= 0; --rr) {
-                        bool bad = false;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) bad |= (-bc[rr][c] > kFullMaxDecay);
-                        if (bad) nc = min(nc, 2 * rp + rr);
-                    }
-                }
-                // first bad row of the workgroup through ONE LDS atomic (a shuffle reduction here made the compiler keep its six
-                // lane-permutation addresses live across the whole main loop)
-                if (nc < C) lds_atomic_max(&s_cut, C - nc);
-                __syncthreads();
-                n = max(min(n, C - s_cut), 1);
-                __syncthreads();   // everyone has read s_cut; the optimistic tiles are dead
-                if (tid == 0) { int z = 0; opaque(z); s_cut = z; }
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    if (ps >= npass) break;
-                    set_pass(w + ps * kLoaders);
-                    float bc[2][4];
-                    gate_scan(PartT{}, FullT{}, bc, nrem);         // (the clamped scan again: nothing is carried across the barriers)
-                    uint2 hq[2], hk[2], hv[2];
-                    if constexpr (MODE == 0) { read_raw(hq, hk, hv); write_vT(PartT{}, hv, n); }
-                    write_tiles(PartT{}, bc, n, par, En, zq, hq, hk, hv);
-                }
-                set_pass(w);
-            } else {
-                float bc[2][4];
-                gate_scan(PartT{}, FullT{}, bc, nrem);             // (with the clamp)
-                int nc = C;
-#pragma unroll
-                for (int rr = 1; rr >= 0; --rr) {
-                    bool bad = false;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) bad |= (-bc[rr][c] > kFullMaxDecay);
-                    if (bad) nc = 2 * rp + rr;
-                }
-                // first bad row of the workgroup through ONE LDS atomic (a shuffle reduction here made the compiler keep its six
-                // lane-permutation addresses live across the whole main loop)
-                if (nc < C) lds_atomic_max(&s_cut, C - nc);
-                __syncthreads();
-                n = max(min(n, C - s_cut), 1);
-                __syncthreads();   // everyone has read s_cut; the optimistic tiles are dead
-                if (tid == 0) { int z = 0; opaque(z); s_cut = z; }
-                {
-                    uint2 hq[2], hk[2], hv[2];
-                    if constexpr (MODE == 0) { read_raw(hq, hk, hv); write_vT(PartT{}, hv, n); }
-                    write_tiles(PartT{}, bc, n, par, En, zq, hq, hk, hv);
-                }
+            // first bad row of the workgroup through ONE LDS atomic (a shuffle reduction here made the compiler keep its six
+            // lane-permutation addresses live across the whole main loop)
+            if (nc < C) lds_atomic_max(&s_cut, C - nc);
+            __syncthreads();
+            n = max(min(n, C - s_cut), 1);
+            __syncthreads();   // everyone has read s_cut; the optimistic tiles are dead
+            if (tid == 0) { int z = 0; opaque(z); s_cut = z; }
+            {
+                uint2 hq[2], hk[2], hv[2];
+                if constexpr (MODE == 0) { read_raw(hq, hk, hv); write_vT(PartT{}, hv, n); }
+                write_tiles(PartT{}, bc, n, par, En, zq, hq, hk, hv);
             }
             __syncthreads();
             fl.y = s_flags[2 * par + 1];                       // the rewritten tiles may have changed both
@@ -668,7 +556,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         const bool more = t0 + n < T;
         // (the loader waves interleaving their 16 DMA instructions with their own step-(1) MFMAs instead: 0.644 ms vs 0.592 --
         //  the pieces land later and everybody waits at (3); measured round 2, tests/gpu_k2var.sh)
-        if (more && (!early || fl.x)) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);   // next chunk's raw q,k,g,v fly under phase B (SKIPA: already in flight)
+        if (more) dma_chunk(t0 + n, STATE_ONLY ? 1 : 0, 4);   // next chunk's raw q,k,g,v fly under phase B
         if (STATE_ONLY && w == 0) {                                    // s_dec is stable between barriers (2) and (3)
             const float4 d = *reinterpret_cast<const float4*>(&s_dec[4 * lane]);
             decp.x *= d.x; decp.y *= d.y; decp.z *= d.z; decp.w *= d.w;
@@ -849,7 +737,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         K2_PROF(8);
         __syncthreads();   // (3) ... and so has everybody's; operand tiles dead; mask(A) complete (its own buffer)
         K2_PROF(9);
-        lane = lane_id_here(); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;   // re-derive, do not carry
+        lane = lane_id(); opaque(lane); tid = w * 64 + lane; li = lane & 15; lg = lane >> 4;   // re-derive, do not carry
         if (tid == 0) {                                        // read by all before (3); set again two chunks later, after (2) of the next
             int z = 0;
             opaque(z);                                         // materialised here: hoisted out of the loop the constant was SPILLED
@@ -877,10 +765,9 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
         }
         par ^= 1;
         t0 += n;
-        ++chunk_no;
         if constexpr (REV) gate_zero0 = false;
     }
-    lane = lane_id_here(); li = lane & 15; lg = lane >> 4;
+    lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
     store_prev();                                              // the last chunk (T >= 1)
 #ifdef LINA_K2_PROF
     if (blockIdx.x == 0 && lane_id() == 0)

@@ -158,33 +158,11 @@ __device__ __forceinline__ int ticket_agent(int* counter) {
 // SGPR: together they let a kernel re-derive threadIdx.x anywhere instead of carrying it in (or spilling it from) a VGPR
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// ... recomputed WHERE IT STANDS (volatile: neither hoisted out of a loop nor merged with another call -- the builtin form is pure, so
-// the compiler computes it once in front of a loop and carries, or spills, the register)
-__device__ __forceinline__ int lane_id_here() {
-    int x;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
-    return x;
-}
 
 // Workgroup barrier that orders LDS traffic only (ds_* via lgkmcnt) and leaves global / LDS-DMA operations in flight:
 // __syncthreads() also drains vmcnt, i.e. it would wait for an asynchronous global->LDS prefetch that nobody reads yet.
 // Use it only where no wave touches the DMA destination before the next full __syncthreads().
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// One-way signalling between the waves of a workgroup through an LDS counter, without a barrier.  The LDS serves a wave's
-// operations in issue order, so an add placed after a wave's reads is applied after them; the waiting wave polls (all its lanes
-// read the same word; the value is made wave-uniform so that the loop is a scalar branch).
-__device__ __forceinline__ void lds_signal_add(int* p, int v) {
-    asm volatile("ds_add_u32 %0, %1" ::"v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)p), "v"(v) : "memory");
-}
-// (bounded: ~2^20 polls of >= 64 clocks = tens of milliseconds -- a signal that never comes then shows as wrong results in a
-// parity test, not as a hung GPU)
-__device__ __forceinline__ void lds_wait_ge(const int* p, int target) {
-    for (int spin = 0; spin < (1 << 20); ++spin) {
-        if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(p)) >= target) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
 
 // value of lane (l - n) of the same 16-lane row, 0 for the first n lanes of a row (v_*_dpp row_shr:n, bound_ctrl): one VALU
 // modifier instead of a ds_bpermute -- the building block of a 16-wide scan
@@ -240,8 +218,6 @@ __device__ __forceinline__ void cfence() { asm volatile("" ::: "memory"); }
 // (and being spilled from) VGPRs across the whole loop
 __device__ __forceinline__ void opaque(int& x) { asm volatile("" : "+v"(x)); }
 
-// the same for a wave-uniform value held in an SGPR
-__device__ __forceinline__ void opaque_s(int& x) { asm volatile("" : "+s"(x)); }
 // the same for the raw bits of a prefetched operand (uint2 / float4 / uint4): placed AFTER a main loop it pins the bf16 -> fp32
 // conversion (a USE of the loaded registers, i.e. a wait for the prefetch) behind the loop -- the compiler otherwise hoists the
 // conversion to right behind the loads and the kernel waits for its epilogue operands before it starts

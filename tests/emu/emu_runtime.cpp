@@ -52,10 +52,6 @@ void dma_flush_mine() {
 
 static void yield() { swapcontext(&cur->ctx, &sched_ctx); }
 
-// a lane that polls an LDS word written by another wave (lds_wait_ge): hand the processor on; the scheduler pass counts as
-// progress (the poll itself bounds nothing -- a kernel whose signal never comes spins here forever, as on the hardware)
-void yield_fiber() { ++progress; yield(); }
-
 void syncthreads() {
     const unsigned g = bar_gen;
     if (++bar_count == (int)fibers.size()) {

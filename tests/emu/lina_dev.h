@@ -60,7 +60,6 @@ extern unsigned char* g_dyn_smem;
 const dim3& cur_tid();
 int cur_lane();
 void syncthreads();
-void yield_fiber();
 bool dma_late();
 void dma_defer(void* dst, const void* src);
 void dma_flush_mine();
@@ -283,14 +282,8 @@ static inline float2 ld_agent8(const float* p) { return make_float2(p[0], p[1]);
 static inline void drain_stores() {}
 static inline int ticket_agent(int* counter) { return (*counter)++; }
 
-// fibers are cooperative: the add is atomic; a waiting lane hands the processor on until the counter is there
-static inline void lds_signal_add(int* p, int v) { *p += v; }
-static inline void lds_wait_ge(const int* p, int target) {
-    while (*reinterpret_cast<const volatile int*>(p) < target) lina_emu::yield_fiber();
-}
 static inline void lds_barrier() { lina_emu::syncthreads(); }
 static inline int lane_id() { return lina_emu::cur_lane(); }
-static inline int lane_id_here() { return lina_emu::cur_lane(); }
 static inline int wave_uniform(int v) { return v; }
 
 template <int N>
@@ -323,7 +316,6 @@ static inline void opaque(int& x) { asm volatile("" : "+r"(x)); }
 
 static inline float4 ld_nt4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static inline void st_nt4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-static inline void opaque_s(int&) {}
 static inline void opaque_raw(uint2&) {}
 static inline void opaque_raw(uint4&) {}
 static inline void opaque_raw(float4&) {}
