@@ -602,9 +602,10 @@ class DecodeEngine:
             # a configuration owns its logs (att log: B x 2 x cap x T_txt, ~134 MB at B = 512) and two hipGraphs; callers that
             # sweep k / temp (captured kernel arguments) or, on the unfused pick path, the seed would otherwise grow the set
             # without bound: keep the MAX_LOOPS most recently used (dropped here, outside any stream capture)
-            loop = None
+            if loop is not None:
+                self._drop_loop(loop)                        # (too short: rebuilt with longer logs)
             while len(self._loops) >= self.MAX_LOOPS:
-                self._loops.pop(next(iter(self._loops)))
+                self._drop_loop(self._loops.pop(next(iter(self._loops))))
             loop = self._build_loop(key, max_steps, lazy)
         self._loops[key] = loop                              # most recently used last
         self._loop = loop
@@ -715,12 +716,18 @@ class DecodeEngine:
 
     MAX_LOOPS = 4            # captured loop configurations kept per engine (least recently used dropped first)
 
+    @staticmethod
+    def _drop_loop(L):
+        """A loop's body closes over the loop object (a reference cycle): cut it, so that its logs and hipGraphs go NOW -- outside
+        any stream capture -- and not whenever the cyclic collector runs."""
+        L.body = L.graph1 = L.graphN = L.att = L.tok_log = L.att_log = L.ctl = L.hid_log = None
+
     def close(self):
         """Release the engine's device memory and hipGraphs now.  An engine is a reference cycle (its loop bodies close over
         it), so dropping the last reference frees nothing until a later pass of Python's cyclic collector -- at B = 512 that
         is ~7 GB of state and logs lingering after a cache eviction.  The engine is unusable afterwards."""
         for L in self._loops.values():
-            L.body = L.graph1 = L.graphN = L.att = L.tok_log = L.att_log = L.ctl = L.hid_log = None
+            self._drop_loop(L)
         self._loops.clear()
         self._loop = self._graph = self._att_direct = None
         for part in self.parts:

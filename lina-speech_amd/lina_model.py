@@ -91,19 +91,23 @@ class LinaModel(nn.Module):
         return st
 
     def clear_decode_cache(self):
-        """Drop the cached decode engines (packed weights, static buffers, captured hipGraphs) NOW.  Not needed for
-        correctness: the cache key carries a content fingerprint of every parameter (``_weights_fingerprint``), so any
-        change of the weights -- optimizer steps, ``load_state_dict``, writes through ``param.data``, in-place writes to
-        inference-mode parameters -- builds a new engine by itself."""
+        """Drop the cached decode engines (packed weights, static buffers, captured hipGraphs) NOW.  Rarely needed for
+        correctness: the cache key carries every parameter's (storage, version) AND a content fingerprint
+        (``_weights_fingerprint``), so optimizer steps, ``load_state_dict``, writes through ``param.data`` and in-place
+        writes to inference-mode parameters build a new engine by themselves."""
         for eng in self.__dict__.pop("_decode_engines", {}).values():
             eng.close()
 
+    _FINGERPRINT_ELEMS = 4096
+
     def _weights_fingerprint(self):
-        """Two numbers per parameter -- the L2 norm of the tensor and of its positive part (the second one tells a sign flip
-        apart) -- from three multi-tensor kernels and one 8-byte-per-parameter read-back (~0.5 ms for L169): a (storage,
-        version) key alone does not see ``param.data`` writes (EMA swaps) or in-place writes to parameters made under
-        ``torch.inference_mode`` (no version counter), and a stale engine would silently decode with the old packed weights."""
-        ps = [p.detach() for p in self.parameters()]
+        """Two numbers per parameter -- the L2 norm of its first ``_FINGERPRINT_ELEMS`` elements and of their positive part (the
+        second one tells a sign flip apart) -- from multi-tensor kernels over views and one 8-byte-per-parameter read-back: the
+        (storage, version) part of the cache key does not see ``param.data`` writes (EMA swaps, hand-edited weights) or in-place
+        writes to parameters made under ``torch.inference_mode`` (no version counter), and a stale engine would silently decode
+        with the old packed weights.  (A write that leaves the first 4096 elements of EVERY tensor, their storage and their
+        version counters untouched is still missed: ``clear_decode_cache()`` after such surgery.)"""
+        ps = [p.detach().reshape(-1)[:self._FINGERPRINT_ELEMS] for p in self.parameters()]
         if not ps:
             return ()
         stats = torch._foreach_norm(ps) + torch._foreach_norm(torch._foreach_clamp_min(ps, 0))
@@ -113,11 +117,12 @@ class LinaModel(nn.Module):
         """The DecodeEngine of (batch size, text length, dtype, device, current weights), built once and re-armed for
         every later ``generate_batch`` call of the same shape: construction packs 0.3 GB of weights and captures two
         hipGraphs (~0.6 k kernel nodes), far more than a call at B = 64 should pay.  "Current weights" = every
-        parameter's storage address AND a content fingerprint (see ``_weights_fingerprint``)."""
+        parameter's (storage, version) AND a content fingerprint (see ``_weights_fingerprint``)."""
         from .decode import DecodeEngine, DecodeEngineGroup
         w = self.logits_head.weight
         key = (B, int(n_engines), int(x_enc.shape[1]), w.dtype, str(w.device), str(state_dtype),
-               tuple(p.data_ptr() for p in self.parameters()), self._weights_fingerprint())
+               tuple((p.data_ptr(), -1 if p.is_inference() else p._version) for p in self.parameters()),
+               self._weights_fingerprint())
         cache = self.__dict__.setdefault("_decode_engines", {})
         eng = cache.pop(key, None)
         if eng is None:
