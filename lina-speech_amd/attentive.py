@@ -71,34 +71,15 @@ class AttentiveGLA(AttentiveRNN):
         kw = dict(use_cache=init_state is not None, past_key_values=init_state)
         # the blocks are chained on (stream, pending branch): a block's last residual add rides in the next block's first
         # norm pass instead of a pass of its own (MixingBlock.forward); the values are those of the plain loop
-        from . import ops
-        blocks = list(self.encoder) + list(self.decoder)
-        # train path with ``ops.wgrad_overlap`` on: the GEMM weights of block j go behind ``_DelayGrad`` nodes created BEFORE
-        # the forward of block j - 1, so that their gradients (computed on a second HIP stream) are joined one block late
-        # in the backward and the GEMMs run beside the memory-bound backward of block j - 1 (autograd.py)
-        delay = self.training and "GRAD_CKPT" not in os.environ and ops.wgrad_overlap()
-        gated = {}
-        if delay:
-            ops.wgrad_join()
-            gated[0] = ops.delayed_params(blocks[0])
-        pend = att = None
-        for j, blk in enumerate(blocks):
-            if j == len(self.encoder):                          # between the two stacks
-                if pend is not None:
-                    x = x + pend
-                v, att = self.cross_att(x, ctx, mask=mask, reset_mask=reset_mask, pos=crossatt_pos)
-                pend = v                                        # x + v: added by the first decoder block's norm
-            if delay and j + 1 < len(blocks):
-                gated[j + 1] = ops.delayed_params(blocks[j + 1])
-            g = gated.pop(j, None)
-            if g is not None:
-                x, pend = torch.func.functional_call(blk, g, (x,), dict(_pending=pend, _defer=True, **kw))
-            else:
-                x, pend = (_maybe_grad_ckpt(blk) if self.training else blk)(x, _pending=pend, _defer=True, **kw)
-        if len(blocks) == len(self.encoder):                    # (no decoder blocks: the cross-attention closes the stack)
-            if pend is not None:
-                x = x + pend
-            pend, att = self.cross_att(x, ctx, mask=mask, reset_mask=reset_mask, pos=crossatt_pos)
+        pend = None
+        for blk in self.encoder:
+            x, pend = (_maybe_grad_ckpt(blk) if self.training else blk)(x, _pending=pend, _defer=True, **kw)
+        if pend is not None:
+            x = x + pend
+        v, att = self.cross_att(x, ctx, mask=mask, reset_mask=reset_mask, pos=crossatt_pos)
+        pend = v                                                # x + v: added by the first decoder block's norm
+        for blk in self.decoder:
+            x, pend = (_maybe_grad_ckpt(blk) if self.training else blk)(x, _pending=pend, _defer=True, **kw)
         if pend is not None:
             x = x + pend
         return x, att

@@ -40,7 +40,6 @@ class _GLAFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_o, d_ht):
-        wgrad_flush()                         # K2b, conv and gate backward follow: no GEMM on the main stream for a while
         q, k, v, gk, h0, ht, *seg_ws = ctx.saved_tensors
         seg_ws = None if not seg_ws else (seg_ws[0] if len(seg_ws) == 1 else seg_ws)
         if d_o is None:                                   # only the final state was used downstream
@@ -260,7 +259,6 @@ class _RMSNormGateFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        wgrad_flush()                         # (see _wgrad_async: the GEMM-free stretch of a block's backward starts here)
         x, g, w = ctx.saved_tensors
         be = _backend._BACKEND
         rows, D = x.shape
@@ -490,139 +488,12 @@ def linear_weight_grad(dy2, x2, split=None):
     return torch.bmm(dy2.view(S, rows // S, n_out).transpose(1, 2), x2.view(S, rows // S, n_in), **f32).sum(0)
 
 
-# --------------------------------------------------------------------------- weight gradients beside the backward chain
-# The weight-gradient GEMMs of a block (dW = dY^T X: MFMA-bound, ~0.9 ms per L169 block at b = 8 x 4096) feed nothing but the
-# optimizer, while the backward chain that continues on the main stream is mostly memory-bound (norm / conv / gate / K2b
-# passes).  With ``wgrad_overlap`` on, a projection whose weight went through ``delay_grad`` computes its dW on a SECOND HIP
-# stream and hands the tensor on un-joined; the ``_DelayGrad`` node in front of the parameter waits for it.  That node is
-# created one block AHEAD in the forward (``delayed_params`` from the stack's loop), so autograd -- which runs the ready node
-# with the highest sequence number first -- reaches it only after the backward of the NEXT-earlier block has been enqueued:
-# the dW GEMMs of block j run beside the backward of block j - 1.  Values are those of the serial order (same kernels, same
-# operands); measured on one MI355X: profiles/r06_wgrad_overlap.txt.
-class _WgradOverlap:
-    enabled = False
-    streams: dict = {}          # device index -> side stream
-    events: dict = {}           # storage address of an un-joined gradient -> event recorded behind its last kernel
-    pending: list = []          # (closure, inputs, preallocated results) not yet launched on the side stream
-
-
-def wgrad_overlap(on: Optional[bool] = None) -> bool:
-    """Switch (``on`` given) / read the side-stream weight-gradient mode.  Off by default: ``train.TrainStep`` turns it on
-    around its forward on ROCm devices."""
-    if on is not None:
-        _WgradOverlap.enabled = bool(on)
-    return _WgradOverlap.enabled
-
-
-def wgrad_join() -> None:
-    """Make the current stream wait for every weight gradient still running on a side stream (``TrainStep.step`` calls this
-    between ``backward()`` and the optimizer; the ``_DelayGrad`` nodes have already waited for their own)."""
-    wgrad_flush()
-    for idx, st in _WgradOverlap.streams.items():
-        torch.cuda.current_stream(idx).wait_stream(st)
-    _WgradOverlap.events.clear()
-
-
-class _DelayGrad(torch.autograd.Function):
-    """Identity on a parameter; its backward is where the main stream joins the side stream that produced the gradient."""
-
-    @staticmethod
-    def forward(ctx, w):
-        return w.view_as(w)
-
-    @staticmethod
-    def backward(ctx, g):
-        if g is not None and g.is_cuda:
-            ptr = g.untyped_storage().data_ptr()
-            if any(o is not None and o.untyped_storage().data_ptr() == ptr for _, _, outs in _WgradOverlap.pending for o in outs):
-                wgrad_flush()                  # (the tail of the backward: nothing else will launch what is still queued)
-            ev = _WgradOverlap.events.get(ptr)
-            if ev is not None:
-                torch.cuda.current_stream(g.device).wait_event(ev)
-        return g
-
-
-def delay_grad(w):
-    """``w`` behind a ``_DelayGrad`` node, marked so that ``linear`` / ``swiglu_mlp`` may leave its gradient un-joined."""
-    out = _DelayGrad.apply(w)
-    out._lina_delayed = True
-    return out
-
-
-_DELAYED_NAMES = ("tmix.q_proj.weight", "tmix.k_proj.weight", "tmix.v_proj.weight", "tmix.g_proj.weight",
-                  "tmix.gk_proj.0.weight", "tmix.o_proj.weight", "cmix.p_in.weight", "cmix.p_out.weight", "cmix.p_out.bias")
-
-
-def delayed_params(block) -> Optional[dict]:
-    """{parameter name: delayed view} for the GEMM weights of a ``MixingBlock`` (``torch.func.functional_call(block, d, ...)``
-    runs the block on them), or None when the mode is off / not applicable.  Call it BEFORE the forward of the block in
-    front (see above)."""
-    if not (_WgradOverlap.enabled and torch.is_grad_enabled()):
-        return None
-    out = {}
-    for name in _DELAYED_NAMES:
-        mod = block
-        try:
-            *path, leaf = name.split(".")
-            for a in path:
-                mod = getattr(mod, a) if not a.isdigit() else mod[int(a)]
-            w = getattr(mod, leaf)
-        except (AttributeError, IndexError, TypeError):
-            continue
-        if isinstance(w, torch.nn.Parameter) and w.requires_grad and fused_ops_available(w):
-            out[name] = delay_grad(w)
-    return out or None
-
-
-def is_delayed(*ws) -> bool:
-    return bool(ws) and all(getattr(w, "_lina_delayed", False) for w in ws)
-
-
-def _wgrad_async(fn, inputs, like):
-    """Defer ``fn`` (torch ops only; returns a tensor or a tuple of tensors) to the device's side stream.  The results are
-    allocated NOW (``like``: a (shape, dtype) per result; the closure's values are copied in), the closure itself is queued and
-    launched by ``wgrad_flush`` -- called where the main stream enters a stretch without GEMMs (the backward of the norm-gate /
-    K2b / conv / gate kernels of a block), so that the GEMMs run beside memory-bound work and not beside the dX GEMMs that
-    follow a projection's backward directly."""
-    dev = inputs[0].device
-    outs = tuple(None if spec is None else torch.empty(spec[0], dtype=spec[1], device=dev) for spec in like)
-    _WgradOverlap.pending.append((fn, tuple(inputs), outs))
-    return outs if len(outs) > 1 else outs[0]
-
-
-def wgrad_flush() -> None:
-    """Launch the queued weight-gradient closures on the side stream, behind everything enqueued on the current stream."""
-    if not _WgradOverlap.pending:
-        return
-    pend, _WgradOverlap.pending = _WgradOverlap.pending, []
-    cur = torch.cuda.current_stream()
-    st = _WgradOverlap.streams.get(cur.device_index)
-    if st is None:
-        st = _WgradOverlap.streams[cur.device_index] = torch.cuda.Stream(device=cur.device)
-    st.wait_stream(cur)
-    with torch.cuda.stream(st):
-        for fn, inputs, outs in pend:
-            res = fn()
-            for o, r in zip(outs, res if isinstance(res, tuple) else (res,)):
-                if o is not None:
-                    o.copy_(r)
-        ev = torch.cuda.Event()
-        ev.record(st)
-    for fn, inputs, outs in pend:
-        for t in inputs:
-            t.record_stream(st)               # the allocator may hand their memory out again only behind the side stream's use
-        for o in outs:
-            if o is not None:
-                o.record_stream(st)
-                _WgradOverlap.events[o.untyped_storage().data_ptr()] = ev
-
-
 class _LinearFunction(torch.autograd.Function):
     """y = x W^T + b in the GEMM dtype (the autocast dtype when autocast is on, like F.linear under autocast); backward:
     dX on the library GEMM, dW by ``linear_weight_grad``, db as the fp32-accumulated column sum."""
 
     @staticmethod
-    def forward(ctx, x, w, b, async_w=False):
+    def forward(ctx, x, w, b):
         cd = x.dtype
         if x.is_cuda and torch.is_autocast_enabled("cuda"):
             cd = torch.get_autocast_dtype("cuda")
@@ -631,7 +502,6 @@ class _LinearFunction(torch.autograd.Function):
             y = F.linear(xc, wc, None if b is None else b.to(cd))
         ctx.save_for_backward(xc, wc)
         ctx.meta = (x.dtype, w.dtype, None if b is None else b.dtype)
-        ctx.async_w = bool(async_w) and x.is_cuda
         return y
 
     @staticmethod
@@ -646,14 +516,10 @@ class _LinearFunction(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = torch.mm(dy2, wc).view(xc.shape).to(xdt)
             if ctx.needs_input_grad[1]:
-                dyc, x2c = dy2.contiguous(), x2.contiguous()
-                if ctx.async_w:                # the weight sits behind a _DelayGrad node: leave the gradient on the side stream
-                    dw = _wgrad_async(lambda: linear_weight_grad(dyc, x2c), (dyc, x2c), [((n_out, n_in), wdt)])
-                else:
-                    dw = linear_weight_grad(dyc, x2c).to(wdt)
+                dw = linear_weight_grad(dy2.contiguous(), x2.contiguous()).to(wdt)
             if bdt is not None and ctx.needs_input_grad[2]:
                 db = column_sum(dy2.contiguous()).to(bdt)
-        return dx, dw, db, None
+        return dx, dw, db
 
 
 def linear(x, weight, bias=None):
@@ -661,7 +527,7 @@ def linear(x, weight, bias=None):
     included), weight gradient posed as a token-split batched GEMM in fp32.  Without gradients: F.linear itself."""
     if not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)) or x.dim() < 2:
         return F.linear(x, weight, bias)
-    return _LinearFunction.apply(x, weight, bias, is_delayed(weight))
+    return _LinearFunction.apply(x, weight, bias)
 
 
 class _SwiGLUMLPFunction(torch.autograd.Function):
@@ -675,9 +541,8 @@ class _SwiGLUMLPFunction(torch.autograd.Function):
     bias epilogue, no column sum.  The up-projection's bias gradient is summed inside the gate's backward (K11c)."""
 
     @staticmethod
-    def forward(ctx, x, w_in, b_in, w_out, b_out, async_w=False):
+    def forward(ctx, x, w_in, b_in, w_out, b_out):
         be = _backend._BACKEND
-        ctx.async_w = bool(async_w) and x.is_cuda
         cd = x.dtype
         if x.is_cuda and torch.is_autocast_enabled("cuda"):
             cd = torch.get_autocast_dtype("cuda")
@@ -703,32 +568,21 @@ class _SwiGLUMLPFunction(torch.autograd.Function):
         be = _backend._BACKEND
         d_out, d_in = Wo.shape[0], x2.shape[1]
         M = x2.shape[0]
-
-        def grads_out(dy2):                                                          # [d_out, Hp] fp32; column H = db_out
-            dWo = linear_weight_grad(dy2, h)
-            return dWo[:, :H].to(wodt), (None if bodt is None else dWo[:, H].to(bodt))
-
-        def grads_in(du):
-            return linear_weight_grad(du, x2).view(2, Hp, d_in)[:, :H].reshape(2 * H, d_in).to(widt)
-
         with torch.autocast(x2.device.type, enabled=False):
             dy2 = dy.reshape(M, d_out).to(x2.dtype).contiguous()
-            if ctx.async_w:           # both weight gradients on the side stream, beside the chain dh -> gate backward -> dx
-                dw_out, db_out = _wgrad_async(lambda: grads_out(dy2), (dy2, h),
-                                              [((d_out, H), wodt), (None if bodt is None else ((d_out,), bodt))])
             dh = torch.mm(dy2, Wo)
+            dWo = linear_weight_grad(dy2, h)                                         # [d_out, Hp] fp32; column H = db_out
             du = torch.empty_like(u)
             part = torch.empty(int(be.lib.lina_swiglu_bwd_partials(M)), 2 * Hp, dtype=torch.float32, device=u.device)
             _check(be.lib.lina_swiglu_bwd_colsum(_ptr(dh), _ptr(u), _ptr(du), _ptr(part), M, Hp, u.stride(0), dh.stride(0),
                                                  du.stride(0), _dt(u), be.stream(u)))
-            if ctx.async_w:
-                dw_in = _wgrad_async(lambda: grads_in(du), (du, x2), [((2 * H, d_in), widt)])
             dx = torch.mm(du, Wi.view(2 * Hp, d_in)).view(x_shape).to(xdt) if ctx.needs_input_grad[0] else None
-            if not ctx.async_w:
-                dw_in = grads_in(du)
-                dw_out, db_out = grads_out(dy2)
+            dWi = linear_weight_grad(du, x2).view(2, Hp, d_in)
+            dw_in = dWi[:, :H].reshape(2 * H, d_in).to(widt)
             db_in = None if bidt is None else _sum_partials(part).view(2, Hp)[:, :H].reshape(2 * H).to(bidt)
-        return dx, dw_in, db_in, dw_out, db_out, None
+            dw_out = dWo[:, :H].to(wodt)
+            db_out = None if bodt is None else dWo[:, H].to(bodt)
+        return dx, dw_in, db_in, dw_out, db_out
 
 
 _MLP_PACK = WeakIdKeyDictionary()            # up-projection weight (the parameter OBJECT) -> (key, Wi, bi, Wo)
@@ -790,8 +644,7 @@ def swiglu_mlp(x, w_in, b_in, w_out, b_out):
     if not ok or cd not in (torch.float32, torch.bfloat16) or x.numel() == 0:
         return linear(swiglu_gate(linear(x, w_in, b_in)), w_out, b_out)
     _backend._BACKEND.require(x, w_in, w_out)
-    return _SwiGLUMLPFunction.apply(x, w_in, b_in, w_out, b_out,
-                                    is_delayed(w_in, w_out) and (b_out is None or is_delayed(b_out)))
+    return _SwiGLUMLPFunction.apply(x, w_in, b_in, w_out, b_out)
 
 
 class _GateLogSigmoidFunction(torch.autograd.Function):

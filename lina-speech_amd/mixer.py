@@ -131,11 +131,8 @@ class GatedLinearAttention(nn.Module):
                 # prefill / training: the five projections of the block input as ONE GEMM over the stacked weights
                 # (same columns, one pass over the activations, a 5136-wide GEMM instead of five narrow ones);
                 # the outputs are strided views of its result
-                parts = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.g_proj.weight,
-                         self.gk_proj[0].weight]
-                w_cat = torch.cat(parts, dim=0)
-                if ops.is_delayed(*parts):                      # all five behind _DelayGrad nodes: dW may stay on the side stream
-                    w_cat._lina_delayed = True
+                w_cat = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.g_proj.weight,
+                                   self.gk_proj[0].weight], dim=0)
                 # (training: the consumers of the slices write their input gradients into ONE slab -- no concat pass)
                 (q, k, v, g_pre, lr_pre), slab = ops.split_slab(ops.linear(hidden_states, w_cat), [
                     self.key_dim, self.key_dim, self.value_dim, self.value_dim, self.gk_proj[0].weight.shape[0]])

@@ -35,5 +35,4 @@ from .autograd import (
     _RMSNormGateFunction, _gate_rows_view, rmsnorm_swish_gate, rmsnorm, _LayerNormFunction, _LN_TRIPLES, layer_norm,
     _SwiGLUFunction, swiglu_gate, linear_weight_grad, _LinearFunction, linear, _SwiGLUMLPFunction, _MLP_ONE,
     _mlp_one, swiglu_mlp, clear_mlp_pack, _GateLogSigmoidFunction, gate_logsigmoid, _GateLowRankFunction, gate_lowrank,
-    _CrossEntropyFunction, cross_entropy, _EmbedSumFunction, embed_sum, wgrad_overlap, wgrad_join, wgrad_flush, delay_grad,
-    delayed_params, is_delayed)
+    _CrossEntropyFunction, cross_entropy, _EmbedSumFunction, embed_sum)

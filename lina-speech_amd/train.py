@@ -68,7 +68,7 @@ class TrainStep:
     def __init__(self, model: LinaModel, lr: float = 5e-4, weight_decay: float = 0.1, betas=(0.9, 0.999),
                  n_warmup_steps: int = 500, n_training_steps: int = 300000,
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16, device: Optional[torch.device] = None,
-                 grad_clip: Optional[float] = None, ddp: Optional[bool] = None, overlap_wgrad: Optional[bool] = None):
+                 grad_clip: Optional[float] = None, ddp: Optional[bool] = None):
         """Optimiser defaults are the reference's (train_lina.py:25-29,104-118): AdamW lr 5e-4, betas (0.9, 0.999),
         weight decay 0.1, cosine schedule with 500 warm-up steps over 300 000 steps, no gradient clipping.
         (Rounds 2-3 carried an opt-in ``graph=True`` -- the whole step as one hipGraph.  It replayed correctly only on some
@@ -78,9 +78,6 @@ class TrainStep:
         self.model = model.to(self.device).train()
         self.autocast_dtype = autocast_dtype
         self.grad_clip = grad_clip
-        # weight-gradient GEMMs on a second HIP stream beside the memory-bound backward of the next-earlier block
-        # (autograd.py ``wgrad_overlap``); default: on ROCm devices
-        self.overlap_wgrad = (self.device.type == "cuda") if overlap_wgrad is None else bool(overlap_wgrad)
         use_ddp = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) if ddp is None else ddp
         self.net = self.model
         if use_ddp:
@@ -102,16 +99,11 @@ class TrainStep:
 
     def loss(self, batch: Batch) -> torch.Tensor:
         kw = dict(logits_mask=batch.logits_mask, return_masked=False)
-        was = ops.wgrad_overlap()
-        ops.wgrad_overlap(self.overlap_wgrad)                # read by the forward only (the decision rides in the graph)
-        try:
-            if self.autocast_dtype is not None and self.device.type == "cuda":
-                with torch.autocast("cuda", dtype=self.autocast_dtype):
-                    out = self.net(batch.x, batch.y, batch.encoder_mask, batch.crossatt_mask, **kw)
-            else:
+        if self.autocast_dtype is not None and self.device.type == "cuda":
+            with torch.autocast("cuda", dtype=self.autocast_dtype):
                 out = self.net(batch.x, batch.y, batch.encoder_mask, batch.crossatt_mask, **kw)
-        finally:
-            ops.wgrad_overlap(was)
+        else:
+            out = self.net(batch.x, batch.y, batch.encoder_mask, batch.crossatt_mask, **kw)
         return out[1]
 
     def step(self, batch: Batch) -> torch.Tensor:
@@ -119,7 +111,6 @@ class TrainStep:
         self.opt.zero_grad(set_to_none=True)
         loss = self.loss(batch)
         loss.backward()                       # DDP: RCCL all-reduce (mean) of the buckets overlaps with backward
-        ops.wgrad_join()                      # (every delayed gradient was joined by its own node; this is the belt)
         if self.grad_clip is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
         self.opt.step()

@@ -113,43 +113,6 @@ def test_grad_ckpt_switch_gives_identical_loss_and_gradients(emu, monkeypatch):
         assert torch.equal(g0[n], g1[n]), n
 
 
-def test_delayed_weight_gradient_nodes_give_identical_loss_and_gradients(emu):
-    """ops.wgrad_overlap: the GEMM weights of a block run behind _DelayGrad nodes created one block ahead (functional_call on
-    the delayed views); off-device the gradients are computed in place, so loss and every gradient are those of the plain
-    graph -- and the nodes really are in the graph, one per delayed parameter."""
-    from lina_speech_amd import autograd as AG, ops
-    from lina_speech_amd.train import synthetic_batch
-    torch.manual_seed(0)
-    model = build_lina(d=64, n_layer=2).train()
-    batch = synthetic_batch(b=2, n=20, t_txt=9, n_codebook=253, seed=5)
-    made = []
-    orig = AG._DelayGrad.apply
-
-    def run(on):
-        model.zero_grad(set_to_none=True)
-        was = ops.wgrad_overlap()
-        ops.wgrad_overlap(on)
-        try:
-            loss = model(batch.x, batch.y, batch.encoder_mask, batch.crossatt_mask, logits_mask=batch.logits_mask)[1]
-        finally:
-            ops.wgrad_overlap(was)
-        loss.backward()
-        ops.wgrad_join()
-        return loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
-
-    l0, g0 = run(False)
-    AG._DelayGrad.apply = lambda w: (made.append(1), orig(w))[1]
-    try:
-        l1, g1 = run(True)
-    finally:
-        AG._DelayGrad.apply = orig
-    assert len(made) == 4 * len(AG._DELAYED_NAMES)             # 2 encoder + 2 decoder blocks
-    assert torch.equal(l0, l1) and set(g0) == set(g1)
-    for n in g0:
-        assert torch.equal(g0[n], g1[n]), n
-    assert not ops.wgrad_overlap()
-
-
 def test_train_step_defaults_follow_the_reference(emu):
     """train_lina.py:25-29,104-118: AdamW 5e-4, betas (0.9, 0.999), wd 0.1, cosine schedule with 500 warm-up steps."""
     from lina_speech_amd.train import TrainStep

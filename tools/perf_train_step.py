@@ -2,7 +2,7 @@
 issue a step (the Python call returns when everything is enqueued) and, under `rocprofv3 --kernel-trace --stats`, the kernel
 table of exactly WARM + STEPS steps (tools/prof_summary.py -> profiles/r05_train_step_kernel_stats.csv: launches per step =
 dispatches / (WARM + STEPS), GPU-busy time per step = total kernel time / (WARM + STEPS)).
-    python tools/perf_train_step.py [steps] [--no-overlap]"""
+    python tools/perf_train_step.py [steps]"""
 import json
 import os
 import sys
@@ -15,11 +15,10 @@ from lina_speech_amd import configs  # noqa: E402
 from lina_speech_amd.train import TrainStep, synthetic_batch  # noqa: E402
 
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5
-OVERLAP = "--no-overlap" not in sys.argv           # TrainStep(overlap_wgrad=): dW GEMMs on a second HIP stream (default on)
 WARM = 2
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
-ts = TrainStep(configs.l169(), device=dev, ddp=False, overlap_wgrad=OVERLAP)
+ts = TrainStep(configs.l169(), device=dev, ddp=False)
 batch = synthetic_batch(b=8, n=4097, t_txt=64, seed=1).to(dev)
 for _ in range(WARM):
     ts.step(batch)
@@ -31,7 +30,7 @@ for _ in range(STEPS):
     host.append(time.perf_counter() - h0)
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / STEPS
-print(json.dumps({"what": "L169 train step b=8 x 4096, bf16 autocast, eager launches", "overlap_wgrad": OVERLAP, "steps": STEPS, "warmup_steps": WARM,
+print(json.dumps({"what": "L169 train step b=8 x 4096, bf16 autocast, eager launches", "steps": STEPS, "warmup_steps": WARM,
                   "ms_per_step": wall * 1e3, "host_issue_ms_per_step": sum(host) / STEPS * 1e3,
                   "host_issue_ms_min_max": [min(host) * 1e3, max(host) * 1e3], "loss": float(loss),
                   "max_mem_GB": torch.cuda.max_memory_allocated() / 1e9}))
