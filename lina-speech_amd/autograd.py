@@ -231,6 +231,100 @@ def short_conv(x, weight, bias=None, mask=None, cache=None, activation: Optional
     return y
 
 
+def _adjacent_columns(ts):
+    """True when the tensors [B, T, D_i] are consecutive column slices of one row-major buffer (same strides, inner
+    contiguous, each starting where the previous one ends)."""
+    a = ts[0]
+    if a.dim() != 3 or a.stride(2) != 1:
+        return False
+    off = a.data_ptr()
+    for t in ts:
+        if (t.dim() != 3 or t.dtype != a.dtype or t.device != a.device or t.shape[:2] != a.shape[:2]
+                or t.stride() != a.stride() or t.data_ptr() != off):
+            return False
+        off += t.shape[2] * t.element_size()
+    return True
+
+
+class _ShortConv3Function(torch.autograd.Function):
+    """K3 / K3b over the q | k | v column slices of a stacked projection in ONE launch each way: the three slices are
+    adjacent columns of the same rows (6 KB contiguous per token at L169 instead of three 2 KB pieces in three launches), the
+    three depthwise filters are stacked to one [sum D_i, W] filter, the outputs are column slices of one buffer (the chunk
+    kernels take them strided) and so are the incoming gradients when K2b produced them (kernels.gla_chunk_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, x2, w0, w1, w2, b0, b1, b2, mask, act, grad_slab):
+        xs, ws, bs = (x0, x1, x2), (w0, w1, w2), (b0, b1, b2)
+        B, T, _ = x0.shape
+        sizes = [x.shape[2] for x in xs]
+        D = sum(sizes)
+        ctx.w_dtypes = [w.dtype for w in ws]
+        ctx.b_dtypes = [None if b is None else b.dtype for b in bs]
+        w = torch.cat([wi.reshape(wi.shape[0], -1) for wi in ws], dim=0).to(x0.dtype).contiguous()
+        bias = None if b0 is None else torch.cat(bs, dim=0).to(x0.dtype).contiguous()
+        x = x0.as_strided((B, T, D), x0.stride())              # the three slices as one [B, T, D] view of the same rows
+        ctx.save_for_backward(x, w, bias, mask)
+        ctx.act, ctx.sizes, ctx.grad_slab = act, sizes, grad_slab
+        y = _short_conv_launch(x, w, bias, mask, None, act)
+        return tuple(y.split(sizes, dim=-1))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, w, bias, mask = ctx.saved_tensors
+        B, T, D = x.shape
+        W = w.shape[1]
+        sizes = ctx.sizes
+        be = _backend._BACKEND
+        dys = [torch.zeros(B, T, n, dtype=x.dtype, device=x.device) if g is None else g.to(x.dtype)
+               for g, n in zip(dys, sizes)]
+        dy = dys[0].as_strided((B, T, D), dys[0].stride()) if _adjacent_columns(dys) else torch.cat(dys, dim=-1)
+        dx = None
+        if ctx.grad_slab is not None:                           # columns 0 .. D of the projection's gradient slab
+            slab, first = ctx.grad_slab
+            parts = [slab.part(first + i) for i in range(3)]
+            if (all(p.dtype == x.dtype and p.device == x.device and p.shape == (B, T, n) for p, n in zip(parts, sizes))
+                    and _adjacent_columns(parts)):
+                dx = parts[0].as_strided((B, T, D), parts[0].stride())
+                parts_out = parts
+        if dx is None:
+            dx = torch.empty(B, T, D, dtype=x.dtype, device=x.device)
+            parts_out = list(dx.split(sizes, dim=-1))
+        nblk = B * ((T + _lib.CONV_BWD_TT - 1) // _lib.CONV_BWD_TT)
+        part = torch.empty(nblk, D, W + 1, dtype=torch.float32, device=x.device)
+        _check(be.lib.lina_short_conv_bwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(mask), _ptr(dy), _ptr(dx), _ptr(part),
+                                          B, T, D, W, x.stride(0), x.stride(1), dy.stride(0), dy.stride(1),
+                                          dx.stride(0), dx.stride(1), ctx.act, _dt(x), be.stream(x)))
+        red = _sum_partials(part)
+        dws, dbs, o = [], [], 0
+        for n, wdt, bdt in zip(sizes, ctx.w_dtypes, ctx.b_dtypes):
+            dws.append(red[o:o + n, :W].to(wdt, copy=True))
+            dbs.append(None if bdt is None else red[o:o + n, W].to(bdt, copy=True))
+            o += n
+        return (*parts_out, *dws, *dbs, None, None, None)
+
+
+def short_conv3(xs, weights, biases, mask=None, activation: Optional[str] = "silu", grad_slab=None):
+    """``[short_conv(x_i, w_i, b_i, mask) for i in 0..2]`` for three column slices ``xs`` of one stacked projection (the
+    mixer's q | k | v, reference model/gla.py:161-163) in one launch each way, or None when the fused form does not apply
+    (the caller then runs the three convolutions).  ``grad_slab``: ``(GradSlab, index of xs[0])``."""
+    if not (len(xs) == 3 and _adjacent_columns(xs) and fused_ops_available(xs[0])):
+        return None
+    if activation not in ("silu", "swish", None):
+        return None
+    ws = [w.reshape(w.shape[0], -1) for w in weights]
+    if len({w.shape[1] for w in ws}) != 1 or any(w.shape[0] != x.shape[2] for w, x in zip(ws, xs)):
+        return None
+    if any(b is None for b in biases) != all(b is None for b in biases):
+        return None
+    if not _needs_grad(*xs, *ws, *biases):
+        return None
+    be = _backend._BACKEND
+    be.require(*xs, *ws, *biases, mask)
+    m = None if mask is None else mask.to(torch.float32).contiguous()
+    act = 1 if activation in ("silu", "swish") else 0
+    return _ShortConv3Function.apply(*xs, *ws, *biases, m, act, grad_slab)
+
+
 # --------------------------------------------------------------------------- norm (K5)
 class _RMSNormGateFunction(torch.autograd.Function):
     """K5 forward + K5b backward on contiguous rows x [rows, D]; the gate is [rows, D] or a strided [R, H, D] view (head

@@ -140,9 +140,12 @@ def gla_chunk_bwd(q, k, v, gk, d_o, scale, initial_state=None, final_state=None,
         if final_state is None:
             raise ValueError("a gradient for the final state needs the final state itself")
         dg_tail = (final_state.float() * dht).sum(-1).contiguous()
-    dq = _head_first_empty(B, H, T, Dk, q.dtype, q.device)
-    dk = _head_first_empty(B, H, T, Dk, q.dtype, q.device)
-    dv = _head_first_empty(B, H, T, Dv, q.dtype, q.device)
+    # dq | dk | dv as column slabs of ONE [B, T, H (2 Dk + Dv)] buffer: the backward of a fused q | k | v short convolution
+    # (autograd.short_conv3) reads them as a single operand; for anybody else they are three head-first tensors as before
+    qkv = torch.empty(B, T, H * (2 * Dk + Dv), dtype=q.dtype, device=q.device)
+    dq = qkv[..., :H * Dk].view(B, T, H, Dk).transpose(1, 2)
+    dk = qkv[..., H * Dk:2 * H * Dk].view(B, T, H, Dk).transpose(1, 2)
+    dv = qkv[..., 2 * H * Dk:].view(B, T, H, Dv).transpose(1, 2)
     dg = _head_first_empty(B, H, T, Dk, gk.dtype, q.device)
     dh0 = torch.empty(B, H, Dk, Dv, dtype=torch.float32, device=q.device) if need_dh0 else None
     path = path or POLICY.k2b_path

@@ -456,6 +456,50 @@ def check_split_slab(dev, B, T, H, D, dtype, in_place=True):
     assert slab.copied == ([1] if in_place else [0, 1, 2]), slab.copied
 
 
+def check_short_conv3(dev, B, T, H, D, dtype, use_bias=False, through_gla=True):
+    """short_conv3: the q | k | v convolutions of a stacked projection in one launch each way, feeding K2 / K2b through
+    STRIDED views of one output buffer and taking K2b's dq | dk | dv as one operand: outputs, dZ and the three filter (and
+    bias) gradients against torch autograd through the oracle conv + the oracle recurrence; the slab must be written in place
+    by the one launch (no copies) and the fused form must really have been taken."""
+    g = torch.Generator().manual_seed(31)
+    Kd, W = H * D, 4
+    z = torch.randn(B, T, 3 * Kd + 8, generator=g)
+    ws = [torch.randn(Kd, 1, W, generator=g) * 0.5 for _ in range(3)]
+    bs = [torch.randn(Kd, generator=g) * 0.1 if use_bias else None for _ in range(3)]
+    mask = (torch.rand(B, T, generator=g) > 0.1).float()
+    gk = (torch.nn.functional.logsigmoid(torch.randn(B, T, H, D, generator=g)) / 16)
+    do = torch.randn(B, T, H, D, generator=g).to(dtype)
+    dys = [torch.randn(B, T, Kd, generator=g).to(dtype) for _ in range(3)]
+    (mz, mgk, *mwb), (rz, rgk, *rwb) = _grad_pair(dev, dtype, z, gk, *ws, *bs)
+    sizes = [Kd, Kd, Kd, 8]
+    (q, k, v, rest), slab = ops.split_slab(mz, sizes)
+    out = ops.short_conv3((q, k, v), mwb[:3], mwb[3:], mask.to(dev), "silu", grad_slab=(slab, 0))
+    assert out is not None, "the fused form was refused"
+    heads = lambda t: t.view(B, T, H, D).transpose(1, 2)
+    rq, rk, rv, _ = rz.split(sizes, dim=-1)
+    rout = [O.short_conv(x, w, mask, None, activation="silu", bias=b) for x, w, b in zip((rq, rk, rv), rwb[:3], rwb[3:])]
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for a, b, n in zip(out, rout, "qkv"):
+        assert_close(a, b, tol, f"conv3 {n}")
+    if through_gla:
+        o, _ = ops.chunk_gla(heads(out[0]), heads(out[1]), heads(out[2]), heads(mgk))
+        (o.float() * heads(do.to(dev)).float()).sum().backward()
+        ro, _ = O.naive_recurrent_gla(heads(rout[0]), heads(rout[1]), heads(rout[2]), heads(rgk))
+        (ro * heads(do.float())).sum().backward()
+        tol = 5e-4 if dtype == torch.float32 else 4e-2
+    else:
+        sum((a.float() * d.to(dev).float()).sum() for a, d in zip(out, dys)).backward()
+        sum((a * d.float()).sum() for a, d in zip(rout, dys)).backward()
+    assert_close(mz.grad, rz.grad, tol, "conv3 dZ")
+    assert torch.count_nonzero(mz.grad[..., -8:]) == 0
+    for i in range(3):
+        assert mwb[i].grad.shape == ws[i].shape
+        assert_close(mwb[i].grad, rwb[i].grad, tol, f"conv3 dw{i}")
+        if use_bias:
+            assert_close(mwb[3 + i].grad, rwb[3 + i].grad, tol, f"conv3 db{i}")
+    assert slab.copied == [], slab.copied                      # q | k | v columns written in place by the ONE launch
+
+
 def check_embed_bwd(dev, Q, B, n, n_emb, d, dtype):
     g = torch.Generator().manual_seed(14)
     table = torch.randn(Q, n_emb, d, generator=g)

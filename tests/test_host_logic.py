@@ -113,6 +113,25 @@ def test_grad_ckpt_switch_gives_identical_loss_and_gradients(emu, monkeypatch):
         assert torch.equal(g0[n], g1[n]), n
 
 
+def test_training_forward_takes_the_fused_qkv_convolution(emu):
+    """mixer.py: with gradients, no cache and the stacked projection, the three depthwise convolutions run as ONE
+    short_conv3 node per block (autograd._ShortConv3Function) and the projection's gradient slab needs no copy for them."""
+    from lina_speech_amd import autograd as AG, ops
+    from lina_speech_amd.train import synthetic_batch
+    torch.manual_seed(0)
+    model = build_lina(d=64, n_layer=1).train()
+    batch = synthetic_batch(b=2, n=20, t_txt=9, n_codebook=253, seed=5)
+    calls, orig = [], AG._ShortConv3Function.apply
+    AG._ShortConv3Function.apply = lambda *a: (calls.append(1), orig(*a))[1]
+    try:
+        loss = model(batch.x, batch.y, batch.encoder_mask, batch.crossatt_mask, logits_mask=batch.logits_mask)[1]
+        loss.backward()
+    finally:
+        AG._ShortConv3Function.apply = orig
+    assert len(calls) == 3                                     # encoder block, decoder block, pos_net block
+    assert all(p.grad is not None for n, p in model.named_parameters() if "conv1d" in n)
+
+
 def test_train_step_defaults_follow_the_reference(emu):
     """train_lina.py:25-29,104-118: AdamW 5e-4, betas (0.9, 0.999), wd 0.1, cosine schedule with 500 warm-up steps."""
     from lina_speech_amd.train import TrainStep

@@ -385,6 +385,12 @@ def test_split_slab(emu, B, T, H, D, dtype, in_place):
     check_split_slab(DEV, B, T, H, D, dtype, in_place)
 
 
+@pytest.mark.parametrize("dtype,bias,through_gla", [(torch.float32, True, True), (torch.bfloat16, False, True), (torch.bfloat16, True, False)])
+def test_short_conv3_fused_qkv(emu, dtype, bias, through_gla):
+    from kernel_cases import check_short_conv3
+    check_short_conv3(DEV, 2, 70, 2, 64, dtype, bias, through_gla)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,T,C,L,clamp,bias,strided", [(2, 70, 64, 16, None, True, True), (1, 130, 40, 16, -0.2, True, False), (2, 33, 64, 7, None, False, False)])
 def test_gate_lowrank(emu, B, T, C, L, clamp, bias, strided, dtype):

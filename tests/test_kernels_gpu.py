@@ -448,6 +448,13 @@ def test_split_slab(hip, B, T, H, D, dtype, in_place):
     check_split_slab(DEV, B, T, H, D, dtype, in_place)
 
 
+@pytest.mark.parametrize("dtype,bias,through_gla", [(torch.float32, True, True), (torch.bfloat16, False, True), (torch.bfloat16, True, False)])
+@pytest.mark.parametrize("B,T,H,D", [(2, 70, 2, 64), (2, 515, 4, 256)])
+def test_short_conv3_fused_qkv(hip, B, T, H, D, dtype, bias, through_gla):
+    from kernel_cases import check_short_conv3
+    check_short_conv3(DEV, B, T, H, D, dtype, bias, through_gla)
+
+
 @pytest.mark.parametrize("n_out,n_in,bias", [(1024, 1365, True), (2730, 1024, True), (1024, 1024, False), (1024, 16, True),
                                              (4112, 1024, False)])
 def test_linear_train_path_under_autocast(hip, n_out, n_in, bias):
