@@ -338,43 +338,53 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 }
 
 // K13 -- second level of the two-level parameter-gradient sums: out[o][n] = sum_p part[o][p][n] (fp32 partials written by
-// K3b / K5b / K10b / K11c / K12b, one row per workgroup of those kernels).  These inputs are small (2-20 MB) and the sum is
-// LATENCY-bound: what matters is how many dependent load rounds a wave makes.  A workgroup of 16 waves takes 256 columns
-// (a lane 4 of them), wave w the partial rows w, w + 16, ... with 16 rows requested per round: P = 512 is 2 rounds per
-// wave.  (First form: 4 waves, 8 rows per round -- 16 rounds at P = 512, 40-100 us, slower than torch's generic
-// reduction at 12-23 us.)  The waves meet in LDS.
-constexpr int kSumWaves = 16, kSumRows = 16;
-template <typename TO>
+// K3b / K5b / K10b / K11c / K12b, one row per workgroup of those kernels).  These inputs are small (1-30 MB) and the sum is
+// LATENCY-bound: what matters is how many dependent load rounds a wave makes and how many CUs take part.  A workgroup of 16
+// waves takes CL x 4 columns (CL = 64, 32, 16 or 8 lanes along the columns -- the launcher narrows the workgroup until the grid
+// has ~64 of them: at CL = 64 the LayerNorm's [2][1024][1024] partials ran on 8 CUs, the norm-gate's [1024][256] on one); the
+// other 64 / CL lane groups and the 16 waves split the partial rows, QR rows requested per round.  The lane groups meet by
+// shuffles (fixed order), the waves in LDS.  (First form: 4 waves, 8 rows per round -- 16 rounds at P = 512, 40-100 us, slower
+// than torch's generic reduction at 12-23 us; second form: CL = 64 only, 9-20 us per launch, 125 launches per train step.)
+constexpr int kSumWaves = 16;
+template <typename TO, int CL, int QR>
 __global__ __launch_bounds__(64 * kSumWaves) void sum_partials_kernel(const float* __restrict__ part, TO* __restrict__ out, int P,
                                                                       int64_t N) {
-    __shared__ float4 s_red[kSumWaves - 1][64];
+    constexpr int RL = 64 / CL;                                       // lane groups along the partial rows
+    __shared__ float4 s_red[kSumWaves - 1][CL];
     const int lane = threadIdx.x & 63, wv = wave_uniform(threadIdx.x >> 6);
-    const int64_t n = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    const int cl = lane % CL, rl = lane / CL;
+    const int64_t n = ((int64_t)blockIdx.x * CL + cl) * 4;
     const bool ok = n < N;
     const float* src = part + (int64_t)blockIdx.y * P * N + (ok ? n : N - 4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p0 = wv; p0 < P; p0 += kSumWaves * kSumRows) {
-        float4 v[kSumRows];
+    constexpr int kStride = kSumWaves * RL;                           // row lanes of the workgroup
+    for (int p0 = wv * RL + rl; p0 < P; p0 += kStride * QR) {
+        float4 v[QR];
 #pragma unroll
-        for (int q = 0; q < kSumRows; ++q) {
-            const int p = p0 + kSumWaves * q;
+        for (int q = 0; q < QR; ++q) {
+            const int p = p0 + kStride * q;
             v[q] = *reinterpret_cast<const float4*>(src + (int64_t)(p < P ? p : P - 1) * N);
         }
         sched_fence();                                               // every load of the round before the first use
 #pragma unroll
-        for (int q = 0; q < kSumRows; ++q) {
+        for (int q = 0; q < QR; ++q) {
             // no branch here: a `break` made the compiler fold each load into its own load / wait / add / branch chain
-            const float m = p0 + kSumWaves * q < P ? 1.0f : 0.0f;
+            const float m = p0 + kStride * q < P ? 1.0f : 0.0f;
             acc.x = fmaf(m, v[q].x, acc.x); acc.y = fmaf(m, v[q].y, acc.y);
             acc.z = fmaf(m, v[q].z, acc.z); acc.w = fmaf(m, v[q].w, acc.w);
         }
     }
-    if (wv > 0) s_red[wv - 1][lane] = acc;
+#pragma unroll
+    for (int off = CL; off < 64; off <<= 1) {                         // the RL lane groups of the wave
+        acc.x += shfl_xor(acc.x, off); acc.y += shfl_xor(acc.y, off);
+        acc.z += shfl_xor(acc.z, off); acc.w += shfl_xor(acc.w, off);
+    }
+    if (wv > 0 && rl == 0) s_red[wv - 1][cl] = acc;
     __syncthreads();
-    if (wv == 0 && ok) {
+    if (wv == 0 && rl == 0 && ok) {
 #pragma unroll
         for (int o = 0; o < kSumWaves - 1; ++o) {
-            const float4 c = s_red[o][lane];
+            const float4 c = s_red[o][cl];
             acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
         }
         st4(out + (int64_t)blockIdx.y * N + n, acc);
@@ -665,6 +675,134 @@ __global__ __launch_bounds__(256) void gate_lowrank_kernel(const T* __restrict__
     }
 }
 
+// K12c -- the bf16 form of K12b with both rank-16 contractions on the matrix core (L = 16, C a multiple of 64, 16-byte
+// aligned rows).  K12b spends 16 FMAs per element on lr W^T and, backward, 16 more on dW += dpre^T lr: ~50 VALU instructions
+// per element against 4 bytes of traffic -- the forward wrote its 67 MB at 1.25 TB/s, the backward moved 134 MB at 1.65 TB/s.
+// Here a wave owns 64 columns and walks the rows 16 at a time:
+//   pre^T [cols x rows] = W [cols x 16] . lr^T [16 x rows]   one v_mfma_f32_16x16x32_bf16 per 16 columns (k >= 16: zeros);
+//     the column each A row stands for is permuted so that lane (row = l & 15, g = l >> 4) ends up with 8 CONSECUTIVE columns
+//     per pair of tiles: dy comes in and the result goes out as one 16-byte access per lane and tile pair;
+//   backward, per 32 rows: dpre (rounded to bf16, as K12b rounds it) goes to global memory AND row-major into the wave's
+//     own LDS tile; dW^T [16 x cols] += lr^T [16 x rows] . dpre [rows x cols] takes both operands from LDS with the
+//     transposing read ds_read_b64_tr_b16 (a lane needs 8 rows of one column); dbias is summed per lane and folded over the
+//     16 row lanes once at the end.  No workgroup barrier: the four waves share rows, not data.
+// Same values as K12b up to the summation order inside a 16-term dot product (fp32) / a 128-row partial sum.
+constexpr int kGate2Pad = 8;                                          // LDS row = 64 + 8 bf16: the four row groups of a
+                                                                      // transposing read land on different banks
+template <bool BWD>
+__global__ __launch_bounds__(256) void gate_lowrank_mfma_kernel(const bf16_t* __restrict__ lr, int64_t lr_stride,
+                                                                const float* __restrict__ w, const float* __restrict__ b,
+                                                                const bf16_t* __restrict__ dy, bf16_t* __restrict__ out,
+                                                                float* __restrict__ dwb_partial, int64_t R, int C,
+                                                                float inv_norm, float clamp_min, int has_clamp) {
+    constexpr int L = kGateL, kRow = 64 + kGate2Pad;
+    __shared__ __attribute__((aligned(16))) bf16_t s_dp[BWD ? 4 : 1][BWD ? 32 * kRow : 8];
+    __shared__ __attribute__((aligned(16))) bf16_t s_lr[BWD ? 4 : 1][BWD ? 32 * L : 8];
+    const int lane = threadIdx.x & 63, wv = wave_uniform(threadIdx.x >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int cw = blockIdx.y * 256 + wv * 64;                        // first column of this wave
+    if (cw >= C) return;
+    // A operands: tile t, MFMA row m = li stands for column cw + 32 (t / 2) + 8 (m / 4) + 4 (t % 2) + m % 4
+    bf16x8 wa[4];
+    float br[2][8];                                                   // bias of this lane's 8 columns per tile pair
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = cw + 32 * (t >> 1) + 8 * (li >> 2) + 4 * (t & 1) + (li & 3);
+        uint32_t u[4] = {0u, 0u, 0u, 0u};
+        if (lg < 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                u[j] = pack_bf16x2(w[(int64_t)col * L + 8 * lg + 2 * j], w[(int64_t)col * L + 8 * lg + 2 * j + 1]);
+        }
+        wa[t] = as_bf16x8(make_uint4(u[0], u[1], u[2], u[3]));
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) br[s][e] = b ? bf2f(f2bf(b[cw + 32 * s + 8 * lg + e])) : 0.0f;
+    f32x4 dwt[4];                                                     // dW^T tiles: lane (col = 16 t + li, j = 4 lg + i)
+    float dba[2][8];
+    if (BWD) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dwt[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dba[s][e] = 0.0f;
+    }
+    const int64_t r_begin = (int64_t)blockIdx.x * kGateRows;
+    const int64_t r_end = r_begin + kGateRows < R ? r_begin + kGateRows : R;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 32) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                                 // two groups of 16 rows
+            const int64_t row = r0 + 16 * h + li;
+            const bool row_ok = row < r_end;
+            const int64_t rc = row_ok ? row : r_end - 1;
+            uint4 lb = make_uint4(0u, 0u, 0u, 0u);
+            if (lg < 2) lb = *reinterpret_cast<const uint4*>(lr + rc * lr_stride + 8 * lg);
+            uint4 dr[2];
+            if (BWD) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) dr[s] = *reinterpret_cast<const uint4*>(dy + rc * C + cw + 32 * s + 8 * lg);
+                if (lg < 2) *reinterpret_cast<uint4*>(&s_lr[wv][(16 * h + li) * L + 8 * lg]) = lb;
+            }
+            const bf16x8 bop = as_bf16x8(lb);
+            f32x4 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16_16x16x32(wa[t], bop, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float o[8];
+                const uint32_t du[4] = {dr[s].x, dr[s].y, dr[s].z, dr[s].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pre = bf2f(f2bf(acc[2 * s + (e >> 2)][e & 3] + br[s][e]));
+                    if (BWD) {
+                        const float dv = bf2f((bf16_t)((e & 1) ? du[e >> 1] >> 16 : du[e >> 1] & 0xffff));
+                        const bool clamped = has_clamp && logsigmoidf(pre) * inv_norm < clamp_min;
+                        o[e] = (clamped || !row_ok) ? 0.0f : bf2f(f2bf(dv * inv_norm * sigmoidf(-pre)));
+                        dba[s][e] += o[e];
+                    } else {
+                        o[e] = logsigmoidf(pre) * inv_norm;
+                        if (has_clamp) o[e] = fmaxf(o[e], clamp_min);
+                    }
+                }
+                const uint4 pk = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
+                                            pack_bf16x2(o[6], o[7]));
+                if (row_ok) *reinterpret_cast<uint4*>(out + row * C + cw + 32 * s + 8 * lg) = pk;
+                if (BWD) *reinterpret_cast<uint4*>(&s_dp[wv][(16 * h + li) * kRow + 32 * s + 8 * lg]) = pk;
+            }
+        }
+        if (BWD) {
+            // lane group lg takes rows 8 lg .. 8 lg + 7 of the 32 as its eight k values; inside the group lane p passes the
+            // piece (row p / 4 of four, elements 4 (p % 4) ..): lane i receives column i of those four rows
+            const int pr = 8 * lg + (li >> 2), pc = 4 * (li & 3);
+            const bf16x8 la = as_bf16x8(lds_read_tr16_b64(&s_lr[wv][pr * L + pc]), lds_read_tr16_b64(&s_lr[wv][(pr + 4) * L + pc]));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 db = as_bf16x8(lds_read_tr16_b64(&s_dp[wv][pr * kRow + 16 * t + pc]),
+                                            lds_read_tr16_b64(&s_dp[wv][(pr + 4) * kRow + 16 * t + pc]));
+                dwt[t] = mfma_bf16_16x16x32(la, db, dwt[t]);
+            }
+        }
+    }
+    if (BWD) {
+        float* dst = dwb_partial + ((int64_t)blockIdx.x * C + cw) * (L + 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[(16 * t + li) * (L + 1) + 4 * lg + i] = dwt[t][i];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = dba[s][e];
+                v += shfl_xor(v, 1); v += shfl_xor(v, 2); v += shfl_xor(v, 4); v += shfl_xor(v, 8);
+                if (li == 0) dst[(32 * s + 8 * lg + e) * (L + 1) + L] = v;
+            }
+    }
+}
+
 }  // namespace lina
 
 extern "C" int lina_swiglu_bwd_partials(int64_t rows);
@@ -689,11 +827,25 @@ extern "C" int lina_sum_partials(const float* part, void* out, int outer, int P,
     LINA_REQUIRE(outer >= 1 && outer <= 65535 && P >= 1 && N >= 4 && N % 4 == 0,
                  "lina_sum_partials: bad shape outer=%d P=%d N=%lld (N must be a multiple of 4)", outer, P, (long long)N);
     LINA_REQUIRE(valid_dtype(out_dtype), "lina_sum_partials: bad dtype %d", out_dtype);
-    dim3 grid((unsigned)((N / 4 + 63) / 64), (unsigned)outer);
-    if (out_dtype == LINA_F32)
-        LINA_LAUNCH((sum_partials_kernel<float>), grid, dim3(64 * kSumWaves), 0, stream, part, (float*)out, P, N);
-    else
-        LINA_LAUNCH((sum_partials_kernel<bf16_t>), grid, dim3(64 * kSumWaves), 0, stream, part, (bf16_t*)out, P, N);
+    // lanes along the columns: the widest workgroup that still gives the grid ~64 of them (>= 128-byte row pieces)
+    const int64_t cols4 = N / 4;
+    int cl = 64;
+    while (cl > 8 && ((cols4 + cl - 1) / cl) * outer < 64) cl >>= 1;
+    const int per_lane = (P + kSumWaves * (64 / cl) - 1) / (kSumWaves * (64 / cl));   // partial rows per (wave, lane group)
+    const int qr = per_lane <= 4 ? 4 : per_lane <= 8 ? 8 : 16;
+    dim3 grid((unsigned)((cols4 + cl - 1) / cl), (unsigned)outer);
+#define LINA_SUMP(TT, CLL, QRR)                                                                                      \
+    LINA_LAUNCH((sum_partials_kernel<TT, CLL, QRR>), grid, dim3(64 * kSumWaves), 0, stream, part, (TT*)out, P, N)
+#define LINA_SUMP_Q(TT, CLL) do { if (qr == 4) LINA_SUMP(TT, CLL, 4); else if (qr == 8) LINA_SUMP(TT, CLL, 8); else LINA_SUMP(TT, CLL, 16); } while (0)
+#define LINA_SUMP_C(TT)                                                                                              \
+    do {                                                                                                             \
+        if (cl == 64) LINA_SUMP_Q(TT, 64); else if (cl == 32) LINA_SUMP_Q(TT, 32);                                   \
+        else if (cl == 16) LINA_SUMP_Q(TT, 16); else LINA_SUMP_Q(TT, 8);                                             \
+    } while (0)
+    if (out_dtype == LINA_F32) LINA_SUMP_C(float); else LINA_SUMP_C(bf16_t);
+#undef LINA_SUMP_C
+#undef LINA_SUMP_Q
+#undef LINA_SUMP
     return check_launch("lina_sum_partials");
 }
 
@@ -769,6 +921,17 @@ extern "C" int lina_gate_lowrank(const void* lr, int64_t lr_stride, const float*
     const int has_clamp = (clamp_min == clamp_min) ? 1 : 0;          // NaN = no clamp
     dim3 grid((unsigned)lina_gate_lowrank_partials(rows), (unsigned)((C + 255) / 256));
     const bool full = L == kGateL && lr_stride % 2 == 0 && (reinterpret_cast<uintptr_t>(lr) & 3) == 0;
+    if (dtype == LINA_BF16 && L == kGateL && C % 64 == 0 && lr_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(lr) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!dy || (reinterpret_cast<uintptr_t>(dy) & 15) == 0)) {
+        // K12c: both rank-16 contractions on the matrix core
+        if (dy)
+            LINA_LAUNCH((gate_lowrank_mfma_kernel<true>), grid, dim3(256), 0, stream, (const bf16_t*)lr, lr_stride, w, b,
+                        (const bf16_t*)dy, (bf16_t*)out, dwb_partial, rows, C, 1.0f / normalizer, clamp_min, has_clamp);
+        else
+            LINA_LAUNCH((gate_lowrank_mfma_kernel<false>), grid, dim3(256), 0, stream, (const bf16_t*)lr, lr_stride, w, b,
+                        (const bf16_t*)dy, (bf16_t*)out, dwb_partial, rows, C, 1.0f / normalizer, clamp_min, has_clamp);
+        return check_launch("lina_gate_lowrank");
+    }
 #define LINA_GLR(TT, BB, FF)                                                                                         \
     LINA_LAUNCH((gate_lowrank_kernel<TT, BB, FF>), grid, dim3(256), 0, stream, (const TT*)lr, lr_stride, w, b, (const TT*)dy, \
                 (TT*)out, dwb_partial, rows, C, L, 1.0f / normalizer, clamp_min, has_clamp)

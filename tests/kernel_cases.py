@@ -730,8 +730,11 @@ def check_gate_lowrank(dev, B, T, C, L, dtype, clamp, bias=True, strided=False):
     """K12b: logsigmoid(lr W^T + b) / normalizer (+ clamp) and the gradients of lr, W, b against fp64 autograd of the
     unfused chain on the operands the kernel sees (weights rounded to the GEMM dtype, as autocast does)."""
     g = torch.Generator().manual_seed(43)
-    z = torch.randn(B, T, L + 8, generator=g).to(dtype)
-    lr0 = z[..., 4:4 + L] if strided else z[..., :L].contiguous()
+    # strided: True = a column slice at an 8-byte offset (the K12b kernel), "aligned" = a 16-byte aligned slice (bf16, L = 16,
+    # C % 64 == 0: the matrix-core form K12c -- the layout of the mixer's stacked projection)
+    off = 8 if strided == "aligned" else 4
+    z = torch.randn(B, T, L + 16, generator=g).to(dtype)
+    lr0 = z[..., off:off + L] if strided else z[..., :L].contiguous()
     w = torch.randn(C, L, generator=g) * 1.5
     b = torch.randn(C, generator=g) if bias else None
     dy = torch.randn(B, T, C, generator=g).to(dtype)
@@ -745,7 +748,7 @@ def check_gate_lowrank(dev, B, T, C, L, dtype, clamp, bias=True, strided=False):
         y64 = torch.clamp_min(y64, clamp)
     (y64 * dy.to(F64)).sum().backward()
     zd = z.to(dev)
-    lrd = (zd[..., 4:4 + L] if strided else zd[..., :L].contiguous()).requires_grad_()
+    lrd = (zd[..., off:off + L] if strided else zd[..., :L].contiguous()).requires_grad_()
     wd = w.to(dev).requires_grad_()
     bd = None if b is None else b.to(dev).requires_grad_()
     y = ops.gate_lowrank(lrd, wd, bd, 16.0, clamp)
@@ -889,7 +892,10 @@ def check_sum_partials(dev):
     rows of one round), a width that is not a multiple of 256, the outer axis, a bf16 result; widths the kernel does not
     take (N % 4 != 0) fall back to torch."""
     g = torch.Generator().manual_seed(61)
-    for P, shape in ((1, (8,)), (7, (40, 5)), (37, (256,)), (300, (1024, 5)), (513, (260,)), (16, (3,))):
+    # (the launcher narrows the workgroup to 32 / 16 / 8 lanes along the columns when there are few of them, and picks 4 / 8 /
+    # 16 rows per round from the row count: the shapes below reach every combination incl. the train step's own)
+    for P, shape in ((1, (8,)), (7, (40, 5)), (37, (256,)), (300, (1024, 5)), (513, (260,)), (16, (3,)), (1024, (256,)),
+                     (130, (2816,)), (64, (3072, 5)), (256, (1024, 17)), (1025, (1024,))):
         part = torch.randn(P, *shape, generator=g).to(dev)
         got = ops._sum_partials(part)
         assert got.shape == shape and got.dtype == torch.float32

@@ -392,7 +392,7 @@ def test_short_conv3_fused_qkv(emu, dtype, bias, through_gla):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,T,C,L,clamp,bias,strided", [(2, 70, 64, 16, None, True, True), (1, 130, 40, 16, -0.2, True, False), (2, 33, 64, 7, None, False, False)])
+@pytest.mark.parametrize("B,T,C,L,clamp,bias,strided", [(2, 70, 64, 16, None, True, True), (1, 130, 40, 16, -0.2, True, False), (2, 33, 64, 7, None, False, False), (2, 70, 64, 16, None, True, False), (1, 150, 128, 16, -0.2, True, "aligned"), (2, 45, 320, 16, None, False, "aligned")])
 def test_gate_lowrank(emu, B, T, C, L, clamp, bias, strided, dtype):
     from kernel_cases import check_gate_lowrank
     check_gate_lowrank(DEV, B, T, C, L, dtype, clamp, bias, strided)

@@ -490,7 +490,7 @@ def test_linear_train_path_under_autocast(hip, n_out, n_in, bias):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,T,C,L,clamp,bias,strided", [(2, 70, 64, 16, None, True, True), (8, 4096, 1024, 16, None, True, True), (3, 1000, 1024, 16, -0.2, True, False), (2, 333, 2048, 7, None, False, False)])
+@pytest.mark.parametrize("B,T,C,L,clamp,bias,strided", [(2, 70, 64, 16, None, True, True), (8, 4096, 1024, 16, None, True, True), (3, 1000, 1024, 16, -0.2, True, False), (2, 333, 2048, 7, None, False, False), (2, 70, 64, 16, None, True, False), (1, 150, 128, 16, -0.2, True, "aligned"), (3, 515, 1024, 16, None, True, "aligned"), (2, 300, 320, 16, None, False, "aligned")])
 def test_gate_lowrank(hip, B, T, C, L, clamp, bias, strided, dtype):
     from kernel_cases import check_gate_lowrank
     check_gate_lowrank(DEV, B, T, C, L, dtype, clamp, bias, strided)
