@@ -182,7 +182,9 @@ int lina_rmsnorm_gate_fwd(const void* x, const void* g, const void* w, void* y,
  *   gate is read from, and its gradient written into, head slices of wider rows in place (the stacked projection's
  *   output and the gradient slab of that projection);
  *   dw_partial: fp32 [lina_rmsnorm_gate_bwd_partials(rows)][D], summed over dim 0 by the caller. */
+#ifndef LINA_NORM_BWD_MAX_WG            /* (A/B builds of the library override it; callers size by the function below) */
 #define LINA_NORM_BWD_MAX_WG 1024
+#endif
 int lina_rmsnorm_gate_bwd_partials(int64_t rows);
 int lina_rmsnorm_gate_bwd(const void* x, const void* g, const void* w, const void* dy, void* dx, void* dg,
                           float* dw_partial, int64_t rows, int rows_inner, int D, int64_t g_outer, int64_t g_inner,

@@ -65,3 +65,8 @@ for lib in "" tools/abl/liblina_k2_nt0.so; do
   done
 done
 cat gpurun_out/${TAG}_k2_dma_nt_ab.txt
+# ---- train step (a-11): wall time, then the kernel table of exactly 7 steps under rocprofv3
+timeout 300 python tools/perf_train_step.py 10 > gpurun_out/${TAG}_train_step.json 2>/dev/null; echo "train_step=$?"; cat gpurun_out/${TAG}_train_step.json
+rm -rf /tmp/tp; timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/tp -o tp -- python tools/perf_train_step.py 5 > /dev/null 2>&1; echo "train_prof=$?"
+db=$(find /tmp/tp -name "*results.db" | head -1)
+python tools/prof_summary.py $db gpurun_out/${TAG}_train_step_kernel_stats.csv
