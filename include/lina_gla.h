@@ -308,7 +308,9 @@ int lina_swiglu_bwd_colsum(const void* ds, const void* u, void* du, float* colsu
  *   dy == NULL:  out [rows, C] = logsigmoid(lr w^T + b) / normalizer, clamped from below unless clamp_min is NaN;
  *   dy given:    out [rows, C] = d(pre) = dy (1 - sigmoid(pre)) / normalizer (0 where clamped), and
  *                dwb_partial fp32 [lina_gate_lowrank_partials(rows)][C][L + 1] = per-workgroup sums of d(pre)^T [lr | 1]
- *                (slot L = bias gradient), summed over dim 0 by the caller.  d(lr) = d(pre) w is the caller's GEMM. */
+ *                (slot L = bias gradient), summed over dim 0 by the caller.  d(lr) = d(pre) w is the caller's GEMM.
+ * bf16 with L == 16, C % 64 == 0 and 16-byte aligned rows (the mixer's layout) takes K12c: both rank-16 contractions on the
+ * matrix core; same contract, sums in a different order. */
 #define LINA_GATE_LOWRANK_ROWS 128
 int lina_gate_lowrank_partials(int64_t rows);
 int lina_gate_lowrank(const void* lr, int64_t lr_stride, const float* w, const float* b, const void* dy, void* out,
