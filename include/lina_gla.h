@@ -153,7 +153,9 @@ int lina_short_conv_step(const void* x, const void* w, const void* bias, void* c
  * weight / bias gradient, dwb_partial [B * ceil(T / LINA_CONV_BWD_TT)][D][W+1] (slot W = bias), which
  * the caller sums over dim 0.  Replaces the autograd backward of ShortConvolution.forward
  * (reference model/gla.py:161-163 under loss.backward()). */
+#ifndef LINA_CONV_BWD_TT                /* (A/B builds of the library override it) */
 #define LINA_CONV_BWD_TT 64
+#endif
 int lina_short_conv_bwd(const void* x, const void* w, const void* bias, const float* mask, const void* dy,
                         void* dx, float* dwb_partial, int B, int T, int D, int W,
                         int64_t x_sb, int64_t x_st, int64_t dy_sb, int64_t dy_st, int64_t dx_sb, int64_t dx_st,
