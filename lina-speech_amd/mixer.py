@@ -131,11 +131,25 @@ class GatedLinearAttention(nn.Module):
                 # prefill / training: the five projections of the block input as ONE GEMM over the stacked weights
                 # (same columns, one pass over the activations, a 5136-wide GEMM instead of five narrow ones);
                 # the outputs are strided views of its result
-                w_cat = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.g_proj.weight,
-                                   self.gk_proj[0].weight], dim=0)
+                parts = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.g_proj.weight,
+                         self.gk_proj[0].weight]
+                sizes = [self.key_dim, self.key_dim, self.value_dim, self.value_dim, self.gk_proj[0].weight.shape[0]]
+                # rows of the stacked output padded to a multiple of 128 bytes (L169: 4112 -> 4160 columns, zero weight rows):
+                # with 8224-byte rows every 512-byte wave access of the slices' consumers (conv, norm-gate, gate kernels: they
+                # read q | k | v | g | lr in place) straddles one more cache line -- the fused convolution ran 89 us forward /
+                # 171 us backward on such rows against 76 / 150 on aligned ones (profiles/r06_conv_ab.txt); the GEMM works on
+                # 17 column tiles of 256 either way
+                pad = (-sum(sizes)) % 64
+                if pad:
+                    zp = self.__dict__.get("_stack_pad")          # constant zero rows (not a parameter, not in the state dict)
+                    w0 = self.q_proj.weight
+                    if zp is None or zp.shape[0] != pad or zp.device != w0.device or zp.dtype != w0.dtype:
+                        zp = self.__dict__["_stack_pad"] = w0.new_zeros(pad, w0.shape[1])
+                    parts.append(zp)
+                    sizes.append(pad)
+                w_cat = torch.cat(parts, dim=0)
                 # (training: the consumers of the slices write their input gradients into ONE slab -- no concat pass)
-                (q, k, v, g_pre, lr_pre), slab = ops.split_slab(ops.linear(hidden_states, w_cat), [
-                    self.key_dim, self.key_dim, self.value_dim, self.value_dim, self.gk_proj[0].weight.shape[0]])
+                (q, k, v, g_pre, lr_pre, *_), slab = ops.split_slab(ops.linear(hidden_states, w_cat), sizes)
             else:
                 q, k, v = self.q_proj(hidden_states), self.k_proj(hidden_states), self.v_proj(hidden_states)
             if self.use_short_conv:
