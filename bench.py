@@ -181,7 +181,8 @@ def measure_chunk(dev, B=64, H=4, T=4096, Dk=256, Dv=256, reps=200):
                        ("r06_k2_b8_traffic.json", "; state-only pass + combine + full pass of the segment-parallel form"),
                        ("r06_k2_h4_traffic.json", "; the training call"), ("r06_k2_h8_traffic.json", "; the training call"),
                        ("r06_k2_h16_traffic.json", "; the training call"),
-                       ("r06_k2_dv512_traffic.json", "; the training call, two 256-column launches per call: q, k, g read by both")):
+                       ("r06_k2_dv512_traffic.json", "; the training call, ONE launch of two XCD-paired workgroups per head: the second "
+                                                     "reader of q, k, g hits the XCD's L2 (rounds 2-5, two launches: 1.43 x algorithmic)")):
         tpath = os.path.join(ROOT, "profiles", name)                 # PMC passes are separate runs; their committed summaries
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -1014,8 +1015,16 @@ def main():
                     ck = measure_chunk(dev, B=64, H=hh, Dk=1024 // hh, Dv=1024 // hh, reps=100)
                     ck["kernel"] = f"lina::gla_chunk_bf16_h256_kernel<false, G={256 * hh // 1024}> ({256 * hh // 1024} heads per workgroup)"
                     out[f"chunk_kernel_h{hh}"] = ck
-                ck = measure_chunk(dev, B=64, H=4, Dk=256, Dv=512, reps=60)   # expand_v = 2: two 256-column blocks per head
-                ck["kernel"] = "lina::gla_chunk_bf16_h256_kernel<false, 1> x 2 (one launch per 256-column block of v / o)"
+                ck = measure_chunk(dev, B=64, H=4, Dk=256, Dv=512, reps=60)   # expand_v = 2 (the reference's default, model/gla.py:52,267)
+                ck["kernel"] = ("lina::gla_chunk_bf16_h256_kernel<false, 1, NCB = 2>: both 256-column blocks of v / o in ONE launch, "
+                                "the two workgroups of a head on one XCD (block ids i, i + 8)")
+                from lina_speech_amd import ops as _ops
+                _ops.POLICY.dv512_one_launch = False                  # rounds 2-5: one launch per column block, same session
+                try:
+                    two = measure_chunk(dev, B=64, H=4, Dk=256, Dv=512, reps=30)
+                finally:
+                    _ops.POLICY.dv512_one_launch = True
+                ck["two_launches"] = {"ms": two["ms"], "frac": two["frac"]}
                 out["chunk_kernel_dv512"] = ck
                 small = measure_chunk(dev, B=8)                      # training micro-batch: segment-parallel form
                 small["kernel"] = "lina_gla_chunk_fwd_seg (state-only pass + combine + full pass, 8 segments)"

@@ -83,7 +83,14 @@ __device__ __forceinline__ bf16x8 frag8x2(const bf16_t* p_lo, const bf16_t* p_hi
 //           z = q (this sweep's own Z rows: in MODE 1 a phase-A thread reads exactly the (token, channel) values whose output
 //           it will hold), aux2 = dq (sweep Q's output) and aux = k that is dg = reverse-cumsum(q dq - k dk), formed while dk
 //           is still fp32 in registers.
-template <bool STATE_ONLY, int G, int MODE = 0, bool REV = false, bool DG = false, bool NTD = (LINA_DMA_NT != 0)>
+//
+// NCB = 2 (round 6: Dv = 2 Dk = 512, the reference's default expand_v = 2 at the L169 key width -- model/gla.py:52,267): the
+// head's value columns are split over TWO workgroups of ONE launch (the recurrence is independent per value column; the state
+// of a 256 x 512 head does not fit one CU's accumulators).  The two halves of a head get block ids i and i + 8: the dispatcher
+// deals consecutive ids round-robin over the 8 XCDs, so both land on the SAME XCD in the same dispatch round, run in step
+// and the second reader of a q / k / g row pair finds it in that XCD's L2 (plain cache policy for this form) -- HBM sees
+// q, k, g once.  h0 / ht keep their natural [B, H, 256, 512] layout (row stride 512, column offset 256 cb).
+template <bool STATE_ONLY, int G, int MODE = 0, bool REV = false, bool DG = false, bool NTD = (LINA_DMA_NT != 0), int NCB = 1>
 __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ gk, bf16_t* __restrict__ o, const float* h0, float* ht, float* dec_out, int H,
@@ -92,6 +99,7 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     const bf16_t* aux2, lina_bht_strides saux2, bf16_t* dg, lina_bht_strides sdg, const float* carry) {
     static_assert(MODE == 0 || !STATE_ONLY, "the state-only pass exists in the key-gated form only");
     static_assert(!DG || MODE == 1, "dg is formed by a value-gated sweep");
+    static_assert(NCB == 1 || (NCB == 2 && G == 1 && MODE == 0 && !STATE_ONLY && !REV), "column blocks: the plain forward of a 256 x 512 head");
     constexpr int DK = 256, DV = 256, C = kFullC;       // the WORKGROUP's channel / column width: G heads of D each
     constexpr int D = 256 / G;                            // head dimension
     constexpr int NTL = 16 / G;                           // waves per head = state row tiles per wave
@@ -144,7 +152,14 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int w_s = wave_uniform(w);                         // wave index in an SGPR for the whole kernel
     int li = lane & 15, lg = lane >> 4;
-    const int slot = blockIdx.x;                             // state slot: (head group) * nseg + segment
+    int slot_ = blockIdx.x, cb_ = 0;                         // NCB = 2: (head, column block) from the block id
+    if constexpr (NCB == 2) {
+        if (gridDim.x & 15) { cb_ = slot_ & 1; slot_ >>= 1; }                                       // heads % 8 != 0: no pairing
+        else { cb_ = (slot_ >> 3) & 1; slot_ = ((slot_ >> 4) << 3) | (slot_ & 7); }                  // ids i, i + 8 = one head
+    }
+    const int slot = slot_;                                  // state slot: (head group) * nseg + segment
+    const int cb = wave_uniform(cb_);
+    constexpr int HS = D * NCB;                              // row stride of h0 / ht
     const int bh = (slot / nseg) * G, b = bh / H, h = bh % H;   // first head of the group (H % G == 0: one batch row)
     const int hw = w_s / NTL, wl = w_s % NTL;                // this wave's head inside the group, its index inside the head
     const int seg_t = REV ? nseg - 1 - slot % nseg : slot % nseg;   // REV: slot order = visiting order = last segment first
@@ -168,18 +183,19 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
                 S[p] = f32x4{t4.x * h0_scale, t4.y * h0_scale, t4.z * h0_scale, t4.w * h0_scale};
             }
         } else {
-            const float* hp = h0 + (((int64_t)slot * G + hw) * D + 4 * lg) * D + li;
+            const float* hp = h0 + (((int64_t)slot * G + hw) * D + 4 * lg) * HS + (NCB > 1 ? cb * D : 0) + li;
 #pragma unroll
             for (int p = 0; p < NTL; ++p)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) S[p][r] = hp[(tile_row(p) + r) * D + tile_col(p)] * h0_scale;
+                for (int r = 0; r < 4; ++r) S[p][r] = hp[(tile_row(p) + r) * HS + tile_col(p)] * h0_scale;
         }
     }
 
     const bf16_t* gsrc[4] = {q + b * sq.b + h * sq.h + t_begin * sq.t, k + b * sk.b + h * sk.h + t_begin * sk.t,
-                             gk + b * sg.b + h * sg.h + t_begin * sg.t, v + b * sv.b + h * sv.h + t_begin * sv.t};
+                             gk + b * sg.b + h * sg.h + t_begin * sg.t,
+                             v + b * sv.b + h * sv.h + t_begin * sv.t + (NCB > 1 ? cb * DV : 0)};
     const unsigned gst[4] = {(unsigned)sq.t, (unsigned)sk.t, (unsigned)sg.t, (unsigned)sv.t};   // < 2^31 (launcher)
-    bf16_t* ob = STATE_ONLY ? nullptr : o + b * so.b + h * so.h + t_begin * so.t;
+    bf16_t* ob = STATE_ONLY ? nullptr : o + b * so.b + h * so.h + t_begin * so.t + (NCB > 1 ? cb * DV : 0);
     float4 decp = make_float4(1.f, 1.f, 1.f, 1.f);            // STATE_ONLY, wave 0: product of the chunk decays, channels 4*lane..+3
 
     // One DMA instruction = one row pair (2 rows x 512 B, 16 B per lane) of one raw tile.  A DMA instruction blocks its wave
@@ -788,11 +804,11 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
             const float4 r4 = *reinterpret_cast<const float4*>(&s_R[tile_ch(p) + 4 * lg]);
             S[p][0] *= fast_exp2(r4.x); S[p][1] *= fast_exp2(r4.y); S[p][2] *= fast_exp2(r4.z); S[p][3] *= fast_exp2(r4.w);
         }
-        float* hp = ht + (((int64_t)slot * G + hw) * D + 4 * lg) * D + li;
+        float* hp = ht + (((int64_t)slot * G + hw) * D + 4 * lg) * HS + (NCB > 1 ? cb * D : 0) + li;
 #pragma unroll
         for (int p = 0; p < NTL; ++p)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hp[(tile_row(p) + r) * D + tile_col(p)] = S[p][r];
+            for (int r = 0; r < 4; ++r) hp[(tile_row(p) + r) * HS + tile_col(p)] = S[p][r];
     }
 }
 
@@ -804,8 +820,10 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
 
 static bool full_ok(int H, int Dk, int Dv, int dtype, const void* q, const void* k, const void* v, const void* gk,
                     const void* o, int g_dtype, lina_bht_strides sq, lina_bht_strides sk, lina_bht_strides sv,
-                    lina_bht_strides sg, lina_bht_strides so) {
-    if (dtype != LINA_BF16 || g_dtype != LINA_BF16 || Dk != Dv || (Dk != 256 && Dk != 128 && Dk != 64)) return false;
+                    lina_bht_strides sg, lina_bht_strides so, bool two_blocks = false) {
+    // two_blocks: also Dk = 256, Dv = 512 (two value column blocks in one launch, NCB = 2 of the kernel)
+    if (dtype != LINA_BF16 || g_dtype != LINA_BF16 || (Dk != 256 && Dk != 128 && Dk != 64)) return false;
+    if (Dk != Dv && !(two_blocks && Dk == 256 && Dv == 512)) return false;
     const int G = 256 / Dk;
     if (G > 1) {
         if (H % G) return false;
@@ -825,9 +843,15 @@ int launch_chunk_full(const void* q, const void* k, const void* v, const void* g
                       lina_bht_strides sv, lina_bht_strides sg, lina_bht_strides so, int dtype, int g_dtype,
                       float scale, lina_stream_t stream, bool* taken) {
     auto fits32 = [T](lina_bht_strides st) { return (int64_t)T * st.t < (1LL << 31); };
-    *taken = full_ok(H, Dk, Dv, dtype, q, k, v, gk, o, g_dtype, sq, sk, sv, sg, so) && fits32(sq) && fits32(sk) &&
+    *taken = full_ok(H, Dk, Dv, dtype, q, k, v, gk, o, g_dtype, sq, sk, sv, sg, so, true) && fits32(sq) && fits32(sk) &&
              fits32(sv) && fits32(sg) && fits32(so);
     if (!*taken) return LINA_OK;
+    if (Dv == 2 * Dk) {                                       // 256 x 512 heads: both value column blocks in ONE launch
+        LINA_LAUNCH((gla_chunk_bf16_h256_kernel<false, 1, 0, false, false, false, 2>), dim3((unsigned)(2 * B * H)), dim3(1024), 0,
+                    stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gk, (bf16_t*)o, h0, ht,
+                    (float*)nullptr, H, T, 1, T, sq, sk, sv, sg, so, scale, LINA_FWD_ONLY);
+        return check_launch("lina_gla_chunk_fwd(full, two value blocks)");
+    }
     const int G = 256 / Dk;
     dim3 grid((unsigned)(B * H / G));
 #define LINA_FULL(GG)                                                                                                  \

@@ -54,6 +54,8 @@ def _gla_launch(entry: str, q, k, v, gk, scale, initial_state, output_final_stat
     Dv = v.shape[-1]
     be = _backend._BACKEND
     m = _value_blocks(q, v, gk) if entry == "lina_gla_chunk_fwd" else 1
+    if m == 2 and POLICY.dv512_one_launch and (chunk_segments(2 * B * H, T) if nseg is None else nseg) <= 1:
+        m = 1                                   # the C entry runs both value column blocks of a 256 x 512 head in one launch
     if m > 1:
         o = _head_first_empty(B, H, T, Dv, q.dtype, q.device)
         ht = torch.empty(B, H, Dk, Dv, dtype=torch.float32, device=q.device) if output_final_state else None

@@ -11,6 +11,10 @@ class Policy:
     """``k2b_path``: "full" = K2b as three sweeps of the full-head kernel (bf16, Dk = Dv in {64,128,256}, falls back when the
     layout is not eligible), "sweeps" = always the generic kernel (lina_gla_chunk_bwd)."""
     k2b_path: str = "full"
+    # 256 x 512 heads (expand_v = 2), chunk forward: True = both value column blocks in ONE launch, the two workgroups of a
+    # head paired on one XCD (gla_chunk_full.hip, NCB = 2: q, k, g reach HBM once); False = one launch per column block
+    # (rounds 2-5; still what the segment-parallel form and the backward do)
+    dv512_one_launch: bool = True
 
 
 POLICY = Policy()

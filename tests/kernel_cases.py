@@ -122,6 +122,27 @@ def check_chunk(dev, B, H, T, Dk, Dv, dtype, resets=False):
     assert_close(o, o3.float(), 2 * tol_out(dtype, chunk=True), "K2 vs K1")
 
 
+def check_chunk_dv512_one_launch(dev, monkeypatch, B, H, T, oracle=True):
+    """256 x 512 heads (the reference's default expand_v = 2, model/gla.py:52,267): ONE launch with two workgroups per head
+    (gla_chunk_full.hip NCB = 2) gives bit for bit what two launches on the value column blocks give (the recurrence is
+    independent per value column) -- outputs and final state, with and without an initial state -- and both are the oracle's."""
+    dtype = torch.bfloat16
+    q, k, v, gk, h0 = make_gla_inputs(B, H, T, 256, 512, dtype, dev, seed=33, resets=True)
+    res = {}
+    for one in (True, False):
+        monkeypatch.setattr(ops.POLICY, "dv512_one_launch", one)
+        res[one] = (ops.chunk_gla(q, k, v, gk, initial_state=h0, output_final_state=True, nseg=1),
+                    ops.chunk_gla(q, k, v, gk, nseg=1))
+    (o1, S1), (o1n, _) = res[True]
+    (o2, S2), (o2n, _) = res[False]
+    assert torch.equal(o1, o2) and torch.equal(S1, S2) and torch.equal(o1n, o2n), "one launch != two launches"
+    assert o1.shape == (B, H, T, 512) and S1.shape == (B, H, 256, 512)
+    if oracle:
+        ro, rS = oracle_gla(q, k, v, gk, h0)
+        assert_close(o1, ro, tol_out(dtype, chunk=True), "K2 (256 x 512, one launch) o")
+        assert_close(S1, rS, 1e-2, "K2 (256 x 512, one launch) state")
+
+
 def check_chunk_segmented(dev, B, H, T, nseg, resets=False, D=256):
     """Segment-parallel K2 (state-only pass + combine + full pass) == the fp64 recurrent oracle and == the plain
     one-workgroup-per-head(-group) kernel, with and without an initial state; bf16, Dk = Dv = D (256, or 128 / 64 with

@@ -364,9 +364,16 @@ def test_chunk_autograd_hands_the_forward_segment_states_to_the_backward(emu):
 
 
 def test_chunk_and_its_backward_for_value_column_blocks(emu):
-    # expand_v = 2 heads (256 x 512): K2 / K2b run as two 256 x 256 calls on column blocks of v, o and the states
+    # expand_v = 2 heads (256 x 512): the forward runs both value column blocks in ONE launch (two workgroups per head), K2b
+    # as two 256 x 256 calls on column blocks of v, o and the states
     check_chunk(DEV, B=1, H=1, T=40, Dk=256, Dv=512, dtype=torch.bfloat16, resets=True)
     check_chunk_bwd(DEV, B=1, H=1, T=40, Dk=256, Dv=512, dtype=torch.bfloat16, resets=True)
+
+
+def test_chunk_two_value_blocks_in_one_launch_equals_two_launches(emu, monkeypatch):
+    from kernel_cases import check_chunk_dv512_one_launch
+    check_chunk_dv512_one_launch(DEV, monkeypatch, B=1, H=8, T=33)     # 8 heads: the XCD-paired block-id mapping
+    check_chunk_dv512_one_launch(DEV, monkeypatch, B=1, H=3, T=36)     # heads % 8 != 0: the plain mapping
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

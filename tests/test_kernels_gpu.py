@@ -208,8 +208,16 @@ def test_chunk_bwd_generic_kernel_for_bf16(hip, monkeypatch):
     check_chunk_bwd(DEV, B=2, H=2, T=70, Dk=64, Dv=64, dtype=torch.bfloat16, resets=True)
 
 
+def test_chunk_two_value_blocks_in_one_launch_equals_two_launches(hip, monkeypatch):
+    from kernel_cases import check_chunk_dv512_one_launch
+    check_chunk_dv512_one_launch(DEV, monkeypatch, B=16, H=4, T=1000)  # 64 heads: the XCD-paired block-id mapping, ragged T
+    check_chunk_dv512_one_launch(DEV, monkeypatch, B=3, H=3, T=300)    # heads % 8 != 0: the plain mapping
+    check_chunk_dv512_one_launch(DEV, monkeypatch, B=64, H=4, T=4096, oracle=False)   # the benchmark shape: 512 workgroups, two rounds
+
+
 def test_chunk_and_its_backward_for_value_column_blocks(hip):
-    # expand_v = 2 heads (256 x 512): two full-head calls on column blocks; the long case also runs segment-parallel
+    # expand_v = 2 heads (256 x 512): the forward as ONE launch of two workgroups per head, the backward as two full-head calls
+    # on column blocks; the long case also runs segment-parallel
     check_chunk(DEV, B=2, H=2, T=300, Dk=256, Dv=512, dtype=torch.bfloat16, resets=True)
     check_chunk_bwd(DEV, B=2, H=2, T=150, Dk=256, Dv=512, dtype=torch.bfloat16, resets=True)
     from kernel_cases import check_chunk_bwd_long

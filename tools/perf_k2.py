@@ -10,6 +10,8 @@ H = int(os.environ.get("K2_H", 4))                        # heads of the 1024-wi
 B, T, Dk = int(os.environ.get("K2_B", 64)), int(os.environ.get("K2_T", 4096)), 1024 // H
 Dv = int(os.environ.get("K2_DV", Dk))                     # K2_DV=512: expand_v = 2 (two 256-column launches per call)
 reps = int(os.environ.get("K2_REPS", 5))
+if os.environ.get("K2_DV512_ONE") is not None:            # 256 x 512 heads: "1" one launch of two workgroups per head (default), "0" two launches
+    ops.POLICY.dv512_one_launch = os.environ["K2_DV512_ONE"] != "0"
 dev = "cuda"
 g = torch.Generator().manual_seed(0)
 mk = lambda D: torch.randn(B, T, H * D, generator=g).to(torch.bfloat16).to(dev).view(B, T, H, D).transpose(1, 2)

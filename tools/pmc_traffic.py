@@ -13,7 +13,7 @@ BK = int(os.environ.get("PMC_B", 64))        # batch rows of the K2 / K2b shape 
 
 which, fdir, wdir, out = sys.argv[1:5]
 pat = {"k1w": "gla_decode_window_kernel", "k2": "gla_chunk_bf16_h256", "k2b": "gla_chunk_bf16_h256", "k2seg": "gla_",
-       "k2dv512": "gla_chunk_bf16_h256"}[which]
+       "k2dv512": "gla_chunk_bf16_h256", "k2dv512one": "gla_chunk_bf16_h256"}[which]
 res = {}
 for c, d in (("FETCH_SIZE", fdir), ("WRITE_SIZE", wdir)):
     f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)
@@ -41,6 +41,14 @@ if which == "k2dv512":     # expand_v = 2: one call = two launches of the 256-co
              kernel="lina::gla_chunk_bf16_h256_kernel<false, 1> x 2 (one launch per 256-column block of v / o), per CALL",
              shape={"B": BK, "H": heads, "T": 4096, "Dk": D, "Dv": 2 * D},
              command=f"K2_B={BK} K2_H={heads} K2_DV={2 * D} K2_HT=0 rocprofv3 --kernel-trace --pmc <COUNTER> -- python tools/perf_k2.py (tests/gpu_r06_evidence.sh)",
+             algorithmic_bytes_per_launch=alg, traffic_over_algorithmic=(rd + wr) / alg)
+elif which == "k2dv512one":  # expand_v = 2 since round 6: ONE launch, two workgroups per head paired on an XCD
+    heads = int(sys.argv[5])
+    D = 1024 // heads
+    alg = BK * heads * 4096 * 2 * (3 * D + 2 * 2 * D)
+    o.update(kernel="lina::gla_chunk_bf16_h256_kernel<false, 1, 0, false, false, false, NCB = 2> (both 256-column blocks of v / o in one launch)",
+             shape={"B": BK, "H": heads, "T": 4096, "Dk": D, "Dv": 2 * D},
+             command=f"K2_B={BK} K2_H={heads} K2_DV={2 * D} K2_HT=0 rocprofv3 --kernel-trace --pmc <COUNTER> -- python tools/perf_k2.py (tests/gpu_r06_dv512.sh)",
              algorithmic_bytes_per_launch=alg, traffic_over_algorithmic=(rd + wr) / alg)
 elif which == "k2seg":       # segment-parallel forward: state-only pass + combine + full pass, summed per call
     rd, wr = 2 * res["FETCH_SIZE"]["per_call_KiB"] * 1024, res["WRITE_SIZE"]["per_call_KiB"] * 1024
