@@ -64,10 +64,24 @@ __device__ __forceinline__ void st_hist(float* p, float v) {
 // Cache.update's copy_): every step upcasts it, updates in fp32 and rounds the result back.  With a bf16 state the arithmetic
 // below is unchanged (fp32 registers); only what is read / written back differs -- at window 1 exactly the reference's
 // per-step rounding, at window W a rounding every W-th step.
-__device__ __forceinline__ float4 ld_state4(const float* p) { return LINA_K1W_STATE_LOAD(p); }
-__device__ __forceinline__ float4 ld_state4(const bf16_t* p) { return cvt4(ld_nt8(p)); }
-__device__ __forceinline__ void st_state4(float* p, float4 v) { st_nt4(p, v); }
-__device__ __forceinline__ void st_state4(bf16_t* p, float4 v) { st_nt8(p, make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w))); }
+// A lane's piece of a state row is ONE 16-byte access whatever the state dtype: four fp32 or (round 6, late) EIGHT bf16 elements.
+// (The first bf16-state build kept four elements per lane = 8-byte accesses and ran the read-only launch at 4.1 TB/s where the fp32
+// state's 16-byte accesses reach 5.5: the CU's memory path is priced per instruction as much as per byte.)
+template <typename TS> struct state_piece { static constexpr int n = 4; };
+template <> struct state_piece<bf16_t> { static constexpr int n = 8; };
+__device__ __forceinline__ void ld_state(const float* p, float (&x)[4]) {
+    const float4 t = LINA_K1W_STATE_LOAD(p);
+    x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+}
+__device__ __forceinline__ void ld_state(const bf16_t* p, float (&x)[8]) {
+    const uint4 u = ld_nt16(p);
+    const float4 lo = cvt4(make_uint2(u.x, u.y)), hi = cvt4(make_uint2(u.z, u.w));
+    x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+}
+__device__ __forceinline__ void st_state(float* p, const float (&x)[4]) { st_nt4(p, make_float4(x[0], x[1], x[2], x[3])); }
+__device__ __forceinline__ void st_state(bf16_t* p, const float (&x)[8]) {
+    st_nt16(p, make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7])));
+}
 
 template <int DV, int NRB, int CS, typename TIO, typename TG, typename TS = float>
 __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
@@ -83,9 +97,10 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
     constexpr int DVT = DV * CS;      // the head's full value width
     constexpr int RB = 64;            // rows per thread group
     constexpr int DK = RB * NRB;
-    constexpr int CG = DV / 4;        // lanes per row
+    constexpr int EPL = state_piece<TS>::n;   // state elements per lane and access (16 bytes)
+    constexpr int CG = DV / EPL;      // lanes per row
     constexpr int RPI = 256 / CG;     // rows per pass of a thread group
-    constexpr int NP = RB / RPI;      // float4 per thread
+    constexpr int NP = RB / RPI;      // 16-byte pieces per thread
     __shared__ float s_q[DK], s_e[DK], s_a[kWinMax][NRB];
     __shared__ float s_w[kWinMax][DK];                                   // e^{c_j - c_s} k_s per row
     __shared__ __attribute__((aligned(16))) float s_v[kWinMax][DV];
@@ -98,7 +113,7 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
     const int r0 = rb * RB;
     const int64_t BH = gridDim.x;
     const int col0 = CS > 1 ? (int)blockIdx.y * DV : 0;
-    TS* tile = S + ((int64_t)bh * DK + r0) * DVT + col0 + 4 * cg;
+    TS* tile = S + ((int64_t)bh * DK + r0) * DVT + col0 + EPL * cg;
 
     // window position: workgroup-uniform.  flush_n >= 0: apply the first flush_n history entries to the state, no output
     const bool flush_only = flush_n >= 0;
@@ -135,9 +150,9 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
         if (!flush_only) vj = ld(v + b * v_sb + h * v_sh + col0 + vc);
     }
 
-    float4 St[NP];
+    float St[NP][EPL];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) St[i] = ld_state4(tile + (int64_t)(rg + RPI * i) * DVT);
+    for (int i = 0; i < NP; ++i) ld_state(tile + (int64_t)(rg + RPI * i) * DVT, St[i]);
 
     // ---- per-row gate bookkeeping and the window's v rows
     if (row_wave) {
@@ -191,54 +206,59 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
     }
     __syncthreads();
 
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
     if (write_back) {
         // S <- e^{c_j} S + sum_s w_s (x) v_s  (the window's rank-(j+1) update), o from the UPDATED rows
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const float d = s_e[r0 + rg + RPI * i];
-            St[i].x *= d; St[i].y *= d; St[i].z *= d; St[i].w *= d;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) St[i][e] *= d;
         }
         for (int s = 0; s <= j; ++s) {
-            const float4 vv = *reinterpret_cast<const float4*>(&s_v[s][4 * cg]);
+            float vv[EPL];
+#pragma unroll
+            for (int e4 = 0; e4 < EPL; e4 += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(&s_v[s][EPL * cg + e4]);
+                vv[e4] = t.x; vv[e4 + 1] = t.y; vv[e4 + 2] = t.z; vv[e4 + 3] = t.w;
+            }
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const float ws = s_w[s][r0 + rg + RPI * i];
-                St[i].x = fmaf(ws, vv.x, St[i].x);
-                St[i].y = fmaf(ws, vv.y, St[i].y);
-                St[i].z = fmaf(ws, vv.z, St[i].z);
-                St[i].w = fmaf(ws, vv.w, St[i].w);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) St[i][e] = fmaf(ws, vv[e], St[i][e]);
             }
         }
 #pragma unroll
-        for (int i = 0; i < NP; ++i) st_state4(tile + (int64_t)(rg + RPI * i) * DVT, St[i]);
+        for (int i = 0; i < NP; ++i) st_state(tile + (int64_t)(rg + RPI * i) * DVT, St[i]);
         if (flush_only) return;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const float qq = s_q[r0 + rg + RPI * i];
-            acc.x = fmaf(qq, St[i].x, acc.x);
-            acc.y = fmaf(qq, St[i].y, acc.y);
-            acc.z = fmaf(qq, St[i].z, acc.z);
-            acc.w = fmaf(qq, St[i].w, acc.w);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = fmaf(qq, St[i][e], acc[e]);
         }
     } else {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int rr = r0 + rg + RPI * i;
             const float qe = s_q[rr] * s_e[rr];
-            acc.x = fmaf(qe, St[i].x, acc.x);
-            acc.y = fmaf(qe, St[i].y, acc.y);
-            acc.z = fmaf(qe, St[i].z, acc.z);
-            acc.w = fmaf(qe, St[i].w, acc.w);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = fmaf(qe, St[i][e], acc[e]);
         }
     }
-    *reinterpret_cast<float4*>(&s_red[(rb * RPI + rg) * DV + 4 * cg]) = acc;
+#pragma unroll
+    for (int e4 = 0; e4 < EPL; e4 += 4)
+        *reinterpret_cast<float4*>(&s_red[(rb * RPI + rg) * DV + EPL * cg + e4]) = make_float4(acc[e4], acc[e4 + 1], acc[e4 + 2], acc[e4 + 3]);
     __syncthreads();
     if (tid < 64) {
         // ---- wave 0 finishes the head: sum of the NRB*RPI row-group partials (+ the pending window terms), then K5:
         // RMS-normalise over Dv, weight, swish gate (reference model/gla.py:219)
+        constexpr int CG4 = DV / 4;                               // the tail's lanes: four columns each, whatever EPL
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < CG) {
+        if (tid < CG4) {
             r = *reinterpret_cast<const float4*>(&s_red[4 * tid]);
 #pragma unroll
             for (int jj = 1; jj < NRB * RPI; ++jj) {
@@ -259,7 +279,7 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
         ss += shfl_xor(ss, 8); ss += shfl_xor(ss, 16); ss += shfl_xor(ss, 32);
         // finish columns [c0, c0 + DV) of the head from the un-normalised values r (lane = 4 columns)
         auto finish = [&](float4 x, int c0, float rs) {
-            if (tid < CG) {
+            if (tid < CG4) {
                 x.x *= rs; x.y *= rs; x.z *= rs; x.w *= rs;
 #if LINA_K1W_NO_TAIL_LOADS
                 const float4 ww = make_float4(1.f, 1.f, 1.f, 1.f), gg = make_float4(eps, scale, eps, scale);
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
         } else {
             // publish this half, take a ticket; the LAST arriver reads the other halves and normalises the whole head
             float* ox = o_x + (int64_t)bh * DVT;
-            if (tid < CG) { st_agent8(ox + col0 + 4 * tid, r.x, r.y); st_agent8(ox + col0 + 4 * tid + 2, r.z, r.w); }
+            if (tid < CG4) { st_agent8(ox + col0 + 4 * tid, r.x, r.y); st_agent8(ox + col0 + 4 * tid + 2, r.z, r.w); }
             drain_stores();
             int t = 0;
             if (tid == 0) t = ticket_agent(&counters[bh]);
@@ -293,7 +313,7 @@ __global__ __launch_bounds__(256 * NRB) void gla_decode_window_kernel(
                     oth[c] = r;
                     if (c != (int)blockIdx.y) {
                         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (tid < CG) {
+                        if (tid < CG4) {
                             const float2 lo = ld_agent8(ox + c * DV + 4 * tid), hi = ld_agent8(ox + c * DV + 4 * tid + 2);
                             x = make_float4(lo.x, lo.y, hi.x, hi.y);
                         }

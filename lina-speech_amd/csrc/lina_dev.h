@@ -247,6 +247,11 @@ __device__ __forceinline__ void st_nt8(void* p, uint2 v) {
     const u32x2_t t = {v.x, v.y};
     __builtin_nontemporal_store(t, reinterpret_cast<u32x2_t*>(p));
 }
+__device__ __forceinline__ void st_nt16(void* p, uint4 v) {
+    typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
+    u32x4s_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4s_t*>(p));
+}
 __device__ __forceinline__ float ld_nt1(const float* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void st_nt1(float* p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void st_nt4(float* p, float4 v) {

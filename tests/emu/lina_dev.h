@@ -320,6 +320,7 @@ static inline void opaque_raw(uint2&) {}
 static inline void opaque_raw(uint4&) {}
 static inline void opaque_raw(float4&) {}
 static inline uint4 ld_nt16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+static inline void st_nt16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
 static inline float ld_nt1(const float* p) { return *p; }
 static inline uint2 ld_nt8(const void* p) { return *reinterpret_cast<const uint2*>(p); }
 static inline void st_nt8(void* p, uint2 v) { *reinterpret_cast<uint2*>(p) = v; }
