@@ -244,7 +244,7 @@ def measure_chunk_bwd(dev, B=8, H=4, T=4096, Dk=256, Dv=256, reps=100):
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS}
 
 
-def measure_train_step(dev, b=8, T=4096, steps=5):
+def measure_train_step(dev, b=8, T=4096, steps=10):
     """a-11: one L169 training step (teacher-forced forward, CE loss, backward through K2b/K3b/K5b, fused AdamW) in
     bf16 autocast on one GPU; synthetic config-5 batch."""
     from lina_speech_amd.configs import l169
@@ -252,17 +252,32 @@ def measure_train_step(dev, b=8, T=4096, steps=5):
     torch.manual_seed(0)
     ts = TrainStep(l169(), device=dev, ddp=False)
     batch = synthetic_batch(b=b, n=T + 1, t_txt=T_TXT, seed=1).to(dev)
-    for _ in range(2):
+    import gc
+    for _ in range(3):
         ts.step(batch)
     torch.cuda.synchronize()
+    # The bench process holds the decode engines' object graphs by now: ONE full (generation-2) collection over them inside the
+    # timed region stalled the host for 139 ms -- a 5-step mean of 59.5 ms against 52.3 with those objects frozen and 51.4 for
+    # the same step in a fresh process (tools/perf_train_step.py), same box, same session (profiles/r06_train_gc.txt).  Collect
+    # now and keep the collector off the OLD objects (young-generation collections still run, and are counted below).
+    if os.environ.get("BENCH_TRAIN_GC", "freeze") == "freeze":
+        gc.collect()
+        gc.freeze()
+    gc0 = [g["collections"] for g in gc.get_stats()]
+    host = []
     t0 = time.perf_counter()
     for _ in range(steps):
+        h0 = time.perf_counter()
         loss = ts.step(batch)
+        host.append(time.perf_counter() - h0)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     res = {"what": "L169 train step: fwd + CE + bwd + AdamW, bf16 autocast, fp32 master weights", "micro_batch": b,
            "seq_len": T, "ms_per_step": dt * 1e3, "tokens_per_s": b * T / dt, "loss": float(loss),
-           "mode": "eager launches", "steps_timed": steps, "max_mem_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
+           "mode": "eager launches", "steps_timed": steps, "max_mem_GB": torch.cuda.max_memory_allocated(dev) / 1e9,
+           "host_issue_ms_per_step": sum(host) / steps * 1e3, "host_issue_ms_min_max": [min(host) * 1e3, max(host) * 1e3],
+           "gc_collections_in_timed_region": [g["collections"] - a for g, a in zip(gc.get_stats(), gc0)]}
+    gc.unfreeze()
     del ts, batch
     torch.cuda.empty_cache()
     return res
