@@ -17,7 +17,7 @@ from .backend import _check, _dt, _inner_contig, _ptr, fused_ops_available
 from .kernels import (
     _gla_prepare, _gla_launch, gla_chunk_bwd, _short_conv_launch, _sum_partials, _sum_partials2, column_sum,
     _sum_vector, _embed_sum_launch)
-from .policy import _MLP_PAD, _linear_split
+from .policy import POLICY, _MLP_PAD, _linear_split
 
 
 class _GLAFunction(torch.autograd.Function):
@@ -616,6 +616,66 @@ class _LinearFunction(torch.autograd.Function):
         return dx, dw, db
 
 
+class _StackedLinearFunction(torch.autograd.Function):
+    """``F.linear(x, cat(parts, 0))`` for row blocks ``parts`` that are separate fp32 parameters (the q | k | v | g | low-rank
+    projections of a mixer input, reference model/gla.py:158-160,216): the stacked GEMM-dtype operand is ONE pass over the
+    master weights (K16 ``lina_stack_rows``, with ``pad`` zero rows after the blocks) instead of ``torch.cat`` (an fp32 copy of
+    all of them) + the autocast cast; backward: dX on the library GEMM, dW as in ``_LinearFunction`` (fp32, token-split), and
+    every block's gradient is its row range of dW -- a contiguous view, no split pass."""
+
+    @staticmethod
+    def forward(ctx, x, pad, *parts):
+        be = _backend._BACKEND
+        cd = x.dtype
+        if x.is_cuda and torch.is_autocast_enabled("cuda"):
+            cd = torch.get_autocast_dtype("cuda")
+        rows = [int(p.shape[0]) for p in parts]
+        n_in = parts[0].shape[1]
+        wc = torch.empty(sum(rows) + pad, n_in, dtype=cd, device=x.device)
+        import ctypes as C
+        srcs = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+        nrow = (C.c_int * len(parts))(*rows)
+        _check(be.lib.lina_stack_rows(srcs, nrow, len(parts), n_in, wc.shape[0], _ptr(wc), _dt(wc), be.stream(wc)))
+        xc = x.to(cd)
+        with torch.autocast(x.device.type, enabled=False):
+            y = F.linear(xc, wc)
+        ctx.save_for_backward(xc, wc)
+        ctx.rows, ctx.xdt = rows, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc = ctx.saved_tensors
+        n_out, n_in = wc.shape
+        dy2 = dy.to(xc.dtype).reshape(-1, n_out)
+        with torch.autocast(xc.device.type, enabled=False):
+            dx = torch.mm(dy2, wc).view(xc.shape).to(ctx.xdt) if ctx.needs_input_grad[0] else None
+            grads = [None] * len(ctx.rows)
+            if any(ctx.needs_input_grad[2:]):
+                dw = linear_weight_grad(dy2.contiguous(), xc.reshape(-1, n_in).contiguous())       # fp32 [n_out, n_in]
+                r0 = 0
+                for i, r in enumerate(ctx.rows):
+                    if ctx.needs_input_grad[2 + i]:
+                        grads[i] = dw[r0:r0 + r]
+                    r0 += r
+        return (dx, None, *grads)
+
+
+def stacked_linear(x, parts, pad: int = 0):
+    """``F.linear(x, torch.cat(parts + [zeros(pad, n_in)], 0))`` -- see ``_StackedLinearFunction``.  Falls back to that very
+    expression (through ``linear``) when the blocks are not contiguous fp32 parameters on the fused-op device."""
+    ok = (POLICY.one_pass_operands and torch.is_grad_enabled() and fused_ops_available(x) and x.dim() >= 2 and 1 <= len(parts) <= 8
+          and all(p.dtype == torch.float32 and p.is_contiguous() and p.dim() == 2 and p.shape[1] == parts[0].shape[1]
+                  and p.data_ptr() % 16 == 0 for p in parts) and parts[0].shape[1] % 4 == 0)
+    cd = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled("cuda")) else x.dtype
+    if not ok or cd not in (torch.float32, torch.bfloat16):
+        w = list(parts)
+        if pad:
+            w.append(parts[0].new_zeros(pad, parts[0].shape[1]))
+        return linear(x, torch.cat(w, dim=0))
+    return _StackedLinearFunction.apply(x, pad, *parts)
+
+
 def linear(x, weight, bias=None):
     """``F.linear(x, weight, bias)`` for the projections of the train path: same forward GEMM (autocast semantics
     included), weight gradient posed as a token-split batched GEMM in fp32.  Without gradients: F.linear itself."""
@@ -702,17 +762,27 @@ def _mlp_padded_weights(w_in, b_in, w_out, b_out, cd, H, Hp):
         return hit[1], hit[2], hit[3]
     dev, d_in, d_out = w_in.device, w_in.shape[1], w_out.shape[0]
     Wi = torch.empty(2, Hp, d_in, dtype=cd, device=dev)
-    Wi[:, H:].zero_()
-    Wi[:, :H].copy_(w_in.detach().view(2, H, d_in))
-    bi = torch.zeros(2, Hp, dtype=cd, device=dev)
-    if b_in is not None:
-        bi[:, :H].copy_(b_in.detach().view(2, H))
+    bi = torch.empty(2, Hp, dtype=cd, device=dev)
     Wo = torch.empty(d_out, Hp, dtype=cd, device=dev)
-    Wo[:, H:].zero_()
-    Wo[:, :H].copy_(w_out.detach())
-    if b_out is not None:
-        bi[:, H] = _mlp_one(cd, dev)
-        Wo[:, H].copy_(b_out.detach())
+    f32c = lambda t: t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    if POLICY.one_pass_operands and f32c(w_in) and f32c(b_in) and f32c(w_out) and f32c(b_out) and d_in % 4 == 0:
+        # K15: the three operands in ONE pass over the fp32 master weights (torch built them with three fills and five strided
+        # copies: nine launches per block and step)
+        be = _backend._BACKEND
+        _check(be.lib.lina_mlp_pack(_ptr(w_in.detach()), _ptr(None if b_in is None else b_in.detach()), _ptr(w_out.detach()),
+                                    _ptr(None if b_out is None else b_out.detach()), _ptr(Wi), _ptr(bi), _ptr(Wo), H, Hp, d_in,
+                                    d_out, _dt(Wi), be.stream(Wi)))
+    else:                                       # master weights that are not contiguous fp32: the same values with torch ops
+        Wi[:, H:].zero_()
+        Wi[:, :H].copy_(w_in.detach().view(2, H, d_in))
+        bi.zero_()
+        if b_in is not None:
+            bi[:, :H].copy_(b_in.detach().view(2, H))
+        Wo[:, H:].zero_()
+        Wo[:, :H].copy_(w_out.detach())
+        if b_out is not None:
+            bi[:, H] = _mlp_one(cd, dev)
+            Wo[:, H].copy_(b_out.detach())
     _MLP_PACK[w_in] = (key, Wi, bi, Wo)
     return Wi, bi, Wo
 

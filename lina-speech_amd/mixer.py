@@ -141,15 +141,11 @@ class GatedLinearAttention(nn.Module):
                 # 17 column tiles of 256 either way
                 pad = (-sum(sizes)) % 64
                 if pad:
-                    zp = self.__dict__.get("_stack_pad")          # constant zero rows (not a parameter, not in the state dict)
-                    w0 = self.q_proj.weight
-                    if zp is None or zp.shape[0] != pad or zp.device != w0.device or zp.dtype != w0.dtype:
-                        zp = self.__dict__["_stack_pad"] = w0.new_zeros(pad, w0.shape[1])
-                    parts.append(zp)
                     sizes.append(pad)
-                w_cat = torch.cat(parts, dim=0)
+                # the stacked GEMM-dtype operand in ONE pass over the master weights (K16; zero pad rows included) and the
+                # blocks' gradients as row ranges of dW -- no torch.cat of fp32 weights, no cast, no split in backward
                 # (training: the consumers of the slices write their input gradients into ONE slab -- no concat pass)
-                (q, k, v, g_pre, lr_pre, *_), slab = ops.split_slab(ops.linear(hidden_states, w_cat), sizes)
+                (q, k, v, g_pre, lr_pre, *_), slab = ops.split_slab(ops.stacked_linear(hidden_states, parts, pad), sizes)
             else:
                 q, k, v = self.q_proj(hidden_states), self.k_proj(hidden_states), self.v_proj(hidden_states)
             if self.use_short_conv:

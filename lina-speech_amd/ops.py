@@ -33,6 +33,6 @@ from .autograd import (
     _GLAFunction, _needs_grad, _gla, fused_recurrent_gla, naive_recurrent_gla, chunk_gla, fused_chunk_gla,
     chunk_simple_gla, GradSlab, _slab_part, _SplitSlabFunction, split_slab, _ShortConvFunction, short_conv, _ShortConv3Function, short_conv3,
     _RMSNormGateFunction, _gate_rows_view, rmsnorm_swish_gate, rmsnorm, _LayerNormFunction, _LN_TRIPLES, layer_norm,
-    _SwiGLUFunction, swiglu_gate, linear_weight_grad, _LinearFunction, linear, _SwiGLUMLPFunction, _MLP_ONE,
+    _SwiGLUFunction, swiglu_gate, linear_weight_grad, _LinearFunction, linear, _StackedLinearFunction, stacked_linear, _SwiGLUMLPFunction, _MLP_ONE,
     _mlp_one, swiglu_mlp, clear_mlp_pack, _GateLogSigmoidFunction, gate_logsigmoid, _GateLowRankFunction, gate_lowrank,
     _CrossEntropyFunction, cross_entropy, _EmbedSumFunction, embed_sum)

@@ -15,6 +15,9 @@ class Policy:
     # head paired on one XCD (gla_chunk_full.hip, NCB = 2: q, k, g reach HBM once); False = one launch per column block
     # (rounds 2-5; still what the segment-parallel form and the backward do)
     dv512_one_launch: bool = True
+    # train path: the stacked projection weight (K16) and the channel mixer's padded operands (K15) in ONE pass each over the
+    # fp32 master weights; False = torch.cat / cast / fills / strided copies (rounds 3-6, ~190 more launches per step)
+    one_pass_operands: bool = True
 
 
 POLICY = Policy()

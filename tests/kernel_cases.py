@@ -839,6 +839,61 @@ def check_swiglu_mlp(dev, B, T, d, H, dtype, bias=True):
     assert_close(y4, y64.detach(), tol, "MLP y after a .data write + clear_mlp_pack()")
 
 
+def check_mlp_pack(dev, H=45, d_in=24, d_out=20, out_dtype=torch.bfloat16, bias=True):
+    """K15 ``lina_mlp_pack`` (the channel mixer's padded GEMM operands in one pass over the fp32 master weights) against the
+    torch construction it replaces -- bit for bit: zero pads, the (32, 1/32) bias pair, b_out in column H."""
+    from lina_speech_amd.autograd import _mlp_padded_weights, _MLP_PAD
+    g = torch.Generator().manual_seed(61)
+    w_in = torch.randn(2 * H, d_in, generator=g).to(dev)
+    b_in = torch.randn(2 * H, generator=g).to(dev) if bias else None
+    w_out = torch.randn(d_out, H, generator=g).to(dev)
+    b_out = torch.randn(d_out, generator=g).to(dev) if bias else None
+    Hp = (H + _MLP_PAD) // _MLP_PAD * _MLP_PAD
+    ops.clear_mlp_pack()
+    Wi, bi, Wo = _mlp_padded_weights(w_in, b_in, w_out, b_out, out_dtype, H, Hp)
+    rWi = torch.zeros(2, Hp, d_in, dtype=out_dtype, device=dev)
+    rWi[:, :H] = w_in.view(2, H, d_in).to(out_dtype)
+    rbi = torch.zeros(2, Hp, dtype=out_dtype, device=dev)
+    rWo = torch.zeros(d_out, Hp, dtype=out_dtype, device=dev)
+    rWo[:, :H] = w_out.to(out_dtype)
+    if bias:
+        rbi[:, :H] = b_in.view(2, H).to(out_dtype)
+        rbi[0, H], rbi[1, H] = 32.0, 1.0 / 32.0
+        rWo[:, H] = b_out.to(out_dtype)
+    assert Wi.dtype == out_dtype and torch.equal(Wi, rWi) and torch.equal(bi, rbi) and torch.equal(Wo, rWo)
+    ops.clear_mlp_pack()
+
+
+def check_stacked_linear(dev, rows=(8, 8, 16, 16, 4), n_in=24, pad=12, B=3, T=7, autocast=False):
+    """``ops.stacked_linear`` (K16: the stacked operand in one pass, block gradients as row ranges of dW) against
+    ``F.linear(x, cat(parts + zero rows))`` through fp64 autograd; the blocks' gradients are contiguous views of ONE tensor."""
+    g = torch.Generator().manual_seed(62)
+    parts64 = [torch.randn(r, n_in, generator=g).to(F64).requires_grad_() for r in rows]
+    x64 = torch.randn(B, T, n_in, generator=g).to(F64).requires_grad_()
+    dy = torch.randn(B, T, sum(rows) + pad, generator=g)
+    y64 = F.linear(x64, torch.cat(parts64 + [torch.zeros(pad, n_in, dtype=F64)], 0))
+    (y64 * dy.to(F64)).sum().backward()
+    parts = [p.detach().float().to(dev).requires_grad_() for p in parts64]
+    x = x64.detach().float().to(dev).requires_grad_()
+    if autocast:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = ops.stacked_linear(x, parts, pad)
+        assert y.dtype == torch.bfloat16
+        tol = 3e-2
+    else:
+        y = ops.stacked_linear(x, parts, pad)
+        tol = 2e-5
+    assert type(y.grad_fn).__name__ == "_StackedLinearFunctionBackward", type(y.grad_fn).__name__
+    assert y.shape == (B, T, sum(rows) + pad)
+    assert_close(y, y64.detach(), tol, "stacked linear y")
+    assert pad == 0 or float(y.detach()[..., sum(rows):].abs().max()) == 0.0, "pad columns must be exactly zero"
+    (y.float() * dy.to(dev)).sum().backward()
+    assert_close(x.grad, x64.grad, tol, "stacked linear dx")
+    for i, (p, r) in enumerate(zip(parts, parts64)):
+        assert p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.shape == r.grad.shape
+        assert_close(p.grad, r.grad, tol, f"stacked linear dW[{i}]")
+
+
 def check_block_chain(dev, dtype, B=2, T=70, d=64):
     """MixingBlock chained on (stream, pending branch) -- the last residual add of a block inside the next block's norm1
     pass (K10 with a residual), the way AttentiveGLA.forward runs a stack -- against the plain loop over the same blocks:

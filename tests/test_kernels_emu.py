@@ -440,3 +440,12 @@ def test_cross_entropy_edge_shapes(emu, N, V, ld, dtype):
 def test_column_sum(emu):
     from kernel_cases import check_column_sum
     check_column_sum(DEV)
+
+
+def test_train_weight_operands_in_one_pass(emu):
+    from kernel_cases import check_mlp_pack, check_stacked_linear
+    check_mlp_pack(DEV)
+    check_mlp_pack(DEV, out_dtype=torch.float32, bias=False)
+    check_mlp_pack(DEV, H=127, d_in=8, d_out=3)              # H + 1 = Hp: the bias column is the last one
+    check_stacked_linear(DEV)
+    check_stacked_linear(DEV, rows=(5,), pad=0)

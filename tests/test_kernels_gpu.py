@@ -539,3 +539,14 @@ def test_cross_entropy_edge_shapes(hip, N, V, ld, dtype):
 def test_column_sum(hip):
     from kernel_cases import check_column_sum
     check_column_sum(DEV)
+
+
+def test_train_weight_operands_in_one_pass(hip):
+    from kernel_cases import check_mlp_pack, check_stacked_linear
+    check_mlp_pack(DEV)
+    check_mlp_pack(DEV, out_dtype=torch.float32, bias=False)
+    check_mlp_pack(DEV, H=127, d_in=8, d_out=3)              # H + 1 = Hp: the bias column is the last one
+    check_stacked_linear(DEV)
+    check_stacked_linear(DEV, rows=(5,), pad=0)
+    check_stacked_linear(DEV, rows=(1024, 1024, 1024, 1024, 16), n_in=1024, pad=48, B=2, T=600, autocast=True)   # the L169 mixer's stack under autocast
+    check_mlp_pack(DEV, H=1365, d_in=1024, d_out=1024)

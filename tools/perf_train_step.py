@@ -14,6 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lina_speech_amd import configs  # noqa: E402
 from lina_speech_amd.train import TrainStep, synthetic_batch  # noqa: E402
 
+if os.environ.get("TRAIN_OPERANDS") == "0":               # A/B: the torch-op construction of the stacked / padded weight operands
+    from lina_speech_amd import ops as _ops
+    _ops.POLICY.one_pass_operands = False
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5
 WARM = 2
 dev = torch.device("cuda", 0)
