@@ -25,6 +25,22 @@ def attention_with_weights(q, k, v, mask=None):
     return w @ v, w
 
 
+def train_attention(q, k, v, mask=None, dropout_p: float = 0.0):
+    """``F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=p)`` (what the reference's training branch calls,
+    crossatt.py:141-144) for THIS shape -- one head of width d (1024: above every fused kernel's head size, so torch takes its
+    math path), thousands of queries against a few dozen text positions.  The math path scales q AND k by d^-1/4 before the
+    product and expands a shared operand per batch row: six passes over [B, 1, T, d] tensors for products whose results are
+    [B, 1, T, Ttxt].  Here the scale is applied to the small score tensor and shared operands stay shared (a [1, 1, Ttxt, d]
+    operand folds the batch into ONE GEMM); mask, softmax and dropout as in the math path (bool mask -> -inf)."""
+    w = torch.matmul(q, k.transpose(-2, -1)) * (1.0 / math.sqrt(q.size(-1)))
+    if mask is not None:
+        w = w.masked_fill(~mask, float("-inf")) if mask.dtype == torch.bool else w + mask
+    w = torch.softmax(w, dim=-1)
+    if dropout_p > 0.0:
+        w = torch.dropout(w, dropout_p, True)
+    return torch.matmul(w, v)        # (under autocast the fp32 softmax output is cast with v; otherwise the dtypes agree)
+
+
 class ConvPos(nn.Module):
     def __init__(self, dim: int, max_seq_len: int = 2000, kernel_size: int = 31):
         super().__init__()
@@ -75,9 +91,7 @@ class BlindCrossAttention(nn.Module):
         if mask is not None:
             mask = mask.unsqueeze(1)
         if self.training:
-            sdpa = lambda a, b, c: (nn.functional.scaled_dot_product_attention(
-                a, b, c.expand(a.shape[0], -1, -1, -1) if c.shape[0] != a.shape[0] else c,
-                attn_mask=mask, dropout_p=self.dropout_att.p), None)
+            sdpa = lambda a, b, c: (train_attention(a, b, c, mask, self.dropout_att.p), None)
         else:
             sdpa = lambda a, b, c: attention_with_weights(a, b, c, mask=mask)
         x, att1 = sdpa(qq, kk, pe)
