@@ -77,17 +77,26 @@ class BlindCrossAttention(nn.Module):
         self.dropout_att = nn.Dropout(dropout)
         self._prepared = None
 
+    @staticmethod
+    def _norm(ln: nn.LayerNorm, x):
+        """``ln(x)`` on the fused LayerNorm (K10) where the ops run: under autocast nn.LayerNorm casts its bf16 input to fp32,
+        normalises, and the attention product casts the fp32 result back -- two passes over [B, T, d] each way that K10's
+        bf16-in / bf16-out form (fp32 statistics inside, the same rounding point) does not make."""
+        if ops.fused_ops_available(x) and ln.weight is not None and ln.bias is not None:
+            return ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
+        return ln(x)
+
     def prepare(self, ctx, pos=None):
         """Step-invariant text side: (k, v, pos_emb), each [B|1, 1, Ttxt, d]."""
-        k = self.ln_k(ops.linear(ctx, self.k.weight, self.k.bias)).unsqueeze(1)      # (ops.linear: nn.Linear's forward;
-        v = self.ln_v(ops.linear(ctx, self.v.weight, self.v.bias)).unsqueeze(1)      #  bias gradient as K13a / K13)
+        k = self._norm(self.ln_k, ops.linear(ctx, self.k.weight, self.k.bias)).unsqueeze(1)   # (ops.linear: nn.Linear's forward;
+        v = self._norm(self.ln_v, ops.linear(ctx, self.v.weight, self.v.bias)).unsqueeze(1)   #  bias gradient as K13a / K13)
         if pos is None:
             pos = torch.arange(ctx.shape[1], device=ctx.device).unsqueeze(0)
         return k, v, self.pos_embed(pos).unsqueeze(1)
 
     def forward(self, q, k, mask=None, time_step=None, pos=None, prepared=None, **kwargs):
         kk, vv, pe = prepared if prepared is not None else self.prepare(k, pos)
-        qq = self.ln_q(ops.linear(q, self.q.weight, self.q.bias)).unsqueeze(1)
+        qq = self._norm(self.ln_q, ops.linear(q, self.q.weight, self.q.bias)).unsqueeze(1)
         if mask is not None:
             mask = mask.unsqueeze(1)
         if self.training:
