@@ -314,6 +314,16 @@ int lina_mlp_pack(const float* w_in, const float* b_in, const float* w_out, cons
 int lina_stack_rows(const float* const* srcs, const int* rows, int n_src, int cols, int total_rows, void* out, int out_dtype,
                     lina_stream_t stream);
 
+/* K17 -- AdamW (decoupled weight decay) over n_tensors fp32 tensors, 48 per launch (reference train_lina.py:104-118:
+ * torch.optim.AdamW; the operation order of torch's `_fused_adamw_` in fp32):
+ *   p -= lr wd p;  m += (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g g;  p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)
+ * params / grads / exp_avg / exp_avg_sq / numel are HOST arrays of n_tensors device pointers / element counts;
+ * bias_correction1 = 1 - beta1^t, bias_correction2 = 1 - beta2^t for the step t >= 1 being taken. */
+int lina_adamw_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                     const int64_t* numel, int n_tensors, double lr, double beta1, double beta2, double eps, double weight_decay,
+                     double bias_correction1, double bias_correction2, lina_stream_t stream);
+int lina_adamw_multi_max(void);   /* tensors per launch */
+
 /* K11c -- K11b that also leaves the column sums of du (the bias gradient of the up-projection):
  *   colsum_partial fp32 [lina_swiglu_bwd_partials(rows)][2 Hd], summed over dim 0 by the caller (sums of the values as
  *   stored in `dtype`).  Hd and the row strides must be multiples of 4. */

@@ -120,3 +120,97 @@ extern "C" int lina_stack_rows(const float* const* srcs, const int* rows, int n_
     else LINA_LAUNCH((stack_rows_kernel<bf16_t>), grid, dim3(256), 0, stream, s, n_src, cols, total_rows, (bf16_t*)out);
     return check_launch("lina_stack_rows");
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// K17 -- AdamW over MANY tensors per launch (reference train_lina.py:104-118: torch.optim.AdamW, lr 5e-4, betas (0.9, 0.999),
+// weight decay 0.1).  The decoupled-weight-decay update of torch's own `_fused_adamw_`, same operation order in fp32:
+//     p -= lr wd p;   m += (1 - b1)(g - m);   v = b2 v + (1 - b2) g g;   p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)
+// with bc1 = 1 - b1^t, bc2 = 1 - b2^t formed on the host in double.  One launch takes up to kAdamMax tensors by value (no
+// device-side table to keep current: gradient tensors are new allocations every step); a block owns 4096 consecutive elements of
+// one tensor and streams p, g, m, v with 16-byte accesses (m, v, g non-temporal: touched once per step).
+namespace lina {
+
+constexpr int kAdamMax = 48;
+constexpr int kAdamBlock = 4096;          // elements per block: 256 threads x 4 pieces of 4
+struct adam_tensors {
+    float* p[kAdamMax];
+    const float* g[kAdamMax];
+    float* m[kAdamMax];
+    float* v[kAdamMax];
+    int64_t n[kAdamMax];
+    int blk_end[kAdamMax];                // first block AFTER tensor i's blocks
+};
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(adam_tensors T, int n_tensors, float step_size, float decay, float omb1,
+                                                          float beta2, float omb2, float eps, float bc2_sqrt) {
+    int t = 0, b0 = 0;
+    const int blk = blockIdx.x;
+#pragma unroll 1
+    while (t < n_tensors - 1 && blk >= T.blk_end[t]) { b0 = T.blk_end[t]; ++t; }
+    if (t > 0) b0 = T.blk_end[t - 1];
+    float* __restrict__ p = T.p[t];
+    const float* __restrict__ g = T.g[t];
+    float* __restrict__ m = T.m[t];
+    float* __restrict__ v = T.v[t];
+    const int64_t n = T.n[t];
+    const int64_t base = (int64_t)(blk - b0) * kAdamBlock;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        pp -= decay * pp;
+        mm = mm + omb1 * (gg - mm);
+        vv = beta2 * vv + omb2 * gg * gg;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pp -= step_size * mm / denom;
+    };
+    const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15u) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t e = base + (int64_t)(i * 256 + threadIdx.x) * 4;
+        if (e >= n) break;
+        if (vec && e + 4 <= n) {
+            float4 pp = *reinterpret_cast<const float4*>(p + e);
+            const float4 gg = ld_nt4(g + e);
+            float4 mm = ld_nt4(m + e), vv = ld_nt4(v + e);
+            upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+            *reinterpret_cast<float4*>(p + e) = pp;
+            st_nt4(m + e, mm);
+            st_nt4(v + e, vv);
+        } else {
+            for (int64_t j = e; j < n && j < e + 4; ++j) {
+                float pp = p[j], mm = m[j], vv = v[j];
+                upd(pp, g[j], mm, vv);
+                p[j] = pp; m[j] = mm; v[j] = vv;
+            }
+        }
+    }
+}
+
+}  // namespace lina
+
+extern "C" int lina_adamw_multi_max(void) { return lina::kAdamMax; }
+
+extern "C" int lina_adamw_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                                const int64_t* numel, int n_tensors, double lr, double beta1, double beta2, double eps,
+                                double weight_decay, double bias_correction1, double bias_correction2, lina_stream_t stream) {
+    using namespace lina;
+    LINA_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel, "lina_adamw_multi: null pointer");
+    LINA_REQUIRE(n_tensors >= 0, "lina_adamw_multi: n_tensors must be >= 0");
+    LINA_REQUIRE(bias_correction1 > 0.0 && bias_correction2 > 0.0, "lina_adamw_multi: bias corrections must be positive (step >= 1)");
+    for (int i0 = 0; i0 < n_tensors; i0 += kAdamMax) {
+        adam_tensors T{};
+        const int nt = n_tensors - i0 < kAdamMax ? n_tensors - i0 : kAdamMax;
+        int64_t blocks = 0;
+        for (int i = 0; i < nt; ++i) {
+            const int j = i0 + i;
+            LINA_REQUIRE(params[j] && grads[j] && exp_avg[j] && exp_avg_sq[j] && numel[j] > 0, "lina_adamw_multi: tensor %d is empty", j);
+            T.p[i] = params[j]; T.g[i] = grads[j]; T.m[i] = exp_avg[j]; T.v[i] = exp_avg_sq[j]; T.n[i] = numel[j];
+            blocks += (numel[j] + kAdamBlock - 1) / kAdamBlock;
+            LINA_REQUIRE(blocks < (1LL << 31), "lina_adamw_multi: too many elements in one launch");
+            T.blk_end[i] = (int)blocks;
+        }
+        // the scalars are formed in double and rounded once (1 - 0.999 taken in fp32 is off by 1.3e-5 of itself)
+        LINA_LAUNCH(adamw_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, T, nt, (float)(lr / bias_correction1),
+                    (float)(lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                    (float)sqrt(bias_correction2));
+    }
+    return check_launch("lina_adamw_multi");
+}

@@ -29,6 +29,69 @@ from .lina_model import LinaModel
 DDP_BUCKET_MB = 128        # ~0.67 GB of fp32 gradients at L169 -> 6 buckets
 
 
+class FusedAdamW(torch.optim.AdamW):
+    """``torch.optim.AdamW`` (the reference's optimizer, train_lina.py:104-118) with the update on K17 ``lina_adamw_multi``:
+    same hyper-parameters, ``param_groups`` and per-parameter state (``step`` / ``exp_avg`` / ``exp_avg_sq`` -- ``state_dict``s
+    move freely between the two), the operation order of torch's fused kernel; 48 tensors per launch with the pointer table
+    passed by value.  Falls back to torch's implementation for a step that holds anything K17 is not built for (non-fp32 or
+    non-contiguous parameters / gradients, sparse gradients, amsgrad, maximize, tensors off the fused-op device)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, maximize=False):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, maximize=maximize,
+                         foreach=False, fused=False)
+
+    def _eligible(self) -> bool:
+        for group in self.param_groups:
+            if group["amsgrad"] or group["maximize"] or group.get("capturable") or group.get("differentiable"):
+                return False
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                if (g.is_sparse or p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_contiguous()
+                        or not g.is_contiguous() or p.device != g.device or not ops.fused_ops_available(p)):
+                    return False
+        return True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if not self._eligible():
+            return super().step(closure)
+        import ctypes as C
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        be = ops.get_backend()
+        for group in self.param_groups:
+            by_step = {}
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:                              # torch.optim.AdamW's own lazy state (non-capturable form)
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if st["step"].is_cuda or not st["exp_avg"].is_contiguous() or not st["exp_avg_sq"].is_contiguous():
+                    return super().step(None)                 # (a state loaded from a fused / capturable run: torch's path)
+                st["step"] += 1
+                by_step.setdefault(float(st["step"]), []).append((p, st))
+            beta1, beta2 = group["betas"]
+            lr = float(group["lr"])
+            for t, items in by_step.items():
+                n = len(items)
+                arr = lambda f: (C.c_void_p * n)(*[f(p, st) for p, st in items])
+                numel = (C.c_int64 * n)(*[p.numel() for p, _ in items])
+                ops._check(be.lib.lina_adamw_multi(arr(lambda p, st: p.data_ptr()), arr(lambda p, st: p.grad.data_ptr()),
+                                                   arr(lambda p, st: st["exp_avg"].data_ptr()),
+                                                   arr(lambda p, st: st["exp_avg_sq"].data_ptr()), numel, n, lr, beta1, beta2,
+                                                   group["eps"], group["weight_decay"], 1.0 - beta1 ** t, 1.0 - beta2 ** t,
+                                                   be.stream(items[0][0])))
+        ops.clear_mlp_pack()          # K17 writes the parameters behind their version counters: drop the cached padded operands
+        return loss
+
+
 @dataclass
 class Batch:
     x: torch.Tensor                 # [b, Ttxt] text ids
@@ -85,8 +148,11 @@ class TrainStep:
             ids = [self.device.index] if self.device.type == "cuda" else None
             self.net = DDP(self.model, device_ids=ids, bucket_cap_mb=DDP_BUCKET_MB, gradient_as_bucket_view=True,
                            broadcast_buffers=False)
-        fused = self.device.type == "cuda"
-        self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=weight_decay, betas=betas, fused=fused)
+        # K17 where the fused ops run (a ROCm device, or the test emulator); elsewhere torch's own AdamW
+        if ops.fused_ops_available(next(self.model.parameters())):
+            self.opt = FusedAdamW(self.model.parameters(), lr=lr, weight_decay=weight_decay, betas=betas)
+        else:
+            self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=weight_decay, betas=betas)
 
         def cosine_with_warmup(step: int) -> float:          # transformers.get_cosine_schedule_with_warmup, half a cycle
             if step < n_warmup_steps:

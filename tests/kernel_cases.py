@@ -894,6 +894,47 @@ def check_stacked_linear(dev, rows=(8, 8, 16, 16, 4), n_in=24, pad=12, B=3, T=7,
         assert_close(p.grad, r.grad, tol, f"stacked linear dW[{i}]")
 
 
+def check_fused_adamw(dev, n_small=60, steps=3):
+    """``train.FusedAdamW`` (K17 lina_adamw_multi) against ``torch.optim.AdamW`` on the same parameters / gradients for a few
+    steps: parameters and both moments to fp32 round-off; more tensors than one launch takes, sizes that are not multiples of
+    4 or of a block, a parameter without a gradient, a changing lr; the state dict of one loads into the other."""
+    from lina_speech_amd.train import FusedAdamW
+    g = torch.Generator().manual_seed(71)
+    shapes = [(4099, 64), (1024, 1365), (7,), (1,), (4096,), (4097,), (3, 5, 11)] + [(17 + i,) for i in range(n_small)]
+    ref = [torch.randn(*s, generator=g).requires_grad_() for s in shapes]
+    mine = [r.detach().clone().to(dev).requires_grad_() for r in ref]
+    kw = dict(lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
+    o_ref, o_mine = torch.optim.AdamW(ref, foreach=False, **kw), FusedAdamW(mine, **kw)
+    for it in range(steps):
+        for r, m in zip(ref, mine):
+            gr = torch.randn(r.shape, generator=g)
+            r.grad, m.grad = gr.clone(), gr.clone().to(dev)
+        if it == 1:                                  # a parameter that skips a step (its own step count)
+            ref[3].grad = mine[3].grad = None
+        for o in (o_ref, o_mine):
+            o.param_groups[0]["lr"] = 5e-4 * (it + 1)
+        o_ref.step()
+        o_mine.step()
+    for i, (r, m) in enumerate(zip(ref, mine)):
+        assert_close(m.detach(), r.detach(), 2e-6, f"AdamW param {i} {tuple(r.shape)}")
+        assert_close(o_mine.state[m]["exp_avg"], o_ref.state[r]["exp_avg"], 2e-6, f"AdamW exp_avg {i}")
+        assert_close(o_mine.state[m]["exp_avg_sq"], o_ref.state[r]["exp_avg_sq"], 2e-6, f"AdamW exp_avg_sq {i}")
+        assert float(o_mine.state[m]["step"]) == float(o_ref.state[r]["step"])
+    # state dicts are interchangeable: torch's AdamW continues from ours and the other way round
+    o_ref2 = torch.optim.AdamW([r.detach().clone().requires_grad_() for r in ref], foreach=False, **kw)
+    sd = o_mine.state_dict()
+    sd["state"] = {k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in sd["state"].items()}
+    o_ref2.load_state_dict(sd)
+    o_mine2 = FusedAdamW([m.detach().clone().requires_grad_() for m in mine], **kw)
+    o_mine2.load_state_dict(o_ref.state_dict())
+    for o, ps in ((o_ref2, o_ref2.param_groups[0]["params"]), (o_mine2, o_mine2.param_groups[0]["params"])):
+        for p_ in ps:
+            p_.grad = torch.ones_like(p_)
+        o.step()
+    for a, b in zip(o_ref2.param_groups[0]["params"], o_mine2.param_groups[0]["params"]):
+        assert_close(b.detach(), a.detach(), 2e-6, "AdamW after exchanging state dicts")
+
+
 def check_block_chain(dev, dtype, B=2, T=70, d=64):
     """MixingBlock chained on (stream, pending branch) -- the last residual add of a block inside the next block's norm1
     pass (K10 with a residual), the way AttentiveGLA.forward runs a stack -- against the plain loop over the same blocks:

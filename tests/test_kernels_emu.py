@@ -449,3 +449,8 @@ def test_train_weight_operands_in_one_pass(emu):
     check_mlp_pack(DEV, H=127, d_in=8, d_out=3)              # H + 1 = Hp: the bias column is the last one
     check_stacked_linear(DEV)
     check_stacked_linear(DEV, rows=(5,), pad=0)
+
+
+def test_fused_adamw_matches_torch_adamw(emu):
+    from kernel_cases import check_fused_adamw
+    check_fused_adamw(DEV)

@@ -550,3 +550,8 @@ def test_train_weight_operands_in_one_pass(hip):
     check_stacked_linear(DEV, rows=(5,), pad=0)
     check_stacked_linear(DEV, rows=(1024, 1024, 1024, 1024, 16), n_in=1024, pad=48, B=2, T=600, autocast=True)   # the L169 mixer's stack under autocast
     check_mlp_pack(DEV, H=1365, d_in=1024, d_out=1024)
+
+
+def test_fused_adamw_matches_torch_adamw(hip):
+    from kernel_cases import check_fused_adamw
+    check_fused_adamw(DEV)

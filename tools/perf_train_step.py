@@ -22,6 +22,9 @@ WARM = 2
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 ts = TrainStep(configs.l169(), device=dev, ddp=False)
+if os.environ.get("TRAIN_TORCH_ADAMW") == "1":            # A/B: torch's own fused AdamW instead of K17
+    ts.opt = torch.optim.AdamW(ts.model.parameters(), lr=5e-4, weight_decay=0.1, betas=(0.9, 0.999), fused=True)
+    ts.sched = None
 batch = synthetic_batch(b=8, n=4097, t_txt=64, seed=1).to(dev)
 for _ in range(WARM):
     ts.step(batch)
