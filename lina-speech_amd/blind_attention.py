@@ -25,20 +25,90 @@ def attention_with_weights(q, k, v, mask=None):
     return w @ v, w
 
 
+def _mm_f32(a, b):
+    """a [.., m, k] @ b [.., k, n] with an fp32 RESULT for operands of one GEMM dtype (bf16 operands: the matrix core's fp32
+    accumulators written out unrounded -- ``out_dtype=`` of recent torch; elsewhere the same sums on upcast operands).  ``b`` may
+    have a leading batch of 1: the batch then folds into ONE GEMM."""
+    from .autograd import _mm_has_out_dtype
+    kw = {}
+    if a.dtype != torch.float32:
+        if a.is_cuda and _mm_has_out_dtype(a.device):
+            kw = {"out_dtype": torch.float32}
+        else:
+            a, b = a.float(), b.float()
+    if b.shape[0] == 1:
+        return torch.mm(a.reshape(-1, a.shape[-1]), b[0], **kw).view(*a.shape[:-1], b.shape[-1])
+    return torch.bmm(a, b, **kw)
+
+
+class _TrainAttentionFunction(torch.autograd.Function):
+    """One head of softmax(q k^T / sqrt(d) + mask) v for q [B, T, d], k [B|1, S, d], v [B|1, S, dv], S small (the text) -- the
+    arithmetic of torch's SDPA math path on low-precision inputs (scores and probabilities in fp32) without its passes over
+    [B, T, d]: the score GEMM writes its fp32 accumulators, the probabilities are rounded to the GEMM dtype only as the operand of
+    the second product (as every fused attention kernel does); backward the same way round (dP in fp32, dS rounded as an operand)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask):
+        scale = 1.0 / math.sqrt(q.shape[-1])
+        s = _mm_f32(q, k.transpose(-2, -1)) * scale                       # [B, T, S] fp32
+        if mask is not None:
+            s = s.masked_fill(~mask, float("-inf"))
+        w = torch.softmax(s, dim=-1)
+        wb = w.to(v.dtype)
+        out = torch.matmul(wb, v)                                         # [B, T, dv] (v [1, S, dv]: one GEMM over B T rows)
+        ctx.save_for_backward(q, k, v, w)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, w = ctx.saved_tensors
+        dout = dout.to(v.dtype).contiguous()
+        B, T, S = w.shape
+        dq = dk = dv = None
+        wb = w.to(v.dtype)
+        if ctx.needs_input_grad[2]:
+            dv = (torch.mm(wb.reshape(B * T, S).t(), dout.reshape(B * T, -1)).unsqueeze(0) if v.shape[0] == 1
+                  else torch.bmm(wb.transpose(1, 2), dout))
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dw = _mm_f32(dout, v.transpose(-2, -1))                       # [B, T, S] fp32
+            ds = (w * (dw - (dw * w).sum(-1, keepdim=True)) * ctx.scale).to(q.dtype)
+            if ctx.needs_input_grad[0]:
+                dq = torch.matmul(ds, k)
+            if ctx.needs_input_grad[1]:
+                dk = (torch.mm(ds.reshape(B * T, S).t(), q.reshape(B * T, -1)).unsqueeze(0) if k.shape[0] == 1
+                      else torch.bmm(ds.transpose(1, 2), q))
+        return dq, dk, dv, None
+
+
 def train_attention(q, k, v, mask=None, dropout_p: float = 0.0):
     """``F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=p)`` (what the reference's training branch calls,
-    crossatt.py:141-144) for THIS shape -- one head of width d (1024: above every fused kernel's head size, so torch takes its
-    math path), thousands of queries against a few dozen text positions.  The math path scales q AND k by d^-1/4 before the
-    product and expands a shared operand per batch row: six passes over [B, 1, T, d] tensors for products whose results are
-    [B, 1, T, Ttxt].  Here the scale is applied to the small score tensor and shared operands stay shared (a [1, 1, Ttxt, d]
-    operand folds the batch into ONE GEMM); mask, softmax and dropout as in the math path (bool mask -> -inf)."""
-    w = torch.matmul(q, k.transpose(-2, -1)) * (1.0 / math.sqrt(q.size(-1)))
-    if mask is not None:
-        w = w.masked_fill(~mask, float("-inf")) if mask.dtype == torch.bool else w + mask
-    w = torch.softmax(w, dim=-1)
-    if dropout_p > 0.0:
-        w = torch.dropout(w, dropout_p, True)
-    return torch.matmul(w, v)        # (under autocast the fp32 softmax output is cast with v; otherwise the dtypes agree)
+    crossatt.py:141-144) for THIS shape -- [B, 1, T, d]: one head of width d (1024: above every fused kernel's head size, so torch
+    takes its math path), thousands of queries against a few dozen text positions.  The math path upcasts q, k, v to fp32, scales q
+    AND k by d^-1/4 and expands a shared operand per batch row: six passes over [B, 1, T, d] tensors for products whose results are
+    [B, 1, T, Ttxt].  ``_TrainAttentionFunction`` keeps the math path's precision where it matters (fp32 scores and
+    probabilities) on the low-precision operands as they are.  Dropout on the weights (not used by the L169 configuration) and
+    non-boolean masks take the written-out fp32 form."""
+    cd = q.dtype
+    if q.is_cuda and torch.is_autocast_enabled("cuda"):
+        cd = torch.get_autocast_dtype("cuda")
+    ok = (dropout_p == 0.0 and q.dim() == 4 and q.shape[1] == 1 and k.shape[1] == 1 and v.shape[1] == 1
+          and (mask is None or mask.dtype == torch.bool) and k.shape[0] in (1, q.shape[0]) and v.shape[0] in (1, q.shape[0]))
+    if ok:
+        m3 = None
+        if mask is not None:
+            m3 = mask.expand(q.shape[0], 1, q.shape[2], k.shape[2])[:, 0]
+        with torch.autocast(q.device.type, enabled=False):
+            return _TrainAttentionFunction.apply(q[:, 0].to(cd), k[:, 0].to(cd), v[:, 0].to(cd), m3).unsqueeze(1)
+    with torch.autocast(q.device.type, enabled=False):
+        qf, kf, vf = q.float(), k.float(), v.float()
+        w = torch.matmul(qf, kf.transpose(-2, -1)) * (1.0 / math.sqrt(q.size(-1)))
+        if mask is not None:
+            w = w.masked_fill(~mask, float("-inf")) if mask.dtype == torch.bool else w + mask
+        w = torch.softmax(w, dim=-1)
+        if dropout_p > 0.0:
+            w = torch.dropout(w, dropout_p, True)
+        return torch.matmul(w, vf).to(cd)
 
 
 class ConvPos(nn.Module):

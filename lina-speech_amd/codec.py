@@ -25,6 +25,8 @@ class MultiEmbedding(nn.Module):
         nn.init.normal_(self.weight)
 
     def forward(self, idx):
+        if self.n_level == 1:                   # one level: the gather itself, seen as [1, ...] (no stacking copy)
+            return nn.functional.embedding(idx[0], self.weight[0], padding_idx=self.padding_idx).unsqueeze(0)
         return torch.stack([nn.functional.embedding(idx[q], self.weight[q], padding_idx=self.padding_idx)
                             for q in range(self.n_level)], dim=0)
 

@@ -51,7 +51,8 @@ class LinaModel(nn.Module):
         boolean indexing has a data-dependent shape, i.e. a host sync, which a captured (hipGraph) train step cannot
         contain; the loss does not need them."""
         x_embd = self.txt_embed(x)
-        y_embd = self.rvq_embed(y.permute(2, 0, 1)).sum(0)            # 'b n q -> q b n' -> sum over q
+        y_embd = self.rvq_embed(y.permute(2, 0, 1))                   # 'b n q -> q b n' -> sum over q
+        y_embd = y_embd[0] if y_embd.shape[0] == 1 else y_embd.sum(0)  # (one quantizer: the sum of one term is a copy -- skipped)
         x_enc = self.txt_encoder(x_embd, mask=encoder_mask)
         if self.spk_encoder is not None:
             y_embd[:, 0] = self.spk_encoder(y_embd)
