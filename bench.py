@@ -377,7 +377,8 @@ def cpu_baseline(model, B=8, steps=200, repeats=3):
         for rep in range(repeats):
             state = orc.init_state(B)
             y = orc.embed(torch.ones(1, B, 1, dtype=torch.long))
-            for _ in range(3 if rep == 0 else 1):                       # untimed warm-up steps
+            for _ in range(40 if rep == 0 else 1):                      # untimed warm-up steps (the first run of a session read 46 tok/s
+                                                                        # against 147 / 153 after THREE warm-up steps: thread pool + clocks still cold)
                 logits, _ = orc.step(y, x_enc, state)
                 y = orc.embed(logits[:, 0].argmax(-1).t().unsqueeze(-1))
             n, t0 = 0, time.time()
