@@ -786,9 +786,13 @@ __global__ __launch_bounds__(1024) void gla_chunk_bf16_h256_kernel(
     lane = lane_id(); opaque(lane); li = lane & 15; lg = lane >> 4;
     store_prev();                                              // the last chunk (T >= 1)
 #ifdef LINA_K2_PROF
-    if (blockIdx.x == 0 && lane_id() == 0)
+#ifndef LINA_K2_PROF_WHICH
+#define LINA_K2_PROF_WHICH 0      // tools-only: 0 = every instantiation records (the last launch wins), 1 = only the forward STATE_ONLY pass
+#endif
+    constexpr bool prof_me = LINA_K2_PROF_WHICH == 0 || (LINA_K2_PROF_WHICH == 1 && STATE_ONLY && !REV);
+    if (prof_me && blockIdx.x == 0 && lane_id() == 0)
         for (int i = 0; i < 16; ++i) lina_k2_prof[w_s * 16 + i] = pacc[i];
-    if (blockIdx.x < 1024 && w_s == 0 && lane_id() == 0) {
+    if (prof_me && blockIdx.x < 1024 && w_s == 0 && lane_id() == 0) {
         lina_k2_prof[256 + 3 * blockIdx.x] = clock64() - pstart;
         lina_k2_prof[256 + 3 * blockIdx.x + 1] = pacc[8];
         lina_k2_prof[256 + 3 * blockIdx.x + 2] = pacc[9];

@@ -51,14 +51,15 @@ if os.environ.get("K2_PROF"):
     torch.cuda.synchronize()
     buf = np.zeros(256 + 3 * 1024, dtype=np.uint64)
     rc = lib.lina_k2_prof_read(buf.ctypes.data_as(ctypes.c_void_p))
-    a = buf[:256].reshape(16, 16).astype(np.float64) / (T / 32)
+    chunks = T / 32 / max(1, ops.chunk_segments(B * H, T) if NSEG is None else int(NSEG))   # chunks ONE workgroup walks (segments split T)
+    a = buf[:256].reshape(16, 16).astype(np.float64) / chunks
     names = ["phaseA", "bar(2)", "flags/roll", "maskA(w<4)", "step1 qS", "step4 upd", "bar(1')+dma", "rawrd+step3", "wait_vmem",
              "bar(3)", "o stores", "(unused)"]   # o stores: of the previous chunk, at the end of phase A
     print("clk/chunk per phase (shader clock), waves 0, 3, 4, 15 and mean:  rc =", rc)
     for i, nm in enumerate(names):
         print(f"  {nm:12s} " + " ".join(f"{a[w, i]:8.0f}" for w in (0, 3, 4, 15)) + f"   mean {a[:, i].mean():8.0f}")
     print(f"  total        {a[0, :12].sum():8.0f}")
-    wg = buf[256:256 + 3 * B * H].reshape(-1, 3).astype(np.float64) / (T / 32)
+    wg = buf[256:256 + 3 * B * H].reshape(-1, 3).astype(np.float64) / chunks
     print("per-workgroup clk/chunk (wave 0): total min/median/max", np.min(wg[:, 0]), np.median(wg[:, 0]), np.max(wg[:, 0]),
           " wait_vmem median/max", np.median(wg[:, 1]), np.max(wg[:, 1]), " bar(3) median/max", np.median(wg[:, 2]), np.max(wg[:, 2]))
     order = np.argsort(wg[:, 0])
