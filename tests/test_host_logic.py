@@ -245,3 +245,36 @@ def test_linear_matches_f_linear_and_splits_the_weight_gradient(rows, n_out, n_i
     assert torch.allclose(one, many, rtol=1e-4, atol=1e-3)
     # no gradient wanted: the plain library call, no autograd node of ours
     assert ops.linear(x, w.to(dtype), None).grad_fn is None
+
+
+def test_host_paths_of_the_late_round6_train_ops_fall_back_to_torch():
+    """Off the fused-op device (CPU tensors, HIP backend): ``FusedAdamW`` takes torch's own AdamW step, ``ops.stacked_linear`` is
+    ``F.linear`` on the concatenated weight, ``train_attention`` equals ``F.scaled_dot_product_attention`` -- same numbers as
+    the plain torch expressions, no kernel call."""
+    from lina_speech_amd import ops
+    from lina_speech_amd.blind_attention import train_attention
+    from lina_speech_amd.train import FusedAdamW
+    g = torch.Generator().manual_seed(5)
+    ref = [torch.randn(7, 5, generator=g).requires_grad_(), torch.randn(11, generator=g).requires_grad_()]
+    mine = [r.detach().clone().requires_grad_() for r in ref]
+    kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.1)
+    o_ref, o_mine = torch.optim.AdamW(ref, **kw), FusedAdamW(mine, **kw)
+    for _ in range(3):
+        for r, m in zip(ref, mine):
+            r.grad = torch.randn(r.shape, generator=g)
+            m.grad = r.grad.clone()
+        o_ref.step()
+        o_mine.step()
+    for r, m in zip(ref, mine):
+        assert torch.allclose(r, m, rtol=1e-6, atol=1e-7)
+    parts = [torch.randn(4, 8, generator=g).requires_grad_(), torch.randn(2, 8, generator=g).requires_grad_()]
+    x = torch.randn(3, 5, 8, generator=g)
+    y = ops.stacked_linear(x, parts, pad=2)
+    yr = torch.nn.functional.linear(x, torch.cat(parts + [torch.zeros(2, 8)], 0))
+    assert torch.equal(y, yr)
+    q, k, v = torch.randn(2, 1, 9, 16, generator=g), torch.randn(1, 1, 4, 16, generator=g), torch.randn(2, 1, 4, 16, generator=g)
+    mask = torch.rand(2, 1, 9, 4, generator=g) > 0.3
+    mask[..., 0] = True
+    a = train_attention(q, k, v, mask)
+    r = torch.nn.functional.scaled_dot_product_attention(q, k.expand(2, -1, -1, -1), v, attn_mask=mask)
+    assert torch.allclose(a, r, rtol=1e-5, atol=1e-6)
