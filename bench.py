@@ -822,10 +822,14 @@ def main():
     ap.add_argument("--engines", type=int, default=0,
                     help="engines (row ranges, one HIP stream each) per GPU; 0 = what generate_batch picks for the batch (2 from 512 rows up)")
     ap.add_argument("--window", type=int, default=None, help="state window of the decode loop (1 = immediate update K1d; default 8)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed decode loop (no secondary blocks): what a rocprofv3 trace of the headline should contain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chunk", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline = args.no_chunk = args.no_train = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(relaunch_under_torchrun(args.gpus, sys.argv[1:]))
@@ -986,7 +990,7 @@ def main():
                                 "rccl": rccl_summary()}
             # secondary, untimed-region measurements (rank 0 only): the default sampling mode of the reference
             # (top-k 100, temperature) through the same graph, K2 / K2b at the training shape
-            if world == 1:
+            if world == 1 and not args.headline_only:
                 eng.begin_greedy(80, k=100, temp=1.0, seed=1, first_greedy_quant=1)
                 eng.greedy_steps(16)
                 torch.cuda.synchronize()
@@ -1005,7 +1009,7 @@ def main():
                     except Exception as e:                       # (a secondary block must not cost the headline line)
                         per[f"B={bb}"] = {"error": repr(e)}
                 out["per_gpu_batch"] = per
-            if world == 1 and dtype == torch.bfloat16:
+            if world == 1 and dtype == torch.bfloat16 and not args.headline_only:
                 # the reference's entry point end to end, on the headline batch and on configs[1]'s 64 rows
                 gb = {}
                 for bb in sorted({B, 64}):
