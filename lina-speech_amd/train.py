@@ -51,6 +51,11 @@ class FusedAdamW(torch.optim.AdamW):
                 if (g.is_sparse or p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_contiguous()
                         or not g.is_contiguous() or p.device != g.device or not ops.fused_ops_available(p)):
                     return False
+                st = self.state.get(p)
+                if st:                                        # a state loaded from a fused / capturable run: torch's path
+                    if (st["step"].is_cuda or not st["exp_avg"].is_contiguous() or not st["exp_avg_sq"].is_contiguous()
+                            or st["exp_avg"].dtype != torch.float32 or st["exp_avg"].device != p.device):
+                        return False
         return True
 
     @torch.no_grad()
@@ -73,21 +78,21 @@ class FusedAdamW(torch.optim.AdamW):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if st["step"].is_cuda or not st["exp_avg"].is_contiguous() or not st["exp_avg_sq"].is_contiguous():
-                    return super().step(None)                 # (a state loaded from a fused / capturable run: torch's path)
                 st["step"] += 1
-                by_step.setdefault(float(st["step"]), []).append((p, st))
+                if p.numel():
+                    by_step.setdefault((p.device, float(st["step"])), []).append((p, st))
             beta1, beta2 = group["betas"]
             lr = float(group["lr"])
-            for t, items in by_step.items():
+            for (_, t), items in by_step.items():
                 n = len(items)
                 arr = lambda f: (C.c_void_p * n)(*[f(p, st) for p, st in items])
                 numel = (C.c_int64 * n)(*[p.numel() for p, _ in items])
-                ops._check(be.lib.lina_adamw_multi(arr(lambda p, st: p.data_ptr()), arr(lambda p, st: p.grad.data_ptr()),
-                                                   arr(lambda p, st: st["exp_avg"].data_ptr()),
-                                                   arr(lambda p, st: st["exp_avg_sq"].data_ptr()), numel, n, lr, beta1, beta2,
-                                                   group["eps"], group["weight_decay"], 1.0 - beta1 ** t, 1.0 - beta2 ** t,
-                                                   be.stream(items[0][0])))
+                with torch.cuda.device_of(items[0][0]):       # (no-op for the emulator's host tensors)
+                    ops._check(be.lib.lina_adamw_multi(arr(lambda p, st: p.data_ptr()), arr(lambda p, st: p.grad.data_ptr()),
+                                                       arr(lambda p, st: st["exp_avg"].data_ptr()),
+                                                       arr(lambda p, st: st["exp_avg_sq"].data_ptr()), numel, n, lr, beta1,
+                                                       beta2, group["eps"], group["weight_decay"], 1.0 - beta1 ** t,
+                                                       1.0 - beta2 ** t, be.stream(items[0][0])))
         ops.clear_mlp_pack()          # K17 writes the parameters behind their version counters: drop the cached padded operands
         return loss
 
