@@ -765,7 +765,8 @@ def _mlp_padded_weights(w_in, b_in, w_out, b_out, cd, H, Hp):
     bi = torch.empty(2, Hp, dtype=cd, device=dev)
     Wo = torch.empty(d_out, Hp, dtype=cd, device=dev)
     f32c = lambda t: t is None or (t.dtype == torch.float32 and t.is_contiguous())
-    if POLICY.one_pass_operands and f32c(w_in) and f32c(b_in) and f32c(w_out) and f32c(b_out) and d_in % 4 == 0:
+    if (POLICY.one_pass_operands and f32c(w_in) and f32c(b_in) and f32c(w_out) and f32c(b_out) and d_in % 4 == 0
+            and w_in.data_ptr() % 16 == 0):             # (K15 reads w_in's rows with 16-byte accesses)
         # K15: the three operands in ONE pass over the fp32 master weights (torch built them with three fills and five strided
         # copies: nine launches per block and step)
         be = _backend._BACKEND
