@@ -99,7 +99,8 @@ def train_attention(q, k, v, mask=None, dropout_p: float = 0.0):
         if mask is not None:
             m3 = mask.expand(q.shape[0], 1, q.shape[2], k.shape[2])[:, 0]
         with torch.autocast(q.device.type, enabled=False):
-            return _TrainAttentionFunction.apply(q[:, 0].to(cd), k[:, 0].to(cd), v[:, 0].to(cd), m3).unsqueeze(1)
+            # (squeeze, not q[:, 0]: a select's backward zero-fills a full-size tensor and copies the gradient into it)
+            return _TrainAttentionFunction.apply(q.squeeze(1).to(cd), k.squeeze(1).to(cd), v.squeeze(1).to(cd), m3).unsqueeze(1)
     with torch.autocast(q.device.type, enabled=False):
         qf, kf, vf = q.float(), k.float(), v.float()
         w = torch.matmul(qf, kf.transpose(-2, -1)) * (1.0 / math.sqrt(q.size(-1)))

@@ -51,14 +51,20 @@ class LinaModel(nn.Module):
         boolean indexing has a data-dependent shape, i.e. a host sync, which a captured (hipGraph) train step cannot
         contain; the loss does not need them."""
         x_embd = self.txt_embed(x)
-        y_embd = self.rvq_embed(y.permute(2, 0, 1))                   # 'b n q -> q b n' -> sum over q
-        y_embd = y_embd[0] if y_embd.shape[0] == 1 else y_embd.sum(0)  # (one quantizer: the sum of one term is a copy -- skipped)
+        # the LAST token's embedding is only ever read by the speaker encoder: without one, embed y[:, :-1] -- the values the
+        # reference slices out of the full embedding (modeling_lina.py:80-84), minus the slice's copy forward and its
+        # zero-fill + copy backward over [b, n, d]
+        n_in = y.shape[1] - 1
+        y_src = y if self.spk_encoder is not None else y[:, :-1]
+        y_embd = self.rvq_embed(y_src.permute(2, 0, 1))               # 'b n q -> q b n' -> sum over q
+        y_embd = y_embd.squeeze(0) if y_embd.shape[0] == 1 else y_embd.sum(0)   # (one quantizer: the sum of one term is a copy -- skipped)
         x_enc = self.txt_encoder(x_embd, mask=encoder_mask)
         if self.spk_encoder is not None:
             y_embd[:, 0] = self.spk_encoder(y_embd)
+            y_embd = y_embd[:, :-1, :]
         y_hat, att = self.attentive_rnn(
-            y_embd[:, :-1, :], x_enc, mask=crossatt_mask[:, :-1],
-            forced_attention=None if forced_attention is None else forced_attention[:, :, :y_embd.shape[1] - 1],
+            y_embd, x_enc, mask=crossatt_mask[:, :-1],
+            forced_attention=None if forced_attention is None else forced_attention[:, :, :n_in],
             attention_only=attention_only, init_state=init_state, crossatt_pos=crossatt_pos)
         if attention_only:
             return att
