@@ -246,6 +246,28 @@ def _adjacent_columns(ts):
     return True
 
 
+def _stack_rows(parts, dtype, pad: int = 0):
+    """``torch.cat(parts, 0)`` (+ ``pad`` zero rows) cast to ``dtype`` -- ONE pass on K16 ``lina_stack_rows`` when the blocks are
+    contiguous, 16-byte aligned fp32 [r_i, cols] with cols % 4 == 0 (master weights), else the torch expression."""
+    cols = parts[0].shape[1]
+    if (POLICY.one_pass_operands and dtype in (torch.float32, torch.bfloat16) and 1 <= len(parts) <= 8 and cols % 4 == 0
+            and fused_ops_available(parts[0])
+            and all(p.dtype == torch.float32 and p.dim() == 2 and p.shape[1] == cols and p.is_contiguous()
+                    and p.data_ptr() % 16 == 0 for p in parts)):
+        import ctypes as C
+        be = _backend._BACKEND
+        rows = [int(p.shape[0]) for p in parts]
+        out = torch.empty(sum(rows) + pad, cols, dtype=dtype, device=parts[0].device)
+        srcs = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+        _check(be.lib.lina_stack_rows(srcs, (C.c_int * len(parts))(*rows), len(parts), cols, out.shape[0], _ptr(out), _dt(out),
+                                      be.stream(out)))
+        return out
+    w = [p.detach() for p in parts]
+    if pad:
+        w.append(parts[0].new_zeros(pad, cols))
+    return torch.cat(w, dim=0).to(dtype).contiguous()
+
+
 class _ShortConv3Function(torch.autograd.Function):
     """K3 / K3b over the q | k | v column slices of a stacked projection in ONE launch each way: the three slices are
     adjacent columns of the same rows (6 KB contiguous per token at L169 instead of three 2 KB pieces in three launches), the
@@ -260,7 +282,7 @@ class _ShortConv3Function(torch.autograd.Function):
         D = sum(sizes)
         ctx.w_dtypes = [w.dtype for w in ws]
         ctx.b_dtypes = [None if b is None else b.dtype for b in bs]
-        w = torch.cat([wi.reshape(wi.shape[0], -1) for wi in ws], dim=0).to(x0.dtype).contiguous()
+        w = _stack_rows([wi.reshape(wi.shape[0], -1) for wi in ws], x0.dtype)   # the three filters as one, one pass (K16)
         bias = None if b0 is None else torch.cat(bs, dim=0).to(x0.dtype).contiguous()
         x = x0.as_strided((B, T, D), x0.stride())              # the three slices as one [B, T, D] view of the same rows
         ctx.save_for_backward(x, w, bias, mask)
@@ -296,8 +318,9 @@ class _ShortConv3Function(torch.autograd.Function):
                                           dx.stride(0), dx.stride(1), ctx.act, _dt(x), be.stream(x)))
         red = _sum_partials(part)
         dws, dbs, o = [], [], 0
+        rw = red[:, :W].contiguous()                           # ONE compaction: the filters' gradients are row ranges of it
         for n, wdt, bdt in zip(sizes, ctx.w_dtypes, ctx.b_dtypes):
-            dws.append(red[o:o + n, :W].to(wdt, copy=True))
+            dws.append(rw[o:o + n].to(wdt))
             dbs.append(None if bdt is None else red[o:o + n, W].to(bdt, copy=True))
             o += n
         return (*parts_out, *dws, *dbs, None, None, None)
@@ -725,17 +748,34 @@ class _SwiGLUMLPFunction(torch.autograd.Function):
         with torch.autocast(x2.device.type, enabled=False):
             dy2 = dy.reshape(M, d_out).to(x2.dtype).contiguous()
             dh = torch.mm(dy2, Wo)
-            dWo = linear_weight_grad(dy2, h)                                         # [d_out, Hp] fp32; column H = db_out
+            # weight gradients as token-split batched GEMMs whose PARTIAL products are summed straight into the parameters'
+            # own (unpadded) layouts: the sum over the split reads only the rows / columns that exist in w_in / w_out, so no
+            # padded [2 Hp, d] / [d, Hp] gradient is formed and re-packed afterwards (a reshape clone + two AccumulateGrad clones
+            # per block, profiles/r06_train_step_ops.txt)
+            S = _linear_split(M, 2 * Hp, d_in)
+            compact = (S > 1 and S == _linear_split(M, d_out, Hp) and dy2.is_cuda and dy2.dtype != torch.float32
+                       and _mm_has_out_dtype(dy2.device) and d_in % 8 == 0 and Hp % 8 == 0)
+            Po = None
+            if compact:
+                Po = torch.bmm(dy2.view(S, M // S, d_out).transpose(1, 2), h.view(S, M // S, Hp), out_dtype=torch.float32)
+            else:
+                dWo = linear_weight_grad(dy2, h)                                     # [d_out, Hp] fp32; column H = db_out
             du = torch.empty_like(u)
             part = torch.empty(int(be.lib.lina_swiglu_bwd_partials(M)), 2 * Hp, dtype=torch.float32, device=u.device)
             _check(be.lib.lina_swiglu_bwd_colsum(_ptr(dh), _ptr(u), _ptr(du), _ptr(part), M, Hp, u.stride(0), dh.stride(0),
                                                  du.stride(0), _dt(u), be.stream(u)))
             dx = torch.mm(du, Wi.view(2 * Hp, d_in)).view(x_shape).to(xdt) if ctx.needs_input_grad[0] else None
-            dWi = linear_weight_grad(du, x2).view(2, Hp, d_in)
-            dw_in = dWi[:, :H].reshape(2 * H, d_in).to(widt)
             db_in = None if bidt is None else _sum_partials(part).view(2, Hp)[:, :H].reshape(2 * H).to(bidt)
-            dw_out = dWo[:, :H].to(wodt)
-            db_out = None if bodt is None else dWo[:, H].to(bodt)
+            if compact:
+                Pi = torch.bmm(du.view(S, M // S, 2 * Hp).transpose(1, 2), x2.view(S, M // S, d_in), out_dtype=torch.float32)
+                dw_in = Pi.view(S, 2, Hp, d_in)[:, :, :H].sum(0).view(2 * H, d_in).to(widt)
+                dw_out = Po[:, :, :H].sum(0).to(wodt)
+                db_out = None if bodt is None else Po[:, :, H].sum(0).to(bodt)
+            else:
+                dWi = linear_weight_grad(du, x2).view(2, Hp, d_in)
+                dw_in = dWi[:, :H].reshape(2 * H, d_in).to(widt)
+                dw_out = dWo[:, :H].to(wodt)
+                db_out = None if bodt is None else dWo[:, H].to(bodt)
         return dx, dw_in, db_in, dw_out, db_out
 
 

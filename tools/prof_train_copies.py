@@ -18,13 +18,18 @@ batch = synthetic_batch(b=8, n=4097, t_txt=64, seed=1).to(dev)
 for _ in range(3):
     ts.step(batch)
 torch.cuda.synchronize()
+SMALL = "--small" in sys.argv
+
+
 def table(prof, tag):
     agg = defaultdict(lambda: [0.0, 0])
     for e in prof.events():
-        if e.name not in ("aten::copy_", "aten::add", "aten::add_", "aten::mul", "aten::sum", "aten::fill_", "aten::_to_copy"):
+        if e.name not in ("aten::copy_", "aten::add", "aten::add_", "aten::mul", "aten::sum", "aten::fill_", "aten::_to_copy", "aten::cat"):
             continue
         shp = str(e.input_shapes)
-        if "4096, 1024" not in shp and "4097, 1024" not in shp:
+        big = "4096, 1024" in shp or "4097, 1024" in shp
+        small = any(shp.startswith(pre) for pre in ("[[1024, 4]", "[[1024]", "[[1024, 16]", "[[3072, 4]", "[[256]", "[[2, 1365", "[[1024, 1365]"))
+        if not (big or (SMALL and small)):
             continue
         dt = getattr(e, "device_time_total", None) or getattr(e, "cuda_time_total", 0)
         par, chain = e.cpu_parent, []
