@@ -660,28 +660,66 @@ class _StackedLinearFunction(torch.autograd.Function):
         nrow = (C.c_int * len(parts))(*rows)
         _check(be.lib.lina_stack_rows(srcs, nrow, len(parts), n_in, wc.shape[0], _ptr(wc), _dt(wc), be.stream(wc)))
         xc = x.to(cd)
+        n_out = wc.shape[0]
+        main = _stacked_main(n_out, rows) if POLICY.split_stacked_gemm else n_out
         with torch.autocast(x.device.type, enabled=False):
-            y = F.linear(xc, wc)
+            if main < n_out:
+                # a 256-aligned main product and the narrow tail, both written into ONE [.., n_out] buffer (out= views)
+                x2 = xc.reshape(-1, n_in)
+                y2 = torch.empty(x2.shape[0], n_out, dtype=cd, device=x.device)
+                torch.mm(x2, wc[:main].t(), out=y2[:, :main])
+                torch.mm(x2, wc[main:].t(), out=y2[:, main:])
+                y = y2.view(*xc.shape[:-1], n_out)
+            else:
+                y = F.linear(xc, wc)
         ctx.save_for_backward(xc, wc)
-        ctx.rows, ctx.xdt = rows, x.dtype
+        ctx.rows, ctx.xdt, ctx.main = rows, x.dtype, main
         return y
 
     @staticmethod
     def backward(ctx, dy):
         xc, wc = ctx.saved_tensors
         n_out, n_in = wc.shape
+        main = ctx.main
         dy2 = dy.to(xc.dtype).reshape(-1, n_out)
         with torch.autocast(xc.device.type, enabled=False):
             dx = torch.mm(dy2, wc).view(xc.shape).to(ctx.xdt) if ctx.needs_input_grad[0] else None
             grads = [None] * len(ctx.rows)
             if any(ctx.needs_input_grad[2:]):
-                dw = linear_weight_grad(dy2.contiguous(), xc.reshape(-1, n_in).contiguous())       # fp32 [n_out, n_in]
+                x2 = xc.reshape(-1, n_in).contiguous()
+                dy2 = dy2.contiguous()
+                if main < n_out:
+                    # the main rows token-split (the library's one-GEMM form of a [4096, 1024] result from 32768 tokens runs
+                    # 334 us, split in four + a sum 259), the narrow tail on its own; every block lies inside one of the two
+                    M = dy2.shape[0]
+                    S = _linear_split(M, main, n_in)
+                    if S == 1 and M % 4 == 0 and M // 4 >= 2048:
+                        S = 4
+                    pieces = [(0, main, linear_weight_grad(dy2[:, :main], x2, split=S)),
+                              (main, n_out, linear_weight_grad(dy2[:, main:].contiguous(), x2))]
+                else:
+                    pieces = [(0, n_out, linear_weight_grad(dy2, x2))]                  # fp32 [n_out, n_in]
                 r0 = 0
                 for i, r in enumerate(ctx.rows):
                     if ctx.needs_input_grad[2 + i]:
-                        grads[i] = dw[r0:r0 + r]
+                        lo, _, t = next(pc for pc in pieces if pc[0] <= r0 and r0 + r <= pc[1])
+                        grads[i] = t[r0 - lo:r0 - lo + r]
                     r0 += r
         return (dx, None, *grads)
+
+
+def _stacked_main(n_out: int, rows) -> int:
+    """Rows of a stacked weight that go into the 256-aligned main product (the rest: a narrow tail product), or ``n_out`` when the
+    split does not apply: the tail must be short (<= 128 rows), the main part large, and no block may straddle the cut."""
+    main = n_out // 256 * 256
+    if main == n_out or main < 1024 or n_out - main > 128:
+        return n_out
+    r0 = 0
+    for r in rows:
+        if r0 < main < r0 + r:
+            return n_out
+        r0 += r
+    return main
 
 
 def stacked_linear(x, parts, pad: int = 0):

@@ -18,6 +18,11 @@ class Policy:
     # train path: the stacked projection weight (K16) and the channel mixer's padded operands (K15) in ONE pass each over the
     # fp32 master weights; False = torch.cat / cast / fills / strided copies (rounds 3-6, ~190 more launches per step)
     one_pass_operands: bool = True
+    # train path, the stacked projection (4160 output columns at L169: q | k | v | g | low-rank 16 | pad 48): the GEMM library runs
+    # N = 4096 at 1.3 PFLOP/s and N = 4160 at 0.95 (and its weight gradient token-split at 259 us instead of 337 as one GEMM:
+    # profiles/r06_inproj_gemm_split.txt) -- True = the forward and the weight gradient as a 256-aligned main product plus a
+    # narrow tail product into / out of the same buffers; dX stays one GEMM
+    split_stacked_gemm: bool = True
 
 
 POLICY = Policy()

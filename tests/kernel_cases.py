@@ -864,7 +864,7 @@ def check_mlp_pack(dev, H=45, d_in=24, d_out=20, out_dtype=torch.bfloat16, bias=
     ops.clear_mlp_pack()
 
 
-def check_stacked_linear(dev, rows=(8, 8, 16, 16, 4), n_in=24, pad=12, B=3, T=7, autocast=False):
+def check_stacked_linear(dev, rows=(8, 8, 16, 16, 4), n_in=24, pad=12, B=3, T=7, autocast=False, expect_split=None):
     """``ops.stacked_linear`` (K16: the stacked operand in one pass, block gradients as row ranges of dW) against
     ``F.linear(x, cat(parts + zero rows))`` through fp64 autograd; the blocks' gradients are contiguous views of ONE tensor."""
     g = torch.Generator().manual_seed(62)
@@ -885,6 +885,8 @@ def check_stacked_linear(dev, rows=(8, 8, 16, 16, 4), n_in=24, pad=12, B=3, T=7,
         tol = 2e-5
     assert type(y.grad_fn).__name__ == "_StackedLinearFunctionBackward", type(y.grad_fn).__name__
     assert y.shape == (B, T, sum(rows) + pad)
+    if expect_split is not None:                # the 256-aligned main product + narrow tail form of the GEMMs
+        assert (y.grad_fn.main < sum(rows) + pad) == expect_split, y.grad_fn.main
     assert_close(y, y64.detach(), tol, "stacked linear y")
     assert pad == 0 or float(y.detach()[..., sum(rows):].abs().max()) == 0.0, "pad columns must be exactly zero"
     (y.float() * dy.to(dev)).sum().backward()

@@ -449,6 +449,8 @@ def test_train_weight_operands_in_one_pass(emu):
     check_mlp_pack(DEV, H=127, d_in=8, d_out=3)              # H + 1 = Hp: the bias column is the last one
     check_stacked_linear(DEV)
     check_stacked_linear(DEV, rows=(5,), pad=0)
+    check_stacked_linear(DEV, rows=(512, 512, 16), n_in=16, pad=48, B=1, T=9, expect_split=True)    # main 1024 + tail 64
+    check_stacked_linear(DEV, rows=(512, 500, 28), n_in=16, pad=48, B=1, T=9, expect_split=False)   # a block straddles the cut
 
 
 def test_fused_adamw_matches_torch_adamw(emu):

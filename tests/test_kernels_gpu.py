@@ -548,7 +548,9 @@ def test_train_weight_operands_in_one_pass(hip):
     check_mlp_pack(DEV, H=127, d_in=8, d_out=3)              # H + 1 = Hp: the bias column is the last one
     check_stacked_linear(DEV)
     check_stacked_linear(DEV, rows=(5,), pad=0)
-    check_stacked_linear(DEV, rows=(1024, 1024, 1024, 1024, 16), n_in=1024, pad=48, B=2, T=600, autocast=True)   # the L169 mixer's stack under autocast
+    check_stacked_linear(DEV, rows=(512, 512, 16), n_in=16, pad=48, B=1, T=9, expect_split=True)    # main 1024 + tail 64
+    check_stacked_linear(DEV, rows=(512, 500, 28), n_in=16, pad=48, B=1, T=9, expect_split=False)   # a block straddles the cut
+    check_stacked_linear(DEV, rows=(1024, 1024, 1024, 1024, 16), n_in=1024, pad=48, B=2, T=4096, autocast=True, expect_split=True)   # the L169 mixer's stack under autocast
     check_mlp_pack(DEV, H=1365, d_in=1024, d_out=1024)
 
 

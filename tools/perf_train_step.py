@@ -17,6 +17,9 @@ from lina_speech_amd.train import TrainStep, synthetic_batch  # noqa: E402
 if os.environ.get("TRAIN_OPERANDS") == "0":               # A/B: the torch-op construction of the stacked / padded weight operands
     from lina_speech_amd import ops as _ops
     _ops.POLICY.one_pass_operands = False
+if os.environ.get("TRAIN_SPLIT_GEMM") == "0":             # A/B: the stacked projection's forward / dW as single GEMMs (N = 4160)
+    from lina_speech_amd import ops as _ops2
+    _ops2.POLICY.split_stacked_gemm = False
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5
 WARM = 2
 dev = torch.device("cuda", 0)
