@@ -7,6 +7,7 @@ timeout 300 python tools/perf_train_step.py 10 > gpurun_out/${TAG}_train_step.js
 { echo "same box, same session: python tools/perf_train_step.py 10 with the round's train-path changes switched off one at a time";
   echo -n "final tree                         "; timeout 300 python tools/perf_train_step.py 10 2>/dev/null | cut -c80-170;
   echo -n "TRAIN_OPERANDS=0 (torch cat/cast/pad) "; TRAIN_OPERANDS=0 timeout 300 python tools/perf_train_step.py 10 2>/dev/null | cut -c80-170;
+  echo -n "TRAIN_SPLIT_GEMM=0 (N = 4160 GEMMs) "; TRAIN_SPLIT_GEMM=0 timeout 300 python tools/perf_train_step.py 10 2>/dev/null | cut -c80-170;
   echo -n "TRAIN_TORCH_ADAMW=1 (torch fused)  "; TRAIN_TORCH_ADAMW=1 timeout 300 python tools/perf_train_step.py 10 2>/dev/null | cut -c80-170;
   echo -n "final tree again                   "; timeout 300 python tools/perf_train_step.py 10 2>/dev/null | cut -c80-170; } > gpurun_out/${TAG}_train_ab.txt 2>&1
 cat gpurun_out/${TAG}_train_ab.txt
