@@ -301,11 +301,12 @@ int lina_sum_partials(const float* part, void* out, int outer, int P, int64_t N,
  * parameter each step -- reference train_lina.py:72-120 -- written straight into the padded layout of the train path:
  * reference model/base_blocks.py:42-50 `p_in` / `p_out`):
  *   Wi [2][Hp][d_in]: rows [0, H) of half s = w_in rows [s H, s H + H), the rest 0;   bi [2][Hp]: b_in likewise, and with b_out
- *   given (32, 1/32) at row H (the gate's column H is then exactly 1);   Wo [d_out][Hp]: w_out in columns [0, H), b_out in
- *   column H, the rest 0.   w_in fp32 [2 H][d_in], b_in fp32 [2 H] or NULL, w_out fp32 [d_out][H], b_out fp32 [d_out] or NULL;
- *   Hp > H, Hp and d_in multiples of 4; the three outputs are of out_dtype. */
+ *   given (32, 1/32) at row H (the gate's column H is then exactly 1);   Wo [d_out][Hq]: w_out in columns [0, H), b_out in
+ *   column H, the rest 0 (Hq >= Hp: the row length the down-projection's dX GEMM wants; its other uses take the first Hp
+ *   columns).   w_in fp32 [2 H][d_in], b_in fp32 [2 H] or NULL, w_out fp32 [d_out][H], b_out fp32 [d_out] or NULL;
+ *   Hp > H; Hp, Hq and d_in multiples of 4; the three outputs are of out_dtype. */
 int lina_mlp_pack(const float* w_in, const float* b_in, const float* w_out, const float* b_out, void* Wi, void* bi, void* Wo,
-                  int H, int Hp, int d_in, int d_out, int out_dtype, lina_stream_t stream);
+                  int H, int Hp, int Hq, int d_in, int d_out, int out_dtype, lina_stream_t stream);
 
 /* K16 -- row blocks stacked into one GEMM operand, ONE pass: out [total_rows][cols] of out_dtype = the n_src <= 8 fp32 blocks
  * srcs[i] [rows[i]][cols] one under the other, zero rows after them (the q | k | v | g | low-rank projections of reference

@@ -60,7 +60,7 @@ PROTOTYPES = {
     "lina_cross_entropy": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i, _i64, _i64, _i64, _i, _p]),
     "lina_colsum": (C.c_int, [_p, _p, _i64, _i, _i64, _i, _p]),
     "lina_sum_partials": (C.c_int, [_p, _p, _i, _i, _i64, _i, _p]),
-    "lina_mlp_pack": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "lina_mlp_pack": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "lina_stack_rows": (C.c_int, [_p, _p, _i, _i, _i, _p, _i, _p]),
     "lina_adamw_multi": (C.c_int, [_p, _p, _p, _p, _p, _i] + [C.c_double] * 7 + [_p]),
     "lina_adamw_multi_max": (C.c_int, []),

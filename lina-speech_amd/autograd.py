@@ -766,26 +766,29 @@ class _SwiGLUMLPFunction(torch.autograd.Function):
         dev = x.device
         x2 = x.reshape(-1, d_in).to(cd).contiguous()
         with torch.autocast(dev.type, enabled=False):
-            Wi, bi, Wo = _mlp_padded_weights(w_in, b_in, w_out, b_out, cd, H, Hp)
+            Wi, bi, Wo, Wo_wide = _mlp_padded_weights(w_in, b_in, w_out, b_out, cd, H, Hp)
             u = torch.addmm(bi.view(-1), x2, Wi.view(2 * Hp, d_in).t())
             h = torch.empty(x2.shape[0], Hp, dtype=cd, device=dev)
             _check(be.lib.lina_swiglu(_ptr(u), _ptr(h), x2.shape[0], Hp, u.stride(0), h.stride(0), _dt(u), be.stream(u)))
             y = torch.mm(h, Wo.t())
-        ctx.save_for_backward(x2, u, h, Wi, Wo)
+        ctx.save_for_backward(x2, u, h, Wi, Wo_wide)
         ctx.meta = (x.shape, x.dtype, H, Hp, w_in.dtype, None if b_in is None else b_in.dtype, w_out.dtype,
                     None if b_out is None else b_out.dtype)
         return y.view(*x.shape[:-1], d_out)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, u, h, Wi, Wo = ctx.saved_tensors
+        x2, u, h, Wi, Wo_wide = ctx.saved_tensors
         x_shape, xdt, H, Hp, widt, bidt, wodt, bodt = ctx.meta
         be = _backend._BACKEND
-        d_out, d_in = Wo.shape[0], x2.shape[1]
+        d_out, d_in = Wo_wide.shape[0], x2.shape[1]
         M = x2.shape[0]
         with torch.autocast(x2.device.type, enabled=False):
             dy2 = dy.reshape(M, d_out).to(x2.dtype).contiguous()
-            dh = torch.mm(dy2, Wo)
+            # dX of the down-projection on the WIDE operand ([d_out, Hq], zero columns past H + 1): the library runs
+            # [M, 1024] x [1024, 1536] in 90-100 us and [M, 1024] x [1024, 1408] in 112-119 (profiles/r06_inproj_gemm_split.txt);
+            # K11c reads the first Hp columns of dh through its row stride
+            dh = torch.mm(dy2, Wo_wide)
             # weight gradients as token-split batched GEMMs whose PARTIAL products are summed straight into the parameters'
             # own (unpadded) layouts: the sum over the split reads only the rows / columns that exist in w_in / w_out, so no
             # padded [2 Hp, d] / [d, Hp] gradient is formed and re-packed afterwards (a reshape clone + two AccumulateGrad clones
@@ -837,11 +840,17 @@ def _mlp_padded_weights(w_in, b_in, w_out, b_out, cd, H, Hp):
     key = (cd, H, Hp, ver(w_in), ver(b_in), ver(w_out), ver(b_out))
     hit = _MLP_PACK.get(w_in)
     if hit is not None and hit[0] == key:
-        return hit[1], hit[2], hit[3]
+        return hit[1], hit[2], hit[3], hit[4]
     dev, d_in, d_out = w_in.device, w_in.shape[1], w_out.shape[0]
     Wi = torch.empty(2, Hp, d_in, dtype=cd, device=dev)
     bi = torch.empty(2, Hp, dtype=cd, device=dev)
-    Wo = torch.empty(d_out, Hp, dtype=cd, device=dev)
+    # the down-projection's operand lives in rows of Hq >= Hp elements (zero past column H): Hq = the next multiple of 512 when that
+    # costs <= 1/8 more columns (1408 -> 1536: the width the GEMM library prefers for the dX product), else Hp
+    Hq = -(-Hp // 512) * 512
+    if Hp < 1024 or Hq * 8 > Hp * 9 or not POLICY.wide_down_dx:
+        Hq = Hp
+    Wo_wide = torch.empty(d_out, Hq, dtype=cd, device=dev)
+    Wo = Wo_wide[:, :Hp]
     f32c = lambda t: t is None or (t.dtype == torch.float32 and t.is_contiguous())
     if (POLICY.one_pass_operands and f32c(w_in) and f32c(b_in) and f32c(w_out) and f32c(b_out) and d_in % 4 == 0
             and w_in.data_ptr() % 16 == 0):             # (K15 reads w_in's rows with 16-byte accesses)
@@ -849,21 +858,21 @@ def _mlp_padded_weights(w_in, b_in, w_out, b_out, cd, H, Hp):
         # copies: nine launches per block and step)
         be = _backend._BACKEND
         _check(be.lib.lina_mlp_pack(_ptr(w_in.detach()), _ptr(None if b_in is None else b_in.detach()), _ptr(w_out.detach()),
-                                    _ptr(None if b_out is None else b_out.detach()), _ptr(Wi), _ptr(bi), _ptr(Wo), H, Hp, d_in,
-                                    d_out, _dt(Wi), be.stream(Wi)))
+                                    _ptr(None if b_out is None else b_out.detach()), _ptr(Wi), _ptr(bi), _ptr(Wo_wide), H, Hp, Hq,
+                                    d_in, d_out, _dt(Wi), be.stream(Wi)))
     else:                                       # master weights that are not contiguous fp32: the same values with torch ops
         Wi[:, H:].zero_()
         Wi[:, :H].copy_(w_in.detach().view(2, H, d_in))
         bi.zero_()
         if b_in is not None:
             bi[:, :H].copy_(b_in.detach().view(2, H))
-        Wo[:, H:].zero_()
+        Wo_wide[:, H:].zero_()
         Wo[:, :H].copy_(w_out.detach())
         if b_out is not None:
             bi[:, H] = _mlp_one(cd, dev)
             Wo[:, H].copy_(b_out.detach())
-    _MLP_PACK[w_in] = (key, Wi, bi, Wo)
-    return Wi, bi, Wo
+    _MLP_PACK[w_in] = (key, Wi, bi, Wo, Wo_wide)
+    return Wi, bi, Wo, Wo_wide
 
 
 _MLP_ONE = {}

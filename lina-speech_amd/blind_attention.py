@@ -67,8 +67,12 @@ class _TrainAttentionFunction(torch.autograd.Function):
         B, T, S = w.shape
         dq = dk = dv = None
         wb = w.to(v.dtype)
+        # a SHARED text-side operand ([1, S, d]: the positional table) gathers its gradient over all B T rows into an [S, d]
+        # result -- as one GEMM the library runs that [64, 32768] x [32768, 1024] product in 115 us; token-split (the form of
+        # every weight gradient of the train path, ops.linear_weight_grad) in 28
+        from .autograd import linear_weight_grad
         if ctx.needs_input_grad[2]:
-            dv = (torch.mm(wb.reshape(B * T, S).t(), dout.reshape(B * T, -1)).unsqueeze(0) if v.shape[0] == 1
+            dv = (linear_weight_grad(wb.reshape(B * T, S), dout.reshape(B * T, -1)).to(v.dtype).unsqueeze(0) if v.shape[0] == 1
                   else torch.bmm(wb.transpose(1, 2), dout))
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dw = _mm_f32(dout, v.transpose(-2, -1))                       # [B, T, S] fp32
@@ -76,7 +80,7 @@ class _TrainAttentionFunction(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dq = torch.matmul(ds, k)
             if ctx.needs_input_grad[1]:
-                dk = (torch.mm(ds.reshape(B * T, S).t(), q.reshape(B * T, -1)).unsqueeze(0) if k.shape[0] == 1
+                dk = (linear_weight_grad(ds.reshape(B * T, S), q.reshape(B * T, -1)).to(k.dtype).unsqueeze(0) if k.shape[0] == 1
                       else torch.bmm(ds.transpose(1, 2), q))
         return dq, dk, dv, None
 

@@ -6,7 +6,7 @@
 // folded in (autograd._SwiGLUMLPFunction).  Built with torch ops that took ~11 launches per block and step (cat, cast, three
 // fills, five strided copies: ~190 launches and ~0.9 ms of a 51 ms step, profiles/r06_train_step_kernel_stats.csv); here each
 // operand set is ONE pass: read the fp32 master weights once, write the GEMM-dtype operand in its final layout.
-//   K15  lina_mlp_pack     w_in [2H, d_in], b_in [2H], w_out [d_out, H], b_out [d_out]  ->  Wi [2, Hp, d_in], bi [2, Hp], Wo [d_out, Hp]
+//   K15  lina_mlp_pack     w_in [2H, d_in], b_in [2H], w_out [d_out, H], b_out [d_out]  ->  Wi [2, Hp, d_in], bi [2, Hp], Wo [d_out, Hq >= Hp]
 //   K16  lina_stack_rows   up to 8 row blocks [r_i, cols]  ->  one [R, cols] operand (rows past the blocks: zero)
 #include <lina_dev.h>
 #include "lina_common.h"
@@ -24,8 +24,10 @@ template <typename TO>
 __global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__ w_in, const float* __restrict__ b_in,
                                                        const float* __restrict__ w_out, const float* __restrict__ b_out,
                                                        TO* __restrict__ Wi, TO* __restrict__ bi, TO* __restrict__ Wo, int H,
-                                                       int Hp, int d_in, int d_out) {
-    const int64_t n_wi = (int64_t)2 * Hp * d_in, n_wo = (int64_t)d_out * Hp, n_bi = (int64_t)2 * Hp;
+                                                       int Hp, int Hq, int d_in, int d_out) {
+    // Hq >= Hp: row length of Wo (columns past H + 1 are zero): the down-projection's dX GEMM runs on the whole [d_out, Hq]
+    // operand when Hq is the width the GEMM library prefers (1536 for Hp = 1408), everything else on its first Hp columns
+    const int64_t n_wi = (int64_t)2 * Hp * d_in, n_wo = (int64_t)d_out * Hq, n_bi = (int64_t)2 * Hp;
     const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (e < n_wi) {                                          // Wi[s][r][c] = w_in[s H + r][c] for r < H, else 0
         const int64_t row = e / d_in;
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__
     }
     int64_t f = e - n_wi;
     if (f < n_wo) {                                          // Wo[r][c] = w_out[r][c] for c < H; column H = b_out (the bias rides in the GEMM)
-        const int r = (int)(f / Hp), c0 = (int)(f - (int64_t)r * Hp);
+        const int r = (int)(f / Hq), c0 = (int)(f - (int64_t)r * Hq);
         float x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -80,20 +82,21 @@ __global__ __launch_bounds__(256) void stack_rows_kernel(stack_srcs src, int n_s
 }  // namespace lina
 
 extern "C" int lina_mlp_pack(const float* w_in, const float* b_in, const float* w_out, const float* b_out, void* Wi, void* bi,
-                             void* Wo, int H, int Hp, int d_in, int d_out, int out_dtype, lina_stream_t stream) {
+                             void* Wo, int H, int Hp, int Hq, int d_in, int d_out, int out_dtype, lina_stream_t stream) {
     using namespace lina;
     LINA_REQUIRE(w_in && w_out && Wi && bi && Wo, "lina_mlp_pack: null pointer");
     LINA_REQUIRE(H > 0 && Hp > H && d_in > 0 && d_out > 0, "lina_mlp_pack: needs 0 < H < Hp and positive widths");
     LINA_REQUIRE(Hp % 4 == 0 && d_in % 4 == 0, "lina_mlp_pack: Hp and d_in must be multiples of 4");
+    LINA_REQUIRE(Hq >= Hp && Hq % 4 == 0, "lina_mlp_pack: Hq must be a multiple of 4, >= Hp");
     LINA_REQUIRE(valid_dtype(out_dtype), "lina_mlp_pack: bad dtype %d", out_dtype);
-    const int64_t n = (int64_t)2 * Hp * d_in + (int64_t)d_out * Hp + (int64_t)2 * Hp;
+    const int64_t n = (int64_t)2 * Hp * d_in + (int64_t)d_out * Hq + (int64_t)2 * Hp;
     dim3 grid((unsigned)((n / 4 + 255) / 256));
     if (out_dtype == LINA_F32)
         LINA_LAUNCH((mlp_pack_kernel<float>), grid, dim3(256), 0, stream, w_in, b_in, w_out, b_out, (float*)Wi, (float*)bi, (float*)Wo,
-                    H, Hp, d_in, d_out);
+                    H, Hp, Hq, d_in, d_out);
     else
         LINA_LAUNCH((mlp_pack_kernel<bf16_t>), grid, dim3(256), 0, stream, w_in, b_in, w_out, b_out, (bf16_t*)Wi, (bf16_t*)bi,
-                    (bf16_t*)Wo, H, Hp, d_in, d_out);
+                    (bf16_t*)Wo, H, Hp, Hq, d_in, d_out);
     return check_launch("lina_mlp_pack");
 }
 

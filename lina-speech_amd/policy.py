@@ -23,6 +23,9 @@ class Policy:
     # profiles/r06_inproj_gemm_split.txt) -- True = the forward and the weight gradient as a 256-aligned main product plus a
     # narrow tail product into / out of the same buffers; dX stays one GEMM
     split_stacked_gemm: bool = True
+    # train path, channel mixer: the down-projection's operand in rows of 1536 (not 1408) elements so that its dX GEMM
+    # ([M, 1024] x [1024, 1536]: 90-100 us; x [1024, 1408]: 112-119) runs on the width the GEMM library prefers
+    wide_down_dx: bool = True
 
 
 POLICY = Policy()

@@ -850,7 +850,8 @@ def check_mlp_pack(dev, H=45, d_in=24, d_out=20, out_dtype=torch.bfloat16, bias=
     b_out = torch.randn(d_out, generator=g).to(dev) if bias else None
     Hp = (H + _MLP_PAD) // _MLP_PAD * _MLP_PAD
     ops.clear_mlp_pack()
-    Wi, bi, Wo = _mlp_padded_weights(w_in, b_in, w_out, b_out, out_dtype, H, Hp)
+    Wi, bi, Wo, Wo_wide = _mlp_padded_weights(w_in, b_in, w_out, b_out, out_dtype, H, Hp)
+    assert Wo_wide.shape[1] >= Hp and Wo.data_ptr() == Wo_wide.data_ptr() and float(Wo_wide[:, Hp:].abs().sum()) == 0.0
     rWi = torch.zeros(2, Hp, d_in, dtype=out_dtype, device=dev)
     rWi[:, :H] = w_in.view(2, H, d_in).to(out_dtype)
     rbi = torch.zeros(2, Hp, dtype=out_dtype, device=dev)

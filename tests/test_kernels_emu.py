@@ -447,6 +447,7 @@ def test_train_weight_operands_in_one_pass(emu):
     check_mlp_pack(DEV)
     check_mlp_pack(DEV, out_dtype=torch.float32, bias=False)
     check_mlp_pack(DEV, H=127, d_in=8, d_out=3)              # H + 1 = Hp: the bias column is the last one
+    check_mlp_pack(DEV, H=1365, d_in=8, d_out=5)             # Hp = 1408 in rows of Hq = 1536 (the wide dX operand)
     check_stacked_linear(DEV)
     check_stacked_linear(DEV, rows=(5,), pad=0)
     check_stacked_linear(DEV, rows=(512, 512, 16), n_in=16, pad=48, B=1, T=9, expect_split=True)    # main 1024 + tail 64

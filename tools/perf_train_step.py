@@ -20,6 +20,9 @@ if os.environ.get("TRAIN_OPERANDS") == "0":               # A/B: the torch-op co
 if os.environ.get("TRAIN_SPLIT_GEMM") == "0":             # A/B: the stacked projection's forward / dW as single GEMMs (N = 4160)
     from lina_speech_amd import ops as _ops2
     _ops2.POLICY.split_stacked_gemm = False
+if os.environ.get("TRAIN_WIDE_DX") == "0":                # A/B: the down-projection's dX on the 1408-column operand
+    from lina_speech_amd import ops as _ops3
+    _ops3.POLICY.wide_down_dx = False
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5
 WARM = 2
 dev = torch.device("cuda", 0)
